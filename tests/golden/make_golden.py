@@ -1,0 +1,213 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz from the REFERENCE itself.  Run in the build container only
+(needs /root/reference; the GPU box never runs this -- it only reads the committed .npz files).
+
+    python tests/golden/make_golden.py
+
+Two families of fixtures:
+
+* ``dwconv_*.npz``  -- what the reference's own tests use as ground truth for the conv op:
+  ``F.conv2d(x, w, padding=k//2, groups=C)`` + autograd on torch CPU
+  (cutlass/examples/19_large_depthwise_conv2d_torch_extension/test_correctness.py:8-9, :67-90).
+  Seeds {0, 42} and ``torch.randn`` inputs as in that file (:20-35); shapes cover the reference's
+  square kernels AND the rectangular LoRA kernels of models/SLaK.py:76-80 which the reference never
+  pins.  Stored: x, w, dy, y, dx, dw (float32; computed in float64 and rounded once).
+
+* ``mask_*.npz``    -- ``sparse_core.Masking`` + ``funcs.magnitude_prune`` / ``funcs.gradient_growth``
+  imported UNMODIFIED from /root/reference and run on CPU (growth='gradient', prune='magnitude',
+  redistribution='none', sparse_init='uniform', distributed=False), on a tiny module whose parameter
+  names follow models/SLaK.py (so ``--only-L`` name filtering, sparse_core.py:124-127, is exercised).
+  Inputs are continuous random values, so no key ties occur at the cut: the
+  unstable ``torch.sort`` of the reference is then unambiguous.
+"""
+import argparse
+import math
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF = "/root/reference"
+
+
+# --------------------------------------------------------------------------- conv fixtures
+CONV_CASES = [
+    # name,            N, C,  H,  W,  kh, kw, seed
+    ("sq3_r16",        2, 8, 16, 16,  3,  3, 0),
+    ("sq7_r16",        1, 8, 16, 16,  7,  7, 42),
+    ("sq13_r16",       2, 4, 16, 16, 13, 13, 0),
+    ("sq31_r32",       1, 3, 32, 32, 31, 31, 42),
+    ("lora1_51x5_s1",  1, 4, 56, 56, 51,  5, 0),      # cfg-1 stage-1 shape (C reduced)
+    ("lora2_5x51_s1",  1, 4, 56, 56,  5, 51, 42),
+    ("small_5x5_s1",   2, 4, 56, 56,  5,  5, 0),
+    ("lora1_49x5_s2",  2, 6, 28, 28, 49,  5, 42),     # kernel larger than the map
+    ("lora2_5x47_s3",  3, 5, 14, 14,  5, 47, 0),
+    ("lora1_13x5_s4",  4, 7,  7,  7, 13,  5, 42),
+    ("lora2_5x13_s4",  4, 7,  7,  7,  5, 13, 0),
+    ("ragged_9x11",    3, 5,  9, 11,  7,  3, 42),     # H != W, odd sizes
+    ("one_pixel",      2, 3,  1,  1,  5,  5, 0),
+]
+
+
+def make_conv():
+    for name, N, C, H, W, kh, kw, seed in CONV_CASES:
+        torch.random.manual_seed(seed)
+        x = torch.randn(N, C, H, W)
+        conv = nn.Conv2d(C, C, (kh, kw), groups=C, bias=False)      # default init, as the reference tests
+        w = conv.weight.detach().clone()
+        dy = torch.randn(N, C, H, W)
+        xd = x.double().requires_grad_(True)
+        wd = w.double().requires_grad_(True)
+        y = F.conv2d(xd, wd, None, 1, (kh // 2, kw // 2), 1, C)
+        y.backward(dy.double())
+        np.savez_compressed(
+            os.path.join(HERE, f"dwconv_{name}.npz"),
+            x=x.numpy(), w=w.numpy(), dy=dy.numpy(),
+            y=y.detach().float().numpy(), dx=xd.grad.float().numpy(), dw=wd.grad.float().numpy(),
+            y64=y.detach().numpy(), dx64=xd.grad.numpy(), dw64=wd.grad.numpy(),
+            meta=np.array([N, C, H, W, kh, kw, seed]))
+        print("wrote dwconv_%s" % name)
+
+
+# --------------------------------------------------------------------------- mask fixtures
+class _ConvBN(nn.Module):
+    def __init__(self, C, k):
+        super().__init__()
+        self.conv = nn.Conv2d(C, C, k, groups=C, bias=False)
+        self.bn = nn.BatchNorm2d(C)
+
+
+class _LK(nn.Module):
+    def __init__(self, C, K):
+        super().__init__()
+        self.LoRA1 = _ConvBN(C, (K, 5))
+        self.LoRA2 = _ConvBN(C, (5, K))
+        self.small_conv = _ConvBN(C, 5)
+
+
+class _Block(nn.Module):
+    def __init__(self, C, K):
+        super().__init__()
+        self.large_kernel = _LK(C, K)
+        self.norm = nn.LayerNorm(C)
+        self.pwconv1 = nn.Linear(C, 4 * C)
+        self.pwconv2 = nn.Linear(4 * C, C)
+        self.gamma = nn.Parameter(torch.ones(C))
+
+
+class TinyNet(nn.Module):
+    """Parameter names mirror models/SLaK.py:193-201 (``stages.{i}.{j}.large_kernel.LoRA1.conv.weight`` ...)."""
+
+    def __init__(self, C=(6, 10), K=(13, 7)):
+        super().__init__()
+        self.stages = nn.ModuleList([nn.Sequential(_Block(c, k), _Block(c, k)) for c, k in zip(C, K)])
+        self.head = nn.Linear(C[-1], 11)
+
+
+def _ref_masking(model, optimizer, only_L, sparsity, update_frequency, prune_rate, T_max, seed):
+    sys.path.insert(0, REF)
+    import sparse_core  # noqa: E402  (the reference, unmodified)
+    args = types.SimpleNamespace(device="cpu", fix=False, update_frequency=update_frequency, only_L=only_L,
+                                 sparse_init="uniform", sparsity=sparsity, distributed=False)
+    decay = sparse_core.CosineDecay(prune_rate, T_max)
+    torch.manual_seed(seed)
+    m = sparse_core.Masking(optimizer, train_loader=None, prune_rate_decay=decay, prune_rate=prune_rate,
+                            prune_mode="magnitude", growth_mode="gradient", redistribution_mode="none", args=args)
+    m.add_module(model)
+    return m
+
+
+def _snap(d):
+    return {k: v.detach().cpu().numpy().copy() for k, v in d.items()}
+
+
+def make_masks():
+    import contextlib, io
+    for tag, only_L, opt_kind in (("all_sgd", False, "sgd"), ("onlyL_adamw", True, "adamw")):
+        torch.manual_seed(123)
+        model = TinyNet()
+        for p in model.parameters():                     # continuous values -> no ties
+            p.data = torch.randn_like(p) * 0.05
+        if opt_kind == "sgd":
+            opt = torch.optim.SGD(model.parameters(), lr=0.05, momentum=0.9)
+        else:
+            opt = torch.optim.AdamW(model.parameters(), lr=1e-2, weight_decay=0.05)
+        with contextlib.redirect_stdout(io.StringIO()):
+            mask = _ref_masking(model, opt, only_L, sparsity=0.4, update_frequency=3, prune_rate=0.3, T_max=20, seed=7)
+        names = list(mask.masks.keys())
+        out = {"names": np.array(names), "param_names": np.array([n for n, _ in model.named_parameters()])}
+        for n, p in model.named_parameters():
+            out[f"w_init/{n}"] = p.detach().numpy().copy()          # AFTER init's apply_mask
+        for n in names:
+            out[f"m_init/{n}"] = mask.masks[n].numpy().copy()
+        nsteps = 7
+        g = torch.Generator().manual_seed(99)
+        rates = []
+        # wrap (NOT modify) the reference's truncate_weights to snapshot the state it sees
+        orig_truncate = mask.truncate_weights
+        cur = {"step": 0}
+
+        def _wrapped_truncate():
+            for n, p in model.named_parameters():
+                out[f"wpre{cur['step']}/{n}"] = p.detach().numpy().copy()
+            out[f"rate_at{cur['step']}"] = np.array(mask.prune_rate, np.float64)
+            orig_truncate()
+        mask.truncate_weights = _wrapped_truncate
+        for step in range(1, nsteps + 1):
+            for n, p in model.named_parameters():
+                p.grad = torch.randn(p.shape, generator=g) * 0.1
+                out[f"g{step}/{n}"] = p.grad.numpy().copy()
+            cur["step"] = step
+            with contextlib.redirect_stdout(io.StringIO()):
+                mask.step()                                          # sparse_core.py:300-313
+            rates.append(mask.prune_rate)
+            for n, p in model.named_parameters():
+                out[f"w{step}/{n}"] = p.detach().numpy().copy()
+            for n in names:
+                out[f"m{step}/{n}"] = mask.masks[n].numpy().copy()
+            if step % 3 == 0:
+                for n in names:
+                    out[f"stats{step}/{n}"] = np.array([mask.name2nonzeros[n], mask.name2zeros[n], mask.name2removed[n]], np.float64)
+            opt.zero_grad(set_to_none=False)
+        out["prune_rates"] = np.array(rates, np.float64)
+        out["meta"] = np.array([nsteps, 3, 20], np.int64)            # nsteps, update_frequency, T_max
+        out["hyper"] = np.array([0.4, 0.3], np.float64)              # sparsity, prune_rate
+        np.savez_compressed(os.path.join(HERE, f"mask_{tag}.npz"), **out)
+        print("wrote mask_%s (%d masked tensors)" % (tag, len(names)))
+
+    # single-call fixtures of the two pure functions, including a tie-at-the-cut case that documents the
+    # reference's arbitrary behaviour (stored but only compared as a count, not as an index set)
+    sys.path.insert(0, REF)
+    import funcs  # noqa: E402
+    torch.manual_seed(5)
+    w = torch.randn(9, 1, 13, 5) * 0.05
+    m = (torch.rand(w.shape) < 0.6).float()
+    w = w * m
+    grad = torch.randn(w.shape)
+    fake = types.SimpleNamespace(prune_rate=0.25, name2nonzeros={"t": m.sum().item()},
+                                 name2zeros={"t": m.numel() - m.sum().item()})
+    pruned = funcs.magnitude_prune(fake, m.clone(), nn.Parameter(w.clone()), "t").float()
+    removed = m.sum().item() - pruned.sum().item()
+    p = nn.Parameter(w.clone()); p.grad = grad.clone()
+    fake.get_gradient_for_weights = lambda weight: weight.grad.clone()
+    grown = funcs.gradient_growth(fake, "t", pruned.clone().byte(), math.floor(removed), p).float()
+    np.savez_compressed(os.path.join(HERE, "mask_funcs.npz"), w=w.numpy(), m=m.numpy(), grad=grad.numpy(),
+                        pruned=pruned.numpy(), grown=grown.numpy(), rate=np.array(0.25), removed=np.array(removed))
+    print("wrote mask_funcs")
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", choices=["conv", "mask"], default=None)
+    a = ap.parse_args()
+    if not os.path.isdir(REF):
+        sys.exit("needs /root/reference (build container only)")
+    if a.only in (None, "conv"):
+        make_conv()
+    if a.only in (None, "mask"):
+        make_masks()

@@ -1,0 +1,91 @@
+"""The oracle is pinned before it is trusted (CPU, no GPU):
+ * C restatement (oracle/dwconv_oracle.c) vs the committed fixtures produced by the reference's own
+   ground truth F.conv2d(+autograd)  (test_correctness.py:8-9, :67-90)
+ * numpy mask restatement (oracle/mask_oracle.py) vs fixtures produced by the UNMODIFIED reference
+   sparse_core.Masking / funcs running on CPU (tests/golden/make_golden.py).
+"""
+import math
+
+import numpy as np
+import pytest
+
+import oracle
+from conftest import golden_conv_cases, load_golden
+
+
+@pytest.mark.parametrize("case", golden_conv_cases())
+def test_c_oracle_matches_reference_conv(case):
+    g = load_golden("dwconv_" + case)
+    N, C, H, W, kh, kw, _ = g["meta"]
+    y = oracle.dwconv2d_fwd(g["x"], g["w"])
+    dx = oracle.dwconv2d_bwd_data(g["dy"], g["w"])
+    dw = oracle.dwconv2d_bwd_filter(g["dy"], g["x"], int(kh), int(kw))
+    # both sides accumulate in fp64: agreement is at fp64 round-off of a <=961-term sum
+    np.testing.assert_allclose(y, g["y64"], rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(dx, g["dx64"], rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(dw, g["dw64"], rtol=1e-11, atol=1e-11)
+
+
+def test_c_oracle_properties():
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal((2, 3, 10, 9)).astype(np.float32)
+    w = rng.standard_normal((3, 1, 7, 5)).astype(np.float32)
+    dy = rng.standard_normal(x.shape).astype(np.float32)
+    # adjointness: <conv(x,w), dy> == <x, dgrad(dy,w)> == <w, wgrad(dy,x)>
+    a = (oracle.dwconv2d_fwd(x, w) * dy).sum()
+    b = (oracle.dwconv2d_bwd_data(dy, w) * x).sum()
+    c = (oracle.dwconv2d_bwd_filter(dy, x, 7, 5) * w).sum()
+    assert abs(a - b) < 1e-9 * abs(a) + 1e-9 and abs(a - c) < 1e-9 * abs(a) + 1e-9
+    # identity kernel
+    wi = np.zeros((3, 1, 7, 5), np.float32); wi[:, 0, 3, 2] = 1
+    np.testing.assert_array_equal(oracle.dwconv2d_fwd(x, wi), x.astype(np.float64))
+
+
+def test_bf16_round_matches_torch():
+    import torch
+    v = torch.randn(10000) * 3
+    v[:4] = torch.tensor([0.0, -0.0, 1.00390625, 65504.0])
+    ref = v.to(torch.bfloat16).float().numpy()
+    np.testing.assert_array_equal(oracle.bf16_round(v.numpy()), ref)
+
+
+def test_mask_funcs_match_reference():
+    g = load_golden("mask_funcs")
+    m, w = g["m"], g["w"]
+    nz = float(m.sum()); zeros = m.size - nz
+    pruned = oracle.magnitude_prune(m, w, float(g["rate"]), nz, zeros)
+    np.testing.assert_array_equal(pruned, g["pruned"])
+    removed = nz - float(pruned.sum())
+    assert removed == float(g["removed"])
+    grown = oracle.gradient_growth(pruned.astype(np.uint8), math.floor(removed), g["grad"])
+    np.testing.assert_array_equal(grown, g["grown"])
+
+
+@pytest.mark.parametrize("tag", ["all_sgd", "onlyL_adamw"])
+def test_mask_truncate_matches_reference_masking(tag):
+    """At every update step of the recorded run, oracle.truncate_weights reproduces the reference's
+    masks bit-exactly.  State just before truncate_weights (sparse_core.py:309-311) is reconstructed
+    from the recording: weights there are  w_after_step  on positions that survive, and the prune
+    decision only looks at |w| of the (optimizer-stepped, mask-applied) weights."""
+    g = load_golden("mask_" + tag)
+    nsteps, ufreq, T_max = (int(v) for v in g["meta"])
+    names = [str(n) for n in g["names"]]
+    for step in range(ufreq, nsteps + 1, ufreq):
+        m_prev = {n: g[f"m{step-1}/{n}" if step > 1 else f"m_init/{n}"] for n in names}
+        grads = {n: g[f"g{step}/{n}"] for n in names}
+        w_pre = {n: g[f"wpre{step}/{n}"] for n in names}
+        rate = float(g[f"rate_at{step}"])
+        assert rate == float(g["prune_rates"][step - 1])
+        w_new, m_new, stats = oracle.truncate_weights(w_pre, m_prev, grads, rate)
+        for n in names:
+            np.testing.assert_array_equal(m_new[n], g[f"m{step}/{n}"], err_msg=f"{n} step {step}")
+            np.testing.assert_array_equal(w_new[n], g[f"w{step}/{n}"], err_msg=f"{n} step {step}")
+            nz, zeros, removed = g[f"stats{step}/{n}"]
+            assert (stats[n]["nonzeros"], stats[n]["zeros"], stats[n]["removed"]) == (nz, zeros, removed)
+    # ordinary steps: apply_mask only (sparse_core.py:302, :326)
+    for s_ in range(1, nsteps + 1):
+        for n in names:
+            assert np.all(g[f"w{s_}/{n}"][g[f"m{s_}/{n}"] == 0] == 0)
+    # cosine schedule closed form == recorded torch scheduler values
+    for s_ in range(1, nsteps + 1):
+        assert abs(oracle.cosine_prune_rate(0.3, T_max, s_) - g["prune_rates"][s_ - 1]) < 1e-12
