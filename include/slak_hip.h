@@ -1,0 +1,119 @@
+/*
+ * include/slak_hip.h -- C ABI of libslak_hip.so, the MI355X (gfx950) drop-in for the two native
+ * boundaries of VITA-Group/SLaK's training hot path.  Plain pointers and sizes only: no torch
+ * types, no C++ in the signatures.  All pointers are DEVICE pointers unless a name ends in _host.
+ * Every entry point returns a slak_status_t (0 == ok) and never calls exit()
+ * (the reference exits the process on failure: forward_fp32.cu:173-192).
+ * Work is enqueued on `stream` (a hipStream_t passed as void*; NULL = the null stream).  The
+ * reference launches on the null stream (cutlass/include/cutlass/convolution/device/convolution.h:243);
+ * callers here pass PyTorch's current stream.
+ *
+ * Boundary 1 -- depthwise conv, replaces pybind module `_depthwise_conv2d_implicit_gemm_C`
+ *   (cutlass/examples/19_large_depthwise_conv2d_torch_extension/frontend.h:3-10, frontend.cpp:3-16):
+ *     forward_fp32/fp16(x, w)            -> slak_dwconv2d_forward
+ *     backward_data_fp32/fp16(dy, w)     -> slak_dwconv2d_backward_data
+ *     backward_filter_fp32/fp16(dy,x,w)  -> slak_dwconv2d_backward_filter
+ *   Semantics fixed by the reference kernels (forward_fp32.cu:135-144, :227, :235): NCHW contiguous,
+ *   weight (C,1,kh,kw), stride 1, dilation 1, padding (kh/2, kw/2), groups == C, cross-correlation,
+ *   output shape == input shape, so kh and kw must be odd (the reference silently mis-sizes even
+ *   kernels; here that is SLAK_ERR_INVALID_ARG).  bf16 is added (the reference raises TypeError:
+ *   depthwise_conv2d_implicit_gemm.py:63).  The filter gradient is always fp32
+ *   (backward_filter_fp16.cu:187).
+ *
+ * Boundary 2 -- dynamic-sparsity step, replaces the per-tensor torch loops of
+ *   sparse_core.Masking.apply_mask (sparse_core.py:316-333), .truncate_weights (:335-357),
+ *   funcs.magnitude_prune (funcs.py:107-114) and funcs.gradient_growth (funcs.py:196-205).
+ *   Masks stay fp32 0/1 tensors owned by the caller (Masking.masks, read by model_sema.py:83-89).
+ *   Ties at the cut are broken by LOWEST FLAT INDEX (== torch.sort(stable=True)); the reference's
+ *   unstable torch.sort is arbitrary there.
+ */
+#ifndef SLAK_HIP_H
+#define SLAK_HIP_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    SLAK_OK = 0,
+    SLAK_ERR_INVALID_ARG = 1,   /* null pointer, non-positive dim, even kernel, bad dtype enum */
+    SLAK_ERR_UNSUPPORTED = 2,   /* dtype combination / size outside what the kernels cover     */
+    SLAK_ERR_WORKSPACE = 3,     /* workspace missing or smaller than *_workspace_bytes()       */
+    SLAK_ERR_LAUNCH = 4,        /* HIP launch/runtime error; see slak_last_hip_error()         */
+    SLAK_ERR_NO_DEVICE = 5
+} slak_status_t;
+
+typedef enum { SLAK_F32 = 0, SLAK_F16 = 1, SLAK_BF16 = 2 } slak_dtype_t;
+
+/* conv algorithm selector: AUTO picks per dtype/shape; DIRECT = fp32-exact VALU kernels (any dtype);
+ * MFMA = banded-Toeplitz matrix-core kernels (f16/bf16 inputs only). */
+typedef enum { SLAK_ALGO_AUTO = 0, SLAK_ALGO_DIRECT = 1, SLAK_ALGO_MFMA = 2 } slak_algo_t;
+
+const char* slak_status_string(int status);
+const char* slak_last_hip_error(void);      /* text of the last HIP error seen by this library */
+int slak_version(void);                     /* ABI version, currently 1 */
+int slak_device_info(int* cu_count, int* lds_bytes_per_cu, char* arch_name, size_t arch_name_len);
+int slak_set_conv_algo(int algo);           /* process-wide override of the AUTO choice */
+
+/* ---------------------------------------------------------------- boundary 1: depthwise conv */
+
+/* Bytes of scratch each op needs for these dims (0 is possible).  `op`: 0 fwd, 1 bwd-data, 2 bwd-filter. */
+size_t slak_dwconv2d_workspace_bytes(int op, int N, int C, int H, int W, int kh, int kw, int dtype);
+
+/* y[n,c,p,q] = sum_{r,s} x[n,c,p-kh/2+r,q-kw/2+s] * w[c,0,r,s]      (forward_fp32.cu:199-263) */
+int slak_dwconv2d_forward(const void* x, int x_dtype, const void* w, int w_dtype, void* y, int y_dtype,
+                          int N, int C, int H, int W, int kh, int kw,
+                          void* workspace, size_t workspace_bytes, void* stream);
+
+/* dx[n,c,h,w] = sum_{r,s} dy[n,c,h+kh/2-r,w+kw/2-s] * w[c,0,r,s]    (backward_data_fp32.cu:199-263) */
+int slak_dwconv2d_backward_data(const void* dy, int dy_dtype, const void* w, int w_dtype, void* dx, int dx_dtype,
+                                int N, int C, int H, int W, int kh, int kw,
+                                void* workspace, size_t workspace_bytes, void* stream);
+
+/* dw[c,0,r,s] = sum_{n,p,q} dy[n,c,p,q] * x[n,c,p-kh/2+r,q-kw/2+s], fp32 out, deterministic
+ * (no atomics; the reference atomically adds: dwconv2d_direct_epilogue_simt.h:180)
+ *                                                                   (backward_filter_fp32.cu:199-263) */
+int slak_dwconv2d_backward_filter(const void* dy, int dy_dtype, const void* x, int x_dtype, float* dw,
+                                  int N, int C, int H, int W, int kh, int kw,
+                                  void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---------------------------------------------------------------- boundary 2: mask step       */
+
+typedef struct {
+    float* weight;        /* fp32 parameter, updated in place                                   */
+    float* mask;          /* fp32 0/1 mask, same numel                                          */
+    const float* grad;    /* fp32 gradient (only read by slak_mask_prune_and_grow; may be NULL) */
+    float* momentum;      /* optional SGD momentum buffer masked too (sparse_core.py:327-328)   */
+    long long numel;
+} slak_mask_segment_t;
+
+typedef struct slak_mask_plan slak_mask_plan_t;   /* opaque: device tables + select scratch      */
+
+/* Build a plan over `nseg` masked tensors (descriptor array in HOST memory, device pointers inside). */
+int slak_mask_plan_create(const slak_mask_segment_t* segs_host, int nseg, slak_mask_plan_t** plan_out);
+/* Re-point grad / momentum (they are re-allocated by optimizers); arrays of nseg device pointers, in HOST memory. */
+int slak_mask_plan_set_grads(slak_mask_plan_t* plan, const void* const* grads_host, void* stream);
+int slak_mask_plan_set_momentum(slak_mask_plan_t* plan, void* const* momentum_host, void* stream);
+int slak_mask_plan_destroy(slak_mask_plan_t* plan);
+
+/* w *= mask (and momentum *= mask) for every segment, one launch            (sparse_core.py:316-333) */
+int slak_mask_apply(slak_mask_plan_t* plan, void* stream);
+
+/* One truncate_weights(): per segment, magnitude-prune then gradient-regrow then apply, all on device.
+ * `prune_rate` is the host scheduler's fp64 value; k = ceil(zeros + ceil(rate*nonzeros)) is evaluated
+ * on device in fp64 exactly as Python does (funcs.py:107-109).       (sparse_core.py:335-357)       */
+int slak_mask_prune_and_grow(slak_mask_plan_t* plan, double prune_rate, void* stream);
+
+/* Copy per-segment statistics of the last prune_and_grow to the host (synchronises `stream`):
+ * out_host[4*i + {0,1,2,3}] = nonzeros before, zeros before, removed by prune, nonzeros after. */
+int slak_mask_read_stats(slak_mask_plan_t* plan, double* out_host, void* stream);
+
+/* 64-bit order-independent checksum of all masks (for cross-rank agreement checks); synchronises. */
+int slak_mask_checksum(slak_mask_plan_t* plan, unsigned long long* out_host, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SLAK_HIP_H */

@@ -1,0 +1,75 @@
+"""ctypes binding of libslak_hip.so (C ABI in include/slak_hip.h).
+
+The product path has NO fallback: if the HIP library is missing or a call fails, this raises.
+(The reference binds its native module with ``import _depthwise_conv2d_implicit_gemm_C``:
+depthwise_conv2d_implicit_gemm.py:8.)
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libslak_hip.so")
+
+SLAK_F32, SLAK_F16, SLAK_BF16 = 0, 1, 2
+ALGO_AUTO, ALGO_DIRECT, ALGO_MFMA = 0, 1, 2
+OP_FWD, OP_BWD_DATA, OP_BWD_FILTER = 0, 1, 2
+
+_lib = None
+
+
+class SlakHipError(RuntimeError):
+    pass
+
+
+class MaskSegment(ctypes.Structure):
+    _fields_ = [("weight", ctypes.c_void_p), ("mask", ctypes.c_void_p), ("grad", ctypes.c_void_p),
+                ("momentum", ctypes.c_void_p), ("numel", ctypes.c_longlong)]
+
+
+# name -> (restype, argtypes): every symbol include/slak_hip.h declares (tests/test_boundary.py checks this)
+_vp, _i, _sz, _d = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t, ctypes.c_double
+_CONV = [_vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]
+SIGNATURES = {
+    "slak_status_string": (ctypes.c_char_p, [_i]),
+    "slak_last_hip_error": (ctypes.c_char_p, []),
+    "slak_version": (_i, []),
+    "slak_device_info": (_i, [ctypes.POINTER(_i), ctypes.POINTER(_i), ctypes.c_char_p, _sz]),
+    "slak_set_conv_algo": (_i, [_i]),
+    "slak_dwconv2d_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i, _i, _i]),
+    "slak_dwconv2d_forward": (_i, _CONV),
+    "slak_dwconv2d_backward_data": (_i, _CONV),
+    "slak_dwconv2d_backward_filter": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
+    "slak_mask_plan_create": (_i, [ctypes.POINTER(MaskSegment), _i, ctypes.POINTER(_vp)]),
+    "slak_mask_plan_set_grads": (_i, [_vp, ctypes.POINTER(_vp), _vp]),
+    "slak_mask_plan_set_momentum": (_i, [_vp, ctypes.POINTER(_vp), _vp]),
+    "slak_mask_plan_destroy": (_i, [_vp]),
+    "slak_mask_apply": (_i, [_vp, _vp]),
+    "slak_mask_prune_and_grow": (_i, [_vp, _d, _vp]),
+    "slak_mask_read_stats": (_i, [_vp, ctypes.POINTER(_d), _vp]),
+    "slak_mask_checksum": (_i, [_vp, ctypes.POINTER(ctypes.c_ulonglong), _vp]),
+}
+
+
+def lib():
+    """Load the library once; raise (never fall back) if it is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise SlakHipError(
+                "libslak_hip.so is not built (%s). Run `python -m slak_amd.build` "
+                "(or __graft_entry__.build()); there is no CPU fallback." % LIB_PATH)
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype, fn.argtypes = res, args
+        _lib = L
+    return _lib
+
+
+def check(status, what=""):
+    if status != 0:
+        L = lib()
+        msg = L.slak_status_string(status).decode()
+        if status == 4:
+            msg += ": " + L.slak_last_hip_error().decode()
+        raise SlakHipError("%s failed: %s (status %d)" % (what or "libslak_hip call", msg, status))

@@ -1,0 +1,115 @@
+// slak_amd/csrc/capi.hip -- extern "C" entry points of libslak_hip.so (see include/slak_hip.h).
+// Argument validation lives here; the reference's extension validates almost nothing and exit()s on
+// failure (forward_fp32.cu:173-196).  Every function returns a status code instead.
+#include <mutex>
+#include <string>
+
+#include "slak_common.h"
+
+namespace slak {
+static std::mutex g_err_mu;
+static std::string g_last_hip_error = "";
+static int g_conv_algo = SLAK_ALGO_AUTO;
+
+void set_last_hip_error(hipError_t e) {
+    std::lock_guard<std::mutex> lk(g_err_mu);
+    g_last_hip_error = hipGetErrorString(e);
+}
+
+static int check_conv_args(const void* a, const void* b, const void* c, int dt0, int dt1, int dt2,
+                           int N, int C, int H, int W, int kh, int kw) {
+    if (!a || !b || !c) return SLAK_ERR_INVALID_ARG;
+    if (!dtype_ok(dt0) || !dtype_ok(dt1) || !dtype_ok(dt2)) return SLAK_ERR_INVALID_ARG;
+    if (N <= 0 || C <= 0 || H <= 0 || W <= 0 || kh <= 0 || kw <= 0) return SLAK_ERR_INVALID_ARG;
+    if ((kh & 1) == 0 || (kw & 1) == 0) return SLAK_ERR_INVALID_ARG;   // output shape == input shape needs odd kernels
+    if ((long long)N * C * H * W >= (1LL << 31)) return SLAK_ERR_UNSUPPORTED;
+    if (kh > 127 || kw > 127) return SLAK_ERR_UNSUPPORTED;
+    return SLAK_OK;
+}
+}  // namespace slak
+
+using namespace slak;
+
+extern "C" {
+
+const char* slak_status_string(int status) {
+    switch (status) {
+        case SLAK_OK: return "ok";
+        case SLAK_ERR_INVALID_ARG: return "invalid argument";
+        case SLAK_ERR_UNSUPPORTED: return "unsupported dtype/shape";
+        case SLAK_ERR_WORKSPACE: return "workspace missing or too small";
+        case SLAK_ERR_LAUNCH: return "HIP launch/runtime error";
+        case SLAK_ERR_NO_DEVICE: return "no HIP device";
+    }
+    return "unknown status";
+}
+
+const char* slak_last_hip_error(void) {
+    std::lock_guard<std::mutex> lk(g_err_mu);
+    static thread_local std::string copy;
+    copy = g_last_hip_error;
+    return copy.c_str();
+}
+
+int slak_version(void) { return 1; }
+
+int slak_device_info(int* cu_count, int* lds_bytes_per_cu, char* arch_name, size_t arch_name_len) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return SLAK_ERR_NO_DEVICE;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return SLAK_ERR_NO_DEVICE;
+    if (cu_count) *cu_count = prop.multiProcessorCount;
+    if (lds_bytes_per_cu) *lds_bytes_per_cu = (int)prop.maxSharedMemoryPerMultiProcessor;
+    if (arch_name && arch_name_len) {
+        size_t i = 0;
+        for (; i + 1 < arch_name_len && prop.gcnArchName[i]; ++i) arch_name[i] = prop.gcnArchName[i];
+        arch_name[i] = 0;
+    }
+    return SLAK_OK;
+}
+
+int slak_set_conv_algo(int algo) {
+    if (algo != SLAK_ALGO_AUTO && algo != SLAK_ALGO_DIRECT && algo != SLAK_ALGO_MFMA) return SLAK_ERR_INVALID_ARG;
+    g_conv_algo = algo;
+    return SLAK_OK;
+}
+
+size_t slak_dwconv2d_workspace_bytes(int op, int N, int C, int H, int W, int kh, int kw, int dtype) {
+    (void)dtype;
+    if (N <= 0 || C <= 0 || H <= 0 || W <= 0 || kh <= 0 || kw <= 0) return 0;
+    ConvDims d{N, C, H, W, kh, kw};
+    if (op == 0 || op == 1) return dwconv_direct_workspace(d);
+    if (op == 2) return dwconv_wgrad_workspace(d);
+    return 0;
+}
+
+int slak_dwconv2d_forward(const void* x, int x_dtype, const void* w, int w_dtype, void* y, int y_dtype,
+                          int N, int C, int H, int W, int kh, int kw,
+                          void* workspace, size_t workspace_bytes, void* stream) {
+    int rc = check_conv_args(x, w, y, x_dtype, w_dtype, y_dtype, N, C, H, W, kh, kw);
+    if (rc != SLAK_OK) return rc;
+    ConvDims d{N, C, H, W, kh, kw};
+    return launch_dwconv_direct(x, x_dtype, w, w_dtype, y, y_dtype, d, /*flip=*/false, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+int slak_dwconv2d_backward_data(const void* dy, int dy_dtype, const void* w, int w_dtype, void* dx, int dx_dtype,
+                                int N, int C, int H, int W, int kh, int kw,
+                                void* workspace, size_t workspace_bytes, void* stream) {
+    int rc = check_conv_args(dy, w, dx, dy_dtype, w_dtype, dx_dtype, N, C, H, W, kh, kw);
+    if (rc != SLAK_OK) return rc;
+    ConvDims d{N, C, H, W, kh, kw};
+    // data-grad of a stride-1 "same" cross-correlation with odd kernels == cross-correlation of dy with
+    // the filter rotated by 180 degrees (h + kh/2 - r == h - kh/2 + (kh-1-r)).
+    return launch_dwconv_direct(dy, dy_dtype, w, w_dtype, dx, dx_dtype, d, /*flip=*/true, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+int slak_dwconv2d_backward_filter(const void* dy, int dy_dtype, const void* x, int x_dtype, float* dw,
+                                  int N, int C, int H, int W, int kh, int kw,
+                                  void* workspace, size_t workspace_bytes, void* stream) {
+    int rc = check_conv_args(dy, x, dw, dy_dtype, x_dtype, SLAK_F32, N, C, H, W, kh, kw);
+    if (rc != SLAK_OK) return rc;
+    ConvDims d{N, C, H, W, kh, kw};
+    return launch_dwconv_wgrad(dy, dy_dtype, x, x_dtype, dw, d, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+}  // extern "C"

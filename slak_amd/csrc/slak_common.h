@@ -1,0 +1,63 @@
+// slak_amd/csrc/slak_common.h -- shared device/host helpers for the gfx950 kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "../../include/slak_hip.h"
+
+namespace slak {
+
+// ---- element types -------------------------------------------------------------------------
+struct bf16_t { uint16_t v; };          // storage-only bfloat16
+typedef _Float16 f16_t;
+
+template <typename T> struct dtype_of;
+template <> struct dtype_of<float>  { static constexpr int value = SLAK_F32; };
+template <> struct dtype_of<f16_t>  { static constexpr int value = SLAK_F16; };
+template <> struct dtype_of<bf16_t> { static constexpr int value = SLAK_BF16; };
+
+__device__ __forceinline__ float to_f32(float v) { return v; }
+__device__ __forceinline__ float to_f32(f16_t v) { return (float)v; }
+__device__ __forceinline__ float to_f32(bf16_t v) { return __uint_as_float(((uint32_t)v.v) << 16); }
+
+// round-to-nearest-even, NaN stays (quiet) NaN -- same rule as torch's float->bfloat16 cast
+__device__ __forceinline__ uint16_t f32_to_bf16_bits(float f) {
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x0040u);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+template <typename T> __device__ __forceinline__ T from_f32(float v);
+template <> __device__ __forceinline__ float  from_f32<float>(float v)  { return v; }
+template <> __device__ __forceinline__ f16_t  from_f32<f16_t>(float v)  { return (f16_t)v; }
+template <> __device__ __forceinline__ bf16_t from_f32<bf16_t>(float v) { bf16_t r; r.v = f32_to_bf16_bits(v); return r; }
+
+static inline size_t dtype_size(int dt) { return dt == SLAK_F32 ? 4 : 2; }
+static inline bool dtype_ok(int dt) { return dt == SLAK_F32 || dt == SLAK_F16 || dt == SLAK_BF16; }
+
+__device__ __forceinline__ int wave_id_uniform() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
+
+static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+#define SLAK_LAUNCH_CHECK()                                                  \
+    do {                                                                     \
+        hipError_t e__ = hipGetLastError();                                  \
+        if (e__ != hipSuccess) { slak::set_last_hip_error(e__); return SLAK_ERR_LAUNCH; } \
+    } while (0)
+
+void set_last_hip_error(hipError_t e);
+
+// ---- launchers implemented in the .hip files (host side, C++ linkage) -----------------------
+struct ConvDims { int N, C, H, W, kh, kw; };
+
+int launch_dwconv_direct(const void* x, int x_dt, const void* w, int w_dt, void* y, int y_dt,
+                         const ConvDims& d, bool flip_filter, void* ws, size_t ws_bytes, hipStream_t st);
+size_t dwconv_direct_workspace(const ConvDims& d);
+
+int launch_dwconv_wgrad(const void* dy, int dy_dt, const void* x, int x_dt, float* dw,
+                        const ConvDims& d, void* ws, size_t ws_bytes, hipStream_t st);
+size_t dwconv_wgrad_workspace(const ConvDims& d);
+
+}  // namespace slak

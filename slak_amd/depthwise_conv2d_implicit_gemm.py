@@ -1,0 +1,71 @@
+"""Drop-in for the reference's ``depthwise_conv2d_implicit_gemm`` module
+(depthwise_conv2d_implicit_gemm.py:11-66): same class name, constructor, parameter shape, state-dict
+keys, dtype dispatch and error behaviour; the native module underneath is libslak_hip.so (gfx950 HIP).
+
+Differences, all additive:
+  * bf16 is supported (the reference raises TypeError for it: depthwise_conv2d_implicit_gemm.py:63);
+  * kernels run on PyTorch's current stream (the reference uses the null stream: convolution.h:243);
+  * failures raise instead of exit()ing the process (forward_fp32.cu:173-192).
+"""
+import torch
+import torch.nn as nn
+
+from . import ops as _extension
+
+__all__ = ["DepthWiseConv2dImplicitGEMM"]
+
+
+def _make_function(cast_dtype, name):
+    class _Fn(torch.autograd.Function):
+        # mirrors _DepthWiseConv2dImplicitGEMMFP32/FP16 (depthwise_conv2d_implicit_gemm.py:14-49):
+        # under autocast the inputs are cast to `cast_dtype` and autocast is disabled inside.
+        @staticmethod
+        @torch.amp.custom_fwd(device_type="cuda", cast_inputs=cast_dtype)
+        def forward(ctx, x, w):
+            ctx.save_for_backward(x, w)
+            return _extension.dwconv2d_forward(x.contiguous(), w.contiguous())
+
+        @staticmethod
+        @torch.amp.custom_bwd(device_type="cuda")
+        def backward(ctx, grad):
+            x, w = ctx.saved_tensors
+            grad = grad.contiguous()
+            x = x.contiguous()
+            w = w.contiguous()
+            dx = dw = None
+            if ctx.needs_input_grad[0]:
+                dx = _extension.dwconv2d_backward_data(grad, w)
+            if ctx.needs_input_grad[1]:
+                dw = _extension.dwconv2d_backward_filter(grad, x, w)      # fp32, like backward_filter_fp16.cu:187
+                if dw.dtype != w.dtype:
+                    dw = dw.to(w.dtype)
+            return dx, dw
+
+    _Fn.__name__ = _Fn.__qualname__ = name
+    return _Fn
+
+
+_DepthWiseConv2dImplicitGEMMFP32 = _make_function(torch.float32, "_DepthWiseConv2dImplicitGEMMFP32")
+_DepthWiseConv2dImplicitGEMMFP16 = _make_function(torch.float16, "_DepthWiseConv2dImplicitGEMMFP16")
+_DepthWiseConv2dImplicitGEMMBF16 = _make_function(torch.bfloat16, "_DepthWiseConv2dImplicitGEMMBF16")
+
+
+class DepthWiseConv2dImplicitGEMM(nn.Conv2d):
+    """``nn.Conv2d`` subclass with weight ``(C,1,kh,kw)``; computes a stride-1 "same" depthwise conv
+    regardless of ``self.padding`` (which stays (0,0), as in the reference)."""
+
+    def __init__(self, channels, kernel, bias=False):
+        super().__init__(channels, channels, kernel, groups=channels, bias=bias)
+
+    def forward(self, x):
+        if x.dtype == torch.float32:
+            x = _DepthWiseConv2dImplicitGEMMFP32.apply(x, self.weight)
+        elif x.dtype == torch.float16:
+            x = _DepthWiseConv2dImplicitGEMMFP16.apply(x, self.weight)
+        elif x.dtype == torch.bfloat16:
+            x = _DepthWiseConv2dImplicitGEMMBF16.apply(x, self.weight)
+        else:
+            raise TypeError("Only support fp32, fp16 and bf16, get {}".format(x.dtype))
+        if self.bias is not None:
+            x = x + self.bias.to(x).view(1, -1, 1, 1)
+        return x

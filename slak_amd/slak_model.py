@@ -1,0 +1,249 @@
+"""Caller-side mirror of the reference model (models/SLaK.py) -- the code that CALLS the hot path.
+
+It exists for two reasons only: (i) bench.py needs the SLaK-T 51x51 train step BASELINE.json names, and
+/root/reference is not present on the GPU box; (ii) the full-model parity tests need the exact parameter
+set (95 maskable tensors / 30,816,232 params for SLaK-T).  Module names, parameter shapes and state-dict keys
+are identical to the reference (``stages.{i}.{j}.large_kernel.{LoRA1,LoRA2,small_conv}.{conv,bn}.*``,
+``downsample_layers``, ``norm``, ``head``: models/SLaK.py:186-215), so checkpoints interchange.  timm is not
+installed here; the two helpers it provided are restated (DropPath: timm1/layers/drop.py:137-166 semantics,
+trunc_normal_: absolute bounds [-2, 2], timm1/layers/weight_init.py:43-67 == torch.nn.init.trunc_normal_).
+
+One deliberate addition, off by default: ``lowp_dwconv=True`` makes the large-kernel block hand its input to
+the three depthwise convs in the autocast dtype (bf16).  In the reference the residual stream reaching the op
+is fp32 even under autocast (gamma is fp32: models/SLaK.py:149, :161-162) and custom_fwd casts to fp32
+(depthwise_conv2d_implicit_gemm.py:16), so its "AMP" run still executes the fp32 SIMT kernels.
+BASELINE.json's metric is a bf16 train step, so bench.py turns this on; parity tests cover both settings.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .depthwise_conv2d_implicit_gemm import DepthWiseConv2dImplicitGEMM
+
+use_sync_bn = True       # same module-level switch as models/SLaK.py:19
+
+
+def get_conv2d(in_channels, out_channels, kernel_size, stride, padding, dilation, groups, bias):
+    # the reference ignores everything but channels/kernel/bias as well (models/SLaK.py:21-22)
+    return DepthWiseConv2dImplicitGEMM(in_channels, kernel_size, bias=bias)
+
+
+def get_bn(channels):
+    return nn.SyncBatchNorm(channels) if use_sync_bn else nn.BatchNorm2d(channels)
+
+
+def conv_bn(in_channels, out_channels, kernel_size, stride, padding, groups, dilation=1, bn=True):
+    seq = nn.Sequential()
+    seq.add_module('conv', get_conv2d(in_channels, out_channels, kernel_size, stride, padding, dilation, groups, False))
+    if bn:
+        seq.add_module('bn', get_bn(out_channels))
+    return seq
+
+
+def fuse_bn(conv, bn):
+    std = (bn.running_var + bn.eps).sqrt()
+    scale = (bn.weight / std).reshape(-1, 1, 1, 1)
+    return conv.weight * scale, bn.bias - bn.running_mean * bn.weight / std
+
+
+class DropPath(nn.Module):
+    """Stochastic depth per sample."""
+
+    def __init__(self, drop_prob=0.0):
+        super().__init__()
+        self.drop_prob = drop_prob
+
+    def forward(self, x):
+        if self.drop_prob == 0.0 or not self.training:
+            return x
+        keep = 1.0 - self.drop_prob
+        mask = x.new_empty((x.shape[0],) + (1,) * (x.dim() - 1)).bernoulli_(keep)
+        if keep > 0.0:
+            mask.div_(keep)
+        return x * mask
+
+
+class LayerNorm(nn.Module):
+    """channels_last -> F.layer_norm; channels_first -> explicit mean/var over dim 1 (models/SLaK.py:235-261)."""
+
+    def __init__(self, normalized_shape, eps=1e-6, data_format="channels_last"):
+        super().__init__()
+        if data_format not in ("channels_last", "channels_first"):
+            raise NotImplementedError
+        self.weight = nn.Parameter(torch.ones(normalized_shape))
+        self.bias = nn.Parameter(torch.zeros(normalized_shape))
+        self.eps = eps
+        self.data_format = data_format
+        self.normalized_shape = (normalized_shape,)
+
+    def forward(self, x):
+        if self.data_format == "channels_last":
+            return F.layer_norm(x, self.normalized_shape, self.weight, self.bias, self.eps)
+        u = x.mean(1, keepdim=True)
+        s = (x - u).pow(2).mean(1, keepdim=True)
+        x = (x - u) / torch.sqrt(s + self.eps)
+        return self.weight[:, None, None] * x + self.bias[:, None, None]
+
+
+class ReparamLargeKernelConv(nn.Module):
+    """K x small + small x K (+ small x small) depthwise branches, each conv -> BN, summed (models/SLaK.py:60-100)."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride, groups, small_kernel,
+                 small_kernel_merged=False, Decom=False, bn=True, lowp_dwconv=False):
+        super().__init__()
+        self.kernel_size = kernel_size
+        self.small_kernel = small_kernel
+        self.Decom = Decom
+        self.lowp_dwconv = lowp_dwconv
+        padding = kernel_size // 2
+        if small_kernel_merged:
+            self.lkb_reparam = get_conv2d(in_channels, out_channels, kernel_size, stride, padding, 1, groups, True)
+            return
+        if Decom:
+            self.LoRA1 = conv_bn(in_channels, out_channels, (kernel_size, small_kernel), stride, padding, groups, bn=bn)
+            self.LoRA2 = conv_bn(in_channels, out_channels, (small_kernel, kernel_size), stride, padding, groups, bn=bn)
+        else:
+            self.lkb_origin = conv_bn(in_channels, out_channels, kernel_size, stride, padding, groups, bn=bn)
+        if small_kernel is not None and small_kernel < kernel_size:
+            self.small_conv = conv_bn(in_channels, out_channels, small_kernel, stride, small_kernel // 2, groups, bn=bn)
+
+    def forward(self, inputs):
+        if self.lowp_dwconv and torch.is_autocast_enabled():
+            inputs = inputs.to(torch.get_autocast_dtype("cuda"))
+        if hasattr(self, 'lkb_reparam'):
+            return self.lkb_reparam(inputs)
+        if self.Decom:
+            out = self.LoRA1(inputs) + self.LoRA2(inputs)
+        else:
+            out = self.lkb_origin(inputs)
+        if hasattr(self, 'small_conv'):
+            out += self.small_conv(inputs)
+        return out
+
+    def get_equivalent_kernel_bias(self):
+        k, b = fuse_bn(self.lkb_origin.conv, self.lkb_origin.bn)
+        if hasattr(self, 'small_conv'):
+            sk, sb = fuse_bn(self.small_conv.conv, self.small_conv.bn)
+            b = b + sb
+            k = k + F.pad(sk, [(self.kernel_size - self.small_kernel) // 2] * 4)
+        return k, b
+
+    def merge_kernel(self):
+        k, b = self.get_equivalent_kernel_bias()
+        c = self.lkb_origin.conv
+        self.lkb_reparam = get_conv2d(c.in_channels, c.out_channels, c.kernel_size, c.stride, c.padding, c.dilation, c.groups, True)
+        self.lkb_reparam.weight.data = k
+        self.lkb_reparam.bias.data = b
+        del self.lkb_origin
+        if hasattr(self, 'small_conv'):
+            del self.small_conv
+
+
+class Block(nn.Module):
+    """dw large-kernel -> LN (channels_last) -> Linear(C,4C) -> GELU -> Linear(4C,C) -> gamma -> residual."""
+
+    def __init__(self, dim, drop_path=0., layer_scale_init_value=1e-6, kernel_size=(7, 7), Decom=None, bn=True, lowp_dwconv=False):
+        super().__init__()
+        self.large_kernel = ReparamLargeKernelConv(dim, dim, kernel_size[0], stride=1, groups=dim, small_kernel=kernel_size[1],
+                                                   small_kernel_merged=False, Decom=Decom, bn=bn, lowp_dwconv=lowp_dwconv)
+        self.norm = LayerNorm(dim, eps=1e-6)
+        self.pwconv1 = nn.Linear(dim, 4 * dim)
+        self.act = nn.GELU()
+        self.pwconv2 = nn.Linear(4 * dim, dim)
+        self.gamma = nn.Parameter(layer_scale_init_value * torch.ones((dim)), requires_grad=True) if layer_scale_init_value > 0 else None
+        self.drop_path = DropPath(drop_path) if drop_path > 0. else nn.Identity()
+
+    def forward(self, x):
+        shortcut = x
+        x = self.large_kernel(x)
+        x = x.permute(0, 2, 3, 1)
+        x = self.pwconv2(self.act(self.pwconv1(self.norm(x))))
+        if self.gamma is not None:
+            x = self.gamma * x
+        x = x.permute(0, 3, 1, 2)
+        return shortcut + self.drop_path(x)
+
+
+class SLaK(nn.Module):
+    def __init__(self, in_chans=3, num_classes=1000, depths=(3, 3, 9, 3), dims=(96, 192, 384, 768), drop_path_rate=0.,
+                 layer_scale_init_value=1e-6, head_init_scale=1., kernel_size=(51, 49, 47, 13, 5), width_factor=1.0,
+                 Decom=None, bn=True, lowp_dwconv=False):
+        super().__init__()
+        dims = [int(d * width_factor) for d in dims]
+        self.kernel_size = list(kernel_size)
+        self.downsample_layers = nn.ModuleList()
+        self.downsample_layers.append(nn.Sequential(nn.Conv2d(in_chans, dims[0], kernel_size=4, stride=4),
+                                                    LayerNorm(dims[0], eps=1e-6, data_format="channels_first")))
+        for i in range(3):
+            self.downsample_layers.append(nn.Sequential(LayerNorm(dims[i], eps=1e-6, data_format="channels_first"),
+                                                        nn.Conv2d(dims[i], dims[i + 1], kernel_size=2, stride=2)))
+        rates = [r.item() for r in torch.linspace(0, drop_path_rate, sum(depths))]
+        self.stages = nn.ModuleList()
+        at = 0
+        for i in range(4):
+            self.stages.append(nn.Sequential(*[
+                Block(dims[i], drop_path=rates[at + j], layer_scale_init_value=layer_scale_init_value,
+                      kernel_size=(self.kernel_size[i], self.kernel_size[-1]), Decom=Decom, bn=bn, lowp_dwconv=lowp_dwconv)
+                for j in range(depths[i])]))
+            at += depths[i]
+        self.norm = nn.LayerNorm(dims[-1], eps=1e-6)
+        self.head = nn.Linear(dims[-1], num_classes)
+        self.apply(self._init_weights)
+        self.head.weight.data.mul_(head_init_scale)
+        self.head.bias.data.mul_(head_init_scale)
+
+    @staticmethod
+    def _init_weights(m):
+        if isinstance(m, (nn.Conv2d, nn.Linear)):           # DepthWiseConv2dImplicitGEMM IS an nn.Conv2d
+            nn.init.trunc_normal_(m.weight, std=.02, a=-2., b=2.)
+            if m.bias is not None:
+                nn.init.constant_(m.bias, 0)
+
+    def forward_features(self, x):
+        for i in range(4):
+            x = self.stages[i](self.downsample_layers[i](x))
+        return self.norm(x.mean([-2, -1]))
+
+    def forward(self, x):
+        return self.head(self.forward_features(x))
+
+
+_VARIANTS = {
+    "tiny": dict(depths=(3, 3, 9, 3), dims=(96, 192, 384, 768)),
+    "small": dict(depths=(3, 3, 27, 3), dims=(96, 192, 384, 768)),
+    "base": dict(depths=(3, 3, 27, 3), dims=(128, 256, 512, 1024)),
+    "large": dict(depths=(3, 3, 27, 3), dims=(192, 384, 768, 1536)),
+}
+
+
+def SLaK_tiny(pretrained=False, **kw): return SLaK(**_VARIANTS["tiny"], **kw)
+def SLaK_small(pretrained=False, **kw): return SLaK(**_VARIANTS["small"], **kw)
+def SLaK_base(pretrained=False, in_22k=False, **kw): return SLaK(**_VARIANTS["base"], **kw)
+def SLaK_large(pretrained=False, in_22k=False, **kw): return SLaK(**_VARIANTS["large"], **kw)
+
+
+def create_model(name, **kw):
+    """Stand-in for timm's registry lookup used by main.py:301-312."""
+    return {"SLaK_tiny": SLaK_tiny, "SLaK_small": SLaK_small, "SLaK_base": SLaK_base, "SLaK_large": SLaK_large}[name](**kw)
+
+
+def slak_mask_set_shapes(variant="tiny", kernel_size=(51, 49, 47, 13, 5), num_classes=1000, in_chans=3, only_L=False):
+    """Shapes of the tensors ``Masking.add_module`` would mask (2-D / 4-D parameters, sparse_core.py:121-130),
+    computed arithmetically (no model instantiation)."""
+    cfg = _VARIANTS[variant]
+    dims, depths = cfg["dims"], cfg["depths"]
+    # parameter order follows named_parameters(): downsample_layers first, then stages, then head
+    shapes = []
+    if not only_L:
+        shapes.append((dims[0], in_chans, 4, 4))
+        for i in range(3):
+            shapes.append((dims[i + 1], dims[i], 2, 2))
+    for i in range(4):
+        K, s, C = kernel_size[i], kernel_size[-1], dims[i]
+        for _ in range(depths[i]):
+            shapes.append((C, 1, K, s)); shapes.append((C, 1, s, K))
+            if not only_L:
+                shapes.append((C, 1, s, s)); shapes.append((4 * C, C)); shapes.append((C, 4 * C))
+    if not only_L:
+        shapes.append((num_classes, dims[-1]))
+    return shapes

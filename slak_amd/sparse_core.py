@@ -1,0 +1,417 @@
+"""Drop-in for the reference's ``sparse_core`` module (sparse_core.py:49-407): ``CosineDecay`` and
+``Masking`` with the same constructor, attributes and methods, but with the per-step and per-update
+work done by batched HIP kernels (slak_amd/csrc/mask_kernels.hip) over ALL masked tensors at once:
+
+    reference (per tensor, Python)                         here (all tensors, on device)
+    -----------------------------------------------------  -----------------------------------------
+    apply_mask: w.data = w.data*mask           :316-333     slak_mask_apply          (1 launch)
+    truncate_weights: mask.sum().item(),       :335-357     slak_mask_prune_and_grow (no host sync;
+      torch.sort(|w|), torch.sort(|grad|), ...                 radix select, counts stay on device)
+    synchronism_masks: broadcast every mask    :404-407     ONE broadcast after init; afterwards masks
+      from rank 0, every step                                 are a deterministic function of replicated
+                                                              weights + all-reduced grads (checksum
+                                                              all-reduce available as a debug check)
+
+Scope (BASELINE.json north star): growth='gradient', prune='magnitude'.  Other growth/prune/
+redistribution modes of funcs.py are out of scope and raise NotImplementedError rather than silently
+falling back.  Mask initialisation (uniform / resume / snip / ERK, sparse_core.py:141-261) is one-time
+host logic and stays in Python, using the same torch RNG calls so that seeds reproduce the reference.
+
+Masks stay fp32 tensors in ``self.masks[name]`` (``model_sema.py:83-89`` reads them), keyed by
+``named_parameters()`` names of whatever was passed to ``add_module`` (the DDP wrapper in main.py:425,
+so keys carry ``module.``).  Ties at the prune/grow cut: lowest flat index first (torch.sort(stable=True));
+the reference's unstable torch.sort is arbitrary there.
+"""
+from __future__ import print_function
+
+import ctypes
+import math
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+import torch.optim as optim
+
+from . import _lib
+
+__all__ = ["CosineDecay", "Masking", "SNIP"]
+
+
+def SNIP(net, keep_ratio, train_dataloader, device, masks, args):
+    """Layer-wise sparsities from one batch of |w * dL/dw| saliencies (sparse_core.py:11-47)."""
+    import copy
+    if args.distributed:
+        train_dataloader.sampler.set_epoch(0)
+    images, labels = next(iter(train_dataloader))
+    images = images.to(device, non_blocking=True)
+    labels = labels.to(device, non_blocking=True)
+    probe = copy.deepcopy(net)            # never touch the training copy
+    probe.zero_grad()
+    F.cross_entropy(probe(images), labels).backward()
+    saliency = [torch.abs(p * p.grad) for n, p in probe.named_parameters() if n in masks]
+    flat = torch.cat([s.flatten() for s in saliency])
+    keep = int(len(flat) * keep_ratio)
+    cut = torch.topk(flat, keep, sorted=True)[0][-1]
+    out = []
+    for s in saliency:
+        kept = (s > cut).float()
+        out.append(float((kept == 0).sum().item() / kept.numel()))
+    probe.zero_grad()
+    return out
+
+
+class CosineDecay(object):
+    """Prune-rate schedule: torch's CosineAnnealingLR on a dummy SGD, exactly as the reference builds it
+    (sparse_core.py:49-64), kept on the host so ``ceil(rate*nnz)`` sees the bit-identical fp64 rate."""
+
+    def __init__(self, prune_rate, T_max, eta_min=0.005, last_epoch=-1, init_step=0):
+        self.sgd = optim.SGD(torch.nn.ParameterList([torch.nn.Parameter(torch.zeros(1))]), lr=prune_rate)
+        self.cosine_stepper = torch.optim.lr_scheduler.CosineAnnealingLR(self.sgd, T_max, eta_min, last_epoch)
+        for _ in range(init_step):
+            self.cosine_stepper.step()
+
+    def step(self):
+        self.cosine_stepper.step()
+
+    def get_dr(self, prune_rate):
+        return self.sgd.param_groups[0]['lr']
+
+
+class Masking(object):
+    """Same surface as the reference class (sparse_core.py:67-407).
+
+    Basic usage (unchanged from the reference):
+        decay = CosineDecay(args.prune_rate, len(train_loader)*args.epochs)
+        mask = Masking(optimizer, train_loader, prune_rate_decay=decay, prune_rate=args.prune_rate,
+                       prune_mode='magnitude', growth_mode='gradient', redistribution_mode='none', args=args)
+        mask.add_module(model)
+        ...
+        mask.step()        # instead of optimizer.step()
+    """
+
+    def __init__(self, optimizer, train_loader, prune_rate_decay, prune_rate=0.5, prune_mode='magnitude',
+                 growth_mode='random', redistribution_mode='momentum', verbose=False, fp16=False, args=False):
+        self.args = args
+        self.device = torch.device(args.device)
+        self.growth_mode = growth_mode
+        self.prune_mode = prune_mode
+        self.redistribution_mode = redistribution_mode
+        self.prune_rate_decay = prune_rate_decay
+        self.verbose = verbose
+        self.train_loader = train_loader
+        self.growth_func = growth_mode
+        self.prune_func = prune_mode
+        self.redistribution_func = redistribution_mode
+        self.global_growth = False
+        self.global_prune = False
+
+        self.masks = {}
+        self.modules = []
+        self.names = []
+        self.optimizer = optimizer
+        self.baseline_nonzero = None
+
+        self.name2zeros = {}
+        self.name2nonzeros = {}
+        self.name2removed = {}
+        self.prune_rate = prune_rate
+        self.steps = 0
+        self.half = fp16
+        self.name_to_32bit = {}
+
+        if self.args.fix:
+            self.args.update_frequency = None
+
+        # device plan state
+        self._plan = None
+        self._plan_names = []
+        self._plan_key = None
+        self._synced_once = False
+        self.debug_check_ranks = bool(getattr(args, "debug_mask_sync", False))
+
+        if self.half:
+            raise NotImplementedError("fp16 master-copy masking (apex FP16_Optimizer, sparse_core.py:135-139, :329-333) "
+                                      "is outside the MI355X hot path; use bf16 autocast with fp32 parameters")
+
+    # ------------------------------------------------------------------ construction / init
+    def add_module(self, module):
+        self.modules.append(module)
+        self.module = module
+        for name, tensor in module.named_parameters():
+            if tensor.dim() in (2, 4):
+                if self.args.only_L and 'large_kernel.LoRA' not in name:
+                    continue
+                self.names.append(name)
+                self.masks[name] = torch.zeros_like(tensor, dtype=torch.float32, requires_grad=False).to(self.device)
+        self.init(mode=self.args.sparse_init, density=1 - self.args.sparsity)
+
+    def init_optimizer(self):
+        if 'fp32_from_fp16' in self.optimizer.state_dict():
+            raise NotImplementedError("fp16 master-copy optimizers are not supported")
+
+    def init_growth_prune_and_redist(self):
+        if self.growth_mode != 'gradient':
+            raise NotImplementedError("growth mode %r: only 'gradient' (funcs.py:196-205) is on the MI355X hot path" % (self.growth_mode,))
+        if self.prune_mode != 'magnitude':
+            raise NotImplementedError("prune mode %r: only 'magnitude' (funcs.py:107-114) is on the MI355X hot path" % (self.prune_mode,))
+        # the reference resolves a redistribution function but never calls it (sparse_core.py:288-297)
+
+    def _rand_mask(self, shape, density):
+        # same RNG stream as the reference: CPU torch.rand, then moved (sparse_core.py:155, :180, :241)
+        return (torch.rand(shape) < density).float().data.to(self.device)
+
+    def init(self, mode='snip', density=0.05, erk_power_scale=1.0):
+        self.init_growth_prune_and_redist()
+        self.init_optimizer()
+        self.density = density
+
+        if mode == 'uniform':
+            print('initialized with uniform')
+            self.baseline_nonzero = 0
+            for module in self.modules:
+                for name, weight in module.named_parameters():
+                    if name not in self.masks:
+                        continue
+                    self.masks[name][:] = self._rand_mask(weight.shape, density)
+                    self.baseline_nonzero += weight.numel() * density
+        elif mode == 'resume':
+            print('initialized with resume')
+            self.baseline_nonzero = 0
+            for module in self.modules:
+                for name, weight in module.named_parameters():
+                    if name not in self.masks:
+                        continue
+                    print((weight != 0.0).sum().item())
+                    self.masks[name][:] = (weight != 0.0).float().data.to(self.device)
+                    self.baseline_nonzero += weight.numel() * density
+        elif mode == 'snip':
+            print('initialize by snip')
+            self.baseline_nonzero = 0
+            sparsities = SNIP(self.module, density, self.train_loader, self.device, self.masks, self.args)
+            for sp, name in zip(sparsities, self.masks):
+                self.masks[name][:] = self._rand_mask(self.masks[name].shape, 1 - sp)
+        elif mode == 'ERK':
+            print('initialize by fixed_ERK')
+            self._init_erk(density, erk_power_scale)
+        else:
+            raise ValueError("unknown sparse_init %r" % (mode,))
+
+        total_size = sparse_size = 0
+        dense_layers = []
+        for name, m in self.masks.items():
+            n_all = m.numel()
+            n_on = (m != 0).sum().int().item()
+            total_size += n_all
+            sparse_size += n_on
+            layer_density = n_on / n_all
+            if layer_density >= 0.99:
+                dense_layers.append(name)
+            print(f'Density of layer {name} with tensor {m.size()} is {layer_density}')
+        print('Final sparsity level of {0}: {1}'.format(1 - self.density, 1 - sparse_size / total_size))
+        for name in dense_layers:                       # (almost) dense layers are not masked at all
+            self.masks.pop(name)
+            print(f"pop out layer {name}")
+        self._plan_key = None
+        self._synced_once = False
+        self.apply_mask()
+
+    def _init_erk(self, density, erk_power_scale):
+        """Erdos-Renyi-Kernel densities: layer probability ~ (sum of dims / prod of dims)^scale, scaled by a
+        global epsilon so the total budget is met; layers whose probability would exceed 1 become dense and
+        the rest is re-solved (sparse_core.py:183-245)."""
+        total_params = sum(m.numel() for m in self.masks.values())
+        self.baseline_nonzero = sum(m.numel() * density for m in self.masks.values())
+        dense = set()
+        while True:
+            divisor, rhs, raw = 0, 0, {}
+            for name, m in self.masks.items():
+                n_param = np.prod(m.shape)
+                if name in dense:
+                    rhs -= n_param * (1 - density)
+                else:
+                    rhs += n_param * density
+                    raw[name] = (np.sum(m.shape) / np.prod(m.shape)) ** erk_power_scale
+                    divisor += raw[name] * n_param
+            epsilon = rhs / divisor
+            top = np.max(list(raw.values()))
+            if top * epsilon > 1:
+                for name, r in raw.items():
+                    if r == top:
+                        print(f"Sparsity of var:{name} had to be set to 0.")
+                        dense.add(name)
+            else:
+                break
+        total_nonzero = 0.0
+        for name, m in self.masks.items():
+            d = 1.0 if name in dense else epsilon * raw[name]
+            print(f"layer: {name}, shape: {m.shape}, density: {d}")
+            self.masks[name][:] = self._rand_mask(m.shape, d)
+            total_nonzero += d * m.numel()
+        print(f"Overall sparsity {total_nonzero / total_params}")
+
+    # ------------------------------------------------------------------ device plan
+    def _masked_params(self):
+        out = []
+        for module in self.modules:
+            for name, tensor in module.named_parameters():
+                if name in self.masks:
+                    out.append((name, tensor))
+        return out
+
+    def _ensure_plan(self):
+        params = self._masked_params()
+        if not params:
+            return None
+        for name, t in params:
+            if not t.is_cuda:
+                raise _lib.SlakHipError("slak_amd Masking needs parameters on a HIP device (got %s for %s); there is no CPU fallback" % (t.device, name))
+            if t.dtype != torch.float32 or not t.data.is_contiguous():
+                raise _lib.SlakHipError("masked parameter %s must be contiguous float32" % name)
+        key = tuple((n, t.data.data_ptr(), self.masks[n].data_ptr(), t.numel()) for n, t in params)
+        if key != self._plan_key:
+            L = _lib.lib()
+            if self._plan is not None:
+                L.slak_mask_plan_destroy(self._plan)
+                self._plan = None
+            segs = (_lib.MaskSegment * len(params))()
+            for i, (n, t) in enumerate(params):
+                segs[i].weight = t.data.data_ptr()
+                segs[i].mask = self.masks[n].data_ptr()
+                segs[i].grad = None
+                segs[i].momentum = None
+                segs[i].numel = t.numel()
+            plan = ctypes.c_void_p()
+            with torch.cuda.device(self.device):
+                _lib.check(L.slak_mask_plan_create(segs, len(params), ctypes.byref(plan)), "slak_mask_plan_create")
+            self._plan, self._plan_key = plan, key
+            self._plan_names = [n for n, _ in params]
+            self._momentum_key = None
+        return params
+
+    def _stream(self):
+        return torch.cuda.current_stream(self.device).cuda_stream
+
+    def _bind_momentum(self, params):
+        ptrs = []
+        for _, t in params:
+            st = self.optimizer.state.get(t, {}) if self.optimizer is not None else {}
+            mb = st.get('momentum_buffer') if isinstance(st, dict) else None
+            ptrs.append(mb.data_ptr() if (mb is not None and mb.is_cuda and mb.dtype == torch.float32 and mb.is_contiguous()) else 0)
+        key = tuple(ptrs)
+        if key != self._momentum_key:
+            arr = (ctypes.c_void_p * len(ptrs))(*[p or None for p in ptrs])
+            _lib.check(_lib.lib().slak_mask_plan_set_momentum(self._plan, arr, self._stream()), "slak_mask_plan_set_momentum")
+            self._momentum_key = key
+
+    # ------------------------------------------------------------------ the per-step surface
+    def step(self):
+        self.optimizer.step()
+        self.apply_mask()
+        self.prune_rate_decay.step()
+        self.prune_rate = self.prune_rate_decay.get_dr(self.prune_rate)
+        self.steps += 1
+        if self.args.update_frequency is not None:
+            if self.steps % self.args.update_frequency == 0:
+                print('*********************************Dynamic Sparsity********************************')
+                self.truncate_weights()
+                self.print_nonzero_counts()
+
+    def apply_mask(self):
+        if self.args.distributed:
+            self.synchronism_masks()
+        params = self._ensure_plan()
+        if params is None:
+            return
+        with torch.cuda.device(self.device):
+            self._bind_momentum(params)
+            _lib.check(_lib.lib().slak_mask_apply(self._plan, self._stream()), "slak_mask_apply")
+
+    def truncate_weights(self):
+        params = self._ensure_plan()
+        if params is None:
+            return
+        L = _lib.lib()
+        grads = []
+        for name, t in params:
+            g = t.grad
+            if g is None:
+                raise RuntimeError("truncate_weights needs .grad of %s (gradient growth, funcs.py:196-205)" % name)
+            if g.dtype != torch.float32 or not g.is_contiguous():
+                raise _lib.SlakHipError("gradient of %s must be contiguous float32" % name)
+            grads.append(g)
+        with torch.cuda.device(self.device):
+            self._bind_momentum(params)
+            arr = (ctypes.c_void_p * len(grads))(*[g.data_ptr() for g in grads])
+            _lib.check(L.slak_mask_plan_set_grads(self._plan, arr, self._stream()), "slak_mask_plan_set_grads")
+            _lib.check(L.slak_mask_prune_and_grow(self._plan, float(self.prune_rate), self._stream()), "slak_mask_prune_and_grow")
+            stats = (ctypes.c_double * (4 * len(params)))()
+            _lib.check(L.slak_mask_read_stats(self._plan, stats, self._stream()), "slak_mask_read_stats")
+        self._nonzeros_after = {}
+        for i, (name, _) in enumerate(params):
+            self.name2nonzeros[name] = stats[4 * i + 0]
+            self.name2zeros[name] = stats[4 * i + 1]
+            self.name2removed[name] = stats[4 * i + 2]
+            self._nonzeros_after[name] = stats[4 * i + 3]
+        if self.args.distributed and self.debug_check_ranks:
+            self.check_rank_agreement()
+
+    # ------------------------------------------------------------------ utilities
+    def get_gradient_for_weights(self, weight):
+        return weight.grad.clone()
+
+    def print_nonzero_counts(self):
+        after = getattr(self, "_nonzeros_after", {})
+        for module in self.modules:
+            for name, tensor in module.named_parameters():
+                if name not in self.masks:
+                    continue
+                mask = self.masks[name]
+                num_nonzeros = int(after[name]) if name in after else (mask != 0).sum().item()
+                print('{0}: {1}->{2}, density: {3:.3f}'.format(name, self.name2nonzeros.get(name), num_nonzeros,
+                                                               num_nonzeros / float(mask.numel())))
+        print('Prune rate: {0}\n'.format(self.prune_rate))
+
+    def mask_checksum(self):
+        """64-bit order-independent checksum of all masks (device kernel); equal on every rank iff masks agree."""
+        self._ensure_plan()
+        out = ctypes.c_ulonglong(0)
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib().slak_mask_checksum(self._plan, ctypes.byref(out), self._stream()), "slak_mask_checksum")
+        return out.value
+
+    def check_rank_agreement(self):
+        import torch.distributed as dist
+        c = self.mask_checksum()
+        t = torch.tensor([c & 0x7fffffff, (c >> 31) & 0x7fffffff, c >> 62], dtype=torch.int64, device=self.device)
+        lo, hi = t.clone(), t.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        if not torch.equal(lo, hi):
+            raise RuntimeError("mask checksum differs across ranks")
+
+    def synchronism_masks(self):
+        """The reference broadcasts every mask from rank 0 on EVERY apply_mask (sparse_core.py:404-407: 95
+        blocking collectives per step for SLaK-T).  Rank-0-wins is only observable once: masks come from
+        per-rank RNG at init (main.py:232), and from then on they are a deterministic function of replicated
+        weights and all-reduced gradients, so every rank computes the same masks.  One coalesced broadcast
+        after (re-)initialisation preserves the reference's semantics; later calls are free."""
+        if self._synced_once:
+            return
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            names = list(self.masks.keys())
+            flat = torch.cat([self.masks[n].reshape(-1) for n in names])
+            dist.broadcast(flat, src=0)
+            off = 0
+            for n in names:
+                k = self.masks[n].numel()
+                self.masks[n].copy_(flat[off:off + k].view_as(self.masks[n]))
+                off += k
+        self._synced_once = True
+
+    def __del__(self):
+        try:
+            if self._plan is not None:
+                _lib.lib().slak_mask_plan_destroy(self._plan)
+        except Exception:
+            pass
