@@ -1,0 +1,230 @@
+#!/usr/bin/env python3
+"""bench.py -- BASELINE.json's metric on MI355X: images/sec of a SLaK-T 51x51, 224 px, bf16 TRAIN STEP
+(forward + loss + backward + AdamW step) with every depthwise conv running the hand-written HIP kernels,
+plus the HBM roofline of the dominant hot-path kernel and the reference CPU nn.Conv2d path timed beside it.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+           bench.py --gpus N --steps K --warmup W
+
+Workload: N=1 -> BASELINE.json configs[1] (bs 128, sparsity off).  N>1 -> configs[2] (bs 128 per GPU, DDP over
+RCCL, SyncBN, Masking sparsity 0.4 with prune-and-grow every 2000 steps), weak scaling.  Synthetic data
+(seeded randn images, randint targets), random-init weights.  One JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+import types
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+import torch.nn.functional as F
+
+HBM_PEAK_GBS = 8000.0           # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+STAGES_T = [(96, 56, 51, 3), (192, 28, 49, 3), (384, 14, 47, 9), (768, 7, 13, 3)]    # C, H=W, K, blocks  
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=128, help="per-GPU batch (BASELINE cfg 2/3: 128)")
+    ap.add_argument("--sparsity", type=float, default=None, help="default: 0 at N=1 (cfg 2), 0.4 at N>1 (cfg 3)")
+    ap.add_argument("--update-frequency", type=int, default=2000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--kernel-reps", type=int, default=10)
+    ap.add_argument("--fp32-dwconv", action="store_true", help="reference dtype flow: dw convs see fp32 even under autocast")
+    return ap.parse_args()
+
+
+def event_time_ms(fn, reps, stream_device):
+    """Average duration of fn() over `reps` launches, HIP events on the stream the kernels are launched on
+    (torch's current stream == the stream slak_amd.ops passes to the C ABI)."""
+    for _ in range(2):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize(stream_device)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    e1.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+def hot_path_kernels(device, batch, reps, dtype):
+    """Every distinct (stage, kernel, pass) of the dw-conv hot path at the bench shapes, timed alone."""
+    from slak_amd import ops
+    out = []
+    b = 2 if dtype != torch.float32 else 4
+    for si, (C, HW, K, blocks) in enumerate(STAGES_T):
+        x = torch.randn(batch, C, HW, HW, device=device).to(dtype)
+        dy = torch.randn_like(x)
+        for kname, (kh, kw) in (("Kx5", (K, 5)), ("5xK", (5, K)), ("5x5", (5, 5))):
+            w = torch.randn(C, 1, kh, kw, device=device) * 0.02
+            S = x.numel()
+            for pname, fn, extra in (("fwd", lambda: ops.dwconv2d_forward(x, w), C * kh * kw * 4),
+                                     ("bwd_data", lambda: ops.dwconv2d_backward_data(dy, w), C * kh * kw * 4),
+                                     ("bwd_filter", lambda: ops.dwconv2d_backward_filter(dy, x, w), C * kh * kw * 4)):
+                ms = event_time_ms(fn, reps, device)
+                alg_bytes = 2 * S * b + extra                       # 2*S*b (+ C*kh*kw*4)
+                out.append(dict(stage=si + 1, kernel="%dx%d" % (kh, kw), branch=kname, op=pname, ms=ms, calls_per_step=blocks,
+                                alg_bytes=alg_bytes, gbs=alg_bytes / ms / 1e6, gflop_nominal=2.0 * S * kh * kw / 1e9))
+        del x, dy
+    return out
+
+
+def cpu_baseline(threads):
+    """Reference CPU path (north star: 'the reference CPU nn.Conv2d path timed on the node's host cores'):
+    torch CPU F.conv2d fp32 fwd + bwd of every distinct dw conv of SLaK-T at batch 1 (BASELINE cfg 1 is the
+    stage-1 block of this list), weighted by how often each occurs per image -> images/s of the dw-conv hot
+    path alone.  Bounded: a few iterations per shape, ~10-30 s total."""
+    torch.set_num_threads(threads)
+    total = 0.0
+    detail = {}
+    t_start = time.perf_counter()
+    for (C, HW, K, blocks) in STAGES_T:
+        x = torch.randn(1, C, HW, HW, requires_grad=True)
+        for kh, kw in ((K, 5), (5, K), (5, 5)):
+            w = (torch.randn(C, 1, kh, kw) * 0.02).requires_grad_(True)
+            def it():
+                y = F.conv2d(x, w, None, 1, (kh // 2, kw // 2), 1, C)
+                y.backward(torch.ones_like(y))
+            it()                                                  # warm-up
+            ts = []
+            for _ in range(3):
+                t0 = time.perf_counter(); it(); ts.append(time.perf_counter() - t0)
+                if sum(ts) > 2.0:                                 # keep the whole leg bounded (~10-30 s)
+                    break
+            t = sorted(ts)[len(ts) // 2]
+            detail["s%d_%dx%d" % (HW, kh, kw)] = t
+            total += t * blocks
+    return dict(value=1.0 / total, unit="images/s (dw-conv hot path only: all 54 convs fwd+bwd)", cores=threads, kind="reference",
+                sample="torch %s CPU F.conv2d fp32 fwd+bwd, batch 1, every distinct SLaK-T dw-conv shape (cfg-1 stage-1 block: "
+                       "%.1f ms), median of <=3, weighted by blocks/stage; wall %.1f s" % (
+                           torch.__version__, 1e3 * sum(v for k, v in detail.items() if k.startswith("s56")), time.perf_counter() - t_start))
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs an MI355X (no CPU fallback for the hot path)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    distributed = world > 1
+    if distributed:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=device)        # "nccl" is RCCL on ROCm
+    n_gpus = world if distributed else 1
+    sparsity = a.sparsity if a.sparsity is not None else (0.4 if n_gpus > 1 else 0.0)
+
+    import slak_amd.slak_model as M
+    from slak_amd.sparse_core import CosineDecay, Masking
+    M.use_sync_bn = True                                          # reference default (models/SLaK.py:19); falls back to BN math at world 1
+    torch.manual_seed(0 + rank)                                   # main.py:232  seed = args.seed + rank
+    model = M.SLaK_tiny(kernel_size=[51, 49, 47, 13, 5], Decom=True, bn=True, drop_path_rate=0.1,
+                        lowp_dwconv=not a.fp32_dwconv).to(device)
+    if distributed:
+        model = nn.parallel.DistributedDataParallel(model, device_ids=[local_rank], find_unused_parameters=False)   # main.py:374-376
+    decay, no_decay = [], []
+    for n, p in model.named_parameters():
+        (no_decay if (p.dim() == 1 or n.endswith(".bias")) else decay).append(p)                                     # optim_factory.py no-decay rule
+    opt = torch.optim.AdamW([dict(params=decay, weight_decay=0.05), dict(params=no_decay, weight_decay=0.0)], lr=4e-3, fused=True)
+    criterion = nn.CrossEntropyLoss(label_smoothing=0.1)
+    mask = None
+    if sparsity > 0:
+        margs = types.SimpleNamespace(device=str(device), fix=False, update_frequency=a.update_frequency, only_L=False,
+                                      sparse_init="uniform", sparsity=sparsity, distributed=distributed)
+        import contextlib, io
+        with contextlib.redirect_stdout(io.StringIO()):
+            mask = Masking(opt, None, CosineDecay(0.3, 300 * 1251), prune_rate=0.3, prune_mode="magnitude",
+                           growth_mode="gradient", redistribution_mode="none", args=margs)
+            mask.add_module(model)
+
+    g = torch.Generator(device=device).manual_seed(1234 + rank)
+    samples = torch.randn(a.batch, 3, 224, 224, device=device, generator=g)
+    targets = torch.randint(0, 1000, (a.batch,), device=device, generator=g)
+
+    def step():
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            loss = criterion(model(samples), targets)
+        loss.backward()
+        if mask is not None:
+            mask.step()                                           # engine.py:82-83
+        else:
+            opt.step()
+        opt.zero_grad(set_to_none=True)
+        return loss
+
+    model.train()
+    for _ in range(a.warmup):
+        loss = step()
+    if distributed:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        loss = step()
+    if distributed:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if distributed:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+    final_loss = float(loss.item())
+    ms_per_step = 1e3 * elapsed / a.steps
+    value = n_gpus * a.batch * a.steps / elapsed
+
+    out = {
+        "metric": "images/sec SLaK-T 51x51 224px bf16 train step", "value": value, "unit": "images/s",
+        "n_gpus": n_gpus, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_per_step,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": ("BASELINE configs[1]: SLaK-T 51x51 full model, bs=128, 224x224, bf16, sparsity off" if sparsity == 0 else
+                                "BASELINE configs[2]: SLaK-T 51x51, bs=128/GPU, 224x224, bf16, DDP over RCCL, Masking sparsity %.2f, prune-and-grow every %d steps" % (sparsity, a.update_frequency)),
+                   "global_batch": n_gpus * a.batch, "per_gpu_batch": a.batch, "parallelism": "dp%d" % n_gpus,
+                   "dwconv_dtype": "fp32" if a.fp32_dwconv else "bf16 in/out, fp32 accumulate", "optimizer": "AdamW(fused)",
+                   "sync_bn": True, "final_loss": final_loss},
+    }
+
+    if rank == 0 and not a.no_roofline:
+        ks = hot_path_kernels(device, a.batch, a.kernel_reps, torch.float32 if a.fp32_dwconv else torch.bfloat16)
+        for k in ks:
+            k["step_ms"] = k["ms"] * k["calls_per_step"]
+        dom = max(ks, key=lambda k: k["step_ms"])
+        hot_ms = sum(k["step_ms"] for k in ks)
+        hot_bytes = sum(k["alg_bytes"] * k["calls_per_step"] for k in ks)
+        out["roofline"] = {"bound": "hbm", "achieved": dom["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": dom["gbs"] / HBM_PEAK_GBS,
+                           "traffic": None, "kernel": "dwconv %s %s stage %d (N=%d)" % (dom["kernel"], dom["op"], dom["stage"], a.batch),
+                           "avg_launch_ms": dom["ms"], "alg_bytes_per_launch": dom["alg_bytes"],
+                           "valu_tflops_nominal": dom["gflop_nominal"] / dom["ms"]}
+        out["hot_path"] = {"dwconv_ms_per_step": hot_ms, "dwconv_alg_gb_per_step": hot_bytes / 1e9,
+                           "dwconv_gbs": hot_bytes / hot_ms / 1e6, "dwconv_frac_of_hbm_peak": hot_bytes / hot_ms / 1e6 / HBM_PEAK_GBS,
+                           "share_of_step": hot_ms / ms_per_step,
+                           "images_per_s_dwconv_only": a.batch / (hot_ms / 1e3),
+                           "kernels": [{k2: (round(v, 4) if isinstance(v, float) else v) for k2, v in k.items()} for k in ks]}
+    if rank == 0 and n_gpus == 1 and not a.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(min(os.cpu_count() or 1, 32))   # >32 threads only oversubscribes a 96-channel depthwise conv
+    if rank == 0:
+        print(json.dumps(out))
+    if distributed:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

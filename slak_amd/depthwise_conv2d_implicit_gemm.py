@@ -16,11 +16,19 @@ __all__ = ["DepthWiseConv2dImplicitGEMM"]
 
 
 def _make_function(cast_dtype, name):
+    # mirrors _DepthWiseConv2dImplicitGEMMFP32/FP16 (depthwise_conv2d_implicit_gemm.py:14-49).
+    # fp32: custom_fwd(cast_inputs=float32) exactly as the reference (:16) -- under autocast an fp32 activation
+    #       stays on the fp32 kernels.
+    # fp16/bf16: the activation already has the low-precision dtype (that is how this branch was chosen);
+    #       the fp32 master weight is deliberately NOT down-cast (the reference's cast_inputs=float16 rounds
+    #       it, :35): the HIP kernels read fp32 weights directly and the fp32 dw (backward_filter_fp16.cu:187)
+    #       reaches the fp32 parameter without a round trip through 16 bits.
+    fwd_deco = (torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32) if cast_dtype == torch.float32
+                else torch.amp.custom_fwd(device_type="cuda"))
+
     class _Fn(torch.autograd.Function):
-        # mirrors _DepthWiseConv2dImplicitGEMMFP32/FP16 (depthwise_conv2d_implicit_gemm.py:14-49):
-        # under autocast the inputs are cast to `cast_dtype` and autocast is disabled inside.
         @staticmethod
-        @torch.amp.custom_fwd(device_type="cuda", cast_inputs=cast_dtype)
+        @fwd_deco
         def forward(ctx, x, w):
             ctx.save_for_backward(x, w)
             return _extension.dwconv2d_forward(x.contiguous(), w.contiguous())

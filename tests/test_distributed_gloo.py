@@ -1,0 +1,99 @@
+"""world_size-2 gloo tests (CPU) of the N>1 logic: data-parallel sharding of the hot path and the
+one-broadcast mask synchronisation that replaces the reference's per-step, per-tensor broadcasts
+(sparse_core.py:404-407).  The arithmetic here is done by the oracle -- these tests pin the
+DISTRIBUTED LOGIC (what is sharded, what is reduced, what is broadcast), not the kernels."""
+import os
+import socket
+import types
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, fn, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        ret[rank] = fn(rank, world)
+    finally:
+        dist.destroy_process_group()
+
+
+def _run(fn, world=2):
+    mgr = mp.Manager(); ret = mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), fn, ret), nprocs=world, join=True)
+    return [ret[r] for r in range(world)]
+
+
+def _sync_masks(rank, world):
+    from slak_amd.sparse_core import Masking
+    args = types.SimpleNamespace(device="cpu", fix=False, update_frequency=None, only_L=False, sparse_init="uniform", sparsity=0.4, distributed=True)
+    mk = Masking(None, None, None, prune_mode="magnitude", growth_mode="gradient", redistribution_mode="none", args=args)
+    torch.manual_seed(100 + rank)                                  # per-rank RNG, as main.py:232
+    mk.masks = {"a": (torch.rand(7, 1, 51, 5) < 0.6).float(), "b": (torch.rand(33, 17) < 0.6).float()}
+    before = {k: v.clone() for k, v in mk.masks.items()}
+    mk.synchronism_masks()                                         # ONE coalesced broadcast from rank 0
+    after1 = {k: v.clone() for k, v in mk.masks.items()}
+    mk.masks["a"][0, 0, 0, 0] = 1 - mk.masks["a"][0, 0, 0, 0]      # later local edits are NOT overwritten:
+    mk.synchronism_masks()                                         # subsequent calls are free (no collective)
+    return dict(before={k: v.numpy() for k, v in before.items()}, after={k: v.numpy() for k, v in after1.items()},
+                edited=float(mk.masks["a"][0, 0, 0, 0]), synced=mk._synced_once)
+
+
+def test_mask_sync_is_one_broadcast_rank0_wins():
+    r0, r1 = _run(_sync_masks)
+    for k in ("a", "b"):
+        assert not np.array_equal(r0["before"][k], r1["before"][k])          # per-rank init differs
+        np.testing.assert_array_equal(r0["after"][k], r0["before"][k])       # rank 0 keeps its masks
+        np.testing.assert_array_equal(r1["after"][k], r0["before"][k])       # rank 1 adopts rank 0's
+    assert r0["synced"] and r1["synced"]
+    assert r1["edited"] == 1 - r0["before"]["a"][0, 0, 0, 0]                 # second call did not re-broadcast
+
+
+def _dp_wgrad(rank, world):
+    """bwd-filter is a sum over the batch: each rank's local dw, summed by the (DDP) all-reduce, equals the
+    full-batch dw; fwd / bwd-data shard trivially over n."""
+    import oracle
+    rng = np.random.default_rng(0)
+    N, C, H, W, kh, kw = 4, 3, 9, 9, 13, 5
+    x = rng.standard_normal((N, C, H, W)).astype(np.float32)
+    dy = rng.standard_normal((N, C, H, W)).astype(np.float32)
+    w = (rng.standard_normal((C, 1, kh, kw)) * 0.1).astype(np.float32)
+    sl = slice(rank * N // world, (rank + 1) * N // world)
+    dw_local = torch.from_numpy(oracle.dwconv2d_bwd_filter(dy[sl], x[sl], kh, kw))
+    dist.all_reduce(dw_local)                                      # what DDP's bucketed all-reduce does (sum; DDP then /world)
+    y_local = oracle.dwconv2d_fwd(x[sl], w)
+    return dict(dw=dw_local.numpy(), dw_full=oracle.dwconv2d_bwd_filter(dy, x, kh, kw), y_ok=np.allclose(y_local, oracle.dwconv2d_fwd(x, w)[sl]))
+
+
+def test_data_parallel_sharding_of_the_path():
+    r0, r1 = _run(_dp_wgrad)
+    np.testing.assert_allclose(r0["dw"], r0["dw_full"], rtol=1e-12, atol=1e-12)
+    np.testing.assert_array_equal(r0["dw"], r1["dw"])              # every rank ends with identical grads
+    assert r0["y_ok"] and r1["y_ok"]
+
+
+def _identical_masks_without_collectives(rank, world):
+    """After the one init broadcast, prune/regrow needs NO collective: identical (weights, all-reduced grads,
+    masks, rate) on every rank give identical masks.  (Oracle arithmetic; the HIP kernels implement the same
+    deterministic function -- tests/test_masking_gpu.py.)"""
+    import oracle
+    rng = np.random.default_rng(3)                                 # replicated state: same on every rank
+    w = {"t": rng.standard_normal((6, 1, 13, 5)).astype(np.float32)}
+    m = {"t": (rng.random((6, 1, 13, 5)) < 0.6).astype(np.float32)}
+    w["t"] *= m["t"]
+    g_local = torch.from_numpy(np.random.default_rng(10 + rank).standard_normal((6, 1, 13, 5)).astype(np.float32))
+    dist.all_reduce(g_local); g_local /= world                     # DDP-averaged gradient
+    _, nm, _ = oracle.truncate_weights(w, m, {"t": g_local.numpy()}, 0.3)
+    return nm["t"]
+
+
+def test_masks_agree_across_ranks_without_per_step_broadcast():
+    r0, r1 = _run(_identical_masks_without_collectives)
+    np.testing.assert_array_equal(r0, r1)
