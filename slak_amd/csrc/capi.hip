@@ -89,6 +89,9 @@ int slak_dwconv2d_forward(const void* x, int x_dtype, const void* w, int w_dtype
     int rc = check_conv_args(x, w, y, x_dtype, w_dtype, y_dtype, N, C, H, W, kh, kw);
     if (rc != SLAK_OK) return rc;
     ConvDims d{N, C, H, W, kh, kw};
+    if (g_conv_algo != SLAK_ALGO_DIRECT && dwconv_mfma_supported(d, x_dtype, w_dtype, y_dtype))
+        return launch_dwconv_mfma(x, x_dtype, w, w_dtype, y, y_dtype, d, /*flip=*/false, (hipStream_t)stream);
+    if (g_conv_algo == SLAK_ALGO_MFMA) return SLAK_ERR_UNSUPPORTED;
     return launch_dwconv_direct(x, x_dtype, w, w_dtype, y, y_dtype, d, /*flip=*/false, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
@@ -100,6 +103,9 @@ int slak_dwconv2d_backward_data(const void* dy, int dy_dtype, const void* w, int
     ConvDims d{N, C, H, W, kh, kw};
     // data-grad of a stride-1 "same" cross-correlation with odd kernels == cross-correlation of dy with
     // the filter rotated by 180 degrees (h + kh/2 - r == h - kh/2 + (kh-1-r)).
+    if (g_conv_algo != SLAK_ALGO_DIRECT && dwconv_mfma_supported(d, dy_dtype, w_dtype, dx_dtype))
+        return launch_dwconv_mfma(dy, dy_dtype, w, w_dtype, dx, dx_dtype, d, /*flip=*/true, (hipStream_t)stream);
+    if (g_conv_algo == SLAK_ALGO_MFMA) return SLAK_ERR_UNSUPPORTED;
     return launch_dwconv_direct(dy, dy_dtype, w, w_dtype, dx, dx_dtype, d, /*flip=*/true, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
