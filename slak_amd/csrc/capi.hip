@@ -79,7 +79,7 @@ size_t slak_dwconv2d_workspace_bytes(int op, int N, int C, int H, int W, int kh,
     if (N <= 0 || C <= 0 || H <= 0 || W <= 0 || kh <= 0 || kw <= 0) return 0;
     ConvDims d{N, C, H, W, kh, kw};
     if (op == 0 || op == 1) return dwconv_direct_workspace(d);
-    if (op == 2) return dwconv_wgrad_workspace(d);
+    if (op == 2) { size_t a = dwconv_wgrad_workspace(d), b = dwconv_mfma_wgrad_workspace(d); return a > b ? a : b; }
     return 0;
 }
 
@@ -115,6 +115,9 @@ int slak_dwconv2d_backward_filter(const void* dy, int dy_dtype, const void* x, i
     int rc = check_conv_args(dy, x, dw, dy_dtype, x_dtype, SLAK_F32, N, C, H, W, kh, kw);
     if (rc != SLAK_OK) return rc;
     ConvDims d{N, C, H, W, kh, kw};
+    if (g_conv_algo != SLAK_ALGO_DIRECT && dwconv_mfma_wgrad_supported(d, dy_dtype, x_dtype))
+        return launch_dwconv_mfma_wgrad(dy, dy_dtype, x, x_dtype, dw, d, workspace, workspace_bytes, (hipStream_t)stream);
+    if (g_conv_algo == SLAK_ALGO_MFMA) return SLAK_ERR_UNSUPPORTED;
     return launch_dwconv_wgrad(dy, dy_dtype, x, x_dtype, dw, d, workspace, workspace_bytes, (hipStream_t)stream);
 }
 

@@ -23,24 +23,9 @@
 //   * vertical kernels (Kx5): t = H -> B fragments come from ds_read_b64_tr_b16 (LDS transpose read).
 // Data-grad is the same kernel with the filter rotated by 180 degrees.  Weights are rounded to the
 // activation dtype for the MFMA (what autocast does to an nn.Conv2d weight); accumulation is fp32.
-#include "slak_common.h"
+#include "mfma_common.h"
 
 namespace slak {
-
-typedef __attribute__((ext_vector_type(8))) short s16x8;
-typedef __attribute__((ext_vector_type(4))) short s16x4;
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
-typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
-typedef __attribute__((ext_vector_type(16))) float f32x16;
-typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
-typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
-
-#define SLAK_LDS(T, p) ((__attribute__((address_space(3))) T*)(p))
-
-constexpr int MF_WAVES = 4;
-constexpr int MF_THREADS = MF_WAVES * 64;
-constexpr int MF_NCH = 4;              // staging chunks per thread per iteration (upper bound)
-constexpr int MF_TAPS = 5;             // short-axis taps the lane-shift epilogue is written for
 
 struct MfmaFwdParams {
     const void* x; const float* w; void* y;
@@ -56,50 +41,6 @@ struct MfmaFwdParams {
     int planes_per_wg, slices;
     int nchunks, cpp, cpr; // staging chunks per iteration / per plane / per row
 };
-
-__device__ __forceinline__ uint16_t cvt_to_bits(float v, bf16_t*) { return f32_to_bf16_bits(v); }
-__device__ __forceinline__ uint16_t cvt_to_bits(float v, f16_t*) { f16_t h = (f16_t)v; return __builtin_bit_cast(uint16_t, h); }
-
-template <typename T> __device__ __forceinline__ f32x16 mfma32(s16x8 a, s16x8 b, f32x16 c);
-template <> __device__ __forceinline__ f32x16 mfma32<bf16_t>(s16x8 a, s16x8 b, f32x16 c) {
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
-}
-template <> __device__ __forceinline__ f32x16 mfma32<f16_t>(s16x8 a, s16x8 b, f32x16 c) {
-    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
-}
-
-// lane i <- lane i-1 (0 shifted in) / lane i <- lane i+1
-__device__ __forceinline__ float wave_shr1(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138, 0xf, 0xf, false)); }
-__device__ __forceinline__ float wave_shl1(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130, 0xf, 0xf, false)); }
-
-template <int V> struct chunk_t;
-template <> struct chunk_t<8> { u32x4 v; };
-template <> struct chunk_t<4> { u32x2 v; };
-template <> struct chunk_t<2> { unsigned v; };
-template <> struct chunk_t<1> { uint16_t v; };
-
-template <int V> __device__ __forceinline__ chunk_t<V> chunk_zero() { chunk_t<V> c; c.v = {}; return c; }
-template <int V> __device__ __forceinline__ chunk_t<V> chunk_load(const uint16_t* p) {
-    chunk_t<V> c;
-    if constexpr (V == 8) c.v = *(const u32x4*)p;
-    else if constexpr (V == 4) c.v = *(const u32x2*)p;
-    else if constexpr (V == 2) c.v = *(const unsigned*)p;
-    else c.v = *p;
-    return c;
-}
-template <int V> __device__ __forceinline__ void chunk_store(uint16_t* p, const chunk_t<V>& c) {
-    if constexpr (V == 8) *(u32x4*)p = c.v;
-    else if constexpr (V == 4) *(u32x2*)p = c.v;
-    else if constexpr (V == 2) *(unsigned*)p = c.v;
-    else *p = c.v;
-}
-// LDS store of a chunk whose address is only 4-byte aligned (vertical kernels place planes at lane offset 2)
-template <int V> __device__ __forceinline__ void chunk_store_lds_a4(uint16_t* p, const chunk_t<V>& c) {
-    if constexpr (V == 8) { unsigned* q = (unsigned*)p; q[0] = c.v[0]; q[1] = c.v[1]; q[2] = c.v[2]; q[3] = c.v[3]; }
-    else if constexpr (V == 4) { unsigned* q = (unsigned*)p; q[0] = c.v[0]; q[1] = c.v[1]; }
-    else if constexpr (V == 2) *(unsigned*)p = c.v;
-    else *p = c.v;
-}
 
 // MT: 32-row tiles along the Toeplitz axis (wave w owns tile w % MT); KS: 16-deep k-steps (Wt <= 16*KS);
 // RPM: short taps packed per MFMA (32/RPM rows each); V: staging vector width (elements); VERT: long axis = H.
@@ -366,7 +307,7 @@ static int launch_mfma_fwd_shape(const MfmaFwdParams& p, const MfmaShape& s, boo
 }
 
 static int g_cu_count = 0;
-static int cu_count() {
+int mfma_cu_count() {
     if (g_cu_count == 0) {
         int dev = 0; hipDeviceProp_t prop;
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) g_cu_count = prop.multiProcessorCount;
@@ -391,7 +332,7 @@ int launch_dwconv_mfma(const void* x, int x_dt, const void* w, int w_dt, void* y
     const bool vert = d.kh > d.kw;
     MfmaShape s; MfmaFwdParams p;
     mfma_fwd_shape(d, vert, s);
-    fill_mfma_params(p, d, vert, s, cu_count());
+    fill_mfma_params(p, d, vert, s, mfma_cu_count());
     p.x = x; p.w = (const float*)w; p.y = y; p.flip = flip_filter ? 1 : 0;
     if (x_dt == SLAK_BF16) return launch_mfma_fwd_shape<bf16_t>(p, s, vert, st);
     return launch_mfma_fwd_shape<f16_t>(p, s, vert, st);

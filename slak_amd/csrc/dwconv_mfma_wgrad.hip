@@ -1,0 +1,306 @@
+// slak_amd/csrc/dwconv_mfma_wgrad.hip -- matrix-core (MFMA) depthwise-conv weight gradient for gfx950, 16-bit
+// activations, fp32 result.
+//
+// Replaces backward_filter_fp16 of the reference extension
+// (cutlass/examples/19_large_depthwise_conv2d_torch_extension/backward_filter_fp16.cu:181-243), which forms a
+// PQ x HW correlation matrix per channel with K = batch and atomically adds its diagonals into the taps
+// (cutlass/include/cutlass/epilogue/threadblock/dwconv2d_direct_epilogue_volta_tensor_op.h).  Here the correlation
+// is 1-D along the LONG axis only, one small matrix per short tap:
+//
+//   long axis t (extent Wt, KL taps, pad padL)     short axis l (extent Wl, 5 taps, pad 2)
+//   G_rho[o, i] = sum_{n, u} dy[o, u] * x[i, u + rho - 2]        (Wt x Wt, contraction over the short axis AND the batch)
+//   dw[tau, rho] = sum_o G_rho[o, o + tau - padL]                (diagonal sums, once per workgroup)
+//
+// The contraction index k runs over a STACK of staged planes separated by 2 zero positions, so the +-2 shift of x is
+// a plain address offset and k-steps straddle planes freely (no per-plane padding of K to 16).
+//   * horizontal kernels (5xK): k = rows  -> both operands via ds_read_b64_tr_b16 (x at row offset rho);
+//   * vertical kernels (Kx5):   k = cols  -> dy via aligned ds_read_b128, x via ds_read_b128 at a 2-byte-granular
+//     offset rho (misaligned LDS reads are legal on gfx950: tools/mfma_probe.hip).
+// Accumulators live in registers across the whole batch slice of the workgroup.  The diagonal reduction uses
+// per-wave private LDS arrays and a fixed summation order: no atomics, bitwise run-to-run reproducible; a second
+// tiny kernel (dwconv_wgrad_reduce) sums the batch slices in a fixed order.
+#include "mfma_common.h"
+
+namespace slak {
+
+struct MfmaWgradParams {
+    const void* dy; const void* x; float* partial;
+    int N, C, H, W, kh, kw;
+    int Wt, Wl, KL, padL;
+    int G;                 // planes staged per iteration
+    int NKS;               // 16-deep k-steps per iteration
+    int P;                 // LDS pitch (elements) of both stacks
+    int dy_elems, x_elems; // LDS elements of the two stacks (multiples of 8)
+    int planes_per_wg, slices;
+    int nchunks, cpp, cpr; // staging chunks per iteration / per plane / per row
+};
+
+// MT: 32-wide tiles along the long axis for both o and i (wave w owns (w & 1, w >> 1) when MT == 2; when MT == 1 the
+// four waves split the k-steps); RPN: short taps packed per 32 MFMA columns; V: staging vector width; VERT: long axis = H.
+template <typename T, int MT, int RPN, int V, bool VERT>
+__global__ __launch_bounds__(MF_THREADS, 2) void dwconv_mfma_wgrad_kernel(const MfmaWgradParams p) {
+    constexpr int NG = (MF_TAPS + RPN - 1) / RPN;
+    constexpr int NPAD = 32 / RPN;
+    extern __shared__ __attribute__((aligned(16))) uint16_t lds[];
+    uint16_t* dys = lds;
+    uint16_t* xs = lds + p.dy_elems;
+    float* dwl = (float*)(xs + p.x_elems);                  // [MF_WAVES][kh*kw]
+
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, lhi = lane >> 5;
+    const int wave = wave_id_uniform();
+    const int mt = (MT == 2) ? (wave & 1) : 0, nt = (MT == 2) ? (wave >> 1) : 0;
+    const int c = blockIdx.x % p.C, slice = blockIdx.x / p.C;
+    const int HW = p.H * p.W, ntap = p.kh * p.kw;
+    const uint16_t* __restrict__ gx = (const uint16_t*)p.x;
+    const uint16_t* __restrict__ gdy = (const uint16_t*)p.dy;
+
+    const int n_begin = slice * p.planes_per_wg;
+    int n_end = n_begin + p.planes_per_wg; if (n_end > p.N) n_end = p.N;
+    const int iters = (n_end > n_begin) ? (n_end - n_begin + p.G - 1) / p.G : 0;
+
+    // ---- per-thread staging map ---------------------------------------------------------------------
+    int goff[MF_NCH], loff[MF_NCH], jpl[MF_NCH];
+#pragma unroll
+    for (int k = 0; k < MF_NCH; ++k) {
+        const int idx = tid + k * MF_THREADS;
+        const bool ok = idx < p.nchunks;
+        const int j = ok ? idx / p.cpp : 0, rem = ok ? idx - j * p.cpp : 0;
+        const int h = rem / p.cpr, w0 = (rem - h * p.cpr) * V;
+        jpl[k] = ok ? j : -1;
+        goff[k] = j * p.C * HW + rem * V;
+        // k-position of (plane j, short-axis position): 2 + j*(Wl+2) + position
+        loff[k] = VERT ? (h * p.P + 2 + j * (p.Wl + 2) + w0) : ((2 + j * (p.Wl + 2) + h) * p.P + w0);
+    }
+    chunk_t<V> sx[MF_NCH], sd[MF_NCH];
+    auto prefetch = [&](int it) {
+        const int n0 = n_begin + it * p.G;
+        const size_t base = ((size_t)n0 * p.C + c) * HW;
+#pragma unroll
+        for (int k = 0; k < MF_NCH; ++k) {
+            if (jpl[k] >= 0 && n0 + jpl[k] < n_end) { sx[k] = chunk_load<V>(gx + base + goff[k]); sd[k] = chunk_load<V>(gdy + base + goff[k]); }
+            else { sx[k] = chunk_zero<V>(); sd[k] = chunk_zero<V>(); }
+        }
+    };
+    // the x stack carries 2 extra k-positions in front, so that "k + rho" (rho = 0..4) addresses x[k + rho - 2]
+    const int xshift = VERT ? 2 : 2 * p.P;
+    auto stage_write = [&]() {
+#pragma unroll
+        for (int k = 0; k < MF_NCH; ++k) {
+            if (jpl[k] >= 0) {
+                if constexpr (VERT) { chunk_store_lds_a4<V>(dys + loff[k], sd[k]); chunk_store_lds_a4<V>(xs + loff[k] + xshift, sx[k]); }
+                else { chunk_store<V>(dys + loff[k], sd[k]); chunk_store<V>(xs + loff[k] + xshift, sx[k]); }
+            }
+        }
+    };
+
+    if (iters > 0) prefetch(0);
+    {
+        u32x4* z = (u32x4*)lds;
+        const int n8 = (p.dy_elems + p.x_elems) / 8;
+        for (int i = tid; i < n8; i += MF_THREADS) z[i] = u32x4{0u, 0u, 0u, 0u};
+        for (int i = tid; i < MF_WAVES * ntap; i += MF_THREADS) dwl[i] = 0.f;
+    }
+    __syncthreads();
+    if (iters > 0) stage_write();
+    __syncthreads();
+
+    f32x16 acc[NG];
+#pragma unroll
+    for (int g = 0; g < NG; ++g)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[g][i] = 0.f;
+
+    // ---- per-lane fragment addresses (element offsets at k-step 0) -----------------------------------
+    const int grp = lane >> 4, i16 = lane & 15;
+    int a_off, b_off[NG];
+    if constexpr (!VERT) {
+        // tr-read: group grp reads a 4(k) x 16 block; lane supplies (k row = (grp>>1)*8 + (i16>>2), 4-col chunk i16&3)
+        const int krow = (grp >> 1) * 8 + (i16 >> 2);
+        a_off = krow * p.P + mt * 32 + (grp & 1) * 16 + (i16 & 3) * 4;
+        const int ncol = (grp & 1) * 16 + (i16 & 3) * 4;          // MFMA column of this lane's chunk
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            int rho = g * RPN + ncol / NPAD; if (rho > MF_TAPS - 1) rho = MF_TAPS - 1;
+            b_off[g] = (krow + rho) * p.P + nt * 32 + (ncol % NPAD);
+        }
+    } else {
+        a_off = (mt * 32 + l31) * p.P + lhi * 8;
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            int rho = g * RPN + l31 / NPAD; if (rho > MF_TAPS - 1) rho = MF_TAPS - 1;
+            b_off[g] = (nt * 32 + (l31 % NPAD)) * p.P + lhi * 8 + rho;
+        }
+    }
+    const int kstep_elems = VERT ? 16 : 16 * p.P;
+    const int ks_first = (MT == 2) ? 0 : wave, ks_stride = (MT == 2) ? 1 : MF_WAVES;
+
+    for (int it = 0; it < iters; ++it) {
+        if (it + 1 < iters) prefetch(it + 1);
+        for (int ks = ks_first; ks < p.NKS; ks += ks_stride) {
+            const uint16_t* ap = dys + a_off + ks * kstep_elems;
+            s16x8 a;
+            if constexpr (!VERT) {
+                s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(SLAK_LDS(s16x4, ap));
+                s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(SLAK_LDS(s16x4, ap + 4 * p.P));
+                a = s16x8{a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+            } else {
+                a = *(const s16x8*)ap;
+            }
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                const uint16_t* bp = xs + b_off[g] + ks * kstep_elems;
+                s16x8 b;
+                if constexpr (!VERT) {
+                    s16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(SLAK_LDS(s16x4, bp));
+                    s16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(SLAK_LDS(s16x4, bp + 4 * p.P));
+                    b = s16x8{b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+                } else {
+                    b = *(const s16x8_u*)bp;                          // 2-byte-granular address -> one ds_read_b128 (legal on gfx950)
+                }
+                acc[g] = mfma32<T>(a, b, acc[g]);
+            }
+        }
+        __syncthreads();
+        if (it + 1 < iters) stage_write();
+        __syncthreads();
+    }
+
+    // ---- diagonal sums: wave-private LDS arrays, the two lane halves in separate passes (distinct addresses per
+    //      instruction, in-order LDS ops per wave => deterministic) ---------------------------------------
+    float* mine = dwl + wave * ntap;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            const int rho = g * RPN + l31 / NPAD;
+            const int i = nt * 32 + (l31 % NPAD);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int o = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                const int tau = i - o + p.padL;
+                if (lhi == half && rho < MF_TAPS && o < p.Wt && i < p.Wt && tau >= 0 && tau < p.KL) {
+                    const int idx = VERT ? (tau * p.kw + rho) : (rho * p.kw + tau);
+                    mine[idx] += acc[g][r];
+                }
+            }
+        }
+    }
+    __syncthreads();
+    for (int t = tid; t < ntap; t += MF_THREADS) {
+        float s = dwl[t];
+#pragma unroll
+        for (int w = 1; w < MF_WAVES; ++w) s += dwl[w * ntap + t];
+        p.partial[((size_t)slice * p.C + c) * ntap + t] = s;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+struct WShape { int MT, RPN, V; };
+
+static bool mfma_wgrad_shape(const ConvDims& d, bool vert, WShape& s) {
+    const int Wt = vert ? d.H : d.W;
+    if ((vert ? d.kw : d.kh) != MF_TAPS) return false;
+    if (Wt > 64) return false;
+    if (Wt > 32) s = WShape{2, 1, 8};
+    else if (Wt > 16) s = WShape{1, 1, 4};
+    else if (Wt > 8) s = WShape{1, 2, 2};
+    else s = WShape{1, 4, 1};
+    return d.W % s.V == 0;
+}
+
+static bool fill_wgrad_params(MfmaWgradParams& p, const ConvDims& d, bool vert, const WShape& s, int cu_count) {
+    p.N = d.N; p.C = d.C; p.H = d.H; p.W = d.W; p.kh = d.kh; p.kw = d.kw;
+    p.Wt = vert ? d.H : d.W; p.Wl = vert ? d.W : d.H;
+    p.KL = vert ? d.kh : d.kw; p.padL = p.KL / 2;
+    const int HW = d.H * d.W;
+    p.cpr = d.W / s.V; p.cpp = HW / s.V;
+    // batch slices first: ~2 workgroups per CU
+    int slices = (2 * cu_count + d.C - 1) / d.C; if (slices < 1) slices = 1;
+    if (slices > d.N) slices = d.N;
+    int per = (d.N + slices - 1) / slices;
+    // planes per iteration: as many as the staging registers hold, not more than the slice
+    int G = (MF_NCH * MF_THREADS) / p.cpp; if (G < 1) return false;
+    if (G > per) G = per;
+    if (G > 24) G = 24;
+    p.G = G;
+    per = (per + G - 1) / G * G;
+    p.planes_per_wg = per; p.slices = (d.N + per - 1) / per;
+    p.nchunks = G * p.cpp;
+    const int K = 2 + G * (p.Wl + 2);
+    p.NKS = (K + 15) / 16;
+    const int Kp = p.NKS * 16;
+    if (vert) {
+        p.P = (Kp + 8 + 7) & ~7;                           // k along columns; +8: x reads run rho (<= 4) past the last k-step
+        if ((p.P / 8) % 2 == 0) p.P += 8;                  // P/8 odd: conflict-free aligned ds_read_b128 across rows
+        p.dy_elems = s.MT * 32 * p.P;
+        p.x_elems = s.MT * 32 * p.P;
+    } else {
+        p.P = s.MT * 32;                                   // k along rows
+        p.dy_elems = Kp * p.P;
+        p.x_elems = (Kp + 8) * p.P;                        // 2 rows in front + rho <= 4 behind
+    }
+    p.dy_elems = (p.dy_elems + 7) & ~7; p.x_elems = (p.x_elems + 7) & ~7;
+    return true;
+}
+
+static size_t mfma_wgrad_lds_bytes(const MfmaWgradParams& p) {
+    return (size_t)(p.dy_elems + p.x_elems) * 2 + (size_t)MF_WAVES * p.kh * p.kw * 4 + 16;
+}
+
+bool dwconv_mfma_wgrad_supported(const ConvDims& d, int dy_dt, int x_dt) {
+    if (dy_dt != x_dt || (x_dt != SLAK_BF16 && x_dt != SLAK_F16)) return false;
+    const bool vert = d.kh > d.kw;
+    WShape s; MfmaWgradParams p;
+    if (!mfma_wgrad_shape(d, vert, s)) return false;
+    if (!fill_wgrad_params(p, d, vert, s, 256)) return false;
+    return mfma_wgrad_lds_bytes(p) <= 72 * 1024;
+}
+
+size_t dwconv_mfma_wgrad_workspace(const ConvDims& d) {
+    // upper bound over any CU count: slices <= N
+    const bool vert = d.kh > d.kw;
+    WShape s; MfmaWgradParams p;
+    if (!mfma_wgrad_shape(d, vert, s) || !fill_wgrad_params(p, d, vert, s, mfma_cu_count())) return 0;
+    return align_up((size_t)p.slices * d.C * d.kh * d.kw * sizeof(float), 256);
+}
+
+template <typename T, int MT, int RPN, int V>
+static int launch_wgrad_t(const MfmaWgradParams& p, bool vert, hipStream_t st) {
+    const size_t lds = mfma_wgrad_lds_bytes(p);
+    dim3 grid((unsigned)(p.C * p.slices));
+    if (vert) {
+        auto k = dwconv_mfma_wgrad_kernel<T, MT, RPN, V, true>;
+        if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(k, grid, dim3(MF_THREADS), lds, st, p);
+    } else {
+        auto k = dwconv_mfma_wgrad_kernel<T, MT, RPN, V, false>;
+        if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(k, grid, dim3(MF_THREADS), lds, st, p);
+    }
+    SLAK_LAUNCH_CHECK();
+    return SLAK_OK;
+}
+
+template <typename T>
+static int launch_wgrad_shape(const MfmaWgradParams& p, const WShape& s, bool vert, hipStream_t st) {
+    if (s.MT == 2) return launch_wgrad_t<T, 2, 1, 8>(p, vert, st);
+    if (s.RPN == 1) return launch_wgrad_t<T, 1, 1, 4>(p, vert, st);
+    if (s.RPN == 2) return launch_wgrad_t<T, 1, 2, 2>(p, vert, st);
+    return launch_wgrad_t<T, 1, 4, 1>(p, vert, st);
+}
+
+int launch_dwconv_mfma_wgrad(const void* dy, int dy_dt, const void* x, int x_dt, float* dw,
+                             const ConvDims& d, void* ws, size_t ws_bytes, hipStream_t st) {
+    if (!dwconv_mfma_wgrad_supported(d, dy_dt, x_dt)) return SLAK_ERR_UNSUPPORTED;
+    const bool vert = d.kh > d.kw;
+    WShape s; MfmaWgradParams p;
+    mfma_wgrad_shape(d, vert, s);
+    fill_wgrad_params(p, d, vert, s, mfma_cu_count());
+    if (ws == nullptr || ws_bytes < dwconv_mfma_wgrad_workspace(d)) return SLAK_ERR_WORKSPACE;
+    p.dy = dy; p.x = x; p.partial = (float*)ws;
+    int rc = (x_dt == SLAK_BF16) ? launch_wgrad_shape<bf16_t>(p, s, vert, st) : launch_wgrad_shape<f16_t>(p, s, vert, st);
+    if (rc != SLAK_OK) return rc;
+    return launch_wgrad_reduce((const float*)ws, dw, d.C * d.kh * d.kw, p.slices, st);
+}
+
+}  // namespace slak

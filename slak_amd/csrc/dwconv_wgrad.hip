@@ -255,8 +255,11 @@ int launch_dwconv_wgrad(const void* dy, int dy_dt, const void* x, int x_dt, floa
         default: return SLAK_ERR_INVALID_ARG;
     }
     if (rc != SLAK_OK) return rc;
-    const int total = d.C * d.kh * d.kw;
-    hipLaunchKernelGGL(dwconv_wgrad_reduce, dim3(ceil_div(total, 256)), dim3(256), 0, st, (const float*)ws, dw, total, p.nslices);
+    return launch_wgrad_reduce((const float*)ws, dw, d.C * d.kh * d.kw, p.nslices, st);
+}
+
+int launch_wgrad_reduce(const float* partial, float* dw, int total, int nslices, hipStream_t st) {
+    hipLaunchKernelGGL(dwconv_wgrad_reduce, dim3(ceil_div(total, 256)), dim3(256), 0, st, partial, dw, total, nslices);
     SLAK_LAUNCH_CHECK();
     return SLAK_OK;
 }

@@ -63,5 +63,11 @@ int launch_dwconv_mfma(const void* x, int x_dt, const void* w, int w_dt, void* y
 int launch_dwconv_wgrad(const void* dy, int dy_dt, const void* x, int x_dt, float* dw,
                         const ConvDims& d, void* ws, size_t ws_bytes, hipStream_t st);
 size_t dwconv_wgrad_workspace(const ConvDims& d);
+int launch_wgrad_reduce(const float* partial, float* dw, int total, int nslices, hipStream_t st);
+
+bool dwconv_mfma_wgrad_supported(const ConvDims& d, int dy_dt, int x_dt);
+size_t dwconv_mfma_wgrad_workspace(const ConvDims& d);
+int launch_dwconv_mfma_wgrad(const void* dy, int dy_dt, const void* x, int x_dt, float* dw,
+                             const ConvDims& d, void* ws, size_t ws_bytes, hipStream_t st);
 
 }  // namespace slak

@@ -37,16 +37,28 @@ for dt in (torch.bfloat16, torch.float16):
             y = ops.dwconv2d_forward(x, w); dx = ops.dwconv2d_backward_data(x, w)
         except Exception as e:
             print("MFMA unsupported", (N, C, H, W, kh, kw), str(e)[:60]); L.slak_set_conv_algo(_lib.ALGO_AUTO); continue
+        dy = torch.randn(N, C, H, W, device=dev).to(dt)
+        dw = ops.dwconv2d_backward_filter(dy, x, w)
+        dw2 = ops.dwconv2d_backward_filter(dy, x, w)
+        L.slak_set_conv_algo(_lib.ALGO_DIRECT)
+        dwref = ops.dwconv2d_backward_filter(dy, x, w)
+        L.slak_set_conv_algo(_lib.ALGO_MFMA)
+        e3 = (dw - dwref).abs().max().item() / max(1.0, dwref.abs().max().item())
+        det = torch.equal(dw, dw2)
         e1 = (y.float() - ref).abs().max().item() / max(1.0, ref.abs().max().item())
         e2 = (dx.float() - refd).abs().max().item() / max(1.0, refd.abs().max().item())
         msg = "%s %-28s fwd relerr %.2e dgrad relerr %.2e" % (str(dt)[6:], (N, C, H, W, kh, kw), e1, e2)
-        if e1 > 6e-3 or e2 > 6e-3: bad += 1; msg += "  <<<<<< BAD"
+        msg += " wgrad relerr %.2e det %s" % (e3, det)
+        if e1 > 6e-3 or e2 > 6e-3 or e3 > 2e-4 or not det: bad += 1; msg += "  <<<<<< BAD"
         if do_time and N == 128 and dt == torch.bfloat16:
             tm = ev(lambda: ops.dwconv2d_forward(x, w))
             L.slak_set_conv_algo(_lib.ALGO_DIRECT)
             td = ev(lambda: ops.dwconv2d_forward(x, w))
             by = 2 * x.numel() * 2
-            msg += "  mfma %.1f us (%.0f GB/s)  direct %.1f us" % (tm, by / tm / 1e3, td)
+            tw_d = ev(lambda: ops.dwconv2d_backward_filter(dy, x, w))
+            L.slak_set_conv_algo(_lib.ALGO_MFMA)
+            tw_m = ev(lambda: ops.dwconv2d_backward_filter(dy, x, w))
+            msg += "  fwd mfma %.1f us (%.0f GB/s) direct %.1f | wgrad mfma %.1f us (%.0f GB/s) direct %.1f" % (tm, by / tm / 1e3, td, tw_m, by / tw_m / 1e3, tw_d)
         L.slak_set_conv_algo(_lib.ALGO_AUTO)
         print(msg, flush=True)
 print("BAD" if bad else "ALL OK", bad)
