@@ -1,6 +1,7 @@
 // slak_amd/csrc/capi.hip -- extern "C" entry points of libslak_hip.so (see include/slak_hip.h).
 // Argument validation lives here; the reference's extension validates almost nothing and exit()s on
 // failure (forward_fp32.cu:173-196).  Every function returns a status code instead.
+#include <stdlib.h>
 #include <mutex>
 #include <string>
 
@@ -10,6 +11,11 @@ namespace slak {
 static std::mutex g_err_mu;
 static std::string g_last_hip_error = "";
 static int g_conv_algo = SLAK_ALGO_AUTO;
+static bool use_dma() {                      // SLAK_MFMA_DMA=0 keeps the register-staged MFMA kernels (A/B testing)
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("SLAK_MFMA_DMA"); v = (e && e[0] == '0') ? 0 : 1; }
+    return v != 0;
+}
 
 void set_last_hip_error(hipError_t e) {
     std::lock_guard<std::mutex> lk(g_err_mu);
@@ -30,7 +36,12 @@ static int check_conv_args(const void* a, const void* b, const void* c, int dt0,
 
 using namespace slak;
 
+namespace slak { extern unsigned long long* g_dma_dbg; }
+
 extern "C" {
+
+/* dev hook (not in the public header): device buffer of 4x8 u64 that workgroup 0 of the DMA conv kernel fills with per-phase cycle counts */
+void slak_debug_set_phase_buffer(void* p) { slak::g_dma_dbg = (unsigned long long*)p; }
 
 const char* slak_status_string(int status) {
     switch (status) {
@@ -78,7 +89,7 @@ size_t slak_dwconv2d_workspace_bytes(int op, int N, int C, int H, int W, int kh,
     (void)dtype;
     if (N <= 0 || C <= 0 || H <= 0 || W <= 0 || kh <= 0 || kw <= 0) return 0;
     ConvDims d{N, C, H, W, kh, kw};
-    if (op == 0 || op == 1) return dwconv_direct_workspace(d);
+    if (op == 0 || op == 1) { size_t a = dwconv_direct_workspace(d), b = dwconv_mfma_workspace(d); return a > b ? a : b; }
     if (op == 2) { size_t a = dwconv_wgrad_workspace(d), b = dwconv_mfma_wgrad_workspace(d); return a > b ? a : b; }
     return 0;
 }
@@ -89,8 +100,10 @@ int slak_dwconv2d_forward(const void* x, int x_dtype, const void* w, int w_dtype
     int rc = check_conv_args(x, w, y, x_dtype, w_dtype, y_dtype, N, C, H, W, kh, kw);
     if (rc != SLAK_OK) return rc;
     ConvDims d{N, C, H, W, kh, kw};
+    if (g_conv_algo != SLAK_ALGO_DIRECT && use_dma() && dwconv_mfma_dma_supported(d, x_dtype, w_dtype, y_dtype))
+        return launch_dwconv_mfma_dma(x, x_dtype, w, w_dtype, y, y_dtype, d, /*flip=*/false, workspace, workspace_bytes, (hipStream_t)stream);
     if (g_conv_algo != SLAK_ALGO_DIRECT && dwconv_mfma_supported(d, x_dtype, w_dtype, y_dtype))
-        return launch_dwconv_mfma(x, x_dtype, w, w_dtype, y, y_dtype, d, /*flip=*/false, (hipStream_t)stream);
+        return launch_dwconv_mfma(x, x_dtype, w, w_dtype, y, y_dtype, d, /*flip=*/false, workspace, workspace_bytes, (hipStream_t)stream);
     if (g_conv_algo == SLAK_ALGO_MFMA) return SLAK_ERR_UNSUPPORTED;
     return launch_dwconv_direct(x, x_dtype, w, w_dtype, y, y_dtype, d, /*flip=*/false, workspace, workspace_bytes, (hipStream_t)stream);
 }
@@ -103,8 +116,10 @@ int slak_dwconv2d_backward_data(const void* dy, int dy_dtype, const void* w, int
     ConvDims d{N, C, H, W, kh, kw};
     // data-grad of a stride-1 "same" cross-correlation with odd kernels == cross-correlation of dy with
     // the filter rotated by 180 degrees (h + kh/2 - r == h - kh/2 + (kh-1-r)).
+    if (g_conv_algo != SLAK_ALGO_DIRECT && use_dma() && dwconv_mfma_dma_supported(d, dy_dtype, w_dtype, dx_dtype))
+        return launch_dwconv_mfma_dma(dy, dy_dtype, w, w_dtype, dx, dx_dtype, d, /*flip=*/true, workspace, workspace_bytes, (hipStream_t)stream);
     if (g_conv_algo != SLAK_ALGO_DIRECT && dwconv_mfma_supported(d, dy_dtype, w_dtype, dx_dtype))
-        return launch_dwconv_mfma(dy, dy_dtype, w, w_dtype, dx, dx_dtype, d, /*flip=*/true, (hipStream_t)stream);
+        return launch_dwconv_mfma(dy, dy_dtype, w, w_dtype, dx, dx_dtype, d, /*flip=*/true, workspace, workspace_bytes, (hipStream_t)stream);
     if (g_conv_algo == SLAK_ALGO_MFMA) return SLAK_ERR_UNSUPPORTED;
     return launch_dwconv_direct(dy, dy_dtype, w, w_dtype, dx, dx_dtype, d, /*flip=*/true, workspace, workspace_bytes, (hipStream_t)stream);
 }

@@ -28,7 +28,7 @@
 namespace slak {
 
 struct MfmaFwdParams {
-    const void* x; const float* w; void* y;
+    const void* x; const uint16_t* frags; void* y;
     int N, C, H, W, kh, kw, flip;
     int Wt, Wl, KL, padL;
     int G;                 // planes staged per iteration
@@ -42,6 +42,40 @@ struct MfmaFwdParams {
     int nchunks, cpp, cpr; // staging chunks per iteration / per plane / per row
 };
 
+__global__ void toeplitz_pack_kernel(const ToeplitzPackParams p) {
+    const int total = p.C * p.MT * p.NG * p.KS * 64;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int lane = idx & 63;
+    int f = idx >> 6;
+    const int ks = f % p.KS; f /= p.KS;
+    const int g = f % p.NG; f /= p.NG;
+    const int mt = f % p.MT; const int c = f / p.MT;
+    const int MPAD = 32 / p.RPM, l31 = lane & 31, lhi = lane >> 5;
+    const int r = g * p.RPM + l31 / MPAD, o_abs = mt * 32 + (l31 % MPAD);
+    const float* wc = p.w + (size_t)c * p.kh * p.kw;
+    u32x4 out;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int i_abs = ks * 16 + lhi * 8 + e;
+        int t = i_abs - o_abs + p.padL;
+        float v = 0.f;
+        if (r < MF_TAPS && o_abs < p.Wt && i_abs < p.Wt && t >= 0 && t < p.KL) {
+            int rr = r;
+            if (p.flip) { t = p.KL - 1 - t; rr = MF_TAPS - 1 - r; }
+            v = p.vert ? wc[t * p.kw + rr] : wc[rr * p.kw + t];
+        }
+        const unsigned bits = p.is_bf16 ? cvt_to_bits(v, (bf16_t*)nullptr) : cvt_to_bits(v, (f16_t*)nullptr);
+        if (e & 1) out[e >> 1] |= bits << 16; else out[e >> 1] = bits;
+    }
+    ((u32x4*)p.frags)[idx] = out;
+}
+
+void launch_toeplitz_pack(const ToeplitzPackParams& p, hipStream_t st) {
+    const int total = p.C * p.MT * p.NG * p.KS * 64;
+    hipLaunchKernelGGL(toeplitz_pack_kernel, dim3((total + 255) / 256), dim3(256), 0, st, p);
+}
+
 // MT: 32-row tiles along the Toeplitz axis (wave w owns tile w % MT); KS: 16-deep k-steps (Wt <= 16*KS);
 // RPM: short taps packed per MFMA (32/RPM rows each); V: staging vector width (elements); VERT: long axis = H.
 template <typename T, int MT, int KS, int RPM, int V, bool VERT>
@@ -53,7 +87,6 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dwconv_mfma_fwd_kernel(const Mf
     extern __shared__ __attribute__((aligned(16))) uint16_t lds[];
     uint16_t* lin = lds;                                    // staged stack
     uint16_t* lout = lds + p.in_elems;                      // [G][HWp] results
-    float* lw = (float*)(lout + p.G * p.HWp);               // kh*kw weights of this channel
 
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, lhi = lane >> 5;
     const int wave = wave_id_uniform();
@@ -107,8 +140,6 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dwconv_mfma_fwd_kernel(const Mf
     {
         u32x4* z = (u32x4*)lin;
         for (int i = tid; i < p.in_elems / 8; i += MF_THREADS) z[i] = u32x4{0u, 0u, 0u, 0u};
-        const int ntap = p.kh * p.kw;
-        for (int i = tid; i < ntap; i += MF_THREADS) lw[i] = p.w[(size_t)c * ntap + i];
     }
     __syncthreads();
     stage_write();
@@ -117,33 +148,7 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dwconv_mfma_fwd_kernel(const Mf
     //      k = ks*16 + lhi*8 + e -> i, the weight w[r][i - o + padL] (0 outside the filter or the plane) ----
     s16x8 afrag[NG][KS];
     bool ks_active[KS];
-    {
-        const int rsel = l31 / MPAD, o_abs = mt * 32 + (l31 % MPAD);
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            // block (mt, ks) touches the band |i - o| <= padL ?  (wave-uniform)
-            const int i_lo = ks * 16, i_hi = ks * 16 + 15, o_lo = mt * 32, o_hi = mt * 32 + MPAD - 1;
-            ks_active[ks] = (i_lo < p.Wt) && (o_lo < p.Wt) && (i_lo - o_hi <= p.KL - 1 - p.padL) && (o_lo - i_hi <= p.padL);
-#pragma unroll
-            for (int g = 0; g < NG; ++g) {
-                const int r = g * RPM + rsel;
-                s16x8 a;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const int i_abs = ks * 16 + lhi * 8 + e;
-                    int t = i_abs - o_abs + p.padL;
-                    float v = 0.f;
-                    if (r < MF_TAPS && o_abs < p.Wt && i_abs < p.Wt && t >= 0 && t < p.KL) {
-                        int rr = r;
-                        if (p.flip) { t = p.KL - 1 - t; rr = MF_TAPS - 1 - r; }
-                        v = VERT ? lw[t * p.kw + rr] : lw[rr * p.kw + t];
-                    }
-                    a[e] = (short)cvt_to_bits(v, (T*)nullptr);
-                }
-                afrag[g][ks] = a;
-            }
-        }
-    }
+    load_toeplitz_frags<NG, KS>(afrag, ks_active, p.frags, c, MT, mt, lane, MPAD, p.Wt, p.KL, p.padL);
     __syncthreads();
 
     for (int it = 0; it < iters; ++it) {
@@ -271,14 +276,14 @@ static bool fill_mfma_params(MfmaFwdParams& p, const ConvDims& d, bool vert, con
     p.cpr = d.W / s.V; p.cpp = HW / s.V; p.nchunks = p.G * p.cpp;
     if (p.nchunks > MF_NCH * MF_THREADS) return false;
     // batch slices: ~2 workgroups per CU, each a multiple of G planes
-    int slices = (2 * cu_count + d.C - 1) / d.C; if (slices < 1) slices = 1;
+    int slices = (2 * cu_count) / d.C; if (slices < 1) slices = 1;   // one resident round: never more workgroups than 2 per CU
     int per = (d.N + slices - 1) / slices; per = (per + p.G - 1) / p.G * p.G; if (per < p.G) per = p.G;
     p.planes_per_wg = per; p.slices = (d.N + per - 1) / per;
     return true;
 }
 
 static size_t mfma_fwd_lds_bytes(const MfmaFwdParams& p) {
-    return (size_t)p.in_elems * 2 + (size_t)p.G * p.HWp * 2 + (size_t)p.kh * p.kw * 4 + 16;
+    return (size_t)p.in_elems * 2 + (size_t)p.G * p.HWp * 2 + 16;
 }
 
 template <typename T, int MT, int KS, int RPM, int V>
@@ -326,14 +331,26 @@ bool dwconv_mfma_supported(const ConvDims& d, int x_dt, int w_dt, int y_dt) {
     return mfma_fwd_lds_bytes(p) <= 64 * 1024;
 }
 
+size_t dwconv_mfma_workspace(const ConvDims& d) {
+    const bool vert = d.kh > d.kw;
+    MfmaShape s;
+    if (!mfma_fwd_shape(d, vert, s)) return 0;
+    return align_up(toeplitz_pack_bytes(d.C, s.MT, (MF_TAPS + s.RPM - 1) / s.RPM, s.KS), 256);
+}
+
 int launch_dwconv_mfma(const void* x, int x_dt, const void* w, int w_dt, void* y, int y_dt,
-                       const ConvDims& d, bool flip_filter, hipStream_t st) {
+                       const ConvDims& d, bool flip_filter, void* ws, size_t ws_bytes, hipStream_t st) {
     if (!dwconv_mfma_supported(d, x_dt, w_dt, y_dt)) return SLAK_ERR_UNSUPPORTED;
+    if (ws == nullptr || ws_bytes < dwconv_mfma_workspace(d)) return SLAK_ERR_WORKSPACE;
     const bool vert = d.kh > d.kw;
     MfmaShape s; MfmaFwdParams p;
     mfma_fwd_shape(d, vert, s);
     fill_mfma_params(p, d, vert, s, mfma_cu_count());
-    p.x = x; p.w = (const float*)w; p.y = y; p.flip = flip_filter ? 1 : 0;
+    ToeplitzPackParams tp{(const float*)w, (uint16_t*)ws, d.C, d.kh, d.kw, s.MT, (MF_TAPS + s.RPM - 1) / s.RPM, s.KS, s.RPM,
+                          vert ? 1 : 0, flip_filter ? 1 : 0, p.Wt, p.KL, p.padL, x_dt == SLAK_BF16 ? 1 : 0};
+    launch_toeplitz_pack(tp, st);
+    SLAK_LAUNCH_CHECK();
+    p.x = x; p.frags = (const uint16_t*)ws; p.y = y; p.flip = flip_filter ? 1 : 0;
     if (x_dt == SLAK_BF16) return launch_mfma_fwd_shape<bf16_t>(p, s, vert, st);
     return launch_mfma_fwd_shape<f16_t>(p, s, vert, st);
 }

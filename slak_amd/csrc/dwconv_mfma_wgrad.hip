@@ -23,6 +23,8 @@
 
 namespace slak {
 
+extern unsigned long long* g_dma_dbg;
+
 struct MfmaWgradParams {
     const void* dy; const void* x; float* partial;
     int N, C, H, W, kh, kw;
@@ -33,6 +35,7 @@ struct MfmaWgradParams {
     int dy_elems, x_elems; // LDS elements of the two stacks (multiples of 8)
     int planes_per_wg, slices;
     int nchunks, cpp, cpr; // staging chunks per iteration / per plane / per row
+    unsigned long long* dbg;
 };
 
 // MT: 32-wide tiles along the long axis for both o and i (wave w owns (w & 1, w >> 1) when MT == 2; when MT == 1 the
@@ -44,7 +47,8 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dwconv_mfma_wgrad_kernel(const 
     extern __shared__ __attribute__((aligned(16))) uint16_t lds[];
     uint16_t* dys = lds;
     uint16_t* xs = lds + p.dy_elems;
-    float* dwl = (float*)(xs + p.x_elems);                  // [MF_WAVES][kh*kw]
+    const int stack_elems = (p.dy_elems + p.x_elems) > MF_WAVES * 32 * 33 * 2 ? (p.dy_elems + p.x_elems) : MF_WAVES * 32 * 33 * 2;
+    float* dwl = (float*)(lds + stack_elems);               // [MF_WAVES][kh*kw]
 
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, lhi = lane >> 5;
     const int wave = wave_id_uniform();
@@ -93,6 +97,8 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dwconv_mfma_wgrad_kernel(const 
         }
     };
 
+    const bool prof = p.dbg != nullptr && blockIdx.x == 0 && threadIdx.x == 0;
+    unsigned long long t0 = __builtin_readcyclecounter(), t1 = 0, t2 = 0, t3 = 0, t4 = 0;
     if (iters > 0) prefetch(0);
     {
         u32x4* z = (u32x4*)lds;
@@ -104,6 +110,7 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dwconv_mfma_wgrad_kernel(const 
     if (iters > 0) stage_write();
     __syncthreads();
 
+    t1 = __builtin_readcyclecounter();
     f32x16 acc[NG];
 #pragma unroll
     for (int g = 0; g < NG; ++g)
@@ -165,26 +172,42 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dwconv_mfma_wgrad_kernel(const 
         __syncthreads();
     }
 
-    // ---- diagonal sums: wave-private LDS arrays, the two lane halves in separate passes (distinct addresses per
-    //      instruction, in-order LDS ops per wave => deterministic) ---------------------------------------
+    // ---- diagonal sums.  Each wave dumps one accumulator tile at a time into a private 32x33 fp32 LDS scratch (aliased over
+    //      the stacks, which are dead now) and lane (rho_sel, dd) adds up the diagonal i - o = dd - (NPAD-1) with plain
+    //      loads in a fixed order: no atomics, bitwise reproducible.  Each (rho, tau) is produced by exactly one lane. ----
+    t2 = __builtin_readcyclecounter();
+    __syncthreads();                                          // every wave is done reading the stacks
     float* mine = dwl + wave * ntap;
+    float* tile = (float*)lds + wave * (32 * 33);
+    constexpr int ND = 2 * NPAD - 1;                          // diagonals per tap sub-block
+    constexpr int OROWS = (RPN == 1) ? 32 : NPAD;             // rows that can be non-zero (Wt <= NPAD when taps are packed)
+    const int rsel = lane / ND, dd = lane - rsel * ND;
 #pragma unroll
-    for (int half = 0; half < 2; ++half) {
+    for (int g = 0; g < NG; ++g) {
 #pragma unroll
-        for (int g = 0; g < NG; ++g) {
-            const int rho = g * RPN + l31 / NPAD;
-            const int i = nt * 32 + (l31 % NPAD);
+        for (int r = 0; r < 16; ++r) tile[((r & 3) + 8 * (r >> 2) + 4 * lhi) * 33 + l31] = acc[g][r];
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        float ssum = 0.f;
+        if (rsel < RPN) {
+            // unconditional loads (clamped address, masked value) so that all OROWS loads are in flight together
+            float part[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int o = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-                const int tau = i - o + p.padL;
-                if (lhi == half && rho < MF_TAPS && o < p.Wt && i < p.Wt && tau >= 0 && tau < p.KL) {
-                    const int idx = VERT ? (tau * p.kw + rho) : (rho * p.kw + tau);
-                    mine[idx] += acc[g][r];
-                }
+            for (int o = 0; o < OROWS; ++o) {
+                const int il = o + dd - (NPAD - 1);
+                const bool ok = il >= 0 && il < NPAD && mt * 32 + o < p.Wt && nt * 32 + il < p.Wt;
+                const float v = tile[o * 33 + rsel * NPAD + (ok ? il : 0)];
+                part[o & 3] += ok ? v : 0.f;
             }
+            ssum = (part[0] + part[1]) + (part[2] + part[3]);
+            const int rho = g * RPN + rsel;
+            const int tau = dd - (NPAD - 1) + (nt - mt) * 32 + p.padL;
+            if (rho < MF_TAPS && tau >= 0 && tau < p.KL) mine[VERT ? (tau * p.kw + rho) : (rho * p.kw + tau)] = ssum;
         }
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
+    t3 = __builtin_readcyclecounter();
     __syncthreads();
     for (int t = tid; t < ntap; t += MF_THREADS) {
         float s = dwl[t];
@@ -192,6 +215,8 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dwconv_mfma_wgrad_kernel(const 
         for (int w = 1; w < MF_WAVES; ++w) s += dwl[w * ntap + t];
         p.partial[((size_t)slice * p.C + c) * ntap + t] = s;
     }
+    t4 = __builtin_readcyclecounter();
+    if (prof) { p.dbg[0] = t1 - t0; p.dbg[1] = t2 - t1; p.dbg[2] = t3 - t2; p.dbg[3] = t4 - t3; p.dbg[4] = iters; }
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -215,7 +240,7 @@ static bool fill_wgrad_params(MfmaWgradParams& p, const ConvDims& d, bool vert, 
     const int HW = d.H * d.W;
     p.cpr = d.W / s.V; p.cpp = HW / s.V;
     // batch slices first: ~2 workgroups per CU
-    int slices = (2 * cu_count + d.C - 1) / d.C; if (slices < 1) slices = 1;
+    int slices = (2 * cu_count) / d.C; if (slices < 1) slices = 1;    // one resident round (2 workgroups per CU)
     if (slices > d.N) slices = d.N;
     int per = (d.N + slices - 1) / slices;
     // planes per iteration: as many as the staging registers hold, not more than the slice
@@ -244,7 +269,8 @@ static bool fill_wgrad_params(MfmaWgradParams& p, const ConvDims& d, bool vert, 
 }
 
 static size_t mfma_wgrad_lds_bytes(const MfmaWgradParams& p) {
-    return (size_t)(p.dy_elems + p.x_elems) * 2 + (size_t)MF_WAVES * p.kh * p.kw * 4 + 16;
+    size_t stacks = (size_t)(p.dy_elems + p.x_elems) * 2, scratch = (size_t)MF_WAVES * 32 * 33 * 4;
+    return (stacks > scratch ? stacks : scratch) + (size_t)MF_WAVES * p.kh * p.kw * 4 + 16;
 }
 
 bool dwconv_mfma_wgrad_supported(const ConvDims& d, int dy_dt, int x_dt) {
@@ -297,7 +323,7 @@ int launch_dwconv_mfma_wgrad(const void* dy, int dy_dt, const void* x, int x_dt,
     mfma_wgrad_shape(d, vert, s);
     fill_wgrad_params(p, d, vert, s, mfma_cu_count());
     if (ws == nullptr || ws_bytes < dwconv_mfma_wgrad_workspace(d)) return SLAK_ERR_WORKSPACE;
-    p.dy = dy; p.x = x; p.partial = (float*)ws;
+    p.dy = dy; p.x = x; p.partial = (float*)ws; p.dbg = g_dma_dbg;
     int rc = (x_dt == SLAK_BF16) ? launch_wgrad_shape<bf16_t>(p, s, vert, st) : launch_wgrad_shape<f16_t>(p, s, vert, st);
     if (rc != SLAK_OK) return rc;
     return launch_wgrad_reduce((const float*)ws, dw, d.C * d.kh * d.kw, p.slices, st);

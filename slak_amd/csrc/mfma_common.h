@@ -34,6 +34,18 @@ template <> __device__ __forceinline__ f32x16 mfma32<f16_t>(s16x8 a, s16x8 b, f3
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
 }
 
+// two fp32 -> packed pair of T (round-to-nearest-even; bf16 via v_cvt_pk_bf16_f32), low half = a
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_t;
+template <typename T> __device__ __forceinline__ unsigned pack2(float a, float b);
+template <> __device__ __forceinline__ unsigned pack2<bf16_t>(float a, float b) {
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_t{a, b}, bf16x2_t));
+}
+template <> __device__ __forceinline__ unsigned pack2<f16_t>(float a, float b) {
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_t{a, b}, f16x2_t));
+}
+
 // lane i <- lane i-1 (0 shifted in) / lane i <- lane i+1
 __device__ __forceinline__ float wave_shr1(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138, 0xf, 0xf, false)); }
 __device__ __forceinline__ float wave_shl1(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130, 0xf, 0xf, false)); }
@@ -67,6 +79,33 @@ template <int V> __device__ __forceinline__ void chunk_store_lds_a4(uint16_t* p,
     else *p = c.v;
 }
 
+
+// Toeplitz fragments.  A[g][ks] holds, for MFMA row m = lane&31 -> (tap r = g*RPM + m/MPAD, o = mt*32 + m%MPAD) and
+// k = ks*16 + (lane>>5)*8 + e -> i, the weight w[r][i - o + padL] (0 outside the filter or the plane), rounded to the
+// activation dtype.  They are the same for every workgroup of a channel, so a tiny pre-kernel (toeplitz_pack_kernel) writes
+// them to the workspace in register layout -- frag[((c*MT + mt)*NG + g)*KS + ks][lane][8] -- and the conv kernels fetch
+// their NG*KS fragments with one 16-byte load each (building them in the conv kernel cost ~40 us per workgroup).
+struct ToeplitzPackParams {
+    const float* w; uint16_t* frags;
+    int C, kh, kw, MT, NG, KS, RPM, vert, flip, Wt, KL, padL, is_bf16;
+};
+void launch_toeplitz_pack(const ToeplitzPackParams& p, hipStream_t st);
+static inline size_t toeplitz_pack_bytes(int C, int MT, int NG, int KS) { return (size_t)C * MT * NG * KS * 64 * 8 * 2; }
+
+template <int NG, int KS>
+__device__ __forceinline__ void load_toeplitz_frags(s16x8 (&afrag)[NG][KS], bool (&ks_active)[KS], const uint16_t* frags,
+                                                    int c, int MT, int mt, int lane, int MPAD, int Wt, int KL, int padL) {
+    const s16x8* base = (const s16x8*)frags + ((size_t)(c * MT + mt) * NG * KS) * 64 + lane;
+#pragma unroll
+    for (int g = 0; g < NG; ++g)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) afrag[g][ks] = base[(g * KS + ks) * 64];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {        // block (mt, ks) intersects the band |i - o| <= padL ?  (wave-uniform)
+        const int i_lo = ks * 16, i_hi = ks * 16 + 15, o_lo = mt * 32, o_hi = mt * 32 + MPAD - 1;
+        ks_active[ks] = (i_lo < Wt) && (o_lo < Wt) && (i_lo - o_hi <= KL - 1 - padL) && (o_lo - i_hi <= padL);
+    }
+}
 
 int mfma_cu_count();
 
