@@ -54,20 +54,23 @@ __global__ void toeplitz_pack_kernel(const ToeplitzPackParams p) {
     const int MPAD = 32 / p.RPM, l31 = lane & 31, lhi = lane >> 5;
     const int r = g * p.RPM + l31 / MPAD, o_abs = mt * 32 + (l31 % MPAD);
     const float* wc = p.w + (size_t)c * p.kh * p.kw;
-    u32x4 out;
+    // all 8 loads are issued unconditionally (clamped index) and masked afterwards, so they overlap
+    float v[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
         const int i_abs = ks * 16 + lhi * 8 + e;
         int t = i_abs - o_abs + p.padL;
-        float v = 0.f;
-        if (r < MF_TAPS && o_abs < p.Wt && i_abs < p.Wt && t >= 0 && t < p.KL) {
-            int rr = r;
-            if (p.flip) { t = p.KL - 1 - t; rr = MF_TAPS - 1 - r; }
-            v = p.vert ? wc[t * p.kw + rr] : wc[rr * p.kw + t];
-        }
-        const unsigned bits = p.is_bf16 ? cvt_to_bits(v, (bf16_t*)nullptr) : cvt_to_bits(v, (f16_t*)nullptr);
-        if (e & 1) out[e >> 1] |= bits << 16; else out[e >> 1] = bits;
+        const bool ok = r < MF_TAPS && o_abs < p.Wt && i_abs < p.Wt && t >= 0 && t < p.KL;
+        int rr = r < MF_TAPS ? r : 0;
+        t = ok ? t : 0;
+        if (p.flip) { t = p.KL - 1 - t; rr = MF_TAPS - 1 - rr; }
+        const float wv = p.vert ? wc[t * p.kw + rr] : wc[rr * p.kw + t];
+        v[e] = ok ? wv : 0.f;
     }
+    u32x4 out;
+#pragma unroll
+    for (int e = 0; e < 8; e += 2)
+        out[e >> 1] = p.is_bf16 ? pack2<bf16_t>(v[e], v[e + 1]) : pack2<f16_t>(v[e], v[e + 1]);
     ((u32x4*)p.frags)[idx] = out;
 }
 

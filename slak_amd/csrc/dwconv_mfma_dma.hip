@@ -74,7 +74,8 @@ constexpr int DMA_NTR = 4;              // transpose blocks (4 rows x 16 cols) p
 
 // MT: 32-row tiles along the Toeplitz axis (wave w owns tile w % MT); KS: 16-deep k-steps; VERT: long axis = H;
 // BAND: the filter is much shorter than the map (5x5 branch) -> skip all-zero Toeplitz blocks (wave-uniform branches).
-template <typename T, int MT, int KS, bool VERT, bool BAND>
+// R16: image rows are 16-byte aligned (W % 8 == 0); otherwise B fragments are read as two 8-byte halves.
+template <typename T, int MT, int KS, bool VERT, bool BAND, bool R16>
 __global__ __launch_bounds__(MF_THREADS, 3) void dwconv_mfma_dma_kernel(const MfmaDmaParams p) {
     constexpr int NG = MF_TAPS;
     constexpr int WL = MF_WAVES / MT;
@@ -216,7 +217,12 @@ __global__ __launch_bounds__(MF_THREADS, 3) void dwconv_mfma_dma_kernel(const Mf
                 rp[r] = pim + (inb[r] ? row : 0) * pitch + lhi * 8;
             }
             auto load_b = [&](int r, int ks) -> s16x8 {
-                u32x4 b = __builtin_bit_cast(u32x4, *(const s16x8_u*)(rp[r] + ks * 16));
+                u32x4 b;
+                if constexpr (VERT || R16) b = *(const u32x4*)(rp[r] + ks * 16);            // 16-byte aligned rows
+                else {                                                                    // W % 8 == 4: rows are 8-byte aligned
+                    const u32x2 lo = *(const u32x2*)(rp[r] + ks * 16), hi = *(const u32x2*)(rp[r] + ks * 16 + 4);
+                    b = u32x4{lo[0], lo[1], hi[0], hi[1]};
+                }
                 const int k0 = ks * 16 + lhi * 8;
                 const bool lo_ok = inb[r] && (VERT || k0 < p.Wt), hi_ok = inb[r] && (VERT || k0 + 4 < p.Wt);
                 b[0] = lo_ok ? b[0] : 0u; b[1] = lo_ok ? b[1] : 0u; b[2] = hi_ok ? b[2] : 0u; b[3] = hi_ok ? b[3] : 0u;
@@ -365,9 +371,9 @@ static int resident_workgroups(K kernel, size_t lds) {          // workgroups th
     return per_cu * mfma_cu_count();
 }
 
-template <typename T, int MT, int KS, bool VERT, bool BAND>
+template <typename T, int MT, int KS, bool VERT, bool BAND, bool R16>
 static int launch_dma_tv(MfmaDmaParams& p, const ConvDims& d, hipStream_t st) {
-    auto k = dwconv_mfma_dma_kernel<T, MT, KS, VERT, BAND>;
+    auto k = dwconv_mfma_dma_kernel<T, MT, KS, VERT, BAND, R16>;
     fill_dma_params(p, d, VERT, MT, KS, 512);
     const size_t lds = dma_lds_bytes(p, VERT);                   // does not depend on the slice count
     static int resident = 0;                                      // per instantiation; LDS size varies little within a class
@@ -381,8 +387,9 @@ static int launch_dma_tv(MfmaDmaParams& p, const ConvDims& d, hipStream_t st) {
 
 template <typename T, int MT, int KS>
 static int launch_dma_t(MfmaDmaParams& p, const ConvDims& d, bool vert, bool band, hipStream_t st) {
-    if (vert) return band ? launch_dma_tv<T, MT, KS, true, true>(p, d, st) : launch_dma_tv<T, MT, KS, true, false>(p, d, st);
-    return band ? launch_dma_tv<T, MT, KS, false, true>(p, d, st) : launch_dma_tv<T, MT, KS, false, false>(p, d, st);
+    if (vert) return band ? launch_dma_tv<T, MT, KS, true, true, true>(p, d, st) : launch_dma_tv<T, MT, KS, true, false, true>(p, d, st);
+    if (d.W % 8 == 0) return band ? launch_dma_tv<T, MT, KS, false, true, true>(p, d, st) : launch_dma_tv<T, MT, KS, false, false, true>(p, d, st);
+    return band ? launch_dma_tv<T, MT, KS, false, true, false>(p, d, st) : launch_dma_tv<T, MT, KS, false, false, false>(p, d, st);
 }
 
 int launch_dwconv_mfma_dma(const void* x, int x_dt, const void* w, int w_dt, void* y, int y_dt,

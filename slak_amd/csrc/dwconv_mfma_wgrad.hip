@@ -24,6 +24,7 @@
 namespace slak {
 
 extern unsigned long long* g_dma_dbg;
+constexpr int WG_NTR = 4;               // transpose blocks of one plane per 16-lane group (upper bound: 64 blocks per plane)
 
 struct MfmaWgradParams {
     const void* dy; const void* x; float* partial;
@@ -32,6 +33,7 @@ struct MfmaWgradParams {
     int G;                 // planes staged per iteration
     int NKS;               // 16-deep k-steps per iteration
     int P;                 // LDS pitch (elements) of both stacks
+    int Hi, Pi;            // vertical: rows / pitch of a staging image (H, W rounded up to 4)
     int dy_elems, x_elems; // LDS elements of the two stacks (multiples of 8)
     int planes_per_wg, slices;
     int nchunks, cpp, cpr; // staging chunks per iteration / per plane / per row
@@ -49,6 +51,7 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dwconv_mfma_wgrad_kernel(const 
     uint16_t* xs = lds + p.dy_elems;
     const int stack_elems = (p.dy_elems + p.x_elems) > MF_WAVES * 32 * 33 * 2 ? (p.dy_elems + p.x_elems) : MF_WAVES * 32 * 33 * 2;
     float* dwl = (float*)(lds + stack_elems);               // [MF_WAVES][kh*kw]
+    uint16_t* img = (uint16_t*)(dwl + MF_WAVES * p.kh * p.kw);   // vertical only: row-major staging images [dy|x][G][Hi][Pi]
 
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, lhi = lane >> 5;
     const int wave = wave_id_uniform();
@@ -72,8 +75,28 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dwconv_mfma_wgrad_kernel(const 
         const int h = rem / p.cpr, w0 = (rem - h * p.cpr) * V;
         jpl[k] = ok ? j : -1;
         goff[k] = j * p.C * HW + rem * V;
-        // k-position of (plane j, short-axis position): 2 + j*(Wl+2) + position
-        loff[k] = VERT ? (h * p.P + 2 + j * (p.Wl + 2) + w0) : ((2 + j * (p.Wl + 2) + h) * p.P + w0);
+        // horizontal: straight into the stacks, k-position of (plane j, row h) = 2 + j*(Wl+2) + h;
+        // vertical: into the row-major staging image of plane j (transposed into the stacks afterwards)
+        loff[k] = VERT ? ((j * p.Hi + h) * p.Pi + w0) : ((2 + j * (p.Wl + 2) + h) * p.P + w0);
+    }
+    // vertical: transpose map.  Block b = (tensor t, plane j, 4 image rows kb, 16 image columns cb): one ds_read_b64_tr_b16 per
+    // 16-lane group (lane i16 supplies row kb*4 + i16/4, columns cb*16 + 4*(i16%4); receives column cb*16 + i16, rows kb*4..+3),
+    // written as 8 bytes of stack row k = 2 + j*(Wl+2) + column, stack columns kb*4..+3.
+    // Per plane the block pattern is the same, so only the <= WG_NTR blocks of ONE plane are kept per 16-lane group.
+    int tr_r[WG_NTR], tr_w[WG_NTR];
+    if constexpr (VERT) {
+        const int g16 = lane >> 4, i16t = lane & 15;
+        const int cbs = (p.W + 15) / 16, per_plane = (p.Hi / 4) * cbs;
+#pragma unroll
+        for (int k = 0; k < WG_NTR; ++k) {
+            const int b = (k * MF_WAVES + wave) * 4 + g16;
+            const bool ok = b < per_plane;
+            const int kb = ok ? b / cbs : 0, cb = ok ? b - kb * cbs : 0;
+            const int col = cb * 16 + i16t;
+            const bool rd_ok = (cb * 16 + (i16t & 3) * 4) < p.Pi;      // source chunk inside the image pitch (else any valid address)
+            tr_r[k] = ok ? (rd_ok ? (kb * 4 + (i16t >> 2)) * p.Pi + cb * 16 + (i16t & 3) * 4 : 0) : -1;
+            tr_w[k] = (ok && col < p.W) ? (2 + col) * p.P + kb * 4 : -1;
+        }
     }
     chunk_t<V> sx[MF_NCH], sd[MF_NCH];
     auto prefetch = [&](int it) {
@@ -85,14 +108,30 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dwconv_mfma_wgrad_kernel(const 
             else { sx[k] = chunk_zero<V>(); sd[k] = chunk_zero<V>(); }
         }
     };
-    // the x stack carries 2 extra k-positions in front, so that "k + rho" (rho = 0..4) addresses x[k + rho - 2]
-    const int xshift = VERT ? 2 : 2 * p.P;
+    // the x stack carries 2 extra k-rows in front, so that row "k + rho" (rho = 0..4) holds x[k + rho - 2]
     auto stage_write = [&]() {
 #pragma unroll
         for (int k = 0; k < MF_NCH; ++k) {
             if (jpl[k] >= 0) {
-                if constexpr (VERT) { chunk_store_lds_a4<V>(dys + loff[k], sd[k]); chunk_store_lds_a4<V>(xs + loff[k] + xshift, sx[k]); }
-                else { chunk_store<V>(dys + loff[k], sd[k]); chunk_store<V>(xs + loff[k] + xshift, sx[k]); }
+                if constexpr (VERT) { chunk_store<V>(img + loff[k], sd[k]); chunk_store<V>(img + p.G * p.Hi * p.Pi + loff[k], sx[k]); }
+                else { chunk_store<V>(dys + loff[k], sd[k]); chunk_store<V>(xs + loff[k] + 2 * p.P, sx[k]); }
+            }
+        }
+    };
+    auto transpose_images = [&]() {                          // vertical: images -> stacks (all threads; caller syncs around it)
+        if constexpr (VERT) {
+            for (int t = 0; t < 2; ++t) {
+                for (int j = 0; j < p.G; ++j) {
+                    const uint16_t* src = img + (t * p.G + j) * p.Hi * p.Pi;
+                    uint16_t* dst = (t ? xs + 2 * p.P : dys) + j * (p.Wl + 2) * p.P;
+#pragma unroll
+                    for (int k = 0; k < WG_NTR; ++k) {
+                        if (tr_r[k] >= 0) {
+                            const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16(SLAK_LDS(s16x4, src + tr_r[k]));
+                            if (tr_w[k] >= 0) *(s16x4*)(dst + tr_w[k]) = v;
+                        }
+                    }
+                }
             }
         }
     };
@@ -106,9 +145,11 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dwconv_mfma_wgrad_kernel(const 
         for (int i = tid; i < n8; i += MF_THREADS) z[i] = u32x4{0u, 0u, 0u, 0u};
         for (int i = tid; i < MF_WAVES * ntap; i += MF_THREADS) dwl[i] = 0.f;
     }
+    if constexpr (VERT) { for (int i = tid; i < p.G * p.Hi * p.Pi; i += MF_THREADS) ((unsigned*)img)[i] = 0u; }   // 2 images x G planes, 2 elements per dword
     __syncthreads();
     if (iters > 0) stage_write();
     __syncthreads();
+    if constexpr (VERT) { transpose_images(); __syncthreads(); }
 
     t1 = __builtin_readcyclecounter();
     f32x16 acc[NG];
@@ -120,7 +161,7 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dwconv_mfma_wgrad_kernel(const 
     // ---- per-lane fragment addresses (element offsets at k-step 0) -----------------------------------
     const int grp = lane >> 4, i16 = lane & 15;
     int a_off, b_off[NG];
-    if constexpr (!VERT) {
+    {
         // tr-read: group grp reads a 4(k) x 16 block; lane supplies (k row = (grp>>1)*8 + (i16>>2), 4-col chunk i16&3)
         const int krow = (grp >> 1) * 8 + (i16 >> 2);
         a_off = krow * p.P + mt * 32 + (grp & 1) * 16 + (i16 & 3) * 4;
@@ -130,45 +171,30 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dwconv_mfma_wgrad_kernel(const 
             int rho = g * RPN + ncol / NPAD; if (rho > MF_TAPS - 1) rho = MF_TAPS - 1;
             b_off[g] = (krow + rho) * p.P + nt * 32 + (ncol % NPAD);
         }
-    } else {
-        a_off = (mt * 32 + l31) * p.P + lhi * 8;
-#pragma unroll
-        for (int g = 0; g < NG; ++g) {
-            int rho = g * RPN + l31 / NPAD; if (rho > MF_TAPS - 1) rho = MF_TAPS - 1;
-            b_off[g] = (nt * 32 + (l31 % NPAD)) * p.P + lhi * 8 + rho;
-        }
     }
-    const int kstep_elems = VERT ? 16 : 16 * p.P;
+    const int kstep_elems = 16 * p.P;
     const int ks_first = (MT == 2) ? 0 : wave, ks_stride = (MT == 2) ? 1 : MF_WAVES;
 
     for (int it = 0; it < iters; ++it) {
         if (it + 1 < iters) prefetch(it + 1);
         for (int ks = ks_first; ks < p.NKS; ks += ks_stride) {
             const uint16_t* ap = dys + a_off + ks * kstep_elems;
-            s16x8 a;
-            if constexpr (!VERT) {
-                s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(SLAK_LDS(s16x4, ap));
-                s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(SLAK_LDS(s16x4, ap + 4 * p.P));
-                a = s16x8{a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
-            } else {
-                a = *(const s16x8*)ap;
-            }
+            const s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(SLAK_LDS(s16x4, ap));
+            const s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(SLAK_LDS(s16x4, ap + 4 * p.P));
+            const s16x8 a = s16x8{a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
 #pragma unroll
             for (int g = 0; g < NG; ++g) {
                 const uint16_t* bp = xs + b_off[g] + ks * kstep_elems;
-                s16x8 b;
-                if constexpr (!VERT) {
-                    s16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(SLAK_LDS(s16x4, bp));
-                    s16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(SLAK_LDS(s16x4, bp + 4 * p.P));
-                    b = s16x8{b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
-                } else {
-                    b = *(const s16x8_u*)bp;                          // 2-byte-granular address -> one ds_read_b128 (legal on gfx950)
-                }
-                acc[g] = mfma32<T>(a, b, acc[g]);
+                const s16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(SLAK_LDS(s16x4, bp));
+                const s16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(SLAK_LDS(s16x4, bp + 4 * p.P));
+                acc[g] = mfma32<T>(a, s16x8{b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]}, acc[g]);
             }
         }
         __syncthreads();
-        if (it + 1 < iters) stage_write();
+        if (it + 1 < iters) {
+            stage_write();
+            if constexpr (VERT) { __syncthreads(); transpose_images(); }
+        }
         __syncthreads();
     }
 
@@ -254,23 +280,18 @@ static bool fill_wgrad_params(MfmaWgradParams& p, const ConvDims& d, bool vert, 
     const int K = 2 + G * (p.Wl + 2);
     p.NKS = (K + 15) / 16;
     const int Kp = p.NKS * 16;
-    if (vert) {
-        p.P = (Kp + 8 + 7) & ~7;                           // k along columns; +8: x reads run rho (<= 4) past the last k-step
-        if ((p.P / 8) % 2 == 0) p.P += 8;                  // P/8 odd: conflict-free aligned ds_read_b128 across rows
-        p.dy_elems = s.MT * 32 * p.P;
-        p.x_elems = s.MT * 32 * p.P;
-    } else {
-        p.P = s.MT * 32;                                   // k along rows
-        p.dy_elems = Kp * p.P;
-        p.x_elems = (Kp + 8) * p.P;                        // 2 rows in front + rho <= 4 behind
-    }
+    p.P = s.MT * 32;                                       // k along rows, long-axis positions along columns
+    p.dy_elems = Kp * p.P;
+    p.x_elems = (Kp + 8) * p.P;                            // 2 rows in front + rho <= 4 behind
+    p.Hi = (d.H + 3) & ~3; p.Pi = (d.W + 3) & ~3;
+    if (vert && (p.Hi / 4) * ((d.W + 15) / 16) > WG_NTR * MF_WAVES * 4) return false;
     p.dy_elems = (p.dy_elems + 7) & ~7; p.x_elems = (p.x_elems + 7) & ~7;
     return true;
 }
 
-static size_t mfma_wgrad_lds_bytes(const MfmaWgradParams& p) {
+static size_t mfma_wgrad_lds_bytes(const MfmaWgradParams& p, bool vert) {
     size_t stacks = (size_t)(p.dy_elems + p.x_elems) * 2, scratch = (size_t)MF_WAVES * 32 * 33 * 4;
-    return (stacks > scratch ? stacks : scratch) + (size_t)MF_WAVES * p.kh * p.kw * 4 + 16;
+    return (stacks > scratch ? stacks : scratch) + (size_t)MF_WAVES * p.kh * p.kw * 4 + (vert ? (size_t)2 * p.G * p.Hi * p.Pi * 2 : 0) + 32;
 }
 
 bool dwconv_mfma_wgrad_supported(const ConvDims& d, int dy_dt, int x_dt) {
@@ -279,7 +300,7 @@ bool dwconv_mfma_wgrad_supported(const ConvDims& d, int dy_dt, int x_dt) {
     WShape s; MfmaWgradParams p;
     if (!mfma_wgrad_shape(d, vert, s)) return false;
     if (!fill_wgrad_params(p, d, vert, s, 256)) return false;
-    return mfma_wgrad_lds_bytes(p) <= 72 * 1024;
+    return mfma_wgrad_lds_bytes(p, vert) <= 72 * 1024;
 }
 
 size_t dwconv_mfma_wgrad_workspace(const ConvDims& d) {
@@ -292,7 +313,7 @@ size_t dwconv_mfma_wgrad_workspace(const ConvDims& d) {
 
 template <typename T, int MT, int RPN, int V>
 static int launch_wgrad_t(const MfmaWgradParams& p, bool vert, hipStream_t st) {
-    const size_t lds = mfma_wgrad_lds_bytes(p);
+    const size_t lds = mfma_wgrad_lds_bytes(p, vert);
     dim3 grid((unsigned)(p.C * p.slices));
     if (vert) {
         auto k = dwconv_mfma_wgrad_kernel<T, MT, RPN, V, true>;
