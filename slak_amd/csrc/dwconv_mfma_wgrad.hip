@@ -24,7 +24,7 @@
 namespace slak {
 
 extern unsigned long long* g_dma_dbg;
-constexpr int WG_NTR = 4;               // transpose blocks of one plane per 16-lane group (upper bound: 64 blocks per plane)
+constexpr int WG_NTR = 8;               // transpose blocks per 16-lane group (large planes: of one plane; small planes: of all staged planes)
 
 struct MfmaWgradParams {
     const void* dy; const void* x; float* partial;
@@ -82,20 +82,28 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dwconv_mfma_wgrad_kernel(const 
     // vertical: transpose map.  Block b = (tensor t, plane j, 4 image rows kb, 16 image columns cb): one ds_read_b64_tr_b16 per
     // 16-lane group (lane i16 supplies row kb*4 + i16/4, columns cb*16 + 4*(i16%4); receives column cb*16 + i16, rows kb*4..+3),
     // written as 8 bytes of stack row k = 2 + j*(Wl+2) + column, stack columns kb*4..+3.
-    // Per plane the block pattern is the same, so only the <= WG_NTR blocks of ONE plane are kept per 16-lane group.
+    // The WG_NTR blocks a 16-lane group handles are fixed per thread.  Large planes (>= 8 blocks): the per-plane pattern,
+    // repeated over (tensor, plane) in a loop; small planes: blocks of all 2*G planes flattened over the 16 groups.
     int tr_r[WG_NTR], tr_w[WG_NTR];
+    const int tr_cbs = (p.W + 15) / 16, tr_per_plane = (p.Hi / 4) * tr_cbs;
+    const bool tr_flat = tr_per_plane < 8;
     if constexpr (VERT) {
         const int g16 = lane >> 4, i16t = lane & 15;
-        const int cbs = (p.W + 15) / 16, per_plane = (p.Hi / 4) * cbs;
+        const int total = tr_flat ? 2 * p.G * tr_per_plane : tr_per_plane;
 #pragma unroll
         for (int k = 0; k < WG_NTR; ++k) {
             const int b = (k * MF_WAVES + wave) * 4 + g16;
-            const bool ok = b < per_plane;
-            const int kb = ok ? b / cbs : 0, cb = ok ? b - kb * cbs : 0;
+            const bool ok = b < total;
+            const int pl = (ok && tr_flat) ? b / tr_per_plane : 0;          // flattened: (tensor t, plane j) index
+            const int blk = ok ? b - pl * tr_per_plane : 0;
+            const int t = pl / p.G, j = pl - t * p.G;
+            const int kb = blk / tr_cbs, cb = blk - kb * tr_cbs;
             const int col = cb * 16 + i16t;
             const bool rd_ok = (cb * 16 + (i16t & 3) * 4) < p.Pi;      // source chunk inside the image pitch (else any valid address)
-            tr_r[k] = ok ? (rd_ok ? (kb * 4 + (i16t >> 2)) * p.Pi + cb * 16 + (i16t & 3) * 4 : 0) : -1;
-            tr_w[k] = (ok && col < p.W) ? (2 + col) * p.P + kb * 4 : -1;
+            const int src_plane = tr_flat ? pl * p.Hi * p.Pi : 0;
+            const int dst_plane = tr_flat ? (t ? p.dy_elems + 2 * p.P : 0) + j * (p.Wl + 2) * p.P : 0;
+            tr_r[k] = ok ? src_plane + (rd_ok ? (kb * 4 + (i16t >> 2)) * p.Pi + cb * 16 + (i16t & 3) * 4 : 0) : -1;
+            tr_w[k] = (ok && col < p.W) ? dst_plane + (2 + col) * p.P + kb * 4 : -1;
         }
     }
     chunk_t<V> sx[MF_NCH], sd[MF_NCH];
@@ -120,15 +128,25 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dwconv_mfma_wgrad_kernel(const 
     };
     auto transpose_images = [&]() {                          // vertical: images -> stacks (all threads; caller syncs around it)
         if constexpr (VERT) {
-            for (int t = 0; t < 2; ++t) {
-                for (int j = 0; j < p.G; ++j) {
-                    const uint16_t* src = img + (t * p.G + j) * p.Hi * p.Pi;
-                    uint16_t* dst = (t ? xs + 2 * p.P : dys) + j * (p.Wl + 2) * p.P;
+            if (tr_flat) {
 #pragma unroll
-                    for (int k = 0; k < WG_NTR; ++k) {
-                        if (tr_r[k] >= 0) {
-                            const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16(SLAK_LDS(s16x4, src + tr_r[k]));
-                            if (tr_w[k] >= 0) *(s16x4*)(dst + tr_w[k]) = v;
+                for (int k = 0; k < WG_NTR; ++k) {
+                    if (tr_r[k] >= 0) {
+                        const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16(SLAK_LDS(s16x4, img + tr_r[k]));
+                        if (tr_w[k] >= 0) *(s16x4*)(lds + tr_w[k]) = v;
+                    }
+                }
+            } else {
+                for (int t = 0; t < 2; ++t) {
+                    for (int j = 0; j < p.G; ++j) {
+                        const uint16_t* src = img + (t * p.G + j) * p.Hi * p.Pi;
+                        uint16_t* dst = (t ? xs + 2 * p.P : dys) + j * (p.Wl + 2) * p.P;
+#pragma unroll
+                        for (int k = 0; k < WG_NTR; ++k) {
+                            if (tr_r[k] >= 0) {
+                                const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16(SLAK_LDS(s16x4, src + tr_r[k]));
+                                if (tr_w[k] >= 0) *(s16x4*)(dst + tr_w[k]) = v;
+                            }
                         }
                     }
                 }
@@ -284,7 +302,10 @@ static bool fill_wgrad_params(MfmaWgradParams& p, const ConvDims& d, bool vert, 
     p.dy_elems = Kp * p.P;
     p.x_elems = (Kp + 8) * p.P;                            // 2 rows in front + rho <= 4 behind
     p.Hi = (d.H + 3) & ~3; p.Pi = (d.W + 3) & ~3;
-    if (vert && (p.Hi / 4) * ((d.W + 15) / 16) > WG_NTR * MF_WAVES * 4) return false;
+    {
+        const int per_plane = (p.Hi / 4) * ((d.W + 15) / 16);
+        if (vert && (per_plane < 8 ? 2 * G * per_plane : per_plane) > WG_NTR * MF_WAVES * 4) return false;
+    }
     p.dy_elems = (p.dy_elems + 7) & ~7; p.x_elems = (p.x_elems + 7) & ~7;
     return true;
 }
