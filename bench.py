@@ -83,17 +83,32 @@ def hot_path_kernels(device, batch, reps, dtype):
     return out
 
 
-def cpu_baseline(threads):
+def measured_traffic(k):
+    """HBM bytes per launch of kernel `k` from the committed PMC passes (profiles/pmc_traffic.json, produced by
+    tools/pmc_traffic.py from two rocprofv3 --pmc runs: FETCH_SIZE doubled per MI355X_MICROARCH.md, WRITE_SIZE as read);
+    None if that kernel/shape was not profiled."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            tab = json.load(f)
+        e = tab.get("s%d_%s_%s" % (k["stage"], k["kernel"], k["op"]))
+        return None if e is None else e["hbm_bytes_per_launch"]
+    except (OSError, ValueError):
+        return None
+
+
+def cpu_baseline(threads, batch=4, seconds_per_shape=1.5):
     """Reference CPU path (north star: 'the reference CPU nn.Conv2d path timed on the node's host cores'):
-    torch CPU F.conv2d fp32 fwd + bwd of every distinct dw conv of SLaK-T at batch 1 (BASELINE cfg 1 is the
-    stage-1 block of this list), weighted by how often each occurs per image -> images/s of the dw-conv hot
-    path alone.  Bounded: a few iterations per shape, ~10-30 s total."""
+    torch CPU F.conv2d fp32 fwd + bwd of every distinct dw conv of SLaK-T (BASELINE cfg 1 is the stage-1 block of
+    this list), weighted by how often each occurs per image -> images/s of the dw-conv hot path alone.
+    Bounded sample: `batch` images per call, each of the 12 shapes repeated for ~seconds_per_shape (>= 3 calls),
+    median taken -> ~20 s of CPU work in total."""
     torch.set_num_threads(threads)
     total = 0.0
     detail = {}
+    ncalls = 0
     t_start = time.perf_counter()
     for (C, HW, K, blocks) in STAGES_T:
-        x = torch.randn(1, C, HW, HW, requires_grad=True)
+        x = torch.randn(batch, C, HW, HW, requires_grad=True)
         for kh, kw in ((K, 5), (5, K), (5, 5)):
             w = (torch.randn(C, 1, kh, kw) * 0.02).requires_grad_(True)
             def it():
@@ -101,17 +116,18 @@ def cpu_baseline(threads):
                 y.backward(torch.ones_like(y))
             it()                                                  # warm-up
             ts = []
-            for _ in range(3):
+            t_shape = time.perf_counter()
+            while len(ts) < 3 or (time.perf_counter() - t_shape < seconds_per_shape and len(ts) < 200):
                 t0 = time.perf_counter(); it(); ts.append(time.perf_counter() - t0)
-                if sum(ts) > 2.0:                                 # keep the whole leg bounded (~10-30 s)
-                    break
+            ncalls += len(ts)
             t = sorted(ts)[len(ts) // 2]
             detail["s%d_%dx%d" % (HW, kh, kw)] = t
             total += t * blocks
-    return dict(value=1.0 / total, unit="images/s (dw-conv hot path only: all 54 convs fwd+bwd)", cores=threads, kind="reference",
-                sample="torch %s CPU F.conv2d fp32 fwd+bwd, batch 1, every distinct SLaK-T dw-conv shape (cfg-1 stage-1 block: "
-                       "%.1f ms), median of <=3, weighted by blocks/stage; wall %.1f s" % (
-                           torch.__version__, 1e3 * sum(v for k, v in detail.items() if k.startswith("s56")), time.perf_counter() - t_start))
+    return dict(value=batch / total, unit="images/s (dw-conv hot path only: all 54 convs fwd+bwd)", cores=threads, kind="reference",
+                sample="torch %s CPU F.conv2d fp32 fwd+bwd, batch %d, every distinct SLaK-T dw-conv shape (cfg-1 stage-1 block: "
+                       "%.1f ms per image), median of %d calls in total, weighted by blocks/stage; wall %.1f s" % (
+                           torch.__version__, batch, 1e3 / batch * sum(v for k, v in detail.items() if k.startswith("s56")), ncalls,
+                           time.perf_counter() - t_start))
 
 
 def main():
@@ -209,7 +225,7 @@ def main():
         hot_ms = sum(k["step_ms"] for k in ks)
         hot_bytes = sum(k["alg_bytes"] * k["calls_per_step"] for k in ks)
         out["roofline"] = {"bound": "hbm", "achieved": dom["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": dom["gbs"] / HBM_PEAK_GBS,
-                           "traffic": None, "kernel": "dwconv %s %s stage %d (N=%d)" % (dom["kernel"], dom["op"], dom["stage"], a.batch),
+                           "traffic": measured_traffic(dom), "kernel": "dwconv %s %s stage %d (N=%d)" % (dom["kernel"], dom["op"], dom["stage"], a.batch),
                            "avg_launch_ms": dom["ms"], "alg_bytes_per_launch": dom["alg_bytes"],
                            "valu_tflops_nominal": dom["gflop_nominal"] / dom["ms"]}
         out["hot_path"] = {"dwconv_ms_per_step": hot_ms, "dwconv_alg_gb_per_step": hot_bytes / 1e9,

@@ -1,0 +1,153 @@
+"""GPU parity tests of the matrix-core (MFMA) depthwise-conv kernels (pytest -m gpu, MI355X).
+
+All calls go through the C ABI (slak_amd.ops -> ctypes -> libslak_hip.so).  The checker is the CPU oracle on the
+ROUNDED operands: the MFMA path rounds the fp32 filter to the activation dtype (what autocast does to an nn.Conv2d
+weight), accumulates in fp32 and rounds the result once, so against an fp64 evaluation of the same rounded operands the
+only error is the output rounding (half an ulp: 2^-8 relative for bf16, 2^-11 for fp16) plus fp32 accumulation noise.
+Tolerance asserted: 1e-2 (BASELINE.json, bf16) -- and the tighter "half an output ulp + accumulation" bound below.
+"""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+
+pytestmark = pytest.mark.gpu
+
+LOWP_TOL = 1e-2
+
+
+def _ops():
+    from slak_amd import ops
+    return ops
+
+
+def _lib():
+    from slak_amd import _lib
+    return _lib
+
+
+@pytest.fixture()
+def mfma_only(gpu):
+    """Force the MFMA algorithm (unsupported shapes raise instead of silently running the direct kernels)."""
+    L = _lib()
+    L.lib().slak_set_conv_algo(L.ALGO_MFMA)
+    yield
+    L.lib().slak_set_conv_algo(L.ALGO_AUTO)
+
+
+def _round(t, dtype):
+    return t.to(dtype).float().cpu().numpy()
+
+
+def _check(got, ref, ulp_rel, what):
+    got = got.detach().double().cpu().numpy()
+    scale = max(1.0, float(np.abs(ref).max()))
+    err = np.abs(got - ref)
+    assert err.max() <= LOWP_TOL * scale, "%s: max err %.3e vs |ref|max %.3e" % (what, err.max(), scale)
+    # tighter: half an output ulp of the element (+ accumulation noise proportional to the tensor scale)
+    bound = ulp_rel * np.abs(ref) + 5e-6 * scale
+    assert (err <= bound).all(), "%s: exceeds rounding bound by %.3e" % (what, float((err - bound).max()))
+
+
+# every kernel class: DMA ring (56-class, 28-class; aligned and 8-byte-aligned rows), register-staged (14, 7, odd sizes),
+# band-skipping (5x5 on a large map), batch tails (N not a multiple of the planes per iteration), ragged channel counts
+SHAPES = [
+    (5, 3, 56, 56, 5, 51), (5, 3, 56, 56, 51, 5), (3, 4, 56, 56, 5, 5),
+    (9, 5, 28, 28, 5, 49), (9, 5, 28, 28, 49, 5), (6, 2, 28, 28, 5, 5),
+    (7, 3, 48, 40, 51, 5), (7, 3, 40, 48, 5, 51), (3, 2, 64, 64, 5, 61), (3, 2, 64, 64, 61, 5),
+    (5, 4, 24, 28, 5, 31), (5, 4, 28, 24, 31, 5), (4, 3, 32, 32, 31, 5),
+    (11, 5, 14, 14, 5, 47), (11, 5, 14, 14, 47, 5), (13, 3, 12, 16, 13, 5), (13, 3, 16, 12, 5, 13),
+    (17, 6, 7, 7, 5, 13), (17, 6, 7, 7, 13, 5), (1, 1, 7, 7, 13, 5), (11, 2, 7, 8, 5, 9),
+    (2, 130, 14, 14, 5, 5), (3, 2, 18, 20, 5, 21), (3, 2, 20, 24, 21, 5),
+]
+
+
+@pytest.mark.parametrize("N,C,H,W,kh,kw", SHAPES)
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_mfma_forward_dgrad_wgrad_vs_oracle(N, C, H, W, kh, kw, dtype, mfma_only, gpu):
+    ops = _ops()
+    torch.manual_seed(N * 1000 + H * 10 + kh)
+    x = torch.randn(N, C, H, W, device=gpu).to(dtype)
+    dy = torch.randn(N, C, H, W, device=gpu).to(dtype)
+    w = torch.randn(C, 1, kh, kw, device=gpu) * 0.05
+    xr, dyr, wr = _round(x, dtype), _round(dy, dtype), _round(w, dtype)
+    ulp = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11      # half an ulp, relative (8 / 11 significand bits)
+    y = ops.dwconv2d_forward(x, w)
+    assert y.dtype == dtype
+    _check(y, oracle.dwconv2d_fwd(xr, wr), ulp, "fwd")
+    dx = ops.dwconv2d_backward_data(dy, w)
+    _check(dx, oracle.dwconv2d_bwd_data(dyr, wr), ulp, "dgrad")
+    dw = ops.dwconv2d_backward_filter(dy, x, w)
+    assert dw.dtype == torch.float32
+    ref = oracle.dwconv2d_bwd_filter(dyr, xr, kh, kw)
+    err = np.abs(dw.double().cpu().numpy() - ref).max()
+    assert err <= 1e-5 * max(1.0, np.abs(ref).max()) * max(1.0, (N * H * W) ** 0.5 / 30), err    # fp32 accumulation only
+    assert torch.equal(dw, ops.dwconv2d_backward_filter(dy, x, w))                                 # no atomics
+
+
+def test_mfma_is_what_auto_runs_for_lowp(gpu):
+    """AUTO must pick the matrix-core kernels for 16-bit activations with a 5-tap side, and the fp32-exact direct
+    kernels otherwise; forcing MFMA on an unsupported case must fail loudly, not fall back."""
+    ops, L = _ops(), _lib()
+    x = torch.randn(2, 3, 28, 28, device=gpu).bfloat16()
+    w = torch.randn(3, 1, 5, 49, device=gpu) * 0.05
+    L.lib().slak_set_conv_algo(L.ALGO_AUTO)
+    y_auto = ops.dwconv2d_forward(x, w)
+    L.lib().slak_set_conv_algo(L.ALGO_MFMA)
+    try:
+        y_mfma = ops.dwconv2d_forward(x, w)
+        with pytest.raises(L.SlakHipError):
+            ops.dwconv2d_forward(x.float(), w)                     # fp32 activations: no MFMA kernel
+        with pytest.raises(L.SlakHipError):
+            ops.dwconv2d_forward(x, torch.randn(3, 1, 7, 7, device=gpu))   # no 5-tap side
+        L.lib().slak_set_conv_algo(L.ALGO_DIRECT)
+        y_direct = ops.dwconv2d_forward(x, w)
+    finally:
+        L.lib().slak_set_conv_algo(L.ALGO_AUTO)
+    assert torch.equal(y_auto, y_mfma)
+    assert not torch.equal(y_auto, y_direct)                       # direct keeps the fp32 filter: different rounding
+    assert (y_auto.float() - y_direct.float()).abs().max().item() <= 1e-2 * max(1.0, y_direct.float().abs().max().item())
+
+
+@pytest.mark.parametrize("H,W,kh,kw", [(56, 56, 5, 51), (56, 56, 51, 5), (28, 28, 49, 5), (14, 14, 5, 47), (7, 7, 13, 5)])
+def test_mfma_nan_stays_in_its_plane(H, W, kh, kw, mfma_only, gpu):
+    """The DMA images carry no padding and planes are packed into shared MFMA tiles: a NaN/Inf in one plane must not
+    reach any other plane (zero padding is applied with selects, never by multiplying)."""
+    ops = _ops()
+    torch.manual_seed(1)
+    x = torch.randn(6, 4, H, W, device=gpu).bfloat16()
+    w = torch.randn(4, 1, kh, kw, device=gpu) * 0.05
+    y0 = ops.dwconv2d_forward(x, w)
+    xb = x.clone()
+    xb[2, 1] = float("nan")
+    xb[4, 3, H - 1, W - 1] = float("inf")
+    y1 = ops.dwconv2d_forward(xb, w)
+    clean = torch.ones(6, 4, dtype=torch.bool, device=gpu)
+    clean[2, 1] = False; clean[4, 3] = False
+    assert torch.equal(y1[clean], y0[clean])
+    assert torch.isnan(y1[2, 1]).all()
+
+
+def test_mfma_identity_and_adjoint_full_size(mfma_only, gpu):
+    ops = _ops()
+    torch.manual_seed(3)
+    for (N, C, H, W, kh, kw) in [(128, 96, 56, 56, 51, 5), (128, 96, 56, 56, 5, 51), (128, 192, 28, 28, 5, 49), (128, 384, 14, 14, 47, 5)]:
+        x = torch.randn(N, C, H, W, device=gpu).bfloat16()
+        dy = torch.randn(N, C, H, W, device=gpu).bfloat16()
+        w = (torch.randn(C, 1, kh, kw, device=gpu) * 0.02).bfloat16().float()      # exactly representable filter
+        wi = torch.zeros_like(w); wi[:, 0, kh // 2, kw // 2] = 1
+        assert torch.equal(ops.dwconv2d_forward(x, wi), x)
+        assert torch.equal(ops.dwconv2d_backward_data(x, wi), x)
+        y, dx, dw = ops.dwconv2d_forward(x, w), ops.dwconv2d_backward_data(dy, w), ops.dwconv2d_backward_filter(dy, x, w)
+        a = (y.double() * dy.double()).sum().item()
+        b = (dx.double() * x.double()).sum().item()
+        c = (dw.double() * w.double()).sum().item()
+        norm = (y.double().norm() * dy.double().norm()).item()
+        assert abs(a - b) <= 2e-3 * norm and abs(a - c) <= 2e-3 * norm, (a, b, c, norm)
+        # a second stream must give bit-identical results (workspace is per stream)
+        s = torch.cuda.Stream()
+        with torch.cuda.stream(s):
+            y2 = ops.dwconv2d_forward(x, w)
+        s.synchronize()
+        assert torch.equal(y, y2)
