@@ -1,0 +1,70 @@
+#!/usr/bin/env python3
+"""Turn the two rocprofv3 PMC passes of tools/pmc_workload.py into profiles/pmc_traffic.json.
+
+    python tools/pmc_traffic.py gpurun_out/pmc_fetch/pmc_results.db gpurun_out/pmc_write/pmc_results.db > profiles/r01_pmc_traffic.txt
+
+HBM bytes per op launch = 2 * FETCH_SIZE*1024 + WRITE_SIZE*1024: FETCH_SIZE on gfx950 reports exactly half of a wide
+coalesced streaming read (MI355X_MICROARCH.md, HBM section: TCC_EA0_RDREQ counted at 64 B for 128-B requests), WRITE_SIZE
+is taken as read (uncalibrated).  An "op" is everything one C-ABI call launches (Toeplitz pack + conv, or wgrad + slice
+reduce).  The workload issues, per (stage, filter), 3 x (forward, backward_data, backward_filter); the median is kept.
+"""
+import json
+import os
+import sqlite3
+import statistics
+import sys
+
+STAGES = [(96, 56, 51), (192, 28, 49), (384, 14, 47), (768, 7, 13)]
+
+
+def ops_of(db, counter):
+    c = sqlite3.connect(db)
+    rows = list(c.execute("select kernel_name, value, start from counters_collection where counter_name = ? order by start", (counter,)))
+    seq = [(n, v) for (n, v, _) in rows if "slak::" in n]
+    ops, cur = [], None
+    for n, v in seq:
+        if "toeplitz_pack" in n:
+            cur = ["conv", v]
+        elif "dwconv_mfma_dma_kernel" in n or "dwconv_mfma_fwd_kernel" in n or "dwconv_direct_kernel" in n:
+            if cur is None: cur = ["conv", 0.0]
+            cur[1] += v; ops.append(tuple(cur)); cur = None
+        elif "dwconv_prep_weights" in n:
+            cur = ["conv", v]
+        elif "wgrad_kernel" in n:
+            cur = ["wgrad", v]
+        elif "wgrad_reduce" in n:
+            cur[1] += v; ops.append(tuple(cur)); cur = None
+    return ops
+
+
+def main():
+    fetch_db, write_db = sys.argv[1], sys.argv[2]
+    f, w = ops_of(fetch_db, "FETCH_SIZE"), ops_of(write_db, "WRITE_SIZE")
+    assert len(f) == len(w) == 4 * 3 * 3 * 3, (len(f), len(w))
+    out = {}
+    i = 0
+    print("%-28s %14s %14s %14s %14s %8s" % ("op", "alg bytes", "2*FETCH", "WRITE", "HBM bytes", "HBM/alg"))
+    for si, (C, H, K) in enumerate(STAGES):
+        S = 128 * C * H * H
+        for (kh, kw) in ((K, 5), (5, K), (5, 5)):
+            vals = {"fwd": [], "bwd_data": [], "bwd_filter": []}
+            for rep in range(3):
+                for name in ("fwd", "bwd_data", "bwd_filter"):
+                    kind = "wgrad" if name == "bwd_filter" else "conv"
+                    assert f[i][0] == kind and w[i][0] == kind, (i, f[i], w[i])
+                    vals[name].append((2.0 * f[i][1] * 1024, w[i][1] * 1024))
+                    i += 1
+            for name, v in vals.items():
+                rd = statistics.median(a for a, b in v); wr = statistics.median(b for a, b in v)
+                alg = 2 * S * 2 + C * kh * kw * 4
+                key = "s%d_%dx%d_%s" % (si + 1, kh, kw, name)
+                out[key] = {"hbm_bytes_per_launch": rd + wr, "read_bytes_2xFETCH_SIZE": rd, "write_bytes_WRITE_SIZE": wr, "alg_bytes": alg}
+                print("%-28s %14d %14.0f %14.0f %14.0f %8.2f" % (key, alg, rd, wr, rd + wr, (rd + wr) / alg))
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "pmc_traffic.json")
+    with open(path, "w") as fh:
+        json.dump(out, fh, indent=1, sort_keys=True)
+    print("# wrote", path)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,17 @@
+"""Workload for the rocprofv3 PMC passes: every SLaK-T dw-conv kernel shape (bf16, N=128), 3 launches each.
+    rocprofv3 --pmc FETCH_SIZE --kernel-trace -d gpurun_out/pmc_fetch -o pmc -- python tools/pmc_workload.py
+    rocprofv3 --pmc WRITE_SIZE --kernel-trace -d gpurun_out/pmc_write -o pmc -- python tools/pmc_workload.py
+then tools/pmc_traffic.py turns the two databases into profiles/pmc_traffic.json."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from slak_amd import ops
+dev = torch.device("cuda:0")
+torch.manual_seed(0)
+for (C, H, K) in ((96, 56, 51), (192, 28, 49), (384, 14, 47), (768, 7, 13)):
+    x = torch.randn(128, C, H, H, device=dev).bfloat16(); dy = torch.randn_like(x)
+    for (kh, kw) in ((K, 5), (5, K), (5, 5)):
+        w = torch.randn(C, 1, kh, kw, device=dev) * 0.02
+        for _ in range(3):
+            ops.dwconv2d_forward(x, w); ops.dwconv2d_backward_data(dy, w); ops.dwconv2d_backward_filter(dy, x, w)
+        torch.cuda.synchronize()
