@@ -11,6 +11,11 @@ namespace slak {
 static std::mutex g_err_mu;
 static std::string g_last_hip_error = "";
 static int g_conv_algo = SLAK_ALGO_AUTO;
+static bool use_small() {                    // SLAK_MFMA_SMALL=0 keeps the generic register-staged kernel for H,W <= 16 (A/B testing)
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("SLAK_MFMA_SMALL"); v = (e && e[0] == '0') ? 0 : 1; }
+    return v != 0;
+}
 static bool use_dma() {                      // SLAK_MFMA_DMA=0 keeps the register-staged MFMA kernels (A/B testing)
     static int v = -1;
     if (v < 0) { const char* e = getenv("SLAK_MFMA_DMA"); v = (e && e[0] == '0') ? 0 : 1; }
@@ -89,7 +94,7 @@ size_t slak_dwconv2d_workspace_bytes(int op, int N, int C, int H, int W, int kh,
     (void)dtype;
     if (N <= 0 || C <= 0 || H <= 0 || W <= 0 || kh <= 0 || kw <= 0) return 0;
     ConvDims d{N, C, H, W, kh, kw};
-    if (op == 0 || op == 1) { size_t a = dwconv_direct_workspace(d), b = dwconv_mfma_workspace(d); return a > b ? a : b; }
+    if (op == 0 || op == 1) { size_t a = dwconv_direct_workspace(d), b = dwconv_mfma_workspace(d), c = dwconv_mfma_small_workspace(d); a = a > b ? a : b; return a > c ? a : c; }
     if (op == 2) { size_t a = dwconv_wgrad_workspace(d), b = dwconv_mfma_wgrad_workspace(d); return a > b ? a : b; }
     return 0;
 }
@@ -102,6 +107,8 @@ int slak_dwconv2d_forward(const void* x, int x_dtype, const void* w, int w_dtype
     ConvDims d{N, C, H, W, kh, kw};
     if (g_conv_algo != SLAK_ALGO_DIRECT && use_dma() && dwconv_mfma_dma_supported(d, x_dtype, w_dtype, y_dtype))
         return launch_dwconv_mfma_dma(x, x_dtype, w, w_dtype, y, y_dtype, d, /*flip=*/false, workspace, workspace_bytes, (hipStream_t)stream);
+    if (g_conv_algo != SLAK_ALGO_DIRECT && use_small() && dwconv_mfma_small_supported(d, x_dtype, w_dtype, y_dtype))
+        return launch_dwconv_mfma_small(x, x_dtype, w, w_dtype, y, y_dtype, d, /*flip=*/false, workspace, workspace_bytes, (hipStream_t)stream);
     if (g_conv_algo != SLAK_ALGO_DIRECT && dwconv_mfma_supported(d, x_dtype, w_dtype, y_dtype))
         return launch_dwconv_mfma(x, x_dtype, w, w_dtype, y, y_dtype, d, /*flip=*/false, workspace, workspace_bytes, (hipStream_t)stream);
     if (g_conv_algo == SLAK_ALGO_MFMA) return SLAK_ERR_UNSUPPORTED;
@@ -118,6 +125,8 @@ int slak_dwconv2d_backward_data(const void* dy, int dy_dtype, const void* w, int
     // the filter rotated by 180 degrees (h + kh/2 - r == h - kh/2 + (kh-1-r)).
     if (g_conv_algo != SLAK_ALGO_DIRECT && use_dma() && dwconv_mfma_dma_supported(d, dy_dtype, w_dtype, dx_dtype))
         return launch_dwconv_mfma_dma(dy, dy_dtype, w, w_dtype, dx, dx_dtype, d, /*flip=*/true, workspace, workspace_bytes, (hipStream_t)stream);
+    if (g_conv_algo != SLAK_ALGO_DIRECT && use_small() && dwconv_mfma_small_supported(d, dy_dtype, w_dtype, dx_dtype))
+        return launch_dwconv_mfma_small(dy, dy_dtype, w, w_dtype, dx, dx_dtype, d, /*flip=*/true, workspace, workspace_bytes, (hipStream_t)stream);
     if (g_conv_algo != SLAK_ALGO_DIRECT && dwconv_mfma_supported(d, dy_dtype, w_dtype, dx_dtype))
         return launch_dwconv_mfma(dy, dy_dtype, w, w_dtype, dx, dx_dtype, d, /*flip=*/true, workspace, workspace_bytes, (hipStream_t)stream);
     if (g_conv_algo == SLAK_ALGO_MFMA) return SLAK_ERR_UNSUPPORTED;

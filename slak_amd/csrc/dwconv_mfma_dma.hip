@@ -31,7 +31,7 @@ constexpr int DMA_NB = 4;               // ring depth (groups)
 unsigned long long* g_dma_dbg = nullptr;   // dev hook: slak_debug_set_phase_buffer()
 
 struct MfmaDmaParams {
-    const void* x; const uint16_t* frags; void* y;
+    const void* x; const float* w; const uint16_t* frags; void* y;
     int N, C, H, W, kh, kw, flip;
     int Wt, Wl, KL, padL;
     int G;                 // planes per group (iteration)
@@ -74,8 +74,10 @@ constexpr int DMA_NTR = 4;              // transpose blocks (4 rows x 16 cols) p
 
 // MT: 32-row tiles along the Toeplitz axis (wave w owns tile w % MT); KS: 16-deep k-steps; VERT: long axis = H;
 // BAND: the filter is much shorter than the map (5x5 branch) -> skip all-zero Toeplitz blocks (wave-uniform branches).
+// PACKED: Toeplitz fragments come from the workspace (toeplitz_pack_kernel; pays for MT=2: 20 fragments per wave), else they are
+// built in the kernel from the fp32 filter (MT=1: 10 fragments per wave, cheaper than a second launch).
 // R16: image rows are 16-byte aligned (W % 8 == 0); otherwise B fragments are read as two 8-byte halves.
-template <typename T, int MT, int KS, bool VERT, bool BAND, bool R16>
+template <typename T, int MT, int KS, bool VERT, bool BAND, bool R16, bool PACKED>
 __global__ __launch_bounds__(MF_THREADS, 3) void dwconv_mfma_dma_kernel(const MfmaDmaParams p) {
     constexpr int NG = MF_TAPS;
     constexpr int WL = MF_WAVES / MT;
@@ -83,7 +85,8 @@ __global__ __launch_bounds__(MF_THREADS, 3) void dwconv_mfma_dma_kernel(const Mf
     const int HW = p.H * p.W;
     uint16_t* ring = lds;                                            // DMA_NB slots of group_elems (+ slack behind the last)
     uint16_t* lout = lds + DMA_NB * p.group_elems + 64;              // 2 x [G][HW]
-    uint16_t* xt = lout + 2 * p.G * HW;                              // vertical only: [G][xt_rows][PT]
+    float* lw = (float*)(lout + 2 * p.G * HW);                       // this channel's kh*kw filter (fp32)
+    uint16_t* xt = (uint16_t*)(lw + ((p.kh * p.kw + 3) & ~3));       // vertical only: [G][xt_rows][PT]
 
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, lhi = lane >> 5;
     const int wave = wave_id_uniform();
@@ -138,7 +141,15 @@ __global__ __launch_bounds__(MF_THREADS, 3) void dwconv_mfma_dma_kernel(const Mf
     for (int g = 0; g < DMA_NB - 1; ++g) issue_group(g);
     s16x8 afrag[NG][KS];
     bool ks_active[KS];
-    load_toeplitz_frags<NG, KS>(afrag, ks_active, p.frags, c, MT, mt, lane, 32, p.Wt, p.KL, p.padL);   // (its vmcnt(0) drains the prologue DMAs: once)
+    if constexpr (PACKED) {
+        // (the vmcnt(0) in front of the first use also drains the prologue DMAs: once)
+        load_toeplitz_frags<NG, KS>(afrag, ks_active, p.frags, c, MT, mt, lane, 32, p.Wt, p.KL, p.padL);
+    } else {
+        const int ntap = p.kh * p.kw;
+        for (int i = tid; i < ntap; i += MF_THREADS) lw[i] = p.w[(size_t)c * ntap + i];
+        __syncthreads();
+        build_toeplitz_frags_lds<T, NG, KS, VERT>(afrag, ks_active, lw, mt, lane, p.Wt, p.KL, p.padL, p.kw, p.flip);
+    }
 
     // copy-out map of the storing waves (fixed per thread): 16-byte chunk idx -> out-buffer offset == idx*8, global offset
     int co_g[DMA_NCO], co_j[DMA_NCO];
@@ -343,7 +354,8 @@ static bool fill_dma_params(MfmaDmaParams& p, const ConvDims& d, bool vert, int 
 }
 
 static size_t dma_lds_bytes(const MfmaDmaParams& p, bool vert) {
-    return (size_t)(DMA_NB * p.group_elems + 64) * 2 + (size_t)2 * p.G * p.H * p.W * 2 + (vert ? (size_t)p.G * p.xt_rows * p.PT * 2 : 0) + 16;
+    return (size_t)(DMA_NB * p.group_elems + 64) * 2 + (size_t)2 * p.G * p.H * p.W * 2 + (size_t)((p.kh * p.kw + 3) & ~3) * 4 +
+           (vert ? (size_t)p.G * p.xt_rows * p.PT * 2 : 0) + 16;
 }
 
 static int dma_class(const ConvDims& d, bool vert) {              // 2: MT=2/KS=4, 1: MT=1/KS=2, 0: not covered
@@ -373,7 +385,7 @@ static int resident_workgroups(K kernel, size_t lds) {          // workgroups th
 
 template <typename T, int MT, int KS, bool VERT, bool BAND, bool R16>
 static int launch_dma_tv(MfmaDmaParams& p, const ConvDims& d, hipStream_t st) {
-    auto k = dwconv_mfma_dma_kernel<T, MT, KS, VERT, BAND, R16>;
+    auto k = dwconv_mfma_dma_kernel<T, MT, KS, VERT, BAND, R16, (MT == 2)>;
     fill_dma_params(p, d, VERT, MT, KS, 512);
     const size_t lds = dma_lds_bytes(p, VERT);                   // does not depend on the slice count
     static int resident = 0;                                      // per instantiation; LDS size varies little within a class
@@ -398,14 +410,16 @@ int launch_dwconv_mfma_dma(const void* x, int x_dt, const void* w, int w_dt, voi
     const bool vert = d.kh > d.kw;
     const int cls = dma_class(d, vert);
     const int MT = cls == 2 ? 2 : 1, KS = cls == 2 ? 4 : 2;
-    if (ws == nullptr || ws_bytes < toeplitz_pack_bytes(d.C, MT, MF_TAPS, KS)) return SLAK_ERR_WORKSPACE;
     MfmaDmaParams p;
     fill_dma_params(p, d, vert, MT, KS, 512);
-    ToeplitzPackParams tp{(const float*)w, (uint16_t*)ws, d.C, d.kh, d.kw, MT, MF_TAPS, KS, 1,
-                          vert ? 1 : 0, flip_filter ? 1 : 0, p.Wt, p.KL, p.padL, x_dt == SLAK_BF16 ? 1 : 0};
-    launch_toeplitz_pack(tp, st);
-    SLAK_LAUNCH_CHECK();
-    p.x = x; p.frags = (const uint16_t*)ws; p.y = y; p.flip = flip_filter ? 1 : 0;
+    p.x = x; p.w = (const float*)w; p.frags = (const uint16_t*)ws; p.y = y; p.flip = flip_filter ? 1 : 0;
+    if (MT == 2) {                                            // fragments packed once per call (20 per wave: cheaper than in-kernel)
+        if (ws == nullptr || ws_bytes < toeplitz_pack_bytes(d.C, MT, MF_TAPS, KS)) return SLAK_ERR_WORKSPACE;
+        ToeplitzPackParams tp{(const float*)w, (uint16_t*)ws, d.C, d.kh, d.kw, MT, MF_TAPS, KS, 1,
+                              vert ? 1 : 0, flip_filter ? 1 : 0, p.Wt, p.KL, p.padL, x_dt == SLAK_BF16 ? 1 : 0};
+        launch_toeplitz_pack(tp, st);
+        SLAK_LAUNCH_CHECK();
+    }
     p.dbg = g_dma_dbg;
     // band skipping pays when some (mt, ks) Toeplitz block is empty: filter half-width + 32 < 16*(KS-1)
     const bool band = (MT == 2) && (p.padL + 31 < 16 * (KS - 1));

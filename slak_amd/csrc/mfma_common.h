@@ -71,6 +71,21 @@ template <int V> __device__ __forceinline__ void chunk_store(uint16_t* p, const 
     else if constexpr (V == 2) *(unsigned*)p = c.v;
     else *p = c.v;
 }
+// element access without taking the address of a register value
+template <int V> __device__ __forceinline__ uint16_t chunk_get(const chunk_t<V>& c, int i) {
+    if constexpr (V == 8) return (uint16_t)(c.v[i >> 1] >> (16 * (i & 1)));
+    else if constexpr (V == 4) return (uint16_t)(c.v[i >> 1] >> (16 * (i & 1)));
+    else if constexpr (V == 2) return (uint16_t)(c.v >> (16 * (i & 1)));
+    else return c.v;
+}
+template <int V> __device__ __forceinline__ void chunk_set(chunk_t<V>& c, int i, uint16_t val) {
+    const unsigned sh = 16 * (i & 1), m = 0xffffu << sh;
+    if constexpr (V == 8 || V == 4) {
+#pragma unroll
+        for (int d = 0; d < V / 2; ++d) if (d == (i >> 1)) c.v[d] = (c.v[d] & ~m) | ((unsigned)val << sh);
+    } else if constexpr (V == 2) c.v = (c.v & ~m) | ((unsigned)val << sh);
+    else c.v = val;
+}
 // LDS store of a chunk whose address is only 4-byte aligned (vertical kernels place planes at lane offset 2)
 template <int V> __device__ __forceinline__ void chunk_store_lds_a4(uint16_t* p, const chunk_t<V>& c) {
     if constexpr (V == 8) { unsigned* q = (unsigned*)p; q[0] = c.v[0]; q[1] = c.v[1]; q[2] = c.v[2]; q[3] = c.v[3]; }
@@ -91,6 +106,39 @@ struct ToeplitzPackParams {
 };
 void launch_toeplitz_pack(const ToeplitzPackParams& p, hipStream_t st);
 static inline size_t toeplitz_pack_bytes(int C, int MT, int NG, int KS) { return (size_t)C * MT * NG * KS * 64 * 8 * 2; }
+
+// In-kernel, branch-free construction of the same fragments from this channel's fp32 filter staged in LDS (lw[kh*kw]):
+// one clamped ds_read_b32 + select per element, packed with v_cvt_pk.  Used by the kernels whose workgroups need few enough
+// fragments that this beats a separate pack launch (~5 us of launch + latency per conv call).
+template <typename T, int NG, int KS, bool VERT>
+__device__ __forceinline__ void build_toeplitz_frags_lds(s16x8 (&afrag)[NG][KS], bool (&ks_active)[KS], const float* lw,
+                                                         int mt, int lane, int Wt, int KL, int padL, int kw, int flip) {
+    const int l31 = lane & 31, lhi = lane >> 5, o_abs = mt * 32 + l31;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        const int i_lo = ks * 16, i_hi = ks * 16 + 15, o_lo = mt * 32, o_hi = mt * 32 + 31;
+        ks_active[ks] = (i_lo < Wt) && (o_lo < Wt) && (i_lo - o_hi <= KL - 1 - padL) && (o_lo - i_hi <= padL);
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int i_abs = ks * 16 + lhi * 8 + e;
+                int t = i_abs - o_abs + padL;
+                const bool ok = o_abs < Wt && i_abs < Wt && t >= 0 && t < KL;
+                t = ok ? t : 0;
+                int rr = g;
+                if (flip) { t = KL - 1 - t; rr = MF_TAPS - 1 - g; }
+                const float wv = VERT ? lw[t * kw + rr] : lw[rr * kw + t];
+                v[e] = ok ? wv : 0.f;
+            }
+            u32x4 a;
+#pragma unroll
+            for (int e = 0; e < 8; e += 2) a[e >> 1] = pack2<T>(v[e], v[e + 1]);
+            afrag[g][ks] = __builtin_bit_cast(s16x8, a);
+        }
+    }
+}
 
 template <int NG, int KS>
 __device__ __forceinline__ void load_toeplitz_frags(s16x8 (&afrag)[NG][KS], bool (&ks_active)[KS], const uint16_t* frags,

@@ -66,6 +66,11 @@ int launch_dwconv_wgrad(const void* dy, int dy_dt, const void* x, int x_dt, floa
 size_t dwconv_wgrad_workspace(const ConvDims& d);
 int launch_wgrad_reduce(const float* partial, float* dw, int total, int nslices, hipStream_t st);
 
+bool dwconv_mfma_small_supported(const ConvDims& d, int x_dt, int w_dt, int y_dt);
+size_t dwconv_mfma_small_workspace(const ConvDims& d);
+int launch_dwconv_mfma_small(const void* x, int x_dt, const void* w, int w_dt, void* y, int y_dt,
+                             const ConvDims& d, bool flip_filter, void* ws, size_t ws_bytes, hipStream_t st);
+
 bool dwconv_mfma_dma_supported(const ConvDims& d, int x_dt, int w_dt, int y_dt);
 int launch_dwconv_mfma_dma(const void* x, int x_dt, const void* w, int w_dt, void* y, int y_dt,
                            const ConvDims& d, bool flip_filter, void* ws, size_t ws_bytes, hipStream_t st);
