@@ -113,6 +113,27 @@ int slak_mask_read_stats(slak_mask_plan_t* plan, double* out_host, void* stream)
 /* 64-bit order-independent checksum of all masks (for cross-rank agreement checks); synchronises. */
 int slak_mask_checksum(slak_mask_plan_t* plan, unsigned long long* out_host, void* stream);
 
+/* ---------------------------------------------------------------- next row: block tail glue
+ * The layout / normalisation / residual steps around the two pointwise GEMMs of a SLaK block
+ * (models/SLaK.py:153-166: permute -> LayerNorm -> [pwconv1, GELU, pwconv2] -> gamma -> permute -> shortcut + drop_path),
+ * one HBM-bound kernel per arrow and direction.  Activations bf16, statistics / residual stream / parameters fp32.
+ * P = H*W pixels per image; x, dx, shortcut, out are NCHW; y, g, z, dz are NHWC (N,H,W,C) contiguous; C even, <= 1024. */
+size_t slak_block_tail_workspace_bytes(int N, int C, int P);
+
+/* y[n,p,:] = LayerNorm_C(x[n,:,p]) * weight + bias   (F.layer_norm over the last dim of x.permute(0,2,3,1): models/SLaK.py:156-157, :253-255) */
+int slak_ln_nchw_to_nhwc_forward(const void* x_bf16, const float* weight, const float* bias, void* y_bf16, float* mean, float* rstd,
+                                 int N, int C, int P, float eps, void* stream);
+int slak_ln_nchw_to_nhwc_backward(const void* g_bf16, const void* x_bf16, const float* weight, const float* mean, const float* rstd,
+                                  void* dx_bf16, float* dweight, float* dbias, int N, int C, int P,
+                                  void* workspace, size_t workspace_bytes, void* stream);
+
+/* out[n,c,p] = shortcut[n,c,p] + sample_scale[n] * gamma[c] * z[n,p,c]        (models/SLaK.py:161-165; sample_scale = the
+ * DropPath mask/keep_prob per sample or NULL) ; backward: dz = sample_scale*gamma*dout (bf16 NHWC), dgamma = sum sample_scale*dout*z */
+int slak_scale_residual_forward(const void* shortcut, int shortcut_dtype, const void* z_bf16, const float* gamma, const float* sample_scale,
+                                float* out, int N, int C, int P, void* stream);
+int slak_scale_residual_backward(const float* dout, const void* z_bf16, const float* gamma, const float* sample_scale,
+                                 void* dz_bf16, float* dgamma, int N, int C, int P, void* workspace, size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -47,6 +47,11 @@ SIGNATURES = {
     "slak_mask_prune_and_grow": (_i, [_vp, _d, _vp]),
     "slak_mask_read_stats": (_i, [_vp, ctypes.POINTER(_d), _vp]),
     "slak_mask_checksum": (_i, [_vp, ctypes.POINTER(ctypes.c_ulonglong), _vp]),
+    "slak_block_tail_workspace_bytes": (_sz, [_i, _i, _i]),
+    "slak_ln_nchw_to_nhwc_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, ctypes.c_float, _vp]),
+    "slak_ln_nchw_to_nhwc_backward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _sz, _vp]),
+    "slak_scale_residual_forward": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    "slak_scale_residual_backward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _sz, _vp]),
 }
 
 

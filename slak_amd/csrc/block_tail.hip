@@ -1,0 +1,409 @@
+// slak_amd/csrc/block_tail.hip -- the layout / normalisation / residual glue around the two pointwise GEMMs of a SLaK block
+// (reference models/SLaK.py:153-166, :253-261):
+//
+//     x = large_kernel(x)                       (N,C,H,W)
+//     x = x.permute(0,2,3,1); x = LayerNorm_C(x)            -> ln_nchw_to_nhwc   (one pass: read NCHW, write NHWC)
+//     x = pwconv2(gelu(pwconv1(x)))                            (hipBLASLt GEMMs, untouched)
+//     x = gamma * x; x = x.permute(0,3,1,2); x = shortcut + drop_path(x)   -> scale_residual (one pass: read NHWC, write NCHW)
+//
+// In PyTorch these lines are ~14 kernels per block and direction (permute copies, dtype casts, layer_norm, broadcast
+// multiplies, adds, reductions for dgamma): 25 ms of a 61 ms SLaK-T step on MI355X.  Here each arrow is ONE HBM-bound kernel
+// per direction: a workgroup owns (image n, TP consecutive pixels, all C channels), stages the tile in LDS and transposes
+// through it, so that both the NCHW side (lanes along pixels) and the NHWC side (lanes along channels) are coalesced.
+// LDS pitches are odd in dwords, so row and column walks are both conflict-free.  Per-channel gradient sums (dweight, dbias,
+// dgamma) are written as per-tile partials and added in a fixed order by block_tail_reduce (deterministic, no atomics).
+// Activations bf16 (autocast), statistics / residual stream / parameters fp32.
+#include "slak_common.h"
+
+namespace slak {
+
+constexpr int BT_THREADS = 256;
+
+__device__ __forceinline__ float bf2f(uint16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+typedef __attribute__((ext_vector_type(2))) float bt_f32x2;
+typedef __attribute__((ext_vector_type(2))) __bf16 bt_bf16x2;
+__device__ __forceinline__ unsigned bt_pack2(float a, float b) { return __builtin_bit_cast(unsigned, __builtin_convertvector(bt_f32x2{a, b}, bt_bf16x2)); }
+__device__ __forceinline__ uint16_t bt_f2bf(float a) { return (uint16_t)(bt_pack2(a, 0.f) & 0xffffu); }
+
+struct TailDims { int N, C, P, TP, tiles_per_image; };
+
+static inline int tail_tp(int C) { return C <= 128 ? 64 : (C <= 256 ? 64 : (C <= 512 ? 32 : 16)); }
+
+// stage x[n, :, p0:p0+TP] (NCHW, bf16) into xs[C][TP+2]; pixels beyond P are zero
+__device__ __forceinline__ void load_nchw_tile(uint16_t* xs, const uint16_t* __restrict__ xn, int C, int P, int p0, int TP, int tid) {
+    const int pitch = TP + 2;
+    if ((P & 3) == 0) {                                   // 8-byte chunks of 4 pixels (rows are 8-byte aligned)
+        const int cpr = TP / 4;
+        for (int idx = tid; idx < C * cpr; idx += BT_THREADS) {
+            const int c = idx / cpr, q = idx - c * cpr, p = p0 + q * 4;
+            unsigned lo = 0u, hi = 0u;
+            if (p < P) { const unsigned* src = (const unsigned*)(xn + (size_t)c * P + p); lo = src[0]; hi = src[1]; }
+            unsigned* dst = (unsigned*)(xs + c * pitch + q * 4);
+            dst[0] = lo; dst[1] = hi;
+        }
+    } else {
+        for (int idx = tid; idx < C * TP; idx += BT_THREADS) {
+            const int c = idx / TP, q = idx - c * TP, p = p0 + q;
+            xs[c * pitch + q] = p < P ? xn[(size_t)c * P + p] : (uint16_t)0;
+        }
+    }
+}
+// stage z[n, p0:p0+TP, :] (NHWC, bf16, C % 2 == 0) into zs[TP][C+2]; pixels beyond P are zero
+__device__ __forceinline__ void load_nhwc_tile(uint16_t* zs, const uint16_t* __restrict__ zn, int C, int P, int p0, int TP, int tid) {
+    const int pitch = C + 2, cp = C / 2;
+    for (int idx = tid; idx < TP * cp; idx += BT_THREADS) {
+        const int q = idx / cp, k = idx - q * cp, p = p0 + q;
+        unsigned v = 0u;
+        if (p < P) v = ((const unsigned*)(zn + (size_t)p * C))[k];
+        ((unsigned*)(zs + q * pitch))[k] = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// y[n,p,:] = LN_C(x[n,:,p]) * w + b   (two-pass statistics in fp32 on the staged tile), y bf16 NHWC; saves mean, rstd
+__global__ __launch_bounds__(BT_THREADS) void ln_nchw_to_nhwc_fwd_kernel(const uint16_t* __restrict__ x, const float* __restrict__ w,
+                                                                       const float* __restrict__ b, uint16_t* __restrict__ y,
+                                                                       float* __restrict__ mean, float* __restrict__ rstd,
+                                                                       const TailDims d, float eps) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int C = d.C, P = d.P, TP = d.TP, pitch = TP + 2;
+    uint16_t* xs = (uint16_t*)smem;                                        // [C][TP+2]
+    float* red = (float*)(smem + (((size_t)C * pitch * 2 + 15) & ~(size_t)15));   // [NG][TP]
+    float* st = red + (BT_THREADS / TP) * TP;                              // [2][TP]: mean, rstd
+    const int tid = threadIdx.x;
+    const int n = blockIdx.x / d.tiles_per_image, p0 = (blockIdx.x % d.tiles_per_image) * TP;
+    load_nchw_tile(xs, x + (size_t)n * C * P, C, P, p0, TP, tid);
+    __syncthreads();
+    const int q = tid % TP, g = tid / TP, NG = BT_THREADS / TP;
+    float s = 0.f;
+    for (int c = g; c < C; c += NG) s += bf2f(xs[c * pitch + q]);
+    red[g * TP + q] = s;
+    __syncthreads();
+    if (g == 0) { float t = 0.f; for (int k = 0; k < NG; ++k) t += red[k * TP + q]; st[q] = t / (float)C; }
+    __syncthreads();
+    const float mu = st[q];
+    float ss = 0.f;
+    for (int c = g; c < C; c += NG) { const float v = bf2f(xs[c * pitch + q]) - mu; ss += v * v; }
+    __syncthreads();
+    red[g * TP + q] = ss;
+    __syncthreads();
+    if (g == 0) {
+        float t = 0.f; for (int k = 0; k < NG; ++k) t += red[k * TP + q];
+        const float r = 1.0f / sqrtf(t / (float)C + eps);
+        st[TP + q] = r;
+        if (p0 + q < P) { mean[(size_t)n * P + p0 + q] = mu; rstd[(size_t)n * P + p0 + q] = r; }
+    }
+    __syncthreads();
+    // write NHWC: lanes along channel pairs
+    const int cp = C / 2;
+    uint16_t* yn = y + ((size_t)n * P + p0) * C;
+    for (int idx = tid; idx < TP * cp; idx += BT_THREADS) {
+        const int qq = idx / cp, k = idx - qq * cp;
+        if (p0 + qq < P) {
+            const float m = st[qq], r = st[TP + qq];
+            const float v0 = (bf2f(xs[(2 * k) * pitch + qq]) - m) * r * w[2 * k] + b[2 * k];
+            const float v1 = (bf2f(xs[(2 * k + 1) * pitch + qq]) - m) * r * w[2 * k + 1] + b[2 * k + 1];
+            ((unsigned*)(yn + (size_t)qq * C))[k] = bt_pack2(v0, v1);
+        }
+    }
+}
+
+// dx[n,:,p] (bf16 NCHW) from g[n,p,:] (bf16 NHWC); per-tile partial sums part[tile][0][c] = sum_p g*xhat, part[tile][1][c] = sum_p g
+__global__ __launch_bounds__(BT_THREADS) void ln_nchw_to_nhwc_bwd_kernel(const uint16_t* __restrict__ g, const uint16_t* __restrict__ x,
+                                                                       const float* __restrict__ w, const float* __restrict__ mean,
+                                                                       const float* __restrict__ rstd, uint16_t* __restrict__ dx,
+                                                                       float* __restrict__ part, const TailDims d) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int C = d.C, P = d.P, TP = d.TP, xp = TP + 2, gp = C + 2;
+    uint16_t* xs = (uint16_t*)smem;                                                  // [C][TP+2]
+    uint16_t* gs = (uint16_t*)(smem + (((size_t)C * xp * 2 + 15) & ~(size_t)15));  // [TP][C+2]
+    float* red = (float*)((unsigned char*)gs + (((size_t)TP * gp * 2 + 15) & ~(size_t)15));   // [2][NG][TP]
+    float* st = red + 2 * (BT_THREADS / TP) * TP;                                    // [4][TP]: mean, rstd, m1, m2
+    const int tid = threadIdx.x;
+    const int n = blockIdx.x / d.tiles_per_image, p0 = (blockIdx.x % d.tiles_per_image) * TP;
+    load_nchw_tile(xs, x + (size_t)n * C * P, C, P, p0, TP, tid);
+    load_nhwc_tile(gs, g + (size_t)n * P * C, C, P, p0, TP, tid);
+    if (tid < TP) {
+        const bool ok = p0 + tid < P;
+        st[tid] = ok ? mean[(size_t)n * P + p0 + tid] : 0.f;
+        st[TP + tid] = ok ? rstd[(size_t)n * P + p0 + tid] : 0.f;
+    }
+    __syncthreads();
+    const int q = tid % TP, grp = tid / TP, NG = BT_THREADS / TP;
+    {
+        const float mu = st[q], r = st[TP + q];
+        float s1 = 0.f, s2 = 0.f;
+        for (int c = grp; c < C; c += NG) {
+            const float gw = bf2f(gs[q * gp + c]) * w[c];
+            s1 += gw; s2 += gw * ((bf2f(xs[c * xp + q]) - mu) * r);
+        }
+        red[grp * TP + q] = s1; red[(NG + grp) * TP + q] = s2;
+    }
+    __syncthreads();
+    if (grp == 0) {
+        float t1 = 0.f, t2 = 0.f;
+        for (int k = 0; k < NG; ++k) { t1 += red[k * TP + q]; t2 += red[(NG + k) * TP + q]; }
+        st[2 * TP + q] = t1 / (float)C; st[3 * TP + q] = t2 / (float)C;
+    }
+    __syncthreads();
+    // dx: lanes along pixels (4 pixels per thread when rows are 8-byte aligned)
+    uint16_t* dxn = dx + (size_t)n * C * P;
+    if ((P & 3) == 0) {
+        const int cpr = TP / 4;
+        for (int idx = tid; idx < C * cpr; idx += BT_THREADS) {
+            const int c = idx / cpr, qq = (idx - c * cpr) * 4;
+            if (p0 + qq < P) {
+                const float wc = w[c];
+                float o[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float mu = st[qq + e], r = st[TP + qq + e];
+                    const float xh = (bf2f(xs[c * xp + qq + e]) - mu) * r;
+                    o[e] = r * (bf2f(gs[(qq + e) * gp + c]) * wc - st[2 * TP + qq + e] - xh * st[3 * TP + qq + e]);
+                }
+                unsigned* dst = (unsigned*)(dxn + (size_t)c * P + p0 + qq);
+                dst[0] = bt_pack2(o[0], o[1]); dst[1] = bt_pack2(o[2], o[3]);
+            }
+        }
+    } else {
+        for (int idx = tid; idx < C * TP; idx += BT_THREADS) {
+            const int c = idx / TP, qq = idx - c * TP;
+            if (p0 + qq < P) {
+                const float mu = st[qq], r = st[TP + qq];
+                const float xh = (bf2f(xs[c * xp + qq]) - mu) * r;
+                dxn[(size_t)c * P + p0 + qq] = bt_f2bf(r * (bf2f(gs[qq * gp + c]) * w[c] - st[2 * TP + qq] - xh * st[3 * TP + qq]));
+            }
+        }
+    }
+    // per-channel partials over the tile's pixels (padding pixels have g == 0)
+    float* pt = part + (size_t)blockIdx.x * 2 * C;
+    for (int c = tid; c < C; c += BT_THREADS) {
+        float a = 0.f, bsum = 0.f;
+        for (int qq = 0; qq < TP; ++qq) {
+            const float gv = bf2f(gs[qq * gp + c]);
+            a += gv * ((bf2f(xs[c * xp + qq]) - st[qq]) * st[TP + qq]);
+            bsum += gv;
+        }
+        pt[c] = a; pt[C + c] = bsum;
+    }
+}
+
+// out[n,c,p] (fp32 NCHW) = shortcut[n,c,p] + scale[n] * gamma[c] * z[n,p,c] (bf16 NHWC)
+template <typename Tsc>
+__global__ __launch_bounds__(BT_THREADS) void scale_residual_fwd_kernel(const Tsc* __restrict__ sc, const uint16_t* __restrict__ z,
+                                                                      const float* __restrict__ gamma, const float* __restrict__ scale,
+                                                                      float* __restrict__ out, const TailDims d) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int C = d.C, P = d.P, TP = d.TP, zp = C + 2;
+    uint16_t* zs = (uint16_t*)smem;
+    const int tid = threadIdx.x;
+    const int n = blockIdx.x / d.tiles_per_image, p0 = (blockIdx.x % d.tiles_per_image) * TP;
+    load_nhwc_tile(zs, z + (size_t)n * P * C, C, P, p0, TP, tid);
+    __syncthreads();
+    const float sn = scale ? scale[n] : 1.0f;
+    const Tsc* scn = sc + (size_t)n * C * P;
+    float* on = out + (size_t)n * C * P;
+    if ((P & 3) == 0) {
+        const int cpr = TP / 4;
+        for (int idx = tid; idx < C * cpr; idx += BT_THREADS) {
+            const int c = idx / cpr, qq = (idx - c * cpr) * 4;
+            if (p0 + qq < P) {
+                const float gm = gamma[c] * sn;
+                const size_t off = (size_t)c * P + p0 + qq;
+                float4 o;
+                o.x = to_f32(scn[off + 0]) + gm * bf2f(zs[(qq + 0) * zp + c]);
+                o.y = to_f32(scn[off + 1]) + gm * bf2f(zs[(qq + 1) * zp + c]);
+                o.z = to_f32(scn[off + 2]) + gm * bf2f(zs[(qq + 2) * zp + c]);
+                o.w = to_f32(scn[off + 3]) + gm * bf2f(zs[(qq + 3) * zp + c]);
+                *(float4*)(on + off) = o;
+            }
+        }
+    } else {
+        for (int idx = tid; idx < C * TP; idx += BT_THREADS) {
+            const int c = idx / TP, qq = idx - c * TP;
+            if (p0 + qq < P) {
+                const size_t off = (size_t)c * P + p0 + qq;
+                on[off] = to_f32(scn[off]) + gamma[c] * sn * bf2f(zs[qq * zp + c]);
+            }
+        }
+    }
+}
+
+// dz[n,p,c] (bf16 NHWC) = scale[n] * gamma[c] * dout[n,c,p] (fp32 NCHW); part[tile][c] = scale[n] * sum_p dout * z
+__global__ __launch_bounds__(BT_THREADS) void scale_residual_bwd_kernel(const float* __restrict__ dout, const uint16_t* __restrict__ z,
+                                                                      const float* __restrict__ gamma, const float* __restrict__ scale,
+                                                                      uint16_t* __restrict__ dz, float* __restrict__ part, const TailDims d) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int C = d.C, P = d.P, TP = d.TP, dp = TP + 1, zp = C + 2;
+    float* ds = (float*)smem;                                                        // [C][TP+1] fp32
+    uint16_t* zs = (uint16_t*)(smem + (size_t)C * dp * 4);                          // [TP][C+2]
+    const int tid = threadIdx.x;
+    const int n = blockIdx.x / d.tiles_per_image, p0 = (blockIdx.x % d.tiles_per_image) * TP;
+    const float* dn = dout + (size_t)n * C * P;
+    if ((P & 3) == 0) {
+        const int cpr = TP / 4;
+        for (int idx = tid; idx < C * cpr; idx += BT_THREADS) {
+            const int c = idx / cpr, qq = (idx - c * cpr) * 4;
+            float4 v = float4{0.f, 0.f, 0.f, 0.f};
+            if (p0 + qq < P) v = *(const float4*)(dn + (size_t)c * P + p0 + qq);
+            float* dst = ds + c * dp + qq;
+            dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
+        }
+    } else {
+        for (int idx = tid; idx < C * TP; idx += BT_THREADS) {
+            const int c = idx / TP, qq = idx - c * TP;
+            ds[c * dp + qq] = (p0 + qq < P) ? dn[(size_t)c * P + p0 + qq] : 0.f;
+        }
+    }
+    load_nhwc_tile(zs, z + (size_t)n * P * C, C, P, p0, TP, tid);
+    __syncthreads();
+    const float sn = scale ? scale[n] : 1.0f;
+    const int cp = C / 2;
+    uint16_t* dzn = dz + ((size_t)n * P + p0) * C;
+    for (int idx = tid; idx < TP * cp; idx += BT_THREADS) {
+        const int qq = idx / cp, k = idx - qq * cp;
+        if (p0 + qq < P)
+            ((unsigned*)(dzn + (size_t)qq * C))[k] = bt_pack2(sn * gamma[2 * k] * ds[(2 * k) * dp + qq], sn * gamma[2 * k + 1] * ds[(2 * k + 1) * dp + qq]);
+    }
+    float* pt = part + (size_t)blockIdx.x * C;
+    for (int c = tid; c < C; c += BT_THREADS) {
+        float a = 0.f;
+        for (int qq = 0; qq < TP; ++qq) a += ds[c * dp + qq] * bf2f(zs[qq * zp + c]);
+        pt[c] = a * sn;
+    }
+}
+
+// Column sums of part[ntiles][width] in a fixed order.  gridDim.y slices of the tile range; with one slice the result goes
+// to out0[j] (j < split) / out1[j - split], with several to out0[slice][width] (a second launch adds the slices).
+__global__ void block_tail_reduce(const float* __restrict__ part, float* __restrict__ out0, float* __restrict__ out1, int split,
+                                  int ntiles, int width) {
+    __shared__ float acc[8][64];
+    const int j = blockIdx.x * 64 + (threadIdx.x & 63), r = threadIdx.x >> 6;       // 8 rows of 64 columns
+    const int chunk = (ntiles + gridDim.y - 1) / gridDim.y;
+    const int t0 = blockIdx.y * chunk, t1 = (t0 + chunk < ntiles) ? t0 + chunk : ntiles;
+    float s = 0.f;
+    if (j < width) for (int t = t0 + r; t < t1; t += 8) s += part[(size_t)t * width + j];
+    acc[r][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (r == 0 && j < width) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t += acc[k][threadIdx.x & 63];
+        if (gridDim.y > 1) out0[(size_t)blockIdx.y * width + j] = t;
+        else if (j < split) out0[j] = t;
+        else out1[j - split] = t;
+    }
+}
+
+constexpr int BT_SLICES = 64;
+static int reduce_partials(const float* part, float* tmp, float* out0, float* out1, int split, int ntiles, int width, hipStream_t st) {
+    const int slices = ntiles >= 8 * BT_SLICES ? BT_SLICES : 1;
+    const dim3 g1((unsigned)((width + 63) / 64), (unsigned)slices);
+    if (slices > 1) {
+        hipLaunchKernelGGL(block_tail_reduce, g1, dim3(512), 0, st, part, tmp, (float*)nullptr, width, ntiles, width);
+        hipLaunchKernelGGL(block_tail_reduce, dim3((unsigned)((width + 63) / 64), 1), dim3(512), 0, st, (const float*)tmp, out0, out1, split, slices, width);
+    } else {
+        hipLaunchKernelGGL(block_tail_reduce, g1, dim3(512), 0, st, part, out0, out1, split, ntiles, width);
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { set_last_hip_error(e); return SLAK_ERR_LAUNCH; }
+    return SLAK_OK;
+}
+
+static TailDims make_dims(int N, int C, int P) {
+    TailDims d; d.N = N; d.C = C; d.P = P; d.TP = tail_tp(C);
+    d.tiles_per_image = (P + d.TP - 1) / d.TP;
+    return d;
+}
+static int set_lds(const void* k, size_t lds) {
+    if (lds > 48 * 1024) return hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess ? 0 : 1;
+    return 0;
+}
+
+}  // namespace slak
+
+using namespace slak;
+
+extern "C" {
+
+size_t slak_block_tail_workspace_bytes(int N, int C, int P) {
+    if (N <= 0 || C <= 0 || P <= 0) return 0;
+    const TailDims d = make_dims(N, C, P);
+    return align_up(((size_t)N * d.tiles_per_image + BT_SLICES) * 2 * C * sizeof(float), 256);
+}
+
+static int tail_args_ok(int N, int C, int P) {
+    if (N <= 0 || C <= 0 || P <= 0) return SLAK_ERR_INVALID_ARG;
+    if ((C & 1) || C > 1024) return SLAK_ERR_UNSUPPORTED;
+    if ((long long)N * C * P >= (1LL << 31)) return SLAK_ERR_UNSUPPORTED;
+    return SLAK_OK;
+}
+
+int slak_ln_nchw_to_nhwc_forward(const void* x, const float* weight, const float* bias, void* y, float* mean, float* rstd,
+                                 int N, int C, int P, float eps, void* stream) {
+    if (!x || !weight || !bias || !y || !mean || !rstd) return SLAK_ERR_INVALID_ARG;
+    int rc = tail_args_ok(N, C, P); if (rc) return rc;
+    const TailDims d = make_dims(N, C, P);
+    const size_t lds = (((size_t)C * (d.TP + 2) * 2 + 15) & ~(size_t)15) + (size_t)(BT_THREADS / d.TP) * d.TP * 4 + 2 * d.TP * 4;
+    if (set_lds((const void*)ln_nchw_to_nhwc_fwd_kernel, lds)) return SLAK_ERR_LAUNCH;
+    hipLaunchKernelGGL(ln_nchw_to_nhwc_fwd_kernel, dim3((unsigned)(N * d.tiles_per_image)), dim3(BT_THREADS), lds, (hipStream_t)stream,
+                       (const uint16_t*)x, weight, bias, (uint16_t*)y, mean, rstd, d, eps);
+    SLAK_LAUNCH_CHECK();
+    return SLAK_OK;
+}
+
+int slak_ln_nchw_to_nhwc_backward(const void* g, const void* x, const float* weight, const float* mean, const float* rstd,
+                                  void* dx, float* dweight, float* dbias, int N, int C, int P,
+                                  void* workspace, size_t workspace_bytes, void* stream) {
+    if (!g || !x || !weight || !mean || !rstd || !dx || !dweight || !dbias) return SLAK_ERR_INVALID_ARG;
+    int rc = tail_args_ok(N, C, P); if (rc) return rc;
+    if (!workspace || workspace_bytes < slak_block_tail_workspace_bytes(N, C, P)) return SLAK_ERR_WORKSPACE;
+    const TailDims d = make_dims(N, C, P);
+    const size_t lds = (((size_t)C * (d.TP + 2) * 2 + 15) & ~(size_t)15) + (((size_t)d.TP * (C + 2) * 2 + 15) & ~(size_t)15) +
+                       (size_t)2 * (BT_THREADS / d.TP) * d.TP * 4 + 4 * d.TP * 4;
+    if (set_lds((const void*)ln_nchw_to_nhwc_bwd_kernel, lds)) return SLAK_ERR_LAUNCH;
+    const int ntiles = N * d.tiles_per_image;
+    float* part = (float*)workspace;
+    hipLaunchKernelGGL(ln_nchw_to_nhwc_bwd_kernel, dim3((unsigned)ntiles), dim3(BT_THREADS), lds, (hipStream_t)stream,
+                       (const uint16_t*)g, (const uint16_t*)x, weight, mean, rstd, (uint16_t*)dx, part, d);
+    SLAK_LAUNCH_CHECK();
+    return reduce_partials(part, part + (size_t)ntiles * 2 * C, dweight, dbias, C, ntiles, 2 * C, (hipStream_t)stream);
+}
+
+int slak_scale_residual_forward(const void* shortcut, int shortcut_dtype, const void* z, const float* gamma, const float* sample_scale,
+                                float* out, int N, int C, int P, void* stream) {
+    if (!shortcut || !z || !gamma || !out) return SLAK_ERR_INVALID_ARG;
+    int rc = tail_args_ok(N, C, P); if (rc) return rc;
+    const TailDims d = make_dims(N, C, P);
+    const size_t lds = (size_t)d.TP * (C + 2) * 2 + 16;
+    const dim3 grid((unsigned)(N * d.tiles_per_image));
+    if (shortcut_dtype == SLAK_F32) {
+        if (set_lds((const void*)scale_residual_fwd_kernel<float>, lds)) return SLAK_ERR_LAUNCH;
+        hipLaunchKernelGGL(scale_residual_fwd_kernel<float>, grid, dim3(BT_THREADS), lds, (hipStream_t)stream,
+                           (const float*)shortcut, (const uint16_t*)z, gamma, sample_scale, out, d);
+    } else if (shortcut_dtype == SLAK_BF16) {
+        if (set_lds((const void*)scale_residual_fwd_kernel<bf16_t>, lds)) return SLAK_ERR_LAUNCH;
+        hipLaunchKernelGGL(scale_residual_fwd_kernel<bf16_t>, grid, dim3(BT_THREADS), lds, (hipStream_t)stream,
+                           (const bf16_t*)shortcut, (const uint16_t*)z, gamma, sample_scale, out, d);
+    } else return SLAK_ERR_UNSUPPORTED;
+    SLAK_LAUNCH_CHECK();
+    return SLAK_OK;
+}
+
+int slak_scale_residual_backward(const float* dout, const void* z, const float* gamma, const float* sample_scale,
+                                 void* dz, float* dgamma, int N, int C, int P, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!dout || !z || !gamma || !dz || !dgamma) return SLAK_ERR_INVALID_ARG;
+    int rc = tail_args_ok(N, C, P); if (rc) return rc;
+    if (!workspace || workspace_bytes < slak_block_tail_workspace_bytes(N, C, P)) return SLAK_ERR_WORKSPACE;
+    const TailDims d = make_dims(N, C, P);
+    const size_t lds = (size_t)C * (d.TP + 1) * 4 + (size_t)d.TP * (C + 2) * 2 + 16;
+    if (set_lds((const void*)scale_residual_bwd_kernel, lds)) return SLAK_ERR_LAUNCH;
+    const int ntiles = N * d.tiles_per_image;
+    float* part = (float*)workspace;
+    hipLaunchKernelGGL(scale_residual_bwd_kernel, dim3((unsigned)ntiles), dim3(BT_THREADS), lds, (hipStream_t)stream,
+                       dout, (const uint16_t*)z, gamma, sample_scale, (uint16_t*)dz, part, d);
+    SLAK_LAUNCH_CHECK();
+    return reduce_partials(part, part + (size_t)ntiles * 2 * C, dgamma, dgamma, C, ntiles, C, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -156,12 +156,36 @@ class Block(nn.Module):
     def forward(self, x):
         shortcut = x
         x = self.large_kernel(x)
+        if self.fused_tail and x.is_cuda and x.dtype == torch.bfloat16 and self.gamma is not None and x.shape[1] % 2 == 0:
+            return self._forward_fused_tail(shortcut, x)
         x = x.permute(0, 2, 3, 1)
         x = self.pwconv2(self.act(self.pwconv1(self.norm(x))))
         if self.gamma is not None:
             x = self.gamma * x
         x = x.permute(0, 3, 1, 2)
         return shortcut + self.drop_path(x)
+
+
+def _block_forward_fused_tail(self, shortcut, x):
+    """Same arithmetic as the lines below it in Block.forward, with the permute/LayerNorm and gamma/permute/residual steps as
+    one HIP kernel each (slak_amd/block_ops.py); the two Linear layers and GELU are unchanged."""
+    from . import block_ops
+    t = block_ops.ln_nchw_to_nhwc(x.contiguous(), self.norm.weight.float(), self.norm.bias.float(), self.norm.eps)
+    z = self.pwconv2(self.act(self.pwconv1(t)))
+    if z.dtype != torch.bfloat16:
+        z = z.to(torch.bfloat16)
+    scale = None
+    dp = self.drop_path
+    if isinstance(dp, DropPath) and dp.drop_prob > 0.0 and self.training:
+        keep = 1.0 - dp.drop_prob
+        scale = torch.empty(x.shape[0], device=x.device, dtype=torch.float32).bernoulli_(keep)
+        if keep > 0.0:
+            scale.div_(keep)
+    return block_ops.scale_residual(shortcut.contiguous(), z.contiguous(), self.gamma.float(), scale)
+
+
+Block._forward_fused_tail = _block_forward_fused_tail
+Block.fused_tail = False
 
 
 class SLaK(nn.Module):

@@ -1,0 +1,95 @@
+"""GPU parity tests of the block-tail glue kernels (pytest -m gpu).
+
+Reference arithmetic = the PyTorch lines of models/SLaK.py:153-166 evaluated in fp32/fp64 on the same bf16 inputs;
+the kernels compute in fp32 and round their bf16 outputs once, so the tolerance is bf16 output rounding (2^-8 relative).
+"""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+SHAPES = [(3, 96, 56, 56), (5, 192, 28, 28), (4, 384, 14, 14), (7, 768, 7, 7), (2, 64, 9, 11), (1, 130, 5, 3), (2, 256, 20, 20)]
+
+
+def _close(a, b, rel, what):
+    a, b = a.double(), b.double()
+    err = (a - b).abs().max().item()
+    scale = max(1e-6, b.abs().max().item())
+    assert err <= rel * scale, "%s: err %.3e vs scale %.3e" % (what, err, scale)
+
+
+@pytest.mark.parametrize("N,C,H,W", SHAPES)
+def test_ln_nchw_to_nhwc_matches_layer_norm(N, C, H, W, gpu):
+    from slak_amd import block_ops
+    torch.manual_seed(C + H)
+    x = (torch.randn(N, C, H, W, device=gpu) * 2 + 0.3).bfloat16().requires_grad_(True)
+    w = (torch.randn(C, device=gpu) * 0.5 + 1).requires_grad_(True)
+    b = (torch.randn(C, device=gpu) * 0.1).requires_grad_(True)
+    g = torch.randn(N, H, W, C, device=gpu).bfloat16()
+    y = block_ops.ln_nchw_to_nhwc(x, w, b, 1e-6)
+    assert y.dtype == torch.bfloat16 and y.shape == (N, H, W, C)
+    y.backward(g)
+    xr = x.detach().double().requires_grad_(True); wr = w.detach().double().requires_grad_(True); br = b.detach().double().requires_grad_(True)
+    yr = F.layer_norm(xr.permute(0, 2, 3, 1), (C,), wr, br, 1e-6)
+    yr.backward(g.double())
+    _close(y, yr, 2.0 ** -8 * 1.01, "y")
+    _close(x.grad, xr.grad, 2.0 ** -8 * 1.5, "dx")
+    _close(w.grad, wr.grad, 1e-4, "dweight")
+    _close(b.grad, br.grad, 1e-4, "dbias")
+
+
+@pytest.mark.parametrize("N,C,H,W", SHAPES)
+@pytest.mark.parametrize("sc_dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("with_scale", [False, True])
+def test_scale_residual_matches_torch(N, C, H, W, sc_dtype, with_scale, gpu):
+    from slak_amd import block_ops
+    torch.manual_seed(C + W)
+    sc = torch.randn(N, C, H, W, device=gpu).to(sc_dtype).requires_grad_(True)
+    z = torch.randn(N, H, W, C, device=gpu).bfloat16().requires_grad_(True)
+    gamma = (torch.randn(C, device=gpu) * 0.3).requires_grad_(True)
+    scale = (torch.rand(N, device=gpu) > 0.3).float() / 0.7 if with_scale else None
+    dout = torch.randn(N, C, H, W, device=gpu)
+    out = block_ops.scale_residual(sc, z, gamma, scale)
+    assert out.dtype == torch.float32
+    out.backward(dout)
+    scr = sc.detach().double().requires_grad_(True); zr = z.detach().double().requires_grad_(True); gr = gamma.detach().double().requires_grad_(True)
+    t = (gr * zr).permute(0, 3, 1, 2)
+    if scale is not None:
+        t = t * scale.double().view(N, 1, 1, 1)
+    outr = scr + t
+    outr.backward(dout.double())
+    _close(out, outr, 1e-6, "out")
+    _close(sc.grad, scr.grad, 2.0 ** -8 * 1.01 if sc_dtype == torch.bfloat16 else 1e-7, "dshortcut")
+    _close(z.grad, zr.grad, 2.0 ** -8 * 1.01, "dz")
+    _close(gamma.grad, gr.grad, 1e-4, "dgamma")
+    # determinism of the partial-sum reductions
+    sc2 = sc.detach().clone().requires_grad_(True); z2 = z.detach().clone().requires_grad_(True); g2 = gamma.detach().clone().requires_grad_(True)
+    block_ops.scale_residual(sc2, z2, g2, scale).backward(dout)
+    assert torch.equal(g2.grad, gamma.grad)
+
+
+def test_block_with_fused_tail_matches_reference_composition(gpu):
+    """A whole Block (dw convs + BN + tail) under bf16 autocast: fused tail vs the reference's op sequence."""
+    import slak_amd.slak_model as M
+    M.use_sync_bn = False
+    torch.manual_seed(0)
+    blk = M.Block(96, drop_path=0.0, layer_scale_init_value=0.5, kernel_size=(51, 5), Decom=True, bn=True, lowp_dwconv=True).to(gpu)
+    with torch.no_grad():
+        blk.gamma.uniform_(0.2, 0.8)
+    x = torch.randn(4, 96, 56, 56, device=gpu)
+    dy = torch.randn_like(x)
+    outs = {}
+    for fused in (False, True):
+        blk.fused_tail = fused
+        blk.zero_grad()
+        xi = x.clone().requires_grad_(True)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            y = blk(xi)
+        y.backward(dy)
+        outs[fused] = (y.detach(), xi.grad.detach(), blk.gamma.grad.clone(), blk.norm.weight.grad.clone(), blk.pwconv1.weight.grad.clone(),
+                       blk.large_kernel.LoRA1.conv.weight.grad.clone())
+    names = ("y", "dx", "dgamma", "dnorm.weight", "dpwconv1.weight", "dLoRA1.weight")
+    for a, b, n in zip(outs[True], outs[False], names):
+        assert a.dtype == b.dtype, n
+        _close(a, b, 3e-2, n)           # two bf16 pipelines with different rounding points
