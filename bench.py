@@ -43,6 +43,7 @@ def parse():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--kernel-reps", type=int, default=10)
     ap.add_argument("--fp32-dwconv", action="store_true", help="reference dtype flow: dw convs see fp32 even under autocast")
+    ap.add_argument("--no-fused-bn", action="store_true", help="run the three branch BatchNorms + adds as the reference's PyTorch modules")
     ap.add_argument("--no-fused-tail", action="store_true", help="run the block tail (permute/LayerNorm/gamma/residual) as the reference's PyTorch ops")
     return ap.parse_args()
 
@@ -151,6 +152,7 @@ def main():
     import slak_amd.slak_model as M
     from slak_amd.sparse_core import CosineDecay, Masking
     M.Block.fused_tail = not a.no_fused_tail and not a.fp32_dwconv    # HIP glue kernels around the pointwise GEMMs
+    M.ReparamLargeKernelConv.fused_bn = not a.no_fused_bn and not a.fp32_dwconv   # branch BatchNorms + adds as one HIP op
     M.use_sync_bn = True                                          # reference default (models/SLaK.py:19); falls back to BN math at world 1
     torch.manual_seed(0 + rank)                                   # main.py:232  seed = args.seed + rank
     model = M.SLaK_tiny(kernel_size=[51, 49, 47, 13, 5], Decom=True, bn=True, drop_path_rate=0.1,
@@ -217,6 +219,7 @@ def main():
                    "global_batch": n_gpus * a.batch, "per_gpu_batch": a.batch, "parallelism": "dp%d" % n_gpus,
                    "dwconv_dtype": "fp32" if a.fp32_dwconv else "bf16 in/out, fp32 accumulate", "optimizer": "AdamW(fused)",
                    "sync_bn": True, "block_tail": "hip (ln_nchw_to_nhwc + scale_residual)" if M.Block.fused_tail else "pytorch ops",
+                   "branch_bn": "hip (bn3: one stats pass + one apply pass)" if M.ReparamLargeKernelConv.fused_bn else "pytorch (Sync)BatchNorm x3 + adds",
                    "final_loss": final_loss},
     }
 

@@ -47,6 +47,12 @@ SIGNATURES = {
     "slak_mask_prune_and_grow": (_i, [_vp, _d, _vp]),
     "slak_mask_read_stats": (_i, [_vp, ctypes.POINTER(_d), _vp]),
     "slak_mask_checksum": (_i, [_vp, ctypes.POINTER(ctypes.c_ulonglong), _vp]),
+    "slak_bn3_workspace_bytes": (_sz, [_i, _i]),
+    "slak_bn3_forward_sums": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _sz, _vp]),
+    "slak_bn3_forward_apply": (_i, [_vp, _vp, _vp, _vp, _d, ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(_vp),
+                                    ctypes.c_float, ctypes.c_float, _i, _i, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    "slak_bn3_backward_sums": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _sz, _vp]),
+    "slak_bn3_backward_apply": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _d, _vp, ctypes.POINTER(_vp), _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "slak_block_tail_workspace_bytes": (_sz, [_i, _i, _i]),
     "slak_ln_nchw_to_nhwc_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, ctypes.c_float, _vp]),
     "slak_ln_nchw_to_nhwc_backward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _sz, _vp]),

@@ -134,3 +134,115 @@ class _LinearSplitK(torch.autograd.Function):
 
 def linear_splitk(x, weight, bias):
     return _LinearSplitK.apply(x, weight, bias)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# out = BN1(y1) + BN2(y2) + BN3(y3)   (models/SLaK.py:38-47, :92-95)
+def _ptr3(ts):
+    import ctypes
+    arr = (ctypes.c_void_p * 3)(*[t.data_ptr() for t in ts])
+    return arr
+
+
+class _BranchBN3(torch.autograd.Function):
+    """Training-mode batch statistics (cross-rank when ``group`` is given: one all-reduce of 6C+1 floats forward and 4C backward,
+    instead of SyncBatchNorm's three all_gathers + three all_reduces per block), running-stat update, fused scale/shift/add."""
+
+    @staticmethod
+    def forward(ctx, y1, y2, y3, g1, b1, g2, b2, g3, b3, bns, group):
+        import torch.distributed as dist
+        for t, n in ((y1, "y1"), (y2, "y2"), (y3, "y3")):
+            _chk(t, n, torch.bfloat16)
+        N, C, H, W = y1.shape
+        P = H * W
+        dev = y1.device
+        L = _lib.lib()
+        gam, bet = [g1, g2, g3], [b1, b2, b3]
+        rmean = [bn.running_mean for bn in bns]; rvar = [bn.running_var for bn in bns]
+        eps = float(bns[0].eps)
+        momentum = bns[0].momentum
+        for bn in bns:
+            if bn.track_running_stats and bn.num_batches_tracked is not None:
+                bn.num_batches_tracked.add_(1)
+        if momentum is None:                                     # cumulative moving average, as nn.BatchNorm
+            momentum = 1.0 / float(bns[0].num_batches_tracked.item())
+        ws, nb = _workspace(L.slak_bn3_workspace_bytes(N, C), dev)
+        sums = torch.empty(C * 6 + 1, dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(L.slak_bn3_forward_sums(y1.data_ptr(), y2.data_ptr(), y3.data_ptr(), sums.data_ptr(), N, C, P,
+                                               ws.data_ptr(), nb, _stream(dev)), "slak_bn3_forward_sums")
+        count = float(N * P)
+        if group is not None:
+            sums[C * 6] = count
+            dist.all_reduce(sums, group=group)
+            count = float(sums[C * 6].item())
+        coef = torch.empty(C * 4, dtype=torch.float32, device=dev)
+        stats = torch.empty(C * 6, dtype=torch.float32, device=dev)
+        out = torch.empty_like(y1)
+        with torch.cuda.device(dev):
+            _lib.check(L.slak_bn3_forward_apply(y1.data_ptr(), y2.data_ptr(), y3.data_ptr(), sums.data_ptr(), count,
+                                                _ptr3(gam), _ptr3(bet), _ptr3(rmean), _ptr3(rvar), eps, float(momentum), 1,
+                                                1 if bns[0].track_running_stats else 0,
+                                                coef.data_ptr(), stats.data_ptr(), out.data_ptr(), N, C, P, _stream(dev)), "slak_bn3_forward_apply")
+        ctx.save_for_backward(y1, y2, y3, g1, g2, g3, stats)
+        ctx.group = group
+        ctx.count = count
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        import torch.distributed as dist
+        y1, y2, y3, g1, g2, g3, stats = ctx.saved_tensors
+        N, C, H, W = y1.shape
+        P = H * W
+        dev = y1.device
+        dout = dout.contiguous()
+        if dout.dtype != torch.bfloat16:
+            dout = dout.to(torch.bfloat16)
+        L = _lib.lib()
+        ws, nb = _workspace(L.slak_bn3_workspace_bytes(N, C), dev)
+        lsums = torch.empty(C * 4, dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(L.slak_bn3_backward_sums(dout.data_ptr(), y1.data_ptr(), y2.data_ptr(), y3.data_ptr(), lsums.data_ptr(), N, C, P,
+                                                ws.data_ptr(), nb, _stream(dev)), "slak_bn3_backward_sums")
+        gsums = lsums
+        if ctx.group is not None:
+            gsums = lsums.clone()
+            dist.all_reduce(gsums, group=ctx.group)
+        bcoef = torch.empty(C * 9, dtype=torch.float32, device=dev)
+        dgamma = torch.empty(3, C, dtype=torch.float32, device=dev)
+        dbeta = torch.empty(3, C, dtype=torch.float32, device=dev)
+        d1, d2, d3 = torch.empty_like(y1), torch.empty_like(y2), torch.empty_like(y3)
+        with torch.cuda.device(dev):
+            _lib.check(L.slak_bn3_backward_apply(dout.data_ptr(), y1.data_ptr(), y2.data_ptr(), y3.data_ptr(), gsums.data_ptr(),
+                                                 lsums.data_ptr(), ctx.count, stats.data_ptr(), _ptr3([g1, g2, g3]),
+                                                 bcoef.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(),
+                                                 d1.data_ptr(), d2.data_ptr(), d3.data_ptr(), N, C, P, _stream(dev)), "slak_bn3_backward_apply")
+        return d1, d2, d3, dgamma[0], dbeta[0], dgamma[1], dbeta[1], dgamma[2], dbeta[2], None, None
+
+
+def branch_bn3(y1, y2, y3, bn1, bn2, bn3):
+    """``bn1(y1) + bn2(y2) + bn3(y3)`` for three nn.BatchNorm2d / nn.SyncBatchNorm modules (their parameters and buffers are used and
+    updated in place).  Training: batch statistics (synchronised across the default/``process_group`` ranks for SyncBatchNorm);
+    eval: running statistics."""
+    import torch.distributed as dist
+    bns = (bn1, bn2, bn3)
+    if bn1.training or not bn1.track_running_stats:
+        group = None
+        if isinstance(bn1, torch.nn.SyncBatchNorm) and dist.is_available() and dist.is_initialized():
+            pg = bn1.process_group if bn1.process_group is not None else dist.group.WORLD
+            if dist.get_world_size(pg) > 1:
+                group = pg
+        return _BranchBN3.apply(y1, y2, y3, bn1.weight, bn1.bias, bn2.weight, bn2.bias, bn3.weight, bn3.bias, bns, group)
+    # eval: one apply pass with coefficients from the running statistics (no autograd needed for the statistics)
+    N, C, H, W = y1.shape
+    L = _lib.lib()
+    coef = torch.empty(C * 4, dtype=torch.float32, device=y1.device)
+    out = torch.empty_like(y1)
+    with torch.cuda.device(y1.device):
+        _lib.check(L.slak_bn3_forward_apply(y1.data_ptr(), y2.data_ptr(), y3.data_ptr(), None, 0.0,
+                                            _ptr3([b.weight for b in bns]), _ptr3([b.bias for b in bns]),
+                                            _ptr3([b.running_mean for b in bns]), _ptr3([b.running_var for b in bns]),
+                                            float(bn1.eps), 0.0, 0, 0, coef.data_ptr(), None, out.data_ptr(), N, C, H * W, _stream(y1.device)),
+                   "slak_bn3_forward_apply")
+    return out

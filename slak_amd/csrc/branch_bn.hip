@@ -1,0 +1,324 @@
+// slak_amd/csrc/branch_bn.hip -- the three branch BatchNorms + the two adds of ReparamLargeKernelConv as ONE op
+// (reference models/SLaK.py:38-47, :92-95):
+//
+//     out = BN1(y1) + BN2(y2) + BN3(y3)          y_b = LoRA1 / LoRA2 / small_conv output, (N,C,H,W) bf16
+//
+// PyTorch runs this as 3 BatchNorm kernels (each reads its input twice) and 2 adds per direction: ~18 passes over the
+// activation per block.  Here: one statistics pass over the three inputs, a per-channel finalise, one apply pass.
+//   forward : rowsums (sum y_b, sum y_b^2 per (n,c) row)  ->  [SyncBN: all-reduce of 6C+1 floats]  ->  finalize (mean, invstd,
+//             running stats, fused scale_b / shift)  ->  apply:  out = sum_b scale_b[c]*y_b + shift[c]
+//   backward: rowsums (sum dout, sum dout*y_b)  ->  [all-reduce 4C]  ->  finalize (dgamma_b, dbeta_b, per-channel A,B,C)  ->
+//             apply:  dy_b = A_b[c]*dout + B_b[c]*y_b + C_b[c]     (the BatchNorm backward is affine in (dout, y_b) per channel)
+// The tensors are treated as [N*C rows][P = H*W columns]: one wavefront per row with vector loads and a wavefront-wide
+// reduction; per-channel sums add the N rows of a channel in a fixed order (deterministic).  All HBM-bound.
+#include "slak_common.h"
+
+namespace slak {
+
+constexpr int BN_THREADS = 256;
+
+__device__ __forceinline__ float bnf(uint16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+typedef __attribute__((ext_vector_type(2))) float bn_f32x2;
+typedef __attribute__((ext_vector_type(2))) __bf16 bn_bf16x2;
+__device__ __forceinline__ unsigned bn_pack2(float a, float b) { return __builtin_bit_cast(unsigned, __builtin_convertvector(bn_f32x2{a, b}, bn_bf16x2)); }
+
+__device__ __forceinline__ float bn_wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// 8 consecutive bf16 of a row; zeros beyond P.  mode 2: rows 16-byte aligned (P % 8 == 0), 1: 8-byte aligned (P % 4 == 0), 0: scalar
+__device__ __forceinline__ void unpack2(unsigned u, float& a, float& b) { a = bnf((uint16_t)(u & 0xffff)); b = bnf((uint16_t)(u >> 16)); }
+__device__ __forceinline__ void load8(const uint16_t* __restrict__ row, int p, int P, int mode, float (&v)[8]) {
+    if (mode == 2 && p + 8 <= P) {
+        const uint4 u = *(const uint4*)(row + p);
+        unpack2(u.x, v[0], v[1]); unpack2(u.y, v[2], v[3]); unpack2(u.z, v[4], v[5]); unpack2(u.w, v[6], v[7]);
+    } else if (mode == 1) {
+        uint2 lo = uint2{0u, 0u}, hi = uint2{0u, 0u};
+        if (p + 4 <= P) lo = *(const uint2*)(row + p);
+        if (p + 8 <= P) hi = *(const uint2*)(row + p + 4);
+        unpack2(lo.x, v[0], v[1]); unpack2(lo.y, v[2], v[3]); unpack2(hi.x, v[4], v[5]); unpack2(hi.y, v[6], v[7]);
+    } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (p + e < P) ? bnf(row[p + e]) : 0.f;
+    }
+}
+__device__ __forceinline__ void store8(uint16_t* __restrict__ row, int p, int P, int mode, const float (&v)[8]) {
+    if (mode == 2 && p + 8 <= P) {
+        uint4 u; u.x = bn_pack2(v[0], v[1]); u.y = bn_pack2(v[2], v[3]); u.z = bn_pack2(v[4], v[5]); u.w = bn_pack2(v[6], v[7]);
+        *(uint4*)(row + p) = u;
+    } else if (mode == 1) {
+        if (p + 4 <= P) *(uint2*)(row + p) = uint2{bn_pack2(v[0], v[1]), bn_pack2(v[2], v[3])};
+        if (p + 8 <= P) *(uint2*)(row + p + 4) = uint2{bn_pack2(v[4], v[5]), bn_pack2(v[6], v[7])};
+    } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) if (p + e < P) row[p + e] = (uint16_t)(bn_pack2(v[e], 0.f) & 0xffffu);
+    }
+}
+
+// rows[r][0..5] = sum y1, sum y1^2, sum y2, sum y2^2, sum y3, sum y3^2 over the P elements of row r
+__global__ __launch_bounds__(BN_THREADS) void bn3_rowsums_fwd(const uint16_t* __restrict__ y1, const uint16_t* __restrict__ y2,
+                                                            const uint16_t* __restrict__ y3, float* __restrict__ rows, int R, int P) {
+    const int lane = threadIdx.x & 63, wv = blockIdx.x * (BN_THREADS / 64) + (threadIdx.x >> 6), nw = gridDim.x * (BN_THREADS / 64);
+    const int vec = (P & 7) == 0 ? 2 : ((P & 3) == 0 ? 1 : 0);
+    for (int r = wv; r < R; r += nw) {
+        const size_t base = (size_t)r * P;
+        float s[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int p = lane * 8; p < P; p += 64 * 8) {
+            float a[8], b[8], c[8];
+            load8(y1 + base, p, P, vec, a); load8(y2 + base, p, P, vec, b); load8(y3 + base, p, P, vec, c);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { s[0] += a[e]; s[1] += a[e] * a[e]; s[2] += b[e]; s[3] += b[e] * b[e]; s[4] += c[e]; s[5] += c[e] * c[e]; }
+        }
+#pragma unroll
+        for (int k = 0; k < 6; ++k) s[k] = bn_wave_sum(s[k]);
+        if (lane < 6) rows[(size_t)r * 6 + lane] = s[lane];
+    }
+}
+
+// rows[r][0..3] = sum dout, sum dout*y1, sum dout*y2, sum dout*y3
+__global__ __launch_bounds__(BN_THREADS) void bn3_rowsums_bwd(const uint16_t* __restrict__ dout, const uint16_t* __restrict__ y1,
+                                                            const uint16_t* __restrict__ y2, const uint16_t* __restrict__ y3,
+                                                            float* __restrict__ rows, int R, int P) {
+    const int lane = threadIdx.x & 63, wv = blockIdx.x * (BN_THREADS / 64) + (threadIdx.x >> 6), nw = gridDim.x * (BN_THREADS / 64);
+    const int vec = (P & 7) == 0 ? 2 : ((P & 3) == 0 ? 1 : 0);
+    for (int r = wv; r < R; r += nw) {
+        const size_t base = (size_t)r * P;
+        float s[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int p = lane * 8; p < P; p += 64 * 8) {
+            float g[8], a[8], b[8], c[8];
+            load8(dout + base, p, P, vec, g); load8(y1 + base, p, P, vec, a); load8(y2 + base, p, P, vec, b); load8(y3 + base, p, P, vec, c);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { s[0] += g[e]; s[1] += g[e] * a[e]; s[2] += g[e] * b[e]; s[3] += g[e] * c[e]; }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) s[k] = bn_wave_sum(s[k]);
+        if (lane < 4) rows[(size_t)r * 4 + lane] = s[lane];
+    }
+}
+
+// sums[c][k] = sum_n rows[(n*C + c)][k]   (fixed order over n)
+__global__ void bn3_colreduce(const float* __restrict__ rows, float* __restrict__ sums, int N, int C, int K) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= C * K) return;
+    const int c = i / K, k = i - c * K;
+    float s = 0.f;
+    for (int n = 0; n < N; ++n) s += rows[((size_t)n * C + c) * K + k];
+    sums[i] = s;
+}
+
+// Forward finalise.  sums[c][6] are GLOBAL sums (after the SyncBN all-reduce), count = global N*P.
+// coef[c][0..3] = scale_1, scale_2, scale_3, shift;  stats[c][0..5] = mean_b, invstd_b (saved for backward);
+// running stats updated in place like nn.BatchNorm2d (momentum, unbiased variance).
+struct Bn3Params {
+    const float* gamma[3]; const float* beta[3];
+    float* running_mean[3]; float* running_var[3];
+};
+__global__ void bn3_finalize_fwd(const float* __restrict__ sums, Bn3Params bp, float* __restrict__ coef, float* __restrict__ stats,
+                                 int C, float count, float eps, float momentum, int update_running) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float shift = 0.f;
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+        const float mean = sums[c * 6 + 2 * b] / count;
+        float var = sums[c * 6 + 2 * b + 1] / count - mean * mean;
+        var = var > 0.f ? var : 0.f;
+        const float inv = 1.0f / sqrtf(var + eps);
+        const float sc = bp.gamma[b][c] * inv;
+        coef[c * 4 + b] = sc;
+        shift += bp.beta[b][c] - mean * sc;
+        stats[c * 6 + 2 * b] = mean; stats[c * 6 + 2 * b + 1] = inv;
+        if (update_running) {
+            const float unb = count > 1.f ? var * count / (count - 1.f) : var;
+            bp.running_mean[b][c] = (1.f - momentum) * bp.running_mean[b][c] + momentum * mean;
+            bp.running_var[b][c] = (1.f - momentum) * bp.running_var[b][c] + momentum * unb;
+        }
+    }
+    coef[c * 4 + 3] = shift;
+}
+// Eval mode: coefficients from the running statistics
+__global__ void bn3_finalize_eval(Bn3Params bp, float* __restrict__ coef, int C, float eps) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float shift = 0.f;
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+        const float sc = bp.gamma[b][c] / sqrtf(bp.running_var[b][c] + eps);
+        coef[c * 4 + b] = sc;
+        shift += bp.beta[b][c] - bp.running_mean[b][c] * sc;
+    }
+    coef[c * 4 + 3] = shift;
+}
+
+// out[r][p] = coef[c][0]*y1 + coef[c][1]*y2 + coef[c][2]*y3 + coef[c][3],  c = r % C
+__global__ __launch_bounds__(BN_THREADS) void bn3_apply_fwd(const uint16_t* __restrict__ y1, const uint16_t* __restrict__ y2,
+                                                          const uint16_t* __restrict__ y3, const float* __restrict__ coef,
+                                                          uint16_t* __restrict__ out, int R, int C, int P) {
+    const int lane = threadIdx.x & 63, wv = blockIdx.x * (BN_THREADS / 64) + (threadIdx.x >> 6), nw = gridDim.x * (BN_THREADS / 64);
+    const int vec = (P & 7) == 0 ? 2 : ((P & 3) == 0 ? 1 : 0);
+    for (int r = wv; r < R; r += nw) {
+        const int c = r % C;
+        const float k1 = coef[c * 4], k2 = coef[c * 4 + 1], k3 = coef[c * 4 + 2], k0 = coef[c * 4 + 3];
+        const size_t base = (size_t)r * P;
+        for (int p = lane * 8; p < P; p += 64 * 8) {
+            float a[8], b[8], cc[8], o[8];
+            load8(y1 + base, p, P, vec, a); load8(y2 + base, p, P, vec, b); load8(y3 + base, p, P, vec, cc);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = k1 * a[e] + k2 * b[e] + k3 * cc[e] + k0;
+            store8(out + base, p, P, vec, o);
+        }
+    }
+}
+
+// Backward finalise.  sums[c][4] GLOBAL: sum dout, sum dout*y_b.  stats[c][6] = mean_b, invstd_b.
+// dgamma_b = invstd_b*(sum dout*y_b - mean_b*sum dout), dbeta_b = sum dout (LOCAL sums give the local parameter gradients that DDP
+// then all-reduces, exactly like SyncBatchNorm: the caller passes local sums for the gradients and global sums for the coefficients).
+// bcoef[c][b][0..2] = A, B, C0 with dy_b = A*dout + B*y_b + C0.
+__global__ void bn3_finalize_bwd(const float* __restrict__ gsums, const float* __restrict__ lsums, const float* __restrict__ stats,
+                                 Bn3Params bp, float* __restrict__ bcoef, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                 int C, float count) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+        const float mean = stats[c * 6 + 2 * b], inv = stats[c * 6 + 2 * b + 1], g = bp.gamma[b][c];
+        const float gd = gsums[c * 4], gdy = gsums[c * 4 + 1 + b];
+        const float dgam_g = inv * (gdy - mean * gd);                    // global dgamma (for the input gradient)
+        const float A = g * inv;
+        const float B = -g * inv * inv * dgam_g / count;
+        bcoef[(c * 3 + b) * 3 + 0] = A;
+        bcoef[(c * 3 + b) * 3 + 1] = B;
+        bcoef[(c * 3 + b) * 3 + 2] = -A * gd / count - B * mean;
+        dgamma[b * C + c] = inv * (lsums[c * 4 + 1 + b] - mean * lsums[c * 4]);
+        dbeta[b * C + c] = lsums[c * 4];
+    }
+}
+
+// dy_b[r][p] = A_b*dout + B_b*y_b + C_b
+__global__ __launch_bounds__(BN_THREADS) void bn3_apply_bwd(const uint16_t* __restrict__ dout, const uint16_t* __restrict__ y1,
+                                                          const uint16_t* __restrict__ y2, const uint16_t* __restrict__ y3,
+                                                          const float* __restrict__ bcoef, uint16_t* __restrict__ d1,
+                                                          uint16_t* __restrict__ d2, uint16_t* __restrict__ d3, int R, int C, int P) {
+    const int lane = threadIdx.x & 63, wv = blockIdx.x * (BN_THREADS / 64) + (threadIdx.x >> 6), nw = gridDim.x * (BN_THREADS / 64);
+    const int vec = (P & 7) == 0 ? 2 : ((P & 3) == 0 ? 1 : 0);
+    for (int r = wv; r < R; r += nw) {
+        const int c = r % C;
+        float k[9];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) k[i] = bcoef[c * 9 + i];
+        const size_t base = (size_t)r * P;
+        for (int p = lane * 8; p < P; p += 64 * 8) {
+            float g[8], a[8], o[8];
+            load8(dout + base, p, P, vec, g);
+            load8(y1 + base, p, P, vec, a);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = k[0] * g[e] + k[1] * a[e] + k[2];
+            store8(d1 + base, p, P, vec, o);
+            load8(y2 + base, p, P, vec, a);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = k[3] * g[e] + k[4] * a[e] + k[5];
+            store8(d2 + base, p, P, vec, o);
+            load8(y3 + base, p, P, vec, a);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = k[6] * g[e] + k[7] * a[e] + k[8];
+            store8(d3 + base, p, P, vec, o);
+        }
+    }
+}
+
+static int bn_grid(int R) {
+    long long g = ((long long)R + (BN_THREADS / 64) - 1) / (BN_THREADS / 64);
+    const long long cap = 256LL * 16;
+    return (int)(g < cap ? g : cap);
+}
+
+}  // namespace slak
+
+using namespace slak;
+
+extern "C" {
+
+/* scratch: rows[N*C][6] + sums[C][6] */
+size_t slak_bn3_workspace_bytes(int N, int C) { return (N <= 0 || C <= 0) ? 0 : align_up(((size_t)N * C * 6 + (size_t)C * 6) * sizeof(float), 256); }
+
+static int bn_args_ok(int N, int C, int P) {
+    if (N <= 0 || C <= 0 || P <= 0) return SLAK_ERR_INVALID_ARG;
+    if ((long long)N * C * P >= (1LL << 31)) return SLAK_ERR_UNSUPPORTED;
+    return SLAK_OK;
+}
+
+/* local_sums[C][6] = per-channel sums of y_b and y_b^2 over this rank's batch */
+int slak_bn3_forward_sums(const void* y1, const void* y2, const void* y3, float* local_sums, int N, int C, int P,
+                          void* workspace, size_t workspace_bytes, void* stream) {
+    if (!y1 || !y2 || !y3 || !local_sums) return SLAK_ERR_INVALID_ARG;
+    int rc = bn_args_ok(N, C, P); if (rc) return rc;
+    if (!workspace || workspace_bytes < slak_bn3_workspace_bytes(N, C)) return SLAK_ERR_WORKSPACE;
+    float* rows = (float*)workspace;
+    const int R = N * C;
+    hipLaunchKernelGGL(bn3_rowsums_fwd, dim3(bn_grid(R)), dim3(BN_THREADS), 0, (hipStream_t)stream,
+                       (const uint16_t*)y1, (const uint16_t*)y2, (const uint16_t*)y3, rows, R, P);
+    hipLaunchKernelGGL(bn3_colreduce, dim3((C * 6 + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const float*)rows, local_sums, N, C, 6);
+    SLAK_LAUNCH_CHECK();
+    return SLAK_OK;
+}
+
+/* gamma/beta/running_*: arrays of 3 device pointers (host memory).  training != 0: statistics from global_sums / count, running stats
+ * updated; training == 0: running statistics (global_sums ignored).  Writes coef[C][4], stats[C][6] and out. */
+int slak_bn3_forward_apply(const void* y1, const void* y2, const void* y3, const float* global_sums, double count,
+                           const float* const* gamma, const float* const* beta, float* const* running_mean, float* const* running_var,
+                           float eps, float momentum, int training, int update_running,
+                           float* coef, float* stats, void* out, int N, int C, int P, void* stream) {
+    if (!y1 || !y2 || !y3 || !gamma || !beta || !running_mean || !running_var || !coef || !out) return SLAK_ERR_INVALID_ARG;
+    if (training && (!global_sums || !stats)) return SLAK_ERR_INVALID_ARG;
+    int rc = bn_args_ok(N, C, P); if (rc) return rc;
+    Bn3Params bp;
+    for (int b = 0; b < 3; ++b) { bp.gamma[b] = gamma[b]; bp.beta[b] = beta[b]; bp.running_mean[b] = running_mean[b]; bp.running_var[b] = running_var[b]; }
+    if (training)
+        hipLaunchKernelGGL(bn3_finalize_fwd, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, global_sums, bp, coef, stats, C,
+                           (float)count, eps, momentum, update_running);
+    else
+        hipLaunchKernelGGL(bn3_finalize_eval, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, bp, coef, C, eps);
+    const int R = N * C;
+    hipLaunchKernelGGL(bn3_apply_fwd, dim3(bn_grid(R)), dim3(BN_THREADS), 0, (hipStream_t)stream,
+                       (const uint16_t*)y1, (const uint16_t*)y2, (const uint16_t*)y3, (const float*)coef, (uint16_t*)out, R, C, P);
+    SLAK_LAUNCH_CHECK();
+    return SLAK_OK;
+}
+
+/* local_sums[C][4] = sum dout, sum dout*y_b over this rank's batch */
+int slak_bn3_backward_sums(const void* dout, const void* y1, const void* y2, const void* y3, float* local_sums, int N, int C, int P,
+                           void* workspace, size_t workspace_bytes, void* stream) {
+    if (!dout || !y1 || !y2 || !y3 || !local_sums) return SLAK_ERR_INVALID_ARG;
+    int rc = bn_args_ok(N, C, P); if (rc) return rc;
+    if (!workspace || workspace_bytes < slak_bn3_workspace_bytes(N, C)) return SLAK_ERR_WORKSPACE;
+    float* rows = (float*)workspace;
+    const int R = N * C;
+    hipLaunchKernelGGL(bn3_rowsums_bwd, dim3(bn_grid(R)), dim3(BN_THREADS), 0, (hipStream_t)stream,
+                       (const uint16_t*)dout, (const uint16_t*)y1, (const uint16_t*)y2, (const uint16_t*)y3, rows, R, P);
+    hipLaunchKernelGGL(bn3_colreduce, dim3((C * 4 + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const float*)rows, local_sums, N, C, 4);
+    SLAK_LAUNCH_CHECK();
+    return SLAK_OK;
+}
+
+/* dgamma, dbeta: [3][C] (local gradients); bcoef scratch [C][9]; dy1..3 outputs */
+int slak_bn3_backward_apply(const void* dout, const void* y1, const void* y2, const void* y3, const float* global_sums,
+                            const float* local_sums, double count, const float* stats, const float* const* gamma,
+                            float* bcoef, float* dgamma, float* dbeta, void* dy1, void* dy2, void* dy3, int N, int C, int P, void* stream) {
+    if (!dout || !y1 || !y2 || !y3 || !global_sums || !local_sums || !stats || !gamma || !bcoef || !dgamma || !dbeta || !dy1 || !dy2 || !dy3)
+        return SLAK_ERR_INVALID_ARG;
+    int rc = bn_args_ok(N, C, P); if (rc) return rc;
+    Bn3Params bp;
+    for (int b = 0; b < 3; ++b) { bp.gamma[b] = gamma[b]; bp.beta[b] = nullptr; bp.running_mean[b] = nullptr; bp.running_var[b] = nullptr; }
+    hipLaunchKernelGGL(bn3_finalize_bwd, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, global_sums, local_sums, stats, bp,
+                       bcoef, dgamma, dbeta, C, (float)count);
+    const int R = N * C;
+    hipLaunchKernelGGL(bn3_apply_bwd, dim3(bn_grid(R)), dim3(BN_THREADS), 0, (hipStream_t)stream,
+                       (const uint16_t*)dout, (const uint16_t*)y1, (const uint16_t*)y2, (const uint16_t*)y3, (const float*)bcoef,
+                       (uint16_t*)dy1, (uint16_t*)dy2, (uint16_t*)dy3, R, C, P);
+    SLAK_LAUNCH_CHECK();
+    return SLAK_OK;
+}
+
+}  // extern "C"

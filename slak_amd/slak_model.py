@@ -112,6 +112,12 @@ class ReparamLargeKernelConv(nn.Module):
             inputs = inputs.to(torch.get_autocast_dtype("cuda"))
         if hasattr(self, 'lkb_reparam'):
             return self.lkb_reparam(inputs)
+        if (self.fused_bn and self.Decom and hasattr(self, 'small_conv') and inputs.is_cuda and inputs.dtype == torch.bfloat16
+                and hasattr(self.LoRA1, 'bn') and (self.training or not torch.is_grad_enabled())):
+            # same arithmetic, the three BatchNorms and the two adds as one HIP op (slak_amd/block_ops.py)
+            from . import block_ops
+            return block_ops.branch_bn3(self.LoRA1.conv(inputs), self.LoRA2.conv(inputs), self.small_conv.conv(inputs),
+                                        self.LoRA1.bn, self.LoRA2.bn, self.small_conv.bn)
         if self.Decom:
             out = self.LoRA1(inputs) + self.LoRA2(inputs)
         else:
@@ -186,6 +192,7 @@ def _block_forward_fused_tail(self, shortcut, x):
 
 Block._forward_fused_tail = _block_forward_fused_tail
 Block.fused_tail = False
+ReparamLargeKernelConv.fused_bn = False
 
 
 class SLaK(nn.Module):

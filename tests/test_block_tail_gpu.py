@@ -93,3 +93,41 @@ def test_block_with_fused_tail_matches_reference_composition(gpu):
     for a, b, n in zip(outs[True], outs[False], names):
         assert a.dtype == b.dtype, n
         _close(a, b, 3e-2, n)           # two bf16 pipelines with different rounding points
+
+
+@pytest.mark.parametrize("N,C,H,W", [(4, 96, 56, 56), (5, 192, 28, 28), (6, 384, 14, 14), (8, 768, 7, 7), (3, 10, 9, 11)])
+def test_branch_bn3_matches_three_batchnorms(N, C, H, W, gpu):
+    """bn1(y1)+bn2(y2)+bn3(y3): outputs, input grads, parameter grads and running statistics vs nn.BatchNorm2d in fp64."""
+    import copy
+    import torch.nn as nn
+    from slak_amd import block_ops
+    torch.manual_seed(C + H)
+    bns = [nn.BatchNorm2d(C).to(gpu) for _ in range(3)]
+    for bn in bns:
+        with torch.no_grad():
+            bn.weight.uniform_(0.5, 1.5); bn.bias.uniform_(-0.3, 0.3)
+            bn.running_mean.uniform_(-0.2, 0.2); bn.running_var.uniform_(0.5, 2.0)
+    refs = [copy.deepcopy(bn).double() for bn in bns]
+    ys = [((torch.randn(N, C, H, W, device=gpu) * (1 + i) + 0.1 * i).bfloat16()).requires_grad_(True) for i in range(3)]
+    dout = torch.randn(N, C, H, W, device=gpu).bfloat16()
+    out = block_ops.branch_bn3(ys[0], ys[1], ys[2], *bns)
+    assert out.dtype == torch.bfloat16
+    out.backward(dout)
+    yr = [y.detach().double().requires_grad_(True) for y in ys]
+    outr = refs[0](yr[0]) + refs[1](yr[1]) + refs[2](yr[2])
+    outr.backward(dout.double())
+    _close(out, outr, 2.0 ** -8 * 1.05, "out")
+    for i in range(3):
+        _close(ys[i].grad, yr[i].grad, 2.0 ** -8 * 1.5, "dy%d" % i)
+        _close(bns[i].weight.grad, refs[i].weight.grad, 2e-4, "dgamma%d" % i)
+        _close(bns[i].bias.grad, refs[i].bias.grad, 2e-4, "dbeta%d" % i)
+        _close(bns[i].running_mean, refs[i].running_mean, 1e-5, "running_mean%d" % i)
+        _close(bns[i].running_var, refs[i].running_var, 1e-5, "running_var%d" % i)
+        assert int(bns[i].num_batches_tracked) == 1
+    # eval mode uses the running statistics
+    for bn in bns + refs:
+        bn.eval()
+    with torch.no_grad():
+        oe = block_ops.branch_bn3(ys[0].detach(), ys[1].detach(), ys[2].detach(), *bns)
+        oer = refs[0](yr[0].detach()) + refs[1](yr[1].detach()) + refs[2](yr[2].detach())
+    _close(oe, oer, 2.0 ** -8 * 1.05, "eval out")
