@@ -125,10 +125,10 @@ class _LinearSplitK(torch.autograd.Function):
         while S > 1 and M % S:
             S -= 1
         if S > 1:
-            dw = torch.bmm(dy2.view(S, M // S, -1).transpose(1, 2), x2.view(S, M // S, -1)).float().sum(0)
+            dw = torch.bmm(dy2.view(S, M // S, -1).transpose(1, 2), x2.view(S, M // S, -1)).sum(0, dtype=torch.float32)
         else:
             dw = torch.mm(dy2.t(), x2).float()
-        db = dy2.float().sum(0) if ctx.has_bias else None
+        db = dy2.sum(0, dtype=torch.float32) if ctx.has_bias else None
         return dx, dw, db
 
 

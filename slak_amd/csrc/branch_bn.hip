@@ -98,14 +98,15 @@ __global__ __launch_bounds__(BN_THREADS) void bn3_rowsums_bwd(const uint16_t* __
     }
 }
 
-// sums[c][k] = sum_n rows[(n*C + c)][k]   (fixed order over n)
-__global__ void bn3_colreduce(const float* __restrict__ rows, float* __restrict__ sums, int N, int C, int K) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= C * K) return;
-    const int c = i / K, k = i - c * K;
-    float s = 0.f;
-    for (int n = 0; n < N; ++n) s += rows[((size_t)n * C + c) * K + k];
-    sums[i] = s;
+// sums[c][k] = sum_n rows[(n*C + c)][k]: one wavefront per channel, lanes over n, fixed butterfly order (deterministic)
+__global__ __launch_bounds__(64) void bn3_colreduce(const float* __restrict__ rows, float* __restrict__ sums, int N, int C, int K) {
+    const int c = blockIdx.x, lane = threadIdx.x;
+    float s[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int n = lane; n < N; n += 64) {
+        const float* r = rows + ((size_t)n * C + c) * K;
+        for (int k = 0; k < K; ++k) s[k] += r[k];
+    }
+    for (int k = 0; k < K; ++k) { const float t = bn_wave_sum(s[k]); if (lane == 0) sums[c * K + k] = t; }
 }
 
 // Forward finalise.  sums[c][6] are GLOBAL sums (after the SyncBN all-reduce), count = global N*P.
@@ -259,7 +260,7 @@ int slak_bn3_forward_sums(const void* y1, const void* y2, const void* y3, float*
     const int R = N * C;
     hipLaunchKernelGGL(bn3_rowsums_fwd, dim3(bn_grid(R)), dim3(BN_THREADS), 0, (hipStream_t)stream,
                        (const uint16_t*)y1, (const uint16_t*)y2, (const uint16_t*)y3, rows, R, P);
-    hipLaunchKernelGGL(bn3_colreduce, dim3((C * 6 + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const float*)rows, local_sums, N, C, 6);
+    hipLaunchKernelGGL(bn3_colreduce, dim3(C), dim3(64), 0, (hipStream_t)stream, (const float*)rows, local_sums, N, C, 6);
     SLAK_LAUNCH_CHECK();
     return SLAK_OK;
 }
@@ -297,7 +298,7 @@ int slak_bn3_backward_sums(const void* dout, const void* y1, const void* y2, con
     const int R = N * C;
     hipLaunchKernelGGL(bn3_rowsums_bwd, dim3(bn_grid(R)), dim3(BN_THREADS), 0, (hipStream_t)stream,
                        (const uint16_t*)dout, (const uint16_t*)y1, (const uint16_t*)y2, (const uint16_t*)y3, rows, R, P);
-    hipLaunchKernelGGL(bn3_colreduce, dim3((C * 4 + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const float*)rows, local_sums, N, C, 4);
+    hipLaunchKernelGGL(bn3_colreduce, dim3(C), dim3(64), 0, (hipStream_t)stream, (const float*)rows, local_sums, N, C, 4);
     SLAK_LAUNCH_CHECK();
     return SLAK_OK;
 }
