@@ -27,6 +27,13 @@ __device__ __forceinline__ float bn_wave_sum(float v) {
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
     return v;
 }
+// sum over the LPR (power of two) consecutive lanes that share a row
+__device__ __forceinline__ float bn_seg_sum(float v, int lpr) {
+    for (int off = lpr >> 1; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+// lanes per row: enough lanes to cover a row with 8 elements each, at most a wavefront
+static inline int bn_lpr(int P) { int n = (P + 7) / 8, l = 1; while (l < n && l < 64) l <<= 1; return l; }
 
 // 8 consecutive bf16 of a row; zeros beyond P.  mode 2: rows 16-byte aligned (P % 8 == 0), 1: 8-byte aligned (P % 4 == 0), 0: scalar
 __device__ __forceinline__ void unpack2(unsigned u, float& a, float& b) { a = bnf((uint16_t)(u & 0xffff)); b = bnf((uint16_t)(u >> 16)); }
@@ -59,42 +66,54 @@ __device__ __forceinline__ void store8(uint16_t* __restrict__ row, int p, int P,
 
 // rows[r][0..5] = sum y1, sum y1^2, sum y2, sum y2^2, sum y3, sum y3^2 over the P elements of row r
 __global__ __launch_bounds__(BN_THREADS) void bn3_rowsums_fwd(const uint16_t* __restrict__ y1, const uint16_t* __restrict__ y2,
-                                                            const uint16_t* __restrict__ y3, float* __restrict__ rows, int R, int P) {
+                                                            const uint16_t* __restrict__ y3, float* __restrict__ rows, int R, int P, int LPR) {
     const int lane = threadIdx.x & 63, wv = blockIdx.x * (BN_THREADS / 64) + (threadIdx.x >> 6), nw = gridDim.x * (BN_THREADS / 64);
     const int vec = (P & 7) == 0 ? 2 : ((P & 3) == 0 ? 1 : 0);
-    for (int r = wv; r < R; r += nw) {
-        const size_t base = (size_t)r * P;
+    const int rpw = 64 / LPR, sub = lane / LPR, sl = lane - sub * LPR;      // rows per wavefront, my row slot, my lane in the row
+    for (int r0 = wv * rpw; r0 < R; r0 += nw * rpw) {
+        const int r = r0 + sub;
+        const bool rok = r < R;
+        const size_t base = (size_t)(rok ? r : 0) * P;
         float s[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        for (int p = lane * 8; p < P; p += 64 * 8) {
+        for (int p = sl * 8; rok && p < P; p += LPR * 8) {
             float a[8], b[8], c[8];
             load8(y1 + base, p, P, vec, a); load8(y2 + base, p, P, vec, b); load8(y3 + base, p, P, vec, c);
 #pragma unroll
             for (int e = 0; e < 8; ++e) { s[0] += a[e]; s[1] += a[e] * a[e]; s[2] += b[e]; s[3] += b[e] * b[e]; s[4] += c[e]; s[5] += c[e] * c[e]; }
         }
 #pragma unroll
-        for (int k = 0; k < 6; ++k) s[k] = bn_wave_sum(s[k]);
-        if (lane < 6) rows[(size_t)r * 6 + lane] = s[lane];
+        for (int k = 0; k < 6; ++k) s[k] = bn_seg_sum(s[k], LPR);
+        if (rok && sl == 0) {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) rows[(size_t)r * 6 + k] = s[k];
+        }
     }
 }
 
 // rows[r][0..3] = sum dout, sum dout*y1, sum dout*y2, sum dout*y3
 __global__ __launch_bounds__(BN_THREADS) void bn3_rowsums_bwd(const uint16_t* __restrict__ dout, const uint16_t* __restrict__ y1,
                                                             const uint16_t* __restrict__ y2, const uint16_t* __restrict__ y3,
-                                                            float* __restrict__ rows, int R, int P) {
+                                                            float* __restrict__ rows, int R, int P, int LPR) {
     const int lane = threadIdx.x & 63, wv = blockIdx.x * (BN_THREADS / 64) + (threadIdx.x >> 6), nw = gridDim.x * (BN_THREADS / 64);
     const int vec = (P & 7) == 0 ? 2 : ((P & 3) == 0 ? 1 : 0);
-    for (int r = wv; r < R; r += nw) {
-        const size_t base = (size_t)r * P;
+    const int rpw = 64 / LPR, sub = lane / LPR, sl = lane - sub * LPR;
+    for (int r0 = wv * rpw; r0 < R; r0 += nw * rpw) {
+        const int r = r0 + sub;
+        const bool rok = r < R;
+        const size_t base = (size_t)(rok ? r : 0) * P;
         float s[4] = {0.f, 0.f, 0.f, 0.f};
-        for (int p = lane * 8; p < P; p += 64 * 8) {
+        for (int p = sl * 8; rok && p < P; p += LPR * 8) {
             float g[8], a[8], b[8], c[8];
             load8(dout + base, p, P, vec, g); load8(y1 + base, p, P, vec, a); load8(y2 + base, p, P, vec, b); load8(y3 + base, p, P, vec, c);
 #pragma unroll
             for (int e = 0; e < 8; ++e) { s[0] += g[e]; s[1] += g[e] * a[e]; s[2] += g[e] * b[e]; s[3] += g[e] * c[e]; }
         }
 #pragma unroll
-        for (int k = 0; k < 4; ++k) s[k] = bn_wave_sum(s[k]);
-        if (lane < 4) rows[(size_t)r * 4 + lane] = s[lane];
+        for (int k = 0; k < 4; ++k) s[k] = bn_seg_sum(s[k], LPR);
+        if (rok && sl == 0) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) rows[(size_t)r * 4 + k] = s[k];
+        }
     }
 }
 
@@ -156,14 +175,17 @@ __global__ void bn3_finalize_eval(Bn3Params bp, float* __restrict__ coef, int C,
 // out[r][p] = coef[c][0]*y1 + coef[c][1]*y2 + coef[c][2]*y3 + coef[c][3],  c = r % C
 __global__ __launch_bounds__(BN_THREADS) void bn3_apply_fwd(const uint16_t* __restrict__ y1, const uint16_t* __restrict__ y2,
                                                           const uint16_t* __restrict__ y3, const float* __restrict__ coef,
-                                                          uint16_t* __restrict__ out, int R, int C, int P) {
-    const int lane = threadIdx.x & 63, wv = blockIdx.x * (BN_THREADS / 64) + (threadIdx.x >> 6), nw = gridDim.x * (BN_THREADS / 64);
+                                                          uint16_t* __restrict__ out, int R, int C, int P, int LPR) {
+    const int lane0 = threadIdx.x & 63, wv = blockIdx.x * (BN_THREADS / 64) + (threadIdx.x >> 6), nw = gridDim.x * (BN_THREADS / 64);
     const int vec = (P & 7) == 0 ? 2 : ((P & 3) == 0 ? 1 : 0);
-    for (int r = wv; r < R; r += nw) {
+    const int rpw = 64 / LPR, sub = lane0 / LPR, lane = lane0 - sub * LPR;
+    for (int r0 = wv * rpw; r0 < R; r0 += nw * rpw) {
+        const int r = r0 + sub;
+        if (r >= R) continue;
         const int c = r % C;
         const float k1 = coef[c * 4], k2 = coef[c * 4 + 1], k3 = coef[c * 4 + 2], k0 = coef[c * 4 + 3];
         const size_t base = (size_t)r * P;
-        for (int p = lane * 8; p < P; p += 64 * 8) {
+        for (int p = lane * 8; p < P; p += LPR * 8) {
             float a[8], b[8], cc[8], o[8];
             load8(y1 + base, p, P, vec, a); load8(y2 + base, p, P, vec, b); load8(y3 + base, p, P, vec, cc);
 #pragma unroll
@@ -201,16 +223,19 @@ __global__ void bn3_finalize_bwd(const float* __restrict__ gsums, const float* _
 __global__ __launch_bounds__(BN_THREADS) void bn3_apply_bwd(const uint16_t* __restrict__ dout, const uint16_t* __restrict__ y1,
                                                           const uint16_t* __restrict__ y2, const uint16_t* __restrict__ y3,
                                                           const float* __restrict__ bcoef, uint16_t* __restrict__ d1,
-                                                          uint16_t* __restrict__ d2, uint16_t* __restrict__ d3, int R, int C, int P) {
-    const int lane = threadIdx.x & 63, wv = blockIdx.x * (BN_THREADS / 64) + (threadIdx.x >> 6), nw = gridDim.x * (BN_THREADS / 64);
+                                                          uint16_t* __restrict__ d2, uint16_t* __restrict__ d3, int R, int C, int P, int LPR) {
+    const int lane0 = threadIdx.x & 63, wv = blockIdx.x * (BN_THREADS / 64) + (threadIdx.x >> 6), nw = gridDim.x * (BN_THREADS / 64);
     const int vec = (P & 7) == 0 ? 2 : ((P & 3) == 0 ? 1 : 0);
-    for (int r = wv; r < R; r += nw) {
+    const int rpw = 64 / LPR, sub = lane0 / LPR, lane = lane0 - sub * LPR;
+    for (int r0 = wv * rpw; r0 < R; r0 += nw * rpw) {
+        const int r = r0 + sub;
+        if (r >= R) continue;
         const int c = r % C;
         float k[9];
 #pragma unroll
         for (int i = 0; i < 9; ++i) k[i] = bcoef[c * 9 + i];
         const size_t base = (size_t)r * P;
-        for (int p = lane * 8; p < P; p += 64 * 8) {
+        for (int p = lane * 8; p < P; p += LPR * 8) {
             float g[8], a[8], o[8];
             load8(dout + base, p, P, vec, g);
             load8(y1 + base, p, P, vec, a);
@@ -229,8 +254,9 @@ __global__ __launch_bounds__(BN_THREADS) void bn3_apply_bwd(const uint16_t* __re
     }
 }
 
-static int bn_grid(int R) {
-    long long g = ((long long)R + (BN_THREADS / 64) - 1) / (BN_THREADS / 64);
+static int bn_grid(int R, int P) {
+    const int rows_per_block = (BN_THREADS / 64) * (64 / bn_lpr(P));
+    long long g = ((long long)R + rows_per_block - 1) / rows_per_block;
     const long long cap = 256LL * 16;
     return (int)(g < cap ? g : cap);
 }
@@ -258,8 +284,8 @@ int slak_bn3_forward_sums(const void* y1, const void* y2, const void* y3, float*
     if (!workspace || workspace_bytes < slak_bn3_workspace_bytes(N, C)) return SLAK_ERR_WORKSPACE;
     float* rows = (float*)workspace;
     const int R = N * C;
-    hipLaunchKernelGGL(bn3_rowsums_fwd, dim3(bn_grid(R)), dim3(BN_THREADS), 0, (hipStream_t)stream,
-                       (const uint16_t*)y1, (const uint16_t*)y2, (const uint16_t*)y3, rows, R, P);
+    hipLaunchKernelGGL(bn3_rowsums_fwd, dim3(bn_grid(R, P)), dim3(BN_THREADS), 0, (hipStream_t)stream,
+                       (const uint16_t*)y1, (const uint16_t*)y2, (const uint16_t*)y3, rows, R, P, bn_lpr(P));
     hipLaunchKernelGGL(bn3_colreduce, dim3(C), dim3(64), 0, (hipStream_t)stream, (const float*)rows, local_sums, N, C, 6);
     SLAK_LAUNCH_CHECK();
     return SLAK_OK;
@@ -282,8 +308,8 @@ int slak_bn3_forward_apply(const void* y1, const void* y2, const void* y3, const
     else
         hipLaunchKernelGGL(bn3_finalize_eval, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, bp, coef, C, eps);
     const int R = N * C;
-    hipLaunchKernelGGL(bn3_apply_fwd, dim3(bn_grid(R)), dim3(BN_THREADS), 0, (hipStream_t)stream,
-                       (const uint16_t*)y1, (const uint16_t*)y2, (const uint16_t*)y3, (const float*)coef, (uint16_t*)out, R, C, P);
+    hipLaunchKernelGGL(bn3_apply_fwd, dim3(bn_grid(R, P)), dim3(BN_THREADS), 0, (hipStream_t)stream,
+                       (const uint16_t*)y1, (const uint16_t*)y2, (const uint16_t*)y3, (const float*)coef, (uint16_t*)out, R, C, P, bn_lpr(P));
     SLAK_LAUNCH_CHECK();
     return SLAK_OK;
 }
@@ -296,8 +322,8 @@ int slak_bn3_backward_sums(const void* dout, const void* y1, const void* y2, con
     if (!workspace || workspace_bytes < slak_bn3_workspace_bytes(N, C)) return SLAK_ERR_WORKSPACE;
     float* rows = (float*)workspace;
     const int R = N * C;
-    hipLaunchKernelGGL(bn3_rowsums_bwd, dim3(bn_grid(R)), dim3(BN_THREADS), 0, (hipStream_t)stream,
-                       (const uint16_t*)dout, (const uint16_t*)y1, (const uint16_t*)y2, (const uint16_t*)y3, rows, R, P);
+    hipLaunchKernelGGL(bn3_rowsums_bwd, dim3(bn_grid(R, P)), dim3(BN_THREADS), 0, (hipStream_t)stream,
+                       (const uint16_t*)dout, (const uint16_t*)y1, (const uint16_t*)y2, (const uint16_t*)y3, rows, R, P, bn_lpr(P));
     hipLaunchKernelGGL(bn3_colreduce, dim3(C), dim3(64), 0, (hipStream_t)stream, (const float*)rows, local_sums, N, C, 4);
     SLAK_LAUNCH_CHECK();
     return SLAK_OK;
@@ -315,9 +341,9 @@ int slak_bn3_backward_apply(const void* dout, const void* y1, const void* y2, co
     hipLaunchKernelGGL(bn3_finalize_bwd, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, global_sums, local_sums, stats, bp,
                        bcoef, dgamma, dbeta, C, (float)count);
     const int R = N * C;
-    hipLaunchKernelGGL(bn3_apply_bwd, dim3(bn_grid(R)), dim3(BN_THREADS), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(bn3_apply_bwd, dim3(bn_grid(R, P)), dim3(BN_THREADS), 0, (hipStream_t)stream,
                        (const uint16_t*)dout, (const uint16_t*)y1, (const uint16_t*)y2, (const uint16_t*)y3, (const float*)bcoef,
-                       (uint16_t*)dy1, (uint16_t*)dy2, (uint16_t*)dy3, R, C, P);
+                       (uint16_t*)dy1, (uint16_t*)dy2, (uint16_t*)dy3, R, C, P, bn_lpr(P));
     SLAK_LAUNCH_CHECK();
     return SLAK_OK;
 }
