@@ -25,9 +25,13 @@ typedef __attribute__((ext_vector_type(2))) __bf16 bt_bf16x2;
 __device__ __forceinline__ unsigned bt_pack2(float a, float b) { return __builtin_bit_cast(unsigned, __builtin_convertvector(bt_f32x2{a, b}, bt_bf16x2)); }
 __device__ __forceinline__ uint16_t bt_f2bf(float a) { return (uint16_t)(bt_pack2(a, 0.f) & 0xffffu); }
 
-struct TailDims { int N, C, P, TP, tiles_per_image; };
+struct TailDims { int N, C, P, TP, tiles_per_image, ntiles; };
 
-static inline int tail_tp(int C) { return C <= 128 ? 64 : (C <= 256 ? 64 : (C <= 512 ? 32 : 16)); }
+__device__ __forceinline__ float bt_wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
 
 // stage x[n, :, p0:p0+TP] (NCHW, bf16) into xs[C][TP+2]; pixels beyond P are zero
 __device__ __forceinline__ void load_nchw_tile(uint16_t* xs, const uint16_t* __restrict__ xn, int C, int P, int p0, int TP, int tid) {
@@ -48,6 +52,26 @@ __device__ __forceinline__ void load_nchw_tile(uint16_t* xs, const uint16_t* __r
         }
     }
 }
+// write xs[C][TP+2] (bf16) back to an NCHW tensor
+__device__ __forceinline__ void store_nchw_tile(const uint16_t* xs, uint16_t* __restrict__ xn, int C, int P, int p0, int TP, int tid) {
+    const int pitch = TP + 2;
+    if ((P & 3) == 0) {
+        const int cpr = TP / 4;
+        for (int idx = tid; idx < C * cpr; idx += BT_THREADS) {
+            const int c = idx / cpr, q = idx - c * cpr, p = p0 + q * 4;
+            if (p < P) {
+                const unsigned* src = (const unsigned*)(xs + c * pitch + q * 4);
+                unsigned* dst = (unsigned*)(xn + (size_t)c * P + p);
+                dst[0] = src[0]; dst[1] = src[1];
+            }
+        }
+    } else {
+        for (int idx = tid; idx < C * TP; idx += BT_THREADS) {
+            const int c = idx / TP, q = idx - c * TP, p = p0 + q;
+            if (p < P) xn[(size_t)c * P + p] = xs[c * pitch + q];
+        }
+    }
+}
 // stage z[n, p0:p0+TP, :] (NHWC, bf16, C % 2 == 0) into zs[TP][C+2]; pixels beyond P are zero
 __device__ __forceinline__ void load_nhwc_tile(uint16_t* zs, const uint16_t* __restrict__ zn, int C, int P, int p0, int TP, int tid) {
     const int pitch = C + 2, cp = C / 2;
@@ -59,9 +83,9 @@ __device__ __forceinline__ void load_nhwc_tile(uint16_t* zs, const uint16_t* __r
     }
 }
 
-// ---------------------------------------------------------------------------------------------------------------
+// ===== variant A (small C: stages 1-2): one workgroup per tile, thread <-> (pixel, channel group); both tiles staged in LDS =====
 // y[n,p,:] = LN_C(x[n,:,p]) * w + b   (two-pass statistics in fp32 on the staged tile), y bf16 NHWC; saves mean, rstd
-__global__ __launch_bounds__(BT_THREADS) void ln_nchw_to_nhwc_fwd_kernel(const uint16_t* __restrict__ x, const float* __restrict__ w,
+__global__ __launch_bounds__(BT_THREADS) void ln_nchw_to_nhwc_fwd_pix_kernel(const uint16_t* __restrict__ x, const float* __restrict__ w,
                                                                        const float* __restrict__ b, uint16_t* __restrict__ y,
                                                                        float* __restrict__ mean, float* __restrict__ rstd,
                                                                        const TailDims d, float eps) {
@@ -109,7 +133,7 @@ __global__ __launch_bounds__(BT_THREADS) void ln_nchw_to_nhwc_fwd_kernel(const u
 }
 
 // dx[n,:,p] (bf16 NCHW) from g[n,p,:] (bf16 NHWC); per-tile partial sums part[tile][0][c] = sum_p g*xhat, part[tile][1][c] = sum_p g
-__global__ __launch_bounds__(BT_THREADS) void ln_nchw_to_nhwc_bwd_kernel(const uint16_t* __restrict__ g, const uint16_t* __restrict__ x,
+__global__ __launch_bounds__(BT_THREADS) void ln_nchw_to_nhwc_bwd_pix_kernel(const uint16_t* __restrict__ g, const uint16_t* __restrict__ x,
                                                                        const float* __restrict__ w, const float* __restrict__ mean,
                                                                        const float* __restrict__ rstd, uint16_t* __restrict__ dx,
                                                                        float* __restrict__ part, const TailDims d) {
@@ -190,7 +214,7 @@ __global__ __launch_bounds__(BT_THREADS) void ln_nchw_to_nhwc_bwd_kernel(const u
 
 // out[n,c,p] (fp32 NCHW) = shortcut[n,c,p] + scale[n] * gamma[c] * z[n,p,c] (bf16 NHWC)
 template <typename Tsc>
-__global__ __launch_bounds__(BT_THREADS) void scale_residual_fwd_kernel(const Tsc* __restrict__ sc, const uint16_t* __restrict__ z,
+__global__ __launch_bounds__(BT_THREADS) void scale_residual_fwd_pix_kernel(const Tsc* __restrict__ sc, const uint16_t* __restrict__ z,
                                                                       const float* __restrict__ gamma, const float* __restrict__ scale,
                                                                       float* __restrict__ out, const TailDims d) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -230,7 +254,7 @@ __global__ __launch_bounds__(BT_THREADS) void scale_residual_fwd_kernel(const Ts
 }
 
 // dz[n,p,c] (bf16 NHWC) = scale[n] * gamma[c] * dout[n,c,p] (fp32 NCHW); part[tile][c] = scale[n] * sum_p dout * z
-__global__ __launch_bounds__(BT_THREADS) void scale_residual_bwd_kernel(const float* __restrict__ dout, const uint16_t* __restrict__ z,
+__global__ __launch_bounds__(BT_THREADS) void scale_residual_bwd_pix_kernel(const float* __restrict__ dout, const uint16_t* __restrict__ z,
                                                                       const float* __restrict__ gamma, const float* __restrict__ scale,
                                                                       uint16_t* __restrict__ dz, float* __restrict__ part, const TailDims d) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -273,6 +297,217 @@ __global__ __launch_bounds__(BT_THREADS) void scale_residual_bwd_kernel(const fl
     }
 }
 
+// ===== variant B (large C: stages 3-4): persistent workgroups, wavefront <-> pixel, lane <-> channel pair; one tile staged =====
+// All four kernels are persistent: gridDim.x workgroups walk the (image, pixel-tile) list.  Inside a tile, wavefront w owns
+// pixels q = w, w+4, ...; on the NHWC side a lane owns the channel pair (2*lane + 128*k, +1).
+// ---------------------------------------------------------------------------------------------------------------
+// y[n,p,:] = LN_C(x[n,:,p]) * w + b   (two-pass statistics in fp32 on the staged tile), y bf16 NHWC; saves mean, rstd
+__global__ __launch_bounds__(BT_THREADS) void ln_nchw_to_nhwc_fwd_kernel(const uint16_t* __restrict__ x, const float* __restrict__ w,
+                                                                       const float* __restrict__ b, uint16_t* __restrict__ y,
+                                                                       float* __restrict__ mean, float* __restrict__ rstd,
+                                                                       const TailDims d, float eps) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int C = d.C, P = d.P, TP = d.TP, pitch = TP + 2, cp = C / 2;
+    uint16_t* xs = (uint16_t*)smem;                                        // [C][TP+2]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int tile = blockIdx.x; tile < d.ntiles; tile += gridDim.x) {
+        const int n = tile / d.tiles_per_image, p0 = (tile - n * d.tiles_per_image) * TP;
+        load_nchw_tile(xs, x + (size_t)n * C * P, C, P, p0, TP, tid);
+        __syncthreads();
+        uint16_t* yn = y + ((size_t)n * P + p0) * C;
+        for (int q = wave; q < TP && p0 + q < P; q += BT_THREADS / 64) {
+            float s = 0.f;
+            for (int k = lane; k < cp; k += 64) s += bf2f(xs[(2 * k) * pitch + q]) + bf2f(xs[(2 * k + 1) * pitch + q]);
+            const float mu = bt_wave_sum(s) / (float)C;
+            float ss = 0.f;
+            for (int k = lane; k < cp; k += 64) {
+                const float v0 = bf2f(xs[(2 * k) * pitch + q]) - mu, v1 = bf2f(xs[(2 * k + 1) * pitch + q]) - mu;
+                ss += v0 * v0 + v1 * v1;
+            }
+            const float r = 1.0f / sqrtf(bt_wave_sum(ss) / (float)C + eps);
+            if (lane == 0) { mean[(size_t)n * P + p0 + q] = mu; rstd[(size_t)n * P + p0 + q] = r; }
+            for (int k = lane; k < cp; k += 64) {
+                const float v0 = (bf2f(xs[(2 * k) * pitch + q]) - mu) * r * w[2 * k] + b[2 * k];
+                const float v1 = (bf2f(xs[(2 * k + 1) * pitch + q]) - mu) * r * w[2 * k + 1] + b[2 * k + 1];
+                ((unsigned*)(yn + (size_t)q * C))[k] = bt_pack2(v0, v1);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// dx[n,:,p] (bf16 NCHW) from g[n,p,:] (bf16 NHWC, read straight from global on its coalesced side; second read hits L2);
+// x is staged, dx overwrites it in LDS and leaves on the NCHW side.  part[wg][0][c] = sum g*xhat, part[wg][1][c] = sum g over
+// every pixel the workgroup processed.
+__global__ __launch_bounds__(BT_THREADS) void ln_nchw_to_nhwc_bwd_kernel(const uint16_t* __restrict__ g, const uint16_t* __restrict__ x,
+                                                                       const float* __restrict__ w, const float* __restrict__ mean,
+                                                                       const float* __restrict__ rstd, uint16_t* __restrict__ dx,
+                                                                       float* __restrict__ part, const TailDims d) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int C = d.C, P = d.P, TP = d.TP, xp = TP + 2, cp = C / 2;
+    uint16_t* xs = (uint16_t*)smem;                                                  // [C][TP+2]
+    float* red = (float*)(smem + (((size_t)C * xp * 2 + 15) & ~(size_t)15));       // [4 waves][2][C] at the end
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int KMAX = 8;                                                          // channel pairs per lane: C <= 1024
+    float aw[2 * KMAX], ab[2 * KMAX];
+#pragma unroll
+    for (int i = 0; i < 2 * KMAX; ++i) { aw[i] = 0.f; ab[i] = 0.f; }
+    for (int tile = blockIdx.x; tile < d.ntiles; tile += gridDim.x) {
+        const int n = tile / d.tiles_per_image, p0 = (tile - n * d.tiles_per_image) * TP;
+        load_nchw_tile(xs, x + (size_t)n * C * P, C, P, p0, TP, tid);
+        __syncthreads();
+        const uint16_t* gn = g + ((size_t)n * P + p0) * C;
+        for (int q = wave; q < TP && p0 + q < P; q += BT_THREADS / 64) {
+            const float mu = mean[(size_t)n * P + p0 + q], r = rstd[(size_t)n * P + p0 + q];
+            const unsigned* gq = (const unsigned*)(gn + (size_t)q * C);
+            float s1 = 0.f, s2 = 0.f;
+            for (int k = lane; k < cp; k += 64) {
+                const unsigned gv = gq[k];
+                const float g0 = bf2f((uint16_t)(gv & 0xffff)) * w[2 * k], g1 = bf2f((uint16_t)(gv >> 16)) * w[2 * k + 1];
+                s1 += g0 + g1;
+                s2 += g0 * ((bf2f(xs[(2 * k) * xp + q]) - mu) * r) + g1 * ((bf2f(xs[(2 * k + 1) * xp + q]) - mu) * r);
+            }
+            const float m1 = bt_wave_sum(s1) / (float)C, m2 = bt_wave_sum(s2) / (float)C;
+#pragma unroll
+            for (int kk = 0; kk < KMAX; ++kk) {
+                const int k = lane + 64 * kk;
+                if (k < cp) {
+                    const unsigned gv = gq[k];
+                    const float gr0 = bf2f((uint16_t)(gv & 0xffff)), gr1 = bf2f((uint16_t)(gv >> 16));
+                    const float xh0 = (bf2f(xs[(2 * k) * xp + q]) - mu) * r, xh1 = (bf2f(xs[(2 * k + 1) * xp + q]) - mu) * r;
+                    aw[2 * kk] += gr0 * xh0; aw[2 * kk + 1] += gr1 * xh1; ab[2 * kk] += gr0; ab[2 * kk + 1] += gr1;
+                    const unsigned pk = bt_pack2(r * (gr0 * w[2 * k] - m1 - xh0 * m2), r * (gr1 * w[2 * k + 1] - m1 - xh1 * m2));
+                    xs[(2 * k) * xp + q] = (uint16_t)(pk & 0xffffu);
+                    xs[(2 * k + 1) * xp + q] = (uint16_t)(pk >> 16);
+                }
+            }
+        }
+        __syncthreads();
+        store_nchw_tile(xs, dx + (size_t)n * C * P, C, P, p0, TP, tid);
+        __syncthreads();
+    }
+    // per-channel partials of this workgroup: the four wavefronts' sums added in wave order
+#pragma unroll
+    for (int kk = 0; kk < KMAX; ++kk) {
+        const int k = lane + 64 * kk;
+        if (k < cp) {
+            red[(wave * 2 + 0) * C + 2 * k] = aw[2 * kk]; red[(wave * 2 + 0) * C + 2 * k + 1] = aw[2 * kk + 1];
+            red[(wave * 2 + 1) * C + 2 * k] = ab[2 * kk]; red[(wave * 2 + 1) * C + 2 * k + 1] = ab[2 * kk + 1];
+        }
+    }
+    __syncthreads();
+    float* pt = part + (size_t)blockIdx.x * 2 * C;
+    for (int i = tid; i < 2 * C; i += BT_THREADS) {
+        const int which = i / C, c = i - which * C;
+        pt[i] = ((red[(0 * 2 + which) * C + c] + red[(1 * 2 + which) * C + c]) + red[(2 * 2 + which) * C + c]) + red[(3 * 2 + which) * C + c];
+    }
+}
+
+// out[n,c,p] (fp32 NCHW) = shortcut[n,c,p] + scale[n] * gamma[c] * z[n,p,c] (bf16 NHWC)
+template <typename Tsc>
+__global__ __launch_bounds__(BT_THREADS) void scale_residual_fwd_kernel(const Tsc* __restrict__ sc, const uint16_t* __restrict__ z,
+                                                                      const float* __restrict__ gamma, const float* __restrict__ scale,
+                                                                      float* __restrict__ out, const TailDims d) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int C = d.C, P = d.P, TP = d.TP, zp = C + 2;
+    uint16_t* zs = (uint16_t*)smem;
+    const int tid = threadIdx.x;
+    for (int tile = blockIdx.x; tile < d.ntiles; tile += gridDim.x) {
+        const int n = tile / d.tiles_per_image, p0 = (tile - n * d.tiles_per_image) * TP;
+        load_nhwc_tile(zs, z + (size_t)n * P * C, C, P, p0, TP, tid);
+        __syncthreads();
+        const float sn = scale ? scale[n] : 1.0f;
+        const Tsc* scn = sc + (size_t)n * C * P;
+        float* on = out + (size_t)n * C * P;
+        if ((P & 3) == 0) {
+            const int cpr = TP / 4;
+            for (int idx = tid; idx < C * cpr; idx += BT_THREADS) {
+                const int c = idx / cpr, qq = (idx - c * cpr) * 4;
+                if (p0 + qq < P) {
+                    const float gm = gamma[c] * sn;
+                    const size_t off = (size_t)c * P + p0 + qq;
+                    float4 o;
+                    o.x = to_f32(scn[off + 0]) + gm * bf2f(zs[(qq + 0) * zp + c]);
+                    o.y = to_f32(scn[off + 1]) + gm * bf2f(zs[(qq + 1) * zp + c]);
+                    o.z = to_f32(scn[off + 2]) + gm * bf2f(zs[(qq + 2) * zp + c]);
+                    o.w = to_f32(scn[off + 3]) + gm * bf2f(zs[(qq + 3) * zp + c]);
+                    *(float4*)(on + off) = o;
+                }
+            }
+        } else {
+            for (int idx = tid; idx < C * TP; idx += BT_THREADS) {
+                const int c = idx / TP, qq = idx - c * TP;
+                if (p0 + qq < P) {
+                    const size_t off = (size_t)c * P + p0 + qq;
+                    on[off] = to_f32(scn[off]) + gamma[c] * sn * bf2f(zs[qq * zp + c]);
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// dz[n,p,c] (bf16 NHWC) = scale[n] * gamma[c] * dout[n,c,p] (fp32 NCHW, staged);  part[wg][c] = sum scale[n] * dout * z
+// (z read straight from global on its coalesced side)
+__global__ __launch_bounds__(BT_THREADS) void scale_residual_bwd_kernel(const float* __restrict__ dout, const uint16_t* __restrict__ z,
+                                                                      const float* __restrict__ gamma, const float* __restrict__ scale,
+                                                                      uint16_t* __restrict__ dz, float* __restrict__ part, const TailDims d) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int C = d.C, P = d.P, TP = d.TP, dp = TP + 1, cp = C / 2;
+    float* ds = (float*)smem;                                                        // [C][TP+1] fp32
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int KMAX = 8;
+    float ag[2 * KMAX];
+#pragma unroll
+    for (int i = 0; i < 2 * KMAX; ++i) ag[i] = 0.f;
+    for (int tile = blockIdx.x; tile < d.ntiles; tile += gridDim.x) {
+        const int n = tile / d.tiles_per_image, p0 = (tile - n * d.tiles_per_image) * TP;
+        const float* dn = dout + (size_t)n * C * P;
+        if ((P & 3) == 0) {
+            const int cpr = TP / 4;
+            for (int idx = tid; idx < C * cpr; idx += BT_THREADS) {
+                const int c = idx / cpr, qq = (idx - c * cpr) * 4;
+                float4 v = float4{0.f, 0.f, 0.f, 0.f};
+                if (p0 + qq < P) v = *(const float4*)(dn + (size_t)c * P + p0 + qq);
+                float* dst = ds + c * dp + qq;
+                dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
+            }
+        } else {
+            for (int idx = tid; idx < C * TP; idx += BT_THREADS) {
+                const int c = idx / TP, qq = idx - c * TP;
+                ds[c * dp + qq] = (p0 + qq < P) ? dn[(size_t)c * P + p0 + qq] : 0.f;
+            }
+        }
+        __syncthreads();
+        const float sn = scale ? scale[n] : 1.0f;
+        const uint16_t* zn = z + ((size_t)n * P + p0) * C;
+        uint16_t* dzn = dz + ((size_t)n * P + p0) * C;
+        for (int q = wave; q < TP && p0 + q < P; q += BT_THREADS / 64) {
+            const unsigned* zq = (const unsigned*)(zn + (size_t)q * C);
+#pragma unroll
+            for (int kk = 0; kk < KMAX; ++kk) {
+                const int k = lane + 64 * kk;
+                if (k < cp) {
+                    const unsigned zv = zq[k];
+                    const float d0 = ds[(2 * k) * dp + q], d1 = ds[(2 * k + 1) * dp + q];
+                    ag[2 * kk] += sn * d0 * bf2f((uint16_t)(zv & 0xffff)); ag[2 * kk + 1] += sn * d1 * bf2f((uint16_t)(zv >> 16));
+                    ((unsigned*)(dzn + (size_t)q * C))[k] = bt_pack2(sn * gamma[2 * k] * d0, sn * gamma[2 * k + 1] * d1);
+                }
+            }
+        }
+        __syncthreads();
+    }
+    float* red = ds;                                                                 // [4][C], the tile is dead now
+#pragma unroll
+    for (int kk = 0; kk < KMAX; ++kk) {
+        const int k = lane + 64 * kk;
+        if (k < cp) { red[wave * C + 2 * k] = ag[2 * kk]; red[wave * C + 2 * k + 1] = ag[2 * kk + 1]; }
+    }
+    __syncthreads();
+    float* pt = part + (size_t)blockIdx.x * C;
+    for (int c = tid; c < C; c += BT_THREADS) pt[c] = ((red[c] + red[C + c]) + red[2 * C + c]) + red[3 * C + c];
+}
+
 // Column sums of part[ntiles][width] in a fixed order.  gridDim.y slices of the tile range; with one slice the result goes
 // to out0[j] (j < split) / out1[j - split], with several to out0[slice][width] (a second launch adds the slices).
 __global__ void block_tail_reduce(const float* __restrict__ part, float* __restrict__ out0, float* __restrict__ out1, int split,
@@ -310,10 +545,31 @@ static int reduce_partials(const float* part, float* tmp, float* out0, float* ou
     return SLAK_OK;
 }
 
-static TailDims make_dims(int N, int C, int P) {
-    TailDims d; d.N = N; d.C = C; d.P = P; d.TP = tail_tp(C);
-    d.tiles_per_image = (P + d.TP - 1) / d.TP;
+// tile width: the largest of {128,64,32,16} pixels whose tile (elem_bytes per element) fits lds_budget, not (much) wider than an image
+static TailDims make_dims(int N, int C, int P, int elem_bytes, size_t lds_budget = 50 * 1024) {
+    TailDims d; d.N = N; d.C = C; d.P = P;
+    int TP = 128;
+    while (TP > 16 && ((size_t)C * (TP + 2) * elem_bytes > lds_budget || TP / 2 >= P)) TP /= 2;
+    d.TP = TP;
+    d.tiles_per_image = (P + TP - 1) / TP;
+    d.ntiles = N * d.tiles_per_image;
     return d;
+}
+// variant A: fixed 64-pixel tiles, one workgroup per tile
+static TailDims make_dims_pix(int N, int C, int P) {
+    TailDims d; d.N = N; d.C = C; d.P = P; d.TP = 64;
+    d.tiles_per_image = (P + d.TP - 1) / d.TP; d.ntiles = N * d.tiles_per_image;
+    return d;
+}
+static int g_tail_cus = 0;
+static int tail_grid(const TailDims& d, size_t lds) {                  // persistent: as many workgroups as stay resident
+    if (g_tail_cus == 0) {
+        int dev = 0; hipDeviceProp_t prop;
+        g_tail_cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
+    }
+    int per_cu = (int)((size_t)(160 * 1024) / (lds + 1024)); if (per_cu > 8) per_cu = 8; if (per_cu < 1) per_cu = 1;
+    const int resident = per_cu * g_tail_cus;
+    return d.ntiles < resident ? d.ntiles : resident;
 }
 static int set_lds(const void* k, size_t lds) {
     if (lds > 48 * 1024) return hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess ? 0 : 1;
@@ -328,8 +584,9 @@ extern "C" {
 
 size_t slak_block_tail_workspace_bytes(int N, int C, int P) {
     if (N <= 0 || C <= 0 || P <= 0) return 0;
-    const TailDims d = make_dims(N, C, P);
-    return align_up(((size_t)N * d.tiles_per_image + BT_SLICES) * 2 * C * sizeof(float), 256);
+    size_t rows = 8 * 1024;                                                 // variant B: one partial row per persistent workgroup (<= 8 per CU)
+    if (C <= 256) { const size_t t = (size_t)N * ((P + 63) / 64); if (t > rows) rows = t; }   // variant A: one per tile
+    return align_up((rows + BT_SLICES) * 2 * C * sizeof(float), 256);
 }
 
 static int tail_args_ok(int N, int C, int P) {
@@ -343,10 +600,19 @@ int slak_ln_nchw_to_nhwc_forward(const void* x, const float* weight, const float
                                  int N, int C, int P, float eps, void* stream) {
     if (!x || !weight || !bias || !y || !mean || !rstd) return SLAK_ERR_INVALID_ARG;
     int rc = tail_args_ok(N, C, P); if (rc) return rc;
-    const TailDims d = make_dims(N, C, P);
-    const size_t lds = (((size_t)C * (d.TP + 2) * 2 + 15) & ~(size_t)15) + (size_t)(BT_THREADS / d.TP) * d.TP * 4 + 2 * d.TP * 4;
+    if (C <= 256) {
+        const TailDims d = make_dims_pix(N, C, P);
+        const size_t lds = (((size_t)C * (d.TP + 2) * 2 + 15) & ~(size_t)15) + (size_t)(BT_THREADS / d.TP) * d.TP * 4 + 2 * d.TP * 4;
+        if (set_lds((const void*)ln_nchw_to_nhwc_fwd_pix_kernel, lds)) return SLAK_ERR_LAUNCH;
+        hipLaunchKernelGGL(ln_nchw_to_nhwc_fwd_pix_kernel, dim3((unsigned)d.ntiles), dim3(BT_THREADS), lds, (hipStream_t)stream,
+                           (const uint16_t*)x, weight, bias, (uint16_t*)y, mean, rstd, d, eps);
+        SLAK_LAUNCH_CHECK();
+        return SLAK_OK;
+    }
+    const TailDims d = make_dims(N, C, P, 2);
+    const size_t lds = (size_t)C * (d.TP + 2) * 2 + 16;
     if (set_lds((const void*)ln_nchw_to_nhwc_fwd_kernel, lds)) return SLAK_ERR_LAUNCH;
-    hipLaunchKernelGGL(ln_nchw_to_nhwc_fwd_kernel, dim3((unsigned)(N * d.tiles_per_image)), dim3(BT_THREADS), lds, (hipStream_t)stream,
+    hipLaunchKernelGGL(ln_nchw_to_nhwc_fwd_kernel, dim3((unsigned)tail_grid(d, lds)), dim3(BT_THREADS), lds, (hipStream_t)stream,
                        (const uint16_t*)x, weight, bias, (uint16_t*)y, mean, rstd, d, eps);
     SLAK_LAUNCH_CHECK();
     return SLAK_OK;
@@ -358,25 +624,53 @@ int slak_ln_nchw_to_nhwc_backward(const void* g, const void* x, const float* wei
     if (!g || !x || !weight || !mean || !rstd || !dx || !dweight || !dbias) return SLAK_ERR_INVALID_ARG;
     int rc = tail_args_ok(N, C, P); if (rc) return rc;
     if (!workspace || workspace_bytes < slak_block_tail_workspace_bytes(N, C, P)) return SLAK_ERR_WORKSPACE;
-    const TailDims d = make_dims(N, C, P);
-    const size_t lds = (((size_t)C * (d.TP + 2) * 2 + 15) & ~(size_t)15) + (((size_t)d.TP * (C + 2) * 2 + 15) & ~(size_t)15) +
-                       (size_t)2 * (BT_THREADS / d.TP) * d.TP * 4 + 4 * d.TP * 4;
+    if (C <= 256) {
+        const TailDims d = make_dims_pix(N, C, P);
+        const size_t lds = (((size_t)C * (d.TP + 2) * 2 + 15) & ~(size_t)15) + (((size_t)d.TP * (C + 2) * 2 + 15) & ~(size_t)15) +
+                           (size_t)2 * (BT_THREADS / d.TP) * d.TP * 4 + 4 * d.TP * 4;
+        if (set_lds((const void*)ln_nchw_to_nhwc_bwd_pix_kernel, lds)) return SLAK_ERR_LAUNCH;
+        float* part = (float*)workspace;
+        hipLaunchKernelGGL(ln_nchw_to_nhwc_bwd_pix_kernel, dim3((unsigned)d.ntiles), dim3(BT_THREADS), lds, (hipStream_t)stream,
+                           (const uint16_t*)g, (const uint16_t*)x, weight, mean, rstd, (uint16_t*)dx, part, d);
+        SLAK_LAUNCH_CHECK();
+        return reduce_partials(part, part + (size_t)d.ntiles * 2 * C, dweight, dbias, C, d.ntiles, 2 * C, (hipStream_t)stream);
+    }
+    const TailDims d = make_dims(N, C, P, 2);
+    const size_t lds = (((size_t)C * (d.TP + 2) * 2 + 15) & ~(size_t)15) + (size_t)4 * 2 * C * 4;
     if (set_lds((const void*)ln_nchw_to_nhwc_bwd_kernel, lds)) return SLAK_ERR_LAUNCH;
-    const int ntiles = N * d.tiles_per_image;
+    const int grid = tail_grid(d, lds);
     float* part = (float*)workspace;
-    hipLaunchKernelGGL(ln_nchw_to_nhwc_bwd_kernel, dim3((unsigned)ntiles), dim3(BT_THREADS), lds, (hipStream_t)stream,
+    hipLaunchKernelGGL(ln_nchw_to_nhwc_bwd_kernel, dim3((unsigned)grid), dim3(BT_THREADS), lds, (hipStream_t)stream,
                        (const uint16_t*)g, (const uint16_t*)x, weight, mean, rstd, (uint16_t*)dx, part, d);
     SLAK_LAUNCH_CHECK();
-    return reduce_partials(part, part + (size_t)ntiles * 2 * C, dweight, dbias, C, ntiles, 2 * C, (hipStream_t)stream);
+    return reduce_partials(part, part + (size_t)grid * 2 * C, dweight, dbias, C, grid, 2 * C, (hipStream_t)stream);
 }
 
 int slak_scale_residual_forward(const void* shortcut, int shortcut_dtype, const void* z, const float* gamma, const float* sample_scale,
                                 float* out, int N, int C, int P, void* stream) {
     if (!shortcut || !z || !gamma || !out) return SLAK_ERR_INVALID_ARG;
     int rc = tail_args_ok(N, C, P); if (rc) return rc;
-    const TailDims d = make_dims(N, C, P);
+    if (C <= 256) {
+        const TailDims d = make_dims_pix(N, C, P);
+        const size_t lds = (size_t)d.TP * (C + 2) * 2 + 16;
+        const dim3 grid((unsigned)d.ntiles);
+        if (shortcut_dtype == SLAK_F32) {
+            if (set_lds((const void*)scale_residual_fwd_pix_kernel<float>, lds)) return SLAK_ERR_LAUNCH;
+            hipLaunchKernelGGL(scale_residual_fwd_pix_kernel<float>, grid, dim3(BT_THREADS), lds, (hipStream_t)stream,
+                               (const float*)shortcut, (const uint16_t*)z, gamma, sample_scale, out, d);
+        } else if (shortcut_dtype == SLAK_BF16) {
+            if (set_lds((const void*)scale_residual_fwd_pix_kernel<bf16_t>, lds)) return SLAK_ERR_LAUNCH;
+            hipLaunchKernelGGL(scale_residual_fwd_pix_kernel<bf16_t>, grid, dim3(BT_THREADS), lds, (hipStream_t)stream,
+                               (const bf16_t*)shortcut, (const uint16_t*)z, gamma, sample_scale, out, d);
+        } else return SLAK_ERR_UNSUPPORTED;
+        SLAK_LAUNCH_CHECK();
+        return SLAK_OK;
+    }
+    TailDims d = make_dims(N, C, P, 2);
+    // the NHWC tile is [TP][C+2]: same byte count as [C][TP+2] up to the padding
+    while (d.TP > 16 && (size_t)d.TP * (C + 2) * 2 > 50 * 1024) { d.TP /= 2; d.tiles_per_image = (P + d.TP - 1) / d.TP; d.ntiles = N * d.tiles_per_image; }
     const size_t lds = (size_t)d.TP * (C + 2) * 2 + 16;
-    const dim3 grid((unsigned)(N * d.tiles_per_image));
+    const dim3 grid((unsigned)tail_grid(d, lds));
     if (shortcut_dtype == SLAK_F32) {
         if (set_lds((const void*)scale_residual_fwd_kernel<float>, lds)) return SLAK_ERR_LAUNCH;
         hipLaunchKernelGGL(scale_residual_fwd_kernel<float>, grid, dim3(BT_THREADS), lds, (hipStream_t)stream,
@@ -395,15 +689,26 @@ int slak_scale_residual_backward(const float* dout, const void* z, const float* 
     if (!dout || !z || !gamma || !dz || !dgamma) return SLAK_ERR_INVALID_ARG;
     int rc = tail_args_ok(N, C, P); if (rc) return rc;
     if (!workspace || workspace_bytes < slak_block_tail_workspace_bytes(N, C, P)) return SLAK_ERR_WORKSPACE;
-    const TailDims d = make_dims(N, C, P);
-    const size_t lds = (size_t)C * (d.TP + 1) * 4 + (size_t)d.TP * (C + 2) * 2 + 16;
+    if (C <= 256) {
+        const TailDims d = make_dims_pix(N, C, P);
+        const size_t lds = (size_t)C * (d.TP + 1) * 4 + (size_t)d.TP * (C + 2) * 2 + 16;
+        if (set_lds((const void*)scale_residual_bwd_pix_kernel, lds)) return SLAK_ERR_LAUNCH;
+        float* part = (float*)workspace;
+        hipLaunchKernelGGL(scale_residual_bwd_pix_kernel, dim3((unsigned)d.ntiles), dim3(BT_THREADS), lds, (hipStream_t)stream,
+                           dout, (const uint16_t*)z, gamma, sample_scale, (uint16_t*)dz, part, d);
+        SLAK_LAUNCH_CHECK();
+        return reduce_partials(part, part + (size_t)d.ntiles * 2 * C, dgamma, dgamma, C, d.ntiles, C, (hipStream_t)stream);
+    }
+    const TailDims d = make_dims(N, C, P, 4);
+    size_t lds = (size_t)C * (d.TP + 1) * 4 + 16;
+    if (lds < (size_t)4 * C * 4 + 16) lds = (size_t)4 * C * 4 + 16;
     if (set_lds((const void*)scale_residual_bwd_kernel, lds)) return SLAK_ERR_LAUNCH;
-    const int ntiles = N * d.tiles_per_image;
+    const int grid = tail_grid(d, lds);
     float* part = (float*)workspace;
-    hipLaunchKernelGGL(scale_residual_bwd_kernel, dim3((unsigned)ntiles), dim3(BT_THREADS), lds, (hipStream_t)stream,
+    hipLaunchKernelGGL(scale_residual_bwd_kernel, dim3((unsigned)grid), dim3(BT_THREADS), lds, (hipStream_t)stream,
                        dout, (const uint16_t*)z, gamma, sample_scale, (uint16_t*)dz, part, d);
     SLAK_LAUNCH_CHECK();
-    return reduce_partials(part, part + (size_t)ntiles * 2 * C, dgamma, dgamma, C, ntiles, C, (hipStream_t)stream);
+    return reduce_partials(part, part + (size_t)grid * 2 * C, dgamma, dgamma, C, grid, C, (hipStream_t)stream);
 }
 
 }  // extern "C"
