@@ -155,6 +155,30 @@ __device__ __forceinline__ void load_toeplitz_frags(s16x8 (&afrag)[NG][KS], bool
     }
 }
 
+// ---- LDS-DMA (buffer_load_dwordx4 ... lds) and explicit synchronisation (see dwconv_mfma_dma.hip for the protocol) ----
+typedef __attribute__((ext_vector_type(4))) int v4i_t;
+__device__ __forceinline__ void lds_dma16(unsigned voff, v4i_t rsrc, unsigned lds_base) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(rsrc), "s"(lds_base) : "memory");
+}
+__device__ __forceinline__ void wg_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
+__device__ __forceinline__ void wait_vmcnt_dyn(int n) {       // n is wave-uniform
+    switch (n) {
+        case 0: wait_vmcnt<0>(); break;   case 1: wait_vmcnt<1>(); break;   case 2: wait_vmcnt<2>(); break;
+        case 3: wait_vmcnt<3>(); break;   case 4: wait_vmcnt<4>(); break;   case 5: wait_vmcnt<5>(); break;
+        case 6: wait_vmcnt<6>(); break;   case 7: wait_vmcnt<7>(); break;   case 8: wait_vmcnt<8>(); break;
+        case 9: wait_vmcnt<9>(); break;   case 10: wait_vmcnt<10>(); break; case 11: wait_vmcnt<11>(); break;
+        case 12: wait_vmcnt<12>(); break; case 13: wait_vmcnt<13>(); break; case 14: wait_vmcnt<14>(); break;
+        case 15: wait_vmcnt<15>(); break; case 16: wait_vmcnt<16>(); break; case 18: wait_vmcnt<18>(); break;
+        case 20: wait_vmcnt<20>(); break; case 24: wait_vmcnt<24>(); break;
+        default: wait_vmcnt<0>(); break;
+    }
+}
+
+
 int mfma_cu_count();
 
 }  // namespace slak
