@@ -134,6 +134,15 @@ int slak_scale_residual_forward(const void* shortcut, int shortcut_dtype, const 
 int slak_scale_residual_backward(const float* dout, const void* z_bf16, const float* gamma, const float* sample_scale,
                                  void* dz_bf16, float* dgamma, int N, int C, int P, void* workspace, size_t workspace_bytes, void* stream);
 
+/* channels_first LayerNorm of the stem / downsample layers (models/SLaK.py:192-203, :256-261): y[n,c,p] = LN_C(x[n,:,p])*w + b, NCHW in
+ * and out; x/y/g/dx fp32 or bf16 (dx has the dtype of x). */
+size_t slak_ln_cf_workspace_bytes(int N, int C, int P);
+int slak_ln_channels_first_forward(const void* x, int x_dtype, const float* weight, const float* bias, void* y, int y_dtype,
+                                   float* mean, float* rstd, int N, int C, int P, float eps, void* stream);
+int slak_ln_channels_first_backward(const void* g, int g_dtype, const void* x, int x_dtype, const float* weight, const float* mean,
+                                    const float* rstd, void* dx, float* dweight, float* dbias, int N, int C, int P,
+                                    void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---------------------------------------------------------------- next row: branch BatchNorms + adds
  * out = BN1(y1) + BN2(y2) + BN3(y3) of ReparamLargeKernelConv (models/SLaK.py:38-47, :92-95) as one statistics pass, a per-channel
  * finalise and one apply pass; backward likewise (dy_b is affine in (dout, y_b) per channel).  y_b, out, dout, dy_b: bf16 NCHW,

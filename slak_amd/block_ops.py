@@ -246,3 +246,48 @@ def branch_bn3(y1, y2, y3, bn1, bn2, bn3):
                                             float(bn1.eps), 0.0, 0, 0, coef.data_ptr(), None, out.data_ptr(), N, C, H * W, _stream(y1.device)),
                    "slak_bn3_forward_apply")
     return out
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# channels_first LayerNorm of the stem / downsample layers (models/SLaK.py:256-261)
+_SDT = {torch.float32: _lib.SLAK_F32, torch.bfloat16: _lib.SLAK_BF16}
+
+
+class _LnChannelsFirst(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps, out_dtype):
+        _chk(x, "x"); _chk(weight, "weight", torch.float32); _chk(bias, "bias", torch.float32)
+        if x.dtype not in _SDT or out_dtype not in _SDT:
+            raise TypeError("x / out must be float32 or bfloat16")
+        N, C, H, W = x.shape
+        y = torch.empty((N, C, H, W), dtype=out_dtype, device=x.device)
+        mean = torch.empty((N, H * W), dtype=torch.float32, device=x.device)
+        rstd = torch.empty_like(mean)
+        L = _lib.lib()
+        with torch.cuda.device(x.device):
+            _lib.check(L.slak_ln_channels_first_forward(x.data_ptr(), _SDT[x.dtype], weight.data_ptr(), bias.data_ptr(), y.data_ptr(), _SDT[out_dtype],
+                                                        mean.data_ptr(), rstd.data_ptr(), N, C, H * W, float(eps), _stream(x.device)),
+                       "slak_ln_channels_first_forward")
+        ctx.save_for_backward(x, weight, mean, rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, weight, mean, rstd = ctx.saved_tensors
+        N, C, H, W = x.shape
+        g = g.contiguous()
+        if g.dtype not in _SDT:
+            g = g.float()
+        dx = torch.empty_like(x)
+        dw = torch.empty_like(weight); db = torch.empty_like(weight)
+        L = _lib.lib()
+        ws, nb = _workspace(L.slak_ln_cf_workspace_bytes(N, C, H * W), x.device)
+        with torch.cuda.device(x.device):
+            _lib.check(L.slak_ln_channels_first_backward(g.data_ptr(), _SDT[g.dtype], x.data_ptr(), _SDT[x.dtype], weight.data_ptr(), mean.data_ptr(),
+                                                         rstd.data_ptr(), dx.data_ptr(), dw.data_ptr(), db.data_ptr(), N, C, H * W,
+                                                         ws.data_ptr(), nb, _stream(x.device)), "slak_ln_channels_first_backward")
+        return dx, dw, db, None, None
+
+
+def ln_channels_first(x, weight, bias, eps=1e-6, out_dtype=torch.float32):
+    return _LnChannelsFirst.apply(x, weight, bias, eps, out_dtype)

@@ -508,6 +508,109 @@ __global__ __launch_bounds__(BT_THREADS) void scale_residual_bwd_kernel(const fl
     for (int c = tid; c < C; c += BT_THREADS) pt[c] = ((red[c] + red[C + c]) + red[2 * C + c]) + red[3 * C + c];
 }
 
+// ===== channels_first LayerNorm (stem and downsample layers, models/SLaK.py:192-203, :256-261): y[n,c,p] = LN_C(x[n,:,p])*w+b, NCHW in
+// and out.  PyTorch runs it as ~10 elementwise/reduction kernels forward and ~25 backward on fp32 tensors. =====
+template <typename Tin> __device__ __forceinline__ float cf_load(const Tin* p) { return to_f32(*p); }
+template <typename Tout> __device__ __forceinline__ void cf_store(Tout* p, float v);
+template <> __device__ __forceinline__ void cf_store<float>(float* p, float v) { *p = v; }
+template <> __device__ __forceinline__ void cf_store<bf16_t>(bf16_t* p, float v) { p->v = bt_f2bf(v); }
+
+// one workgroup per (image, 64-pixel tile); tile staged as fp32 [C][65]; thread <-> (pixel, channel group)
+template <typename Tin, typename Tout>
+__global__ __launch_bounds__(BT_THREADS) void ln_cf_fwd_kernel(const Tin* __restrict__ x, const float* __restrict__ w, const float* __restrict__ b,
+                                                             Tout* __restrict__ y, float* __restrict__ mean, float* __restrict__ rstd,
+                                                             const TailDims d, float eps) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int C = d.C, P = d.P, TP = d.TP, pitch = TP + 1;
+    float* xs = (float*)smem;                                              // [C][TP+1]
+    float* red = xs + (size_t)C * pitch;                                   // [NG][TP]
+    float* st = red + (BT_THREADS / TP) * TP;                              // [2][TP]
+    const int tid = threadIdx.x;
+    const int n = blockIdx.x / d.tiles_per_image, p0 = (blockIdx.x % d.tiles_per_image) * TP;
+    const Tin* xn = x + (size_t)n * C * P;
+    for (int idx = tid; idx < C * TP; idx += BT_THREADS) {
+        const int c = idx / TP, q = idx - c * TP;
+        xs[c * pitch + q] = (p0 + q < P) ? cf_load(xn + (size_t)c * P + p0 + q) : 0.f;
+    }
+    __syncthreads();
+    const int q = tid % TP, g = tid / TP, NG = BT_THREADS / TP;
+    float s = 0.f;
+    for (int c = g; c < C; c += NG) s += xs[c * pitch + q];
+    red[g * TP + q] = s;
+    __syncthreads();
+    if (g == 0) { float t = 0.f; for (int k = 0; k < NG; ++k) t += red[k * TP + q]; st[q] = t / (float)C; }
+    __syncthreads();
+    const float mu = st[q];
+    float ss = 0.f;
+    for (int c = g; c < C; c += NG) { const float v = xs[c * pitch + q] - mu; ss += v * v; }
+    __syncthreads();
+    red[g * TP + q] = ss;
+    __syncthreads();
+    if (g == 0) {
+        float t = 0.f; for (int k = 0; k < NG; ++k) t += red[k * TP + q];
+        const float r = 1.0f / sqrtf(t / (float)C + eps);
+        st[TP + q] = r;
+        if (p0 + q < P) { mean[(size_t)n * P + p0 + q] = mu; rstd[(size_t)n * P + p0 + q] = r; }
+    }
+    __syncthreads();
+    Tout* yn = y + (size_t)n * C * P;
+    for (int idx = tid; idx < C * TP; idx += BT_THREADS) {
+        const int c = idx / TP, qq = idx - c * TP;
+        if (p0 + qq < P) cf_store(yn + (size_t)c * P + p0 + qq, (xs[c * pitch + qq] - st[qq]) * st[TP + qq] * w[c] + b[c]);
+    }
+}
+
+// dx from g (same NCHW layout); per-tile partials part[tile][0][c] = sum g*xhat, part[tile][1][c] = sum g
+template <typename Tin, typename Tg>
+__global__ __launch_bounds__(BT_THREADS) void ln_cf_bwd_kernel(const Tg* __restrict__ g, const Tin* __restrict__ x, const float* __restrict__ w,
+                                                             const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                             Tin* __restrict__ dx, float* __restrict__ part, const TailDims d) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int C = d.C, P = d.P, TP = d.TP, pitch = TP + 1;
+    float* xh = (float*)smem;                                              // [C][TP+1]  xhat
+    float* gs = xh + (size_t)C * pitch;                                    // [C][TP+1]  g
+    float* red = gs + (size_t)C * pitch;                                   // [2][NG][TP]
+    float* st = red + 2 * (BT_THREADS / TP) * TP;                          // [3][TP]: rstd, m1, m2
+    const int tid = threadIdx.x;
+    const int n = blockIdx.x / d.tiles_per_image, p0 = (blockIdx.x % d.tiles_per_image) * TP;
+    const Tin* xn = x + (size_t)n * C * P;
+    const Tg* gn = g + (size_t)n * C * P;
+    for (int idx = tid; idx < C * TP; idx += BT_THREADS) {
+        const int c = idx / TP, q = idx - c * TP;
+        const bool ok = p0 + q < P;
+        const float mu = ok ? mean[(size_t)n * P + p0 + q] : 0.f, r = ok ? rstd[(size_t)n * P + p0 + q] : 0.f;
+        xh[c * pitch + q] = ok ? (cf_load(xn + (size_t)c * P + p0 + q) - mu) * r : 0.f;
+        gs[c * pitch + q] = ok ? cf_load(gn + (size_t)c * P + p0 + q) : 0.f;
+    }
+    if (tid < TP) st[tid] = (p0 + tid < P) ? rstd[(size_t)n * P + p0 + tid] : 0.f;
+    __syncthreads();
+    const int q = tid % TP, grp = tid / TP, NG = BT_THREADS / TP;
+    {
+        float s1 = 0.f, s2 = 0.f;
+        for (int c = grp; c < C; c += NG) { const float gw = gs[c * pitch + q] * w[c]; s1 += gw; s2 += gw * xh[c * pitch + q]; }
+        red[grp * TP + q] = s1; red[(NG + grp) * TP + q] = s2;
+    }
+    __syncthreads();
+    if (grp == 0) {
+        float t1 = 0.f, t2 = 0.f;
+        for (int k = 0; k < NG; ++k) { t1 += red[k * TP + q]; t2 += red[(NG + k) * TP + q]; }
+        st[TP + q] = t1 / (float)C; st[2 * TP + q] = t2 / (float)C;
+    }
+    __syncthreads();
+    Tin* dxn = dx + (size_t)n * C * P;
+    for (int idx = tid; idx < C * TP; idx += BT_THREADS) {
+        const int c = idx / TP, qq = idx - c * TP;
+        if (p0 + qq < P)
+            cf_store(dxn + (size_t)c * P + p0 + qq, st[qq] * (gs[c * pitch + qq] * w[c] - st[TP + qq] - xh[c * pitch + qq] * st[2 * TP + qq]));
+    }
+    float* pt = part + (size_t)blockIdx.x * 2 * C;
+    for (int c = tid; c < C; c += BT_THREADS) {
+        float a = 0.f, bsum = 0.f;
+        for (int qq = 0; qq < TP; ++qq) { const float gv = gs[c * pitch + qq]; a += gv * xh[c * pitch + qq]; bsum += gv; }
+        pt[c] = a; pt[C + c] = bsum;
+    }
+}
+
 // Column sums of part[ntiles][width] in a fixed order.  gridDim.y slices of the tile range; with one slice the result goes
 // to out0[j] (j < split) / out1[j - split], with several to out0[slice][width] (a second launch adds the slices).
 __global__ void block_tail_reduce(const float* __restrict__ part, float* __restrict__ out0, float* __restrict__ out1, int split,
@@ -709,6 +812,67 @@ int slak_scale_residual_backward(const float* dout, const void* z, const float* 
                        dout, (const uint16_t*)z, gamma, sample_scale, (uint16_t*)dz, part, d);
     SLAK_LAUNCH_CHECK();
     return reduce_partials(part, part + (size_t)grid * 2 * C, dgamma, dgamma, C, grid, C, (hipStream_t)stream);
+}
+
+static TailDims make_dims_cf(int N, int C, int P, int tiles_of_fp32) {
+    TailDims d; d.N = N; d.C = C; d.P = P;
+    int TP = 64;
+    while (TP > 8 && (size_t)tiles_of_fp32 * C * (TP + 1) * 4 > 56 * 1024) TP /= 2;
+    d.TP = TP; d.tiles_per_image = (P + TP - 1) / TP; d.ntiles = N * d.tiles_per_image;
+    return d;
+}
+
+size_t slak_ln_cf_workspace_bytes(int N, int C, int P) {
+    if (N <= 0 || C <= 0 || P <= 0) return 0;
+    const TailDims d = make_dims_cf(N, C, P, 2);
+    return align_up(((size_t)d.ntiles + BT_SLICES) * 2 * C * sizeof(float), 256);
+}
+
+int slak_ln_channels_first_forward(const void* x, int x_dtype, const float* weight, const float* bias, void* y, int y_dtype,
+                                   float* mean, float* rstd, int N, int C, int P, float eps, void* stream) {
+    if (!x || !weight || !bias || !y || !mean || !rstd) return SLAK_ERR_INVALID_ARG;
+    if (N <= 0 || C <= 0 || P <= 0) return SLAK_ERR_INVALID_ARG;
+    if (C > 1024 || (long long)N * C * P >= (1LL << 31)) return SLAK_ERR_UNSUPPORTED;
+    const TailDims d = make_dims_cf(N, C, P, 1);
+    const size_t lds = (size_t)C * (d.TP + 1) * 4 + (size_t)(BT_THREADS / d.TP) * d.TP * 4 + 2 * d.TP * 4 + 16;
+    const dim3 grid((unsigned)d.ntiles);
+#define SLAK_CF_FWD(TI, TO)                                                                                                   \
+    do { if (set_lds((const void*)ln_cf_fwd_kernel<TI, TO>, lds)) return SLAK_ERR_LAUNCH;                                     \
+         hipLaunchKernelGGL((ln_cf_fwd_kernel<TI, TO>), grid, dim3(BT_THREADS), lds, (hipStream_t)stream, (const TI*)x, weight, bias,  \
+                            (TO*)y, mean, rstd, d, eps); } while (0)
+    if (x_dtype == SLAK_F32 && y_dtype == SLAK_F32) SLAK_CF_FWD(float, float);
+    else if (x_dtype == SLAK_F32 && y_dtype == SLAK_BF16) SLAK_CF_FWD(float, bf16_t);
+    else if (x_dtype == SLAK_BF16 && y_dtype == SLAK_F32) SLAK_CF_FWD(bf16_t, float);
+    else if (x_dtype == SLAK_BF16 && y_dtype == SLAK_BF16) SLAK_CF_FWD(bf16_t, bf16_t);
+    else return SLAK_ERR_UNSUPPORTED;
+#undef SLAK_CF_FWD
+    SLAK_LAUNCH_CHECK();
+    return SLAK_OK;
+}
+
+int slak_ln_channels_first_backward(const void* g, int g_dtype, const void* x, int x_dtype, const float* weight, const float* mean,
+                                    const float* rstd, void* dx, float* dweight, float* dbias, int N, int C, int P,
+                                    void* workspace, size_t workspace_bytes, void* stream) {
+    if (!g || !x || !weight || !mean || !rstd || !dx || !dweight || !dbias) return SLAK_ERR_INVALID_ARG;
+    if (N <= 0 || C <= 0 || P <= 0) return SLAK_ERR_INVALID_ARG;
+    if (C > 1024 || (long long)N * C * P >= (1LL << 31)) return SLAK_ERR_UNSUPPORTED;
+    if (!workspace || workspace_bytes < slak_ln_cf_workspace_bytes(N, C, P)) return SLAK_ERR_WORKSPACE;
+    const TailDims d = make_dims_cf(N, C, P, 2);
+    const size_t lds = (size_t)2 * C * (d.TP + 1) * 4 + (size_t)2 * (BT_THREADS / d.TP) * d.TP * 4 + 3 * d.TP * 4 + 16;
+    const dim3 grid((unsigned)d.ntiles);
+    float* part = (float*)workspace;
+#define SLAK_CF_BWD(TI, TG)                                                                                                   \
+    do { if (set_lds((const void*)ln_cf_bwd_kernel<TI, TG>, lds)) return SLAK_ERR_LAUNCH;                                     \
+         hipLaunchKernelGGL((ln_cf_bwd_kernel<TI, TG>), grid, dim3(BT_THREADS), lds, (hipStream_t)stream, (const TG*)g, (const TI*)x, weight, \
+                            mean, rstd, (TI*)dx, part, d); } while (0)
+    if (x_dtype == SLAK_F32 && g_dtype == SLAK_F32) SLAK_CF_BWD(float, float);
+    else if (x_dtype == SLAK_F32 && g_dtype == SLAK_BF16) SLAK_CF_BWD(float, bf16_t);
+    else if (x_dtype == SLAK_BF16 && g_dtype == SLAK_F32) SLAK_CF_BWD(bf16_t, float);
+    else if (x_dtype == SLAK_BF16 && g_dtype == SLAK_BF16) SLAK_CF_BWD(bf16_t, bf16_t);
+    else return SLAK_ERR_UNSUPPORTED;
+#undef SLAK_CF_BWD
+    SLAK_LAUNCH_CHECK();
+    return reduce_partials(part, part + (size_t)d.ntiles * 2 * C, dweight, dbias, C, d.ntiles, 2 * C, (hipStream_t)stream);
 }
 
 }  // extern "C"

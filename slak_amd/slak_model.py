@@ -79,6 +79,10 @@ class LayerNorm(nn.Module):
     def forward(self, x):
         if self.data_format == "channels_last":
             return F.layer_norm(x, self.normalized_shape, self.weight, self.bias, self.eps)
+        if self.fused_cf and x.is_cuda and x.dim() == 4 and x.dtype in (torch.float32, torch.bfloat16) and torch.is_autocast_enabled():
+            # same arithmetic (fp32 statistics, fp32 result) as the explicit ops below, one HIP kernel per direction
+            from . import block_ops
+            return block_ops.ln_channels_first(x.contiguous(), self.weight, self.bias, self.eps, torch.float32)
         u = x.mean(1, keepdim=True)
         s = (x - u).pow(2).mean(1, keepdim=True)
         x = (x - u) / torch.sqrt(s + self.eps)
@@ -193,6 +197,7 @@ def _block_forward_fused_tail(self, shortcut, x):
 Block._forward_fused_tail = _block_forward_fused_tail
 Block.fused_tail = False
 ReparamLargeKernelConv.fused_bn = False
+LayerNorm.fused_cf = False
 
 
 class SLaK(nn.Module):

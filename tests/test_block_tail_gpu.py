@@ -131,3 +131,22 @@ def test_branch_bn3_matches_three_batchnorms(N, C, H, W, gpu):
         oe = block_ops.branch_bn3(ys[0].detach(), ys[1].detach(), ys[2].detach(), *bns)
         oer = refs[0](yr[0].detach()) + refs[1](yr[1].detach()) + refs[2](yr[2].detach())
     _close(oe, oer, 2.0 ** -8 * 1.05, "eval out")
+
+
+@pytest.mark.parametrize("N,C,H,W", [(3, 96, 56, 56), (4, 192, 28, 28), (5, 384, 14, 14), (2, 10, 9, 11)])
+@pytest.mark.parametrize("in_dtype", [torch.float32, torch.bfloat16])
+def test_ln_channels_first_matches_explicit_ops(N, C, H, W, in_dtype, gpu):
+    from slak_amd import block_ops
+    torch.manual_seed(C)
+    x = (torch.randn(N, C, H, W, device=gpu) * 1.5 + 0.2).to(in_dtype).requires_grad_(True)
+    w = (torch.randn(C, device=gpu) * 0.5 + 1).requires_grad_(True); b = (torch.randn(C, device=gpu) * 0.1).requires_grad_(True)
+    g = torch.randn(N, C, H, W, device=gpu)
+    y = block_ops.ln_channels_first(x, w, b, 1e-6, torch.float32)
+    y.backward(g)
+    xr = x.detach().double().requires_grad_(True); wr = w.detach().double().requires_grad_(True); br = b.detach().double().requires_grad_(True)
+    u = xr.mean(1, keepdim=True); s = (xr - u).pow(2).mean(1, keepdim=True)
+    yr = wr[:, None, None] * ((xr - u) / torch.sqrt(s + 1e-6)) + br[:, None, None]          # models/SLaK.py:257-260
+    yr.backward(g.double())
+    _close(y, yr, 2e-6, "y")
+    _close(x.grad, xr.grad, 2.0 ** -8 * 1.05 if in_dtype == torch.bfloat16 else 2e-5, "dx")
+    _close(w.grad, wr.grad, 1e-4, "dw"); _close(b.grad, br.grad, 1e-4, "db")
