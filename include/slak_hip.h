@@ -134,6 +134,12 @@ int slak_scale_residual_forward(const void* shortcut, int shortcut_dtype, const 
 int slak_scale_residual_backward(const float* dout, const void* z_bf16, const float* gamma, const float* sample_scale,
                                  void* dz_bf16, float* dgamma, int N, int C, int P, void* workspace, size_t workspace_bytes, void* stream);
 
+/* GELU backward (exact erf form, nn.GELU()) fused with the bias gradient of the Linear in front of it (models/SLaK.py:158-160):
+ * dy1 = dact * gelu'(y1); dbias[col] = sum_rows dy1.  [rows][cols] bf16 contiguous, cols % 8 == 0. */
+size_t slak_gelu_bwd_workspace_bytes(int rows, int cols);
+int slak_gelu_backward_bias(const void* dact_bf16, const void* y1_bf16, void* dy1_bf16, float* dbias, int rows, int cols,
+                            void* workspace, size_t workspace_bytes, void* stream);
+
 /* channels_first LayerNorm of the stem / downsample layers (models/SLaK.py:192-203, :256-261): y[n,c,p] = LN_C(x[n,:,p])*w + b, NCHW in
  * and out; x/y/g/dx fp32 or bf16 (dx has the dtype of x). */
 size_t slak_ln_cf_workspace_bytes(int N, int C, int P);

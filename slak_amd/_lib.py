@@ -54,6 +54,8 @@ SIGNATURES = {
     "slak_bn3_backward_sums": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _sz, _vp]),
     "slak_bn3_backward_apply": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _d, _vp, ctypes.POINTER(_vp), _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "slak_block_tail_workspace_bytes": (_sz, [_i, _i, _i]),
+    "slak_gelu_bwd_workspace_bytes": (_sz, [_i, _i]),
+    "slak_gelu_backward_bias": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _sz, _vp]),
     "slak_ln_cf_workspace_bytes": (_sz, [_i, _i, _i]),
     "slak_ln_channels_first_forward": (_i, [_vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, ctypes.c_float, _vp]),
     "slak_ln_channels_first_backward": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _sz, _vp]),

@@ -291,3 +291,53 @@ class _LnChannelsFirst(torch.autograd.Function):
 
 def ln_channels_first(x, weight, bias, eps=1e-6, out_dtype=torch.float32):
     return _LnChannelsFirst.apply(x, weight, bias, eps, out_dtype)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+class _MlpSplitK(torch.autograd.Function):
+    """pwconv2(gelu(pwconv1(t))) under bf16 autocast (models/SLaK.py:158-160) with (i) both weight gradients as split-K batched
+    library GEMMs (see _LinearSplitK) and (ii) the GELU backward fused with pwconv1's bias gradient in one HIP kernel.
+    The GEMMs themselves stay hipBLASLt calls."""
+
+    @staticmethod
+    def forward(ctx, t, w1, b1, w2, b2):
+        F = torch.nn.functional
+        w1b, w2b = w1.to(torch.bfloat16), w2.to(torch.bfloat16)
+        y1 = F.linear(t, w1b, b1.to(torch.bfloat16))
+        a = F.gelu(y1)
+        z = F.linear(a, w2b, b2.to(torch.bfloat16))
+        ctx.save_for_backward(t, w1b, y1, a, w2b)
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        t, w1b, y1, a, w2b = ctx.saved_tensors
+        dz2 = dz.reshape(-1, dz.shape[-1])
+        a2 = a.reshape(-1, a.shape[-1]); t2 = t.reshape(-1, t.shape[-1]); y12 = y1.reshape(-1, y1.shape[-1])
+        M = dz2.shape[0]
+        S = max(1, M // 6272)
+        while S > 1 and M % S:
+            S -= 1
+
+        def wgrad(dy, x):
+            if S > 1:
+                return torch.bmm(dy.view(S, M // S, -1).transpose(1, 2), x.view(S, M // S, -1)).sum(0, dtype=torch.float32)
+            return torch.mm(dy.t(), x).float()
+
+        dw2 = wgrad(dz2, a2)
+        db2 = dz2.sum(0, dtype=torch.float32)
+        dact = torch.mm(dz2, w2b)
+        dy1 = torch.empty_like(dact)
+        db1 = torch.empty(dact.shape[1], dtype=torch.float32, device=dact.device)
+        L = _lib.lib()
+        ws, nb = _workspace(L.slak_gelu_bwd_workspace_bytes(M, dact.shape[1]), dact.device)
+        with torch.cuda.device(dact.device):
+            _lib.check(L.slak_gelu_backward_bias(dact.data_ptr(), y12.data_ptr(), dy1.data_ptr(), db1.data_ptr(), M, dact.shape[1],
+                                                 ws.data_ptr(), nb, _stream(dact.device)), "slak_gelu_backward_bias")
+        dw1 = wgrad(dy1, t2)
+        dt = torch.mm(dy1, w1b).view_as(t)
+        return dt, dw1, db1, dw2, db2
+
+
+def mlp_splitk(t, w1, b1, w2, b2):
+    return _MlpSplitK.apply(t, w1, b1, w2, b2)

@@ -611,6 +611,43 @@ __global__ __launch_bounds__(BT_THREADS) void ln_cf_bwd_kernel(const Tg* __restr
     }
 }
 
+// ===== GELU backward fused with the bias gradient of the Linear in front of it: dy1 = dact * gelu'(y1) (exact erf form, like
+// nn.GELU()), part[wg][col] = sum over the workgroup's rows of dy1.  [rows][cols] bf16, cols % 8 == 0.  Thread <-> 8 columns. =====
+__global__ __launch_bounds__(BT_THREADS) void gelu_bwd_bias_kernel(const uint16_t* __restrict__ dact, const uint16_t* __restrict__ y1,
+                                                                 uint16_t* __restrict__ dy1, float* __restrict__ part,
+                                                                 int rows, int cols, int rows_per_wg) {
+    const int cchunks = cols / 8;
+    const int r0 = blockIdx.x * rows_per_wg;
+    int r1 = r0 + rows_per_wg; if (r1 > rows) r1 = rows;
+    for (int cc = threadIdx.x; cc < cchunks; cc += BT_THREADS) {
+        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int r = r0; r < r1; ++r) {
+            const size_t off = (size_t)r * cols + cc * 8;
+            const uint4 gv = *(const uint4*)(dact + off), yv = *(const uint4*)(y1 + off);
+            const unsigned gw[4] = {gv.x, gv.y, gv.z, gv.w}, yw[4] = {yv.x, yv.y, yv.z, yv.w};
+            unsigned ow[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float o[2];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const float g = bf2f((uint16_t)(h ? gw[k] >> 16 : gw[k] & 0xffff)), x = bf2f((uint16_t)(h ? yw[k] >> 16 : yw[k] & 0xffff));
+                    const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
+                    const float pdf = 0.39894228040143268f * __expf(-0.5f * x * x);
+                    o[h] = g * (cdf + x * pdf);
+                }
+                ow[k] = bt_pack2(o[0], o[1]);
+                // the bias gradient sums the ROUNDED values (what dy1.sum(0) over the stored tensor gives)
+                acc[2 * k] += bf2f((uint16_t)(ow[k] & 0xffff)); acc[2 * k + 1] += bf2f((uint16_t)(ow[k] >> 16));
+            }
+            *(uint4*)(dy1 + off) = uint4{ow[0], ow[1], ow[2], ow[3]};
+        }
+        float* pt = part + (size_t)blockIdx.x * cols + cc * 8;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) pt[k] = acc[k];
+    }
+}
+
 // Column sums of part[ntiles][width] in a fixed order.  gridDim.y slices of the tile range; with one slice the result goes
 // to out0[j] (j < split) / out1[j - split], with several to out0[slice][width] (a second launch adds the slices).
 __global__ void block_tail_reduce(const float* __restrict__ part, float* __restrict__ out0, float* __restrict__ out1, int split,
@@ -873,6 +910,28 @@ int slak_ln_channels_first_backward(const void* g, int g_dtype, const void* x, i
 #undef SLAK_CF_BWD
     SLAK_LAUNCH_CHECK();
     return reduce_partials(part, part + (size_t)d.ntiles * 2 * C, dweight, dbias, C, d.ntiles, 2 * C, (hipStream_t)stream);
+}
+
+/* dy1 = dact * gelu'(y1), dbias[col] = sum_rows dy1 (fp32).  workspace >= slak_gelu_bwd_workspace_bytes(rows, cols). */
+size_t slak_gelu_bwd_workspace_bytes(int rows, int cols) {
+    if (rows <= 0 || cols <= 0) return 0;
+    return align_up(((size_t)2048 + BT_SLICES) * cols * sizeof(float), 256);
+}
+int slak_gelu_backward_bias(const void* dact, const void* y1, void* dy1, float* dbias, int rows, int cols,
+                            void* workspace, size_t workspace_bytes, void* stream) {
+    if (!dact || !y1 || !dy1 || !dbias) return SLAK_ERR_INVALID_ARG;
+    if (rows <= 0 || cols <= 0) return SLAK_ERR_INVALID_ARG;
+    if (cols % 8) return SLAK_ERR_UNSUPPORTED;
+    if (!workspace || workspace_bytes < slak_gelu_bwd_workspace_bytes(rows, cols)) return SLAK_ERR_WORKSPACE;
+    // enough workgroups to fill the chip, each a contiguous block of rows (>= 8 rows to amortise the partial row)
+    int nwg = 2048;
+    int rpw = (rows + nwg - 1) / nwg; if (rpw < 8) rpw = 8;
+    nwg = (rows + rpw - 1) / rpw;
+    float* part = (float*)workspace;
+    hipLaunchKernelGGL(gelu_bwd_bias_kernel, dim3((unsigned)nwg), dim3(BT_THREADS), 0, (hipStream_t)stream,
+                       (const uint16_t*)dact, (const uint16_t*)y1, (uint16_t*)dy1, part, rows, cols, rpw);
+    SLAK_LAUNCH_CHECK();
+    return reduce_partials(part, part + (size_t)nwg * cols, dbias, dbias, cols, nwg, cols, (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -181,7 +181,7 @@ def _block_forward_fused_tail(self, shortcut, x):
     one HIP kernel each (slak_amd/block_ops.py); the two Linear layers and GELU are unchanged."""
     from . import block_ops
     t = block_ops.ln_nchw_to_nhwc(x.contiguous(), self.norm.weight.float(), self.norm.bias.float(), self.norm.eps)
-    z = block_ops.linear_splitk(self.act(block_ops.linear_splitk(t, self.pwconv1.weight, self.pwconv1.bias)), self.pwconv2.weight, self.pwconv2.bias)
+    z = block_ops.mlp_splitk(t, self.pwconv1.weight, self.pwconv1.bias, self.pwconv2.weight, self.pwconv2.bias)
     if z.dtype != torch.bfloat16:
         z = z.to(torch.bfloat16)
     scale = None

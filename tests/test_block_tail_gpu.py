@@ -150,3 +150,24 @@ def test_ln_channels_first_matches_explicit_ops(N, C, H, W, in_dtype, gpu):
     _close(y, yr, 2e-6, "y")
     _close(x.grad, xr.grad, 2.0 ** -8 * 1.05 if in_dtype == torch.bfloat16 else 2e-5, "dx")
     _close(w.grad, wr.grad, 1e-4, "dw"); _close(b.grad, br.grad, 1e-4, "db")
+
+
+@pytest.mark.parametrize("M,C", [(6272, 96), (3136, 192), (1000, 384), (77, 768)])
+def test_mlp_splitk_matches_torch(M, C, gpu):
+    """pwconv2(gelu(pwconv1(t))): outputs and all five gradients vs the plain torch modules in fp64 on the same bf16 operands."""
+    from slak_amd import block_ops
+    torch.manual_seed(M)
+    t = torch.randn(M, C, device=gpu).bfloat16().requires_grad_(True)
+    w1 = (torch.randn(4 * C, C, device=gpu) * 0.05).requires_grad_(True); b1 = (torch.randn(4 * C, device=gpu) * 0.05).requires_grad_(True)
+    w2 = (torch.randn(C, 4 * C, device=gpu) * 0.05).requires_grad_(True); b2 = (torch.randn(C, device=gpu) * 0.05).requires_grad_(True)
+    dz = torch.randn(M, C, device=gpu).bfloat16()
+    z = block_ops.mlp_splitk(t, w1, b1, w2, b2)
+    z.backward(dz)
+    td = t.detach().double().requires_grad_(True)
+    ps = [p.detach().bfloat16().double().requires_grad_(True) for p in (w1, b1, w2, b2)]
+    zr = F.linear(F.gelu(F.linear(td, ps[0], ps[1])), ps[2], ps[3])
+    zr.backward(dz.double())
+    _close(z, zr, 1.5e-2, "z")                       # intermediate activations are rounded to bf16 in the bf16 pipeline
+    _close(t.grad, td.grad, 2e-2, "dt")
+    for got, ref, n in ((w1.grad, ps[0].grad, "dw1"), (b1.grad, ps[1].grad, "db1"), (w2.grad, ps[2].grad, "dw2"), (b2.grad, ps[3].grad, "db2")):
+        _close(got, ref, 2e-2, n)
