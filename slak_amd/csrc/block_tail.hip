@@ -616,35 +616,61 @@ __global__ __launch_bounds__(BT_THREADS) void ln_cf_bwd_kernel(const Tg* __restr
 __global__ __launch_bounds__(BT_THREADS) void gelu_bwd_bias_kernel(const uint16_t* __restrict__ dact, const uint16_t* __restrict__ y1,
                                                                  uint16_t* __restrict__ dy1, float* __restrict__ part,
                                                                  int rows, int cols, int rows_per_wg) {
+    // threads as (row lane ry, column chunk cx): narrow matrices (cols = 384) still use the whole workgroup
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float* red = (float*)smem;                                   // [nry][cols]
     const int cchunks = cols / 8;
+    const int ccn = cchunks < BT_THREADS ? cchunks : BT_THREADS, nry = BT_THREADS / ccn;
+    const int ry = threadIdx.x / ccn, cx = threadIdx.x - ry * ccn;
     const int r0 = blockIdx.x * rows_per_wg;
     int r1 = r0 + rows_per_wg; if (r1 > rows) r1 = rows;
-    for (int cc = threadIdx.x; cc < cchunks; cc += BT_THREADS) {
+    for (int cc0 = 0; cc0 < cchunks; cc0 += ccn) {
+        const int cc = cc0 + cx;
         float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        for (int r = r0; r < r1; ++r) {
-            const size_t off = (size_t)r * cols + cc * 8;
-            const uint4 gv = *(const uint4*)(dact + off), yv = *(const uint4*)(y1 + off);
-            const unsigned gw[4] = {gv.x, gv.y, gv.z, gv.w}, yw[4] = {yv.x, yv.y, yv.z, yv.w};
-            unsigned ow[4];
+        if (ry < nry && cc < cchunks) {
+            for (int r = r0 + ry; r < r1; r += nry) {
+                const size_t off = (size_t)r * cols + cc * 8;
+                const uint4 gv = *(const uint4*)(dact + off), yv = *(const uint4*)(y1 + off);
+                const unsigned gw[4] = {gv.x, gv.y, gv.z, gv.w}, yw[4] = {yv.x, yv.y, yv.z, yv.w};
+                unsigned ow[4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                float o[2];
+                for (int k = 0; k < 4; ++k) {
+                    float o[2];
 #pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const float g = bf2f((uint16_t)(h ? gw[k] >> 16 : gw[k] & 0xffff)), x = bf2f((uint16_t)(h ? yw[k] >> 16 : yw[k] & 0xffff));
-                    const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
-                    const float pdf = 0.39894228040143268f * __expf(-0.5f * x * x);
-                    o[h] = g * (cdf + x * pdf);
+                    for (int h = 0; h < 2; ++h) {
+                        const float g = bf2f((uint16_t)(h ? gw[k] >> 16 : gw[k] & 0xffff)), x = bf2f((uint16_t)(h ? yw[k] >> 16 : yw[k] & 0xffff));
+                        // erf(x/sqrt2) by Abramowitz-Stegun 7.1.26 (|err| < 1.5e-7, far below bf16 output rounding); it shares
+                        // exp(-x^2/2) with the density term, so the whole derivative costs one exp and one rcp
+                        const float e = __expf(-0.5f * x * x);
+                        const float zabs = fabsf(x) * 0.70710678118654752f;
+                        const float t = __frcp_rn(1.0f + 0.3275911f * zabs);
+                        const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+                        const float erf_abs = 1.0f - poly * e;
+                        const float cdf = 0.5f * (1.0f + copysignf(erf_abs, x));
+                        o[h] = g * (cdf + x * 0.39894228040143268f * e);
+                    }
+                    ow[k] = bt_pack2(o[0], o[1]);
+                    // the bias gradient sums the ROUNDED values (what dy1.sum(0) over the stored tensor gives)
+                    acc[2 * k] += bf2f((uint16_t)(ow[k] & 0xffff)); acc[2 * k + 1] += bf2f((uint16_t)(ow[k] >> 16));
                 }
-                ow[k] = bt_pack2(o[0], o[1]);
-                // the bias gradient sums the ROUNDED values (what dy1.sum(0) over the stored tensor gives)
-                acc[2 * k] += bf2f((uint16_t)(ow[k] & 0xffff)); acc[2 * k + 1] += bf2f((uint16_t)(ow[k] >> 16));
+                *(uint4*)(dy1 + off) = uint4{ow[0], ow[1], ow[2], ow[3]};
             }
-            *(uint4*)(dy1 + off) = uint4{ow[0], ow[1], ow[2], ow[3]};
         }
-        float* pt = part + (size_t)blockIdx.x * cols + cc * 8;
+        __syncthreads();                                         // previous pass's partials have been consumed
+        if (ry < nry && cc < cchunks) {
 #pragma unroll
-        for (int k = 0; k < 8; ++k) pt[k] = acc[k];
+            for (int k = 0; k < 8; ++k) red[(size_t)ry * cols + cc * 8 + k] = acc[k];
+        }
+        __syncthreads();
+        if (ry == 0 && cc < cchunks) {                           // fixed order over the row lanes
+            float* pt = part + (size_t)blockIdx.x * cols + cc * 8;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                float t = 0.f;
+                for (int q = 0; q < nry; ++q) t += red[(size_t)q * cols + cc * 8 + k];
+                pt[k] = t;
+            }
+        }
     }
 }
 
@@ -928,7 +954,10 @@ int slak_gelu_backward_bias(const void* dact, const void* y1, void* dy1, float* 
     int rpw = (rows + nwg - 1) / nwg; if (rpw < 8) rpw = 8;
     nwg = (rows + rpw - 1) / rpw;
     float* part = (float*)workspace;
-    hipLaunchKernelGGL(gelu_bwd_bias_kernel, dim3((unsigned)nwg), dim3(BT_THREADS), 0, (hipStream_t)stream,
+    const int cchunks = cols / 8, ccn = cchunks < BT_THREADS ? cchunks : BT_THREADS;
+    const size_t lds = (size_t)(BT_THREADS / ccn) * cols * sizeof(float) + 16;
+    if (set_lds((const void*)gelu_bwd_bias_kernel, lds)) return SLAK_ERR_LAUNCH;
+    hipLaunchKernelGGL(gelu_bwd_bias_kernel, dim3((unsigned)nwg), dim3(BT_THREADS), lds, (hipStream_t)stream,
                        (const uint16_t*)dact, (const uint16_t*)y1, (uint16_t*)dy1, part, rows, cols, rpw);
     SLAK_LAUNCH_CHECK();
     return reduce_partials(part, part + (size_t)nwg * cols, dbias, dbias, cols, nwg, cols, (hipStream_t)stream);
