@@ -25,12 +25,12 @@ def ops_of(db, counter):
     for n, v in seq:
         if "toeplitz_pack" in n:
             cur = ["conv", v]
-        elif "dwconv_mfma_dma_kernel" in n or "dwconv_mfma_fwd_kernel" in n or "dwconv_direct_kernel" in n:
+        elif "dwconv_mfma_dma_kernel" in n or "dwconv_mfma_fwd_kernel" in n or "dwconv_direct_kernel" in n or "dwconv_mfma_small_kernel" in n:
             if cur is None: cur = ["conv", 0.0]
             cur[1] += v; ops.append(tuple(cur)); cur = None
         elif "dwconv_prep_weights" in n:
             cur = ["conv", v]
-        elif "wgrad_kernel" in n:
+        elif "wgrad_kernel" in n or "wgrad_dma_kernel" in n:
             cur = ["wgrad", v]
         elif "wgrad_reduce" in n:
             cur[1] += v; ops.append(tuple(cur)); cur = None
