@@ -153,18 +153,20 @@ int slak_ln_channels_first_backward(const void* g, int g_dtype, const void* x, i
  * out = BN1(y1) + BN2(y2) + BN3(y3) of ReparamLargeKernelConv (models/SLaK.py:38-47, :92-95) as one statistics pass, a per-channel
  * finalise and one apply pass; backward likewise (dy_b is affine in (dout, y_b) per channel).  y_b, out, dout, dy_b: bf16 NCHW,
  * P = H*W.  The *_sums calls return THIS RANK's per-channel sums; under SyncBatchNorm the caller all-reduces them (6C / 4C floats,
- * one collective per block instead of three gathers) and passes the global sums and the global element count to the *_apply calls. */
+ * one collective per block instead of three gathers) and passes the global sums and the global element count to the *_apply calls
+ * (`count`, or `count_dev` -- a device float, e.g. the all-reduced count -- when non-NULL: no host synchronisation). */
 size_t slak_bn3_workspace_bytes(int N, int C);
 int slak_bn3_forward_sums(const void* y1, const void* y2, const void* y3, float* local_sums /*[C][6]*/, int N, int C, int P,
                           void* workspace, size_t workspace_bytes, void* stream);
-int slak_bn3_forward_apply(const void* y1, const void* y2, const void* y3, const float* global_sums, double count,
+int slak_bn3_forward_apply(const void* y1, const void* y2, const void* y3, const float* global_sums, double count, const float* count_dev,
                            const float* const* gamma_host3, const float* const* beta_host3, float* const* running_mean_host3,
                            float* const* running_var_host3, float eps, float momentum, int training, int update_running,
                            float* coef /*[C][4]*/, float* stats /*[C][6]*/, void* out, int N, int C, int P, void* stream);
 int slak_bn3_backward_sums(const void* dout, const void* y1, const void* y2, const void* y3, float* local_sums /*[C][4]*/,
                            int N, int C, int P, void* workspace, size_t workspace_bytes, void* stream);
 int slak_bn3_backward_apply(const void* dout, const void* y1, const void* y2, const void* y3, const float* global_sums,
-                            const float* local_sums, double count, const float* stats, const float* const* gamma_host3,
+                            const float* local_sums, double count, const float* count_dev /* device count overrides `count` */,
+                            const float* stats, const float* const* gamma_host3,
                             float* bcoef /*[C][9]*/, float* dgamma /*[3][C]*/, float* dbeta /*[3][C]*/,
                             void* dy1, void* dy2, void* dy3, int N, int C, int P, void* stream);
 

@@ -49,10 +49,10 @@ SIGNATURES = {
     "slak_mask_checksum": (_i, [_vp, ctypes.POINTER(ctypes.c_ulonglong), _vp]),
     "slak_bn3_workspace_bytes": (_sz, [_i, _i]),
     "slak_bn3_forward_sums": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _sz, _vp]),
-    "slak_bn3_forward_apply": (_i, [_vp, _vp, _vp, _vp, _d, ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(_vp),
+    "slak_bn3_forward_apply": (_i, [_vp, _vp, _vp, _vp, _d, _vp, ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(_vp),
                                     ctypes.c_float, ctypes.c_float, _i, _i, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "slak_bn3_backward_sums": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _sz, _vp]),
-    "slak_bn3_backward_apply": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _d, _vp, ctypes.POINTER(_vp), _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    "slak_bn3_backward_apply": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _d, _vp, _vp, ctypes.POINTER(_vp), _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "slak_block_tail_workspace_bytes": (_sz, [_i, _i, _i]),
     "slak_gelu_bwd_workspace_bytes": (_sz, [_i, _i]),
     "slak_gelu_backward_bias": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _sz, _vp]),

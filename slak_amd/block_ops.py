@@ -172,21 +172,23 @@ class _BranchBN3(torch.autograd.Function):
             _lib.check(L.slak_bn3_forward_sums(y1.data_ptr(), y2.data_ptr(), y3.data_ptr(), sums.data_ptr(), N, C, P,
                                                ws.data_ptr(), nb, _stream(dev)), "slak_bn3_forward_sums")
         count = float(N * P)
+        count_dev = None
         if group is not None:
-            sums[C * 6] = count
+            sums[C * 6:].fill_(count)
             dist.all_reduce(sums, group=group)
-            count = float(sums[C * 6].item())
+            count_dev = sums[C * 6:]                                 # global element count, stays on the device (no host sync)
         coef = torch.empty(C * 4, dtype=torch.float32, device=dev)
         stats = torch.empty(C * 6, dtype=torch.float32, device=dev)
         out = torch.empty_like(y1)
         with torch.cuda.device(dev):
             _lib.check(L.slak_bn3_forward_apply(y1.data_ptr(), y2.data_ptr(), y3.data_ptr(), sums.data_ptr(), count,
-                                                _ptr3(gam), _ptr3(bet), _ptr3(rmean), _ptr3(rvar), eps, float(momentum), 1,
+                                                count_dev.data_ptr() if count_dev is not None else None, _ptr3(gam), _ptr3(bet), _ptr3(rmean), _ptr3(rvar), eps, float(momentum), 1,
                                                 1 if bns[0].track_running_stats else 0,
                                                 coef.data_ptr(), stats.data_ptr(), out.data_ptr(), N, C, P, _stream(dev)), "slak_bn3_forward_apply")
         ctx.save_for_backward(y1, y2, y3, g1, g2, g3, stats)
         ctx.group = group
         ctx.count = count
+        ctx.count_dev = count_dev
         return out
 
     @staticmethod
@@ -215,7 +217,8 @@ class _BranchBN3(torch.autograd.Function):
         d1, d2, d3 = torch.empty_like(y1), torch.empty_like(y2), torch.empty_like(y3)
         with torch.cuda.device(dev):
             _lib.check(L.slak_bn3_backward_apply(dout.data_ptr(), y1.data_ptr(), y2.data_ptr(), y3.data_ptr(), gsums.data_ptr(),
-                                                 lsums.data_ptr(), ctx.count, stats.data_ptr(), _ptr3([g1, g2, g3]),
+                                                 lsums.data_ptr(), ctx.count, ctx.count_dev.data_ptr() if ctx.count_dev is not None else None,
+                                                 stats.data_ptr(), _ptr3([g1, g2, g3]),
                                                  bcoef.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(),
                                                  d1.data_ptr(), d2.data_ptr(), d3.data_ptr(), N, C, P, _stream(dev)), "slak_bn3_backward_apply")
         return d1, d2, d3, dgamma[0], dbeta[0], dgamma[1], dbeta[1], dgamma[2], dbeta[2], None, None
@@ -240,7 +243,7 @@ def branch_bn3(y1, y2, y3, bn1, bn2, bn3):
     coef = torch.empty(C * 4, dtype=torch.float32, device=y1.device)
     out = torch.empty_like(y1)
     with torch.cuda.device(y1.device):
-        _lib.check(L.slak_bn3_forward_apply(y1.data_ptr(), y2.data_ptr(), y3.data_ptr(), None, 0.0,
+        _lib.check(L.slak_bn3_forward_apply(y1.data_ptr(), y2.data_ptr(), y3.data_ptr(), None, 0.0, None,
                                             _ptr3([b.weight for b in bns]), _ptr3([b.bias for b in bns]),
                                             _ptr3([b.running_mean for b in bns]), _ptr3([b.running_var for b in bns]),
                                             float(bn1.eps), 0.0, 0, 0, coef.data_ptr(), None, out.data_ptr(), N, C, H * W, _stream(y1.device)),

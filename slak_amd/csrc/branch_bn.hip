@@ -136,9 +136,10 @@ struct Bn3Params {
     float* running_mean[3]; float* running_var[3];
 };
 __global__ void bn3_finalize_fwd(const float* __restrict__ sums, Bn3Params bp, float* __restrict__ coef, float* __restrict__ stats,
-                                 int C, float count, float eps, float momentum, int update_running) {
+                                 int C, float count, const float* __restrict__ count_dev, float eps, float momentum, int update_running) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
+    if (count_dev) count = *count_dev;                             // all-reduced element count (SyncBatchNorm), stays on the device
     float shift = 0.f;
 #pragma unroll
     for (int b = 0; b < 3; ++b) {
@@ -201,9 +202,10 @@ __global__ __launch_bounds__(BN_THREADS) void bn3_apply_fwd(const uint16_t* __re
 // bcoef[c][b][0..2] = A, B, C0 with dy_b = A*dout + B*y_b + C0.
 __global__ void bn3_finalize_bwd(const float* __restrict__ gsums, const float* __restrict__ lsums, const float* __restrict__ stats,
                                  Bn3Params bp, float* __restrict__ bcoef, float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                 int C, float count) {
+                                 int C, float count, const float* __restrict__ count_dev) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
+    if (count_dev) count = *count_dev;
 #pragma unroll
     for (int b = 0; b < 3; ++b) {
         const float mean = stats[c * 6 + 2 * b], inv = stats[c * 6 + 2 * b + 1], g = bp.gamma[b][c];
@@ -293,7 +295,7 @@ int slak_bn3_forward_sums(const void* y1, const void* y2, const void* y3, float*
 
 /* gamma/beta/running_*: arrays of 3 device pointers (host memory).  training != 0: statistics from global_sums / count, running stats
  * updated; training == 0: running statistics (global_sums ignored).  Writes coef[C][4], stats[C][6] and out. */
-int slak_bn3_forward_apply(const void* y1, const void* y2, const void* y3, const float* global_sums, double count,
+int slak_bn3_forward_apply(const void* y1, const void* y2, const void* y3, const float* global_sums, double count, const float* count_dev,
                            const float* const* gamma, const float* const* beta, float* const* running_mean, float* const* running_var,
                            float eps, float momentum, int training, int update_running,
                            float* coef, float* stats, void* out, int N, int C, int P, void* stream) {
@@ -304,7 +306,7 @@ int slak_bn3_forward_apply(const void* y1, const void* y2, const void* y3, const
     for (int b = 0; b < 3; ++b) { bp.gamma[b] = gamma[b]; bp.beta[b] = beta[b]; bp.running_mean[b] = running_mean[b]; bp.running_var[b] = running_var[b]; }
     if (training)
         hipLaunchKernelGGL(bn3_finalize_fwd, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, global_sums, bp, coef, stats, C,
-                           (float)count, eps, momentum, update_running);
+                           (float)count, count_dev, eps, momentum, update_running);
     else
         hipLaunchKernelGGL(bn3_finalize_eval, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, bp, coef, C, eps);
     const int R = N * C;
@@ -331,7 +333,7 @@ int slak_bn3_backward_sums(const void* dout, const void* y1, const void* y2, con
 
 /* dgamma, dbeta: [3][C] (local gradients); bcoef scratch [C][9]; dy1..3 outputs */
 int slak_bn3_backward_apply(const void* dout, const void* y1, const void* y2, const void* y3, const float* global_sums,
-                            const float* local_sums, double count, const float* stats, const float* const* gamma,
+                            const float* local_sums, double count, const float* count_dev, const float* stats, const float* const* gamma,
                             float* bcoef, float* dgamma, float* dbeta, void* dy1, void* dy2, void* dy3, int N, int C, int P, void* stream) {
     if (!dout || !y1 || !y2 || !y3 || !global_sums || !local_sums || !stats || !gamma || !bcoef || !dgamma || !dbeta || !dy1 || !dy2 || !dy3)
         return SLAK_ERR_INVALID_ARG;
@@ -339,7 +341,7 @@ int slak_bn3_backward_apply(const void* dout, const void* y1, const void* y2, co
     Bn3Params bp;
     for (int b = 0; b < 3; ++b) { bp.gamma[b] = gamma[b]; bp.beta[b] = nullptr; bp.running_mean[b] = nullptr; bp.running_var[b] = nullptr; }
     hipLaunchKernelGGL(bn3_finalize_bwd, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, global_sums, local_sums, stats, bp,
-                       bcoef, dgamma, dbeta, C, (float)count);
+                       bcoef, dgamma, dbeta, C, (float)count, count_dev);
     const int R = N * C;
     hipLaunchKernelGGL(bn3_apply_bwd, dim3(bn_grid(R, P)), dim3(BN_THREADS), 0, (hipStream_t)stream,
                        (const uint16_t*)dout, (const uint16_t*)y1, (const uint16_t*)y2, (const uint16_t*)y3, (const float*)bcoef,

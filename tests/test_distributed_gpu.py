@@ -1,0 +1,102 @@
+"""Two ranks on ONE GPU (gloo backend, CUDA tensors) -- the data-parallel semantics of the fused ops that talk to torch.distributed:
+SyncBatchNorm statistics of branch_bn3 (one all-reduce forward, one backward) must reproduce the single-process full-batch result,
+and a DDP-wrapped block with every fused op on must step to the same weights as the single process.  (pytest -m gpu)"""
+import os
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+import torch.nn as nn
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda:0")
+    from slak_amd import block_ops
+    import slak_amd.slak_model as M
+    torch.manual_seed(0)
+    N, C, H = 8, 12, 14
+    ys_full = [(torch.randn(N, C, H, H, device=dev) * (1 + i)).bfloat16() for i in range(3)]
+    dout_full = torch.randn(N, C, H, H, device=dev).bfloat16()
+    bns = [nn.SyncBatchNorm(C).to(dev) for _ in range(3)]
+    for i, bn in enumerate(bns):
+        with torch.no_grad():
+            bn.weight.fill_(1.0 + 0.1 * i); bn.bias.fill_(0.05 * i)
+    sl = slice(rank * N // world, (rank + 1) * N // world)
+    ys = [y[sl].clone().requires_grad_(True) for y in ys_full]
+    o = block_ops.branch_bn3(ys[0], ys[1], ys[2], *bns)
+    o.backward(dout_full[sl])
+    res = dict(out=o.detach().float().cpu(), dy=[y.grad.float().cpu() for y in ys], dgamma=[bn.weight.grad.cpu() for bn in bns],
+               rm=[bn.running_mean.cpu() for bn in bns], rv=[bn.running_var.cpu() for bn in bns])
+    # DDP block step
+    torch.manual_seed(1)
+    M.use_sync_bn = True
+    M.Block.fused_tail = True; M.ReparamLargeKernelConv.fused_bn = True
+    blk = M.Block(16, drop_path=0.0, layer_scale_init_value=0.5, kernel_size=(13, 5), Decom=True, bn=True, lowp_dwconv=True).to(dev)
+    ddp = nn.parallel.DistributedDataParallel(blk, device_ids=[0])
+    opt = torch.optim.SGD(ddp.parameters(), lr=0.1)
+    xfull = torch.randn(8, 16, 14, 14, device=dev)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        loss = ddp(xfull[rank * 4:(rank + 1) * 4]).float().pow(2).mean()
+    loss.backward()
+    opt.step()
+    res["w"] = {k: v.detach().float().cpu() for k, v in blk.state_dict().items()}
+    if rank == 0:
+        torch.save(res, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_match_single_process(gpu, tmp_path):
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    out = str(tmp_path / "r0.pt")
+    mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
+    got = torch.load(out)
+    # single process, full batch
+    from slak_amd import block_ops
+    import slak_amd.slak_model as M
+    dev = gpu
+    torch.manual_seed(0)
+    N, C, H = 8, 12, 14
+    ys_full = [(torch.randn(N, C, H, H, device=dev) * (1 + i)).bfloat16().requires_grad_(True) for i in range(3)]
+    dout_full = torch.randn(N, C, H, H, device=dev).bfloat16()
+    bns = [nn.BatchNorm2d(C).to(dev) for _ in range(3)]
+    for i, bn in enumerate(bns):
+        with torch.no_grad():
+            bn.weight.fill_(1.0 + 0.1 * i); bn.bias.fill_(0.05 * i)
+    o = block_ops.branch_bn3(ys_full[0], ys_full[1], ys_full[2], *bns)
+    o.backward(dout_full)
+    half = slice(0, N // 2)
+    assert (got["out"] - o.detach().float().cpu()[half]).abs().max() <= 2e-2
+    for i in range(3):
+        assert (got["dy"][i] - ys_full[i].grad.float().cpu()[half]).abs().max() <= 2e-2 * max(1.0, ys_full[i].grad.abs().max().item())
+        assert torch.allclose(got["rm"][i], bns[i].running_mean.cpu(), atol=1e-5)
+        assert torch.allclose(got["rv"][i], bns[i].running_var.cpu(), atol=1e-4)
+    # DDP block: same weights after one step as a single process on the full batch (BN stats are global, loss is a mean)
+    torch.manual_seed(1)
+    M.use_sync_bn = False
+    M.Block.fused_tail = True; M.ReparamLargeKernelConv.fused_bn = True
+    try:
+        blk = M.Block(16, drop_path=0.0, layer_scale_init_value=0.5, kernel_size=(13, 5), Decom=True, bn=True, lowp_dwconv=True).to(dev)
+        opt = torch.optim.SGD(blk.parameters(), lr=0.1)
+        xfull = torch.randn(8, 16, 14, 14, device=dev)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            loss = blk(xfull).float().pow(2).mean()
+        loss.backward()
+        opt.step()
+    finally:
+        M.Block.fused_tail = False; M.ReparamLargeKernelConv.fused_bn = False; M.use_sync_bn = True
+    for k, v in blk.state_dict().items():
+        if "num_batches" in k:
+            continue
+        ref = v.detach().float().cpu()
+        assert (got["w"][k] - ref).abs().max() <= 2e-2 * max(1e-3, ref.abs().max().item()) + 1e-5, k
