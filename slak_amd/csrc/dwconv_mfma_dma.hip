@@ -16,20 +16,30 @@
 // tools/dma_probe.hip), so a plane lands as a plain row-major image of pitch W; the zero padding the algorithm needs is
 // applied to the B fragments (v_cndmask on rows outside the plane and on k >= Wt), which also keeps NaN/Inf of a
 // neighbouring row from leaking in.
-// Synchronisation: waves 0,1 issue the DMAs (inline asm, invisible to hipcc's waitcnt pass) and wait for them with a
-// counted `s_waitcnt vmcnt(N)` -- exact, because those waves issue no other vector-memory operation in the loop;
-// waves 2,3 copy finished planes from the LDS out-buffer to HBM.  Barriers are raw s_barrier + lgkmcnt(0), never
+// Synchronisation: ONE barrier per group.  Group g is issued entirely by wave g%4 (inline asm, invisible to hipcc's waitcnt
+// pass); the same wave waits for it with `s_waitcnt vmcnt(0)` just before the barrier of the iteration that consumes it --
+// exact, because between issuing group g and waiting for it that wave issues no other DMA (its next one is g+4), only
+// output stores that are an iteration old.  After the barrier every wave copies the previous group's results from the LDS
+// out-buffer to HBM (16 bytes per lane, fully coalesced) and then computes.  Barriers are raw s_barrier + lgkmcnt(0), never
 // __syncthreads() (which would drain the DMA queue).
+// Toeplitz fragments: T_r[o, i] = w_r[i - o + padL] depends on i - o only, so a lane's 8 consecutive k are an 8-element
+// WINDOW of the zero-padded filter row.  The filter is staged once per workgroup in LDS as bf16/fp16 in two copies (one
+// shifted by an element, so every window starts dword-aligned in one of them) and each fragment is 4 ds_read_b32: no pack
+// kernel, no 40 KB fragment fetch per workgroup.
 #include "mfma_common.h"
 
 namespace slak {
 
-constexpr int DMA_NB = 4;               // ring depth (groups)
+constexpr int DMA_NB = 4;               // ring depth (groups), horizontal kernels
+constexpr int DMA_NBV = 3;              // vertical kernels: 3 slots + double-buffered x^T
+constexpr int WIN_ZP = 64;              // zeros in front of a filter row (window starts never go negative)
+constexpr int WIN_LEN = 192;            // elements per padded filter row
+constexpr int ZROW_LEN = 128;           // elements of the all-zero row B fragments of out-of-plane rows point at
 
 unsigned long long* g_dma_dbg = nullptr;   // dev hook: slak_debug_set_phase_buffer()
 
 struct MfmaDmaParams {
-    const void* x; const float* w; const uint16_t* frags; void* y;
+    const void* x; const float* w; void* y;
     int N, C, H, W, kh, kw, flip;
     int Wt, Wl, KL, padL;
     int G;                 // planes per group (iteration)
@@ -38,32 +48,36 @@ struct MfmaDmaParams {
     int chunks_pp;         // 16-byte chunks per plane (HW/8)
     int group_elems;       // LDS elements per ring slot (G*HW)
     int PT;                // pitch of the transposed image (vertical kernels)
-    int xt_rows;           // rows of one transposed plane image (W rounded up to 16)
+    int xt_rows;           // rows of one transposed plane image (= W)
     int planes_per_wg, slices;
+    unsigned m_cpp, m_pp, m_cbs;   // magic multipliers: n / chunks_pp, n / (blocks per plane), n / (16-column blocks per row)
+    int tr_pp, tr_cbs;             // transpose blocks per plane, per 4-row band
     unsigned tensor_bytes;
     unsigned long long* dbg;   // optional phase timers (s_memtime), [wave][8]; NULL in production
+    int ablate;                // dev: 1 no MFMA phase, 2 no DMA, 3 no global stores
+    int stagger;               // dev: s_sleep units (64 cycles) per co-resident workgroup index
 };
 
-constexpr int DMA_WAVES = 2;            // waves 0..1 issue DMAs, waves 2..3 store results
-constexpr int DMA_NCO = 4;              // 16-byte copy-out chunks per storing thread per group (upper bound)
-constexpr int DMA_MAX_IPW = 4;          // DMA instructions per issuing wave per group (upper bound)
+constexpr int DMA_NCO = 2;              // 16-byte copy-out chunks per thread per group (upper bound)
+constexpr int DMA_MAX_IPG = 16;         // DMA instructions per group (upper bound; one wave issues a whole group)
 constexpr int DMA_NTR = 4;              // transpose blocks (4 rows x 16 cols) per lane group per group of planes (upper bound)
+constexpr int DMA_WCH = 5;              // filter elements staged per lane of the staging wave (upper bound, 64 lanes)
 
 // MT: 32-row tiles along the Toeplitz axis (wave w owns tile w % MT); KS: 16-deep k-steps; VERT: long axis = H;
 // BAND: the filter is much shorter than the map (5x5 branch) -> skip all-zero Toeplitz blocks (wave-uniform branches).
-// PACKED: Toeplitz fragments come from the workspace (toeplitz_pack_kernel; pays for MT=2: 20 fragments per wave), else they are
-// built in the kernel from the fp32 filter (MT=1: 10 fragments per wave, cheaper than a second launch).
 // R16: image rows are 16-byte aligned (W % 8 == 0); otherwise B fragments are read as two 8-byte halves.
-template <typename T, int MT, int KS, bool VERT, bool BAND, bool R16, bool PACKED>
+template <typename T, int MT, int KS, bool VERT, bool BAND, bool R16>
 __global__ __launch_bounds__(MF_THREADS, 3) void dwconv_mfma_dma_kernel(const MfmaDmaParams p) {
     constexpr int NG = MF_TAPS;
     constexpr int WL = MF_WAVES / MT;
+    constexpr int NB = VERT ? DMA_NBV : DMA_NB;
     extern __shared__ __attribute__((aligned(16))) uint16_t lds[];
     const int HW = p.H * p.W;
-    uint16_t* ring = lds;                                            // DMA_NB slots of group_elems (+ slack behind the last)
-    uint16_t* lout = lds + DMA_NB * p.group_elems + 64;              // 2 x [G][HW]
-    float* lw = (float*)(lout + 2 * p.G * HW);                       // this channel's kh*kw filter (fp32)
-    uint16_t* xt = (uint16_t*)(lw + ((p.kh * p.kw + 3) & ~3));       // vertical only: [G][xt_rows][PT]
+    uint16_t* ring = lds;                                            // NB slots of group_elems (+ slack behind the last)
+    uint16_t* lout = lds + NB * p.group_elems + 64;                  // 2 x [G][HW]
+    uint16_t* zrow = lout + 2 * p.G * HW;                            // ZROW_LEN zeros
+    uint16_t* win = zrow + ZROW_LEN;                                 // [2 copies][5 taps][WIN_LEN]
+    uint16_t* xt = win + 2 * MF_TAPS * WIN_LEN;                      // vertical only: 2 x [G][xt_rows][PT]
 
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, lhi = lane >> 5;
     const int wave = wave_id_uniform();
@@ -75,8 +89,9 @@ __global__ __launch_bounds__(MF_THREADS, 3) void dwconv_mfma_dma_kernel(const Mf
     int n_end = n_begin + p.planes_per_wg; if (n_end > p.N) n_end = p.N;
     if (n_begin >= n_end) return;
     const int iters = (n_end - n_begin + p.G - 1) / p.G;
+    if (p.dbg && tid == 0) p.dbg[64 + blockIdx.x * 8 + 0] = __builtin_amdgcn_s_memrealtime();   // dev: 100 MHz stamps per workgroup
 
-    // ---- DMA descriptor and this wave's share of a group's chunks -------------------------------------
+    // ---- DMA descriptor and a group's chunks (one wave issues a whole group) ------------------------------
     v4i_t rsrc;
     {
         const uint64_t a = (uint64_t)p.x;
@@ -86,79 +101,133 @@ __global__ __launch_bounds__(MF_THREADS, 3) void dwconv_mfma_dma_kernel(const Mf
         rsrc[3] = 0x00020000;
     }
     const int TC = p.G * p.chunks_pp;                                // chunks per group
-    const int CPW = (TC + DMA_WAVES - 1) / DMA_WAVES;                // chunks per issuing wave
-    int my_chunks = 0;
-    if (wave < DMA_WAVES) { my_chunks = TC - wave * CPW; if (my_chunks > CPW) my_chunks = CPW; if (my_chunks < 0) my_chunks = 0; }
-    const int my_ipw = (my_chunks + 63) >> 6;                        // wave-uniform
     const unsigned ring_base = (unsigned)(uintptr_t)SLAK_LDS(uint16_t, ring);
-    // chunk ci of a group = (plane j, chunk q): source = plane (n0+j, c) + 16q bytes; LDS = slot + 16*ci (lane-linear)
-    unsigned src_rel[DMA_MAX_IPW]; bool act[DMA_MAX_IPW];
-#pragma unroll
-    for (int i = 0; i < DMA_MAX_IPW; ++i) {
-        const int loc = i * 64 + lane;
-        const int ci = wave * CPW + loc;
-        act[i] = (i < my_ipw) && (loc < my_chunks);
-        const int j = act[i] ? ci / p.chunks_pp : 0, q = act[i] ? ci - j * p.chunks_pp : 0;
-        src_rel[i] = (unsigned)(j * p.C * HW * 2 + q * 16);
-    }
+    // A plane is a contiguous run of 16-byte chunks both in HBM and in its ring slot, and the 12-bit instruction offset of
+    // `buffer_load ... lds` advances BOTH addresses (tools/dma_offset_probe.hip): one M0 setup serves four loads.
+    // 22-bit magic division (one full-rate v_mul_u32_u24 + shift; exact for n, d < 1024) where a map is needed at all.
+    auto fdiv = [](unsigned n, unsigned m) -> unsigned { return m ? (__umul24(n, m) >> 22) : n; };   // m == 0 encodes divisor 1
+    const int cpp_full = p.chunks_pp >> 6, cpp_rem = p.chunks_pp & 63;
     auto issue_group = [&](int g) {
-        if (g >= iters) return;
+        if (g >= iters || wave != (g & 3)) return;                   // wave-uniform
+        if (p.ablate == 2) return;
         const int n0 = n_begin + g * p.G;
-        const unsigned base_off = (unsigned)(((size_t)n0 * p.C + c) * HW * 2);
-        const unsigned slot = ring_base + (unsigned)((g % DMA_NB) * p.group_elems * 2) + (unsigned)(wave * CPW * 16);
-#pragma unroll
-        for (int i = 0; i < DMA_MAX_IPW; ++i) {
-            if (i < my_ipw) {                                         // wave-uniform: the instruction count per group is exact
-                if (act[i]) lds_dma16(base_off + src_rel[i], rsrc, __builtin_amdgcn_readfirstlane(slot + i * 1024));
+        unsigned voff = (unsigned)(((size_t)n0 * p.C + c) * HW * 2) + lane * 16;
+        unsigned m0v = ring_base + (unsigned)((g % NB) * p.group_elems * 2);
+        for (int j = 0; j < p.G; ++j) {
+            unsigned v = voff, m = m0v;
+            int f = cpp_full;
+            for (; f >= 4; f -= 4) { lds_dma_run<4, 0>(v, rsrc, m); v += 4096; m += 4096; }
+            if (f == 3) lds_dma_run<3, 0>(v, rsrc, m); else if (f == 2) lds_dma_run<2, 0>(v, rsrc, m); else if (f == 1) lds_dma_run<1, 0>(v, rsrc, m);
+            if (lane < cpp_rem) {
+                if (f == 0) lds_dma_run<1, 0>(v, rsrc, m); else if (f == 1) lds_dma_run<1, 1024>(v, rsrc, m);
+                else if (f == 2) lds_dma_run<1, 2048>(v, rsrc, m); else lds_dma_run<1, 3072>(v, rsrc, m);
             }
+            voff += (unsigned)(p.C * HW * 2); m0v += (unsigned)(HW * 2);
         }
     };
 
-    // ---- prologue ---------------------------------------------------------------------------------------
-    for (int g = 0; g < DMA_NB - 1; ++g) issue_group(g);
-    s16x8 afrag[NG][KS];
-    bool ks_active[KS];
-    if constexpr (PACKED) {
-        // (the vmcnt(0) in front of the first use also drains the prologue DMAs: once)
-        load_toeplitz_frags<NG, KS>(afrag, ks_active, p.frags, c, MT, mt, lane, 32, p.Wt, p.KL, p.padL);
-    } else {
-        const int ntap = p.kh * p.kw;
-        for (int i = tid; i < ntap; i += MF_THREADS) lw[i] = p.w[(size_t)c * ntap + i];
-        __syncthreads();
-        build_toeplitz_frags_lds<T, NG, KS, VERT>(afrag, ks_active, lw, mt, lane, p.Wt, p.KL, p.padL, p.kw, p.flip);
-    }
-
-    // copy-out map of the storing waves (fixed per thread): 16-byte chunk idx -> out-buffer offset == idx*8, global offset
-    int co_g[DMA_NCO], co_j[DMA_NCO];
-    {
-        const int cpp = HW / 8, total = p.G * cpp;
+    if (p.dbg && tid == 0) p.dbg[64 + blockIdx.x * 8 + 3] = __builtin_amdgcn_s_memrealtime();
+    // ---- prologue: first groups in flight, filter windows, fragments ------------------------------------
+    for (int g = 0; g < 3; ++g) issue_group(g);                      // waves 0..2; wave 3 stages the filter meanwhile
+    const int ntap = p.kh * p.kw;
+    float wreg[DMA_WCH];
+    if (wave == 3) {
 #pragma unroll
-        for (int k = 0; k < DMA_NCO; ++k) {
-            const int idx = (tid - DMA_WAVES * 64) + k * (MF_WAVES - DMA_WAVES) * 64;
-            const bool ok = wave >= DMA_WAVES && idx < total;
-            const int j = ok ? idx / cpp : 0, rem = ok ? idx - j * cpp : 0;
-            co_j[k] = ok ? j : -1;
-            co_g[k] = j * p.C * HW + rem * 8;
+        for (int k = 0; k < DMA_WCH; ++k) { const int e = lane + 64 * k; wreg[k] = e < ntap ? p.w[(size_t)c * ntap + e] : 0.f; }
+    }
+    for (int i = tid; i < (ZROW_LEN + 2 * MF_TAPS * WIN_LEN) / 2; i += MF_THREADS) ((unsigned*)zrow)[i] = 0u;
+    if constexpr (VERT)
+        for (int i = tid; i < 2 * p.G * p.xt_rows * p.PT / 2; i += MF_THREADS) ((unsigned*)xt)[i] = 0u;   // pads of x^T stay zero
+    if (p.dbg && tid == 0) p.dbg[64 + blockIdx.x * 8 + 4] = __builtin_amdgcn_s_memrealtime();
+    wg_barrier();
+    if (wave == 3) {
+#pragma unroll
+        for (int k = 0; k < DMA_WCH; ++k) {
+            const int e = lane + 64 * k;
+            if (e < ntap) {
+                int r = VERT ? e % p.kw : e / p.kw, t = VERT ? e / p.kw : e % p.kw;      // short tap r, long tap t
+                if (p.flip) { r = MF_TAPS - 1 - r; t = p.KL - 1 - t; }
+                const uint16_t v = cvt_to_bits(wreg[k], (T*)nullptr);
+                win[r * WIN_LEN + WIN_ZP + t] = v;                                         // copy 0
+                win[MF_TAPS * WIN_LEN + r * WIN_LEN + WIN_ZP + t - 1] = v;                 // copy 1 = copy 0 shifted by one element
+            }
         }
     }
+    wg_barrier();
+    if (p.dbg && tid == 0) p.dbg[64 + blockIdx.x * 8 + 5] = __builtin_amdgcn_s_memrealtime();
+    s16x8 afrag[NG][KS];
+    bool ks_active[KS];
+    const int kfull = p.Wt >> 4;                                     // k-steps below this lie entirely inside the plane
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        const int i_lo = ks * 16, i_hi = ks * 16 + 15, o_lo = mt * 32, o_hi = mt * 32 + 31;
+        ks_active[ks] = (i_lo < p.Wt) && (o_lo < p.Wt) && (i_lo - o_hi <= p.KL - 1 - p.padL) && (o_lo - i_hi <= p.padL);
+        const int a = WIN_ZP + ks * 16 + lhi * 8 - (mt * 32 + l31) + p.padL;              // window start (element index), >= 1
+        const int par = a & 1;
+        const unsigned* src = (const unsigned*)(win + par * MF_TAPS * WIN_LEN) + ((a - par) >> 1);
+#pragma unroll
+        for (int r = 0; r < NG; ++r) {
+            u32x4 d;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                d[k] = src[r * (WIN_LEN / 2) + k];
+                if (ks >= kfull && ks * 16 + lhi * 8 + 2 * k >= p.Wt) d[k] = 0u;        // i >= Wt: no such input
+            }
+            afrag[r][ks] = __builtin_bit_cast(s16x8, d);
+        }
+    }
+
+    if (p.dbg && tid == 0) p.dbg[64 + blockIdx.x * 8 + 6] = __builtin_amdgcn_s_memrealtime();
+    auto copy_out = [&](int g) {                                     // results of group g: LDS out-buffer -> HBM, 16 bytes per lane
+        const int n0 = n_begin + g * p.G;
+        const uint16_t* ob = lout + (g & 1) * p.G * HW;
+        uint16_t* base = y + ((size_t)n0 * p.C + c) * HW;
+        unsigned td = tid; asm volatile("" : "+v"(td));              // opaque: keeps the map out of loop-invariant registers
+        if (p.ablate == 3) return;
+        if (p.G == 1) {
+#pragma unroll
+            for (int k = 0; k < DMA_NCO; ++k) {
+                const unsigned idx = td + k * MF_THREADS;
+                if ((int)idx < TC) *(u32x4*)(base + idx * 8) = *(const u32x4*)(ob + idx * 8);
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < DMA_NCO; ++k) {
+                const unsigned idx = td + k * MF_THREADS;
+                const unsigned j = fdiv(idx, p.m_cpp), rem = idx - __umul24(j, (unsigned)p.chunks_pp);
+                if ((int)idx < TC && n0 + (int)j < n_end) *(u32x4*)(base + (size_t)j * p.C * HW + rem * 8) = *(const u32x4*)(ob + idx * 8);
+            }
+        }
+    };
     // vertical: transpose map (fixed per thread).  Block b of a group = (plane j, 4 image rows kb, 16 image columns cb);
     // the 16 lanes of a group read it with one ds_read_b64_tr_b16 (lane i16 supplies row kb*4 + i16/4, columns cb*16 + 4*(i16%4)
     // and receives column cb*16 + i16, rows kb*4..+3) and write 8 bytes of x^T.
-    int tr_r[DMA_NTR], tr_w[DMA_NTR];
+    unsigned tr_map[DMA_NTR];                                        // (source element offset) | (x^T element offset << 16); 0xffffffff = none
     if constexpr (VERT) {
         const int grp = lane >> 4, i16 = lane & 15;
-        const int kbs = p.H / 4, cbs = p.xt_rows / 16, per_plane = kbs * cbs, total = p.G * per_plane;
-        for (int i = tid; i < p.G * p.xt_rows * p.PT / 2; i += MF_THREADS) ((unsigned*)xt)[i] = 0u;   // pads of x^T stay zero
+        const int total = p.G * p.tr_pp;
 #pragma unroll
         for (int k = 0; k < DMA_NTR; ++k) {
             const int b = (k * MF_WAVES + wave) * 4 + grp;
-            const bool ok = b < total;
-            const int j = ok ? b / per_plane : 0, rem = ok ? b - j * per_plane : 0;
-            const int kb = rem / cbs, cb = rem - kb * cbs;
-            tr_r[k] = ok ? j * HW + (kb * 4 + (i16 >> 2)) * p.W + cb * 16 + (i16 & 3) * 4 : -1;
-            tr_w[k] = (j * p.xt_rows + cb * 16 + i16) * p.PT + kb * 4;
+            const bool ok = b < total;                                // uniform per 16-lane group
+            const int j = ok ? b / p.tr_pp : 0, rem = ok ? b - j * p.tr_pp : 0;
+            const int kb = rem / p.tr_cbs, cb = rem - kb * p.tr_cbs;
+            const unsigned src = (unsigned)(j * HW + (kb * 4 + (i16 >> 2)) * p.W + cb * 16 + (i16 & 3) * 4);
+            const unsigned dst = (cb * 16 + i16 < p.W) ? (unsigned)((j * p.xt_rows + cb * 16 + i16) * p.PT + kb * 4) : 0xffffu;
+            tr_map[k] = ok ? (src | (dst << 16)) : 0xffffffffu;
         }
     }
+    auto transpose_group = [&](int g) {                              // ring slot of group g -> x^T buffer g&1
+        const uint16_t* img = ring + (g % NB) * p.group_elems;
+        uint16_t* dst = xt + (g & 1) * p.G * p.xt_rows * p.PT;
+#pragma unroll
+        for (int k = 0; k < DMA_NTR; ++k) {
+            if (tr_map[k] != 0xffffffffu) {
+                const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16(SLAK_LDS(s16x4, img + (tr_map[k] & 0xffffu)));
+                if ((tr_map[k] >> 16) != 0xffffu) *(s16x4*)(dst + (tr_map[k] >> 16)) = v;
+            }
+        }
+    };
 
     // ---- per-lane constants of the compute core ------------------------------------------------------------
     const int pitch = VERT ? p.PT : p.W;                              // row pitch of the image the core reads
@@ -168,74 +237,85 @@ __global__ __launch_bounds__(MF_THREADS, 3) void dwconv_mfma_dma_kernel(const Mf
     const bool prof = p.dbg != nullptr && blockIdx.x == 0;
 #define PH_T0() unsigned long long t__ = prof ? __builtin_readcyclecounter() : 0
 #define PH_ADD(k) do { if (prof) { unsigned long long n__ = __builtin_readcyclecounter(); tph[k] += n__ - t__; t__ = n__; } } while (0)
+    if constexpr (VERT) {                                             // group 0 has to be transposed before the loop
+        if (wave == 0) wait_vmcnt<0>();
+        wg_barrier();
+        transpose_group(0);
+    }
+    if (p.stagger) { const int k = (blockIdx.x >> 8) % 3; for (int q = 0; q < k * p.stagger; ++q) __builtin_amdgcn_s_sleep(1); }
+    const unsigned long long cyc0 = p.dbg ? __builtin_readcyclecounter() : 0;
+    if (p.dbg && tid == 0) p.dbg[64 + blockIdx.x * 8 + 1] = __builtin_amdgcn_s_memrealtime();
     for (int it = 0; it < iters; ++it) {
         const int n0 = n_begin + it * p.G;
         PH_T0();
-        if (wave < DMA_WAVES) {                                        // my part of group `it` has landed: only the DMAs of the
-            int younger = iters - 1 - it; if (younger > DMA_NB - 2) younger = DMA_NB - 2;   // younger groups may still be in flight
-            wait_vmcnt_dyn(younger * my_ipw);
-        }
+        // the group this iteration needs in LDS: `it` (horizontal) / `it+1` for the transpose (vertical); its issuing wave waits
+        const int need = VERT ? it + 1 : it;
+        if (need < iters && wave == (need & 3)) wait_vmcnt<0>();
         PH_ADD(0);
-        wg_barrier();                                                 // B1: everyone's part has landed
+        wg_barrier();                        // B: group `need` landed; out-buffer it-1 and (vertical) x^T `it` complete; a ring slot is free
         PH_ADD(1);
-
-        const uint16_t* img = ring + (it % DMA_NB) * p.group_elems;
+        issue_group(VERT ? it + NB : it + NB - 1);
+        if (it > 0) copy_out(it - 1);
+        PH_ADD(5);
+        const uint16_t* img;
         if constexpr (VERT) {
-#pragma unroll
-            for (int k = 0; k < DMA_NTR; ++k) {
-                if (tr_r[k] >= 0) {
-                    const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16(SLAK_LDS(s16x4, img + tr_r[k]));
-                    *(s16x4*)(xt + tr_w[k]) = v;
-                }
-            }
-            wg_barrier();                                             // B1b: x^T complete
-            img = xt;
+            if (it + 1 < iters) transpose_group(it + 1);
+            img = xt + (it & 1) * p.G * p.xt_rows * p.PT;
+        } else {
+            img = ring + (it % NB) * p.group_elems;
         }
+        PH_ADD(4);
         uint16_t* outb = lout + (it & 1) * p.G * HW;
         for (int tile = wl; tile < p.ntiles; tile += WL) {
+            if (p.ablate == 1) break;
             const int j = tile / p.tpp, sub = tile - j * p.tpp;
             const uint16_t* pim = img + j * plane_stride;
             const int pos = sub * 32 + l31;                           // lane -> position along the short (lane) axis
-            // B fragment of tap r, k-step ks: 8 consecutive k of image row pos + r - 2 (zero outside the plane / beyond Wt)
-            const uint16_t* rp[MF_TAPS]; bool inb[MF_TAPS];
+            // B fragment of tap r, k-step ks: 8 consecutive k of image row pos + r - 2; rows outside the plane read the zero row
+            const uint16_t* rp[MF_TAPS];
 #pragma unroll
             for (int r = 0; r < MF_TAPS; ++r) {
                 const int row = pos + r - 2;
-                inb[r] = (unsigned)row < (unsigned)p.Wl;
-                rp[r] = pim + (inb[r] ? row : 0) * pitch + lhi * 8;
+                rp[r] = ((unsigned)row < (unsigned)p.Wl ? pim + row * pitch : zrow) + lhi * 8;
             }
+            const uint16_t* zr = zrow + lhi * 8;
+            // k-steps that can reach past the plane edge (only the last two can: Wt > 16*(KS-2)) redirect the whole 16-byte
+            // (or 8-byte) piece to the zero row instead of masking data: one select per fragment, none for the others
             auto load_b = [&](int r, int ks) -> s16x8 {
+                const uint16_t* q = rp[r] + ks * 16;
                 u32x4 b;
-                if constexpr (VERT || R16) b = *(const u32x4*)(rp[r] + ks * 16);            // 16-byte aligned rows
-                else {                                                                    // W % 8 == 4: rows are 8-byte aligned
-                    const u32x2 lo = *(const u32x2*)(rp[r] + ks * 16), hi = *(const u32x2*)(rp[r] + ks * 16 + 4);
+                if constexpr (VERT) b = *(const u32x4*)q;                                   // x^T pads are zero
+                else if constexpr (R16) {
+                    if (ks >= KS - 2) q = (ks * 16 + lhi * 8 < p.Wt) ? q : zr;
+                    b = *(const u32x4*)q;
+                } else {                                                                  // W % 8 == 4: rows are 8-byte aligned
+                    const uint16_t* q0 = q; const uint16_t* q1 = q + 4;
+                    if (ks >= KS - 2) { q0 = (ks * 16 + lhi * 8 < p.Wt) ? q0 : zr; q1 = (ks * 16 + lhi * 8 + 4 < p.Wt) ? q1 : zr; }
+                    const u32x2 lo = *(const u32x2*)q0, hi = *(const u32x2*)q1;
                     b = u32x4{lo[0], lo[1], hi[0], hi[1]};
                 }
-                const int k0 = ks * 16 + lhi * 8;
-                const bool lo_ok = inb[r] && (VERT || k0 < p.Wt), hi_ok = inb[r] && (VERT || k0 + 4 < p.Wt);
-                b[0] = lo_ok ? b[0] : 0u; b[1] = lo_ok ? b[1] : 0u; b[2] = hi_ok ? b[2] : 0u; b[3] = hi_ok ? b[3] : 0u;
                 return __builtin_bit_cast(s16x8, b);
             };
-            f32x16 acc0, acc1;                                        // two chains (even / odd taps) keep the MFMA pipe busy
+            f32x16 acc;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
+            for (int i = 0; i < 16; ++i) acc[i] = 0.f;
             if constexpr (!BAND) {
-                s16x8 bcur[MF_TAPS], bnxt[MF_TAPS];
+                // software pipeline pinned with sched_barrier: hipcc otherwise sinks every ds_read next to its MFMA
+                // (ds_read; s_waitcnt lgkmcnt(0); v_mfma -- the LDS latency 20 times per tile).  The fragment of tap r for the
+                // next k-step is fetched right after this k-step's MFMA of tap r has issued, into the same registers.
+                s16x8 b[MF_TAPS];
 #pragma unroll
-                for (int r = 0; r < MF_TAPS; ++r) bcur[r] = load_b(r, 0);
+                for (int r = 0; r < MF_TAPS; ++r) b[r] = load_b(r, 0);
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) {
-                    if (ks + 1 < KS) {
-#pragma unroll
-                        for (int r = 0; r < MF_TAPS; ++r) bnxt[r] = load_b(r, ks + 1);
-                    }
 #pragma unroll
                     for (int r = 0; r < MF_TAPS; ++r) {
-                        if (r & 1) acc1 = mfma32<T>(afrag[r][ks], bcur[r], acc1);
-                        else acc0 = mfma32<T>(afrag[r][ks], bcur[r], acc0);
+                        // vertical: operands swapped (D^T = X^T-tile x T^T) so that a lane holds 4 consecutive ow of one output row
+                        acc = VERT ? mfma32<T>(b[r], afrag[r][ks], acc) : mfma32<T>(afrag[r][ks], b[r], acc);
+                        if (ks + 1 < KS) b[r] = load_b(r, ks + 1);
+                        __builtin_amdgcn_sched_barrier(0);
                     }
-#pragma unroll
-                    for (int r = 0; r < MF_TAPS; ++r) bcur[r] = bnxt[r];
                 }
             } else {
 #pragma unroll
@@ -244,61 +324,50 @@ __global__ __launch_bounds__(MF_THREADS, 3) void dwconv_mfma_dma_kernel(const Mf
                     s16x8 b[MF_TAPS];
 #pragma unroll
                     for (int r = 0; r < MF_TAPS; ++r) b[r] = load_b(r, ks);
+                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int r = 0; r < MF_TAPS; ++r) {
-                        if (r & 1) acc1 = mfma32<T>(afrag[r][ks], b[r], acc1);
-                        else acc0 = mfma32<T>(afrag[r][ks], b[r], acc0);
-                    }
+                    for (int r = 0; r < MF_TAPS; ++r) acc = VERT ? mfma32<T>(b[r], afrag[r][ks], acc) : mfma32<T>(afrag[r][ks], b[r], acc);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
             PH_ADD(2);
-            if (pos < p.Wl && (n0 + j) < n_end) {
-                uint16_t* op = outb + j * HW;
-                if constexpr (!VERT) {
-                    // lane = output row oh, register quad = 4 consecutive ow -> one 8-byte LDS store
+            uint16_t* op = outb + j * HW;
+            if constexpr (!VERT) {
+                // lane = output row oh (short axis), register quad = 4 consecutive ow -> one 8-byte LDS store
+                if (pos < p.Wl && (n0 + j) < n_end) {
                     uint16_t* orow = op + pos * p.W + mt * 32 + 4 * lhi;
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         if (mt * 32 + 8 * q + 4 * lhi < p.Wt) {
                             u32x2 v;
-                            v[0] = pack2<T>(acc0[4 * q + 0] + acc1[4 * q + 0], acc0[4 * q + 1] + acc1[4 * q + 1]);
-                            v[1] = pack2<T>(acc0[4 * q + 2] + acc1[4 * q + 2], acc0[4 * q + 3] + acc1[4 * q + 3]);
+                            v[0] = pack2<T>(acc[4 * q + 0], acc[4 * q + 1]);
+                            v[1] = pack2<T>(acc[4 * q + 2], acc[4 * q + 3]);
                             *(u32x2*)(orow + 8 * q) = v;
                         }
                     }
-                } else {
-                    // lane = output column ow, registers = rows oh -> column-wise 2-byte stores into the row-major plane
-                    uint16_t* ocol = op + (mt * 32 + 4 * lhi) * p.W + pos;
+                }
+            } else {
+                // swapped operands: lane = output row oh (long axis, this wave's 32-row tile), register quad = 4 consecutive ow
+                const int oh = mt * 32 + l31;
+                if (oh < p.Wt && (n0 + j) < n_end) {
+                    uint16_t* orow = op + oh * p.W + sub * 32 + 4 * lhi;
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
-                        if (mt * 32 + 8 * q + 4 * lhi < p.Wt) {
-                            const unsigned p0 = pack2<T>(acc0[4 * q + 0] + acc1[4 * q + 0], acc0[4 * q + 1] + acc1[4 * q + 1]);
-                            const unsigned p1 = pack2<T>(acc0[4 * q + 2] + acc1[4 * q + 2], acc0[4 * q + 3] + acc1[4 * q + 3]);
-                            ocol[(8 * q + 0) * p.W] = (uint16_t)(p0 & 0xffffu);
-                            ocol[(8 * q + 1) * p.W] = (uint16_t)(p0 >> 16);
-                            ocol[(8 * q + 2) * p.W] = (uint16_t)(p1 & 0xffffu);
-                            ocol[(8 * q + 3) * p.W] = (uint16_t)(p1 >> 16);
+                        if (sub * 32 + 8 * q + 4 * lhi < p.Wl) {
+                            u32x2 v;
+                            v[0] = pack2<T>(acc[4 * q + 0], acc[4 * q + 1]);
+                            v[1] = pack2<T>(acc[4 * q + 2], acc[4 * q + 3]);
+                            *(u32x2*)(orow + 8 * q) = v;
                         }
                     }
                 }
             }
+            PH_ADD(3);
         }
-        PH_ADD(3);
-        wg_barrier();                                                 // B2: out-buffer complete, ring slot `it` free
-        PH_ADD(4);
-        if (wave < DMA_WAVES) {
-            issue_group(it + DMA_NB - 1);                             // into the slot that group it-1 used
-        } else {
-            // waves 2,3: finished planes -> HBM, 16 bytes per lane
-            uint16_t* base = y + ((size_t)n0 * p.C + c) * HW;
-#pragma unroll
-            for (int k = 0; k < DMA_NCO; ++k) {
-                const int idx = (tid - DMA_WAVES * 64) + k * (MF_WAVES - DMA_WAVES) * 64;
-                if (co_j[k] >= 0 && n0 + co_j[k] < n_end) *(u32x4*)(base + co_g[k]) = *(const u32x4*)(outb + idx * 8);
-            }
-        }
-        PH_ADD(5);
     }
+    wg_barrier();
+    copy_out(iters - 1);
+    if (p.dbg && tid == 0) { p.dbg[64 + blockIdx.x * 8 + 2] = __builtin_amdgcn_s_memrealtime(); p.dbg[64 + blockIdx.x * 8 + 7] = __builtin_readcyclecounter() - cyc0; }
     if (prof && lane == 0) { for (int k = 0; k < 6; ++k) p.dbg[wave * 8 + k] = tph[k]; p.dbg[wave * 8 + 6] = (unsigned long long)iters; }
 }
 
@@ -309,6 +378,8 @@ static bool fill_dma_params(MfmaDmaParams& p, const ConvDims& d, bool vert, int 
     p.KL = vert ? d.kh : d.kw; p.padL = p.KL / 2;
     const int HW = d.H * d.W;
     if (HW % 8 || d.W % 4 || d.H % 4) return false;
+    if (p.KL > 63 || d.kh * d.kw > DMA_WCH * 64) return false;        // window layout / staging wave
+    if (p.Wt <= 16 * (KS - 2)) return false;                          // only the last two k-steps may reach past the plane edge
     p.tpp = (p.Wl + 31) / 32;
     const int WLW = MF_WAVES / MT;
     p.G = p.tpp >= WLW ? 1 : WLW / p.tpp;
@@ -317,22 +388,24 @@ static bool fill_dma_params(MfmaDmaParams& p, const ConvDims& d, bool vert, int 
     p.chunks_pp = HW / 8;
     p.group_elems = p.G * HW;
     p.PT = KS * 16 + 8;
-    p.xt_rows = (d.W + 15) & ~15;
-    const int TC = p.G * p.chunks_pp, CPW = (TC + DMA_WAVES - 1) / DMA_WAVES;
-    if ((CPW + 63) / 64 > DMA_MAX_IPW) return false;
-    if ((DMA_NB - 2) * ((CPW + 63) / 64) > 16) return false;          // wait_vmcnt_dyn covers 0..16
-    if (TC > DMA_NCO * (MF_WAVES - DMA_WAVES) * 64) return false;
-    if (vert && p.G * (d.H / 4) * (p.xt_rows / 16) > DMA_NTR * MF_WAVES * 4) return false;
+    p.xt_rows = d.W;
+    const int TC = p.G * p.chunks_pp;
+    if (TC > DMA_NCO * MF_THREADS || TC >= 1024 || p.chunks_pp >= 1024) return false;
+    if (vert && p.G * (d.H / 4) * ((d.W + 15) / 16) > DMA_NTR * MF_WAVES * 4) return false;
     int slices = resident_wgs / d.C; if (slices < 1) slices = 1;      // one resident round: never more workgroups than fit at once
     int per = (d.N + slices - 1) / slices; per = (per + p.G - 1) / p.G * p.G; if (per < p.G) per = p.G;
     p.planes_per_wg = per; p.slices = (d.N + per - 1) / per;
+    p.tr_cbs = (d.W + 15) / 16; p.tr_pp = (d.H / 4) * p.tr_cbs;
+    auto magic = [](unsigned dv) -> unsigned { return dv <= 1 ? 0u : (unsigned)(((1u << 22) + dv - 1) / dv); };   // n / dv == (n * m) >> 22 for n, dv < 1024
+    p.m_cpp = magic((unsigned)p.chunks_pp); p.m_pp = magic((unsigned)p.tr_pp); p.m_cbs = magic((unsigned)p.tr_cbs);
     p.tensor_bytes = (unsigned)((size_t)d.N * d.C * HW * 2);
     return true;
 }
 
 static size_t dma_lds_bytes(const MfmaDmaParams& p, bool vert) {
-    return (size_t)(DMA_NB * p.group_elems + 64) * 2 + (size_t)2 * p.G * p.H * p.W * 2 + (size_t)((p.kh * p.kw + 3) & ~3) * 4 +
-           (vert ? (size_t)p.G * p.xt_rows * p.PT * 2 : 0) + 16;
+    const int nb = vert ? DMA_NBV : DMA_NB;
+    return (size_t)(nb * p.group_elems + 64) * 2 + (size_t)2 * p.G * p.H * p.W * 2 + (size_t)(ZROW_LEN + 2 * MF_TAPS * WIN_LEN) * 2 +
+           (vert ? (size_t)2 * p.G * p.xt_rows * p.PT * 2 : 0) + 16;
 }
 
 static int dma_class(const ConvDims& d, bool vert) {              // 2: MT=2/KS=4, 1: MT=1/KS=2, 0: not covered
@@ -349,7 +422,7 @@ bool dwconv_mfma_dma_supported(const ConvDims& d, int x_dt, int w_dt, int y_dt) 
     if (!cls) return false;
     MfmaDmaParams p;
     if (!fill_dma_params(p, d, vert, cls == 2 ? 2 : 1, cls == 2 ? 4 : 2, 512)) return false;
-    return dma_lds_bytes(p, vert) <= 64 * 1024;
+    return dma_lds_bytes(p, vert) <= 80 * 1024;
 }
 
 template <typename K>
@@ -362,7 +435,7 @@ static int resident_workgroups(K kernel, size_t lds) {          // workgroups th
 
 template <typename T, int MT, int KS, bool VERT, bool BAND, bool R16>
 static int launch_dma_tv(MfmaDmaParams& p, const ConvDims& d, hipStream_t st) {
-    auto k = dwconv_mfma_dma_kernel<T, MT, KS, VERT, BAND, R16, (MT == 2)>;
+    auto k = dwconv_mfma_dma_kernel<T, MT, KS, VERT, BAND, R16>;
     fill_dma_params(p, d, VERT, MT, KS, 512);
     const size_t lds = dma_lds_bytes(p, VERT);                   // does not depend on the slice count
     static int resident = 0;                                      // per instantiation; LDS size varies little within a class
@@ -383,21 +456,17 @@ static int launch_dma_t(MfmaDmaParams& p, const ConvDims& d, bool vert, bool ban
 
 int launch_dwconv_mfma_dma(const void* x, int x_dt, const void* w, int w_dt, void* y, int y_dt,
                            const ConvDims& d, bool flip_filter, void* ws, size_t ws_bytes, hipStream_t st) {
+    (void)ws; (void)ws_bytes;                                 // no workspace: fragments are built from LDS filter windows
     if (!dwconv_mfma_dma_supported(d, x_dt, w_dt, y_dt)) return SLAK_ERR_UNSUPPORTED;
     const bool vert = d.kh > d.kw;
     const int cls = dma_class(d, vert);
     const int MT = cls == 2 ? 2 : 1, KS = cls == 2 ? 4 : 2;
     MfmaDmaParams p;
     fill_dma_params(p, d, vert, MT, KS, 512);
-    p.x = x; p.w = (const float*)w; p.frags = (const uint16_t*)ws; p.y = y; p.flip = flip_filter ? 1 : 0;
-    if (MT == 2) {                                            // fragments packed once per call (20 per wave: cheaper than in-kernel)
-        if (ws == nullptr || ws_bytes < toeplitz_pack_bytes(d.C, MT, MF_TAPS, KS)) return SLAK_ERR_WORKSPACE;
-        ToeplitzPackParams tp{(const float*)w, (uint16_t*)ws, d.C, d.kh, d.kw, MT, MF_TAPS, KS, 1,
-                              vert ? 1 : 0, flip_filter ? 1 : 0, p.Wt, p.KL, p.padL, x_dt == SLAK_BF16 ? 1 : 0};
-        launch_toeplitz_pack(tp, st);
-        SLAK_LAUNCH_CHECK();
-    }
+    p.x = x; p.w = (const float*)w; p.y = y; p.flip = flip_filter ? 1 : 0;
     p.dbg = g_dma_dbg;
+    { const char* e = getenv("SLAK_DMA_ABLATE"); p.ablate = e ? atoi(e) : 0; }
+    { const char* e = getenv("SLAK_DMA_STAGGER"); p.stagger = e ? atoi(e) : 0; }
     // band skipping pays when some (mt, ks) Toeplitz block is empty: filter half-width + 32 < 16*(KS-1)
     const bool band = (MT == 2) && (p.padL + 31 < 16 * (KS - 1));
     if (x_dt == SLAK_BF16) return cls == 2 ? launch_dma_t<bf16_t, 2, 4>(p, d, vert, band, st) : launch_dma_t<bf16_t, 1, 2>(p, d, vert, false, st);

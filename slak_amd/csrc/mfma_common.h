@@ -162,6 +162,29 @@ __device__ __forceinline__ void lds_dma16(unsigned voff, v4i_t rsrc, unsigned ld
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(voff), "s"(rsrc), "s"(lds_base) : "memory");
 }
+// NI consecutive 1-KiB pieces (instruction offsets OFF0 + i*1024 advance the HBM source AND the LDS destination) under ONE M0 setup
+template <int NI, int OFF0>
+__device__ __forceinline__ void lds_dma_run(unsigned voff, v4i_t rsrc, unsigned lds_base) {
+    static_assert(NI >= 1 && NI <= 4 && OFF0 + (NI - 1) * 1024 < 4096, "12-bit instruction offset");
+    unsigned keep;
+    lds_base = __builtin_amdgcn_readfirstlane(lds_base);
+    if constexpr (NI == 1)
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen offset:%4 lds\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(voff), "s"(rsrc), "s"(lds_base), "n"(OFF0) : "memory");
+    else if constexpr (NI == 2)
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen offset:%4 lds\n\t"
+                     "buffer_load_dwordx4 %1, %2, 0 offen offset:%5 lds\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(voff), "s"(rsrc), "s"(lds_base), "n"(OFF0), "n"(OFF0 + 1024) : "memory");
+    else if constexpr (NI == 3)
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen offset:%4 lds\n\t"
+                     "buffer_load_dwordx4 %1, %2, 0 offen offset:%5 lds\n\tbuffer_load_dwordx4 %1, %2, 0 offen offset:%6 lds\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(voff), "s"(rsrc), "s"(lds_base), "n"(OFF0), "n"(OFF0 + 1024), "n"(OFF0 + 2048) : "memory");
+    else
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen offset:%4 lds\n\t"
+                     "buffer_load_dwordx4 %1, %2, 0 offen offset:%5 lds\n\tbuffer_load_dwordx4 %1, %2, 0 offen offset:%6 lds\n\t"
+                     "buffer_load_dwordx4 %1, %2, 0 offen offset:%7 lds\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(voff), "s"(rsrc), "s"(lds_base), "n"(OFF0), "n"(OFF0 + 1024), "n"(OFF0 + 2048), "n"(OFF0 + 3072) : "memory");
+}
 __device__ __forceinline__ void wg_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }

@@ -4,13 +4,16 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from slak_amd import ops
 dev = torch.device("cuda:0")
-def ev(fn, reps=30):
-    for _ in range(5): fn()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    torch.cuda.synchronize(); e0.record()
-    for _ in range(reps): fn()
-    e1.record(); e1.synchronize()
-    return e0.elapsed_time(e1) / reps * 1e3
+def ev(fn, reps=20, batches=5):
+    for _ in range(20): fn()
+    best = 1e30
+    for _ in range(batches):                      # min over batches: robust against clock ramp / stray activity
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize(); e0.record()
+        for _ in range(reps): fn()
+        e1.record(); e1.synchronize()
+        best = min(best, e0.elapsed_time(e1) / reps * 1e3)
+    return best
 tot = 0
 for (C, H, K, blocks) in ((96, 56, 51, 3), (192, 28, 49, 3), (384, 14, 47, 9), (768, 7, 13, 3)):
     x = torch.randn(128, C, H, H, device=dev).bfloat16(); dy = torch.randn_like(x)
