@@ -11,6 +11,10 @@ namespace slak {
 static std::mutex g_err_mu;
 static std::string g_last_hip_error = "";
 static int g_conv_algo = SLAK_ALGO_AUTO;
+static bool use_small_dma() {                // SLAK_MFMA_SMALL_DMA=0 keeps the channel-blocked small-plane kernel (A/B testing)
+    static const bool v = [] { const char* e = getenv("SLAK_MFMA_SMALL_DMA"); return !(e && e[0] == '0'); }();
+    return v;
+}
 static bool use_small() {                    // SLAK_MFMA_SMALL=0 keeps the generic register-staged kernel for H,W <= 16 (A/B testing)
     static int v = -1;
     if (v < 0) { const char* e = getenv("SLAK_MFMA_SMALL"); v = (e && e[0] == '0') ? 0 : 1; }
@@ -107,6 +111,8 @@ int slak_dwconv2d_forward(const void* x, int x_dtype, const void* w, int w_dtype
     ConvDims d{N, C, H, W, kh, kw};
     if (g_conv_algo != SLAK_ALGO_DIRECT && use_dma() && dwconv_mfma_dma_supported(d, x_dtype, w_dtype, y_dtype))
         return launch_dwconv_mfma_dma(x, x_dtype, w, w_dtype, y, y_dtype, d, /*flip=*/false, workspace, workspace_bytes, (hipStream_t)stream);
+    if (g_conv_algo != SLAK_ALGO_DIRECT && use_small_dma() && dwconv_mfma_small_dma_supported(d, x_dtype, w_dtype, y_dtype))
+        return launch_dwconv_mfma_small_dma(x, x_dtype, w, w_dtype, y, y_dtype, d, /*flip=*/false, (hipStream_t)stream);
     if (g_conv_algo != SLAK_ALGO_DIRECT && use_small() && dwconv_mfma_small_supported(d, x_dtype, w_dtype, y_dtype))
         return launch_dwconv_mfma_small(x, x_dtype, w, w_dtype, y, y_dtype, d, /*flip=*/false, workspace, workspace_bytes, (hipStream_t)stream);
     if (g_conv_algo != SLAK_ALGO_DIRECT && dwconv_mfma_supported(d, x_dtype, w_dtype, y_dtype))
@@ -125,6 +131,8 @@ int slak_dwconv2d_backward_data(const void* dy, int dy_dtype, const void* w, int
     // the filter rotated by 180 degrees (h + kh/2 - r == h - kh/2 + (kh-1-r)).
     if (g_conv_algo != SLAK_ALGO_DIRECT && use_dma() && dwconv_mfma_dma_supported(d, dy_dtype, w_dtype, dx_dtype))
         return launch_dwconv_mfma_dma(dy, dy_dtype, w, w_dtype, dx, dx_dtype, d, /*flip=*/true, workspace, workspace_bytes, (hipStream_t)stream);
+    if (g_conv_algo != SLAK_ALGO_DIRECT && use_small_dma() && dwconv_mfma_small_dma_supported(d, dy_dtype, w_dtype, dx_dtype))
+        return launch_dwconv_mfma_small_dma(dy, dy_dtype, w, w_dtype, dx, dx_dtype, d, /*flip=*/true, (hipStream_t)stream);
     if (g_conv_algo != SLAK_ALGO_DIRECT && use_small() && dwconv_mfma_small_supported(d, dy_dtype, w_dtype, dx_dtype))
         return launch_dwconv_mfma_small(dy, dy_dtype, w, w_dtype, dx, dx_dtype, d, /*flip=*/true, workspace, workspace_bytes, (hipStream_t)stream);
     if (g_conv_algo != SLAK_ALGO_DIRECT && dwconv_mfma_supported(d, dy_dtype, w_dtype, dx_dtype))

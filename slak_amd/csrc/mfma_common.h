@@ -195,8 +195,9 @@ __device__ __forceinline__ void wait_vmcnt_dyn(int n) {       // n is wave-unifo
         case 6: wait_vmcnt<6>(); break;   case 7: wait_vmcnt<7>(); break;   case 8: wait_vmcnt<8>(); break;
         case 9: wait_vmcnt<9>(); break;   case 10: wait_vmcnt<10>(); break; case 11: wait_vmcnt<11>(); break;
         case 12: wait_vmcnt<12>(); break; case 13: wait_vmcnt<13>(); break; case 14: wait_vmcnt<14>(); break;
-        case 15: wait_vmcnt<15>(); break; case 16: wait_vmcnt<16>(); break; case 18: wait_vmcnt<18>(); break;
-        case 20: wait_vmcnt<20>(); break; case 24: wait_vmcnt<24>(); break;
+        case 15: wait_vmcnt<15>(); break; case 16: wait_vmcnt<16>(); break; case 17: wait_vmcnt<17>(); break;
+        case 18: wait_vmcnt<18>(); break; case 19: wait_vmcnt<19>(); break; case 20: wait_vmcnt<20>(); break;
+        case 24: wait_vmcnt<24>(); break;
         default: wait_vmcnt<0>(); break;
     }
 }
