@@ -20,6 +20,7 @@ constexpr int SW_P = 16;                // stack pitch (elements)
 
 struct SmallWgradParams {
     const void* dy; const void* x; float* partial;
+    float* dw; unsigned* counters;   // in-kernel slice reduction (counters == NULL: partials only, reduce kernel follows)
     int N, C, H, W, kh, kw;
     int Wt, Wl, KL, padL;
     int NI;                // images per iteration
@@ -184,8 +185,9 @@ __global__ __launch_bounds__(MF_THREADS) void dwconv_mfma_small_wgrad_kernel(con
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
         float* out = p.partial + ((size_t)slice * p.C + c) * ntap;
-        for (int t = lane; t < ntap; t += 64) out[t] = myres[t];
+        for (int t = lane; t < ntap; t += 64) wgrad_store_partial(&out[t], myres[t]);
     }
+    if (p.counters) wgrad_finish(p.partial, p.dw, p.counters + cb, (int*)lds, p.slices, p.C, c0, nch, ntap, tid, MF_THREADS);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -258,6 +260,7 @@ int launch_dwconv_mfma_small_wgrad(const void* dy, int dy_dt, const void* x, int
     const bool vert = d.kh > d.kw;
     SmallWgradParams p;
     p.dy = dy; p.x = x; p.partial = (float*)ws;
+    p.dw = dw; p.counters = wgrad_arrival_counters((d.C + SW_CB - 1) / SW_CB);
     const int V = sw_V(d);
     int rc;
     if (x_dt == SLAK_BF16) {
@@ -267,7 +270,7 @@ int launch_dwconv_mfma_small_wgrad(const void* dy, int dy_dt, const void* x, int
         if (V == 8) rc = vert ? launch_sw_t<f16_t, 8, true>(p, d, ws_bytes, st) : launch_sw_t<f16_t, 8, false>(p, d, ws_bytes, st);
         else rc = vert ? launch_sw_t<f16_t, 4, true>(p, d, ws_bytes, st) : launch_sw_t<f16_t, 4, false>(p, d, ws_bytes, st);
     }
-    if (rc != SLAK_OK) return rc;
+    if (rc != SLAK_OK || p.counters) return rc;
     return launch_wgrad_reduce((const float*)ws, dw, d.C * d.kh * d.kw, p.slices, st);
 }
 

@@ -28,6 +28,7 @@ constexpr int WG_NTR = 8;               // transpose blocks per 16-lane group (l
 
 struct MfmaWgradParams {
     const void* dy; const void* x; float* partial;
+    float* dw; unsigned* counters;   // in-kernel slice reduction (counters == NULL: partials only, reduce kernel follows)
     int N, C, H, W, kh, kw;
     int Wt, Wl, KL, padL;
     int G;                 // planes staged per iteration
@@ -257,10 +258,11 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dwconv_mfma_wgrad_kernel(const 
         float s = dwl[t];
 #pragma unroll
         for (int w = 1; w < MF_WAVES; ++w) s += dwl[w * ntap + t];
-        p.partial[((size_t)slice * p.C + c) * ntap + t] = s;
+        wgrad_store_partial(&p.partial[((size_t)slice * p.C + c) * ntap + t], s);
     }
     t4 = __builtin_readcyclecounter();
     if (prof) { p.dbg[0] = t1 - t0; p.dbg[1] = t2 - t1; p.dbg[2] = t3 - t2; p.dbg[3] = t4 - t3; p.dbg[4] = iters; }
+    if (p.counters) wgrad_finish(p.partial, p.dw, p.counters + c, (int*)lds, p.slices, p.C, c, 1, ntap, tid, MF_THREADS);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -366,8 +368,9 @@ int launch_dwconv_mfma_wgrad(const void* dy, int dy_dt, const void* x, int x_dt,
     fill_wgrad_params(p, d, vert, s, mfma_cu_count());
     if (ws == nullptr || ws_bytes < dwconv_mfma_wgrad_workspace(d)) return SLAK_ERR_WORKSPACE;
     p.dy = dy; p.x = x; p.partial = (float*)ws; p.dbg = g_dma_dbg;
+    p.dw = dw; p.counters = wgrad_arrival_counters(d.C);
     int rc = (x_dt == SLAK_BF16) ? launch_wgrad_shape<bf16_t>(p, s, vert, st) : launch_wgrad_shape<f16_t>(p, s, vert, st);
-    if (rc != SLAK_OK) return rc;
+    if (rc != SLAK_OK || p.counters) return rc;
     return launch_wgrad_reduce((const float*)ws, dw, d.C * d.kh * d.kw, p.slices, st);
 }
 

@@ -21,6 +21,7 @@ constexpr int DW_NTR = 4;               // transpose blocks of one plane per 16-
 
 struct WgradDmaParams {
     const void* dy; const void* x; float* partial;
+    float* dw; unsigned* counters;   // in-kernel slice reduction (counters == NULL: partials only, reduce kernel follows)
     int N, C, H, W, kh, kw;
     int Wt, Wl, KL, padL;
     int G;                 // planes per group
@@ -230,8 +231,9 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dwconv_mfma_wgrad_dma_kernel(co
         float s = dwl[t];
 #pragma unroll
         for (int w = 1; w < MF_WAVES; ++w) s += dwl[w * ntap + t];
-        p.partial[((size_t)slice * p.C + c) * ntap + t] = s;
+        wgrad_store_partial(&p.partial[((size_t)slice * p.C + c) * ntap + t], s);
     }
+    if (p.counters) wgrad_finish(p.partial, p.dw, p.counters + c, (int*)lds, p.slices, p.C, c, 1, ntap, tid, MF_THREADS);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -327,6 +329,7 @@ int launch_dwconv_mfma_wgrad_dma(const void* dy, int dy_dt, const void* x, int x
     const int cls = wdma_class(d, vert);
     WgradDmaParams p;
     p.dy = dy; p.x = x; p.partial = (float*)ws;
+    p.dw = dw; p.counters = wgrad_arrival_counters(d.C);
     int rc;
     if (x_dt == SLAK_BF16) {
         if (cls == 2) rc = vert ? launch_wdma_t<bf16_t, 2, true>(p, d, ws_bytes, st) : launch_wdma_t<bf16_t, 2, false>(p, d, ws_bytes, st);
@@ -335,7 +338,7 @@ int launch_dwconv_mfma_wgrad_dma(const void* dy, int dy_dt, const void* x, int x
         if (cls == 2) rc = vert ? launch_wdma_t<f16_t, 2, true>(p, d, ws_bytes, st) : launch_wdma_t<f16_t, 2, false>(p, d, ws_bytes, st);
         else rc = vert ? launch_wdma_t<f16_t, 1, true>(p, d, ws_bytes, st) : launch_wdma_t<f16_t, 1, false>(p, d, ws_bytes, st);
     }
-    if (rc != SLAK_OK) return rc;
+    if (rc != SLAK_OK || p.counters) return rc;
     return launch_wgrad_reduce((const float*)ws, dw, d.C * d.kh * d.kw, p.slices, st);
 }
 

@@ -14,6 +14,7 @@
 //   No atomics, no memset, bitwise run-to-run reproducible.  Output is always fp32
 //   (backward_filter_fp16.cu:187).
 #include "slak_common.h"
+#include <mutex>
 
 namespace slak {
 
@@ -256,6 +257,26 @@ int launch_dwconv_wgrad(const void* dy, int dy_dt, const void* x, int x_dt, floa
     }
     if (rc != SLAK_OK) return rc;
     return launch_wgrad_reduce((const float*)ws, dw, d.C * d.kh * d.kw, p.nslices, st);
+}
+
+unsigned* wgrad_arrival_counters(int ngroups) {
+    // SLOTS launches may be in flight at once before a slot's counters are handed out again (a stream serialises its own launches;
+    // the slots only matter for weight-gradient launches running concurrently on different streams)
+    constexpr int SLOTS = 64, MAXG = 4096, MAXDEV = 16;
+    static std::mutex mu;
+    static unsigned* buf[MAXDEV] = {};
+    static unsigned next[MAXDEV] = {};
+    if (ngroups > MAXG) return nullptr;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAXDEV) return nullptr;
+    std::lock_guard<std::mutex> lk(mu);
+    if (!buf[dev]) {
+        unsigned* b = nullptr;
+        if (hipMalloc((void**)&b, (size_t)SLOTS * MAXG * sizeof(unsigned)) != hipSuccess) return nullptr;
+        if (hipMemset(b, 0, (size_t)SLOTS * MAXG * sizeof(unsigned)) != hipSuccess || hipDeviceSynchronize() != hipSuccess) { (void)hipFree(b); return nullptr; }
+        buf[dev] = b;
+    }
+    return buf[dev] + (size_t)(next[dev]++ % SLOTS) * MAXG;
 }
 
 int launch_wgrad_reduce(const float* partial, float* dw, int total, int nslices, hipStream_t st) {

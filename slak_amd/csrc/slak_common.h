@@ -93,4 +93,48 @@ size_t dwconv_mfma_wgrad_workspace(const ConvDims& d);
 int launch_dwconv_mfma_wgrad(const void* dy, int dy_dt, const void* x, int x_dt, float* dw,
                              const ConvDims& d, void* ws, size_t ws_bytes, hipStream_t st);
 
+
+// ---- weight-gradient slice reduction without a second launch -----------------------------------------------------------
+// Every workgroup stores its partial [ntap] per channel into partial[slice][C][ntap], then ARRIVES at its channel group's
+// counter; the last arriver adds the nslices partials in slice order (bitwise reproducible: the same order whichever
+// workgroup happens to be last) and writes dw.  Counters come zeroed from wgrad_arrival_counters() and the last arriver
+// puts its counter back to zero, so a launch leaves them as it found them.
+unsigned* wgrad_arrival_counters(int ngroups);      // host; nullptr -> use launch_wgrad_reduce() after the kernel instead
+#if defined(__HIPCC__)
+// partial stores go through wgrad_store_partial(): written through to the device coherence point (agent-scope atomic store),
+// so "arriving" needs no L2 write-back -- an agent-scope release fence costs a whole-L2 flush per workgroup on gfx942/gfx950
+// (measured: 18 -> 107 us for the 14x14 weight gradient).
+__device__ __forceinline__ void wgrad_store_partial(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void wgrad_finish(const float* partial, float* dw, unsigned* counter, int* lds_flag,
+                                             int nslices, int C, int c0, int nch, int ntap, int tid, int nthreads) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // my write-through partial stores have been acknowledged (vmcnt(0))
+    __syncthreads();
+    if (tid == 0) {
+        int last = 1;
+        if (nslices > 1) {
+            const unsigned old = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            last = old == (unsigned)(nslices - 1);
+            if (last) __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        *lds_flag = last;
+    }
+    __syncthreads();
+    if (!*lds_flag) return;
+    for (int t = tid; t < nch * ntap; t += nthreads) {
+        float s = 0.f;
+        const float* src = partial + (size_t)c0 * ntap + t;
+        const size_t stride = (size_t)C * ntap;
+        for (int k0 = 0; k0 < nslices; k0 += 8) {      // 8 loads in flight, added in slice order; agent-scope loads read at the coherence point
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                v[j] = k0 + j < nslices ? __hip_atomic_load(src + (size_t)(k0 + j) * stride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s += v[j];
+        }
+        dw[(size_t)c0 * ntap + t] = s;
+    }
+}
+#endif
+
 }  // namespace slak
