@@ -41,7 +41,7 @@ def parse():
     ap.add_argument("--update-frequency", type=int, default=2000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--kernel-reps", type=int, default=10)
+    ap.add_argument("--kernel-reps", type=int, default=30)
     ap.add_argument("--fp32-dwconv", action="store_true", help="reference dtype flow: dw convs see fp32 even under autocast")
     ap.add_argument("--no-fused-bn", action="store_true", help="run the three branch BatchNorms + adds as the reference's PyTorch modules")
     ap.add_argument("--no-fused-tail", action="store_true", help="run the block tail (permute/LayerNorm/gamma/residual) as the reference's PyTorch ops")
@@ -51,7 +51,7 @@ def parse():
 def event_time_ms(fn, reps, stream_device):
     """Average duration of fn() over `reps` launches, HIP events on the stream the kernels are launched on
     (torch's current stream == the stream slak_amd.ops passes to the C ABI)."""
-    for _ in range(2):
+    for _ in range(5):
         fn()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize(stream_device)
@@ -64,24 +64,38 @@ def event_time_ms(fn, reps, stream_device):
 
 
 def hot_path_kernels(device, batch, reps, dtype):
-    """Every distinct (stage, kernel, pass) of the dw-conv hot path at the bench shapes, timed alone."""
-    from slak_amd import ops
+    """Every distinct (stage, kernel, pass) of the dw-conv hot path at the bench shapes, timed alone: the C-ABI entry points
+    are called directly on preallocated buffers (the tensor-level wrappers of slak_amd.ops add ~10 us of host work per call,
+    more than the smallest kernels take), HIP events on the launch stream around `reps` back-to-back launches."""
+    from slak_amd import _lib, ops
+    L = _lib.lib()
+    st = torch.cuda.current_stream(device).cuda_stream
     out = []
     b = 2 if dtype != torch.float32 else 4
     for si, (C, HW, K, blocks) in enumerate(STAGES_T):
         x = torch.randn(batch, C, HW, HW, device=device).to(dtype)
         dy = torch.randn_like(x)
+        y = torch.empty_like(x)
+        dt = ops._DT[x.dtype]
         for kname, (kh, kw) in (("Kx5", (K, 5)), ("5xK", (5, K)), ("5x5", (5, 5))):
             w = torch.randn(C, 1, kh, kw, device=device) * 0.02
+            dw = torch.empty_like(w)
+            dims = (batch, C, HW, HW, kh, kw)
+            nb = max(int(L.slak_dwconv2d_workspace_bytes(op, *dims, dt)) for op in (_lib.OP_FWD, _lib.OP_BWD_DATA, _lib.OP_BWD_FILTER))
+            ws = torch.empty(max(nb, 16), dtype=torch.uint8, device=device)
+            a_f = (x.data_ptr(), dt, w.data_ptr(), _lib.SLAK_F32, y.data_ptr(), dt) + dims + (ws.data_ptr(), ws.numel(), st)
+            a_d = (dy.data_ptr(), dt, w.data_ptr(), _lib.SLAK_F32, y.data_ptr(), dt) + dims + (ws.data_ptr(), ws.numel(), st)
+            a_w = (dy.data_ptr(), dt, x.data_ptr(), dt, dw.data_ptr()) + dims + (ws.data_ptr(), ws.numel(), st)
             S = x.numel()
-            for pname, fn, extra in (("fwd", lambda: ops.dwconv2d_forward(x, w), C * kh * kw * 4),
-                                     ("bwd_data", lambda: ops.dwconv2d_backward_data(dy, w), C * kh * kw * 4),
-                                     ("bwd_filter", lambda: ops.dwconv2d_backward_filter(dy, x, w), C * kh * kw * 4)):
+            for pname, fn, extra in (("fwd", lambda: _lib.check(L.slak_dwconv2d_forward(*a_f)), C * kh * kw * 4),
+                                     ("bwd_data", lambda: _lib.check(L.slak_dwconv2d_backward_data(*a_d)), C * kh * kw * 4),
+                                     ("bwd_filter", lambda: _lib.check(L.slak_dwconv2d_backward_filter(*a_w)), C * kh * kw * 4)):
                 ms = event_time_ms(fn, reps, device)
                 alg_bytes = 2 * S * b + extra                       # SURVEY.md 8(d): 2*S*b (+ C*kh*kw*4)
                 out.append(dict(stage=si + 1, kernel="%dx%d" % (kh, kw), branch=kname, op=pname, ms=ms, calls_per_step=blocks,
                                 alg_bytes=alg_bytes, gbs=alg_bytes / ms / 1e6, gflop_nominal=2.0 * S * kh * kw / 1e9))
-        del x, dy
+            del ws, dw
+        del x, dy, y
     return out
 
 

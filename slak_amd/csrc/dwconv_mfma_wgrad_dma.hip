@@ -32,19 +32,26 @@ struct WgradDmaParams {
     int stack_elems;       // vertical: LDS elements of one transposed stack (dy; the x stack has 8 more rows)
     int planes_per_wg, slices;
     unsigned tensor_bytes;
+    unsigned long long* dbg;   // dev: per-workgroup 100 MHz stamps (NULL in production)
 };
+#define WD_STAMP(k) do { if (p.dbg && threadIdx.x == 0) p.dbg[64 + blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 
-template <typename T, int MT, bool VERT>
+// PC: the pitch P of the stacks as a compile-time constant (0: read it from the parameters) -- with it the ten row offsets of a
+// k-step's fragments are instruction immediates and a k-step costs two address adds instead of twelve.
+template <typename T, int MT, bool VERT, int PC>
 __global__ __launch_bounds__(MF_THREADS, 2) void dwconv_mfma_wgrad_dma_kernel(const WgradDmaParams p) {
     constexpr int NG = MF_TAPS;
     extern __shared__ __attribute__((aligned(16))) uint16_t lds[];
     const int HW = p.H * p.W, ntap = p.kh * p.kw;
     uint16_t* ring = lds;                                         // DW_NB slots of [dy part | x part], img_elems each
     const int slot_elems = 2 * p.img_elems;
-    const int ring_elems = DW_NB * slot_elems > MF_WAVES * 32 * 33 * 2 ? DW_NB * slot_elems : MF_WAVES * 32 * 33 * 2;   // >= the scratch that aliases it
+    // the diagonal-sum scratch ([MF_WAVES][32][64] fp32 = 32 KB) aliases the ring AND the stacks (all dead by then): pad the ring
+    // only if the two together are smaller than that
+    const int live_elems = DW_NB * slot_elems + (VERT ? 2 * p.stack_elems + 8 * p.P : 0);
+    const int ring_elems = DW_NB * slot_elems + (live_elems < MF_WAVES * 32 * 64 * 2 ? MF_WAVES * 32 * 64 * 2 - live_elems : 0);
     uint16_t* stk = lds + ring_elems;                             // vertical: dy stack, then x stack
     float* dwl = (float*)(stk + (VERT ? (2 * p.stack_elems + 8 * p.P) : 0));   // [MF_WAVES][ntap]
-    float* scratch = (float*)lds;                                 // [MF_WAVES][32*33] for the diagonal sums: aliases the (dead) ring
+    float* scratch = (float*)lds;                                 // [MF_WAVES][32][64] for the diagonal sums: aliases the (dead) ring
 
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, lhi = lane >> 5;
     const int wave = wave_id_uniform();
@@ -54,6 +61,7 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dwconv_mfma_wgrad_dma_kernel(co
     int n_end = n_begin + p.planes_per_wg; if (n_end > p.N) n_end = p.N;
     const int iters = (n_end > n_begin) ? (n_end - n_begin + p.G - 1) / p.G : 0;
 
+    WD_STAMP(0);
     // ---- zero the ring (gaps between plane images stay zero), the stacks and the per-wave tap arrays --------------
     {
         const int n8 = (ring_elems + (VERT ? 2 * p.stack_elems + 8 * p.P : 0)) / 8;
@@ -112,6 +120,7 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dwconv_mfma_wgrad_dma_kernel(co
         }
     };
 
+    WD_STAMP(3);
     issue_group(0);
 
     // vertical: transpose map of one plane (as in dwconv_mfma_wgrad.hip)
@@ -137,16 +146,22 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dwconv_mfma_wgrad_dma_kernel(co
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[g][i] = 0.f;
 
-    // fragment addresses (element offsets at k-step 0) -- tr-read: group grp reads a 4(k) x 16 block
+    // fragment addresses (byte offsets at k-step 0) -- tr-read: group grp reads a 4(k) x 16 block
+    const int P = PC ? PC : p.P;
     const int grp = lane >> 4, i16 = lane & 15;
     const int krow = (grp >> 1) * 8 + (i16 >> 2);
-    const int a_off = krow * p.P + mt * 32 + (grp & 1) * 16 + (i16 & 3) * 4;
-    int b_off[NG];
-#pragma unroll
-    for (int g = 0; g < NG; ++g) b_off[g] = (krow + g) * p.P + nt * 32 + (grp & 1) * 16 + (i16 & 3) * 4;
-    const int kstep_elems = 16 * p.P;
+    const unsigned a_off = (unsigned)(krow * P + mt * 32 + (grp & 1) * 16 + (i16 & 3) * 4) * 2;
+    const unsigned b_off = (unsigned)(krow * P + nt * 32 + (grp & 1) * 16 + (i16 & 3) * 4) * 2;     // tap g: + g rows
+    const unsigned kstep_b = (unsigned)(16 * P) * 2;
     const int ks_first = (MT == 2) ? 0 : wave, ks_stride = (MT == 2) ? 1 : MF_WAVES;
+    char* const LB = (char*)lds;
+    auto frag = [&](unsigned addr) -> s16x8 {                     // 8 k of one column: two transposing reads, 4 rows apart
+        const s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(SLAK_LDS(s16x4, LB + addr));
+        const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(SLAK_LDS(s16x4, LB + addr + (unsigned)(4 * P) * 2));
+        return s16x8{v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+    };
 
+    WD_STAMP(1);
     for (int it = 0; it < iters; ++it) {
         wait_vmcnt<0>();                                          // my DMAs of group `it` (the only ones in flight) have landed
         wg_barrier();                                             // everyone's have; everyone is done with the other slot
@@ -183,49 +198,67 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dwconv_mfma_wgrad_dma_kernel(co
         } else {
             dys = slot; xs = slot + p.img_elems;
         }
-        for (int ks = ks_first; ks < p.NKS; ks += ks_stride) {
-            const uint16_t* ap = dys + a_off + ks * kstep_elems;
-            const s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(SLAK_LDS(s16x4, ap));
-            const s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(SLAK_LDS(s16x4, ap + 4 * p.P));
-            const s16x8 a = s16x8{a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+        // k-loop, software-pipelined by hand and pinned with sched_barrier (hipcc otherwise emits ds_read; s_waitcnt lgkmcnt(0);
+        // v_mfma five times per k-step): tap g's fragment of the NEXT k-step is fetched right after this k-step's MFMA g issued
+        if (ks_first < p.NKS) {
+            const unsigned ab = (unsigned)((const char*)dys - LB) + a_off, xb = (unsigned)((const char*)xs - LB) + b_off;
+            unsigned ko = (unsigned)ks_first * kstep_b;
+            s16x8 a = frag(ab + ko), b[NG];
 #pragma unroll
-            for (int g = 0; g < NG; ++g) {
-                const uint16_t* bp = xs + b_off[g] + ks * kstep_elems;
-                const s16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(SLAK_LDS(s16x4, bp));
-                const s16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(SLAK_LDS(s16x4, bp + 4 * p.P));
-                acc[g] = mfma32<T>(a, s16x8{b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]}, acc[g]);
+            for (int g = 0; g < NG; ++g) b[g] = frag(xb + ko + (unsigned)(g * P) * 2);
+            __builtin_amdgcn_sched_barrier(0);
+            for (int ks = ks_first; ks < p.NKS; ks += ks_stride) {
+                const bool more = ks + ks_stride < p.NKS;
+                const unsigned kn = more ? ko + (unsigned)ks_stride * kstep_b : ko;     // last k-step: re-read (discarded)
+                const s16x8 an = frag(ab + kn);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int g = 0; g < NG; ++g) {
+                    acc[g] = mfma32<T>(a, b[g], acc[g]);
+                    b[g] = frag(xb + kn + (unsigned)(g * P) * 2);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                a = an; ko = kn;
             }
         }
         if constexpr (VERT) wg_barrier();                         // the stacks are rewritten at the top of the next iteration
     }
+    WD_STAMP(2);
     wait_vmcnt<0>();
     __syncthreads();                                              // the ring is dead: its space becomes the diagonal-sum scratch
 
-    // ---- diagonal sums (as in dwconv_mfma_wgrad.hip): per-wave 32x33 fp32 tile, fixed order -------------------------------
+    // ---- diagonal sums dw[tau] = sum_o G[o, o + tau - padL], per wave, fixed order.  The 32x32 tile of a tap is written SKEWED --
+    // G[o][i] to row o, column i - o + 31 -- so that a diagonal becomes a column and lane d just adds the rows of column d: no
+    // index arithmetic or selects in the sum (the plain 32x33 tile cost 320 VALU per tap and wave: 9 us of a 47 us kernel).
+    // Cells no (o, i) maps to, and the columns of lanes beyond the plane edge (which never write), stay zero from the fill below.
     float* mine = dwl + wave * ntap;
-    float* tile = scratch + wave * (32 * 33);
-    const int dd = lane;                                          // diagonal i - o = dd - 31
+    float* tile = scratch + wave * (32 * 64);
+    for (int i = lane; i < 32 * 64 / 4; i += 64) ((u32x4*)tile)[i] = u32x4{0u, 0u, 0u, 0u};
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const bool col_ok = nt * 32 + l31 < p.Wt;                     // this lane's input position i exists
+    int o_max = p.Wt - mt * 32; if (o_max > 32) o_max = 32;       // rows o that exist (wave-uniform)
+    float* wr = tile + (4 * lhi) * 64 + (l31 - 4 * lhi + 31);     // register r -> row (r&3) + 8*(r>>2) (+4*lhi), column l31 - row + 31
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
+        if (col_ok) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) tile[((r & 3) + 8 * (r >> 2) + 4 * lhi) * 33 + l31] = acc[g][r];
+            for (int r = 0; r < 16; ++r)                          // rows beyond the plane edge are not written: they stay zero
+                if ((r & 3) + 8 * (r >> 2) + 4 * lhi < o_max) wr[((r & 3) + 8 * (r >> 2)) * 63] = acc[g][r];      // +64 per row, -1 per row
+        }
         __builtin_amdgcn_wave_barrier();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (dd < 63) {
+        if (lane < 63) {
             float part[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int o = 0; o < 32; ++o) {
-                const int il = o + dd - 31;
-                const bool ok = il >= 0 && il < 32 && mt * 32 + o < p.Wt && nt * 32 + il < p.Wt;
-                const float v = tile[o * 33 + (ok ? il : 0)];
-                part[o & 3] += ok ? v : 0.f;
-            }
-            const int tau = dd - 31 + (nt - mt) * 32 + p.padL;
+            for (int o = 0; o < 32; ++o) part[o & 3] += tile[o * 64 + lane];       // 32 independent reads
+            const int tau = lane - 31 + (nt - mt) * 32 + p.padL;
             if (tau >= 0 && tau < p.KL) mine[VERT ? (tau * p.kw + g) : (g * p.kw + tau)] = (part[0] + part[1]) + (part[2] + part[3]);
         }
         __builtin_amdgcn_wave_barrier();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
+    WD_STAMP(4);
     __syncthreads();
     for (int t = tid; t < ntap; t += MF_THREADS) {
         float s = dwl[t];
@@ -233,7 +266,9 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dwconv_mfma_wgrad_dma_kernel(co
         for (int w = 1; w < MF_WAVES; ++w) s += dwl[w * ntap + t];
         wgrad_store_partial(&p.partial[((size_t)slice * p.C + c) * ntap + t], s);
     }
+    WD_STAMP(5);
     if (p.counters) wgrad_finish(p.partial, p.dw, p.counters + c, (int*)lds, p.slices, p.C, c, 1, ntap, tid, MF_THREADS);
+    WD_STAMP(6);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -282,9 +317,10 @@ static bool fill_wdma_params(WgradDmaParams& p, const ConvDims& d, bool vert, in
 }
 
 static size_t wdma_lds_bytes(const WgradDmaParams& p, bool vert) {
-    size_t ring = (size_t)DW_NB * 2 * p.img_elems * 2, scratch = (size_t)MF_WAVES * 32 * 33 * 4;
-    if (ring < scratch) ring = scratch;                              // the diagonal-sum scratch aliases the ring
-    return ring + (vert ? (size_t)(2 * p.stack_elems + 8 * p.P) * 2 : 0) + (size_t)MF_WAVES * p.kh * p.kw * 4 + 32;
+    const size_t stacks = vert ? (size_t)(2 * p.stack_elems + 8 * p.P) * 2 : 0, scratch = (size_t)MF_WAVES * 32 * 64 * 4;
+    size_t live = (size_t)DW_NB * 2 * p.img_elems * 2 + stacks;
+    if (live < scratch) live = scratch;                              // the diagonal-sum scratch aliases the ring and the stacks
+    return live + (size_t)MF_WAVES * p.kh * p.kw * 4 + 32;
 }
 
 bool dwconv_mfma_wgrad_dma_supported(const ConvDims& d, int dy_dt, int x_dt) {
@@ -301,9 +337,9 @@ size_t dwconv_mfma_wgrad_dma_workspace(const ConvDims& d) {
     return align_up((size_t)(d.N < 2048 ? d.N : 2048) * d.C * d.kh * d.kw * sizeof(float), 256);   // slices <= min(N, resident workgroups)
 }
 
-template <typename T, int MT, bool VERT>
-static int launch_wdma_t(WgradDmaParams& p, const ConvDims& d, size_t ws_bytes, hipStream_t st) {
-    auto k = dwconv_mfma_wgrad_dma_kernel<T, MT, VERT>;
+template <typename T, int MT, bool VERT, int PC>
+static int launch_wdma_tp(WgradDmaParams& p, const ConvDims& d, size_t ws_bytes, hipStream_t st) {
+    auto k = dwconv_mfma_wgrad_dma_kernel<T, MT, VERT, PC>;
     fill_wdma_params(p, d, VERT, MT, 512);
     const size_t lds = wdma_lds_bytes(p, VERT);
     static int resident = 0;
@@ -321,6 +357,14 @@ static int launch_wdma_t(WgradDmaParams& p, const ConvDims& d, size_t ws_bytes, 
     return SLAK_OK;
 }
 
+template <typename T, int MT, bool VERT>
+static int launch_wdma_t(WgradDmaParams& p, const ConvDims& d, size_t ws_bytes, hipStream_t st) {
+    constexpr int PCOMMON = VERT ? MT * 32 : (MT == 2 ? 56 : 28);  // the SLaK maps; anything else takes the runtime-pitch build
+    fill_wdma_params(p, d, VERT, MT, 512);
+    if (p.P == PCOMMON) return launch_wdma_tp<T, MT, VERT, PCOMMON>(p, d, ws_bytes, st);
+    return launch_wdma_tp<T, MT, VERT, 0>(p, d, ws_bytes, st);
+}
+
 int launch_dwconv_mfma_wgrad_dma(const void* dy, int dy_dt, const void* x, int x_dt, float* dw,
                                  const ConvDims& d, void* ws, size_t ws_bytes, hipStream_t st) {
     if (!dwconv_mfma_wgrad_dma_supported(d, dy_dt, x_dt)) return SLAK_ERR_UNSUPPORTED;
@@ -330,6 +374,7 @@ int launch_dwconv_mfma_wgrad_dma(const void* dy, int dy_dt, const void* x, int x
     WgradDmaParams p;
     p.dy = dy; p.x = x; p.partial = (float*)ws;
     p.dw = dw; p.counters = wgrad_arrival_counters(d.C);
+    p.dbg = g_dma_dbg;
     int rc;
     if (x_dt == SLAK_BF16) {
         if (cls == 2) rc = vert ? launch_wdma_t<bf16_t, 2, true>(p, d, ws_bytes, st) : launch_wdma_t<bf16_t, 2, false>(p, d, ws_bytes, st);

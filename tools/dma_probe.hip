@@ -31,7 +31,7 @@ int main() {
   for (int i = 0; i < NEL; i++) h[i] = 1000 + i;
   uint16_t *din, *dout; hipMalloc(&din, NEL * 2 + 4096); hipMalloc(&dout, 4096);
   hipMemcpy(din + 1024, h.data(), NEL * 2, hipMemcpyHostToDevice);       // keep slack in front: base = din + 1024
-  for (int shift = 0; shift <= 2; shift += 2) {
+  for (int shift = 0; shift <= 3; shift += 1) {
     k<<<1, 64>>>(din + 1024, dout, 512, shift, 40); hipDeviceSynchronize();
     printf("shift=%d err=%s\n", shift, hipGetErrorString(hipGetLastError()));
     hipMemcpy(o.data(), dout, 4096, hipMemcpyDeviceToHost);
