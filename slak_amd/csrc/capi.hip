@@ -15,6 +15,10 @@ static bool use_small_dma() {                // SLAK_MFMA_SMALL_DMA=0 keeps the 
     static const bool v = [] { const char* e = getenv("SLAK_MFMA_SMALL_DMA"); return !(e && e[0] == '0'); }();
     return v;
 }
+static bool use_vrows() {                    // SLAK_MFMA_VROWS=0 keeps the transposing vertical weight-gradient kernel (A/B testing)
+    static const bool v = [] { const char* e = getenv("SLAK_MFMA_VROWS"); return !(e && e[0] == '0'); }();
+    return v;
+}
 static bool use_small() {                    // SLAK_MFMA_SMALL=0 keeps the generic register-staged kernel for H,W <= 16 (A/B testing)
     static int v = -1;
     if (v < 0) { const char* e = getenv("SLAK_MFMA_SMALL"); v = (e && e[0] == '0') ? 0 : 1; }
@@ -99,7 +103,7 @@ size_t slak_dwconv2d_workspace_bytes(int op, int N, int C, int H, int W, int kh,
     if (N <= 0 || C <= 0 || H <= 0 || W <= 0 || kh <= 0 || kw <= 0) return 0;
     ConvDims d{N, C, H, W, kh, kw};
     if (op == 0 || op == 1) { size_t a = dwconv_direct_workspace(d), b = dwconv_mfma_workspace(d), c = dwconv_mfma_small_workspace(d); a = a > b ? a : b; return a > c ? a : c; }
-    if (op == 2) { size_t a = dwconv_wgrad_workspace(d), b = dwconv_mfma_wgrad_workspace(d), c = dwconv_mfma_wgrad_dma_workspace(d), e = dwconv_mfma_small_wgrad_workspace(d), f = dwconv_mfma_small_wgrad_dma_workspace(d); a = a > b ? a : b; a = a > c ? a : c; a = a > e ? a : e; return a > f ? a : f; }
+    if (op == 2) { size_t a = dwconv_wgrad_workspace(d), b = dwconv_mfma_wgrad_workspace(d), c = dwconv_mfma_wgrad_dma_workspace(d), e = dwconv_mfma_small_wgrad_workspace(d), f = dwconv_mfma_small_wgrad_dma_workspace(d), g = dwconv_mfma_wgrad_vrows_workspace(d); a = a > g ? a : g; a = a > b ? a : b; a = a > c ? a : c; a = a > e ? a : e; return a > f ? a : f; }
     return 0;
 }
 
@@ -153,6 +157,10 @@ int slak_dwconv2d_backward_filter(const void* dy, int dy_dtype, const void* x, i
     }
     if (g_conv_algo != SLAK_ALGO_DIRECT && use_small() && dwconv_mfma_small_wgrad_supported(d, dy_dtype, x_dtype))
         return launch_dwconv_mfma_small_wgrad(dy, dy_dtype, x, x_dtype, dw, d, workspace, workspace_bytes, (hipStream_t)stream);
+    if (g_conv_algo != SLAK_ALGO_DIRECT && use_dma() && use_vrows() && dwconv_mfma_wgrad_vrows_supported(d, dy_dtype, x_dtype)) {
+        const int rc = launch_dwconv_mfma_wgrad_vrows(dy, dy_dtype, x, x_dtype, dw, d, workspace, workspace_bytes, (hipStream_t)stream);
+        if (rc != SLAK_ERR_UNSUPPORTED) return rc;
+    }
     if (g_conv_algo != SLAK_ALGO_DIRECT && use_dma() && dwconv_mfma_wgrad_dma_supported(d, dy_dtype, x_dtype))
         return launch_dwconv_mfma_wgrad_dma(dy, dy_dtype, x, x_dtype, dw, d, workspace, workspace_bytes, (hipStream_t)stream);
     if (g_conv_algo != SLAK_ALGO_DIRECT && dwconv_mfma_wgrad_supported(d, dy_dtype, x_dtype))

@@ -1,0 +1,278 @@
+// slak_amd/csrc/dwconv_mfma_wgrad_vrows.hip -- MFMA weight gradient of the VERTICAL kernels (Kx5) on the 56x56 class
+// (32 < H <= 64, W % 8 == 0, W <= 64) WITHOUT transposing anything.
+//
+//   G_r[o, i] = sum_{n,u} dY[o, u] * X[i, u + r - 2]      (o, i = image rows, u = image columns)      dw[tau, r] = sum_o G_r[o, o+tau-padL]
+// The contraction index u runs along image rows, so both MFMA operands are plain 16-byte reads of 8 consecutive elements of a
+// row -- if the shifted operand X[i, u + s] is available at a 4-byte aligned address for every tap shift s = -2..2.  Even
+// shifts are (+-4 bytes); for the odd ones a SECOND copy of the plane, shifted by one element, is fetched by the DMA itself:
+// `buffer_load_dwordx4 ... lds` accepts a 2-byte-aligned source (tools/dma_probe.hip, shift = 1), so copy c1[j] = x[j-1]
+// costs one more L2->LDS transfer and no LDS pass.  (dwconv_mfma_wgrad_dma.hip transposes both planes LDS->LDS for this case
+// and spends twice the horizontal kernel's time per plane doing it.)
+// LDS image of a plane: rows of CPR 16-byte chunks (W/8 data chunks + pad, CPR odd: conflict-free row-per-lane reads); the
+// pad chunks are never written, so X[i, -2..-1] and X[i, W..W+1] read zeros and dY is zero for the k beyond W.  Each lane
+// of a DMA instruction fetches ONE chunk (row = g / CPR, chunk = g % CPR of its global lane number g; pad lanes inactive).
+// The two elements a shifted copy drags in from the neighbouring row (c1[0] = x[row-1][W-1], c1[W+1] = x[row+1][0]) are
+// masked in the fragments of the two taps that can touch them.
+// Everything else -- per-tap accumulators in registers over the slice, diagonal sums through a skewed per-wave tile,
+// write-through partials, last-arriver reduction -- is dwconv_mfma_wgrad_dma.hip's.
+#include "mfma_common.h"
+
+namespace slak {
+
+constexpr int VR_NB = 2;                // ring depth: the next plane streams in while the current one is consumed
+constexpr int VR_MAX_IPW = 8;           // DMA instructions per wave per plane (upper bound)
+
+struct WgradRowsParams {
+    const void* dy; const void* x; float* partial; float* dw; unsigned* counters;
+    int N, C, H, W, kh, kw, KL, padL;
+    int CPR;               // 16-byte chunks per LDS row (odd, >= W/8 + 1)
+    int ipc;               // DMA instructions per plane copy: ceil(H * CPR / 64)
+    int KS;                // 16-deep k-steps per plane: ceil(W / 16)
+    int planes_per_wg, slices;
+    unsigned tensor_bytes;
+};
+
+template <typename T>
+__global__ __launch_bounds__(MF_THREADS, 3) void dwconv_mfma_wgrad_vrows_kernel(const WgradRowsParams p) {
+    constexpr int NG = MF_TAPS;
+    extern __shared__ __attribute__((aligned(16))) uint16_t lds[];
+    char* const LB = (char*)lds;
+    const int HW = p.H * p.W, ntap = p.kh * p.kw;
+    const unsigned PB = (unsigned)p.CPR * 16;                     // row pitch (bytes)
+    const unsigned copy_b = (unsigned)p.ipc * 1024;               // one plane copy (whole DMA instructions)
+    const unsigned slot_b = 3 * copy_b;                           // [dY][X][X shifted by one element]
+    const unsigned ring_b = 64;                                   // 64 zero bytes in front: "row -1" of the first plane
+    unsigned live_b = VR_NB * slot_b; if (live_b < MF_WAVES * 32 * 64 * 4) live_b = MF_WAVES * 32 * 64 * 4;   // >= the epilogue scratch
+    float* dwl = (float*)(LB + ring_b + live_b);                  // [MF_WAVES][ntap]
+    float* scratch = (float*)(LB + ring_b);                       // [MF_WAVES][32][64]: aliases the (dead) ring
+
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, lhi = lane >> 5;
+    const int wave = wave_id_uniform();
+    const int mt = wave & 1, nt = wave >> 1;
+    const int c = blockIdx.x % p.C, slice = blockIdx.x / p.C;
+    const int n_begin = slice * p.planes_per_wg;
+    int n_end = n_begin + p.planes_per_wg; if (n_end > p.N) n_end = p.N;
+    const int iters = n_end > n_begin ? n_end - n_begin : 0;
+
+    for (unsigned o = tid * 16; o < ring_b + live_b + (unsigned)(MF_WAVES * ntap) * 4; o += MF_THREADS * 16) *(u32x4*)(LB + o) = u32x4{0u, 0u, 0u, 0u};
+    __syncthreads();
+
+    // ---- DMA plan: instruction id -> (copy t, instruction ii of the copy); ids round-robin over the waves -----------------
+    v4i_t rs_dy, rs_x;
+    {
+        const uint64_t a = (uint64_t)p.dy, b = (uint64_t)p.x;
+        rs_dy[0] = __builtin_amdgcn_readfirstlane((int)(a & 0xffffffffu)); rs_dy[1] = __builtin_amdgcn_readfirstlane((int)((a >> 32) & 0xffffu));
+        rs_dy[2] = __builtin_amdgcn_readfirstlane((int)p.tensor_bytes); rs_dy[3] = 0x00020000;
+        rs_x[0] = __builtin_amdgcn_readfirstlane((int)(b & 0xffffffffu)); rs_x[1] = __builtin_amdgcn_readfirstlane((int)((b >> 32) & 0xffffu));
+        rs_x[2] = rs_dy[2]; rs_x[3] = 0x00020000;
+    }
+    const int ninstr = 3 * p.ipc, DC = p.W / 8;
+    int ins_src[VR_MAX_IPW]; unsigned ins_dst[VR_MAX_IPW]; int ins_t[VR_MAX_IPW]; bool ins_ok[VR_MAX_IPW];
+#pragma unroll
+    for (int k = 0; k < VR_MAX_IPW; ++k) {
+        const int id = wave + k * MF_WAVES;
+        const bool live = id < ninstr;
+        const int t = live ? id / p.ipc : 0, ii = live ? id - t * p.ipc : 0;
+        const int g = ii * 64 + lane, row = g / p.CPR, piece = g - row * p.CPR;
+        ins_t[k] = live ? t : -1;
+        ins_ok[k] = live && row < p.H && piece < (t == 2 ? DC + 1 : DC);      // the shifted copy needs one more chunk for x[W-1]
+        ins_src[k] = row * p.W * 2 + piece * 16 - (t == 2 ? 2 : 0);            // (bytes from the plane start; -2: c1[j] = x[j-1])
+        ins_dst[k] = (unsigned)t * copy_b + (unsigned)ii * 1024;
+    }
+    const unsigned lds_base = (unsigned)(uintptr_t)SLAK_LDS(uint16_t, lds);
+    auto issue_plane = [&](int g) {
+        if (g >= iters) return;
+        const int n0 = n_begin + g;
+        const unsigned gbase = (unsigned)(((size_t)n0 * p.C + c) * HW * 2);
+        const unsigned slot = lds_base + ring_b + (unsigned)(g % VR_NB) * slot_b;
+#pragma unroll
+        for (int k = 0; k < VR_MAX_IPW; ++k) {
+            if (ins_t[k] >= 0) {                                      // wave-uniform
+                int off = (int)gbase + ins_src[k];
+                if (off < 0) off = 0;                                 // first chunk of the whole tensor: fetched unshifted, fixed up below
+                if (off + 16 > (int)p.tensor_bytes) off = (int)p.tensor_bytes - 16;   // last chunk of the shifted copy: likewise
+                if (ins_ok[k]) {
+                    if (ins_t[k] == 0) lds_dma16((unsigned)off, rs_dy, __builtin_amdgcn_readfirstlane(slot + ins_dst[k]));
+                    else lds_dma16((unsigned)off, rs_x, __builtin_amdgcn_readfirstlane(slot + ins_dst[k]));
+                }
+            }
+        }
+    };
+    issue_plane(0);
+
+    f32x16 acc[NG];
+#pragma unroll
+    for (int g = 0; g < NG; ++g)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[g][i] = 0.f;
+
+    // ---- fragment addresses: lane -> image row (o resp. i), 8 consecutive k = columns 16*ks + 8*lhi .. +7 -------------------
+    const unsigned a_off = (unsigned)(mt * 32 + l31) * PB + lhi * 16;               // dY copy
+    const unsigned x_off = copy_b + (unsigned)(nt * 32 + l31) * PB + lhi * 16;      // X copy (c0); c1 = + copy_b
+    // the two stray elements of the shifted copy: tap 1 (s = -1) reads c1[u]: u = 0 is x[row-1][W-1] -> k-step 0, lhi 0,
+    // element 0; tap 3 (s = +1) reads c1[u + 2]: u = W-1 is x[row+1][0] -> k-step (W-1)/16, lhi ((W-1)%16)/8, element 7
+    const unsigned m_first = lhi == 0 ? 0xffff0000u : 0xffffffffu;
+    const int ks_last = (p.W - 1) >> 4;
+    const unsigned m_last = lhi == (((p.W - 1) & 15) >> 3) ? 0x0000ffffu : 0xffffffffu;
+    auto rd16 = [&](unsigned addr) -> s16x8 { return __builtin_bit_cast(s16x8, *(const u32x4*)(LB + addr)); };
+    auto rd4 = [&](unsigned addr) -> u32x4 { const unsigned* q = (const unsigned*)(LB + addr); return u32x4{q[0], q[1], q[2], q[3]}; };
+    auto load_b = [&](int g, unsigned xb, int ks) -> s16x8 {          // tap g: X[i, u + g - 2]
+        const unsigned a = xb + (unsigned)ks * 32;
+        if (g == 2) return rd16(a);
+        if (g == 0) return __builtin_bit_cast(s16x8, rd4(a - 4));
+        if (g == 4) return __builtin_bit_cast(s16x8, rd4(a + 4));
+        if (g == 1) { u32x4 v = *(const u32x4*)(LB + a + copy_b); if (ks == 0) v[0] &= m_first; return __builtin_bit_cast(s16x8, v); }
+        u32x4 v = rd4(a + copy_b + 4); if (ks == ks_last) v[3] &= m_last; return __builtin_bit_cast(s16x8, v);
+    };
+
+    for (int it = 0; it < iters; ++it) {
+        wait_vmcnt<0>();                                          // my DMAs of plane `it` (the only ones in flight) have landed
+        wg_barrier();                                             // everyone's have; everyone is done with the other slot
+        issue_plane(it + 1);                                      // streams in while this plane is consumed
+        const unsigned slot = ring_b + (unsigned)(it % VR_NB) * slot_b;
+        if (n_begin + it == 0 && c == 0) {
+            // the very first chunk of the tensor could not be fetched from offset -2: it landed unshifted -> shift it by hand
+            if (tid == 0) {
+                uint16_t* q = (uint16_t*)(LB + slot + 2 * copy_b);
+                for (int e = 7; e > 0; --e) q[e] = q[e - 1];
+                q[0] = 0;
+            }
+            wg_barrier();
+        }
+        if (n_begin + it == p.N - 1 && c == p.C - 1) {
+            // ... and the very last chunk of the shifted copy (it would read past the tensor): it landed as x[W-8..W-1] of the last
+            // row; the copy needs x[W-1] in its first element (the rest of that chunk is never used unmasked)
+            if (tid == 0) {
+                uint16_t* q = (uint16_t*)(LB + slot + 2 * copy_b + (unsigned)(p.H - 1) * PB + (unsigned)(p.W / 8) * 16);
+                q[0] = q[7];
+            }
+            wg_barrier();
+        }
+        const unsigned ab = slot + a_off, xb = slot + x_off;
+        // k-loop, pinned software pipeline: tap g's fragment of the next k-step is fetched right after this k-step's MFMA g
+        s16x8 a = rd16(ab), b[NG];
+#pragma unroll
+        for (int g = 0; g < NG; ++g) b[g] = load_b(g, xb, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        for (int ks = 0; ks < p.KS; ++ks) {
+            const int kn = ks + 1 < p.KS ? ks + 1 : ks;            // last k-step: re-read (discarded)
+            const s16x8 an = rd16(ab + (unsigned)kn * 32);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                acc[g] = mfma32<T>(a, b[g], acc[g]);
+                b[g] = load_b(g, xb, kn);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            a = an;
+        }
+    }
+    wait_vmcnt<0>();
+    __syncthreads();                                              // the ring is dead: its space becomes the diagonal-sum scratch
+
+    // ---- diagonal sums through a skewed per-wave tile (see dwconv_mfma_wgrad_dma.hip) -----------------------------------------
+    float* mine = dwl + wave * ntap;
+    float* tile = scratch + wave * (32 * 64);
+    for (int i = lane; i < 32 * 64 / 4; i += 64) ((u32x4*)tile)[i] = u32x4{0u, 0u, 0u, 0u};
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const bool col_ok = nt * 32 + l31 < p.H;
+    int o_max = p.H - mt * 32; if (o_max > 32) o_max = 32;
+    float* wr = tile + (4 * lhi) * 64 + (l31 - 4 * lhi + 31);
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        if (col_ok) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if ((r & 3) + 8 * (r >> 2) + 4 * lhi < o_max) wr[((r & 3) + 8 * (r >> 2)) * 63] = acc[g][r];
+        }
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (lane < 63) {
+            float part[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int o = 0; o < 32; ++o) part[o & 3] += tile[o * 64 + lane];
+            const int tau = lane - 31 + (nt - mt) * 32 + p.padL;
+            if (tau >= 0 && tau < p.KL) mine[tau * p.kw + g] = (part[0] + part[1]) + (part[2] + part[3]);
+        }
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+    for (int t = tid; t < ntap; t += MF_THREADS) {
+        float s = dwl[t];
+#pragma unroll
+        for (int w = 1; w < MF_WAVES; ++w) s += dwl[w * ntap + t];
+        wgrad_store_partial(&p.partial[((size_t)slice * p.C + c) * ntap + t], s);
+    }
+    wgrad_finish(p.partial, p.dw, p.counters + c, (int*)lds, p.slices, p.C, c, 1, ntap, tid, MF_THREADS);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+static bool fill_vrows_params(WgradRowsParams& p, const ConvDims& d, int resident_wgs) {
+    p.N = d.N; p.C = d.C; p.H = d.H; p.W = d.W; p.kh = d.kh; p.kw = d.kw;
+    p.KL = d.kh; p.padL = p.KL / 2;
+    if (d.kw != MF_TAPS || d.kh <= d.kw) return false;
+    if (d.H <= 32 || d.H > 64 || d.W % 8 || d.W < 16 || d.W > 64) return false;
+    p.CPR = d.W / 8 + 1; if (!(p.CPR & 1)) ++p.CPR;                   // odd number of 16-byte chunks per row, >= 1 pad chunk
+    p.ipc = (d.H * p.CPR + 63) / 64;
+    p.KS = (d.W + 15) / 16;
+    if ((3 * p.ipc + MF_WAVES - 1) / MF_WAVES > VR_MAX_IPW) return false;
+    int slices = resident_wgs / d.C; if (slices < 1) slices = 1;
+    if (slices > d.N) slices = d.N;
+    const int per = (d.N + slices - 1) / slices;
+    p.planes_per_wg = per; p.slices = (d.N + per - 1) / per;
+    p.tensor_bytes = (unsigned)((size_t)d.N * d.C * d.H * d.W * 2);
+    return (size_t)d.N * d.C * d.H * d.W * 2 < 0x7fffffffull;         // (signed source offsets in the DMA plan)
+}
+
+static size_t vrows_lds_bytes(const WgradRowsParams& p) {
+    size_t live = (size_t)VR_NB * 3 * p.ipc * 1024, scratch = (size_t)MF_WAVES * 32 * 64 * 4;
+    if (live < scratch) live = scratch;
+    return 64 + live + (size_t)MF_WAVES * p.kh * p.kw * 4 + 32;
+}
+
+bool dwconv_mfma_wgrad_vrows_supported(const ConvDims& d, int dy_dt, int x_dt) {
+    if (dy_dt != x_dt || (x_dt != SLAK_BF16 && x_dt != SLAK_F16)) return false;
+    WgradRowsParams p;
+    return fill_vrows_params(p, d, 512) && vrows_lds_bytes(p) <= 64 * 1024;
+}
+
+size_t dwconv_mfma_wgrad_vrows_workspace(const ConvDims& d) {
+    return align_up((size_t)(d.N < 2048 ? d.N : 2048) * d.C * d.kh * d.kw * sizeof(float), 256);
+}
+
+template <typename T>
+static int launch_vrows_t(WgradRowsParams& p, const ConvDims& d, size_t ws_bytes, hipStream_t st) {
+    auto k = dwconv_mfma_wgrad_vrows_kernel<T>;
+    fill_vrows_params(p, d, 512);
+    const size_t lds = vrows_lds_bytes(p);
+    static int resident = 0;
+    if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (resident == 0) {
+        int per_cu = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k, MF_THREADS, lds) != hipSuccess || per_cu < 1) per_cu = 1;
+        if (per_cu > 8) per_cu = 8;
+        if ((size_t)per_cu * (lds + 512) > 160 * 1024) --per_cu;       // (the query ignores the LDS allocation granule)
+        if (per_cu < 1) per_cu = 1;
+        resident = per_cu * mfma_cu_count();
+    }
+    fill_vrows_params(p, d, resident);
+    if ((size_t)p.slices * d.C * d.kh * d.kw * sizeof(float) > ws_bytes) return SLAK_ERR_WORKSPACE;
+    hipLaunchKernelGGL(k, dim3((unsigned)(p.C * p.slices)), dim3(MF_THREADS), lds, st, p);
+    SLAK_LAUNCH_CHECK();
+    return SLAK_OK;
+}
+
+int launch_dwconv_mfma_wgrad_vrows(const void* dy, int dy_dt, const void* x, int x_dt, float* dw,
+                                   const ConvDims& d, void* ws, size_t ws_bytes, hipStream_t st) {
+    if (!dwconv_mfma_wgrad_vrows_supported(d, dy_dt, x_dt)) return SLAK_ERR_UNSUPPORTED;
+    if (ws == nullptr) return SLAK_ERR_WORKSPACE;
+    WgradRowsParams p;
+    p.dy = dy; p.x = x; p.partial = (float*)ws; p.dw = dw;
+    p.counters = wgrad_arrival_counters(d.C);
+    if (!p.counters) return SLAK_ERR_UNSUPPORTED;
+    return x_dt == SLAK_BF16 ? launch_vrows_t<bf16_t>(p, d, ws_bytes, st) : launch_vrows_t<f16_t>(p, d, ws_bytes, st);
+}
+
+}  // namespace slak
