@@ -22,6 +22,32 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+
+
+def _use_tuned_gemms():
+    """The pointwise (1x1) convs are plain library GEMMs (hipBLASLt through torch).  PyTorch's TunableOp picks the fastest
+    hipBLASLt solution per GEMM shape; slak_amd/tuning/tunableop_gfx950.csv holds that choice for the 29 shapes of this workload,
+    recorded once on an MI355X (`PYTORCH_TUNABLEOP_ENABLED=1 PYTORCH_TUNABLEOP_TUNING=1 python bench.py`, ~30 s).  It is only
+    READ here (tuning off: shapes that are not in the file, or a file whose validator lines do not match this torch / ROCm /
+    GPU, fall back to the default heuristic).  TunableOp reads <name><device ordinal>.csv, so every rank gets its own copy.
+    SLAK_TUNED_GEMMS=0, or any PYTORCH_TUNABLEOP_* variable set by the caller, leaves everything alone."""
+    src = os.path.join(ROOT, "slak_amd", "tuning", "tunableop_gfx950.csv")
+    if os.environ.get("SLAK_TUNED_GEMMS", "1") == "0" or not os.path.exists(src):
+        return False
+    if any(k.startswith("PYTORCH_TUNABLEOP_") for k in os.environ):
+        return True
+    import shutil
+    import tempfile
+    d = tempfile.mkdtemp(prefix="slak_tunableop_")
+    dev = int(os.environ.get("LOCAL_RANK", "0"))
+    shutil.copy(src, os.path.join(d, "tunableop_results%d.csv" % dev))
+    os.environ.update(PYTORCH_TUNABLEOP_ENABLED="1", PYTORCH_TUNABLEOP_TUNING="0", PYTORCH_TUNABLEOP_RECORD_UNTUNED="0",
+                      PYTORCH_TUNABLEOP_FILENAME=os.path.join(d, "tunableop_results.csv"))
+    return True
+
+
+TUNED_GEMMS = _use_tuned_gemms()        # before torch is imported: TunableOp reads its environment once
+
 import torch
 import torch.distributed as dist
 import torch.nn as nn
@@ -235,6 +261,7 @@ def main():
                    "dwconv_dtype": "fp32" if a.fp32_dwconv else "bf16 in/out, fp32 accumulate", "optimizer": "AdamW(fused)",
                    "sync_bn": True, "block_tail": "hip (ln_nchw_to_nhwc + scale_residual)" if M.Block.fused_tail else "pytorch ops",
                    "branch_bn": "hip (bn3: one stats pass + one apply pass)" if M.ReparamLargeKernelConv.fused_bn else "pytorch (Sync)BatchNorm x3 + adds",
+                   "pointwise_gemm": "hipBLASLt via torch" + (", TunableOp solutions from slak_amd/tuning/tunableop_gfx950.csv" if TUNED_GEMMS else ""),
                    "final_loss": final_loss},
     }
 

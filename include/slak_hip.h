@@ -130,9 +130,13 @@ int slak_ln_nchw_to_nhwc_backward(const void* g_bf16, const void* x_bf16, const 
 /* out[n,c,p] = shortcut[n,c,p] + sample_scale[n] * gamma[c] * z[n,p,c]        (models/SLaK.py:161-165; sample_scale = the
  * DropPath mask/keep_prob per sample or NULL) ; backward: dz = sample_scale*gamma*dout (bf16 NHWC), dgamma = sum sample_scale*dout*z */
 int slak_scale_residual_forward(const void* shortcut, int shortcut_dtype, const void* z_bf16, const float* gamma, const float* sample_scale,
-                                float* out, int N, int C, int P, void* stream);
-int slak_scale_residual_backward(const float* dout, const void* z_bf16, const float* gamma, const float* sample_scale,
-                                 void* dz_bf16, float* dgamma, int N, int C, int P, void* workspace, size_t workspace_bytes, void* stream);
+                                float* out, void* out_bf16 /* NULL, or a second copy of `out` rounded to bf16: the next block's conv input */,
+                                int N, int C, int P, void* stream);
+/* dout_bf16 (NULL or the gradient that arrived through out_bf16) is added to dout; the sum -- the gradient of `shortcut` -- is
+ * written to dout_sum (required iff dout_bf16 is given; otherwise the shortcut gradient is dout itself). */
+int slak_scale_residual_backward(const float* dout, const void* dout_bf16, float* dout_sum, const void* z_bf16, const float* gamma,
+                                 const float* sample_scale, void* dz_bf16, float* dgamma, int N, int C, int P,
+                                 void* workspace, size_t workspace_bytes, void* stream);
 
 /* GELU backward (exact erf form, nn.GELU()) fused with the bias gradient of the Linear in front of it (models/SLaK.py:158-160):
  * dy1 = dact * gelu'(y1); dbias[col] = sum_rows dy1.  [rows][cols] bf16 contiguous, cols % 8 == 0. */

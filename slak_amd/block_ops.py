@@ -52,8 +52,11 @@ class _LnNchwToNhwc(torch.autograd.Function):
 
 
 class _ScaleResidual(torch.autograd.Function):
+    """out = shortcut + scale * gamma * z (NHWC -> NCHW), optionally with a second, bf16-rounded copy of `out` (the next block's
+    depthwise-conv input under autocast: saves the fp32 -> bf16 cast pass forward and a cast + add pass backward)."""
+
     @staticmethod
-    def forward(ctx, shortcut, z, gamma, sample_scale):
+    def forward(ctx, shortcut, z, gamma, sample_scale, emit_lowp):
         _chk(shortcut, "shortcut"); _chk(z, "z", torch.bfloat16); _chk(gamma, "gamma", torch.float32)
         N, C, H, W = shortcut.shape
         if z.shape != (N, H, W, C):
@@ -62,41 +65,56 @@ class _ScaleResidual(torch.autograd.Function):
         if sdt is None:
             raise TypeError("shortcut must be float32 or bfloat16")
         out = torch.empty((N, C, H, W), dtype=torch.float32, device=z.device)
+        out16 = torch.empty((N, C, H, W), dtype=torch.bfloat16, device=z.device) if emit_lowp else None
         L = _lib.lib()
         with torch.cuda.device(z.device):
             _lib.check(L.slak_scale_residual_forward(shortcut.data_ptr(), sdt, z.data_ptr(), gamma.data_ptr(),
                                                      sample_scale.data_ptr() if sample_scale is not None else None,
-                                                     out.data_ptr(), N, C, H * W, _stream(z.device)), "slak_scale_residual_forward")
+                                                     out.data_ptr(), out16.data_ptr() if emit_lowp else None,
+                                                     N, C, H * W, _stream(z.device)), "slak_scale_residual_forward")
         ctx.save_for_backward(z, gamma, sample_scale)
         ctx.shortcut_dtype = shortcut.dtype
+        ctx.emit_lowp = emit_lowp
+        if emit_lowp:
+            return out, out16
         return out
 
     @staticmethod
-    def backward(ctx, dout):
+    def backward(ctx, dout, dout16=None):
         z, gamma, sample_scale = ctx.saved_tensors
         N, H, W, C = z.shape
+        if dout is None:                                   # only the bf16 copy was used downstream
+            dout = torch.zeros((N, C, H, W), dtype=torch.float32, device=z.device)
         dout = dout.contiguous()
         if dout.dtype != torch.float32:
             dout = dout.float()
+        if dout16 is not None:
+            dout16 = dout16.contiguous()
+            if dout16.dtype != torch.bfloat16:
+                dout16 = dout16.to(torch.bfloat16)
+        dsum = torch.empty_like(dout) if dout16 is not None else None
         dz = torch.empty_like(z)
         dgamma = torch.empty_like(gamma)
         L = _lib.lib()
         ws, nb = _workspace(L.slak_block_tail_workspace_bytes(N, C, H * W), z.device)
         with torch.cuda.device(z.device):
-            _lib.check(L.slak_scale_residual_backward(dout.data_ptr(), z.data_ptr(), gamma.data_ptr(),
+            _lib.check(L.slak_scale_residual_backward(dout.data_ptr(), dout16.data_ptr() if dout16 is not None else None,
+                                                      dsum.data_ptr() if dsum is not None else None, z.data_ptr(), gamma.data_ptr(),
                                                       sample_scale.data_ptr() if sample_scale is not None else None,
                                                       dz.data_ptr(), dgamma.data_ptr(), N, C, H * W, ws.data_ptr(), nb, _stream(z.device)),
                        "slak_scale_residual_backward")
-        dshortcut = dout if ctx.shortcut_dtype == torch.float32 else dout.to(ctx.shortcut_dtype)
-        return dshortcut, dz, dgamma, None
+        dsc = dsum if dsum is not None else dout
+        dshortcut = dsc if ctx.shortcut_dtype == torch.float32 else dsc.to(ctx.shortcut_dtype)
+        return dshortcut, dz, dgamma, None, None
 
 
 def ln_nchw_to_nhwc(x, weight, bias, eps=1e-6):
     return _LnNchwToNhwc.apply(x, weight, bias, eps)
 
 
-def scale_residual(shortcut, z, gamma, sample_scale=None):
-    return _ScaleResidual.apply(shortcut, z, gamma, sample_scale)
+def scale_residual(shortcut, z, gamma, sample_scale=None, emit_lowp=False):
+    """Returns `out` (fp32 NCHW), or (out, out_bf16) with emit_lowp."""
+    return _ScaleResidual.apply(shortcut, z, gamma, sample_scale, emit_lowp)
 
 
 class _LinearSplitK(torch.autograd.Function):

@@ -216,7 +216,7 @@ __global__ __launch_bounds__(BT_THREADS) void ln_nchw_to_nhwc_bwd_pix_kernel(con
 template <typename Tsc>
 __global__ __launch_bounds__(BT_THREADS) void scale_residual_fwd_pix_kernel(const Tsc* __restrict__ sc, const uint16_t* __restrict__ z,
                                                                       const float* __restrict__ gamma, const float* __restrict__ scale,
-                                                                      float* __restrict__ out, const TailDims d) {
+                                                                      float* __restrict__ out, uint16_t* __restrict__ out16, const TailDims d) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int C = d.C, P = d.P, TP = d.TP, zp = C + 2;
     uint16_t* zs = (uint16_t*)smem;
@@ -240,6 +240,7 @@ __global__ __launch_bounds__(BT_THREADS) void scale_residual_fwd_pix_kernel(cons
                 o.z = to_f32(scn[off + 2]) + gm * bf2f(zs[(qq + 2) * zp + c]);
                 o.w = to_f32(scn[off + 3]) + gm * bf2f(zs[(qq + 3) * zp + c]);
                 *(float4*)(on + off) = o;
+                if (out16) *(uint2*)(out16 + (size_t)n * C * P + off) = uint2{bt_pack2(o.x, o.y), bt_pack2(o.z, o.w)};
             }
         }
     } else {
@@ -247,14 +248,17 @@ __global__ __launch_bounds__(BT_THREADS) void scale_residual_fwd_pix_kernel(cons
             const int c = idx / TP, qq = idx - c * TP;
             if (p0 + qq < P) {
                 const size_t off = (size_t)c * P + p0 + qq;
-                on[off] = to_f32(scn[off]) + gamma[c] * sn * bf2f(zs[qq * zp + c]);
+                const float ov = to_f32(scn[off]) + gamma[c] * sn * bf2f(zs[qq * zp + c]);
+                on[off] = ov;
+                if (out16) out16[(size_t)n * C * P + off] = bt_f2bf(ov);
             }
         }
     }
 }
 
 // dz[n,p,c] (bf16 NHWC) = scale[n] * gamma[c] * dout[n,c,p] (fp32 NCHW); part[tile][c] = scale[n] * sum_p dout * z
-__global__ __launch_bounds__(BT_THREADS) void scale_residual_bwd_pix_kernel(const float* __restrict__ dout, const uint16_t* __restrict__ z,
+__global__ __launch_bounds__(BT_THREADS) void scale_residual_bwd_pix_kernel(const float* __restrict__ dout, const uint16_t* __restrict__ dout16, float* __restrict__ dsum,
+                                                                      const uint16_t* __restrict__ z,
                                                                       const float* __restrict__ gamma, const float* __restrict__ scale,
                                                                       uint16_t* __restrict__ dz, float* __restrict__ part, const TailDims d) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -269,14 +273,29 @@ __global__ __launch_bounds__(BT_THREADS) void scale_residual_bwd_pix_kernel(cons
         for (int idx = tid; idx < C * cpr; idx += BT_THREADS) {
             const int c = idx / cpr, qq = (idx - c * cpr) * 4;
             float4 v = float4{0.f, 0.f, 0.f, 0.f};
-            if (p0 + qq < P) v = *(const float4*)(dn + (size_t)c * P + p0 + qq);
+            if (p0 + qq < P) {
+                const size_t off = (size_t)c * P + p0 + qq;
+                v = *(const float4*)(dn + off);
+                if (dout16) {                                          // second gradient stream (bf16 copy of `out`): add, hand the sum on
+                    const uint2 h = *(const uint2*)(dout16 + (size_t)n * C * P + off);
+                    v.x += bf2f((uint16_t)(h.x & 0xffff)); v.y += bf2f((uint16_t)(h.x >> 16));
+                    v.z += bf2f((uint16_t)(h.y & 0xffff)); v.w += bf2f((uint16_t)(h.y >> 16));
+                    *(float4*)(dsum + (size_t)n * C * P + off) = v;
+                }
+            }
             float* dst = ds + c * dp + qq;
             dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
         }
     } else {
         for (int idx = tid; idx < C * TP; idx += BT_THREADS) {
             const int c = idx / TP, qq = idx - c * TP;
-            ds[c * dp + qq] = (p0 + qq < P) ? dn[(size_t)c * P + p0 + qq] : 0.f;
+            float v = 0.f;
+            if (p0 + qq < P) {
+                const size_t off = (size_t)c * P + p0 + qq;
+                v = dn[off];
+                if (dout16) { v += bf2f(dout16[(size_t)n * C * P + off]); dsum[(size_t)n * C * P + off] = v; }
+            }
+            ds[c * dp + qq] = v;
         }
     }
     load_nhwc_tile(zs, z + (size_t)n * P * C, C, P, p0, TP, tid);
@@ -407,7 +426,7 @@ __global__ __launch_bounds__(BT_THREADS) void ln_nchw_to_nhwc_bwd_kernel(const u
 template <typename Tsc>
 __global__ __launch_bounds__(BT_THREADS) void scale_residual_fwd_kernel(const Tsc* __restrict__ sc, const uint16_t* __restrict__ z,
                                                                       const float* __restrict__ gamma, const float* __restrict__ scale,
-                                                                      float* __restrict__ out, const TailDims d) {
+                                                                      float* __restrict__ out, uint16_t* __restrict__ out16, const TailDims d) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int C = d.C, P = d.P, TP = d.TP, zp = C + 2;
     uint16_t* zs = (uint16_t*)smem;
@@ -432,6 +451,7 @@ __global__ __launch_bounds__(BT_THREADS) void scale_residual_fwd_kernel(const Ts
                     o.z = to_f32(scn[off + 2]) + gm * bf2f(zs[(qq + 2) * zp + c]);
                     o.w = to_f32(scn[off + 3]) + gm * bf2f(zs[(qq + 3) * zp + c]);
                     *(float4*)(on + off) = o;
+                    if (out16) *(uint2*)(out16 + (size_t)n * C * P + off) = uint2{bt_pack2(o.x, o.y), bt_pack2(o.z, o.w)};
                 }
             }
         } else {
@@ -439,7 +459,9 @@ __global__ __launch_bounds__(BT_THREADS) void scale_residual_fwd_kernel(const Ts
                 const int c = idx / TP, qq = idx - c * TP;
                 if (p0 + qq < P) {
                     const size_t off = (size_t)c * P + p0 + qq;
-                    on[off] = to_f32(scn[off]) + gamma[c] * sn * bf2f(zs[qq * zp + c]);
+                    const float ov = to_f32(scn[off]) + gamma[c] * sn * bf2f(zs[qq * zp + c]);
+                    on[off] = ov;
+                    if (out16) out16[(size_t)n * C * P + off] = bt_f2bf(ov);
                 }
             }
         }
@@ -449,7 +471,8 @@ __global__ __launch_bounds__(BT_THREADS) void scale_residual_fwd_kernel(const Ts
 
 // dz[n,p,c] (bf16 NHWC) = scale[n] * gamma[c] * dout[n,c,p] (fp32 NCHW, staged);  part[wg][c] = sum scale[n] * dout * z
 // (z read straight from global on its coalesced side)
-__global__ __launch_bounds__(BT_THREADS) void scale_residual_bwd_kernel(const float* __restrict__ dout, const uint16_t* __restrict__ z,
+__global__ __launch_bounds__(BT_THREADS) void scale_residual_bwd_kernel(const float* __restrict__ dout, const uint16_t* __restrict__ dout16, float* __restrict__ dsum,
+                                                                      const uint16_t* __restrict__ z,
                                                                       const float* __restrict__ gamma, const float* __restrict__ scale,
                                                                       uint16_t* __restrict__ dz, float* __restrict__ part, const TailDims d) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -468,14 +491,29 @@ __global__ __launch_bounds__(BT_THREADS) void scale_residual_bwd_kernel(const fl
             for (int idx = tid; idx < C * cpr; idx += BT_THREADS) {
                 const int c = idx / cpr, qq = (idx - c * cpr) * 4;
                 float4 v = float4{0.f, 0.f, 0.f, 0.f};
-                if (p0 + qq < P) v = *(const float4*)(dn + (size_t)c * P + p0 + qq);
+                if (p0 + qq < P) {
+                    const size_t off = (size_t)c * P + p0 + qq;
+                    v = *(const float4*)(dn + off);
+                    if (dout16) {
+                        const uint2 h = *(const uint2*)(dout16 + (size_t)n * C * P + off);
+                        v.x += bf2f((uint16_t)(h.x & 0xffff)); v.y += bf2f((uint16_t)(h.x >> 16));
+                        v.z += bf2f((uint16_t)(h.y & 0xffff)); v.w += bf2f((uint16_t)(h.y >> 16));
+                        *(float4*)(dsum + (size_t)n * C * P + off) = v;
+                    }
+                }
                 float* dst = ds + c * dp + qq;
                 dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
             }
         } else {
             for (int idx = tid; idx < C * TP; idx += BT_THREADS) {
                 const int c = idx / TP, qq = idx - c * TP;
-                ds[c * dp + qq] = (p0 + qq < P) ? dn[(size_t)c * P + p0 + qq] : 0.f;
+                float v = 0.f;
+                if (p0 + qq < P) {
+                    const size_t off = (size_t)c * P + p0 + qq;
+                    v = dn[off];
+                    if (dout16) { v += bf2f(dout16[(size_t)n * C * P + off]); dsum[(size_t)n * C * P + off] = v; }
+                }
+                ds[c * dp + qq] = v;
             }
         }
         __syncthreads();
@@ -813,7 +851,7 @@ int slak_ln_nchw_to_nhwc_backward(const void* g, const void* x, const float* wei
 }
 
 int slak_scale_residual_forward(const void* shortcut, int shortcut_dtype, const void* z, const float* gamma, const float* sample_scale,
-                                float* out, int N, int C, int P, void* stream) {
+                                float* out, void* out_bf16, int N, int C, int P, void* stream) {
     if (!shortcut || !z || !gamma || !out) return SLAK_ERR_INVALID_ARG;
     int rc = tail_args_ok(N, C, P); if (rc) return rc;
     if (C <= 256) {
@@ -823,11 +861,11 @@ int slak_scale_residual_forward(const void* shortcut, int shortcut_dtype, const 
         if (shortcut_dtype == SLAK_F32) {
             if (set_lds((const void*)scale_residual_fwd_pix_kernel<float>, lds)) return SLAK_ERR_LAUNCH;
             hipLaunchKernelGGL(scale_residual_fwd_pix_kernel<float>, grid, dim3(BT_THREADS), lds, (hipStream_t)stream,
-                               (const float*)shortcut, (const uint16_t*)z, gamma, sample_scale, out, d);
+                               (const float*)shortcut, (const uint16_t*)z, gamma, sample_scale, out, (uint16_t*)out_bf16, d);
         } else if (shortcut_dtype == SLAK_BF16) {
             if (set_lds((const void*)scale_residual_fwd_pix_kernel<bf16_t>, lds)) return SLAK_ERR_LAUNCH;
             hipLaunchKernelGGL(scale_residual_fwd_pix_kernel<bf16_t>, grid, dim3(BT_THREADS), lds, (hipStream_t)stream,
-                               (const bf16_t*)shortcut, (const uint16_t*)z, gamma, sample_scale, out, d);
+                               (const bf16_t*)shortcut, (const uint16_t*)z, gamma, sample_scale, out, (uint16_t*)out_bf16, d);
         } else return SLAK_ERR_UNSUPPORTED;
         SLAK_LAUNCH_CHECK();
         return SLAK_OK;
@@ -840,19 +878,20 @@ int slak_scale_residual_forward(const void* shortcut, int shortcut_dtype, const 
     if (shortcut_dtype == SLAK_F32) {
         if (set_lds((const void*)scale_residual_fwd_kernel<float>, lds)) return SLAK_ERR_LAUNCH;
         hipLaunchKernelGGL(scale_residual_fwd_kernel<float>, grid, dim3(BT_THREADS), lds, (hipStream_t)stream,
-                           (const float*)shortcut, (const uint16_t*)z, gamma, sample_scale, out, d);
+                           (const float*)shortcut, (const uint16_t*)z, gamma, sample_scale, out, (uint16_t*)out_bf16, d);
     } else if (shortcut_dtype == SLAK_BF16) {
         if (set_lds((const void*)scale_residual_fwd_kernel<bf16_t>, lds)) return SLAK_ERR_LAUNCH;
         hipLaunchKernelGGL(scale_residual_fwd_kernel<bf16_t>, grid, dim3(BT_THREADS), lds, (hipStream_t)stream,
-                           (const bf16_t*)shortcut, (const uint16_t*)z, gamma, sample_scale, out, d);
+                           (const bf16_t*)shortcut, (const uint16_t*)z, gamma, sample_scale, out, (uint16_t*)out_bf16, d);
     } else return SLAK_ERR_UNSUPPORTED;
     SLAK_LAUNCH_CHECK();
     return SLAK_OK;
 }
 
-int slak_scale_residual_backward(const float* dout, const void* z, const float* gamma, const float* sample_scale,
-                                 void* dz, float* dgamma, int N, int C, int P, void* workspace, size_t workspace_bytes, void* stream) {
-    if (!dout || !z || !gamma || !dz || !dgamma) return SLAK_ERR_INVALID_ARG;
+int slak_scale_residual_backward(const float* dout, const void* dout_bf16, float* dout_sum, const void* z, const float* gamma,
+                                 const float* sample_scale, void* dz, float* dgamma, int N, int C, int P,
+                                 void* workspace, size_t workspace_bytes, void* stream) {
+    if (!dout || !z || !gamma || !dz || !dgamma || (dout_bf16 && !dout_sum)) return SLAK_ERR_INVALID_ARG;
     int rc = tail_args_ok(N, C, P); if (rc) return rc;
     if (!workspace || workspace_bytes < slak_block_tail_workspace_bytes(N, C, P)) return SLAK_ERR_WORKSPACE;
     if (C <= 256) {
@@ -861,7 +900,7 @@ int slak_scale_residual_backward(const float* dout, const void* z, const float* 
         if (set_lds((const void*)scale_residual_bwd_pix_kernel, lds)) return SLAK_ERR_LAUNCH;
         float* part = (float*)workspace;
         hipLaunchKernelGGL(scale_residual_bwd_pix_kernel, dim3((unsigned)d.ntiles), dim3(BT_THREADS), lds, (hipStream_t)stream,
-                           dout, (const uint16_t*)z, gamma, sample_scale, (uint16_t*)dz, part, d);
+                           dout, (const uint16_t*)dout_bf16, dout_sum, (const uint16_t*)z, gamma, sample_scale, (uint16_t*)dz, part, d);
         SLAK_LAUNCH_CHECK();
         return reduce_partials(part, part + (size_t)d.ntiles * 2 * C, dgamma, dgamma, C, d.ntiles, C, (hipStream_t)stream);
     }
@@ -872,7 +911,7 @@ int slak_scale_residual_backward(const float* dout, const void* z, const float* 
     const int grid = tail_grid(d, lds);
     float* part = (float*)workspace;
     hipLaunchKernelGGL(scale_residual_bwd_kernel, dim3((unsigned)grid), dim3(BT_THREADS), lds, (hipStream_t)stream,
-                       dout, (const uint16_t*)z, gamma, sample_scale, (uint16_t*)dz, part, d);
+                       dout, (const uint16_t*)dout_bf16, dout_sum, (const uint16_t*)z, gamma, sample_scale, (uint16_t*)dz, part, d);
     SLAK_LAUNCH_CHECK();
     return reduce_partials(part, part + (size_t)grid * 2 * C, dgamma, dgamma, C, grid, C, (hipStream_t)stream);
 }

@@ -113,7 +113,9 @@ class ReparamLargeKernelConv(nn.Module):
 
     def forward(self, inputs):
         if self.lowp_dwconv and torch.is_autocast_enabled():
-            inputs = inputs.to(torch.get_autocast_dtype("cuda"))
+            lowp = getattr(inputs, "_slak_lowp", None)          # bf16 copy the previous block's fused tail wrote alongside (Block.emit_lowp)
+            dt = torch.get_autocast_dtype("cuda")
+            inputs = lowp if (lowp is not None and lowp.dtype == dt and lowp.shape == inputs.shape) else inputs.to(dt)
         if hasattr(self, 'lkb_reparam'):
             return self.lkb_reparam(inputs)
         if (self.fused_bn and self.Decom and hasattr(self, 'small_conv') and inputs.is_cuda and inputs.dtype == torch.bfloat16
@@ -191,11 +193,16 @@ def _block_forward_fused_tail(self, shortcut, x):
         scale = torch.empty(x.shape[0], device=x.device, dtype=torch.float32).bernoulli_(keep)
         if keep > 0.0:
             scale.div_(keep)
+    if self.emit_lowp and torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == torch.bfloat16:
+        out, out16 = block_ops.scale_residual(shortcut.contiguous(), z.contiguous(), self.gamma.float(), scale, emit_lowp=True)
+        out._slak_lowp = out16                                  # picked up by the next block's ReparamLargeKernelConv.forward
+        return out
     return block_ops.scale_residual(shortcut.contiguous(), z.contiguous(), self.gamma.float(), scale)
 
 
 Block._forward_fused_tail = _block_forward_fused_tail
 Block.fused_tail = False
+Block.emit_lowp = False      # per instance: the next module is another Block with lowp_dwconv (set by SLaK.__init__ / bench.py)
 ReparamLargeKernelConv.fused_bn = False
 LayerNorm.fused_cf = False
 
@@ -222,6 +229,9 @@ class SLaK(nn.Module):
                       kernel_size=(self.kernel_size[i], self.kernel_size[-1]), Decom=Decom, bn=bn, lowp_dwconv=lowp_dwconv)
                 for j in range(depths[i])]))
             at += depths[i]
+            if lowp_dwconv:                                     # every block that hands its output to another block of the stage
+                for blk in list(self.stages[-1])[:-1]:
+                    blk.emit_lowp = True
         self.norm = nn.LayerNorm(dims[-1], eps=1e-6)
         self.head = nn.Linear(dims[-1], num_classes)
         self.apply(self._init_weights)

@@ -94,6 +94,47 @@ def test_block_with_fused_tail_matches_reference_composition(gpu):
         assert a.dtype == b.dtype, n
         _close(a, b, 3e-2, n)           # two bf16 pipelines with different rounding points
 
+@pytest.mark.parametrize("C,H", [(96, 28), (384, 14)])
+def test_two_blocks_with_lowp_handoff_match_reference_composition(C, H, gpu):
+    """Two consecutive Blocks: with emit_lowp the first block's fused tail also writes the bf16 copy the second block's convs
+    read, and the gradient that comes back through that copy is added inside scale_residual's backward -- same arithmetic as
+    the cast (forward) and the cast + add (backward) of the reference composition."""
+    import torch.nn as nn
+    import slak_amd.slak_model as M
+    from slak_amd import block_ops
+    M.use_sync_bn = False
+    torch.manual_seed(1)
+    seq = nn.Sequential(*[M.Block(C, drop_path=0.0, layer_scale_init_value=0.5, kernel_size=(13, 5), Decom=True, bn=True, lowp_dwconv=True)
+                          for _ in range(2)]).to(gpu)
+    x = torch.randn(3, C, H, H, device=gpu)
+    dy = torch.randn_like(x)
+    outs = {}
+    for mode in ("reference", "fused", "fused+lowp"):
+        for b in seq:
+            b.fused_tail = mode != "reference"
+            b.emit_lowp = False
+        seq[0].emit_lowp = mode == "fused+lowp"
+        seq.zero_grad()
+        xi = x.clone().requires_grad_(True)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            y = seq(xi)
+        if mode == "fused+lowp":
+            # the handoff really happened: the second block's input carried the bf16 copy
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                mid = seq[0](x)
+            assert getattr(mid, "_slak_lowp", None) is not None and mid._slak_lowp.dtype == torch.bfloat16
+            assert torch.equal(mid._slak_lowp, mid.to(torch.bfloat16))
+        y.backward(dy)
+        outs[mode] = (y.detach(), xi.grad.detach(), seq[0].gamma.grad.clone(), seq[1].gamma.grad.clone(),
+                      seq[0].pwconv2.weight.grad.clone(), seq[1].large_kernel.LoRA2.conv.weight.grad.clone())
+    for b in seq:
+        b.fused_tail = False; b.emit_lowp = False
+    names = ("y", "dx", "dgamma0", "dgamma1", "dpwconv2.weight", "dLoRA2.weight")
+    for a, b, n in zip(outs["fused+lowp"], outs["fused"], names):
+        _close(a, b, 1e-2, n + " (lowp handoff vs fused)")       # identical rounding points except the order of one addition
+    for a, b, n in zip(outs["fused+lowp"], outs["reference"], names):
+        _close(a, b, 3e-2, n + " (vs reference)")
+
 
 @pytest.mark.parametrize("N,C,H,W", [(4, 96, 56, 56), (5, 192, 28, 28), (6, 384, 14, 14), (8, 768, 7, 7), (3, 10, 9, 11)])
 def test_branch_bn3_matches_three_batchnorms(N, C, H, W, gpu):
