@@ -315,6 +315,10 @@ def ln_channels_first(x, weight, bias, eps=1e-6, out_dtype=torch.float32):
 
 
 # ------------------------------------------------------------------------------------------------------------------
+import os as _os
+_SPLITK_ROWS = int(_os.environ.get("SLAK_SPLITK_ROWS", "6272"))     # rows per split of the weight-gradient GEMMs (0: one plain GEMM)
+
+
 class _MlpSplitK(torch.autograd.Function):
     """pwconv2(gelu(pwconv1(t))) under bf16 autocast (models/SLaK.py:158-160) with (i) both weight gradients as split-K batched
     library GEMMs (see _LinearSplitK) and (ii) the GELU backward fused with pwconv1's bias gradient in one HIP kernel.
@@ -336,7 +340,7 @@ class _MlpSplitK(torch.autograd.Function):
         dz2 = dz.reshape(-1, dz.shape[-1])
         a2 = a.reshape(-1, a.shape[-1]); t2 = t.reshape(-1, t.shape[-1]); y12 = y1.reshape(-1, y1.shape[-1])
         M = dz2.shape[0]
-        S = max(1, M // 6272)
+        S = max(1, M // _SPLITK_ROWS) if _SPLITK_ROWS > 0 else 1
         while S > 1 and M % S:
             S -= 1
 

@@ -5,8 +5,7 @@
 
 HBM bytes per op launch = 2 * FETCH_SIZE*1024 + WRITE_SIZE*1024: FETCH_SIZE on gfx950 reports exactly half of a wide
 coalesced streaming read (MI355X_MICROARCH.md, HBM section: TCC_EA0_RDREQ counted at 64 B for 128-B requests), WRITE_SIZE
-is taken as read (uncalibrated).  An "op" is everything one C-ABI call launches (Toeplitz pack + conv, or wgrad + slice
-reduce).  The workload issues, per (stage, filter), 3 x (forward, backward_data, backward_filter); the median is kept.
+is taken as read (uncalibrated).  An "op" is everything one C-ABI call launches (one kernel on the MFMA paths).  The workload issues, per (stage, filter), 3 x (forward, backward_data, backward_filter); the median is kept.
 """
 import json
 import os
@@ -21,19 +20,16 @@ def ops_of(db, counter):
     c = sqlite3.connect(db)
     rows = list(c.execute("select kernel_name, value, start from counters_collection where counter_name = ? order by start", (counter,)))
     seq = [(n, v) for (n, v, _) in rows if "slak::" in n]
-    ops, cur = [], None
+    # every C-ABI call of the MFMA paths launches exactly ONE kernel now (fragments are built in the kernel, the slice reduction of
+    # the weight gradient is folded into it); the fp32-exact direct path (not part of this workload) would add a reduce launch
+    ops = []
     for n, v in seq:
-        if "toeplitz_pack" in n:
-            cur = ["conv", v]
-        elif "dwconv_mfma_dma_kernel" in n or "dwconv_mfma_fwd_kernel" in n or "dwconv_direct_kernel" in n or "dwconv_mfma_small_kernel" in n:
-            if cur is None: cur = ["conv", 0.0]
-            cur[1] += v; ops.append(tuple(cur)); cur = None
-        elif "dwconv_prep_weights" in n:
-            cur = ["conv", v]
-        elif "wgrad_kernel" in n or "wgrad_dma_kernel" in n:
-            cur = ["wgrad", v]
-        elif "wgrad_reduce" in n:
-            cur[1] += v; ops.append(tuple(cur)); cur = None
+        if "reduce" in n or "toeplitz_pack" in n:
+            if ops: ops[-1] = (ops[-1][0], ops[-1][1] + v)
+        elif "wgrad" in n:
+            ops.append(("wgrad", v))
+        elif "dwconv" in n:
+            ops.append(("conv", v))
     return ops
 
 
