@@ -133,9 +133,10 @@ int slak_scale_residual_forward(const void* shortcut, int shortcut_dtype, const 
                                 float* out, void* out_bf16 /* NULL, or a second copy of `out` rounded to bf16: the next block's conv input */,
                                 int N, int C, int P, void* stream);
 /* dout_bf16 (NULL or the gradient that arrived through out_bf16) is added to dout; the sum -- the gradient of `shortcut` -- is
- * written to dout_sum (required iff dout_bf16 is given; otherwise the shortcut gradient is dout itself). */
+ * written to dout_sum (required iff dout_bf16 is given; otherwise the shortcut gradient is dout itself).
+ * dz_colsum[c] = sum over n,p of the (unrounded) dz: the bias gradient of the Linear that produced z (models/SLaK.py:160). */
 int slak_scale_residual_backward(const float* dout, const void* dout_bf16, float* dout_sum, const void* z_bf16, const float* gamma,
-                                 const float* sample_scale, void* dz_bf16, float* dgamma, int N, int C, int P,
+                                 const float* sample_scale, void* dz_bf16, float* dgamma, float* dz_colsum, int N, int C, int P,
                                  void* workspace, size_t workspace_bytes, void* stream);
 
 /* GELU backward (exact erf form, nn.GELU()) fused with the bias gradient of the Linear in front of it (models/SLaK.py:158-160):

@@ -95,14 +95,17 @@ class _ScaleResidual(torch.autograd.Function):
         dsum = torch.empty_like(dout) if dout16 is not None else None
         dz = torch.empty_like(z)
         dgamma = torch.empty_like(gamma)
+        dzc = torch.empty_like(gamma)
         L = _lib.lib()
         ws, nb = _workspace(L.slak_block_tail_workspace_bytes(N, C, H * W), z.device)
         with torch.cuda.device(z.device):
             _lib.check(L.slak_scale_residual_backward(dout.data_ptr(), dout16.data_ptr() if dout16 is not None else None,
                                                       dsum.data_ptr() if dsum is not None else None, z.data_ptr(), gamma.data_ptr(),
                                                       sample_scale.data_ptr() if sample_scale is not None else None,
-                                                      dz.data_ptr(), dgamma.data_ptr(), N, C, H * W, ws.data_ptr(), nb, _stream(z.device)),
+                                                      dz.data_ptr(), dgamma.data_ptr(), dzc.data_ptr(), N, C, H * W,
+                                                      ws.data_ptr(), nb, _stream(z.device)),
                        "slak_scale_residual_backward")
+        dz._slak_colsum = dzc          # sum of dz over (n, p): the bias gradient of the Linear that produced z (picked up by mlp_splitk)
         dsc = dsum if dsum is not None else dout
         dshortcut = dsc if ctx.shortcut_dtype == torch.float32 else dsc.to(ctx.shortcut_dtype)
         return dshortcut, dz, dgamma, None, None
@@ -350,7 +353,9 @@ class _MlpSplitK(torch.autograd.Function):
             return torch.mm(dy.t(), x).float()
 
         dw2 = wgrad(dz2, a2)
-        db2 = dz2.sum(0, dtype=torch.float32)
+        db2 = getattr(dz, "_slak_colsum", None)            # scale_residual's backward already has the column sums of dz
+        if db2 is None or db2.shape != (dz2.shape[1],) or db2.dtype != torch.float32:
+            db2 = dz2.sum(0, dtype=torch.float32)
         dact = torch.mm(dz2, w2b)
         dy1 = torch.empty_like(dact)
         db1 = torch.empty(dact.shape[1], dtype=torch.float32, device=dact.device)

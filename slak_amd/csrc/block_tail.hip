@@ -308,11 +308,11 @@ __global__ __launch_bounds__(BT_THREADS) void scale_residual_bwd_pix_kernel(cons
         if (p0 + qq < P)
             ((unsigned*)(dzn + (size_t)qq * C))[k] = bt_pack2(sn * gamma[2 * k] * ds[(2 * k) * dp + qq], sn * gamma[2 * k + 1] * ds[(2 * k + 1) * dp + qq]);
     }
-    float* pt = part + (size_t)blockIdx.x * C;
+    float* pt = part + (size_t)blockIdx.x * 2 * C;               // [dgamma partial | column sums of dz (= the next Linear's bias gradient)]
     for (int c = tid; c < C; c += BT_THREADS) {
-        float a = 0.f;
-        for (int qq = 0; qq < TP; ++qq) a += ds[c * dp + qq] * bf2f(zs[qq * zp + c]);
-        pt[c] = a * sn;
+        float a = 0.f, b = 0.f;
+        for (int qq = 0; qq < TP; ++qq) { a += ds[c * dp + qq] * bf2f(zs[qq * zp + c]); b += ds[c * dp + qq]; }
+        pt[c] = a * sn; pt[C + c] = b * sn * gamma[c];
     }
 }
 
@@ -480,9 +480,9 @@ __global__ __launch_bounds__(BT_THREADS) void scale_residual_bwd_kernel(const fl
     float* ds = (float*)smem;                                                        // [C][TP+1] fp32
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     constexpr int KMAX = 8;
-    float ag[2 * KMAX];
+    float ag[2 * KMAX], bg[2 * KMAX];
 #pragma unroll
-    for (int i = 0; i < 2 * KMAX; ++i) ag[i] = 0.f;
+    for (int i = 0; i < 2 * KMAX; ++i) { ag[i] = 0.f; bg[i] = 0.f; }
     for (int tile = blockIdx.x; tile < d.ntiles; tile += gridDim.x) {
         const int n = tile / d.tiles_per_image, p0 = (tile - n * d.tiles_per_image) * TP;
         const float* dn = dout + (size_t)n * C * P;
@@ -529,21 +529,30 @@ __global__ __launch_bounds__(BT_THREADS) void scale_residual_bwd_kernel(const fl
                     const unsigned zv = zq[k];
                     const float d0 = ds[(2 * k) * dp + q], d1 = ds[(2 * k + 1) * dp + q];
                     ag[2 * kk] += sn * d0 * bf2f((uint16_t)(zv & 0xffff)); ag[2 * kk + 1] += sn * d1 * bf2f((uint16_t)(zv >> 16));
-                    ((unsigned*)(dzn + (size_t)q * C))[k] = bt_pack2(sn * gamma[2 * k] * d0, sn * gamma[2 * k + 1] * d1);
+                    const float z0 = sn * gamma[2 * k] * d0, z1 = sn * gamma[2 * k + 1] * d1;
+                    bg[2 * kk] += z0; bg[2 * kk + 1] += z1;
+                    ((unsigned*)(dzn + (size_t)q * C))[k] = bt_pack2(z0, z1);
                 }
             }
         }
         __syncthreads();
     }
-    float* red = ds;                                                                 // [4][C], the tile is dead now
+    float* red = ds;                                                                 // 2 x [4][C], the tile is dead now
+    float* red2 = ds + 4 * C;
 #pragma unroll
     for (int kk = 0; kk < KMAX; ++kk) {
         const int k = lane + 64 * kk;
-        if (k < cp) { red[wave * C + 2 * k] = ag[2 * kk]; red[wave * C + 2 * k + 1] = ag[2 * kk + 1]; }
+        if (k < cp) {
+            red[wave * C + 2 * k] = ag[2 * kk]; red[wave * C + 2 * k + 1] = ag[2 * kk + 1];
+            red2[wave * C + 2 * k] = bg[2 * kk]; red2[wave * C + 2 * k + 1] = bg[2 * kk + 1];
+        }
     }
     __syncthreads();
-    float* pt = part + (size_t)blockIdx.x * C;
-    for (int c = tid; c < C; c += BT_THREADS) pt[c] = ((red[c] + red[C + c]) + red[2 * C + c]) + red[3 * C + c];
+    float* pt = part + (size_t)blockIdx.x * 2 * C;               // [dgamma partial | column sums of dz]
+    for (int c = tid; c < C; c += BT_THREADS) {
+        pt[c] = ((red[c] + red[C + c]) + red[2 * C + c]) + red[3 * C + c];
+        pt[C + c] = ((red2[c] + red2[C + c]) + red2[2 * C + c]) + red2[3 * C + c];
+    }
 }
 
 // ===== channels_first LayerNorm (stem and downsample layers, models/SLaK.py:192-203, :256-261): y[n,c,p] = LN_C(x[n,:,p])*w+b, NCHW in
@@ -889,9 +898,9 @@ int slak_scale_residual_forward(const void* shortcut, int shortcut_dtype, const 
 }
 
 int slak_scale_residual_backward(const float* dout, const void* dout_bf16, float* dout_sum, const void* z, const float* gamma,
-                                 const float* sample_scale, void* dz, float* dgamma, int N, int C, int P,
+                                 const float* sample_scale, void* dz, float* dgamma, float* dz_colsum, int N, int C, int P,
                                  void* workspace, size_t workspace_bytes, void* stream) {
-    if (!dout || !z || !gamma || !dz || !dgamma || (dout_bf16 && !dout_sum)) return SLAK_ERR_INVALID_ARG;
+    if (!dout || !z || !gamma || !dz || !dgamma || !dz_colsum || (dout_bf16 && !dout_sum)) return SLAK_ERR_INVALID_ARG;
     int rc = tail_args_ok(N, C, P); if (rc) return rc;
     if (!workspace || workspace_bytes < slak_block_tail_workspace_bytes(N, C, P)) return SLAK_ERR_WORKSPACE;
     if (C <= 256) {
@@ -902,7 +911,7 @@ int slak_scale_residual_backward(const float* dout, const void* dout_bf16, float
         hipLaunchKernelGGL(scale_residual_bwd_pix_kernel, dim3((unsigned)d.ntiles), dim3(BT_THREADS), lds, (hipStream_t)stream,
                            dout, (const uint16_t*)dout_bf16, dout_sum, (const uint16_t*)z, gamma, sample_scale, (uint16_t*)dz, part, d);
         SLAK_LAUNCH_CHECK();
-        return reduce_partials(part, part + (size_t)d.ntiles * 2 * C, dgamma, dgamma, C, d.ntiles, C, (hipStream_t)stream);
+        return reduce_partials(part, part + (size_t)d.ntiles * 2 * C, dgamma, dz_colsum, C, d.ntiles, 2 * C, (hipStream_t)stream);
     }
     const TailDims d = make_dims(N, C, P, 4);
     size_t lds = (size_t)C * (d.TP + 1) * 4 + 16;
@@ -913,7 +922,7 @@ int slak_scale_residual_backward(const float* dout, const void* dout_bf16, float
     hipLaunchKernelGGL(scale_residual_bwd_kernel, dim3((unsigned)grid), dim3(BT_THREADS), lds, (hipStream_t)stream,
                        dout, (const uint16_t*)dout_bf16, dout_sum, (const uint16_t*)z, gamma, sample_scale, (uint16_t*)dz, part, d);
     SLAK_LAUNCH_CHECK();
-    return reduce_partials(part, part + (size_t)grid * 2 * C, dgamma, dgamma, C, grid, C, (hipStream_t)stream);
+    return reduce_partials(part, part + (size_t)grid * 2 * C, dgamma, dz_colsum, C, grid, 2 * C, (hipStream_t)stream);
 }
 
 static TailDims make_dims_cf(int N, int C, int P, int tiles_of_fp32) {

@@ -88,8 +88,8 @@ def test_block_with_fused_tail_matches_reference_composition(gpu):
             y = blk(xi)
         y.backward(dy)
         outs[fused] = (y.detach(), xi.grad.detach(), blk.gamma.grad.clone(), blk.norm.weight.grad.clone(), blk.pwconv1.weight.grad.clone(),
-                       blk.large_kernel.LoRA1.conv.weight.grad.clone())
-    names = ("y", "dx", "dgamma", "dnorm.weight", "dpwconv1.weight", "dLoRA1.weight")
+                       blk.large_kernel.LoRA1.conv.weight.grad.clone(), blk.pwconv2.bias.grad.clone(), blk.pwconv1.bias.grad.clone())
+    names = ("y", "dx", "dgamma", "dnorm.weight", "dpwconv1.weight", "dLoRA1.weight", "dpwconv2.bias", "dpwconv1.bias")
     for a, b, n in zip(outs[True], outs[False], names):
         assert a.dtype == b.dtype, n
         _close(a, b, 3e-2, n)           # two bf16 pipelines with different rounding points
