@@ -194,6 +194,8 @@ def main():
     M.Block.fused_tail = not a.no_fused_tail and not a.fp32_dwconv    # HIP glue kernels around the pointwise GEMMs
     M.ReparamLargeKernelConv.fused_bn = not a.no_fused_bn and not a.fp32_dwconv   # branch BatchNorms + adds as one HIP op
     M.LayerNorm.fused_cf = not a.no_fused_tail                     # channels_first LayerNorm of stem/downsample as one HIP kernel
+    from slak_amd import block_ops
+    block_ops.cache_lowp_weights = True                            # bf16 weight copies refreshed by one multi-tensor launch per step
     M.use_sync_bn = True                                          # reference default (models/SLaK.py:19); falls back to BN math at world 1
     torch.manual_seed(0 + rank)                                   # main.py:232  seed = args.seed + rank
     model = M.SLaK_tiny(kernel_size=[51, 49, 47, 13, 5], Decom=True, bn=True, drop_path_rate=0.1,

@@ -319,6 +319,47 @@ def ln_channels_first(x, weight, bias, eps=1e-6, out_dtype=torch.float32):
 
 # ------------------------------------------------------------------------------------------------------------------
 import os as _os
+import weakref as _weakref
+
+# bf16 copies of the fp32 master weights the pointwise GEMMs read, refreshed in ONE multi-tensor launch per optimizer step
+# (autocast casts each weight with its own kernel each step: 72 launches per SLaK-T step).  Keyed by parameter identity,
+# validated by the tensor version counter (optimizer steps and Masking's kernels bump it).
+# Off by default: a weight changed in place through `.data` (which has its own version counter) would go unnoticed; the training
+# loops of the reference (optimizer.step() + Masking) are safe, and bench.py turns it on.
+_lowp_cache = {}
+cache_lowp_weights = False
+
+
+def lowp_param(p):
+    if not cache_lowp_weights:
+        return p.to(torch.bfloat16)
+    key = id(p)
+    e = _lowp_cache.get(key)
+    if e is not None and e[0]() is p and e[2].device == p.device:
+        if e[1] != p._version:
+            _refresh_lowp()
+        return e[2]
+    with torch.no_grad():
+        c = p.detach().to(torch.bfloat16)
+    _lowp_cache[key] = [_weakref.ref(p), p._version, c]
+    return c
+
+
+def _refresh_lowp():
+    srcs, dsts, dead = [], [], []
+    for key, e in _lowp_cache.items():
+        p = e[0]()
+        if p is None:
+            dead.append(key)
+        elif e[1] != p._version and e[2].device == p.device:
+            srcs.append(p.detach()); dsts.append(e[2]); e[1] = p._version
+    for key in dead:
+        del _lowp_cache[key]
+    if srcs:
+        with torch.no_grad():
+            torch._foreach_copy_(dsts, srcs)
+
+
 _SPLITK_ROWS = int(_os.environ.get("SLAK_SPLITK_ROWS", "6272"))     # rows per split of the weight-gradient GEMMs (0: one plain GEMM)
 
 
@@ -330,10 +371,10 @@ class _MlpSplitK(torch.autograd.Function):
     @staticmethod
     def forward(ctx, t, w1, b1, w2, b2):
         F = torch.nn.functional
-        w1b, w2b = w1.to(torch.bfloat16), w2.to(torch.bfloat16)
-        y1 = F.linear(t, w1b, b1.to(torch.bfloat16))
+        w1b, w2b = lowp_param(w1), lowp_param(w2)
+        y1 = F.linear(t, w1b, lowp_param(b1))
         a = F.gelu(y1)
-        z = F.linear(a, w2b, b2.to(torch.bfloat16))
+        z = F.linear(a, w2b, lowp_param(b2))
         ctx.save_for_backward(t, w1b, y1, a, w2b)
         return z
 

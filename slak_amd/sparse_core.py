@@ -325,6 +325,20 @@ class Masking(object):
         with torch.cuda.device(self.device):
             self._bind_momentum(params)
             _lib.check(_lib.lib().slak_mask_apply(self._plan, self._stream()), "slak_mask_apply")
+        self._bump_versions([t for _, t in params])
+
+    @staticmethod
+    def _bump_versions(params):
+        """The kernels write the weights through raw pointers; tell autograd (and anything that caches by tensor version, e.g. the
+        bf16 weight copies of slak_amd.block_ops) that they changed."""
+        inc = getattr(torch._C, "_increment_version", None)
+        if inc is None:
+            return
+        for p in params:
+            try:
+                inc(p)
+            except (TypeError, RuntimeError):
+                inc([p])
 
     def truncate_weights(self):
         params = self._ensure_plan()
@@ -346,6 +360,7 @@ class Masking(object):
             _lib.check(L.slak_mask_prune_and_grow(self._plan, float(self.prune_rate), self._stream()), "slak_mask_prune_and_grow")
             stats = (ctypes.c_double * (4 * len(params)))()
             _lib.check(L.slak_mask_read_stats(self._plan, stats, self._stream()), "slak_mask_read_stats")
+        self._bump_versions([t for _, t in params])
         self._nonzeros_after = {}
         for i, (name, _) in enumerate(params):
             self.name2nonzeros[name] = stats[4 * i + 0]

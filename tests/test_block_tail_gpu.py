@@ -212,3 +212,24 @@ def test_mlp_splitk_matches_torch(M, C, gpu):
     _close(t.grad, td.grad, 2e-2, "dt")
     for got, ref, n in ((w1.grad, ps[0].grad, "dw1"), (b1.grad, ps[1].grad, "db1"), (w2.grad, ps[2].grad, "dw2"), (b2.grad, ps[3].grad, "db2")):
         _close(got, ref, 2e-2, n)
+
+
+def test_lowp_weight_cache_follows_optimizer_and_mask_updates(gpu):
+    """block_ops.cache_lowp_weights: the bf16 copies of the Linear weights must follow in-place updates that bump the tensor
+    version (optimizer steps, torch._C._increment_version after the mask kernels) -- refreshed in one multi-tensor copy."""
+    from slak_amd import block_ops
+    torch.manual_seed(3)
+    w1 = torch.nn.Parameter(torch.randn(64, 16, device=gpu) * 0.1); b1 = torch.nn.Parameter(torch.zeros(64, device=gpu))
+    w2 = torch.nn.Parameter(torch.randn(16, 64, device=gpu) * 0.1); b2 = torch.nn.Parameter(torch.zeros(16, device=gpu))
+    t = torch.randn(2, 7, 7, 16, device=gpu).bfloat16()
+    block_ops.cache_lowp_weights = True
+    try:
+        z0 = block_ops.mlp_splitk(t, w1, b1, w2, b2)
+        with torch.no_grad():
+            w1.mul_(2.0); b2.add_(1.0)                         # what an optimizer step does
+        z1 = block_ops.mlp_splitk(t, w1, b1, w2, b2)
+        block_ops.cache_lowp_weights = False
+        z1_ref = block_ops.mlp_splitk(t, w1, b1, w2, b2)
+        assert torch.equal(z1, z1_ref) and not torch.equal(z0, z1)
+    finally:
+        block_ops.cache_lowp_weights = False
