@@ -172,6 +172,35 @@ __global__ __launch_bounds__(BT_THREADS) void ln_nchw_to_nhwc_bwd_pix_kernel(con
     __syncthreads();
     // dx: lanes along pixels (4 pixels per thread when rows are 8-byte aligned)
     uint16_t* dxn = dx + (size_t)n * C * P;
+    float* pt = part + (size_t)blockIdx.x * 2 * C;
+    if ((P & 3) == 0 && TP == 64) {
+        // thread <-> (4 pixels qq..qq+3, channels c0, c0+16, ...): its pixel statistics are loop constants, and the per-channel
+        // partials (sum_p g*xhat, sum_p g) are folded from the values it has in hand, reduced over the 16 lanes that share a channel
+        const int qq = (tid & 15) * 4, c0 = tid >> 4;
+        float mu[4], r[4], m1[4], m2[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { mu[e] = st[qq + e]; r[e] = st[TP + qq + e]; m1[e] = st[2 * TP + qq + e]; m2[e] = st[3 * TP + qq + e]; }
+        const bool live = p0 + qq < P;
+        for (int c = c0; c < C; c += BT_THREADS / 16) {
+            const float wc = w[c];
+            float o[4], a = 0.f, b = 0.f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float gv = bf2f(gs[(qq + e) * gp + c]);                    // padding pixels hold g == 0
+                const float xh = (bf2f(xs[c * xp + qq + e]) - mu[e]) * r[e];
+                o[e] = r[e] * (gv * wc - m1[e] - xh * m2[e]);
+                a += gv * xh; b += gv;
+            }
+            if (live) {
+                unsigned* dst = (unsigned*)(dxn + (size_t)c * P + p0 + qq);
+                dst[0] = bt_pack2(o[0], o[1]); dst[1] = bt_pack2(o[2], o[3]);
+            }
+#pragma unroll
+            for (int m = 1; m < 16; m <<= 1) { a += __shfl_xor(a, m, 16); b += __shfl_xor(b, m, 16); }
+            if ((tid & 15) == 0) { pt[c] = a; pt[C + c] = b; }
+        }
+        return;
+    }
     if ((P & 3) == 0) {
         const int cpr = TP / 4;
         for (int idx = tid; idx < C * cpr; idx += BT_THREADS) {
@@ -200,7 +229,6 @@ __global__ __launch_bounds__(BT_THREADS) void ln_nchw_to_nhwc_bwd_pix_kernel(con
         }
     }
     // per-channel partials over the tile's pixels (padding pixels have g == 0)
-    float* pt = part + (size_t)blockIdx.x * 2 * C;
     for (int c = tid; c < C; c += BT_THREADS) {
         float a = 0.f, bsum = 0.f;
         for (int qq = 0; qq < TP; ++qq) {
@@ -760,11 +788,24 @@ static int reduce_partials(const float* part, float* tmp, float* out0, float* ou
 
 // tile width: the largest of {128,64,32,16} pixels whose tile (elem_bytes per element) fits lds_budget, not (much) wider than an image
 static TailDims make_dims(int N, int C, int P, int elem_bytes, size_t lds_budget = 50 * 1024) {
+    // tile width: the persistent kernels want (i) little padding in the last tile of an image (P = 196: 64-pixel tiles waste 31 %),
+    // (ii) enough tiles to keep ~4 workgroups per CU busy, (iii) then the widest tile that fits the LDS budget
     TailDims d; d.N = N; d.C = C; d.P = P;
-    int TP = 128;
-    while (TP > 16 && ((size_t)C * (TP + 2) * elem_bytes > lds_budget || TP / 2 >= P)) TP /= 2;
-    d.TP = TP;
-    d.tiles_per_image = (P + TP - 1) / TP;
+    static const int cand[] = {128, 64, 56, 48, 40, 32, 28, 24, 20, 16, 12, 8};
+    static const char* ov = getenv("SLAK_TAIL_TP");
+    int best = 16; double best_score = -1e30;
+    for (int TP : cand) {
+        if (TP > 16 && (size_t)C * (TP + 2) * elem_bytes > lds_budget) continue;
+        if (TP > 16 && TP / 2 >= P) continue;
+        const int tiles = (P + TP - 1) / TP;
+        const double waste = (double)tiles * TP / P - 1.0;
+        const double fill = (double)N * tiles / 1024.0;                  // tiles per "4 workgroups per CU"
+        const double score = -4.0 * waste + (fill < 1.0 ? fill - 1.0 : 0.0) + 0.001 * TP;
+        if (score > best_score) { best_score = score; best = TP; }
+    }
+    if (ov && atoi(ov) > 0) best = atoi(ov);
+    d.TP = best;
+    d.tiles_per_image = (P + d.TP - 1) / d.TP;
     d.ntiles = N * d.tiles_per_image;
     return d;
 }
