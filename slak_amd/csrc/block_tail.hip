@@ -33,6 +33,16 @@ __device__ __forceinline__ float bt_wave_sum(float v) {
     return v;
 }
 
+// sum over the 16 lanes of a DPP row, valid in the row's LAST lane (i & 15 == 15): four v_add_f32 with a row_shr operand, no LDS
+// crossbar (the wave-wide __shfl_xor reduction is a ds_bpermute + address arithmetic per step)
+__device__ __forceinline__ float bt_row16_sum(float v) {
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x111, 0xf, 0xf, true));   // row_shr:1
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x112, 0xf, 0xf, true));   // row_shr:2
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x114, 0xf, 0xf, true));   // row_shr:4
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x118, 0xf, 0xf, true));   // row_shr:8
+    return v;
+}
+
 // stage x[n, :, p0:p0+TP] (NCHW, bf16) into xs[C][TP+2]; pixels beyond P are zero
 __device__ __forceinline__ void load_nchw_tile(uint16_t* xs, const uint16_t* __restrict__ xn, int C, int P, int p0, int TP, int tid) {
     const int pitch = TP + 2;
@@ -590,99 +600,84 @@ template <typename Tout> __device__ __forceinline__ void cf_store(Tout* p, float
 template <> __device__ __forceinline__ void cf_store<float>(float* p, float v) { *p = v; }
 template <> __device__ __forceinline__ void cf_store<bf16_t>(bf16_t* p, float v) { p->v = bt_f2bf(v); }
 
-// one workgroup per (image, 64-pixel tile); tile staged as fp32 [C][65]; thread <-> (pixel, channel group)
+// No transposition is involved here (NCHW in, NCHW out), so nothing is staged: a lane owns ONE pixel and walks the channels with
+// coalesced 4-byte loads (256 B per wave and channel), statistics in registers, and the second pass re-reads the tile (L2 / MALL).
+// The earlier LDS-tile version spent its time in per-element index arithmetic and a serial per-channel tail (3-5x the HBM time).
+// pixels per workgroup = blockDim.x: 256, or 64 when that leaves too few workgroups (P = 196: one partial workgroup per image)
+
 template <typename Tin, typename Tout>
 __global__ __launch_bounds__(BT_THREADS) void ln_cf_fwd_kernel(const Tin* __restrict__ x, const float* __restrict__ w, const float* __restrict__ b,
                                                              Tout* __restrict__ y, float* __restrict__ mean, float* __restrict__ rstd,
-                                                             const TailDims d, float eps) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int C = d.C, P = d.P, TP = d.TP, pitch = TP + 1;
-    float* xs = (float*)smem;                                              // [C][TP+1]
-    float* red = xs + (size_t)C * pitch;                                   // [NG][TP]
-    float* st = red + (BT_THREADS / TP) * TP;                              // [2][TP]
-    const int tid = threadIdx.x;
-    const int n = blockIdx.x / d.tiles_per_image, p0 = (blockIdx.x % d.tiles_per_image) * TP;
-    const Tin* xn = x + (size_t)n * C * P;
-    for (int idx = tid; idx < C * TP; idx += BT_THREADS) {
-        const int c = idx / TP, q = idx - c * TP;
-        xs[c * pitch + q] = (p0 + q < P) ? cf_load(xn + (size_t)c * P + p0 + q) : 0.f;
+                                                             int C, int P, int tiles_per_image, float eps) {
+    const int n = blockIdx.x / tiles_per_image, p = (blockIdx.x - n * tiles_per_image) * (int)blockDim.x + threadIdx.x;
+    if (p >= P) return;
+    const Tin* xp = x + (size_t)n * C * P + p;
+    // one pass, Welford's update (as accurate as the reference's two-pass (x - u)^2 form; 1/(c+1) is wave-uniform)
+    float mu = 0.f, m2 = 0.f;
+#pragma unroll 8
+    for (int c = 0; c < C; ++c) {
+        const float v = cf_load(xp + (size_t)c * P), d0 = v - mu;
+        mu += d0 * (1.0f / (float)(c + 1));
+        m2 += d0 * (v - mu);
     }
-    __syncthreads();
-    const int q = tid % TP, g = tid / TP, NG = BT_THREADS / TP;
-    float s = 0.f;
-    for (int c = g; c < C; c += NG) s += xs[c * pitch + q];
-    red[g * TP + q] = s;
-    __syncthreads();
-    if (g == 0) { float t = 0.f; for (int k = 0; k < NG; ++k) t += red[k * TP + q]; st[q] = t / (float)C; }
-    __syncthreads();
-    const float mu = st[q];
-    float ss = 0.f;
-    for (int c = g; c < C; c += NG) { const float v = xs[c * pitch + q] - mu; ss += v * v; }
-    __syncthreads();
-    red[g * TP + q] = ss;
-    __syncthreads();
-    if (g == 0) {
-        float t = 0.f; for (int k = 0; k < NG; ++k) t += red[k * TP + q];
-        const float r = 1.0f / sqrtf(t / (float)C + eps);
-        st[TP + q] = r;
-        if (p0 + q < P) { mean[(size_t)n * P + p0 + q] = mu; rstd[(size_t)n * P + p0 + q] = r; }
-    }
-    __syncthreads();
-    Tout* yn = y + (size_t)n * C * P;
-    for (int idx = tid; idx < C * TP; idx += BT_THREADS) {
-        const int c = idx / TP, qq = idx - c * TP;
-        if (p0 + qq < P) cf_store(yn + (size_t)c * P + p0 + qq, (xs[c * pitch + qq] - st[qq]) * st[TP + qq] * w[c] + b[c]);
-    }
+    const float r = 1.0f / sqrtf(m2 / (float)C + eps);
+    mean[(size_t)n * P + p] = mu; rstd[(size_t)n * P + p] = r;
+    Tout* yp = y + (size_t)n * C * P + p;
+#pragma unroll 8
+    for (int c = 0; c < C; ++c) cf_store(yp + (size_t)c * P, (cf_load(xp + (size_t)c * P) - mu) * r * w[c] + b[c]);
 }
 
-// dx from g (same NCHW layout); per-tile partials part[tile][0][c] = sum g*xhat, part[tile][1][c] = sum g
-template <typename Tin, typename Tg>
+// dx from g (same NCHW layout); per-workgroup partials part[wg][0][c] = sum g*xhat, part[wg][1][c] = sum g.
+// CSPLIT: the workgroup's four waves share ONE 64-pixel tile and split the channels (few pixels, many channels: P = 196, C = 384
+// would otherwise leave two long-running waves per CU); their per-pixel sums meet in LDS.
+template <typename Tin, typename Tg, bool CSPLIT>
 __global__ __launch_bounds__(BT_THREADS) void ln_cf_bwd_kernel(const Tg* __restrict__ g, const Tin* __restrict__ x, const float* __restrict__ w,
                                                              const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                             Tin* __restrict__ dx, float* __restrict__ part, const TailDims d) {
+                                                             Tin* __restrict__ dx, float* __restrict__ part, int C, int P, int tiles_per_image) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int C = d.C, P = d.P, TP = d.TP, pitch = TP + 1;
-    float* xh = (float*)smem;                                              // [C][TP+1]  xhat
-    float* gs = xh + (size_t)C * pitch;                                    // [C][TP+1]  g
-    float* red = gs + (size_t)C * pitch;                                   // [2][NG][TP]
-    float* st = red + 2 * (BT_THREADS / TP) * TP;                          // [3][TP]: rstd, m1, m2
-    const int tid = threadIdx.x;
-    const int n = blockIdx.x / d.tiles_per_image, p0 = (blockIdx.x % d.tiles_per_image) * TP;
-    const Tin* xn = x + (size_t)n * C * P;
-    const Tg* gn = g + (size_t)n * C * P;
-    for (int idx = tid; idx < C * TP; idx += BT_THREADS) {
-        const int c = idx / TP, q = idx - c * TP;
-        const bool ok = p0 + q < P;
-        const float mu = ok ? mean[(size_t)n * P + p0 + q] : 0.f, r = ok ? rstd[(size_t)n * P + p0 + q] : 0.f;
-        xh[c * pitch + q] = ok ? (cf_load(xn + (size_t)c * P + p0 + q) - mu) * r : 0.f;
-        gs[c * pitch + q] = ok ? cf_load(gn + (size_t)c * P + p0 + q) : 0.f;
+    float* red = (float*)smem;                                             // [16 rows of 16 lanes][2][C] (CSPLIT: [4 rows][2][C])
+    float* psum = red + (size_t)(BT_THREADS / 16) * 2 * C;                 // CSPLIT: [4 waves][2][64]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int pix = CSPLIT ? 64 : BT_THREADS;
+    const int n = blockIdx.x / tiles_per_image, p = (blockIdx.x - n * tiles_per_image) * pix + (CSPLIT ? lane : tid);
+    const bool ok = p < P;
+    const size_t base = (size_t)n * C * P + (ok ? p : 0);
+    const Tin* xp = x + base; const Tg* gp = g + base;
+    const float mu = ok ? mean[(size_t)n * P + p] : 0.f, r = ok ? rstd[(size_t)n * P + p] : 0.f;
+    const int cq = (C + 3) / 4;
+    const int c_lo = CSPLIT ? wave * cq : 0;
+    int c_hi = CSPLIT ? c_lo + cq : C; if (c_hi > C) c_hi = C;
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll 8
+    for (int c = c_lo; c < c_hi; ++c) {
+        const float gw = cf_load(gp + (size_t)c * P) * w[c];
+        s1 += gw; s2 += gw * ((cf_load(xp + (size_t)c * P) - mu) * r);
     }
-    if (tid < TP) st[tid] = (p0 + tid < P) ? rstd[(size_t)n * P + p0 + tid] : 0.f;
+    if constexpr (CSPLIT) {
+        psum[(wave * 2 + 0) * 64 + lane] = s1; psum[(wave * 2 + 1) * 64 + lane] = s2;
+        __syncthreads();
+        s1 = (psum[0 * 64 + lane] + psum[2 * 64 + lane]) + (psum[4 * 64 + lane] + psum[6 * 64 + lane]);
+        s2 = (psum[1 * 64 + lane] + psum[3 * 64 + lane]) + (psum[5 * 64 + lane] + psum[7 * 64 + lane]);
+    }
+    const float m1 = s1 / (float)C, m2 = s2 / (float)C;
+    Tin* dxp = dx + base;
+    const int row = CSPLIT ? (lane >> 4) : (tid >> 4);                     // CSPLIT: a channel belongs to one wave: 4 rows per channel
+#pragma unroll 4
+    for (int c = c_lo; c < c_hi; ++c) {
+        const float gv = ok ? cf_load(gp + (size_t)c * P) : 0.f;          // lanes beyond the image contribute nothing
+        const float xh = (cf_load(xp + (size_t)c * P) - mu) * r;
+        if (ok) cf_store(dxp + (size_t)c * P, r * (gv * w[c] - m1 - xh * m2));
+        const float a = bt_row16_sum(gv * xh), bs = bt_row16_sum(gv);     // per 16-lane row; the rows are added below
+        if ((lane & 15) == 15) { red[(row * 2 + 0) * C + c] = a; red[(row * 2 + 1) * C + c] = bs; }
+    }
     __syncthreads();
-    const int q = tid % TP, grp = tid / TP, NG = BT_THREADS / TP;
-    {
-        float s1 = 0.f, s2 = 0.f;
-        for (int c = grp; c < C; c += NG) { const float gw = gs[c * pitch + q] * w[c]; s1 += gw; s2 += gw * xh[c * pitch + q]; }
-        red[grp * TP + q] = s1; red[(NG + grp) * TP + q] = s2;
-    }
-    __syncthreads();
-    if (grp == 0) {
-        float t1 = 0.f, t2 = 0.f;
-        for (int k = 0; k < NG; ++k) { t1 += red[k * TP + q]; t2 += red[(NG + k) * TP + q]; }
-        st[TP + q] = t1 / (float)C; st[2 * TP + q] = t2 / (float)C;
-    }
-    __syncthreads();
-    Tin* dxn = dx + (size_t)n * C * P;
-    for (int idx = tid; idx < C * TP; idx += BT_THREADS) {
-        const int c = idx / TP, qq = idx - c * TP;
-        if (p0 + qq < P)
-            cf_store(dxn + (size_t)c * P + p0 + qq, st[qq] * (gs[c * pitch + qq] * w[c] - st[TP + qq] - xh[c * pitch + qq] * st[2 * TP + qq]));
-    }
     float* pt = part + (size_t)blockIdx.x * 2 * C;
-    for (int c = tid; c < C; c += BT_THREADS) {
-        float a = 0.f, bsum = 0.f;
-        for (int qq = 0; qq < TP; ++qq) { const float gv = gs[c * pitch + qq]; a += gv * xh[c * pitch + qq]; bsum += gv; }
-        pt[c] = a; pt[C + c] = bsum;
+    const int nrows = CSPLIT ? 4 : BT_THREADS / 16;
+    for (int i = tid; i < 2 * C; i += BT_THREADS) {
+        const int h = i / C, c = i - h * C;
+        float t = 0.f;
+        for (int k = 0; k < nrows; ++k) t += red[(k * 2 + h) * C + c];
+        pt[i] = t;
     }
 }
 
@@ -966,18 +961,12 @@ int slak_scale_residual_backward(const float* dout, const void* dout_bf16, float
     return reduce_partials(part, part + (size_t)grid * 2 * C, dgamma, dz_colsum, C, grid, 2 * C, (hipStream_t)stream);
 }
 
-static TailDims make_dims_cf(int N, int C, int P, int tiles_of_fp32) {
-    TailDims d; d.N = N; d.C = C; d.P = P;
-    int TP = 64;
-    while (TP > 8 && (size_t)tiles_of_fp32 * C * (TP + 1) * 4 > 56 * 1024) TP /= 2;
-    d.TP = TP; d.tiles_per_image = (P + TP - 1) / TP; d.ntiles = N * d.tiles_per_image;
-    return d;
-}
+static int cf_block(int N, int P) { return (long long)N * ((P + BT_THREADS - 1) / BT_THREADS) >= 1024 ? BT_THREADS : 64; }
+static int cf_tiles(int N, int P) { const int b = cf_block(N, P); return (P + b - 1) / b; }
 
 size_t slak_ln_cf_workspace_bytes(int N, int C, int P) {
     if (N <= 0 || C <= 0 || P <= 0) return 0;
-    const TailDims d = make_dims_cf(N, C, P, 2);
-    return align_up(((size_t)d.ntiles + BT_SLICES) * 2 * C * sizeof(float), 256);
+    return align_up(((size_t)N * cf_tiles(N, P) + BT_SLICES) * 2 * C * sizeof(float), 256);
 }
 
 int slak_ln_channels_first_forward(const void* x, int x_dtype, const float* weight, const float* bias, void* y, int y_dtype,
@@ -985,13 +974,11 @@ int slak_ln_channels_first_forward(const void* x, int x_dtype, const float* weig
     if (!x || !weight || !bias || !y || !mean || !rstd) return SLAK_ERR_INVALID_ARG;
     if (N <= 0 || C <= 0 || P <= 0) return SLAK_ERR_INVALID_ARG;
     if (C > 1024 || (long long)N * C * P >= (1LL << 31)) return SLAK_ERR_UNSUPPORTED;
-    const TailDims d = make_dims_cf(N, C, P, 1);
-    const size_t lds = (size_t)C * (d.TP + 1) * 4 + (size_t)(BT_THREADS / d.TP) * d.TP * 4 + 2 * d.TP * 4 + 16;
-    const dim3 grid((unsigned)d.ntiles);
+    const int tpi = cf_tiles(N, P), blk = cf_block(N, P);
+    const dim3 grid((unsigned)(N * tpi));
 #define SLAK_CF_FWD(TI, TO)                                                                                                   \
-    do { if (set_lds((const void*)ln_cf_fwd_kernel<TI, TO>, lds)) return SLAK_ERR_LAUNCH;                                     \
-         hipLaunchKernelGGL((ln_cf_fwd_kernel<TI, TO>), grid, dim3(BT_THREADS), lds, (hipStream_t)stream, (const TI*)x, weight, bias,  \
-                            (TO*)y, mean, rstd, d, eps); } while (0)
+    hipLaunchKernelGGL((ln_cf_fwd_kernel<TI, TO>), grid, dim3(blk), 0, (hipStream_t)stream, (const TI*)x, weight, bias,   \
+                       (TO*)y, mean, rstd, C, P, tpi, eps)
     if (x_dtype == SLAK_F32 && y_dtype == SLAK_F32) SLAK_CF_FWD(float, float);
     else if (x_dtype == SLAK_F32 && y_dtype == SLAK_BF16) SLAK_CF_FWD(float, bf16_t);
     else if (x_dtype == SLAK_BF16 && y_dtype == SLAK_F32) SLAK_CF_FWD(bf16_t, float);
@@ -1009,14 +996,18 @@ int slak_ln_channels_first_backward(const void* g, int g_dtype, const void* x, i
     if (N <= 0 || C <= 0 || P <= 0) return SLAK_ERR_INVALID_ARG;
     if (C > 1024 || (long long)N * C * P >= (1LL << 31)) return SLAK_ERR_UNSUPPORTED;
     if (!workspace || workspace_bytes < slak_ln_cf_workspace_bytes(N, C, P)) return SLAK_ERR_WORKSPACE;
-    const TailDims d = make_dims_cf(N, C, P, 2);
-    const size_t lds = (size_t)2 * C * (d.TP + 1) * 4 + (size_t)2 * (BT_THREADS / d.TP) * d.TP * 4 + 3 * d.TP * 4 + 16;
-    const dim3 grid((unsigned)d.ntiles);
+    const bool csplit = cf_block(N, P) == 64;                      // few pixels per image: 64-pixel tiles, waves split the channels
+    const int tpi = csplit ? (P + 63) / 64 : cf_tiles(N, P), nwg = N * tpi;
+    const size_t lds = (size_t)(BT_THREADS / 16) * 2 * C * 4 + 8 * 64 * 4 + 16;
+    const dim3 grid((unsigned)nwg);
     float* part = (float*)workspace;
 #define SLAK_CF_BWD(TI, TG)                                                                                                   \
-    do { if (set_lds((const void*)ln_cf_bwd_kernel<TI, TG>, lds)) return SLAK_ERR_LAUNCH;                                     \
-         hipLaunchKernelGGL((ln_cf_bwd_kernel<TI, TG>), grid, dim3(BT_THREADS), lds, (hipStream_t)stream, (const TG*)g, (const TI*)x, weight, \
-                            mean, rstd, (TI*)dx, part, d); } while (0)
+    do { if (csplit) { if (set_lds((const void*)ln_cf_bwd_kernel<TI, TG, true>, lds)) return SLAK_ERR_LAUNCH;                 \
+                       hipLaunchKernelGGL((ln_cf_bwd_kernel<TI, TG, true>), grid, dim3(BT_THREADS), lds, (hipStream_t)stream, (const TG*)g, \
+                                          (const TI*)x, weight, mean, rstd, (TI*)dx, part, C, P, tpi); }                       \
+         else { if (set_lds((const void*)ln_cf_bwd_kernel<TI, TG, false>, lds)) return SLAK_ERR_LAUNCH;                        \
+                hipLaunchKernelGGL((ln_cf_bwd_kernel<TI, TG, false>), grid, dim3(BT_THREADS), lds, (hipStream_t)stream, (const TG*)g, \
+                                   (const TI*)x, weight, mean, rstd, (TI*)dx, part, C, P, tpi); } } while (0)
     if (x_dtype == SLAK_F32 && g_dtype == SLAK_F32) SLAK_CF_BWD(float, float);
     else if (x_dtype == SLAK_F32 && g_dtype == SLAK_BF16) SLAK_CF_BWD(float, bf16_t);
     else if (x_dtype == SLAK_BF16 && g_dtype == SLAK_F32) SLAK_CF_BWD(bf16_t, float);
@@ -1024,7 +1015,7 @@ int slak_ln_channels_first_backward(const void* g, int g_dtype, const void* x, i
     else return SLAK_ERR_UNSUPPORTED;
 #undef SLAK_CF_BWD
     SLAK_LAUNCH_CHECK();
-    return reduce_partials(part, part + (size_t)d.ntiles * 2 * C, dweight, dbias, C, d.ntiles, 2 * C, (hipStream_t)stream);
+    return reduce_partials(part, part + (size_t)nwg * 2 * C, dweight, dbias, C, nwg, 2 * C, (hipStream_t)stream);
 }
 
 /* dy1 = dact * gelu'(y1), dbias[col] = sum_rows dy1 (fp32).  workspace >= slak_gelu_bwd_workspace_bytes(rows, cols). */
