@@ -332,13 +332,13 @@ class Masking(object):
         """The kernels write the weights through raw pointers; tell autograd (and anything that caches by tensor version, e.g. the
         bf16 weight copies of slak_amd.block_ops) that they changed."""
         inc = getattr(torch._C, "_increment_version", None)
-        if inc is None:
+        if inc is None or not params:
             return
-        for p in params:
-            try:
+        try:
+            inc(list(params))                  # torch >= 2.4: an iterable of tensors (a bare tensor would be ITERATED: unbind per row)
+        except TypeError:
+            for p in params:                   # older torch: one tensor per call
                 inc(p)
-            except (TypeError, RuntimeError):
-                inc([p])
 
     def truncate_weights(self):
         params = self._ensure_plan()

@@ -49,6 +49,40 @@ def _worker(rank, world, port, out):
     loss.backward()
     opt.step()
     res["w"] = {k: v.detach().float().cpu() for k, v in blk.state_dict().items()}
+    # the bench's N > 1 configuration in miniature: whole (narrow) SLaK under DDP with every fused op, the bf16 hand-off between
+    # blocks, cached bf16 weights and Masking prune-and-grow: ranks must stay bit-identical (weights and masks)
+    import types, contextlib, io
+    from slak_amd.sparse_core import CosineDecay, Masking
+    from slak_amd import block_ops as B
+    M.LayerNorm.fused_cf = True
+    B.cache_lowp_weights = True
+    torch.manual_seed(7)
+    net = M.SLaK(in_chans=3, num_classes=10, depths=[2, 2, 2, 1], dims=[16, 32, 64, 128], drop_path_rate=0.0,
+                 kernel_size=[13, 13, 9, 7, 5], Decom=True, bn=True, lowp_dwconv=True).to(dev)
+    ddp2 = nn.parallel.DistributedDataParallel(net, device_ids=[0])
+    opt2 = torch.optim.AdamW(ddp2.parameters(), lr=1e-3, fused=True)
+    margs = types.SimpleNamespace(device=str(dev), fix=False, update_frequency=2, only_L=False, sparse_init="uniform", sparsity=0.4,
+                                  distributed=True)
+    with contextlib.redirect_stdout(io.StringIO()):
+        mask = Masking(opt2, None, CosineDecay(0.3, 100), prune_rate=0.3, prune_mode="magnitude", growth_mode="gradient",
+                       redistribution_mode="none", args=margs)
+        mask.add_module(ddp2)
+    g = torch.Generator(device=dev).manual_seed(100 + rank)
+    xs = torch.randn(4, 3, 64, 64, device=dev, generator=g); ys = torch.randint(0, 10, (4,), device=dev, generator=g)
+    for _ in range(5):
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            loss2 = nn.functional.cross_entropy(ddp2(xs), ys)
+        loss2.backward()
+        with contextlib.redirect_stdout(io.StringIO()):
+            mask.step()
+        opt2.zero_grad(set_to_none=True)
+    assert torch.isfinite(loss2).item()
+    flat = torch.cat([p.detach().float().flatten() for p in net.parameters()] + [m.flatten() for m in mask.masks.values()])
+    other = [torch.empty_like(flat) for _ in range(world)]
+    dist.all_gather(other, flat)
+    res["ranks_identical"] = bool(torch.equal(other[0], other[1]))
+    res["mask_density"] = float(torch.cat([m.flatten() for m in mask.masks.values()]).mean().item())
+    M.LayerNorm.fused_cf = False; B.cache_lowp_weights = False
     if rank == 0:
         torch.save(res, out)
     dist.barrier()
@@ -61,6 +95,8 @@ def test_two_ranks_match_single_process(gpu, tmp_path):
     out = str(tmp_path / "r0.pt")
     mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
     got = torch.load(out)
+    assert got["ranks_identical"], "ranks diverged (weights or masks) after DDP + Masking steps"
+    assert 0.55 <= got["mask_density"] <= 0.65, got["mask_density"]
     # single process, full batch
     from slak_amd import block_ops
     import slak_amd.slak_model as M
