@@ -62,6 +62,7 @@ SHAPES = [
     (2, 130, 14, 14, 5, 5), (3, 2, 18, 20, 5, 21), (3, 2, 20, 24, 21, 5),
     # wave-independent 14x14-class kernels: single image / odd batch tails, ragged channel blocks, non-square planes, overlapping row halves
     (1, 1, 14, 14, 47, 5), (1, 1, 14, 14, 5, 47), (6, 4, 10, 12, 5, 9), (6, 4, 12, 10, 9, 5), (4, 2, 14, 8, 5, 7), (9, 7, 8, 14, 5, 5),
+    (5, 3, 12, 16, 5, 13), (5, 3, 16, 12, 13, 5), (3, 9, 14, 16, 5, 31),
     # vertical weight gradient by row reads + shifted copy: first and last chunk of the tensor, non-square planes, narrow planes
     (3, 2, 56, 56, 51, 5), (1, 1, 40, 48, 31, 5), (2, 2, 64, 16, 51, 5), (2, 3, 36, 24, 35, 5),
 ]
