@@ -69,6 +69,7 @@ def parse():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--kernel-reps", type=int, default=30)
     ap.add_argument("--fp32-dwconv", action="store_true", help="reference dtype flow: dw convs see fp32 even under autocast")
+    ap.add_argument("--no-fused-tri", action="store_true", help="run the three branch convolutions as three autograd nodes (one launch each)")
     ap.add_argument("--no-fused-bn", action="store_true", help="run the three branch BatchNorms + adds as the reference's PyTorch modules")
     ap.add_argument("--no-fused-tail", action="store_true", help="run the block tail (permute/LayerNorm/gamma/residual) as the reference's PyTorch ops")
     return ap.parse_args()
@@ -194,6 +195,7 @@ def main():
     M.Block.fused_tail = not a.no_fused_tail and not a.fp32_dwconv    # HIP glue kernels around the pointwise GEMMs
     M.ReparamLargeKernelConv.fused_bn = not a.no_fused_bn and not a.fp32_dwconv   # branch BatchNorms + adds as one HIP op
     M.LayerNorm.fused_cf = not a.no_fused_tail                     # channels_first LayerNorm of stem/downsample as one HIP kernel
+    M.ReparamLargeKernelConv.fused_tri = M.ReparamLargeKernelConv.fused_bn and not a.no_fused_tri   # three branch convs as one autograd node
     from slak_amd import block_ops
     block_ops.cache_lowp_weights = True                            # bf16 weight copies refreshed by one multi-tensor launch per step
     M.use_sync_bn = True                                          # reference default (models/SLaK.py:19); falls back to BN math at world 1

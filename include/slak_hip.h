@@ -113,6 +113,18 @@ int slak_mask_read_stats(slak_mask_plan_t* plan, double* out_host, void* stream)
 /* 64-bit order-independent checksum of all masks (for cross-rank agreement checks); synchronises. */
 int slak_mask_checksum(slak_mask_plan_t* plan, unsigned long long* out_host, void* stream);
 
+/* ---- next row: the three branches of one decomposed large-kernel block in ONE launch ----------------------------
+ * ReparamLargeKernelConv.forward runs LoRA1 (K x 5), LoRA2 (5 x K) and small_conv (5 x 5) on the same input (models/SLaK.py:82-100).
+ * forward: x is read once for the three outputs; backward_data: the three partial input gradients are summed in the accumulator
+ * (autograd would add them with two elementwise passes).  16-bit tensors (dtype = SLAK_BF16 / SLAK_F16), fp32 filters
+ * (C,1,K,5), (C,1,5,K), (C,1,5,5); currently the 14x14 class only (W even, 8 <= W <= 14, H <= 14): anything else returns
+ * SLAK_ERR_UNSUPPORTED and the caller issues the three slak_dwconv2d_* calls instead. */
+int slak_dwconv2d_tri_supported(int dtype, int N, int C, int H, int W, int K);
+int slak_dwconv2d_tri_forward(const void* x, const float* w_v, const float* w_h, const float* w_s, void* y_v, void* y_h, void* y_s,
+                              int dtype, int N, int C, int H, int W, int K, void* stream);
+int slak_dwconv2d_tri_backward_data(const void* dy_v, const void* dy_h, const void* dy_s, const float* w_v, const float* w_h,
+                                    const float* w_s, void* dx, int dtype, int N, int C, int H, int W, int K, void* stream);
+
 /* ---------------------------------------------------------------- next row: block tail glue
  * The layout / normalisation / residual steps around the two pointwise GEMMs of a SLaK block
  * (models/SLaK.py:153-166: permute -> LayerNorm -> [pwconv1, GELU, pwconv2] -> gamma -> permute -> shortcut + drop_path),

@@ -61,6 +61,9 @@ SIGNATURES = {
     "slak_ln_channels_first_backward": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _sz, _vp]),
     "slak_ln_nchw_to_nhwc_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, ctypes.c_float, _vp]),
     "slak_ln_nchw_to_nhwc_backward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _sz, _vp]),
+    "slak_dwconv2d_tri_supported": (_i, [_i, _i, _i, _i, _i, _i]),
+    "slak_dwconv2d_tri_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "slak_dwconv2d_tri_backward_data": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "slak_scale_residual_forward": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "slak_scale_residual_backward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _sz, _vp]),
 }

@@ -111,6 +111,67 @@ class _ScaleResidual(torch.autograd.Function):
         return dshortcut, dz, dgamma, None, None
 
 
+class _TriDwConv(torch.autograd.Function):
+    """The three branch convolutions of a decomposed large-kernel block -- LoRA1 (K x 5), LoRA2 (5 x K), small_conv (5 x 5) on the
+    same input (models/SLaK.py:82-100) -- as one autograd node.  Where the one-launch kernels exist (slak_dwconv2d_tri_*: the 14x14
+    class) the input is read once forward and the three input gradients are summed in the accumulator; elsewhere the three
+    per-branch kernels run and the gradients are added here.  Weight gradients always come from the per-branch kernels."""
+
+    @staticmethod
+    def forward(ctx, x, wv, wh, ws):
+        from . import ops
+        _chk(x, "input")
+        N, C, H, W = x.shape
+        K = wv.shape[2]
+        if wv.shape != (C, 1, K, 5) or wh.shape != (C, 1, 5, K) or ws.shape != (C, 1, 5, 5):
+            raise RuntimeError("tri_dwconv expects filters (C,1,K,5), (C,1,5,K), (C,1,5,5)")
+        L = _lib.lib()
+        dt = ops._DT.get(x.dtype)
+        tri = (dt is not None and all(w.dtype == torch.float32 and w.is_contiguous() for w in (wv, wh, ws))
+               and bool(L.slak_dwconv2d_tri_supported(dt, N, C, H, W, K)))
+        if tri:
+            yv, yh, ys = torch.empty_like(x), torch.empty_like(x), torch.empty_like(x)
+            with torch.cuda.device(x.device):
+                _lib.check(L.slak_dwconv2d_tri_forward(x.data_ptr(), wv.data_ptr(), wh.data_ptr(), ws.data_ptr(), yv.data_ptr(),
+                                                       yh.data_ptr(), ys.data_ptr(), dt, N, C, H, W, K, _stream(x.device)),
+                           "slak_dwconv2d_tri_forward")
+        else:
+            yv, yh, ys = ops.dwconv2d_forward(x, wv), ops.dwconv2d_forward(x, wh), ops.dwconv2d_forward(x, ws)
+        ctx.save_for_backward(x, wv, wh, ws)
+        ctx.tri = tri
+        return yv, yh, ys
+
+    @staticmethod
+    def backward(ctx, dyv, dyh, dys):
+        from . import ops
+        x, wv, wh, ws = ctx.saved_tensors
+        N, C, H, W = x.shape
+        K = wv.shape[2]
+        dyv, dyh, dys = (g.contiguous() if g.dtype == x.dtype else g.to(x.dtype).contiguous() for g in (dyv, dyh, dys))
+        dx = None
+        if ctx.needs_input_grad[0]:
+            if ctx.tri:
+                dx = torch.empty_like(x)
+                L = _lib.lib()
+                with torch.cuda.device(x.device):
+                    _lib.check(L.slak_dwconv2d_tri_backward_data(dyv.data_ptr(), dyh.data_ptr(), dys.data_ptr(), wv.data_ptr(),
+                                                                 wh.data_ptr(), ws.data_ptr(), dx.data_ptr(), ops._DT[x.dtype],
+                                                                 N, C, H, W, K, _stream(x.device)), "slak_dwconv2d_tri_backward_data")
+            else:
+                dx = ops.dwconv2d_backward_data(dyv, wv)
+                dx += ops.dwconv2d_backward_data(dyh, wh)
+                dx += ops.dwconv2d_backward_data(dys, ws)
+        dwv = ops.dwconv2d_backward_filter(dyv, x, wv) if ctx.needs_input_grad[1] else None
+        dwh = ops.dwconv2d_backward_filter(dyh, x, wh) if ctx.needs_input_grad[2] else None
+        dws = ops.dwconv2d_backward_filter(dys, x, ws) if ctx.needs_input_grad[3] else None
+        return dx, dwv, dwh, dws
+
+
+def tri_dwconv(x, w_vertical, w_horizontal, w_small):
+    """(y_v, y_h, y_s) = depthwise conv of x with the (C,1,K,5), (C,1,5,K) and (C,1,5,5) filters (stride 1, 'same' padding)."""
+    return _TriDwConv.apply(x, w_vertical, w_horizontal, w_small)
+
+
 def ln_nchw_to_nhwc(x, weight, bias, eps=1e-6):
     return _LnNchwToNhwc.apply(x, weight, bias, eps)
 

@@ -169,4 +169,23 @@ int slak_dwconv2d_backward_filter(const void* dy, int dy_dtype, const void* x, i
     return launch_dwconv_wgrad(dy, dy_dtype, x, x_dtype, dw, d, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
+
+int slak_dwconv2d_tri_supported(int dtype, int N, int C, int H, int W, int K) {
+    return dwconv_mfma_small_tri_supported(N, C, H, W, K, dtype) ? 1 : 0;
+}
+
+int slak_dwconv2d_tri_forward(const void* x, const float* w_v, const float* w_h, const float* w_s, void* y_v, void* y_h, void* y_s,
+                              int dtype, int N, int C, int H, int W, int K, void* stream) {
+    if (!x || !w_v || !w_h || !w_s || !y_v || !y_h || !y_s) return SLAK_ERR_INVALID_ARG;
+    const void* in[3] = {x, x, x}; void* out[3] = {y_v, y_h, y_s}; const float* w[3] = {w_v, w_h, w_s};
+    return launch_dwconv_mfma_small_tri(false, in, out, w, dtype, N, C, H, W, K, (hipStream_t)stream);
+}
+
+int slak_dwconv2d_tri_backward_data(const void* dy_v, const void* dy_h, const void* dy_s, const float* w_v, const float* w_h,
+                                    const float* w_s, void* dx, int dtype, int N, int C, int H, int W, int K, void* stream) {
+    if (!dy_v || !dy_h || !dy_s || !w_v || !w_h || !w_s || !dx) return SLAK_ERR_INVALID_ARG;
+    const void* in[3] = {dy_v, dy_h, dy_s}; void* out[3] = {dx, dx, dx}; const float* w[3] = {w_v, w_h, w_s};
+    return launch_dwconv_mfma_small_tri(true, in, out, w, dtype, N, C, H, W, K, (hipStream_t)stream);
+}
+
 }  // extern "C"

@@ -1,0 +1,249 @@
+// slak_amd/csrc/dwconv_mfma_small_tri.hip -- the THREE branches of a decomposed large-kernel block (Kx5, 5xK, 5x5:
+// ReparamLargeKernelConv, models/SLaK.py:60-100) in ONE launch on the 14x14 class, with the wave-independent LDS-DMA streaming
+// of dwconv_mfma_small_dma.hip (same plane layout, fragments, counted vmcnt):
+//   forward        x                 -> y_v, y_h, y_s     x is fetched ONCE per plane pair instead of three times
+//   data gradient  dy_v, dy_h, dy_s  -> dx                the three contributions meet in ONE accumulator (both operand orders
+//                                                         leave the same lane/register map), so the two elementwise adds
+//                                                         autograd would run on the three partial gradients disappear
+// At this size a launch is ~10 us of fixed cost for ~8 us of HBM time, so one launch for three is also what removes most of it.
+#include "mfma_common.h"
+
+namespace slak {
+
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+
+constexpr int ST_NS = 4;                // ring slots (plane pairs) per wave
+constexpr int ST_WZP = 16;              // zeros in front of a filter row
+constexpr int ST_WLEN = 96;             // elements per padded filter row (16 + 63 + 17)
+constexpr int ST_WCH = 5;               // filter elements staged per lane (upper bound)
+constexpr int ST_WINB = 2 * MF_TAPS * ST_WLEN * 2;      // bytes of one branch's filter windows (two copies)
+
+struct SmallTriParams {
+    const void* in[3];                   // forward: in[0] = x; data gradient: dy_v, dy_h, dy_s
+    void* out[3];                        // forward: y_v, y_h, y_s; data gradient: out[0] = dx
+    const float* w[3];                   // filters of the vertical (K,5), horizontal (5,K) and small (5,5) branch
+    int N, C, H, W, K, flip;
+    int images_per_slice, slices;
+    unsigned tensor_bytes;
+};
+
+template <typename T> __device__ __forceinline__ f32x4_t st_mfma16(s16x8 a, s16x8 b, f32x4_t c);
+template <> __device__ __forceinline__ f32x4_t st_mfma16<bf16_t>(s16x8 a, s16x8 b, f32x4_t c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+}
+template <> __device__ __forceinline__ f32x4_t st_mfma16<f16_t>(s16x8 a, s16x8 b, f32x4_t c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+}
+
+// DGRAD: three inputs, one output, filters rotated by 180 degrees; else one input, three outputs
+template <typename T, bool DGRAD>
+__global__ __launch_bounds__(MF_THREADS) void dwconv_mfma_small_tri_kernel(const SmallTriParams p) {
+    constexpr int NT = DGRAD ? 3 : 1;                             // input tensors
+    constexpr int SLOT = NT * 1024;                               // bytes per ring slot: NT x [2 planes x 16 rows x 32 B]
+    // per-wave LDS region (bytes): [64 zero pad][ring][64 zero pad][x^T: 2 planes][64 zero row][3 x filter windows]
+    constexpr int RING = 64, XT = RING + ST_NS * SLOT + 64, ZROW = XT + 1024, WIN = ZROW + 64, WAVE_BYTES = WIN + 3 * ST_WINB;
+    constexpr int NSTORE = DGRAD ? 4 : 12;                         // store instructions per complete pair
+    extern __shared__ __attribute__((aligned(16))) uint16_t lds[];
+    const int lane = threadIdx.x & 63;
+    const int wave = wave_id_uniform();
+    const int cblocks = (p.C + 3) >> 2;
+    const int cb = blockIdx.x % cblocks, slice = blockIdx.x / cblocks;
+    const int c = cb * 4 + wave;
+    const int n_begin = slice * p.images_per_slice;
+    int n_end = n_begin + p.images_per_slice; if (n_end > p.N) n_end = p.N;
+    if (c >= p.C || n_begin >= n_end) return;                     // no workgroup barrier anywhere: waves may leave
+    const int npairs = (n_end - n_begin + 1) >> 1;
+    char* const L = (char*)lds + wave * WAVE_BYTES;
+    const int HW = p.H * p.W;
+
+    // ---- filters (three branches), zero fill ------------------------------------------------------------------
+    const int ntap = p.K * MF_TAPS;                               // vertical and horizontal branch; the small one has 25
+    float wv[ST_WCH], wh[ST_WCH], wsm = 0.f;
+#pragma unroll
+    for (int k = 0; k < ST_WCH; ++k) {
+        const int e = lane + 64 * k;
+        wv[k] = e < ntap ? p.w[0][(size_t)c * ntap + e] : 0.f;
+        wh[k] = e < ntap ? p.w[1][(size_t)c * ntap + e] : 0.f;
+    }
+    if (lane < 25) wsm = p.w[2][(size_t)c * 25 + lane];
+    for (int o = lane * 16; o < WAVE_BYTES; o += 64 * 16) *(u32x4*)(L + o) = u32x4{0u, 0u, 0u, 0u};
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");            // zeros are in place before any DMA can land on them
+
+    // ---- DMA: lane -> (plane of the pair, image row, half of the row) ------------------------------------------
+    v4i_t rs[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const uint64_t a = (uint64_t)p.in[t];
+        rs[t][0] = __builtin_amdgcn_readfirstlane((int)(a & 0xffffffffu)); rs[t][1] = __builtin_amdgcn_readfirstlane((int)((a >> 32) & 0xffffu));
+        rs[t][2] = __builtin_amdgcn_readfirstlane((int)p.tensor_bytes); rs[t][3] = 0x00020000;
+    }
+    __amdgpu_buffer_rsrc_t ro[3];
+#pragma unroll
+    for (int t = 0; t < (DGRAD ? 1 : 3); ++t) ro[t] = __builtin_amdgcn_make_buffer_rsrc(p.out[t], 0, (int)p.tensor_bytes, 0x00020000);
+    const unsigned gplane_b = (unsigned)(p.C * HW) * 2;
+    const int d_pp = lane >> 5, d_row = (lane >> 1) & 15, d_half = lane & 1;
+    const unsigned d_src = (unsigned)d_pp * gplane_b + (unsigned)(d_row * p.W) * 2 + (d_half ? (unsigned)(p.W - 8) * 2 : 0u);
+    const bool d_rowok = d_row < p.H;
+    const unsigned lds_wave = (unsigned)(uintptr_t)SLAK_LDS(uint16_t, lds) + wave * WAVE_BYTES;
+    const unsigned chan_b = (unsigned)c * (unsigned)HW * 2;
+    auto issue_pair = [&](int q) {
+        const int n0 = n_begin + 2 * q;
+        const unsigned gb = (unsigned)n0 * gplane_b + chan_b;
+        const unsigned dst = lds_wave + RING + (unsigned)(q % ST_NS) * SLOT;
+        if (d_rowok && n0 + d_pp < n_end) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) lds_dma16(gb + d_src, rs[t], __builtin_amdgcn_readfirstlane(dst + t * 1024));
+        }
+    };
+    for (int q = 0; q < ST_NS - 1 && q < npairs; ++q) issue_pair(q);
+
+    // ---- filter windows: branch b at WIN + b*ST_WINB, two copies one element apart ---------------------------------------
+    auto put = [&](int b, int r, int t, int KL, float v) {        // short tap r, long tap t of branch b
+        if (p.flip) { r = MF_TAPS - 1 - r; t = KL - 1 - t; }
+        const uint16_t h = cvt_to_bits(v, (T*)nullptr);
+        uint16_t* win = (uint16_t*)(L + WIN + b * ST_WINB);
+        win[r * ST_WLEN + ST_WZP + t] = h;
+        win[MF_TAPS * ST_WLEN + r * ST_WLEN + ST_WZP + t - 1] = h;
+    };
+#pragma unroll
+    for (int k = 0; k < ST_WCH; ++k) {
+        const int e = lane + 64 * k;
+        if (e < ntap) {
+            put(0, e % MF_TAPS, e / MF_TAPS, p.K, wv[k]);        // (K,5): element [t][r]
+            put(1, e / p.K, e - (e / p.K) * p.K, p.K, wh[k]);    // (5,K): element [r][t]
+        }
+    }
+    if (lane < 25) put(2, lane / 5, lane % 5, 5, wsm);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    // Toeplitz fragments: lane -> (o = long-axis output position, k-group kg -> tap-in-pair rsel, half of the 16 k-slots)
+    const int l15 = lane & 15, kg = lane >> 4, rsel = kg >> 1, half = kg & 1;
+    s16x8 tf[3][3];
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+        const bool vert = b == 0;
+        const int padL = (b == 2 ? 5 : p.K) / 2;
+        const int i0 = half ? (vert ? 8 : p.W - 8) : 0;
+        const int a = ST_WZP + i0 - l15 + padL;
+        const int par = a & 1;
+        const unsigned* src = (const unsigned*)(L + WIN + b * ST_WINB + par * MF_TAPS * ST_WLEN * 2) + ((a - par) >> 1);
+#pragma unroll
+        for (int m = 0; m < 3; ++m) {
+            const int r = 2 * m + rsel;
+            u32x4 d;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                d[k] = r < MF_TAPS ? src[(r < MF_TAPS ? r : 0) * (ST_WLEN / 2) + k] : 0u;
+                if (!vert && half && 2 * k < 16 - p.W) d[k] = 0u;     // columns already covered by the first half
+            }
+            tf[b][m] = __builtin_bit_cast(s16x8, d);
+        }
+    }
+
+    // ---- lane constants of the loop (see dwconv_mfma_small_dma.hip) --------------------------------------------------
+    const unsigned xlane = (unsigned)(l15 * 32 + rsel * 32 + half * 16);
+    const unsigned zlane = (unsigned)ZROW + half * 16;
+    const int g4 = lane >> 4;
+    const unsigned trd = (unsigned)((4 * g4 + (l15 >> 2)) * 32 + (l15 & 3) * 8);
+    const int xt_row = l15 < 8 ? l15 : l15 - (16 - p.W);
+    const bool twr_ok = l15 < 8 || xt_row >= 8;
+    const unsigned twr = (unsigned)(XT + xt_row * 32 + g4 * 8);
+    const unsigned ooff = (unsigned)(l15 * p.W + 4 * kg) * 2;
+    const bool st0 = l15 < p.H && 4 * kg < p.W, st1 = l15 < p.H && 4 * kg + 2 < p.W;
+    auto frag = [&](unsigned base, int m) -> s16x8 {              // MFMA m of a plane whose guarded image starts 64 bytes after `base`
+        const unsigned a = (m == 2 && rsel) ? zlane : base + xlane + m * 64;
+        return __builtin_bit_cast(s16x8, *(const u32x4*)(L + a));
+    };
+
+    for (int q = 0; q < npairs; ++q) {
+        {
+            const int st = (q < ST_NS - 2 ? q : ST_NS - 2) * NSTORE;
+            int dm = npairs - 1 - q; if (dm > ST_NS - 2) dm = ST_NS - 2;
+            wait_vmcnt_dyn(st + dm * NT);
+        }
+        __builtin_amdgcn_wave_barrier();
+        const int n0 = n_begin + 2 * q;
+        const unsigned slot = (unsigned)RING + (unsigned)(q % ST_NS) * SLOT;
+        // vertical branch: its input plane pair (tensor 0) transposed into x^T
+        {
+            const s16x4 t0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(SLAK_LDS(s16x4, L + slot + trd));
+            const s16x4 t1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(SLAK_LDS(s16x4, L + slot + 512 + trd));
+            if (twr_ok) { *(s16x4*)(L + twr) = t0; *(s16x4*)(L + twr + 512) = t1; }
+        }
+        const unsigned bv = (unsigned)XT - 64;                                    // x^T images
+        const unsigned bh = slot + (DGRAD ? 1024u : 0u) - 64, bs = slot + (DGRAD ? 2048u : 0u) - 64;   // row-major images
+        const unsigned gb = (unsigned)n0 * gplane_b + chan_b;
+#pragma unroll
+        for (int pp = 0; pp < 2; ++pp) {
+            if (pp == 1 && n0 + 1 >= n_end) break;                  // (wave-uniform) odd slice: the second plane does not exist
+            f32x4_t av = {0.f, 0.f, 0.f, 0.f}, ah = av, as = av;
+#pragma unroll
+            for (int m = 0; m < 3; ++m) {
+                av = st_mfma16<T>(frag(bv + pp * 512, m), tf[0][m], av);       // operands swapped: D^T = X^T-tile x T^T
+                ah = st_mfma16<T>(tf[1][m], frag(bh + pp * 512, m), ah);
+                as = st_mfma16<T>(tf[2][m], frag(bs + pp * 512, m), as);
+            }
+            const unsigned go = gb + pp * gplane_b;
+            if constexpr (DGRAD) {
+                const f32x4_t s = (av + ah) + as;                   // the three partial gradients, added in fp32
+                if (st0) __builtin_amdgcn_raw_buffer_store_b32(pack2<T>(s[0], s[1]), ro[0], ooff, go, 0);
+                if (st1) __builtin_amdgcn_raw_buffer_store_b32(pack2<T>(s[2], s[3]), ro[0], ooff + 4, go, 0);
+            } else {
+                if (st0) __builtin_amdgcn_raw_buffer_store_b32(pack2<T>(av[0], av[1]), ro[0], ooff, go, 0);
+                if (st1) __builtin_amdgcn_raw_buffer_store_b32(pack2<T>(av[2], av[3]), ro[0], ooff + 4, go, 0);
+                if (st0) __builtin_amdgcn_raw_buffer_store_b32(pack2<T>(ah[0], ah[1]), ro[1], ooff, go, 0);
+                if (st1) __builtin_amdgcn_raw_buffer_store_b32(pack2<T>(ah[2], ah[3]), ro[1], ooff + 4, go, 0);
+                if (st0) __builtin_amdgcn_raw_buffer_store_b32(pack2<T>(as[0], as[1]), ro[2], ooff, go, 0);
+                if (st1) __builtin_amdgcn_raw_buffer_store_b32(pack2<T>(as[2], as[3]), ro[2], ooff + 4, go, 0);
+            }
+        }
+        if (q + ST_NS - 1 < npairs) issue_pair(q + ST_NS - 1);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+static bool fill_tri_params(SmallTriParams& p, int N, int C, int H, int W, int K, int target_wgs) {
+    p.N = N; p.C = C; p.H = H; p.W = W; p.K = K;
+    if (N <= 0 || C <= 0 || K < 5 || !(K & 1) || K > 63 || K * MF_TAPS > ST_WCH * 64) return false;
+    if (W < 8 || W > 14 || (W & 1) || H > 14 || H < 1) return false;   // both the row-major image and its transpose need guard rows
+    const int cblocks = (C + 3) / 4;
+    int slices = target_wgs / cblocks; if (slices < 1) slices = 1;
+    int per = (N + slices - 1) / slices; per = (per + 1) & ~1;
+    if (per < 8) per = 8;
+    if (per > ((N + 1) & ~1)) per = (N + 1) & ~1;
+    p.images_per_slice = per; p.slices = (N + per - 1) / per;
+    p.tensor_bytes = (unsigned)((size_t)N * C * H * W * 2);
+    return (size_t)N * C * H * W * 2 < 0xffffffffull;
+}
+
+bool dwconv_mfma_small_tri_supported(int N, int C, int H, int W, int K, int dtype) {
+    if (dtype != SLAK_BF16 && dtype != SLAK_F16) return false;
+    SmallTriParams p;
+    return fill_tri_params(p, N, C, H, W, K, 768);
+}
+
+template <typename T, bool DGRAD>
+static int launch_tri_t(SmallTriParams& p, hipStream_t st) {
+    constexpr int NT = DGRAD ? 3 : 1;
+    constexpr size_t WAVE_BYTES = 64 + ST_NS * NT * 1024 + 64 + 1024 + 64 + 3 * ST_WINB;
+    auto k = dwconv_mfma_small_tri_kernel<T, DGRAD>;
+    fill_tri_params(p, p.N, p.C, p.H, p.W, p.K, (DGRAD ? 2 : 3) * mfma_cu_count());   // resident workgroups per CU (LDS)
+    const size_t lds = (size_t)MF_WAVES * WAVE_BYTES;
+    if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k, dim3((unsigned)(((p.C + 3) / 4) * p.slices)), dim3(MF_THREADS), lds, st, p);
+    SLAK_LAUNCH_CHECK();
+    return SLAK_OK;
+}
+
+int launch_dwconv_mfma_small_tri(bool dgrad, const void* const* in, void* const* out, const float* const* w, int dtype,
+                                 int N, int C, int H, int W, int K, hipStream_t st) {
+    if (!dwconv_mfma_small_tri_supported(N, C, H, W, K, dtype)) return SLAK_ERR_UNSUPPORTED;
+    SmallTriParams p;
+    fill_tri_params(p, N, C, H, W, K, 768);
+    for (int i = 0; i < 3; ++i) { p.in[i] = in[dgrad ? i : 0]; p.out[i] = out[dgrad ? 0 : i]; p.w[i] = w[i]; }
+    p.flip = dgrad ? 1 : 0;
+    if (dtype == SLAK_BF16) return dgrad ? launch_tri_t<bf16_t, true>(p, st) : launch_tri_t<bf16_t, false>(p, st);
+    return dgrad ? launch_tri_t<f16_t, true>(p, st) : launch_tri_t<f16_t, false>(p, st);
+}
+
+}  // namespace slak

@@ -188,18 +188,16 @@ __device__ __forceinline__ void lds_dma_run(unsigned voff, v4i_t rsrc, unsigned 
 __device__ __forceinline__ void wg_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
-__device__ __forceinline__ void wait_vmcnt_dyn(int n) {       // n is wave-uniform
+__device__ __forceinline__ void wait_vmcnt_dyn(int n) {       // n is wave-uniform, 0..31 (anything else waits for everything)
+#define SLAK_VMC(k) case k: wait_vmcnt<k>(); break;
     switch (n) {
-        case 0: wait_vmcnt<0>(); break;   case 1: wait_vmcnt<1>(); break;   case 2: wait_vmcnt<2>(); break;
-        case 3: wait_vmcnt<3>(); break;   case 4: wait_vmcnt<4>(); break;   case 5: wait_vmcnt<5>(); break;
-        case 6: wait_vmcnt<6>(); break;   case 7: wait_vmcnt<7>(); break;   case 8: wait_vmcnt<8>(); break;
-        case 9: wait_vmcnt<9>(); break;   case 10: wait_vmcnt<10>(); break; case 11: wait_vmcnt<11>(); break;
-        case 12: wait_vmcnt<12>(); break; case 13: wait_vmcnt<13>(); break; case 14: wait_vmcnt<14>(); break;
-        case 15: wait_vmcnt<15>(); break; case 16: wait_vmcnt<16>(); break; case 17: wait_vmcnt<17>(); break;
-        case 18: wait_vmcnt<18>(); break; case 19: wait_vmcnt<19>(); break; case 20: wait_vmcnt<20>(); break;
-        case 24: wait_vmcnt<24>(); break;
+        SLAK_VMC(0) SLAK_VMC(1) SLAK_VMC(2) SLAK_VMC(3) SLAK_VMC(4) SLAK_VMC(5) SLAK_VMC(6) SLAK_VMC(7)
+        SLAK_VMC(8) SLAK_VMC(9) SLAK_VMC(10) SLAK_VMC(11) SLAK_VMC(12) SLAK_VMC(13) SLAK_VMC(14) SLAK_VMC(15)
+        SLAK_VMC(16) SLAK_VMC(17) SLAK_VMC(18) SLAK_VMC(19) SLAK_VMC(20) SLAK_VMC(21) SLAK_VMC(22) SLAK_VMC(23)
+        SLAK_VMC(24) SLAK_VMC(25) SLAK_VMC(26) SLAK_VMC(27) SLAK_VMC(28) SLAK_VMC(29) SLAK_VMC(30) SLAK_VMC(31)
         default: wait_vmcnt<0>(); break;
     }
+#undef SLAK_VMC
 }
 
 

@@ -78,6 +78,9 @@ int launch_dwconv_mfma_dma(const void* x, int x_dt, const void* w, int w_dt, voi
 bool dwconv_mfma_small_dma_supported(const ConvDims& d, int x_dt, int w_dt, int y_dt);
 int launch_dwconv_mfma_small_dma(const void* x, int x_dt, const void* w, int w_dt, void* y, int y_dt,
                                  const ConvDims& d, bool flip_filter, hipStream_t st);
+bool dwconv_mfma_small_tri_supported(int N, int C, int H, int W, int K, int dtype);
+int launch_dwconv_mfma_small_tri(bool dgrad, const void* const* in, void* const* out, const float* const* w, int dtype,
+                                 int N, int C, int H, int W, int K, hipStream_t st);
 bool dwconv_mfma_wgrad_vrows_supported(const ConvDims& d, int dy_dt, int x_dt);
 size_t dwconv_mfma_wgrad_vrows_workspace(const ConvDims& d);
 int launch_dwconv_mfma_wgrad_vrows(const void* dy, int dy_dt, const void* x, int x_dt, float* dw,

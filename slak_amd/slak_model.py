@@ -122,8 +122,13 @@ class ReparamLargeKernelConv(nn.Module):
                 and hasattr(self.LoRA1, 'bn') and (self.training or not torch.is_grad_enabled())):
             # same arithmetic, the three BatchNorms and the two adds as one HIP op (slak_amd/block_ops.py)
             from . import block_ops
-            return block_ops.branch_bn3(self.LoRA1.conv(inputs), self.LoRA2.conv(inputs), self.small_conv.conv(inputs),
-                                        self.LoRA1.bn, self.LoRA2.bn, self.small_conv.bn)
+            c1, c2, c3 = self.LoRA1.conv, self.LoRA2.conv, self.small_conv.conv
+            if (self.fused_tri and c1.bias is None and c2.bias is None and c3.bias is None and tuple(c3.kernel_size) == (5, 5)
+                    and c1.kernel_size[1] == 5 and c2.kernel_size[0] == 5 and c1.kernel_size[0] == c2.kernel_size[1] and c1.kernel_size[0] > 5):
+                y1, y2, y3 = block_ops.tri_dwconv(inputs.contiguous(), c1.weight, c2.weight, c3.weight)     # one autograd node for the three branches
+            else:
+                y1, y2, y3 = c1(inputs), c2(inputs), c3(inputs)
+            return block_ops.branch_bn3(y1, y2, y3, self.LoRA1.bn, self.LoRA2.bn, self.small_conv.bn)
         if self.Decom:
             out = self.LoRA1(inputs) + self.LoRA2(inputs)
         else:
@@ -204,6 +209,7 @@ Block._forward_fused_tail = _block_forward_fused_tail
 Block.fused_tail = False
 Block.emit_lowp = False      # per instance: the next module is another Block with lowp_dwconv (set by SLaK.__init__ / bench.py)
 ReparamLargeKernelConv.fused_bn = False
+ReparamLargeKernelConv.fused_tri = False     # the three branch convs as one autograd node (block_ops.tri_dwconv); needs fused_bn
 LayerNorm.fused_cf = False
 
 

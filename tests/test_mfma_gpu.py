@@ -156,3 +156,34 @@ def test_mfma_identity_and_adjoint_full_size(mfma_only, gpu):
             y2 = ops.dwconv2d_forward(x, w)
         s.synchronize()
         assert torch.equal(y, y2)
+
+
+@pytest.mark.parametrize("N,C,H,W,K", [(5, 7, 14, 14, 47), (4, 3, 12, 10, 9), (1, 1, 14, 14, 13), (3, 2, 28, 28, 49), (6, 5, 7, 7, 13)])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_tri_dwconv_matches_the_three_branch_convs(N, C, H, W, K, dtype, gpu):
+    """block_ops.tri_dwconv (one launch for Kx5 + 5xK + 5x5 on the 14x14 class; three launches elsewhere): outputs are the
+    per-branch kernels' outputs bit for bit, the input gradient is their sum (added in fp32 before the single rounding), the
+    weight gradients are the per-branch ones."""
+    from slak_amd import block_ops
+    ops = _ops()
+    torch.manual_seed(N + K)
+    x = torch.randn(N, C, H, W, device=gpu).to(dtype).requires_grad_(True)
+    ws = [(torch.randn(C, 1, kh, kw, device=gpu) * 0.05).requires_grad_(True) for kh, kw in ((K, 5), (5, K), (5, 5))]
+    dys = [torch.randn(N, C, H, W, device=gpu).to(dtype) for _ in range(3)]
+    ys = block_ops.tri_dwconv(x, *ws)
+    torch.autograd.backward(ys, dys)
+    for y, w in zip(ys, ws):
+        assert torch.equal(y, ops.dwconv2d_forward(x.detach(), w.detach()))
+    ref_dx = sum(ops.dwconv2d_backward_data(dy, w.detach()).float() for dy, w in zip(dys, ws))
+    scale = max(1.0, ref_dx.abs().max().item())
+    assert (x.grad.float() - ref_dx).abs().max().item() <= 2e-2 * scale
+    for dy, w in zip(dys, ws):
+        assert torch.equal(w.grad, ops.dwconv2d_backward_filter(dy, x.detach(), w.detach()))
+    # where the one-launch kernel ran: the summed gradient is rounded ONCE -> the oracle's half-ulp bound holds for the sum
+    L = _lib()
+    if L.lib().slak_dwconv2d_tri_supported(L.SLAK_BF16 if dtype == torch.bfloat16 else L.SLAK_F16, N, C, H, W, K):
+        xr = [_round(dy, dtype) for dy in dys]
+        ref = sum(oracle.dwconv2d_bwd_data(d, _round(w.detach(), dtype)) for d, w in zip(xr, ws))
+        _check(x.grad, ref, 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11, "tri dgrad")
+    else:
+        assert (H, W) != (14, 14)
