@@ -69,6 +69,8 @@ def parse():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--kernel-reps", type=int, default=30)
     ap.add_argument("--fp32-dwconv", action="store_true", help="reference dtype flow: dw convs see fp32 even under autocast")
+    ap.add_argument("--torch-adamw", action="store_true", help="torch.optim.AdamW(fused=True) (+ a separate mask-apply launch) instead of slak_amd's one-launch MaskedAdamW")
+    ap.add_argument("--model-ema", action="store_true", help="also keep the reference's sparsity-aware EMA (--model_ema true recipes): one HIP launch per step")
     ap.add_argument("--no-fused-tri", action="store_true", help="run the three branch convolutions as three autograd nodes (one launch each)")
     ap.add_argument("--no-fused-bn", action="store_true", help="run the three branch BatchNorms + adds as the reference's PyTorch modules")
     ap.add_argument("--no-fused-tail", action="store_true", help="run the block tail (permute/LayerNorm/gamma/residual) as the reference's PyTorch ops")
@@ -207,7 +209,12 @@ def main():
     decay, no_decay = [], []
     for n, p in model.named_parameters():
         (no_decay if (p.dim() == 1 or n.endswith(".bias")) else decay).append(p)                                     # optim_factory.py no-decay rule
-    opt = torch.optim.AdamW([dict(params=decay, weight_decay=0.05), dict(params=no_decay, weight_decay=0.0)], lr=4e-3, fused=True)
+    groups = [dict(params=decay, weight_decay=0.05), dict(params=no_decay, weight_decay=0.0)]
+    if a.torch_adamw:
+        opt = torch.optim.AdamW(groups, lr=4e-3, fused=True)
+    else:
+        from slak_amd.optim_factory import MaskedAdamW               # AdamW + w *= mask + bf16 weight copies: one HIP launch
+        opt = MaskedAdamW(groups, lr=4e-3)
     criterion = nn.CrossEntropyLoss(label_smoothing=0.1)
     mask = None
     if sparsity > 0:
@@ -218,6 +225,11 @@ def main():
             mask = Masking(opt, None, CosineDecay(0.3, 300 * 1251), prune_rate=0.3, prune_mode="magnitude",
                            growth_mode="gradient", redistribution_mode="none", args=margs)
             mask.add_module(model)
+
+    model_ema = None
+    if a.model_ema:                                               # main.py:339-346 (--model_ema true), updated after every step: engine.py:87-88
+        from slak_amd.model_sema import ModelEma
+        model_ema = ModelEma(model.module if distributed else model, decay=0.9999, device='', resume='')   # built from the unwrapped model (main.py:341 precedes the DDP wrap)
 
     g = torch.Generator(device=device).manual_seed(1234 + rank)
     samples = torch.randn(a.batch, 3, 224, 224, device=device, generator=g)
@@ -232,6 +244,8 @@ def main():
         else:
             opt.step()
         opt.zero_grad(set_to_none=True)
+        if model_ema is not None:
+            model_ema.update(model, mask)
         return loss
 
     model.train()
@@ -262,7 +276,8 @@ def main():
         "config": {"workload": ("BASELINE configs[1]: SLaK-T 51x51 full model, bs=128, 224x224, bf16, sparsity off" if sparsity == 0 else
                                 "BASELINE configs[2]: SLaK-T 51x51, bs=128/GPU, 224x224, bf16, DDP over RCCL, Masking sparsity %.2f, prune-and-grow every %d steps" % (sparsity, a.update_frequency)),
                    "global_batch": n_gpus * a.batch, "per_gpu_batch": a.batch, "parallelism": "dp%d" % n_gpus,
-                   "dwconv_dtype": "fp32" if a.fp32_dwconv else "bf16 in/out, fp32 accumulate", "optimizer": "AdamW(fused)",
+                   "dwconv_dtype": "fp32" if a.fp32_dwconv else "bf16 in/out, fp32 accumulate", "optimizer": "torch AdamW(fused)" if a.torch_adamw else "slak_amd MaskedAdamW (update + mask + bf16 copies, one launch)",
+                   "model_ema": bool(a.model_ema),
                    "sync_bn": True, "block_tail": "hip (ln_nchw_to_nhwc + scale_residual)" if M.Block.fused_tail else "pytorch ops",
                    "branch_bn": "hip (bn3: one stats pass + one apply pass)" if M.ReparamLargeKernelConv.fused_bn else "pytorch (Sync)BatchNorm x3 + adds",
                    "pointwise_gemm": "hipBLASLt via torch" + (", TunableOp solutions from slak_amd/tuning/tunableop_gfx950.csv" if TUNED_GEMMS else ""),

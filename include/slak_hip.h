@@ -45,7 +45,7 @@ typedef enum {
     SLAK_ERR_NO_DEVICE = 5
 } slak_status_t;
 
-typedef enum { SLAK_F32 = 0, SLAK_F16 = 1, SLAK_BF16 = 2 } slak_dtype_t;
+typedef enum { SLAK_F32 = 0, SLAK_F16 = 1, SLAK_BF16 = 2, SLAK_I64 = 3 /* slak_ema_update only */ } slak_dtype_t;
 
 /* conv algorithm selector: AUTO picks per dtype/shape; DIRECT = fp32-exact VALU kernels (any dtype);
  * MFMA = banded-Toeplitz matrix-core kernels (f16/bf16 inputs only). */
@@ -186,6 +186,51 @@ int slak_bn3_backward_apply(const void* dout, const void* y1, const void* y2, co
                             const float* stats, const float* const* gamma_host3,
                             float* bcoef /*[C][9]*/, float* dgamma /*[3][C]*/, float* dbeta /*[3][C]*/,
                             void* dy1, void* dy2, void* dy3, int N, int C, int P, void* stream);
+
+/* ---------------------------------------------------------------- next row: mask-aware optimizer step and EMA
+ * One launch over ALL tensors each.  Descriptor arrays live in HOST memory at plan creation (device pointers inside); plans own their
+ * device tables.
+ *
+ * slak_adamw_step = torch.optim.AdamW's update (optim_factory.py:149-150; decoupled weight decay, bias corrections evaluated in double
+ * from the tensor's own step count) followed by Masking.apply_mask's w *= mask (sparse_core.py:316-333) and, optionally, the bf16 copy
+ * of the updated weight, in one pass.  `step` points at a device float holding the tensor's step count AFTER this step's increment
+ * (the caller adds 1 to its step buffer first: one tiny launch).  Gradients are re-allocated by autograd / DDP every step, so their
+ * pointers arrive separately: `grads_dev` is a DEVICE array of nseg device pointers (NULL entry = no gradient: the tensor is skipped,
+ * as torch skips p.grad is None).  Hyper-parameters are per group (the reference builds one group per layer x {decay, no_decay}:
+ * optim_factory.py:73-112) and are passed by value at every call (lr follows a per-iteration schedule: engine.py:41-46). */
+#define SLAK_ADAMW_MAX_GROUPS 64
+typedef struct {
+    float* param;            /* fp32, updated in place                                        */
+    float* exp_avg;          /* fp32 first moment                                             */
+    float* exp_avg_sq;       /* fp32 second moment                                            */
+    const float* mask;       /* fp32 0/1 mask (Masking.masks[name]) or NULL                   */
+    void* param_bf16;        /* optional bf16 copy of the updated parameter, or NULL          */
+    const float* step;       /* device scalar: step count of this tensor, already incremented */
+    long long numel;
+    int group;               /* index into the groups array of slak_adamw_step                */
+} slak_adamw_segment_t;
+typedef struct { double lr, beta1, beta2, eps, weight_decay; } slak_adamw_group_t;
+typedef struct slak_adamw_plan slak_adamw_plan_t;
+int slak_adamw_plan_create(const slak_adamw_segment_t* segs_host, int nseg, slak_adamw_plan_t** plan_out);
+int slak_adamw_step(slak_adamw_plan_t* plan, const void* const* grads_dev, const slak_adamw_group_t* groups_host, int ngroups, void* stream);
+int slak_adamw_plan_destroy(slak_adamw_plan_t* plan);
+
+/* slak_ema_update = ModelEma.update(model, mask) (model_sema.py:67-91) over every state-dict entry:
+ *   dense  : ema = ema*decay + (1-decay)*model
+ *   masked : ema = (ema*decay + model*(1-decay))*mask + (diff*decay)*model,  diff = ((ema != 0) ^ mask) & mask  (newly grown weights)
+ * each product and sum rounded separately in fp32, so the result is bit-identical to the reference's chain of torch kernels.
+ * dtype SLAK_F32, or SLAK_I64 for BatchNorm's num_batches_tracked (float32 arithmetic, truncating copy back, as torch does). */
+typedef struct {
+    void* ema;               /* EMA copy of the entry, updated in place   */
+    const void* model;       /* the live model's entry                    */
+    const float* mask;       /* fp32 0/1 mask of this entry or NULL       */
+    long long numel;
+    int dtype;               /* SLAK_F32 or SLAK_I64                      */
+} slak_ema_segment_t;
+typedef struct slak_ema_plan slak_ema_plan_t;
+int slak_ema_plan_create(const slak_ema_segment_t* segs_host, int nseg, slak_ema_plan_t** plan_out);
+int slak_ema_update(slak_ema_plan_t* plan, double decay, void* stream);
+int slak_ema_plan_destroy(slak_ema_plan_t* plan);
 
 #ifdef __cplusplus
 }

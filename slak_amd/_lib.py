@@ -26,6 +26,24 @@ class MaskSegment(ctypes.Structure):
                 ("momentum", ctypes.c_void_p), ("numel", ctypes.c_longlong)]
 
 
+class AdamwSegment(ctypes.Structure):
+    _fields_ = [("param", ctypes.c_void_p), ("exp_avg", ctypes.c_void_p), ("exp_avg_sq", ctypes.c_void_p), ("mask", ctypes.c_void_p),
+                ("param_bf16", ctypes.c_void_p), ("step", ctypes.c_void_p), ("numel", ctypes.c_longlong), ("group", ctypes.c_int)]
+
+
+class AdamwGroup(ctypes.Structure):
+    _fields_ = [("lr", ctypes.c_double), ("beta1", ctypes.c_double), ("beta2", ctypes.c_double), ("eps", ctypes.c_double),
+                ("weight_decay", ctypes.c_double)]
+
+
+ADAMW_MAX_GROUPS = 64
+
+
+class EmaSegment(ctypes.Structure):
+    _fields_ = [("ema", ctypes.c_void_p), ("model", ctypes.c_void_p), ("mask", ctypes.c_void_p), ("numel", ctypes.c_longlong),
+                ("dtype", ctypes.c_int)]
+
+
 # name -> (restype, argtypes): every symbol include/slak_hip.h declares (tests/test_boundary.py checks this)
 _vp, _i, _sz, _d = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t, ctypes.c_double
 _CONV = [_vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]
@@ -47,6 +65,12 @@ SIGNATURES = {
     "slak_mask_prune_and_grow": (_i, [_vp, _d, _vp]),
     "slak_mask_read_stats": (_i, [_vp, ctypes.POINTER(_d), _vp]),
     "slak_mask_checksum": (_i, [_vp, ctypes.POINTER(ctypes.c_ulonglong), _vp]),
+    "slak_adamw_plan_create": (_i, [ctypes.POINTER(AdamwSegment), _i, ctypes.POINTER(_vp)]),
+    "slak_adamw_step": (_i, [_vp, _vp, ctypes.POINTER(AdamwGroup), _i, _vp]),
+    "slak_adamw_plan_destroy": (_i, [_vp]),
+    "slak_ema_plan_create": (_i, [ctypes.POINTER(EmaSegment), _i, ctypes.POINTER(_vp)]),
+    "slak_ema_update": (_i, [_vp, _d, _vp]),
+    "slak_ema_plan_destroy": (_i, [_vp]),
     "slak_bn3_workspace_bytes": (_sz, [_i, _i]),
     "slak_bn3_forward_sums": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _sz, _vp]),
     "slak_bn3_forward_apply": (_i, [_vp, _vp, _vp, _vp, _d, _vp, ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(_vp),

@@ -172,6 +172,36 @@ def tri_dwconv(x, w_vertical, w_horizontal, w_small):
     return _TriDwConv.apply(x, w_vertical, w_horizontal, w_small)
 
 
+def tri_dwconv_sum(x, w_vertical, w_horizontal, w_small, bias=None):
+    """y = conv(x, w_v) + conv(x, w_h) + conv(x, w_s) (+ bias): the re-parameterised (BatchNorms folded) decomposed block at inference
+    (ReparamLargeKernelConv.merge_kernel).  No autograd.  Where the one-launch kernel exists the three branches are
+    summed in its accumulator: a forward correlation with w equals the data-gradient kernel run on the spatially flipped filter,
+    so this is slak_dwconv2d_tri_backward_data with x as all three inputs; elsewhere three launches and two adds."""
+    from . import ops
+    with torch.no_grad():
+        _chk(x, "input")
+        N, C, H, W = x.shape
+        K = w_vertical.shape[2]
+        L = _lib.lib()
+        dt = ops._DT.get(x.dtype)
+        ws = [w.detach().float().contiguous() for w in (w_vertical, w_horizontal, w_small)]
+        if (dt is not None and ws[0].shape == (C, 1, K, 5) and ws[1].shape == (C, 1, 5, K) and ws[2].shape == (C, 1, 5, 5)
+                and bool(L.slak_dwconv2d_tri_supported(dt, N, C, H, W, K))):
+            fl = [w.flip(2, 3).contiguous() for w in ws]
+            y = torch.empty_like(x)
+            with torch.cuda.device(x.device):
+                _lib.check(L.slak_dwconv2d_tri_backward_data(x.data_ptr(), x.data_ptr(), x.data_ptr(), fl[0].data_ptr(), fl[1].data_ptr(),
+                                                             fl[2].data_ptr(), y.data_ptr(), dt, N, C, H, W, K, _stream(x.device)),
+                           "slak_dwconv2d_tri_backward_data")
+        else:
+            y = ops.dwconv2d_forward(x, ws[0])
+            y += ops.dwconv2d_forward(x, ws[1])
+            y += ops.dwconv2d_forward(x, ws[2])
+        if bias is not None:
+            y += bias.detach().to(y.dtype).view(1, -1, 1, 1)
+        return y
+
+
 def ln_nchw_to_nhwc(x, weight, bias, eps=1e-6):
     return _LnNchwToNhwc.apply(x, weight, bias, eps)
 

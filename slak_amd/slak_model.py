@@ -118,6 +118,16 @@ class ReparamLargeKernelConv(nn.Module):
             inputs = lowp if (lowp is not None and lowp.dtype == dt and lowp.shape == inputs.shape) else inputs.to(dt)
         if hasattr(self, 'lkb_reparam'):
             return self.lkb_reparam(inputs)
+        if hasattr(self, 'reparam_bias'):                         # merge_kernel() on the decomposed path: thin kernels with the BNs folded in
+            convs = [getattr(self, n) for n in ('LoRA1_reparam', 'LoRA2_reparam', 'small_conv_reparam') if hasattr(self, n)]
+            if (len(convs) == 3 and inputs.is_cuda and inputs.dtype in (torch.bfloat16, torch.float16) and not torch.is_grad_enabled()
+                    and tuple(convs[2].kernel_size) == (5, 5) and convs[0].kernel_size[1] == 5 and convs[1].kernel_size[0] == 5):
+                from . import block_ops                           # one launch where the tri kernel covers the shape
+                return block_ops.tri_dwconv_sum(inputs.contiguous(), convs[0].weight, convs[1].weight, convs[2].weight, self.reparam_bias)
+            out = convs[0](inputs)
+            for c in convs[1:]:
+                out = out + c(inputs)
+            return out + self.reparam_bias.to(out.dtype).view(1, -1, 1, 1)
         if (self.fused_bn and self.Decom and hasattr(self, 'small_conv') and inputs.is_cuda and inputs.dtype == torch.bfloat16
                 and hasattr(self.LoRA1, 'bn') and (self.training or not torch.is_grad_enabled())):
             # same arithmetic, the three BatchNorms and the two adds as one HIP op (slak_amd/block_ops.py)
@@ -146,6 +156,28 @@ class ReparamLargeKernelConv(nn.Module):
         return k, b
 
     def merge_kernel(self):
+        """Inference re-parameterisation (models/SLaK.py:112-122).  The reference can only merge the dense ``lkb_origin`` path; for
+        the decomposed path the BatchNorm of every branch is folded into its thin kernel (fuse_bn, models/SLaK.py:51-58)
+        and the three biases into one: ``LoRA1_reparam`` / ``LoRA2_reparam`` / ``small_conv_reparam`` (bias-free convs) +
+        ``reparam_bias``.  The K x 5 + 5 x K + 5 x 5 taps are kept as three thin kernels (535 taps at K = 51) rather than scattered
+        into one dense K x K kernel (2601 taps): the merged block runs as one launch of the three-branch kernel."""
+        if self.Decom:
+            names = ['LoRA1', 'LoRA2'] + (['small_conv'] if hasattr(self, 'small_conv') else [])
+            bias = None
+            for n in names:
+                br = getattr(self, n)
+                if hasattr(br, 'bn'):
+                    k, b = fuse_bn(br.conv, br.bn)
+                else:
+                    k, b = br.conv.weight, torch.zeros_like(br.conv.weight[:, 0, 0, 0])
+                c = br.conv
+                merged = get_conv2d(c.in_channels, c.out_channels, c.kernel_size, c.stride, c.padding, c.dilation, c.groups, False)
+                merged.weight.data = k.detach().clone()
+                setattr(self, n + '_reparam', merged)
+                bias = b.detach().clone() if bias is None else bias + b.detach()
+                delattr(self, n)
+            self.reparam_bias = nn.Parameter(bias)
+            return
         k, b = self.get_equivalent_kernel_bias()
         c = self.lkb_origin.conv
         self.lkb_reparam = get_conv2d(c.in_channels, c.out_channels, c.kernel_size, c.stride, c.padding, c.dilation, c.groups, True)
@@ -250,6 +282,13 @@ class SLaK(nn.Module):
             nn.init.trunc_normal_(m.weight, std=.02, a=-2., b=2.)
             if m.bias is not None:
                 nn.init.constant_(m.bias, 0)
+
+    def structural_reparam(self):
+        """Fold every block's branch BatchNorms for inference (ReparamLargeKernelConv.merge_kernel on each block)."""
+        for m in self.modules():
+            if isinstance(m, ReparamLargeKernelConv) and not hasattr(m, 'lkb_reparam') and not hasattr(m, 'reparam_bias'):
+                m.merge_kernel()
+        return self
 
     def forward_features(self, x):
         for i in range(4):

@@ -304,9 +304,26 @@ class Masking(object):
             self._momentum_key = key
 
     # ------------------------------------------------------------------ the per-step surface
+    def _bind_optimizer_masks(self):
+        """An optimizer that can apply masks inside its own update kernel (slak_amd.optim_factory.MaskedAdamW) gets the mask of
+        every masked parameter; returns True when it took them, i.e. when optimizer.step() already leaves w == w * mask."""
+        if not getattr(self.optimizer, "applies_masks", False):
+            return False
+        params = self._masked_params()
+        key = tuple((id(t), self.masks[n].data_ptr()) for n, t in params)
+        if key != getattr(self, "_opt_masks_key", None):
+            self.optimizer.set_masks({t: self.masks[n] for n, t in params})
+            self._opt_masks_key = key
+        return True
+
     def step(self):
-        self.optimizer.step()
-        self.apply_mask()
+        if self._bind_optimizer_masks():
+            if self.args.distributed:
+                self.synchronism_masks()
+            self.optimizer.step()                       # AdamW update and w *= mask in one launch (sparse_core.py:300-303)
+        else:
+            self.optimizer.step()
+            self.apply_mask()
         self.prune_rate_decay.step()
         self.prune_rate = self.prune_rate_decay.get_dr(self.prune_rate)
         self.steps += 1
@@ -385,6 +402,75 @@ class Masking(object):
                 print('{0}: {1}->{2}, density: {3:.3f}'.format(name, self.name2nonzeros.get(name), num_nonzeros,
                                                                num_nonzeros / float(mask.numel())))
         print('Prune rate: {0}\n'.format(self.prune_rate))
+
+    # ------------------------------------------------------------------ persistence
+    _BITW = (128, 64, 32, 16, 8, 4, 2, 1)               # numpy.packbits bit order (most significant bit first)
+
+    @classmethod
+    def pack_mask(cls, m):
+        """fp32 0/1 mask -> uint8 CPU tensor, 1 bit per weight, numpy.packbits layout."""
+        bits = (m.reshape(-1) != 0).to(torch.int32)
+        pad = (-bits.numel()) % 8
+        if pad:
+            bits = torch.cat([bits, bits.new_zeros(pad)])
+        return (bits.view(-1, 8) * torch.tensor(cls._BITW, dtype=torch.int32, device=bits.device)).sum(1).to(torch.uint8).cpu()
+
+    @classmethod
+    def unpack_mask(cls, packed, shape):
+        n = 1
+        for d in shape:
+            n *= d
+        w = torch.tensor(cls._BITW, dtype=torch.int32)
+        return ((packed.to(torch.int32).view(-1, 1) & w) != 0).reshape(-1)[:n].to(torch.float32).view(shape)
+
+    def state_dict(self):
+        """Everything a checkpoint needs to resume a sparse run with the SAME masks: the masks bit-packed (1 bit per weight, MSB
+        first like numpy.packbits), the step counter, the current prune rate and the scheduler position.  The reference does not
+        save masks: a resumed run re-derives them as ``weight != 0`` (``--sparse_init resume``, sparse_core.py:158-172), which
+        drops the mask bit of every kept weight that happens to be exactly zero (e.g. freshly regrown ones: funcs.py:196-205
+        grows weights at value 0) and forgets the prune-rate schedule.  utils.save_model (utils.py:447-469) has no mask entry;
+        slak_amd.checkpoint.save_model adds this dict under ``'mask'``."""
+        packed = {name: self.pack_mask(m) for name, m in self.masks.items()}
+        shapes = {name: tuple(m.shape) for name, m in self.masks.items()}
+        return {"masks": packed, "shapes": shapes, "steps": self.steps, "prune_rate": self.prune_rate,
+                "decay_last_epoch": self.prune_rate_decay.cosine_stepper.last_epoch if hasattr(self.prune_rate_decay, "cosine_stepper") else None,
+                "density": getattr(self, "density", None), "baseline_nonzero": self.baseline_nonzero}
+
+    def load_state_dict(self, state):
+        """Inverse of state_dict() on a Masking that went through add_module() on the same architecture: masks are overwritten IN
+        PLACE (device plans and the optimizer's mask bindings stay valid), re-applied to the weights, and the schedule is put back."""
+        shapes = state["shapes"]
+        known = {}
+        for module in self.modules:
+            for name, tensor in module.named_parameters():
+                known[name] = tensor
+        for name in state["masks"]:
+            if name not in known or tuple(known[name].shape) != tuple(shapes[name]):
+                raise KeyError("saved mask %r does not match a parameter of the registered modules" % name)
+        new = {}
+        for name, packed in state["masks"].items():
+            bits = self.unpack_mask(packed, shapes[name])
+            if name in self.masks:
+                self.masks[name].copy_(bits)
+                new[name] = self.masks[name]
+            else:
+                new[name] = bits.to(self.device)
+        self.masks = new                                  # entries the saved run had popped as dense stay unmasked
+        self.names = list(new.keys())
+        self.steps = int(state["steps"])
+        self.prune_rate = state["prune_rate"]
+        if state.get("density") is not None:
+            self.density = state["density"]
+        self.baseline_nonzero = state.get("baseline_nonzero", self.baseline_nonzero)
+        last = state.get("decay_last_epoch")
+        if last is not None and hasattr(self.prune_rate_decay, "cosine_stepper"):
+            st = self.prune_rate_decay.cosine_stepper
+            while st.last_epoch < last:                  # closed-form schedule: replaying the steps reproduces the fp64 rate exactly
+                st.step()
+        self._plan_key = None
+        self._opt_masks_key = None
+        self._synced_once = False
+        self.apply_mask()
 
     def mask_checksum(self):
         """64-bit order-independent checksum of all masks (device kernel); equal on every rank iff masks agree."""

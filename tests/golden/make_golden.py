@@ -200,10 +200,59 @@ def make_masks():
                         pruned=pruned.numpy(), grown=grown.numpy(), rate=np.array(0.25), removed=np.array(removed))
     print("wrote mask_funcs")
 
+# --------------------------------------------------------------------------- EMA fixtures
+def make_ema():
+    """The reference's ModelEma (model_sema.py, imported unmodified) over a run of the reference's Masking + torch AdamW on CPU:
+    7 steps, prune-and-grow at steps 3 and 6 (so regrown weights exercise the new_weighs_diff branch), BatchNorm counters advancing
+    (int64 entries).  Stored: the model's state dict before every update, the masks, and the EMA state dict after every update;
+    plus a dense run (mask=None)."""
+    import contextlib, io
+    sys.path.insert(0, REF)
+    import model_sema  # noqa: E402  (the reference, unmodified)
+    for tag, sparse in (("masked", True), ("dense", False)):
+        torch.manual_seed(321)
+        model = TinyNet()
+        for p in model.parameters():
+            p.data = torch.randn_like(p) * 0.05
+        opt = torch.optim.AdamW(model.parameters(), lr=1e-2, weight_decay=0.05)
+        mask = None
+        if sparse:
+            with contextlib.redirect_stdout(io.StringIO()):
+                mask = _ref_masking(model, opt, False, sparsity=0.5, update_frequency=3, prune_rate=0.4, T_max=20, seed=11)
+        ema = model_sema.ModelEma(model, decay=0.99)
+        keys = list(ema.ema.state_dict().keys())
+        out = {"keys": np.array(keys), "decay": np.array(0.99, np.float64),
+               "mask_names": np.array(list(mask.masks.keys()) if sparse else [], dtype=str)}
+        for k, v in ema.ema.state_dict().items():
+            out[f"e0/{k}"] = v.numpy().copy()
+        g = torch.Generator().manual_seed(17)
+        nsteps = 7
+        for step in range(1, nsteps + 1):
+            for n, p in model.named_parameters():
+                p.grad = torch.randn(p.shape, generator=g) * 0.1
+            with contextlib.redirect_stdout(io.StringIO()):
+                mask.step() if sparse else opt.step()
+            for m in model.modules():                                   # what a training forward does to BatchNorm buffers
+                if isinstance(m, nn.BatchNorm2d):
+                    m.num_batches_tracked += 1
+                    m.running_mean += torch.randn(m.running_mean.shape, generator=g) * 0.01
+                    m.running_var *= 1.0 + 0.01 * torch.rand(m.running_var.shape, generator=g)
+            for k, v in model.state_dict().items():
+                out[f"w{step}/{k}"] = v.numpy().copy()
+            if sparse:
+                for n in mask.masks:
+                    out[f"m{step}/{n}"] = mask.masks[n].numpy().copy()
+            ema.update(model, mask)                                     # model_sema.py:67-91
+            for k, v in ema.ema.state_dict().items():
+                out[f"e{step}/{k}"] = v.numpy().copy()
+        out["meta"] = np.array([nsteps], np.int64)
+        np.savez_compressed(os.path.join(HERE, f"ema_{tag}.npz"), **out)
+        print("wrote ema_%s (%d entries)" % (tag, len(keys)))
+
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", choices=["conv", "mask"], default=None)
+    ap.add_argument("--only", choices=["conv", "mask", "ema"], default=None)
     a = ap.parse_args()
     if not os.path.isdir(REF):
         sys.exit("needs /root/reference (build container only)")
@@ -211,3 +260,5 @@ if __name__ == "__main__":
         make_conv()
     if a.only in (None, "mask"):
         make_masks()
+    if a.only in (None, "ema"):
+        make_ema()

@@ -103,3 +103,50 @@ def test_cosine_decay_matches_closed_form():
             d.step()
             want = 0.005 + (0.3 - 0.005) * (1 + math.cos(math.pi * s / 50)) / 2
             assert abs(d.get_dr(0.3) - want) < 1e-12
+
+
+def test_optimizer_and_ema_have_no_cpu_fallback():
+    """SURVEY 8f-3 product path: CPU tensors are refused loudly instead of being routed through torch ops or the oracle."""
+    import torch
+    from slak_amd import _lib
+    from slak_amd.model_sema import ModelEma
+    from slak_amd.optim_factory import MaskedAdamW
+    m = torch.nn.Linear(4, 4)
+    ema = ModelEma(m)
+    with pytest.raises(_lib.SlakHipError):
+        ema.update(m, None)
+    p = torch.nn.Parameter(torch.zeros(4))
+    p.grad = torch.ones(4)
+    with pytest.raises(_lib.SlakHipError):
+        MaskedAdamW([p]).step()
+
+
+def test_parameter_groups_follow_the_reference_rule():
+    """optim_factory.py:73-112: 1-D parameters and biases get no weight decay; layer ids of optim_factory.py:32-59."""
+    import contextlib, io
+    import torch
+    from slak_amd import optim_factory as OF
+    net = torch.nn.Sequential(torch.nn.Linear(3, 4), torch.nn.LayerNorm(4))
+    with contextlib.redirect_stdout(io.StringIO()):
+        groups = OF.get_parameter_groups(net, weight_decay=0.05)
+    assert [(g["weight_decay"], len(g["params"]), g["lr_scale"]) for g in groups] == [(0.05, 1, 1.0), (0.0, 3, 1.0)]
+    ids = [OF.get_num_layer_for_convnext(n) for n in ("downsample_layers.0.0.weight", "downsample_layers.2.1.bias", "stages.0.2.gamma",
+                                                      "stages.2.7.pwconv1.weight", "stages.3.0.norm.bias", "head.weight")]
+    assert ids == [0, 3, 1, 5, 12, 13]
+    assigner = OF.LayerDecayValueAssigner([0.5 ** (13 - i) for i in range(14)])
+    with contextlib.redirect_stdout(io.StringIO()):
+        groups = OF.get_parameter_groups(net, 0.05, (), lambda n: 13, assigner.get_scale)
+    assert all(g["lr_scale"] == 1.0 for g in groups)
+
+
+def test_mask_bit_packing_round_trip():
+    """Masking.state_dict stores masks 1 bit per weight in numpy.packbits order."""
+    import numpy as np
+    import torch
+    from slak_amd.sparse_core import Masking
+    g = torch.Generator().manual_seed(0)
+    for shape in [(1,), (7,), (8,), (3, 1, 51, 5), (96, 384), (5, 1, 5, 5)]:
+        m = (torch.rand(shape, generator=g) < 0.4).float()
+        p = Masking.pack_mask(m)
+        np.testing.assert_array_equal(p.numpy(), np.packbits(m.numpy().reshape(-1).astype(np.uint8)))
+        assert torch.equal(Masking.unpack_mask(p, shape), m)

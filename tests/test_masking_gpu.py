@@ -30,7 +30,8 @@ def _args(device, only_L=False, update_frequency=3, sparsity=0.4, distributed=Fa
 
 
 # ------------------------------------------------------------------ (1) recorded reference runs
-@pytest.mark.parametrize("tag,only_L,opt_kind", [("all_sgd", False, "sgd"), ("onlyL_adamw", True, "adamw")])
+@pytest.mark.parametrize("tag,only_L,opt_kind", [("all_sgd", False, "sgd"), ("onlyL_adamw", True, "adamw"),
+                                                 ("onlyL_adamw", True, "masked_adamw")])
 def test_recorded_reference_run(tag, only_L, opt_kind, gpu):
     from make_golden import TinyNet                      # same tiny module the fixtures were recorded on
     from slak_amd.sparse_core import CosineDecay, Masking
@@ -43,6 +44,9 @@ def test_recorded_reference_run(tag, only_L, opt_kind, gpu):
     model = model.to(gpu)
     if opt_kind == "sgd":
         opt = torch.optim.SGD(model.parameters(), lr=0.05, momentum=0.9)
+    elif opt_kind == "masked_adamw":                      # AdamW + w *= mask as one HIP launch
+        from slak_amd.optim_factory import MaskedAdamW
+        opt = MaskedAdamW(model.parameters(), lr=1e-2, weight_decay=0.05)
     else:
         opt = torch.optim.AdamW(model.parameters(), lr=1e-2, weight_decay=0.05)
     decay = CosineDecay(0.3, T_max)

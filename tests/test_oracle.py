@@ -89,3 +89,48 @@ def test_mask_truncate_matches_reference_masking(tag):
     # cosine schedule closed form == recorded torch scheduler values
     for s_ in range(1, nsteps + 1):
         assert abs(oracle.cosine_prune_rate(0.3, T_max, s_) - g["prune_rates"][s_ - 1]) < 1e-12
+
+
+# ------------------------------------------------------------------ EMA update and the AdamW step
+def _bits(a):
+    return a.view(np.int32) if a.dtype == np.float32 else a
+
+
+@pytest.mark.parametrize("tag", ["masked", "dense"])
+def test_ema_oracle_matches_reference_model_ema(tag):
+    """oracle/optim_ema_oracle.py vs the recorded run of the UNMODIFIED reference ModelEma: bit-exact over 7 updates, including
+    the entries regrown by prune-and-grow and BatchNorm's int64 counters."""
+    from oracle import optim_ema_oracle as O
+    g = load_golden("ema_" + tag)
+    keys = [str(k) for k in g["keys"]]
+    names = [str(n) for n in g["mask_names"]]
+    e = {k: g[f"e0/{k}"] for k in keys}
+    regrown = 0
+    for step in range(1, int(g["meta"][0]) + 1):
+        masks = {n: g[f"m{step}/{n}"] for n in names}
+        regrown += sum(int(((e[n] == 0) & (masks[n] != 0)).sum()) for n in names)
+        e = O.ema_update(e, {k: g[f"w{step}/{k}"] for k in keys}, float(g["decay"]), masks)
+        for k in keys:
+            np.testing.assert_array_equal(_bits(e[k]), _bits(g[f"e{step}/{k}"]), err_msg=f"{k} step {step}")
+    assert (regrown > 0) == (tag == "masked")
+    assert any(g[f"e0/{k}"].dtype == np.int64 for k in keys)
+
+
+def test_adamw_oracle_matches_torch_adamw_with_reference_masking():
+    """oracle adamw_step (+ mask) vs the recorded torch.optim.AdamW + reference Masking run on CPU.  torch's CPU kernels contract
+    some of the multiply-adds, so agreement is to float32 round-off per step: 1e-6 of each tensor's magnitude over 7 steps."""
+    from oracle import optim_ema_oracle as O
+    g = load_golden("mask_onlyL_adamw")
+    pnames, mnames = [str(n) for n in g["param_names"]], [str(n) for n in g["names"]]
+    nsteps, ufreq, _ = (int(v) for v in g["meta"])
+    w = {n: g[f"w_init/{n}"] for n in pnames}
+    m = {n: np.zeros_like(w[n]) for n in pnames}
+    v = {n: np.zeros_like(w[n]) for n in pnames}
+    for step in range(1, nsteps + 1):
+        for n in pnames:
+            mask = (g[f"m{step - 1}/{n}"] if step > 1 else g[f"m_init/{n}"]) if n in mnames else None
+            w[n], m[n], v[n] = O.adamw_step(w[n], g[f"g{step}/{n}"], m[n], v[n], step, 1e-2, 0.9, 0.999, 1e-8, 0.05, mask)
+            if n in mnames and step % ufreq == 0:
+                w[n] = w[n] * g[f"m{step}/{n}"]                      # truncate_weights ends with apply_mask (sparse_core.py:357)
+            ref = g[f"w{step}/{n}"]
+            assert np.abs(ref - w[n]).max() <= 1e-6 * np.abs(ref).max() + 1e-12, (n, step)

@@ -6,7 +6,7 @@ db = sys.argv[1]
 top = int(sys.argv[sys.argv.index("--top") + 1]) if "--top" in sys.argv else 40
 c = sqlite3.connect(db)
 rows = list(c.execute("select name, start, end from kernels order by start"))
-adam = [r for r in rows if "multi_tensor_apply" in r[0]]
+adam = [r for r in rows if "multi_tensor_apply" in r[0] or "slak::adamw_kernel" in r[0]]
 steps = []
 for r in adam:
     if not steps or r[1] - steps[-1][-1] > 10e6: steps.append([r[1]])
@@ -19,6 +19,7 @@ for n, s, e in rows:
         agg[n][0] += 1; agg[n][1] += e - s
 tot = sum(v[1] for v in agg.values())
 def cat(n):
+    if "slak::adamw" in n or "slak::ema" in n: return "optimizer"
     if "slak::dwconv" in n or "toeplitz" in n: return "slak dwconv"
     if "slak::ln_" in n or "slak::scale_res" in n or "block_tail" in n: return "slak block tail"
     if "slak::" in n: return "slak other"
