@@ -4,7 +4,9 @@
 //   G_r[o, i] = sum_{n,u} dY[o, u] * X[i, u + r - 2]      (o, i = image rows, u = image columns)      dw[tau, r] = sum_o G_r[o, o+tau-padL]
 // The contraction index u runs along image rows, so both MFMA operands are plain 16-byte reads of 8 consecutive elements of a
 // row -- if the shifted operand X[i, u + s] is available at a 4-byte aligned address for every tap shift s = -2..2.  Even
-// shifts are (+-4 bytes); for the odd ones a SECOND copy of the plane, shifted by one element, is fetched by the DMA itself:
+// shifts are whole dwords (the fragment is a selection of four dwords out of three aligned 16-byte chunks held in registers:
+// 4-byte LDS reads at a 16-byte-multiple lane stride are four-way bank conflicted and are avoided entirely, see the k-loop);
+// for the odd ones a SECOND copy of the plane, shifted by one element, is fetched by the DMA itself:
 // `buffer_load_dwordx4 ... lds` accepts a 2-byte-aligned source (tools/dma_probe.hip, shift = 1), so copy c1[j] = x[j-1]
 // costs one more L2->LDS transfer and no LDS pass.  (dwconv_mfma_wgrad_dma.hip transposes both planes LDS->LDS for this case
 // and spends twice the horizontal kernel's time per plane doing it.)
@@ -19,7 +21,7 @@
 
 namespace slak {
 
-constexpr int VR_NB = 2;                // ring depth: the next plane streams in while the current one is consumed
+constexpr int VR_NB_DEFAULT = 2;        // ring depth: the next nb-1 planes stream in while the current one is consumed (env SLAK_VROWS_NB)
 constexpr int VR_MAX_IPW = 8;           // DMA instructions per wave per plane (upper bound)
 
 struct WgradRowsParams {
@@ -29,6 +31,7 @@ struct WgradRowsParams {
     int ipc;               // DMA instructions per plane copy: ceil(H * CPR / 64)
     int KS;                // 16-deep k-steps per plane: ceil(W / 16)
     int planes_per_wg, slices;
+    int nb;                // ring depth (slots)
     unsigned tensor_bytes;
 };
 
@@ -42,7 +45,7 @@ __global__ __launch_bounds__(MF_THREADS, 3) void dwconv_mfma_wgrad_vrows_kernel(
     const unsigned copy_b = (unsigned)p.ipc * 1024;               // one plane copy (whole DMA instructions)
     const unsigned slot_b = 3 * copy_b;                           // [dY][X][X shifted by one element]
     const unsigned ring_b = 64;                                   // 64 zero bytes in front: "row -1" of the first plane
-    unsigned live_b = VR_NB * slot_b; if (live_b < MF_WAVES * 32 * 64 * 4) live_b = MF_WAVES * 32 * 64 * 4;   // >= the epilogue scratch
+    unsigned live_b = (unsigned)p.nb * slot_b; if (live_b < MF_WAVES * 32 * 64 * 4) live_b = MF_WAVES * 32 * 64 * 4;   // >= the epilogue scratch
     float* dwl = (float*)(LB + ring_b + live_b);                  // [MF_WAVES][ntap]
     float* scratch = (float*)(LB + ring_b);                       // [MF_WAVES][32][64]: aliases the (dead) ring
 
@@ -84,7 +87,7 @@ __global__ __launch_bounds__(MF_THREADS, 3) void dwconv_mfma_wgrad_vrows_kernel(
         if (g >= iters) return;
         const int n0 = n_begin + g;
         const unsigned gbase = (unsigned)(((size_t)n0 * p.C + c) * HW * 2);
-        const unsigned slot = lds_base + ring_b + (unsigned)(g % VR_NB) * slot_b;
+        const unsigned slot = lds_base + ring_b + (unsigned)(g % p.nb) * slot_b;
 #pragma unroll
         for (int k = 0; k < VR_MAX_IPW; ++k) {
             if (ins_t[k] >= 0) {                                      // wave-uniform
@@ -98,7 +101,10 @@ __global__ __launch_bounds__(MF_THREADS, 3) void dwconv_mfma_wgrad_vrows_kernel(
             }
         }
     };
-    issue_plane(0);
+    int my_instr = 0;                                             // DMA instructions this wave issues per plane (for the counted wait)
+#pragma unroll
+    for (int k = 0; k < VR_MAX_IPW; ++k) my_instr += (ins_t[k] >= 0 && __builtin_amdgcn_ballot_w64(ins_ok[k]) != 0) ? 1 : 0;
+    for (int g = 0; g < p.nb - 1; ++g) issue_plane(g);
 
     f32x16 acc[NG];
 #pragma unroll
@@ -114,22 +120,24 @@ __global__ __launch_bounds__(MF_THREADS, 3) void dwconv_mfma_wgrad_vrows_kernel(
     const unsigned m_first = lhi == 0 ? 0xffff0000u : 0xffffffffu;
     const int ks_last = (p.W - 1) >> 4;
     const unsigned m_last = lhi == (((p.W - 1) & 15) >> 3) ? 0x0000ffffu : 0xffffffffu;
-    auto rd16 = [&](unsigned addr) -> s16x8 { return __builtin_bit_cast(s16x8, *(const u32x4*)(LB + addr)); };
-    auto rd4 = [&](unsigned addr) -> u32x4 { const unsigned* q = (const unsigned*)(LB + addr); return u32x4{q[0], q[1], q[2], q[3]}; };
-    auto load_b = [&](int g, unsigned xb, int ks) -> s16x8 {          // tap g: X[i, u + g - 2]
-        const unsigned a = xb + (unsigned)ks * 32;
-        if (g == 2) return rd16(a);
-        if (g == 0) return __builtin_bit_cast(s16x8, rd4(a - 4));
-        if (g == 4) return __builtin_bit_cast(s16x8, rd4(a + 4));
-        if (g == 1) { u32x4 v = *(const u32x4*)(LB + a + copy_b); if (ks == 0) v[0] &= m_first; return __builtin_bit_cast(s16x8, v); }
-        u32x4 v = rd4(a + copy_b + 4); if (ks == ks_last) v[3] &= m_last; return __builtin_bit_cast(s16x8, v);
-    };
+    // Fragments are assembled from ALIGNED 16-byte reads only.  A lane's addresses are a multiple of 16 bytes apart from its neighbours'
+    // (one image row per lane), so a 4-byte ds_read hits 16 of the 64 banks: four-way conflicts, 8 cycles per wave instruction against
+    // 4 for a conflict-free b128 that moves four times the data (the first version fetched the +-2 taps with four b32 reads each and
+    // spent 5/6 of its LDS time on them).  A tap shift of 2 elements is exactly one dword, so with the previous / current / next
+    // chunk in registers every tap is a selection of four dwords:
+    //   s=-2: {P.w, C.x, C.y, C.z}   s=0: C   s=+2: {C.y, C.z, C.w, N.x}        (P, C, N: chunks of the X copy)
+    //   s=-1: C1                              s=+1: {C1.y, C1.z, C1.w, N1.x}      (C1, N1: chunks of the copy shifted by one element)
+    // and P of the next k-step is N of this one.
+    auto rdq = [&](unsigned addr) -> u32x4 { return *(const u32x4*)(LB + addr); };
+    auto rd16 = [&](unsigned addr) -> s16x8 { return __builtin_bit_cast(s16x8, rdq(addr)); };
+    auto frag = [](unsigned d0, unsigned d1, unsigned d2, unsigned d3) -> s16x8 { return __builtin_bit_cast(s16x8, u32x4{d0, d1, d2, d3}); };
 
     for (int it = 0; it < iters; ++it) {
-        wait_vmcnt<0>();                                          // my DMAs of plane `it` (the only ones in flight) have landed
-        wg_barrier();                                             // everyone's have; everyone is done with the other slot
-        issue_plane(it + 1);                                      // streams in while this plane is consumed
-        const unsigned slot = ring_b + (unsigned)(it % VR_NB) * slot_b;
+        int later = iters - 1 - it; if (later > p.nb - 2) later = p.nb - 2;       // planes issued after `it` that may still be in flight
+        wait_vmcnt_dyn(later * my_instr);                         // my DMAs of plane `it` have landed (loads retire in order)
+        wg_barrier();                                             // everyone's have; everyone is done with the slot refilled next
+        issue_plane(it + p.nb - 1);                               // streams in while this and the following planes are consumed
+        const unsigned slot = ring_b + (unsigned)(it % p.nb) * slot_b;
         if (n_begin + it == 0 && c == 0) {
             // the very first chunk of the tensor could not be fetched from offset -2: it landed unshifted -> shift it by hand
             if (tid == 0) {
@@ -149,22 +157,40 @@ __global__ __launch_bounds__(MF_THREADS, 3) void dwconv_mfma_wgrad_vrows_kernel(
             wg_barrier();
         }
         const unsigned ab = slot + a_off, xb = slot + x_off;
-        // k-loop, pinned software pipeline: tap g's fragment of the next k-step is fetched right after this k-step's MFMA g
+        // k-loop, pinned software pipeline: the five 16-byte reads of the next k-step are issued one behind each of this k-step's MFMAs
+        const unsigned c1b = xb + copy_b;
         s16x8 a = rd16(ab), b[NG];
-#pragma unroll
-        for (int g = 0; g < NG; ++g) b[g] = load_b(g, xb, 0);
+        u32x4 P = rdq(xb - 16), C = rdq(xb), N = rdq(xb + 16), C1 = rdq(c1b), N1 = rdq(c1b + 16);
+        C1[0] &= m_first;
+        if (ks_last == 0) N1[0] &= m_last;
+        b[0] = frag(P[3], C[0], C[1], C[2]); b[1] = __builtin_bit_cast(s16x8, C1); b[2] = __builtin_bit_cast(s16x8, C);
+        b[3] = frag(C1[1], C1[2], C1[3], N1[0]); b[4] = frag(C[1], C[2], C[3], N[0]);
         __builtin_amdgcn_sched_barrier(0);
         for (int ks = 0; ks < p.KS; ++ks) {
             const int kn = ks + 1 < p.KS ? ks + 1 : ks;            // last k-step: re-read (discarded)
+            const unsigned xo = xb + (unsigned)kn * 32, co = c1b + (unsigned)kn * 32;
             const s16x8 an = rd16(ab + (unsigned)kn * 32);
             __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int g = 0; g < NG; ++g) {
-                acc[g] = mfma32<T>(a, b[g], acc[g]);
-                b[g] = load_b(g, xb, kn);
-                __builtin_amdgcn_sched_barrier(0);
-            }
+            acc[0] = mfma32<T>(a, b[0], acc[0]);
+            const u32x4 Cn = rdq(xo);
+            __builtin_amdgcn_sched_barrier(0);
+            acc[1] = mfma32<T>(a, b[1], acc[1]);
+            const u32x4 Nn = rdq(xo + 16);
+            __builtin_amdgcn_sched_barrier(0);
+            acc[2] = mfma32<T>(a, b[2], acc[2]);
+            u32x4 C1n = rdq(co);
+            __builtin_amdgcn_sched_barrier(0);
+            acc[3] = mfma32<T>(a, b[3], acc[3]);
+            u32x4 N1n = rdq(co + 16);
+            __builtin_amdgcn_sched_barrier(0);
+            acc[4] = mfma32<T>(a, b[4], acc[4]);
+            if (kn == ks_last) N1n[0] &= m_last;
+            b[0] = frag(N[3], Cn[0], Cn[1], Cn[2]);               // this k-step's N is the next one's P
+            b[1] = __builtin_bit_cast(s16x8, C1n); b[2] = __builtin_bit_cast(s16x8, Cn);
+            b[3] = frag(C1n[1], C1n[2], C1n[3], N1n[0]); b[4] = frag(Cn[1], Cn[2], Cn[3], Nn[0]);
+            N = Nn;
             a = an;
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
     wait_vmcnt<0>();
@@ -223,11 +249,13 @@ static bool fill_vrows_params(WgradRowsParams& p, const ConvDims& d, int residen
     const int per = (d.N + slices - 1) / slices;
     p.planes_per_wg = per; p.slices = (d.N + per - 1) / per;
     p.tensor_bytes = (unsigned)((size_t)d.N * d.C * d.H * d.W * 2);
+    static const int nb_env = [] { const char* e = getenv("SLAK_VROWS_NB"); const int v = e ? atoi(e) : VR_NB_DEFAULT; return v < 2 ? 2 : (v > 4 ? 4 : v); }();
+    p.nb = nb_env;
     return (size_t)d.N * d.C * d.H * d.W * 2 < 0x7fffffffull;         // (signed source offsets in the DMA plan)
 }
 
 static size_t vrows_lds_bytes(const WgradRowsParams& p) {
-    size_t live = (size_t)VR_NB * 3 * p.ipc * 1024, scratch = (size_t)MF_WAVES * 32 * 64 * 4;
+    size_t live = (size_t)p.nb * 3 * p.ipc * 1024, scratch = (size_t)MF_WAVES * 32 * 64 * 4;
     if (live < scratch) live = scratch;
     return 64 + live + (size_t)MF_WAVES * p.kh * p.kw * 4 + 32;
 }
@@ -235,7 +263,7 @@ static size_t vrows_lds_bytes(const WgradRowsParams& p) {
 bool dwconv_mfma_wgrad_vrows_supported(const ConvDims& d, int dy_dt, int x_dt) {
     if (dy_dt != x_dt || (x_dt != SLAK_BF16 && x_dt != SLAK_F16)) return false;
     WgradRowsParams p;
-    return fill_vrows_params(p, d, 512) && vrows_lds_bytes(p) <= 64 * 1024;
+    return fill_vrows_params(p, d, 512) && vrows_lds_bytes(p) <= 100 * 1024;
 }
 
 size_t dwconv_mfma_wgrad_vrows_workspace(const ConvDims& d) {

@@ -60,7 +60,10 @@ def _worker(rank, world, port, out):
     net = M.SLaK(in_chans=3, num_classes=10, depths=[2, 2, 2, 1], dims=[16, 32, 64, 128], drop_path_rate=0.0,
                  kernel_size=[13, 13, 9, 7, 5], Decom=True, bn=True, lowp_dwconv=True).to(dev)
     ddp2 = nn.parallel.DistributedDataParallel(net, device_ids=[0])
-    opt2 = torch.optim.AdamW(ddp2.parameters(), lr=1e-3, fused=True)
+    from slak_amd.optim_factory import MaskedAdamW
+    from slak_amd.model_sema import ModelEma
+    ema = ModelEma(net, decay=0.9)                                 # built from the unwrapped model, as main.py:341 does
+    opt2 = MaskedAdamW(ddp2.parameters(), lr=1e-3)                 # AdamW + w *= mask + bf16 copies, one launch (what bench.py runs)
     margs = types.SimpleNamespace(device=str(dev), fix=False, update_frequency=2, only_L=False, sparse_init="uniform", sparsity=0.4,
                                   distributed=True)
     with contextlib.redirect_stdout(io.StringIO()):
@@ -76,8 +79,13 @@ def _worker(rank, world, port, out):
         with contextlib.redirect_stdout(io.StringIO()):
             mask.step()
         opt2.zero_grad(set_to_none=True)
+        ema.update(ddp2, mask)                                     # 'module.'-prefixed keys on the model side (model_sema.py:69-76)
     assert torch.isfinite(loss2).item()
-    flat = torch.cat([p.detach().float().flatten() for p in net.parameters()] + [m.flatten() for m in mask.masks.values()])
+    masked_ok = all(bool(((dict(ddp2.named_parameters())[n] == 0) | (m != 0)).all()) for n, m in mask.masks.items())
+    res["weights_respect_masks"] = masked_ok
+    res["ema_moved"] = bool(any((a != b).any() for a, b in zip(ema.ema.parameters(), net.parameters())))
+    flat = torch.cat([p.detach().float().flatten() for p in net.parameters()] + [m.flatten() for m in mask.masks.values()] +
+                     [p.detach().float().flatten() for p in ema.ema.parameters()])
     other = [torch.empty_like(flat) for _ in range(world)]
     dist.all_gather(other, flat)
     res["ranks_identical"] = bool(torch.equal(other[0], other[1]))
@@ -95,7 +103,8 @@ def test_two_ranks_match_single_process(gpu, tmp_path):
     out = str(tmp_path / "r0.pt")
     mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
     got = torch.load(out)
-    assert got["ranks_identical"], "ranks diverged (weights or masks) after DDP + Masking steps"
+    assert got["ranks_identical"], "ranks diverged (weights, masks or EMA) after DDP + Masking steps"
+    assert got["weights_respect_masks"] and got["ema_moved"]
     assert 0.55 <= got["mask_density"] <= 0.65, got["mask_density"]
     # single process, full batch
     from slak_amd import block_ops

@@ -4,7 +4,7 @@ cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 mkdir -p $R/gpurun_out/sum
 rm -rf /tmp/pb && rocprofv3 --kernel-trace --stats -d /tmp/pb -o bench -- python $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline --kernel-reps 3 > /tmp/pb.log 2>&1
-tail -1 /tmp/pb.log > $R/gpurun_out/sum/bench_under_rocprof.json
+grep '^{' /tmp/pb.log | tail -1 > $R/gpurun_out/sum/bench_under_rocprof.json
 DB=$(find /tmp/pb -name "*.db" | head -1)
 python $R/tools/rocpd_summary.py $DB --top 70 > $R/gpurun_out/sum/bench_kernel_stats.txt
 python $R/tools/step_breakdown.py $DB --top 45 > $R/gpurun_out/sum/step_breakdown.txt

@@ -4,8 +4,11 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from slak_amd import ops
 dev = torch.device("cuda:0")
+_R = int(os.environ.get("SLAK_TIME_ALL_REPS", "0"))
 def ev(fn, reps=20, batches=5):
-    for _ in range(20): fn()
+    if _R:
+        reps, batches = _R, 1
+    for _ in range(2 if _R else 20): fn()
     best = 1e30
     for _ in range(batches):                      # min over batches: robust against clock ramp / stray activity
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
