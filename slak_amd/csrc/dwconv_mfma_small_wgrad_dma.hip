@@ -10,7 +10,7 @@
 //   * vertical kernels (Kx5) transpose both planes LDS->LDS first (one transposing read + one 8-byte write per plane) and
 //     run the same core on dY^T, X^T;
 //   * no global stores in the loop: the counted `s_waitcnt vmcnt(N)` only sees this wave's own DMAs;
-//   * diagonal sums through a per-wave 16x17 fp32 tile in fixed order, partial per slice, last-arriver reduction
+//   * diagonal sums through a skewed per-wave 16x32 fp32 tile in fixed order, partial per slice, last-arriver reduction
 //     (wgrad_finish): bitwise reproducible.
 #include "mfma_common.h"
 
@@ -18,14 +18,14 @@ namespace slak {
 
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 
-constexpr int SWD_NS = 4;               // ring slots (plane pairs of both tensors) per wave
+// ring slots (plane pairs of both tensors) per wave: template parameter NS (4: 47 KB per workgroup, 3 workgroups per CU; 3: 39 KB, 4 per CU)
 constexpr int SWD_SLOT = 2048;          // bytes per slot: [dY pair 1024][X pair 1024]
 // per-wave LDS region (bytes): [64 zero pad][ring][64 zero pad][dY^T pair][X^T pair][64 pad][res: 256 floats]
 constexpr int SWD_RING = 64;
-constexpr int SWD_T = SWD_RING + SWD_NS * SWD_SLOT + 64;
-constexpr int SWD_RES = SWD_T + 2048 + 64;
-constexpr int SWD_WAVE_BYTES = SWD_RES + 320 * 4;
-static_assert(SWD_NS * SWD_SLOT >= 16 * 17 * 4, "the diagonal-sum tile aliases the ring");
+constexpr int swd_t(int ns) { return SWD_RING + ns * SWD_SLOT + 64; }
+constexpr int swd_res(int ns) { return swd_t(ns) + 2048 + 64; }
+constexpr int swd_wave_bytes(int ns) { return swd_res(ns) + 320 * 4; }
+static_assert(3 * SWD_SLOT >= 16 * 32 * 4, "the diagonal-sum tile aliases the ring");
 
 struct SmallWgradDmaParams {
     const void* dy; const void* x; float* partial; float* dw; unsigned* counters;
@@ -42,8 +42,9 @@ template <> __device__ __forceinline__ f32x4_t swd_mfma16<f16_t>(s16x8 a, s16x8 
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
 }
 
-template <typename T, bool VERT>
+template <typename T, bool VERT, int SWD_NS>
 __global__ __launch_bounds__(MF_THREADS) void dwconv_mfma_small_wgrad_dma_kernel(const SmallWgradDmaParams p) {
+    constexpr int SWD_T = swd_t(SWD_NS), SWD_RES = swd_res(SWD_NS), SWD_WAVE_BYTES = swd_wave_bytes(SWD_NS);
     extern __shared__ __attribute__((aligned(16))) uint16_t lds[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = wave_id_uniform();
@@ -139,33 +140,46 @@ __global__ __launch_bounds__(MF_THREADS) void dwconv_mfma_small_wgrad_dma_kernel
     }
 
     // ---- diagonal sums: D of tap r: column i-slot = lane & 15, rows o-slot = 4*(lane>>4) + reg; slot s holds long-axis
-    // position s (s < 8) or s - (16 - Wt) (horizontal kernels: duplicated columns); lane dd adds the diagonal i - o = dd - 15.
+    // position s (s < 8) or s - (16 - Wt) (horizontal kernels: duplicated columns, not valid).  The 16x16 tile of a tap is written
+    // SKEWED -- G[o][i] to row o-slot, column pos(i) - pos(o) + 15 -- so that a diagonal becomes a column and lane dd just adds the
+    // 16 rows of column dd (unconditional reads at immediate offsets; invalid slots are never written and stay zero).  The first
+    // version resolved slots and validity per read: 130 VALU per tap and wave, more than the whole streaming loop of a slice.
     if (live) {
-        float* tile = (float*)(L + SWD_RING);                     // [16][17] fp32: the ring is dead
+        float* tile = (float*)(L + SWD_RING);                     // [16][32] fp32: the ring is dead
         float* res = (float*)(L + SWD_RES);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const int dup = VERT ? 0 : 16 - p.Wt;                     // slot of position pos: pos < 8 ? pos : pos + dup
-        const int dd = lane;
+        *(u32x4*)((char*)tile + lane * 16) = u32x4{0u, 0u, 0u, 0u};
+        *(u32x4*)((char*)tile + 1024 + lane * 16) = u32x4{0u, 0u, 0u, 0u};
+        const int dup = VERT ? 0 : 16 - p.Wt;
+        auto pos = [&](int sl) { return sl < 8 ? sl : sl - dup; };
+        auto valid = [&](int sl) { const int q = pos(sl); return sl < 8 ? sl < p.Wt : (q >= 8 && q < p.Wt); };
+        const int pi = pos(i16);
+        const bool vi = valid(i16);
+        int wofs[4]; bool wok[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int so = 4 * g4 + e;
+            wok[e] = vi && valid(so);
+            wofs[e] = so * 32 + (pi - pos(so) + 15);
+        }
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
         for (int r = 0; r < MF_TAPS; ++r) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) tile[(4 * g4 + e) * 17 + i16] = acc[r][e];
+            for (int e = 0; e < 4; ++e)
+                if (wok[e]) tile[wofs[e]] = acc[r][e];
             __builtin_amdgcn_wave_barrier();
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            if (dd < 31) {
+            if (lane < 31) {
                 float v[16];
 #pragma unroll
-                for (int o = 0; o < 16; ++o) {                    // 16 independent reads, added in order below
-                    const int i = o + dd - 15;
-                    const bool ok = o < p.Wt && i >= 0 && i < p.Wt;
-                    const int so = o < 8 ? o : o + dup, si = i < 8 ? i : i + dup;
-                    v[o] = ok ? tile[(ok ? so : 0) * 17 + (ok ? si : 0)] : 0.f;
-                }
-                float s = 0.f;
+                for (int o = 0; o < 16; ++o) v[o] = tile[o * 32 + lane];       // 16 independent reads, added in order below
+                float sum = 0.f;
 #pragma unroll
-                for (int o = 0; o < 16; ++o) s += v[o];
-                const int tau = dd - 15 + p.padL;
-                if (tau >= 0 && tau < p.KL) res[VERT ? (tau * p.kw + r) : (r * p.kw + tau)] = s;
+                for (int o = 0; o < 16; ++o) sum += v[o];
+                const int tau = lane - 15 + p.padL;
+                if (tau >= 0 && tau < p.KL) res[VERT ? (tau * p.kw + r) : (r * p.kw + tau)] = sum;
             }
             __builtin_amdgcn_wave_barrier();
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -208,17 +222,23 @@ size_t dwconv_mfma_small_wgrad_dma_workspace(const ConvDims& d) {
     return align_up((size_t)((d.N + 7) / 8 + 1) * d.C * d.kh * d.kw * sizeof(float), 256);   // slices <= ceil(N / 8)
 }
 
-template <typename T, bool VERT>
-static int launch_swd_t(SmallWgradDmaParams& p, const ConvDims& d, size_t ws_bytes, hipStream_t st) {
-    auto k = dwconv_mfma_small_wgrad_dma_kernel<T, VERT>;
-    fill_swd_params(p, d, VERT, 3 * mfma_cu_count());
+template <typename T, bool VERT, int NS>
+static int launch_swd_ns(SmallWgradDmaParams& p, const ConvDims& d, size_t ws_bytes, hipStream_t st) {
+    auto k = dwconv_mfma_small_wgrad_dma_kernel<T, VERT, NS>;
+    fill_swd_params(p, d, VERT, (NS == 3 ? 4 : 3) * mfma_cu_count());
     if ((size_t)p.slices * d.C * d.kh * d.kw * sizeof(float) > ws_bytes) return SLAK_ERR_WORKSPACE;
     const int cblocks = (d.C + 3) / 4;
-    const size_t lds = (size_t)MF_WAVES * SWD_WAVE_BYTES;
+    const size_t lds = (size_t)MF_WAVES * swd_wave_bytes(NS);
     if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(k, dim3((unsigned)(cblocks * p.slices)), dim3(MF_THREADS), lds, st, p);
     SLAK_LAUNCH_CHECK();
     return SLAK_OK;
+}
+
+template <typename T, bool VERT>
+static int launch_swd_t(SmallWgradDmaParams& p, const ConvDims& d, size_t ws_bytes, hipStream_t st) {
+    static const int ns = [] { const char* e = getenv("SLAK_SWD_NS"); return e && atoi(e) == 3 ? 3 : 4; }();
+    return ns == 3 ? launch_swd_ns<T, VERT, 3>(p, d, ws_bytes, st) : launch_swd_ns<T, VERT, 4>(p, d, ws_bytes, st);
 }
 
 int launch_dwconv_mfma_small_wgrad_dma(const void* dy, int dy_dt, const void* x, int x_dt, float* dw,
