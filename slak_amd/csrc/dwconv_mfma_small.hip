@@ -121,22 +121,29 @@ __global__ __launch_bounds__(MF_THREADS) void dwconv_mfma_small_kernel(const Sma
             }
         }
     };
+    // LDS element offset of every element of this thread's chunks (-1: beyond the block).  The chunk -> (channel, h, w) map does
+    // not change between iterations: resolving it here keeps the per-iteration staging to V plain ds_write_b16 per chunk (the
+    // div/mod + carry chain it replaces was ~12 VALU per ELEMENT, a third of the loop's instructions on 7x7 planes).
+    int soff[SM_NCH][V];
+#pragma unroll
+    for (int k = 0; k < SM_NCH; ++k) {
+        int e = ch_e0[k];
+        int ch = e / HW, rem = e - ch * HW;
+        int h = rem / p.W, w = rem - h * p.W;
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+            const bool ok = ch_ni[k] >= 0 && e + i < valid_blk;
+            soff[k][i] = ok ? ((ch * p.NI + ch_ni[k]) * p.Wl + (VERT ? w : h)) * p.KP + (VERT ? h : w) : -1;
+            ++w;
+            if (w == p.W) { w = 0; ++h; if (h == p.H) { h = 0; ++ch; } }
+        }
+    }
     auto stage_write = [&]() {
 #pragma unroll
         for (int k = 0; k < SM_NCH; ++k) {
-            if (ch_ni[k] < 0) continue;
-            int e = ch_e0[k];
-            int ch = e / HW, rem = e - ch * HW;
-            int h = rem / p.W, w = rem - h * p.W;
 #pragma unroll
-            for (int i = 0; i < V; ++i) {
-                if (e + i < valid_blk) {
-                    const int off = ((ch * p.NI + ch_ni[k]) * p.Wl + (VERT ? w : h)) * p.KP + (VERT ? h : w);
-                    lin[off] = chunk_get<V>(st[k], i);
-                }
-                ++w;
-                if (w == p.W) { w = 0; ++h; if (h == p.H) { h = 0; ++ch; } }
-            }
+            for (int i = 0; i < V; ++i)
+                if (soff[k][i] >= 0) lin[soff[k][i]] = chunk_get<V>(st[k], i);
         }
     };
 
@@ -259,7 +266,8 @@ static bool fill_small_params(SmallParams& p, const ConvDims& d, bool vert, int 
     int slices = resident_wgs / cblocks; if (slices < 1) slices = 1;
     if (slices > d.N) slices = d.N;
     int per = (d.N + slices - 1) / slices;
-    if (per < 3 * NI) per = 3 * NI;                          // at least 3 iterations per workgroup: amortise its prologue
+    static const int min_iters = [] { const char* e = getenv("SLAK_SMALL_MIN_ITERS"); const int v = e ? atoi(e) : 3; return v < 1 ? 1 : v; }();
+    if (per < min_iters * NI) per = min_iters * NI;                          // at least 3 iterations per workgroup: amortise its prologue
     if (per > d.N) per = d.N;
     if (NI > per) { NI = (per + p.PPT - 1) / p.PPT * p.PPT; }
     per = (per + NI - 1) / NI * NI;

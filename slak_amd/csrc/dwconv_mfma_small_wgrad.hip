@@ -45,8 +45,8 @@ __global__ __launch_bounds__(MF_THREADS) void dwconv_mfma_small_wgrad_kernel(con
     const int dy_elems = p.stack_rows * SW_P, x_elems = (p.stack_rows + 8) * SW_P;      // per channel
     uint16_t* dys = lds;                                      // [SW_CB][stack_rows][16]
     uint16_t* xs = lds + SW_CB * dy_elems;                    // [SW_CB][stack_rows + 8][16]
-    float* scr = (float*)(xs + SW_CB * x_elems);              // per wave: [2][16][17] fp32 scratch for the diagonal sums
-    float* res = scr + MF_WAVES * 2 * 16 * 17;                // per wave: [ntap] results (taps no diagonal reaches stay 0)
+    float* scr = (float*)(xs + SW_CB * x_elems);              // per wave: [16][32] fp32 scratch for the (skewed) diagonal sums
+    float* res = scr + MF_WAVES * 16 * 32;                // per wave: [ntap] results (taps no diagonal reaches stay 0)
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = wave_id_uniform();
@@ -89,23 +89,33 @@ __global__ __launch_bounds__(MF_THREADS) void dwconv_mfma_small_wgrad_kernel(con
             }
         }
     };
-    // element (channel ch, image ni, h, w) -> stack row 2 + ni*(Wl+2) + u, column = long-axis position; zeros for dead images
+    // element (channel ch, image ni, h, w) -> stack row 2 + ni*(Wl+2) + u, column = long-axis position; zeros for dead images.
+    // The LDS offsets of this thread's elements do not change between iterations: resolved once (-1: beyond the block).
+    int doff[SW_NCH][V], xoff[SW_NCH][V];
+#pragma unroll
+    for (int k = 0; k < SW_NCH; ++k) {
+        int e = ch_e0[k];
+        int ch = e / HW, rem = e - ch * HW;
+        int h = rem / p.W, w = rem - h * p.W;
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+            const bool ok = ch_ni[k] >= 0 && e + i < valid_blk;
+            const int row = 2 + (ok ? ch_ni[k] : 0) * (p.Wl + 2) + (VERT ? w : h), col = VERT ? h : w;
+            doff[k][i] = ok ? ch * dy_elems + row * SW_P + col : -1;
+            xoff[k][i] = ok ? ch * x_elems + (row + 2) * SW_P + col : -1;
+            ++w;
+            if (w == p.W) { w = 0; ++h; if (h == p.H) { h = 0; ++ch; } }
+        }
+    }
     auto stage_write = [&]() {
 #pragma unroll
         for (int k = 0; k < SW_NCH; ++k) {
-            if (ch_ni[k] < 0) continue;
-            int e = ch_e0[k];
-            int ch = e / HW, rem = e - ch * HW;
-            int h = rem / p.W, w = rem - h * p.W;
 #pragma unroll
             for (int i = 0; i < V; ++i) {
-                if (e + i < valid_blk) {
-                    const int row = 2 + ch_ni[k] * (p.Wl + 2) + (VERT ? w : h), col = VERT ? h : w;
-                    dys[ch * dy_elems + row * SW_P + col] = chunk_get<V>(sd[k], i);
-                    xs[ch * x_elems + (row + 2) * SW_P + col] = chunk_get<V>(sx[k], i);
+                if (doff[k][i] >= 0) {
+                    dys[doff[k][i]] = chunk_get<V>(sd[k], i);
+                    xs[xoff[k][i]] = chunk_get<V>(sx[k], i);
                 }
-                ++w;
-                if (w == p.W) { w = 0; ++h; if (h == p.H) { h = 0; ++ch; } }
             }
         }
     };
@@ -150,36 +160,38 @@ __global__ __launch_bounds__(MF_THREADS) void dwconv_mfma_small_wgrad_kernel(con
     }
 
     // ---- diagonal sums: dw[rho][tau] = sum_o G_rho[o, o + tau - padL]; D: column i = lane & 15, rows o = 4*(lane>>4) + reg.
-    //      Two taps per pass through a per-wave [2][16][17] fp32 scratch; lane (half, dd) adds the diagonal i - o = dd - 15. ----
+    //      One tap per pass through a per-wave [16][32] fp32 scratch, written SKEWED (G[o][i] -> row o, column i - o + 15: a
+    //      diagonal is a column; positions beyond the plane are never written and stay zero); lane dd adds the 16 rows of column
+    //      dd in order (unconditional reads at immediate offsets). ----
     if (c < p.C) {
-        float* tile = scr + wave * (2 * 16 * 17);
+        float* tile = scr + wave * (16 * 32);
         float* myres = res + wave * ntap;
         for (int t = lane; t < ntap; t += 64) myres[t] = 0.f;
+        for (int t = lane; t < 16 * 32 / 4; t += 64) ((u32x4*)tile)[t] = u32x4{0u, 0u, 0u, 0u};
         __builtin_amdgcn_wave_barrier();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        const int half = lane >> 5, dd = lane & 31;
-        for (int g0 = 0; g0 < MF_TAPS; g0 += 2) {
+        int wofs[4]; bool wok[4];
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                if (g0 + t < MF_TAPS) {
+        for (int r = 0; r < 4; ++r) {
+            wok[r] = i16 < p.Wt && 4 * grp + r < p.Wt;
+            wofs[r] = (4 * grp + r) * 32 + (i16 - (4 * grp + r) + 15);
+        }
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) tile[(t * 16 + 4 * grp + r) * 17 + i16] = acc[g0 + t][r];
-                }
-            }
+        for (int g = 0; g < MF_TAPS; ++g) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (wok[r]) tile[wofs[r]] = acc[g][r];
             __builtin_amdgcn_wave_barrier();
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            const int g = g0 + half;
-            if (g < MF_TAPS && dd < 31) {
-                float s = 0.f;
+            if (lane < 31) {
+                float v[16];
 #pragma unroll
-                for (int o = 0; o < 16; ++o) {
-                    const int i = o + dd - 15;
-                    const bool ok = i >= 0 && i < 16 && o < p.Wt && i < p.Wt;
-                    const float v = tile[(half * 16 + o) * 17 + (ok ? i : 0)];
-                    s += ok ? v : 0.f;
-                }
-                const int tau = dd - 15 + p.padL;
-                if (tau >= 0 && tau < p.KL) myres[VERT ? (tau * p.kw + g) : (g * p.kw + tau)] = s;
+                for (int o = 0; o < 16; ++o) v[o] = tile[o * 32 + lane];
+                float sum = 0.f;
+#pragma unroll
+                for (int o = 0; o < 16; ++o) sum += v[o];
+                const int tau = lane - 15 + p.padL;
+                if (tau >= 0 && tau < p.KL) myres[VERT ? (tau * p.kw + g) : (g * p.kw + tau)] = sum;
             }
             __builtin_amdgcn_wave_barrier();
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -207,7 +219,8 @@ static bool fill_sw_params(SmallWgradParams& p, const ConvDims& d, bool vert, in
     int slices = resident_wgs / cblocks; if (slices < 1) slices = 1;
     if (slices > d.N) slices = d.N;
     int per = (d.N + slices - 1) / slices;
-    if (per < 3 * NI) per = 3 * NI;                          // amortise the prologue / epilogue of a workgroup
+    static const int min_iters = [] { const char* e = getenv("SLAK_SMALL_MIN_ITERS"); const int v = e ? atoi(e) : 3; return v < 1 ? 1 : v; }();
+    if (per < min_iters * NI) per = min_iters * NI;                          // amortise the prologue / epilogue of a workgroup
     if (per > d.N) per = d.N;
     if (NI > per) NI = per;
     per = (per + NI - 1) / NI * NI;
@@ -219,7 +232,7 @@ static bool fill_sw_params(SmallWgradParams& p, const ConvDims& d, bool vert, in
 }
 
 static size_t sw_lds_bytes(const SmallWgradParams& p) {
-    return (size_t)SW_CB * (2 * p.stack_rows + 8) * SW_P * 2 + (size_t)MF_WAVES * 2 * 16 * 17 * 4 + (size_t)MF_WAVES * p.kh * p.kw * 4 + 32;
+    return (size_t)SW_CB * (2 * p.stack_rows + 8) * SW_P * 2 + (size_t)MF_WAVES * 16 * 32 * 4 + (size_t)MF_WAVES * p.kh * p.kw * 4 + 32;
 }
 
 bool dwconv_mfma_small_wgrad_supported(const ConvDims& d, int dy_dt, int x_dt) {
