@@ -69,6 +69,7 @@ def parse():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--kernel-reps", type=int, default=30)
     ap.add_argument("--fp32-dwconv", action="store_true", help="reference dtype flow: dw convs see fp32 even under autocast")
+    ap.add_argument("--cudnn-benchmark", type=int, default=1, help="torch.backends.cudnn.benchmark (main.py:235 sets it): MIOpen find mode for the stem/downsample convolutions")
     ap.add_argument("--torch-adamw", action="store_true", help="torch.optim.AdamW(fused=True) (+ a separate mask-apply launch) instead of slak_amd's one-launch MaskedAdamW")
     ap.add_argument("--model-ema", action="store_true", help="also keep the reference's sparsity-aware EMA (--model_ema true recipes): one HIP launch per step")
     ap.add_argument("--no-fused-tri", action="store_true", help="run the three branch convolutions as three autograd nodes (one launch each)")
@@ -192,6 +193,7 @@ def main():
     n_gpus = world if distributed else 1
     sparsity = a.sparsity if a.sparsity is not None else (0.4 if n_gpus > 1 else 0.0)
 
+    torch.backends.cudnn.benchmark = bool(a.cudnn_benchmark)       # main.py:235
     import slak_amd.slak_model as M
     from slak_amd.sparse_core import CosineDecay, Masking
     M.Block.fused_tail = not a.no_fused_tail and not a.fp32_dwconv    # HIP glue kernels around the pointwise GEMMs
@@ -281,6 +283,7 @@ def main():
                    "sync_bn": True, "block_tail": "hip (ln_nchw_to_nhwc + scale_residual)" if M.Block.fused_tail else "pytorch ops",
                    "branch_bn": "hip (bn3: one stats pass + one apply pass)" if M.ReparamLargeKernelConv.fused_bn else "pytorch (Sync)BatchNorm x3 + adds",
                    "pointwise_gemm": "hipBLASLt via torch" + (", TunableOp solutions from slak_amd/tuning/tunableop_gfx950.csv" if TUNED_GEMMS else ""),
+                   "cudnn_benchmark": bool(a.cudnn_benchmark),
                    "final_loss": final_loss},
     }
 
