@@ -150,3 +150,82 @@ def test_mask_bit_packing_round_trip():
         p = Masking.pack_mask(m)
         np.testing.assert_array_equal(p.numpy(), np.packbits(m.numpy().reshape(-1).astype(np.uint8)))
         assert torch.equal(Masking.unpack_mask(p, shape), m)
+
+
+def test_model_ema_entries_are_the_state_dict(tmp_path):
+    """ModelEma walks parameters and persistent buffers itself (no state_dict() call per step): same keys, same order, same tensors,
+    for a plain and for a wrapped ('module.' prefixed) model; a key the model lacks raises KeyError like the reference's msd[k]."""
+    import torch
+    import slak_amd.slak_model as M
+    from slak_amd.model_sema import ModelEma
+    net = M.SLaK(in_chans=3, num_classes=5, depths=[1, 1, 1, 1], dims=[8, 16, 24, 32], kernel_size=[7, 7, 5, 5, 3], Decom=True, bn=True)
+    ent = ModelEma._entries(net)
+    sd = net.state_dict()
+    assert [k for k, _ in ent] == list(sd.keys())
+    assert all(t.data_ptr() == sd[k].data_ptr() for k, t in ent)
+
+    class Wrap(torch.nn.Module):
+        def __init__(self, m):
+            super().__init__()
+            self.module = m
+    ema = ModelEma(net, decay=0.5)
+    assert not ema.ema_has_module and not any(p.requires_grad for p in ema.ema.parameters())
+    with pytest.raises(Exception):                       # CPU tensors: refused (SlakHipError), but only AFTER the key mapping worked
+        ema.update(Wrap(net), None)
+    assert [k for k, _, _ in ema._tensors[1]][:2] == ["module." + k for k in list(sd.keys())[:2]]
+    with pytest.raises(KeyError):
+        ModelEma(net).update(torch.nn.Linear(2, 2), None)
+
+
+def test_checkpoint_round_trip_on_cpu(tmp_path):
+    """slak_amd.checkpoint mirrors utils.save_model / auto_load_model1 (utils.py:447-512): file name, keys, pruning of old files,
+    auto-resume from the newest checkpoint; plus the 'mask' entry (any object with state_dict / load_state_dict)."""
+    import types
+    import torch
+    from slak_amd import checkpoint
+
+    class FakeMask:
+        def __init__(self): self.state = {"steps": 0}
+        def state_dict(self): return dict(self.state)
+        def load_state_dict(self, s): self.state = dict(s)
+
+    torch.manual_seed(0)
+    net, net2 = torch.nn.Linear(3, 2), torch.nn.Linear(3, 2)
+    opt, opt2 = torch.optim.SGD(net.parameters(), lr=0.1, momentum=0.9), torch.optim.SGD(net2.parameters(), lr=0.1, momentum=0.9)
+    net(torch.randn(4, 3)).sum().backward(); opt.step()
+    mask, mask2 = FakeMask(), FakeMask()
+    mask.state["steps"] = 7
+    args = types.SimpleNamespace(output_dir=str(tmp_path), save_ckpt_num=2, save_ckpt_freq=1, resume='', auto_resume=True)
+    for epoch in range(4):
+        checkpoint.save_model(args, epoch, net, net, opt, None, model_ema=None, mask=mask)
+    import os
+    assert sorted(os.listdir(tmp_path)) == ["checkpoint-2.pth", "checkpoint-3.pth"]       # older ones pruned (utils.py:464-468)
+    ck = torch.load(os.path.join(tmp_path, "checkpoint-3.pth"), weights_only=False)
+    assert set(ck.keys()) == {"model", "optimizer", "epoch", "scaler", "args", "mask"}
+    assert checkpoint.auto_load_model(args, net2, net2, opt2, None, model_ema=None, mask=mask2)
+    assert args.resume.endswith("checkpoint-3.pth") and args.start_epoch == 4 and mask2.state["steps"] == 7
+    assert all(torch.equal(a, b) for a, b in zip(net.state_dict().values(), net2.state_dict().values()))
+    assert torch.equal(opt.state_dict()["state"][0]["momentum_buffer"], opt2.state_dict()["state"][0]["momentum_buffer"])
+    empty = types.SimpleNamespace(output_dir=str(tmp_path / "none"), resume='', auto_resume=True)
+    assert checkpoint.auto_load_model(empty, net2, net2, opt2, None) is False
+
+
+def test_create_optimizer_surface():
+    """optim_factory.create_optimizer (optim_factory.py:115-199): adamw -> MaskedAdamW over the reference's two parameter groups,
+    torch.optim pass-throughs, timm/apex names raise instead of silently substituting."""
+    import contextlib, io, types
+    import torch
+    from slak_amd import optim_factory as OF
+    net = torch.nn.Sequential(torch.nn.Linear(3, 4), torch.nn.LayerNorm(4))
+    args = types.SimpleNamespace(opt="adamw", lr=4e-3, weight_decay=0.05, momentum=0.9, opt_eps=1e-8, opt_betas=None)
+    with contextlib.redirect_stdout(io.StringIO()):
+        opt = OF.create_optimizer(args, net)
+    assert isinstance(opt, OF.MaskedAdamW) and opt.applies_masks
+    assert [(g["weight_decay"], g["lr"], g["lr_scale"]) for g in opt.param_groups] == [(0.05, 4e-3, 1.0), (0.0, 4e-3, 1.0)]
+    args.opt = "sgd"
+    with contextlib.redirect_stdout(io.StringIO()):
+        assert isinstance(OF.create_optimizer(args, net), torch.optim.SGD)
+    for name in ("lookahead_adam", "fusedlamb", "adamp"):
+        args.opt = name
+        with contextlib.redirect_stdout(io.StringIO()), pytest.raises(NotImplementedError):
+            OF.create_optimizer(args, net)
