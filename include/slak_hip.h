@@ -106,6 +106,12 @@ int slak_mask_apply(slak_mask_plan_t* plan, void* stream);
  * on device in fp64 exactly as Python does (funcs.py:107-109).       (sparse_core.py:335-357)       */
 int slak_mask_prune_and_grow(slak_mask_plan_t* plan, double prune_rate, void* stream);
 
+/* The prune half alone (magnitude prune, sparse_core.py:337-347): masks hold the pruned masks afterwards, weights are untouched, the
+ * statistics (nonzeros before, zeros before, removed, nonzeros after prune) are ready for slak_mask_read_stats.  For the growth
+ * modes whose random numbers come from the host generator (funcs.random_growth, funcs.py:170-175: `torch.rand(shape).cuda() < p`):
+ * the caller grows on the pruned masks and finishes with slak_mask_apply. */
+int slak_mask_prune(slak_mask_plan_t* plan, double prune_rate, void* stream);
+
 /* Copy per-segment statistics of the last prune_and_grow to the host (synchronises `stream`):
  * out_host[4*i + {0,1,2,3}] = nonzeros before, zeros before, removed by prune, nonzeros after. */
 int slak_mask_read_stats(slak_mask_plan_t* plan, double* out_host, void* stream);

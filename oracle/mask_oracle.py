@@ -44,13 +44,25 @@ def gradient_growth(new_mask, total_regrowth, grad):
     return out.reshape(new_mask.shape)
 
 
+def random_growth(new_mask, total_regrowth, rand):
+    """funcs.py:170-175.  ``rand``: the float32 numbers the reference draws with ``torch.rand(new_mask.shape)`` (host generator);
+    the comparison against the Python float p happens in float32 (torch compares a float32 tensor with a Python scalar in the
+    tensor's dtype)."""
+    n = int((new_mask == 0).sum())
+    if n == 0:
+        return new_mask.astype(np.float32)
+    p = np.float32(total_regrowth / n)
+    return ((new_mask != 0) | (rand.astype(np.float32) < p)).astype(np.float32)
+
+
 def apply_mask(weight, mask):
     """sparse_core.py:326  ``tensor.data = tensor.data*self.masks[name]`` (fp32)."""
     return (weight.astype(np.float32) * mask.astype(np.float32)).astype(np.float32)
 
 
-def truncate_weights(weights, masks, grads, prune_rate):
-    """sparse_core.py:335-357 over dicts name -> array.  Returns (new_weights, new_masks, stats)."""
+def truncate_weights(weights, masks, grads, prune_rate, growth="gradient", rands=None):
+    """sparse_core.py:335-357 over dicts name -> array.  Returns (new_weights, new_masks, stats).  growth: "gradient" (needs
+    ``grads``) or "random" (needs ``rands``: name -> the numbers torch.rand produced for that tensor)."""
     names = list(masks.keys())
     new_masks, stats = {}, {}
     for name in names:                                   # prune loop  :337-347
@@ -63,7 +75,10 @@ def truncate_weights(weights, masks, grads, prune_rate):
         stats[name] = dict(nonzeros=nonzeros, zeros=zeros, removed=removed)
     for name in names:                                   # growth loop :349-355
         nm = new_masks[name].astype(np.uint8)            # ``.data.byte()``
-        new_masks[name] = gradient_growth(nm, math.floor(stats[name]["removed"]), grads[name])
+        if growth == "random":
+            new_masks[name] = random_growth(nm, math.floor(stats[name]["removed"]), rands[name])
+        else:
+            new_masks[name] = gradient_growth(nm, math.floor(stats[name]["removed"]), grads[name])
     new_weights = {n: (apply_mask(weights[n], new_masks[n]) if n in new_masks else weights[n]) for n in weights}
     return new_weights, new_masks, stats
 

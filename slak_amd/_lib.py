@@ -63,6 +63,7 @@ SIGNATURES = {
     "slak_mask_plan_destroy": (_i, [_vp]),
     "slak_mask_apply": (_i, [_vp, _vp]),
     "slak_mask_prune_and_grow": (_i, [_vp, _d, _vp]),
+    "slak_mask_prune": (_i, [_vp, _d, _vp]),
     "slak_mask_read_stats": (_i, [_vp, ctypes.POINTER(_d), _vp]),
     "slak_mask_checksum": (_i, [_vp, ctypes.POINTER(ctypes.c_ulonglong), _vp]),
     "slak_adamw_plan_create": (_i, [ctypes.POINTER(AdamwSegment), _i, ctypes.POINTER(_vp)]),

@@ -442,6 +442,21 @@ int slak_mask_prune_and_grow(slak_mask_plan_t* p, double prune_rate, void* strea
     return slak_mask_apply(p, stream);                      // sparse_core.py:357
 }
 
+int slak_mask_prune(slak_mask_plan_t* p, double prune_rate, void* stream) {
+    if (!p) return SLAK_ERR_INVALID_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    const int sg = ceil_div(p->nseg, 64), sgh = ceil_div(p->nseg * 256, 256);
+    hipLaunchKernelGGL(mask_reset_state_kernel, dim3(sgh), dim3(256), 0, st, p->state, p->hist, p->nseg);
+    hipLaunchKernelGGL(mask_count_kernel, dim3(p->nblk), dim3(MK_THREADS), 0, st, p->segs, p->blk_seg, p->seg_blk0, p->state);
+    hipLaunchKernelGGL(mask_setup_prune_kernel, dim3(sg), dim3(64), 0, st, p->segs, p->state, p->stats, p->nseg, prune_rate);
+    int rc = run_select(p, KEY_ABS_W, st);                 // prune loop, sparse_core.py:337-347
+    if (rc != SLAK_OK) return rc;
+    hipLaunchKernelGGL(mask_setup_grow_kernel, dim3(sg), dim3(64), 0, st, p->state, p->stats, p->nseg);   // records `removed` (stats[2])
+    hipLaunchKernelGGL(mask_finish_kernel, dim3(sg), dim3(64), 0, st, p->state, p->stats, p->nseg);       // stats[3] = nonzeros - removed
+    SLAK_LAUNCH_CHECK();
+    return SLAK_OK;
+}
+
 int slak_mask_read_stats(slak_mask_plan_t* p, double* out_host, void* stream) {
     if (!p || !out_host) return SLAK_ERR_INVALID_ARG;
     HIPCHK(hipMemcpyAsync(out_host, p->stats, sizeof(double) * 4 * p->nseg, hipMemcpyDeviceToHost, (hipStream_t)stream));

@@ -12,9 +12,12 @@ work done by batched HIP kernels (slak_amd/csrc/mask_kernels.hip) over ALL maske
                                                               weights + all-reduced grads (checksum
                                                               all-reduce available as a debug check)
 
-Scope (BASELINE.json north star): growth='gradient', prune='magnitude'.  Other growth/prune/
-redistribution modes of funcs.py are out of scope and raise NotImplementedError rather than silently
-falling back.  Mask initialisation (uniform / resume / snip / ERK, sparse_core.py:141-261) is one-time
+Scope (BASELINE.json north star): growth='gradient', prune='magnitude' -- all on device.  growth='random'
+(funcs.random_growth, funcs.py:170-175; the default of main.py:211 and what the README recipes pass) is supported too: the
+prune half runs on device (slak_mask_prune), the random numbers are the HOST generator's, as in the reference
+(``torch.rand(shape).cuda() < p``), so a seed reproduces the reference's masks; because ranks draw different numbers the masks
+are re-broadcast from rank 0 after every such growth (the reference broadcasts them every step).  The remaining growth /
+prune / redistribution modes of funcs.py raise NotImplementedError rather than silently falling back.  Mask initialisation (uniform / resume / snip / ERK, sparse_core.py:141-261) is one-time
 host logic and stays in Python, using the same torch RNG calls so that seeds reproduce the reference.
 
 Masks stay fp32 tensors in ``self.masks[name]`` (``model_sema.py:83-89`` reads them), keyed by
@@ -150,8 +153,9 @@ class Masking(object):
             raise NotImplementedError("fp16 master-copy optimizers are not supported")
 
     def init_growth_prune_and_redist(self):
-        if self.growth_mode != 'gradient':
-            raise NotImplementedError("growth mode %r: only 'gradient' (funcs.py:196-205) is on the MI355X hot path" % (self.growth_mode,))
+        if self.growth_mode not in ('gradient', 'random'):
+            raise NotImplementedError("growth mode %r: 'gradient' (funcs.py:196-205, all on device) and 'random' (funcs.py:170-175, the "
+                                      "default of main.py:211; its random numbers come from the HOST generator) are supported" % (self.growth_mode,))
         if self.prune_mode != 'magnitude':
             raise NotImplementedError("prune mode %r: only 'magnitude' (funcs.py:107-114) is on the MI355X hot path" % (self.prune_mode,))
         # the reference resolves a redistribution function but never calls it (sparse_core.py:288-297)
@@ -357,10 +361,42 @@ class Masking(object):
             for p in params:                   # older torch: one tensor per call
                 inc(p)
 
+    def _truncate_weights_random_growth(self, params):
+        """prune on device, then funcs.random_growth (funcs.py:170-175) with the reference's own random numbers:
+        ``torch.rand(shape)`` from the HOST generator, one draw per masked tensor in the reference's loop order, compared against
+        p = total_regrowth / (zeros of the pruned mask) on the device.  The counts come from the prune kernels' statistics (one
+        host synchronisation per prune-and-grow round; the reference has three per tensor).  Ranks draw different numbers
+        (main.py:232 seeds with seed + rank), which is what the reference's per-step mask broadcast papers over: the masks are
+        re-synchronised from rank 0 right after this growth."""
+        L = _lib.lib()
+        with torch.cuda.device(self.device):
+            self._bind_momentum(params)
+            _lib.check(L.slak_mask_prune(self._plan, float(self.prune_rate), self._stream()), "slak_mask_prune")
+            stats = (ctypes.c_double * (4 * len(params)))()
+            _lib.check(L.slak_mask_read_stats(self._plan, stats, self._stream()), "slak_mask_read_stats")
+        self._nonzeros_after = {}
+        for i, (name, t) in enumerate(params):
+            self.name2nonzeros[name] = stats[4 * i + 0]
+            self.name2zeros[name] = stats[4 * i + 1]
+            self.name2removed[name] = stats[4 * i + 2]
+        for i, (name, t) in enumerate(params):                      # growth loop, sparse_core.py:349-355
+            mask = self.masks[name]
+            total_regrowth = math.floor(self.name2removed[name])
+            n = int(mask.numel() - (self.name2nonzeros[name] - self.name2removed[name]))     # (new_mask == 0).sum().item()
+            if n == 0:
+                continue
+            expeced_growth_probability = total_regrowth / n
+            new_weights = torch.rand(mask.shape).to(self.device) < expeced_growth_probability
+            mask.copy_((mask.bool() | new_weights).float())         # in place: the device plan and the optimizer keep their pointers
+        self._synced_once = False                                   # ranks drew different numbers: rank 0's masks win (sparse_core.py:404-407)
+        self.apply_mask()                                           # sparse_core.py:357
+
     def truncate_weights(self):
         params = self._ensure_plan()
         if params is None:
             return
+        if self.growth_mode == 'random':
+            return self._truncate_weights_random_growth(params)
         L = _lib.lib()
         grads = []
         for name, t in params:

@@ -109,7 +109,7 @@ class TinyNet(nn.Module):
         self.head = nn.Linear(C[-1], 11)
 
 
-def _ref_masking(model, optimizer, only_L, sparsity, update_frequency, prune_rate, T_max, seed):
+def _ref_masking(model, optimizer, only_L, sparsity, update_frequency, prune_rate, T_max, seed, growth="gradient"):
     sys.path.insert(0, REF)
     import sparse_core  # noqa: E402  (the reference, unmodified)
     args = types.SimpleNamespace(device="cpu", fix=False, update_frequency=update_frequency, only_L=only_L,
@@ -117,7 +117,7 @@ def _ref_masking(model, optimizer, only_L, sparsity, update_frequency, prune_rat
     decay = sparse_core.CosineDecay(prune_rate, T_max)
     torch.manual_seed(seed)
     m = sparse_core.Masking(optimizer, train_loader=None, prune_rate_decay=decay, prune_rate=prune_rate,
-                            prune_mode="magnitude", growth_mode="gradient", redistribution_mode="none", args=args)
+                            prune_mode="magnitude", growth_mode=growth, redistribution_mode="none", args=args)
     m.add_module(model)
     return m
 
@@ -128,7 +128,14 @@ def _snap(d):
 
 def make_masks():
     import contextlib, io
-    for tag, only_L, opt_kind in (("all_sgd", False, "sgd"), ("onlyL_adamw", True, "adamw")):
+    # "random" = funcs.random_growth (funcs.py:170-175), the default of main.py:211.  It calls ``.cuda()`` on the numbers it draws from
+    # the host generator; this container has no GPU, so for THIS recording Tensor.cuda is the identity (the reference source itself
+    # is imported unmodified): the same numbers are compared on the CPU instead of the GPU.
+    for tag, only_L, opt_kind in (("all_sgd", False, "sgd"), ("onlyL_adamw", True, "adamw"), ("all_adamw_random", False, "adamw")):
+        growth = "random" if tag.endswith("_random") else "gradient"
+        _cuda = torch.Tensor.cuda
+        if growth == "random":
+            torch.Tensor.cuda = lambda self, *a, **k: self
         torch.manual_seed(123)
         model = TinyNet()
         for p in model.parameters():                     # continuous values -> no ties
@@ -138,7 +145,7 @@ def make_masks():
         else:
             opt = torch.optim.AdamW(model.parameters(), lr=1e-2, weight_decay=0.05)
         with contextlib.redirect_stdout(io.StringIO()):
-            mask = _ref_masking(model, opt, only_L, sparsity=0.4, update_frequency=3, prune_rate=0.3, T_max=20, seed=7)
+            mask = _ref_masking(model, opt, only_L, sparsity=0.4, update_frequency=3, prune_rate=0.3, T_max=20, seed=7, growth=growth)
         names = list(mask.masks.keys())
         out = {"names": np.array(names), "param_names": np.array([n for n, _ in model.named_parameters()])}
         for n, p in model.named_parameters():
@@ -177,6 +184,7 @@ def make_masks():
         out["prune_rates"] = np.array(rates, np.float64)
         out["meta"] = np.array([nsteps, 3, 20], np.int64)            # nsteps, update_frequency, T_max
         out["hyper"] = np.array([0.4, 0.3], np.float64)              # sparsity, prune_rate
+        torch.Tensor.cuda = _cuda
         np.savez_compressed(os.path.join(HERE, f"mask_{tag}.npz"), **out)
         print("wrote mask_%s (%d masked tensors)" % (tag, len(names)))
 

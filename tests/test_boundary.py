@@ -76,7 +76,7 @@ def test_no_cpu_fallback_fails_loudly():
                      prune_mode="magnitude", growth_mode="gradient", redistribution_mode="none", args=args)
         mk.add_module(net)                                # apply_mask on CPU params must raise, not fall back
     with pytest.raises(NotImplementedError):
-        Masking(None, None, None, growth_mode="random", args=args).init_growth_prune_and_redist()
+        Masking(None, None, None, growth_mode="momentum", args=args).init_growth_prune_and_redist()   # not on this path: refuse by name
 
 
 def test_module_surface_matches_reference():

@@ -31,7 +31,9 @@ def _args(device, only_L=False, update_frequency=3, sparsity=0.4, distributed=Fa
 
 # ------------------------------------------------------------------ (1) recorded reference runs
 @pytest.mark.parametrize("tag,only_L,opt_kind", [("all_sgd", False, "sgd"), ("onlyL_adamw", True, "adamw"),
-                                                 ("onlyL_adamw", True, "masked_adamw")])
+                                                 ("onlyL_adamw", True, "masked_adamw"),
+                                                 ("all_adamw_random", False, "adamw"),           # growth = funcs.random_growth
+                                                 ("all_adamw_random", False, "masked_adamw")])
 def test_recorded_reference_run(tag, only_L, opt_kind, gpu):
     from make_golden import TinyNet                      # same tiny module the fixtures were recorded on
     from slak_amd.sparse_core import CosineDecay, Masking
@@ -53,7 +55,8 @@ def test_recorded_reference_run(tag, only_L, opt_kind, gpu):
     torch.manual_seed(7)                                 # same CPU RNG stream for the uniform init
     with contextlib.redirect_stdout(io.StringIO()):
         mask = Masking(opt, train_loader=None, prune_rate_decay=decay, prune_rate=0.3, prune_mode="magnitude",
-                       growth_mode="gradient", redistribution_mode="none", args=_args(gpu, only_L))
+                       growth_mode="random" if tag.endswith("_random") else "gradient", redistribution_mode="none",
+                       args=_args(gpu, only_L))
         mask.add_module(model)
     names = [str(n) for n in g["names"]]
     assert list(mask.masks.keys()) == names

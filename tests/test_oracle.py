@@ -134,3 +134,30 @@ def test_adamw_oracle_matches_torch_adamw_with_reference_masking():
                 w[n] = w[n] * g[f"m{step}/{n}"]                      # truncate_weights ends with apply_mask (sparse_core.py:357)
             ref = g[f"w{step}/{n}"]
             assert np.abs(ref - w[n]).max() <= 1e-6 * np.abs(ref).max() + 1e-12, (n, step)
+
+
+def test_mask_truncate_random_growth_matches_reference_masking():
+    """funcs.random_growth (the default growth of main.py:211) on the recorded reference run: the random numbers are the host
+    generator's, so replaying its stream (seed 7: one draw per masked tensor at init, one per masked tensor per prune-and-grow
+    round, in named_parameters order) reproduces the reference's masks bit-exactly."""
+    import torch
+    g = load_golden("mask_all_adamw_random")
+    nsteps, ufreq, _ = (int(v) for v in g["meta"])
+    names = [str(n) for n in g["names"]]
+    torch.manual_seed(7)
+    for n in names:                                                   # uniform init, sparse_core.py:176-183
+        r = torch.rand(g[f"m_init/{n}"].shape)
+        np.testing.assert_array_equal((r < 0.6).float().numpy(), g[f"m_init/{n}"], err_msg="replay of the init draws: " + n)
+    grown_total = 0
+    for step in range(ufreq, nsteps + 1, ufreq):
+        m_prev = {n: g[f"m{step-1}/{n}"] for n in names}
+        w_pre = {n: g[f"wpre{step}/{n}"] for n in names}
+        rands = {n: torch.rand(m_prev[n].shape).numpy() for n in names}
+        w_new, m_new, stats = oracle.truncate_weights(w_pre, m_prev, None, float(g[f"rate_at{step}"]), growth="random", rands=rands)
+        for n in names:
+            np.testing.assert_array_equal(m_new[n], g[f"m{step}/{n}"], err_msg=f"{n} step {step}")
+            np.testing.assert_array_equal(w_new[n], g[f"w{step}/{n}"], err_msg=f"{n} step {step}")
+            nz, zeros, removed = g[f"stats{step}/{n}"]
+            assert (stats[n]["nonzeros"], stats[n]["zeros"], stats[n]["removed"]) == (nz, zeros, removed)
+            grown_total += int(((m_new[n] != 0) & (m_prev[n] == 0)).sum())
+    assert grown_total > 0
