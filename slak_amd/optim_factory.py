@@ -99,7 +99,7 @@ class MaskedAdamW(optim.Optimizer):
         self._state_dirty = True
         self._grad_key = None
         self._grad_tabs = None
-        self._lowp_gen = -1
+        self._active = None         # per-parameter 0/1 step increments when some gradients are missing (None: all present)
 
     # -- Masking hook ---------------------------------------------------------------------------------------------
     def set_masks(self, masks):
