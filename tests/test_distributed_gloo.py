@@ -97,3 +97,61 @@ def _identical_masks_without_collectives(rank, world):
 def test_masks_agree_across_ranks_without_per_step_broadcast():
     r0, r1 = _run(_identical_masks_without_collectives)
     np.testing.assert_array_equal(r0, r1)
+
+
+def _random_growth_resync(rank, world):
+    """growth='random' draws from per-rank host generators (main.py:232), so the masks differ after the growth until they are
+    re-broadcast from rank 0: the mirror marks them unsynchronised right after such a growth (the device part -- prune, apply --
+    is stubbed here; this pins the DISTRIBUTED LOGIC on CPU tensors with the oracle doing the arithmetic)."""
+    import math
+    import oracle
+    from slak_amd.sparse_core import Masking
+    args = types.SimpleNamespace(device="cpu", fix=False, update_frequency=None, only_L=False, sparse_init="uniform", sparsity=0.4, distributed=True)
+    mk = Masking(None, None, None, prune_mode="magnitude", growth_mode="random", redistribution_mode="none", args=args)
+    mk.init_growth_prune_and_redist()                              # 'random' is an accepted growth mode
+    torch.manual_seed(5)                                           # same weights and masks on both ranks ...
+    w = torch.randn(9, 1, 13, 5) * 0.05
+    mk.masks = {"w": (torch.rand(w.shape) < 0.6).float()}
+    mk._synced_once = True
+    torch.manual_seed(100 + rank)                                  # ... but per-rank generators from here on
+    m = mk.masks["w"].numpy()
+    nz = float(m.sum()); pruned = oracle.magnitude_prune(m, (w * mk.masks["w"]).numpy(), 0.3, nz, m.size - nz)
+    removed = nz - float(pruned.sum())
+    grown = oracle.random_growth(pruned.astype(np.uint8), math.floor(removed), torch.rand(w.shape).numpy())
+    mk.masks["w"].copy_(torch.from_numpy(grown))
+    local = mk.masks["w"].clone()
+    mk._synced_once = False                                        # what _truncate_weights_random_growth does after growing
+    mk.synchronism_masks()
+    return dict(local=local.numpy(), synced=mk.masks["w"].numpy())
+
+
+def test_random_growth_masks_are_rebroadcast_from_rank0():
+    r0, r1 = _run(_random_growth_resync)
+    assert not np.array_equal(r0["local"], r1["local"])                     # ranks grew different weights
+    np.testing.assert_array_equal(r0["synced"], r0["local"])                # rank 0's masks win (sparse_core.py:404-407)
+    np.testing.assert_array_equal(r1["synced"], r0["local"])
+
+
+def _checkpoint_main_process_only(rank, world):
+    import tempfile
+    from slak_amd import checkpoint
+    d = [tempfile.mkdtemp() if rank == 0 else None]
+    dist.broadcast_object_list(d, src=0)
+    args = types.SimpleNamespace(output_dir=d[0], save_ckpt_num=2, save_ckpt_freq=1, resume='', auto_resume=True)
+    torch.manual_seed(rank)                                        # ranks hold DIFFERENT weights here: the file must be rank 0's
+    net = torch.nn.Linear(3, 2)
+    opt = torch.optim.SGD(net.parameters(), lr=0.1)
+    checkpoint.save_model(args, 0, net, net, opt, None)
+    dist.barrier()
+    files = sorted(os.listdir(d[0]))
+    net2 = torch.nn.Linear(3, 2)
+    checkpoint.auto_load_model(args, net2, net2, opt, None)
+    return dict(files=files, mine=net.weight.detach().numpy().copy(), loaded=net2.weight.detach().numpy().copy())
+
+
+def test_checkpoint_is_written_by_the_main_process():
+    r0, r1 = _run(_checkpoint_main_process_only)
+    assert r0["files"] == r1["files"] == ["checkpoint-0.pth"]
+    np.testing.assert_array_equal(r0["loaded"], r0["mine"])                 # both ranks resume from rank 0's weights
+    np.testing.assert_array_equal(r1["loaded"], r0["mine"])
+    assert not np.array_equal(r1["mine"], r0["mine"])
