@@ -257,10 +257,29 @@ def make_ema():
         np.savez_compressed(os.path.join(HERE, f"ema_{tag}.npz"), **out)
         print("wrote ema_%s (%d entries)" % (tag, len(keys)))
 
+# --------------------------------------------------------------------------- SNIP fixture (sparse_core.py:11-47; --sparse_init snip)
+def _snip_net():
+    torch.manual_seed(77)
+    return nn.Sequential(nn.Conv2d(3, 6, 3, padding=1), nn.ReLU(), nn.Flatten(), nn.Linear(6 * 8 * 8, 12), nn.ReLU(), nn.Linear(12, 5))
+
+
+def make_snip():
+    sys.path.insert(0, REF)
+    import sparse_core  # noqa: E402  (the reference, unmodified)
+    net = _snip_net()
+    g = torch.Generator().manual_seed(3)
+    images, labels = torch.randn(16, 3, 8, 8, generator=g), torch.randint(0, 5, (16,), generator=g)
+    masks = {n: torch.zeros_like(p) for n, p in net.named_parameters() if p.dim() in (2, 4)}
+    args = types.SimpleNamespace(distributed=False)
+    sp = sparse_core.SNIP(net, 0.6, [(images, labels)], torch.device("cpu"), masks, args)
+    np.savez_compressed(os.path.join(HERE, "snip_small.npz"), images=images.numpy(), labels=labels.numpy(),
+                        names=np.array(list(masks.keys())), sparsities=np.array(sp, np.float64), keep_ratio=np.array(0.6))
+    print("wrote snip_small", sp)
+
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", choices=["conv", "mask", "ema"], default=None)
+    ap.add_argument("--only", choices=["conv", "mask", "ema", "snip"], default=None)
     a = ap.parse_args()
     if not os.path.isdir(REF):
         sys.exit("needs /root/reference (build container only)")
@@ -270,3 +289,5 @@ if __name__ == "__main__":
         make_masks()
     if a.only in (None, "ema"):
         make_ema()
+    if a.only in (None, "snip"):
+        make_snip()

@@ -161,3 +161,22 @@ def test_mask_truncate_random_growth_matches_reference_masking():
             assert (stats[n]["nonzeros"], stats[n]["zeros"], stats[n]["removed"]) == (nz, zeros, removed)
             grown_total += int(((m_new[n] != 0) & (m_prev[n] == 0)).sum())
     assert grown_total > 0
+
+
+def test_snip_layerwise_sparsities_match_reference():
+    """slak_amd.sparse_core.SNIP (one-time host logic of --sparse_init snip, the README recipes' init) against the sparsities the
+    reference's SNIP (sparse_core.py:11-47) produced for the same net and batch (tests/golden/make_golden.py --only snip)."""
+    import sys, types
+    import torch
+    from conftest import GOLDEN
+    sys.path.insert(0, GOLDEN)
+    from make_golden import _snip_net
+    from slak_amd.sparse_core import SNIP
+    g = load_golden("snip_small")
+    net = _snip_net()
+    before = [p.detach().clone() for p in net.parameters()]
+    masks = {str(n): None for n in g["names"]}
+    sp = SNIP(net, float(g["keep_ratio"]), [(torch.from_numpy(g["images"]), torch.from_numpy(g["labels"]))], torch.device("cpu"), masks,
+              types.SimpleNamespace(distributed=False))
+    assert list(sp) == list(g["sparsities"])
+    assert all(torch.equal(a, b) for a, b in zip(before, net.parameters())) and all(p.grad is None for p in net.parameters())
