@@ -276,10 +276,34 @@ def make_snip():
                         names=np.array(list(masks.keys())), sparsities=np.array(sp, np.float64), keep_ratio=np.array(0.6))
     print("wrote snip_small", sp)
 
+# --------------------------------------------------------------------------- ERK init fixture (sparse_core.py:184-262; --sparse_init ERK)
+def make_erk():
+    import contextlib, io
+    sys.path.insert(0, REF)
+    import sparse_core  # noqa: E402
+    out = {}
+    for tag, sparsity in (("s40", 0.4), ("s90", 0.9)):               # 0.9: some layers have to stay dense (the epsilon loop iterates)
+        torch.manual_seed(123)
+        model = TinyNet()
+        args = types.SimpleNamespace(device="cpu", fix=False, update_frequency=3, only_L=False, sparse_init="ERK", sparsity=sparsity,
+                                     distributed=False)
+        torch.manual_seed(9)
+        with contextlib.redirect_stdout(io.StringIO()):
+            m = sparse_core.Masking(torch.optim.SGD(model.parameters(), lr=0.1), train_loader=None,
+                                    prune_rate_decay=sparse_core.CosineDecay(0.3, 20), prune_rate=0.3, prune_mode="magnitude",
+                                    growth_mode="gradient", redistribution_mode="none", args=args)
+            m.add_module(model)
+        out[f"{tag}/names"] = np.array(list(m.masks.keys()))
+        for n, v in m.masks.items():
+            out[f"{tag}/m/{n}"] = v.numpy().copy()
+        out[f"{tag}/sparsity"] = np.array(sparsity)
+    np.savez_compressed(os.path.join(HERE, "erk_init.npz"), **out)
+    print("wrote erk_init")
+
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", choices=["conv", "mask", "ema", "snip"], default=None)
+    ap.add_argument("--only", choices=["conv", "mask", "ema", "snip", "erk"], default=None)
     a = ap.parse_args()
     if not os.path.isdir(REF):
         sys.exit("needs /root/reference (build container only)")
@@ -291,3 +315,5 @@ if __name__ == "__main__":
         make_ema()
     if a.only in (None, "snip"):
         make_snip()
+    if a.only in (None, "erk"):
+        make_erk()

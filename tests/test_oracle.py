@@ -180,3 +180,31 @@ def test_snip_layerwise_sparsities_match_reference():
               types.SimpleNamespace(distributed=False))
     assert list(sp) == list(g["sparsities"])
     assert all(torch.equal(a, b) for a, b in zip(before, net.parameters())) and all(p.grad is None for p in net.parameters())
+
+
+@pytest.mark.parametrize("tag", ["s40", "s90"])
+def test_erk_init_matches_reference(tag):
+    """Masking.init(mode='ERK') (sparse_core.py:184-262): same epsilon iteration, same per-layer densities, same host-generator draws,
+    same (almost) dense layers popped -- masks identical to the reference's for the same seed.  The device apply at the end of
+    init() is stubbed: this pins the one-time host logic."""
+    import contextlib, io, sys, types
+    import torch
+    from conftest import GOLDEN
+    sys.path.insert(0, GOLDEN)
+    from make_golden import TinyNet
+    from slak_amd.sparse_core import CosineDecay, Masking
+    g = load_golden("erk_init")
+    torch.manual_seed(123)
+    model = TinyNet()
+    args = types.SimpleNamespace(device="cpu", fix=False, update_frequency=3, only_L=False, sparse_init="ERK",
+                                 sparsity=float(g[f"{tag}/sparsity"]), distributed=False)
+    torch.manual_seed(9)
+    with contextlib.redirect_stdout(io.StringIO()):
+        mk = Masking(torch.optim.SGD(model.parameters(), lr=0.1), None, CosineDecay(0.3, 20), prune_rate=0.3, prune_mode="magnitude",
+                     growth_mode="gradient", redistribution_mode="none", args=args)
+        mk.apply_mask = lambda: None                               # (device kernel; not part of what is pinned here)
+        mk.add_module(model)
+    names = [str(n) for n in g[f"{tag}/names"]]
+    assert list(mk.masks.keys()) == names
+    for n in names:
+        np.testing.assert_array_equal(mk.masks[n].numpy(), g[f"{tag}/m/{n}"], err_msg=n)
