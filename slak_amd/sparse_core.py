@@ -424,8 +424,40 @@ class Masking(object):
             self.check_rank_agreement()
 
     # ------------------------------------------------------------------ utilities
+    def get_momentum_for_weight(self, weight):
+        """sparse_core.py:362-370 (read by the momentum growth / redistribution functions of funcs.py, which are not on this path;
+        kept as the accessor it is)."""
+        st = self.optimizer.state[weight]
+        if 'exp_avg' in st:
+            return st['exp_avg'] / (torch.sqrt(st['exp_avg_sq']) + 1e-08)
+        if 'momentum_buffer' in st:
+            return st['momentum_buffer']
+        raise KeyError("optimizer state of this weight has neither 'exp_avg' nor 'momentum_buffer'")
+
     def get_gradient_for_weights(self, weight):
         return weight.grad.clone()
+
+    def fired_masks_update(self):
+        """sparse_core.py:388-402: which weights have ever been active.  (The reference never creates ``fired_masks``; here it
+        starts as a copy of the current masks on first use.)"""
+        if not hasattr(self, "fired_masks"):
+            self.fired_masks = {}
+        ntotal_fired_weights = ntotal_weights = 0.0
+        layer_fired_weights = {}
+        for module in self.modules:
+            for name, weight in module.named_parameters():
+                if name not in self.masks:
+                    continue
+                prev = self.fired_masks.get(name)
+                cur = self.masks[name].data.byte()
+                self.fired_masks[name] = cur if prev is None else (cur | prev.data.byte())
+                fired = float(self.fired_masks[name].sum().item())
+                ntotal_fired_weights += fired
+                ntotal_weights += float(self.fired_masks[name].numel())
+                layer_fired_weights[name] = fired / float(self.fired_masks[name].numel())
+        total_fired_weights = ntotal_fired_weights / ntotal_weights
+        print('The percentage of the total fired weights is:', total_fired_weights)
+        return layer_fired_weights, total_fired_weights
 
     def print_nonzero_counts(self):
         after = getattr(self, "_nonzeros_after", {})

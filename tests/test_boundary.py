@@ -229,3 +229,26 @@ def test_create_optimizer_surface():
         args.opt = name
         with contextlib.redirect_stdout(io.StringIO()), pytest.raises(NotImplementedError):
             OF.create_optimizer(args, net)
+
+
+def test_masking_accessors():
+    """Masking.get_momentum_for_weight (sparse_core.py:362-370) and fired_masks_update (:388-402): plain accessors of the reference
+    surface."""
+    import contextlib, io, types
+    import torch
+    from slak_amd.sparse_core import Masking
+    net = torch.nn.Linear(4, 3)
+    opt = torch.optim.Adam(net.parameters(), lr=0.1)
+    net(torch.randn(2, 4)).sum().backward(); opt.step()
+    args = types.SimpleNamespace(device="cpu", fix=False, update_frequency=None, only_L=False, sparse_init="uniform", sparsity=0.5, distributed=False)
+    mk = Masking(opt, None, None, prune_mode="magnitude", growth_mode="gradient", redistribution_mode="none", args=args)
+    st = opt.state[net.weight]
+    assert torch.equal(mk.get_momentum_for_weight(net.weight), st["exp_avg"] / (torch.sqrt(st["exp_avg_sq"]) + 1e-08))
+    mk.modules = [net]
+    mk.masks = {"weight": torch.tensor([[1., 0, 0, 1], [0, 0, 1, 0], [0, 0, 0, 0]])}
+    with contextlib.redirect_stdout(io.StringIO()):
+        layer, total = mk.fired_masks_update()
+        assert layer == {"weight": 3 / 12} and total == 3 / 12
+        mk.masks["weight"] = torch.tensor([[0., 1, 0, 1], [0, 0, 0, 0], [0, 0, 0, 1]])
+        layer, total = mk.fired_masks_update()
+    assert total == 5 / 12                                # union of everything that was ever on
