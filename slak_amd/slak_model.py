@@ -40,6 +40,13 @@ def conv_bn(in_channels, out_channels, kernel_size, stride, padding, groups, dil
     return seq
 
 
+def conv_bn_relu(in_channels, out_channels, kernel_size, stride, padding, groups, dilation=1):
+    """conv -> BN -> ReLU (models/SLaK.py:30-36; not used by the SLaK blocks themselves, kept for the module surface)."""
+    seq = conv_bn(in_channels, out_channels, kernel_size, stride, kernel_size // 2 if padding is None else padding, groups, dilation)
+    seq.add_module('nonlinear', nn.ReLU())
+    return seq
+
+
 def fuse_bn(conv, bn):
     std = (bn.running_var + bn.eps).sqrt()
     scale = (bn.weight / std).reshape(-1, 1, 1, 1)
