@@ -103,7 +103,7 @@ size_t slak_dwconv2d_workspace_bytes(int op, int N, int C, int H, int W, int kh,
     if (N <= 0 || C <= 0 || H <= 0 || W <= 0 || kh <= 0 || kw <= 0) return 0;
     ConvDims d{N, C, H, W, kh, kw};
     if (op == 0 || op == 1) { size_t a = dwconv_direct_workspace(d), b = dwconv_mfma_workspace(d), c = dwconv_mfma_small_workspace(d); a = a > b ? a : b; return a > c ? a : c; }
-    if (op == 2) { size_t a = dwconv_wgrad_workspace(d), b = dwconv_mfma_wgrad_workspace(d), c = dwconv_mfma_wgrad_dma_workspace(d), e = dwconv_mfma_small_wgrad_workspace(d), f = dwconv_mfma_small_wgrad_dma_workspace(d), g = dwconv_mfma_wgrad_vrows_workspace(d); a = a > g ? a : g; a = a > b ? a : b; a = a > c ? a : c; a = a > e ? a : e; return a > f ? a : f; }
+    if (op == 2) { size_t a = dwconv_wgrad_workspace(d), b = dwconv_mfma_wgrad_workspace(d), c = dwconv_mfma_wgrad_dma_workspace(d), e = dwconv_mfma_small_wgrad_workspace(d), f = dwconv_mfma_small_wgrad_dma_workspace(d), g = dwconv_mfma_wgrad_vrows_workspace(d), h = dwconv_mfma_wide_wgrad_workspace(d); a = a > g ? a : g; a = a > h ? a : h; a = a > b ? a : b; a = a > c ? a : c; a = a > e ? a : e; return a > f ? a : f; }
     return 0;
 }
 
@@ -115,6 +115,8 @@ int slak_dwconv2d_forward(const void* x, int x_dtype, const void* w, int w_dtype
     ConvDims d{N, C, H, W, kh, kw};
     if (g_conv_algo != SLAK_ALGO_DIRECT && use_dma() && dwconv_mfma_dma_supported(d, x_dtype, w_dtype, y_dtype))
         return launch_dwconv_mfma_dma(x, x_dtype, w, w_dtype, y, y_dtype, d, /*flip=*/false, workspace, workspace_bytes, (hipStream_t)stream);
+    if (g_conv_algo != SLAK_ALGO_DIRECT && dwconv_mfma_wide_supported(d, x_dtype, w_dtype, y_dtype))
+        return launch_dwconv_mfma_wide(x, x_dtype, w, w_dtype, y, y_dtype, d, /*flip=*/false, (hipStream_t)stream);
     if (g_conv_algo != SLAK_ALGO_DIRECT && use_small_dma() && dwconv_mfma_small_dma_supported(d, x_dtype, w_dtype, y_dtype))
         return launch_dwconv_mfma_small_dma(x, x_dtype, w, w_dtype, y, y_dtype, d, /*flip=*/false, (hipStream_t)stream);
     if (g_conv_algo != SLAK_ALGO_DIRECT && use_small() && dwconv_mfma_small_supported(d, x_dtype, w_dtype, y_dtype))
@@ -135,6 +137,8 @@ int slak_dwconv2d_backward_data(const void* dy, int dy_dtype, const void* w, int
     // the filter rotated by 180 degrees (h + kh/2 - r == h - kh/2 + (kh-1-r)).
     if (g_conv_algo != SLAK_ALGO_DIRECT && use_dma() && dwconv_mfma_dma_supported(d, dy_dtype, w_dtype, dx_dtype))
         return launch_dwconv_mfma_dma(dy, dy_dtype, w, w_dtype, dx, dx_dtype, d, /*flip=*/true, workspace, workspace_bytes, (hipStream_t)stream);
+    if (g_conv_algo != SLAK_ALGO_DIRECT && dwconv_mfma_wide_supported(d, dy_dtype, w_dtype, dx_dtype))
+        return launch_dwconv_mfma_wide(dy, dy_dtype, w, w_dtype, dx, dx_dtype, d, /*flip=*/true, (hipStream_t)stream);
     if (g_conv_algo != SLAK_ALGO_DIRECT && use_small_dma() && dwconv_mfma_small_dma_supported(d, dy_dtype, w_dtype, dx_dtype))
         return launch_dwconv_mfma_small_dma(dy, dy_dtype, w, w_dtype, dx, dx_dtype, d, /*flip=*/true, (hipStream_t)stream);
     if (g_conv_algo != SLAK_ALGO_DIRECT && use_small() && dwconv_mfma_small_supported(d, dy_dtype, w_dtype, dx_dtype))
@@ -163,6 +167,8 @@ int slak_dwconv2d_backward_filter(const void* dy, int dy_dtype, const void* x, i
     }
     if (g_conv_algo != SLAK_ALGO_DIRECT && use_dma() && dwconv_mfma_wgrad_dma_supported(d, dy_dtype, x_dtype))
         return launch_dwconv_mfma_wgrad_dma(dy, dy_dtype, x, x_dtype, dw, d, workspace, workspace_bytes, (hipStream_t)stream);
+    if (g_conv_algo != SLAK_ALGO_DIRECT && dwconv_mfma_wide_wgrad_supported(d, dy_dtype, x_dtype))
+        return launch_dwconv_mfma_wide_wgrad(dy, dy_dtype, x, x_dtype, dw, d, workspace, workspace_bytes, (hipStream_t)stream);
     if (g_conv_algo != SLAK_ALGO_DIRECT && dwconv_mfma_wgrad_supported(d, dy_dtype, x_dtype))
         return launch_dwconv_mfma_wgrad(dy, dy_dtype, x, x_dtype, dw, d, workspace, workspace_bytes, (hipStream_t)stream);
     if (g_conv_algo == SLAK_ALGO_MFMA) return SLAK_ERR_UNSUPPORTED;

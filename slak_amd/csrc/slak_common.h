@@ -75,6 +75,14 @@ bool dwconv_mfma_dma_supported(const ConvDims& d, int x_dt, int w_dt, int y_dt);
 int launch_dwconv_mfma_dma(const void* x, int x_dt, const void* w, int w_dt, void* y, int y_dt,
                            const ConvDims& d, bool flip_filter, void* ws, size_t ws_bytes, hipStream_t st);
 
+bool dwconv_mfma_wide_supported(const ConvDims& d, int x_dt, int w_dt, int y_dt);
+int launch_dwconv_mfma_wide(const void* x, int x_dt, const void* w, int w_dt, void* y, int y_dt,
+                            const ConvDims& d, bool flip_filter, hipStream_t st);
+bool dwconv_mfma_wide_wgrad_supported(const ConvDims& d, int dy_dt, int x_dt);
+size_t dwconv_mfma_wide_wgrad_workspace(const ConvDims& d);
+int launch_dwconv_mfma_wide_wgrad(const void* dy, int dy_dt, const void* x, int x_dt, float* dw,
+                                  const ConvDims& d, void* ws, size_t ws_bytes, hipStream_t st);
+
 bool dwconv_mfma_small_dma_supported(const ConvDims& d, int x_dt, int w_dt, int y_dt);
 int launch_dwconv_mfma_small_dma(const void* x, int x_dt, const void* w, int w_dt, void* y, int y_dt,
                                  const ConvDims& d, bool flip_filter, hipStream_t st);
