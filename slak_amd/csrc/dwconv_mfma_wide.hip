@@ -46,6 +46,32 @@ struct WideParams {
     unsigned tensor_bytes;
 };
 
+// One 32x32 output tile: blocks dd = LO..HI (k-steps 2 mt - 2 + dd; `rp` already points at k-step 2 mt - 2), five short taps each,
+// ONE accumulator.  Software pipeline pinned with sched_barrier: hipcc otherwise sinks every ds_read next to its MFMA (ds_read;
+// s_waitcnt lgkmcnt(0); v_mfma).  The fragment of tap r for the next block is fetched right after this block's MFMA of tap r has
+// issued, into the same registers.
+template <typename T, bool VERT, int LO, int HI>
+__device__ __forceinline__ f32x16 wide_tile_mma(const s16x8 (&afrag)[MF_TAPS][WD_ND], const char* L, unsigned rp, unsigned rpitch) {
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    s16x8 b[MF_TAPS];
+#pragma unroll
+    for (int r = 0; r < MF_TAPS; ++r) b[r] = __builtin_bit_cast(s16x8, *(const u32x4*)(L + rp + (unsigned)r * rpitch + LO * 32u));
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int dd = LO; dd <= HI; ++dd) {
+#pragma unroll
+        for (int r = 0; r < MF_TAPS; ++r) {
+            // vertical: operands swapped (D^T = X^T-tile x T^T) so that a lane holds 4 consecutive columns of one output row
+            acc = VERT ? mfma32<T>(b[r], afrag[r][dd], acc) : mfma32<T>(afrag[r][dd], b[r], acc);
+            if (dd < HI) b[r] = __builtin_bit_cast(s16x8, *(const u32x4*)(L + rp + (unsigned)r * rpitch + (dd + 1) * 32u));
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    return acc;
+}
+
 template <typename T, bool VERT>
 __global__ __launch_bounds__(MF_THREADS, 2) void dwconv_mfma_wide_kernel(const WideParams p) {
     extern __shared__ __attribute__((aligned(16))) uint16_t lds[];
@@ -230,27 +256,17 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dwconv_mfma_wide_kernel(const W
             if (has_tile) {
                 // fragment of tap r, block dd: 16 bytes at row (32 s + l31 + r) of the guarded image, columns 16 ks + 8 lhi ..
                 const unsigned rp = img_b + (unsigned)(s * 32 + l31) * rpitch + (unsigned)lhi * 16u + (unsigned)(2 * mt - 2) * 32u;
-                auto load_b = [&](int r, int dd) -> s16x8 {
-                    return __builtin_bit_cast(s16x8, *(const u32x4*)(L + rp + (unsigned)r * rpitch + (unsigned)dd * 32u));
-                };
                 f32x16 acc;
-#pragma unroll
-                for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-                s16x8 b[MF_TAPS];
-#pragma unroll
-                for (int r = 0; r < MF_TAPS; ++r) b[r] = load_b(r, dd_lo);
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int dd = 0; dd < WD_ND; ++dd) {
-                    if (dd < dd_lo || dd > dd_hi) continue;           // wave-uniform
-#pragma unroll
-                    for (int r = 0; r < MF_TAPS; ++r) {
-                        // vertical: operands swapped (D^T = X^T-tile x T^T) so that a lane holds 4 consecutive columns of one output row
-                        acc = VERT ? mfma32<T>(b[r], afrag[r][dd], acc) : mfma32<T>(afrag[r][dd], b[r], acc);
-                        if (dd < dd_hi) b[r] = load_b(r, dd + 1);
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
+                // the block range is wave-uniform but not a compile-time constant; one straight-line instantiation per range
+                // (conditions inside the pinned pipeline made hipcc shuffle the fragment registers: ~50 instructions per MFMA)
+#define SLAK_WD_CASE(LO, HI) case (LO) * 8 + (HI): acc = wide_tile_mma<T, VERT, LO, HI>(afrag, L, rp, rpitch); break;
+                switch (dd_lo * 8 + dd_hi) {
+                    SLAK_WD_CASE(0, 2) SLAK_WD_CASE(0, 3) SLAK_WD_CASE(0, 4) SLAK_WD_CASE(0, 5)
+                    SLAK_WD_CASE(1, 2) SLAK_WD_CASE(1, 3) SLAK_WD_CASE(1, 4) SLAK_WD_CASE(1, 5)
+                    SLAK_WD_CASE(2, 2) SLAK_WD_CASE(2, 3) SLAK_WD_CASE(2, 4) SLAK_WD_CASE(2, 5)
+                    default: acc = wide_tile_mma<T, VERT, 0, 5>(afrag, L, rp, rpitch); break;      // not reached (fill_wide_params)
                 }
+#undef SLAK_WD_CASE
                 const bool row_ok = VERT ? (mt * 32 + l31 < p.Wt) : (s * 32 + l31 < p.Wl);
                 const int col0 = VERT ? s * 32 + 4 * lhi : mt * 32 + 4 * lhi, ncol = VERT ? p.Wl : p.Wt;
                 if (row_ok) {
@@ -329,11 +345,14 @@ template <typename T, bool VERT>
 static int launch_wide_tv(WideParams& p, const ConvDims& d, hipStream_t st) {
     auto k = dwconv_mfma_wide_kernel<T, VERT>;
     const size_t lds = wide_lds_bytes(p);
-    if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    int per_cu = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k, MF_THREADS, lds) != hipSuccess || per_cu < 1) per_cu = 1;
-    if (per_cu > 8) per_cu = 8;
-    fill_wide_params(p, d, VERT, per_cu * mfma_cu_count());
+    static thread_local size_t cached_lds = 0; static thread_local int cached_per_cu = 0;     // per instantiation; queried once per LDS size
+    if (cached_lds != lds) {
+        if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        int per_cu = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k, MF_THREADS, lds) != hipSuccess || per_cu < 1) per_cu = 1;
+        cached_per_cu = per_cu > 8 ? 8 : per_cu; cached_lds = lds;
+    }
+    fill_wide_params(p, d, VERT, cached_per_cu * mfma_cu_count());
     hipLaunchKernelGGL(k, dim3((unsigned)(p.C * p.slices)), dim3(MF_THREADS), lds, st, p);
     SLAK_LAUNCH_CHECK();
     return SLAK_OK;

@@ -276,11 +276,15 @@ template <typename T, bool VERT>
 static int launch_wide_wgrad_tv(WideWgradParams& p, const ConvDims& d, size_t ws_bytes, hipStream_t st) {
     auto k = dwconv_mfma_wide_wgrad_kernel<T, VERT>;
     const size_t lds = wide_wgrad_lds_bytes(p);
-    if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    int per_cu = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k, p.ntiles * 64, lds) != hipSuccess || per_cu < 1) per_cu = 1;
-    if (per_cu > 8) per_cu = 8;
-    fill_wide_wgrad_params(p, d, VERT, per_cu * mfma_cu_count());
+    static thread_local size_t cached_key = 0; static thread_local int cached_per_cu = 0;     // per instantiation; queried once per (LDS size, block size)
+    const size_t key = lds * 16 + (size_t)p.ntiles;
+    if (cached_key != key) {
+        if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        int per_cu = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k, p.ntiles * 64, lds) != hipSuccess || per_cu < 1) per_cu = 1;
+        cached_per_cu = per_cu > 8 ? 8 : per_cu; cached_key = key;
+    }
+    fill_wide_wgrad_params(p, d, VERT, cached_per_cu * mfma_cu_count());
     if ((size_t)p.slices * d.C * d.kh * d.kw * sizeof(float) > ws_bytes) return SLAK_ERR_WORKSPACE;
     hipLaunchKernelGGL(k, dim3((unsigned)(p.C * p.slices)), dim3((unsigned)(p.ntiles * 64)), lds, st, p);
     SLAK_LAUNCH_CHECK();

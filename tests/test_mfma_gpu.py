@@ -65,6 +65,10 @@ SHAPES = [
     (5, 3, 12, 16, 5, 13), (5, 3, 16, 12, 13, 5), (3, 9, 14, 16, 5, 31),
     # vertical weight gradient by row reads + shifted copy: first and last chunk of the tensor, non-square planes, narrow planes
     (3, 2, 56, 56, 51, 5), (1, 1, 40, 48, 31, 5), (2, 2, 64, 16, 51, 5), (2, 3, 36, 24, 35, 5),
+    # wide maps (64 < long axis <= 128: banded Toeplitz, strip walk, padded-pitch plane DMA): BASELINE configs[4] stage 1 (96x96,
+    # 61-tap), the 128x128 planes of the 512 px segmentation crops, non-square / non-multiple-of-32 maps, single plane
+    (3, 2, 96, 96, 5, 61), (3, 2, 96, 96, 61, 5), (2, 3, 96, 96, 5, 5), (2, 2, 128, 128, 5, 61), (2, 2, 128, 128, 61, 5),
+    (5, 3, 80, 96, 5, 51), (5, 3, 96, 80, 51, 5), (2, 2, 112, 72, 57, 5), (2, 2, 72, 112, 5, 57), (1, 1, 96, 96, 61, 5), (4, 2, 128, 96, 5, 31),
 ]
 
 
@@ -115,7 +119,7 @@ def test_mfma_is_what_auto_runs_for_lowp(gpu):
     assert (y_auto.float() - y_direct.float()).abs().max().item() <= 1e-2 * max(1.0, y_direct.float().abs().max().item())
 
 
-@pytest.mark.parametrize("H,W,kh,kw", [(56, 56, 5, 51), (56, 56, 51, 5), (28, 28, 49, 5), (14, 14, 5, 47), (7, 7, 13, 5)])
+@pytest.mark.parametrize("H,W,kh,kw", [(56, 56, 5, 51), (56, 56, 51, 5), (28, 28, 49, 5), (14, 14, 5, 47), (7, 7, 13, 5), (96, 96, 5, 61), (96, 96, 61, 5)])
 def test_mfma_nan_stays_in_its_plane(H, W, kh, kw, mfma_only, gpu):
     """The DMA images carry no padding and planes are packed into shared MFMA tiles: a NaN/Inf in one plane must not
     reach any other plane (zero padding is applied with selects, never by multiplying)."""
@@ -137,7 +141,8 @@ def test_mfma_nan_stays_in_its_plane(H, W, kh, kw, mfma_only, gpu):
 def test_mfma_identity_and_adjoint_full_size(mfma_only, gpu):
     ops = _ops()
     torch.manual_seed(3)
-    for (N, C, H, W, kh, kw) in [(128, 96, 56, 56, 51, 5), (128, 96, 56, 56, 5, 51), (128, 192, 28, 28, 5, 49), (128, 384, 14, 14, 47, 5)]:
+    for (N, C, H, W, kh, kw) in [(128, 96, 56, 56, 51, 5), (128, 96, 56, 56, 5, 51), (128, 192, 28, 28, 5, 49), (128, 384, 14, 14, 47, 5),
+                               (64, 96, 96, 96, 61, 5), (64, 96, 96, 96, 5, 61)]:      # last two: BASELINE configs[4] stage 1 at its per-GPU batch
         x = torch.randn(N, C, H, W, device=gpu).bfloat16()
         dy = torch.randn(N, C, H, W, device=gpu).bfloat16()
         w = (torch.randn(C, 1, kh, kw, device=gpu) * 0.02).bfloat16().float()      # exactly representable filter
