@@ -10,6 +10,12 @@ plus the HBM roofline of the dominant hot-path kernel and the reference CPU nn.C
 Workload: N=1 -> BASELINE.json configs[1] (bs 128, sparsity off).  N>1 -> configs[2] (bs 128 per GPU, DDP over
 RCCL, SyncBN, Masking sparsity 0.4 with prune-and-grow every 2000 steps), weak scaling.  Synthetic data
 (seeded randn images, randint targets), random-init weights.  One JSON line on rank 0.
+
+The other BASELINE configurations run with the same command and the same JSON line:
+    python bench.py --model base                      configs[3]: SLaK-B 51x51, 64 images per GPU (512 over 8), sparsity 0.4
+    python bench.py --kernel 61 --res 384             configs[4]: SLaK-T 61x61 at 384 px, 64 images per GPU (256 over 4)
+`mask_step` (rank 0, outside the timed region): the Masking kernels alone on the model's mask set -- apply and prune-and-grow,
+HIP-event timed, against SURVEY 8(d)'s 12 / 20 bytes per masked element -- next to a CPU port of the reference step.
 """
 import argparse
 import json
@@ -54,7 +60,20 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 HBM_PEAK_GBS = 8000.0           # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
-STAGES_T = [(96, 56, 51, 3), (192, 28, 49, 3), (384, 14, 47, 9), (768, 7, 13, 3)]    # C, H=W, K, blocks  
+VARIANTS = {"tiny": ((3, 3, 9, 3), (96, 192, 384, 768)), "small": ((3, 3, 27, 3), (96, 192, 384, 768)),
+            "base": ((3, 3, 27, 3), (128, 256, 512, 1024)), "large": ((3, 3, 27, 3), (192, 384, 768, 1536))}   # models/SLaK.py:237-280
+
+
+def kernel_sizes(K):
+    """[51, 49, 47, 13, 5] for K = 51 (the README recipes); K = 61 shifts the three large ones: [61, 59, 57, 13, 5]."""
+    return [K, K - 2, K - 4, 13, 5]
+
+
+def stages_of(model, K, res):
+    """(C, H=W, K_stage, blocks) per stage: SURVEY.md Appendix A for cfg 2-5."""
+    depths, dims = VARIANTS[model]
+    ks = kernel_sizes(K)
+    return [(dims[i], res // (4 << i), ks[i], depths[i]) for i in range(4)]
 
 
 def parse():
@@ -62,8 +81,14 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=128, help="per-GPU batch (BASELINE cfg 2/3: 128)")
-    ap.add_argument("--sparsity", type=float, default=None, help="default: 0 at N=1 (cfg 2), 0.4 at N>1 (cfg 3)")
+    ap.add_argument("--model", choices=sorted(VARIANTS), default="tiny", help="SLaK variant (BASELINE configs[3]: base)")
+    ap.add_argument("--kernel", type=int, default=51, help="largest kernel: 51 -> [51,49,47,13,5]; 61 -> [61,59,57,13,5] (BASELINE configs[4])")
+    ap.add_argument("--res", type=int, default=224, help="input resolution (BASELINE configs[4]: 384)")
+    ap.add_argument("--batch", type=int, default=None, help="per-GPU batch; default 128 (configs[1], [2]), 64 for --model base (configs[3]) and --res 384 (configs[4])")
+    ap.add_argument("--sparsity", type=float, default=None, help="default: 0 at N=1 (configs[1]), 0.4 at N>1 (configs[2]) and for --model base (configs[3])")
+    ap.add_argument("--only-L", action="store_true", help="mask only the large-kernel LoRA weights (--only_L of the reference recipes)")
+    ap.add_argument("--no-mask-bench", action="store_true", help="skip the mask_step measurement")
+    ap.add_argument("--debug-mask-sync", action="store_true", help="N>1: all-reduce a mask checksum after the timed region and fail on disagreement")
     ap.add_argument("--update-frequency", type=int, default=2000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -93,7 +118,7 @@ def event_time_ms(fn, reps, stream_device):
     return e0.elapsed_time(e1) / reps
 
 
-def hot_path_kernels(device, batch, reps, dtype):
+def hot_path_kernels(device, batch, reps, dtype, stages):
     """Every distinct (stage, kernel, pass) of the dw-conv hot path at the bench shapes, timed alone: the C-ABI entry points
     are called directly on preallocated buffers (the tensor-level wrappers of slak_amd.ops add ~10 us of host work per call,
     more than the smallest kernels take), HIP events on the launch stream around `reps` back-to-back launches."""
@@ -102,7 +127,7 @@ def hot_path_kernels(device, batch, reps, dtype):
     st = torch.cuda.current_stream(device).cuda_stream
     out = []
     b = 2 if dtype != torch.float32 else 4
-    for si, (C, HW, K, blocks) in enumerate(STAGES_T):
+    for si, (C, HW, K, blocks) in enumerate(stages):
         x = torch.randn(batch, C, HW, HW, device=device).to(dtype)
         dy = torch.randn_like(x)
         y = torch.empty_like(x)
@@ -137,12 +162,12 @@ def measured_traffic(k):
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
             tab = json.load(f)
         e = tab.get("s%d_%s_%s" % (k["stage"], k["kernel"], k["op"]))
-        return None if e is None else e["hbm_bytes_per_launch"]
+        return None if (e is None or e.get("alg_bytes") != k["alg_bytes"]) else e["hbm_bytes_per_launch"]   # same shape only
     except (OSError, ValueError):
         return None
 
 
-def cpu_baseline(threads, batch=4, seconds_per_shape=1.5):
+def cpu_baseline(threads, stages, label, batch=4, seconds_per_shape=1.5):
     """Reference CPU path (north star: 'the reference CPU nn.Conv2d path timed on the node's host cores'):
     torch CPU F.conv2d fp32 fwd + bwd of every distinct dw conv of SLaK-T (BASELINE cfg 1 is the stage-1 block of
     this list), weighted by how often each occurs per image -> images/s of the dw-conv hot path alone.
@@ -153,7 +178,9 @@ def cpu_baseline(threads, batch=4, seconds_per_shape=1.5):
     detail = {}
     ncalls = 0
     t_start = time.perf_counter()
-    for (C, HW, K, blocks) in STAGES_T:
+    if stages[0][1] > 64:
+        batch = 2                                                 # 96x96 planes: keep the sample inside ~20-30 s
+    for (C, HW, K, blocks) in stages:
         x = torch.randn(batch, C, HW, HW, requires_grad=True)
         for kh, kw in ((K, 5), (5, K), (5, 5)):
             w = (torch.randn(C, 1, kh, kw) * 0.02).requires_grad_(True)
@@ -169,11 +196,68 @@ def cpu_baseline(threads, batch=4, seconds_per_shape=1.5):
             t = sorted(ts)[len(ts) // 2]
             detail["s%d_%dx%d" % (HW, kh, kw)] = t
             total += t * blocks
-    return dict(value=batch / total, unit="images/s (dw-conv hot path only: all 54 convs fwd+bwd)", cores=threads, kind="reference",
-                sample="torch %s CPU F.conv2d fp32 fwd+bwd, batch %d, every distinct SLaK-T dw-conv shape (cfg-1 stage-1 block: "
+    s1 = "s%d_" % stages[0][1]
+    return dict(value=batch / total, unit="images/s (dw-conv hot path only: all %d convs fwd+bwd)" % (3 * sum(st[3] for st in stages)),
+                cores=threads, kind="reference",
+                sample="torch %s CPU F.conv2d fp32 fwd+bwd, batch %d, every distinct %s dw-conv shape (stage-1 block: "
                        "%.1f ms per image), median of %d calls in total, weighted by blocks/stage; wall %.1f s" % (
-                           torch.__version__, batch, 1e3 / batch * sum(v for k, v in detail.items() if k.startswith("s56")), ncalls,
+                           torch.__version__, batch, label, 1e3 / batch * sum(v for k, v in detail.items() if k.startswith(s1)), ncalls,
                            time.perf_counter() - t_start))
+
+
+def mask_step_bench(device, model_name, ks, only_L, reps=20, cpu_seconds=12.0):
+    """The Masking kernels alone: `slak_mask_apply` (ordinary steps when the optimizer does not fold
+    the mask in; 12 B per masked element: w r/w + mask r) and `slak_mask_prune_and_grow` (update steps; fused ideal 20 B per element:
+    w r/w 8 + grad r 4 + mask r/w 8) over the mask set of the bench model -- every 2-D / 4-D parameter (95 tensors / 30.7 M elements
+    for SLaK-T; --only-L: the 36 LoRA tensors) -- through the C ABI, HIP events on the launch stream.  `passes` = how many times the
+    implementation streams the key arrays (exact radix select: 4 histogram passes + tie count + select per k-th-element search,
+    twice, + count + apply).  CPU side: the numpy port of sparse_core.Masking.truncate_weights / funcs.magnitude_prune /
+    gradient_growth (oracle/mask_oracle.py; the reference itself is not on this box) on a bounded prefix of the same tensors."""
+    import ctypes
+    from slak_amd import _lib
+    from slak_amd.slak_model import slak_mask_set_shapes
+    L = _lib.lib()
+    st = torch.cuda.current_stream(device).cuda_stream
+    shapes = slak_mask_set_shapes(model_name, tuple(ks), only_L=only_L)
+    g = torch.Generator(device=device).manual_seed(99)
+    ws = [torch.randn(s, device=device, generator=g) * 0.02 for s in shapes]
+    ms = [(torch.rand(s, device=device, generator=g) < 0.6).float() for s in shapes]
+    for w, m in zip(ws, ms):
+        w.mul_(m)
+    gs = [torch.randn(s, device=device, generator=g) for s in shapes]
+    segs = (_lib.MaskSegment * len(shapes))()
+    for i in range(len(shapes)):
+        segs[i].weight, segs[i].mask, segs[i].grad, segs[i].momentum, segs[i].numel = ws[i].data_ptr(), ms[i].data_ptr(), gs[i].data_ptr(), None, ws[i].numel()
+    plan = ctypes.c_void_p()
+    _lib.check(L.slak_mask_plan_create(segs, len(shapes), ctypes.byref(plan)), "slak_mask_plan_create")
+    elems = sum(w.numel() for w in ws)
+    t_apply = event_time_ms(lambda: _lib.check(L.slak_mask_apply(plan, st)), reps, device)
+    t_update = event_time_ms(lambda: _lib.check(L.slak_mask_prune_and_grow(plan, 0.3, st)), reps, device)
+    density = float(sum(m.sum().item() for m in ms)) / elems
+    L.slak_mask_plan_destroy(plan)
+    out = {"tensors": len(shapes), "elements": elems, "only_L": bool(only_L),
+           "apply_ms": t_apply, "apply_alg_bytes": 12 * elems, "apply_gbs": 12 * elems / t_apply / 1e6, "apply_frac_of_hbm_peak": 12 * elems / t_apply / 1e6 / HBM_PEAK_GBS,
+           "update_ms": t_update, "update_alg_bytes": 20 * elems, "update_gbs": 20 * elems / t_update / 1e6, "update_frac_of_hbm_peak": 20 * elems / t_update / 1e6 / HBM_PEAK_GBS,
+           "update_passes_over_keys": 14, "update_launches": 25, "density_after": density,
+           "note": "apply is folded into MaskedAdamW's update on ordinary steps (0 extra bytes); prune-and-grow runs every update_frequency steps"}
+    # CPU port on a bounded prefix of the same mask set
+    import oracle
+    t0 = time.perf_counter(); done = 0; n_t = 0
+    order = sorted(range(len(shapes)), key=lambda i: ws[i].numel())          # small tensors first: several tensors inside the budget
+    cw, cm, cg = {}, {}, {}
+    for i in order:
+        cw[str(i)] = ws[i].cpu().numpy(); cm[str(i)] = ms[i].cpu().numpy(); cg[str(i)] = gs[i].cpu().numpy()
+        done += ws[i].numel(); n_t += 1
+        if done >= 4_000_000:
+            break
+    t1 = time.perf_counter(); reps_cpu = 0
+    while reps_cpu < 1 or (time.perf_counter() - t1 < cpu_seconds and reps_cpu < 20):
+        oracle.truncate_weights(cw, cm, cg, 0.3); reps_cpu += 1
+    dt = (time.perf_counter() - t1) / reps_cpu
+    out["cpu_port"] = {"kind": "port", "cores": 1, "ms_per_update": dt * 1e3, "elements": done, "tensors": n_t,
+                       "melem_per_s": done / dt / 1e6, "gpu_melem_per_s": elems / (t_update / 1e3) / 1e6,
+                       "sample": "oracle/mask_oracle.py truncate_weights (numpy restatement of sparse_core.py:335-357, funcs.py:107-114,196-205) on the %d smallest tensors (%d elements), %d repetitions" % (n_t, done, reps_cpu)}
+    return out
 
 
 def main():
@@ -191,7 +275,12 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=device)        # "nccl" is RCCL on ROCm
     n_gpus = world if distributed else 1
-    sparsity = a.sparsity if a.sparsity is not None else (0.4 if n_gpus > 1 else 0.0)
+    ks = kernel_sizes(a.kernel)
+    stages = stages_of(a.model, a.kernel, a.res)
+    batch = a.batch if a.batch is not None else (64 if (a.model != "tiny" or a.res > 224) else 128)
+    a.batch = batch
+    sparsity = a.sparsity if a.sparsity is not None else (0.4 if (n_gpus > 1 or a.model == "base") and a.res == 224 else 0.0)
+    label = "SLaK-%s %dx%d" % (a.model[0].upper(), a.kernel, a.kernel)
 
     torch.backends.cudnn.benchmark = bool(a.cudnn_benchmark)       # main.py:235
     import slak_amd.slak_model as M
@@ -204,8 +293,9 @@ def main():
     block_ops.cache_lowp_weights = True                            # bf16 weight copies refreshed by one multi-tensor launch per step
     M.use_sync_bn = True                                          # reference default (models/SLaK.py:19); falls back to BN math at world 1
     torch.manual_seed(0 + rank)                                   # main.py:232  seed = args.seed + rank
-    model = M.SLaK_tiny(kernel_size=[51, 49, 47, 13, 5], Decom=True, bn=True, drop_path_rate=0.1,
-                        lowp_dwconv=not a.fp32_dwconv).to(device)
+    drop_path = {"tiny": 0.1, "small": 0.4, "base": 0.5, "large": 0.5}[a.model]      # README training recipes
+    model = M.create_model("SLaK_" + a.model, kernel_size=ks, Decom=True, bn=True, drop_path_rate=drop_path,
+                           lowp_dwconv=not a.fp32_dwconv).to(device)
     if distributed:
         model = nn.parallel.DistributedDataParallel(model, device_ids=[local_rank], find_unused_parameters=False)   # main.py:374-376
     decay, no_decay = [], []
@@ -220,7 +310,7 @@ def main():
     criterion = nn.CrossEntropyLoss(label_smoothing=0.1)
     mask = None
     if sparsity > 0:
-        margs = types.SimpleNamespace(device=str(device), fix=False, update_frequency=a.update_frequency, only_L=False,
+        margs = types.SimpleNamespace(device=str(device), fix=False, update_frequency=a.update_frequency, only_L=a.only_L,
                                       sparse_init="uniform", sparsity=sparsity, distributed=distributed)
         import contextlib, io
         with contextlib.redirect_stdout(io.StringIO()):
@@ -234,7 +324,7 @@ def main():
         model_ema = ModelEma(model.module if distributed else model, decay=0.9999, device='', resume='')   # built from the unwrapped model (main.py:341 precedes the DDP wrap)
 
     g = torch.Generator(device=device).manual_seed(1234 + rank)
-    samples = torch.randn(a.batch, 3, 224, 224, device=device, generator=g)
+    samples = torch.randn(a.batch, 3, a.res, a.res, device=device, generator=g)
     targets = torch.randint(0, 1000, (a.batch,), device=device, generator=g)
 
     def step():
@@ -263,37 +353,68 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    per_rank_ms = [1e3 * elapsed / a.steps]
+    mask_sync = None
     if distributed:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        allt = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(allt, t)
+        per_rank_ms = [1e3 * x.item() / a.steps for x in allt]
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
+        if mask is not None:                                      # outside the timed region: one 24-byte all-reduce
+            agree = mask.ranks_agree()
+            mask_sync = {"ranks_agree": agree, "resyncs": mask.rank_resyncs}
+            if a.debug_mask_sync and not agree:
+                sys.exit("mask checksum differs across ranks")
     final_loss = float(loss.item())
     ms_per_step = 1e3 * elapsed / a.steps
     value = n_gpus * a.batch * a.steps / elapsed
 
+    if a.model == "tiny" and a.kernel == 51 and a.res == 224:
+        workload = ("BASELINE configs[1]: SLaK-T 51x51 full model, bs=128, 224x224, bf16, sparsity off" if sparsity == 0 else
+                    "BASELINE configs[2]: SLaK-T 51x51, bs=%d/GPU, 224x224, bf16, DDP over RCCL, Masking sparsity %.2f, prune-and-grow every %d steps" % (a.batch, sparsity, a.update_frequency))
+    elif a.model == "base" and a.kernel == 51 and a.res == 224:
+        workload = "BASELINE configs[3]: SLaK-B 51x51, bs=%d/GPU (512 over 8 GPUs), 224x224, bf16, Masking sparsity %.2f, prune-and-grow every %d steps" % (a.batch, sparsity, a.update_frequency)
+    elif a.model == "tiny" and a.kernel == 61 and a.res == 384:
+        workload = "BASELINE configs[4]: SLaK-T 61x61, bs=%d/GPU (256 over 4 GPUs), 384x384 input, bf16, sparsity %s" % (a.batch, "off" if sparsity == 0 else "%.2f" % sparsity)
+    else:
+        workload = "%s, bs=%d/GPU, %dx%d, bf16, sparsity %.2f (not a BASELINE configuration)" % (label, a.batch, a.res, a.res, sparsity)
+    tun = None
+    try:
+        tun = {"enabled": bool(torch.cuda.tunable.is_enabled()), "solutions_in_use": len(torch.cuda.tunable.get_results())}
+    except Exception:
+        pass
     out = {
-        "metric": "images/sec SLaK-T 51x51 224px bf16 train step", "value": value, "unit": "images/s",
+        "metric": "images/sec %s %dpx bf16 train step" % (label, a.res), "value": value, "unit": "images/s",
         "n_gpus": n_gpus, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_per_step,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-        "config": {"workload": ("BASELINE configs[1]: SLaK-T 51x51 full model, bs=128, 224x224, bf16, sparsity off" if sparsity == 0 else
-                                "BASELINE configs[2]: SLaK-T 51x51, bs=128/GPU, 224x224, bf16, DDP over RCCL, Masking sparsity %.2f, prune-and-grow every %d steps" % (sparsity, a.update_frequency)),
+        "config": {"workload": workload,
                    "global_batch": n_gpus * a.batch, "per_gpu_batch": a.batch, "parallelism": "dp%d" % n_gpus,
+                   "kernel_sizes": ks, "resolution": a.res, "variant": a.model,
                    "dwconv_dtype": "fp32" if a.fp32_dwconv else "bf16 in/out, fp32 accumulate", "optimizer": "torch AdamW(fused)" if a.torch_adamw else "slak_amd MaskedAdamW (update + mask + bf16 copies, one launch)",
                    "model_ema": bool(a.model_ema),
                    "sync_bn": True, "block_tail": "hip (ln_nchw_to_nhwc + scale_residual)" if M.Block.fused_tail else "pytorch ops",
                    "branch_bn": "hip (bn3: one stats pass + one apply pass)" if M.ReparamLargeKernelConv.fused_bn else "pytorch (Sync)BatchNorm x3 + adds",
                    "pointwise_gemm": "hipBLASLt via torch" + (", TunableOp solutions from slak_amd/tuning/tunableop_gfx950.csv" if TUNED_GEMMS else ""),
+                   "tunableop": tun,
                    "cudnn_benchmark": bool(a.cudnn_benchmark),
+                   "world_size": (dist.get_world_size() if distributed else 1),
+                   "rccl_version": (".".join(str(v) for v in torch.cuda.nccl.version()) if distributed else None),
+                   "per_rank_ms_per_step": [round(v, 4) for v in per_rank_ms],
+                   "mask_sync": mask_sync,
                    "final_loss": final_loss},
     }
 
     if rank == 0 and not a.no_roofline:
-        ks = hot_path_kernels(device, a.batch, a.kernel_reps, torch.float32 if a.fp32_dwconv else torch.bfloat16)
-        for k in ks:
+        del samples
+        torch.cuda.empty_cache()
+        kl = hot_path_kernels(device, a.batch, a.kernel_reps, torch.float32 if a.fp32_dwconv else torch.bfloat16, stages)
+        for k in kl:
             k["step_ms"] = k["ms"] * k["calls_per_step"]
-        dom = max(ks, key=lambda k: k["step_ms"])
-        hot_ms = sum(k["step_ms"] for k in ks)
-        hot_bytes = sum(k["alg_bytes"] * k["calls_per_step"] for k in ks)
+        dom = max(kl, key=lambda k: k["step_ms"])
+        hot_ms = sum(k["step_ms"] for k in kl)
+        hot_bytes = sum(k["alg_bytes"] * k["calls_per_step"] for k in kl)
         out["roofline"] = {"bound": "hbm", "achieved": dom["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": dom["gbs"] / HBM_PEAK_GBS,
                            "traffic": measured_traffic(dom), "kernel": "dwconv %s %s stage %d (N=%d)" % (dom["kernel"], dom["op"], dom["stage"], a.batch),
                            "avg_launch_ms": dom["ms"], "alg_bytes_per_launch": dom["alg_bytes"],
@@ -302,9 +423,11 @@ def main():
                            "dwconv_gbs": hot_bytes / hot_ms / 1e6, "dwconv_frac_of_hbm_peak": hot_bytes / hot_ms / 1e6 / HBM_PEAK_GBS,
                            "share_of_step": hot_ms / ms_per_step,
                            "images_per_s_dwconv_only": a.batch / (hot_ms / 1e3),
-                           "kernels": [{k2: (round(v, 4) if isinstance(v, float) else v) for k2, v in k.items()} for k in ks]}
+                           "kernels": [{k2: (round(v, 4) if isinstance(v, float) else v) for k2, v in k.items()} for k in kl]}
+    if rank == 0 and not a.no_mask_bench:
+        out["mask_step"] = mask_step_bench(device, a.model, ks, a.only_L)
     if rank == 0 and n_gpus == 1 and not a.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(min(os.cpu_count() or 1, 32))   # >32 threads only oversubscribes a 96-channel depthwise conv
+        out["cpu_baseline"] = cpu_baseline(min(os.cpu_count() or 1, 32), stages, label)   # >32 threads only oversubscribes a 96-channel depthwise conv
     if rank == 0:
         print(json.dumps(out))
     if distributed:

@@ -130,7 +130,14 @@ class Masking(object):
         self._plan_names = []
         self._plan_key = None
         self._synced_once = False
+        # rank agreement: masks are computed independently on every rank after the one broadcast, so a rank-local perturbation
+        # (un-reduced gradients under no_sync(), a rank-local weight edit, a nondeterministic kernel) would otherwise diverge
+        # silently; the reference re-broadcasts every step and so heals itself (sparse_core.py:404-407).  One 24-byte all-reduce
+        # per prune-and-grow round / load_state_dict (every update_frequency steps) checks it; on a mismatch rank 0's masks are
+        # re-broadcast (the reference's rule) and counted in `rank_resyncs`, or an error is raised with args.debug_mask_sync.
+        self.check_ranks = bool(getattr(args, "check_mask_sync", True))
         self.debug_check_ranks = bool(getattr(args, "debug_mask_sync", False))
+        self.rank_resyncs = 0
 
         if self.half:
             raise NotImplementedError("fp16 master-copy masking (apex FP16_Optimizer, sparse_core.py:135-139, :329-333) "
@@ -420,8 +427,7 @@ class Masking(object):
             self.name2zeros[name] = stats[4 * i + 1]
             self.name2removed[name] = stats[4 * i + 2]
             self._nonzeros_after[name] = stats[4 * i + 3]
-        if self.args.distributed and self.debug_check_ranks:
-            self.check_rank_agreement()
+        self._verify_ranks()
 
     # ------------------------------------------------------------------ utilities
     def get_momentum_for_weight(self, weight):
@@ -512,11 +518,22 @@ class Masking(object):
         for module in self.modules:
             for name, tensor in module.named_parameters():
                 known[name] = tensor
+        # the keys carry the 'module.' prefix of whatever wrapper was passed to add_module (the reference registers the DDP
+        # wrapper: main.py:425); a checkpoint written under DDP resumes into a bare model and vice versa
+        def _resolve(saved):
+            if saved in known:
+                return saved
+            alt = saved[len("module."):] if saved.startswith("module.") else "module." + saved
+            return alt if alt in known else None
+        renamed_masks, renamed_shapes = {}, {}
         for name in state["masks"]:
-            if name not in known or tuple(known[name].shape) != tuple(shapes[name]):
+            tgt = _resolve(name)
+            if tgt is None or tuple(known[tgt].shape) != tuple(shapes[name]):
                 raise KeyError("saved mask %r does not match a parameter of the registered modules" % name)
+            renamed_masks[tgt] = state["masks"][name]; renamed_shapes[tgt] = shapes[name]
+        shapes = renamed_shapes
         new = {}
-        for name, packed in state["masks"].items():
+        for name, packed in renamed_masks.items():
             bits = self.unpack_mask(packed, shapes[name])
             if name in self.masks:
                 self.masks[name].copy_(bits)
@@ -548,15 +565,35 @@ class Masking(object):
             _lib.check(_lib.lib().slak_mask_checksum(self._plan, ctypes.byref(out), self._stream()), "slak_mask_checksum")
         return out.value
 
-    def check_rank_agreement(self):
+    def ranks_agree(self):
+        """True iff every rank holds the same masks (64-bit checksum, one 24-byte MIN and MAX all-reduce)."""
         import torch.distributed as dist
         c = self.mask_checksum()
         t = torch.tensor([c & 0x7fffffff, (c >> 31) & 0x7fffffff, c >> 62], dtype=torch.int64, device=self.device)
         lo, hi = t.clone(), t.clone()
         dist.all_reduce(lo, op=dist.ReduceOp.MIN)
         dist.all_reduce(hi, op=dist.ReduceOp.MAX)
-        if not torch.equal(lo, hi):
+        return bool(torch.equal(lo, hi))
+
+    def check_rank_agreement(self):
+        if not self.ranks_agree():
             raise RuntimeError("mask checksum differs across ranks")
+
+    def _verify_ranks(self):
+        """After every prune-and-grow round and load_state_dict of a distributed run (see __init__)."""
+        import torch.distributed as dist
+        if not (self.args.distributed and (self.check_ranks or self.debug_check_ranks)):
+            return
+        if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+            return
+        if self.ranks_agree():
+            return
+        if self.debug_check_ranks:
+            raise RuntimeError("mask checksum differs across ranks")
+        self.rank_resyncs += 1
+        print("slak_amd.Masking: masks diverged across ranks (resync #%d): re-broadcasting rank 0's masks" % self.rank_resyncs)
+        self._synced_once = False
+        self.apply_mask()                                 # synchronism_masks() + w *= mask, as every reference step does
 
     def synchronism_masks(self):
         """The reference broadcasts every mask from rank 0 on EVERY apply_mask (sparse_core.py:404-407: 95

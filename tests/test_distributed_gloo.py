@@ -155,3 +155,39 @@ def test_checkpoint_is_written_by_the_main_process():
     np.testing.assert_array_equal(r0["loaded"], r0["mine"])                 # both ranks resume from rank 0's weights
     np.testing.assert_array_equal(r1["loaded"], r0["mine"])
     assert not np.array_equal(r1["mine"], r0["mine"])
+
+
+def _rank_divergence_heals(rank, world):
+    """A rank-local perturbation after the one broadcast (here: rank 1 flips mask bits) is caught by the checksum all-reduce that
+    follows every prune-and-grow round, and healed the way the reference heals every step: rank 0's masks are re-broadcast
+    (sparse_core.py:404-407).  The device checksum kernel is replaced by a host hash (no GPU here); the control flow is the product's."""
+    from slak_amd.sparse_core import Masking
+    args = types.SimpleNamespace(device="cpu", fix=False, update_frequency=None, only_L=False, sparse_init="uniform", sparsity=0.4, distributed=True)
+    mk = Masking(None, None, None, prune_mode="magnitude", growth_mode="gradient", redistribution_mode="none", args=args)
+    torch.manual_seed(7)
+    mk.masks = {"a": (torch.rand(7, 1, 51, 5) < 0.6).float(), "b": (torch.rand(33, 17) < 0.6).float()}
+    mk.synchronism_masks()
+    mk.mask_checksum = lambda: int(sum(int((m.reshape(-1) * torch.arange(1, m.numel() + 1)).sum().item()) for m in mk.masks.values())) & ((1 << 63) - 1)
+    mk._verify_ranks()                                             # ranks agree: nothing happens
+    first = mk.rank_resyncs
+    ref = {k: v.clone() for k, v in mk.masks.items()}
+    if rank == 1:
+        mk.masks["a"][3, 0, 10:20, :] = 1 - mk.masks["a"][3, 0, 10:20, :]
+    mk._verify_ranks()                                             # mismatch: rank 0's masks come back
+    healed = all(torch.equal(mk.masks[k], ref[k]) for k in ref)
+    strict = Masking(None, None, None, prune_mode="magnitude", growth_mode="gradient", redistribution_mode="none",
+                     args=types.SimpleNamespace(**dict(vars(args), debug_mask_sync=True)))
+    strict.masks = {k: v.clone() for k, v in ref.items()}
+    strict._synced_once = True
+    strict.mask_checksum = lambda: (5 + rank)
+    try:
+        strict._verify_ranks(); raised = False
+    except RuntimeError:
+        raised = True
+    return dict(first=first, resyncs=mk.rank_resyncs, healed=healed, raised=raised)
+
+
+def test_rank_divergence_is_detected_and_healed_by_default():
+    r0, r1 = _run(_rank_divergence_heals)
+    for r in (r0, r1):
+        assert r["first"] == 0 and r["resyncs"] == 1 and r["healed"] and r["raised"]
