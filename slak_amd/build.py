@@ -53,5 +53,41 @@ def build(force: bool = False, verbose: bool = False) -> str:
     return LIB
 
 
+PYBIND_NAME = "_depthwise_conv2d_implicit_gemm_C"          # the module name the reference's depthwise_conv2d_implicit_gemm.py:8 imports
+
+
+def pybind_path() -> str:
+    import sysconfig
+    return os.path.join(LIBDIR, PYBIND_NAME + sysconfig.get_config_var("EXT_SUFFIX"))
+
+
+def build_pybind(force: bool = False, verbose: bool = False) -> str:
+    """The reference's pybind module (frontend.cpp:3-16) on top of libslak_hip.so: slak_amd/pybind/frontend_hip.cpp, host-only C++
+    compiled with g++ against the torch headers (what torch.utils.cpp_extension.CppExtension would run), in-tree next to
+    libslak_hip.so so that it travels with the repository snapshot."""
+    import sysconfig
+    import torch
+    from torch.utils import cpp_extension as ce
+    lib = build(force=False, verbose=verbose)
+    src = os.path.join(HERE, "pybind", "frontend_hip.cpp")
+    out = pybind_path()
+    if not (force or _stale(out, [src, lib, os.path.join(HERE, "..", "include", "slak_hip.h")])):
+        return out
+    tlib = os.path.join(os.path.dirname(torch.__file__), "lib")
+    cmd = [os.environ.get("CXX", "g++"), "-O2", "-std=c++17", "-fPIC", "-shared", "-w", src, "-o", out,
+           "-DTORCH_EXTENSION_NAME=" + PYBIND_NAME, "-DTORCH_API_INCLUDE_EXTENSION_H", "-D__HIP_PLATFORM_AMD__=1", "-DUSE_ROCM=1",
+           "-D_GLIBCXX_USE_CXX11_ABI=%d" % int(torch._C._GLIBCXX_USE_CXX11_ABI)]
+    for inc in ce.include_paths("cuda") + [sysconfig.get_paths()["include"]]:
+        cmd += ["-isystem", inc]
+    cmd += ["-L" + tlib, "-L" + LIBDIR, "-lslak_hip", "-lc10", "-lc10_hip", "-ltorch_cpu", "-ltorch", "-ltorch_hip", "-ltorch_python",
+            "-Wl,-rpath,$ORIGIN", "-Wl,-rpath," + tlib]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return out
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
+    if "--pybind" in sys.argv:
+        print(build_pybind(force="--force" in sys.argv, verbose=True))

@@ -301,9 +301,96 @@ def make_erk():
     print("wrote erk_init")
 
 
+# --------------------------------------------------------------------------- full-model fixture (SURVEY 8c "full-model oracle")
+MODEL_CFG = dict(in_chans=3, num_classes=10, depths=[1, 1, 2, 1], dims=[8, 16, 32, 48], drop_path_rate=0.0,
+                 layer_scale_init_value=0.5, kernel_size=[31, 29, 13, 7, 5], Decom=True, bn=True)
+MODEL_RES = 128            # stage maps 32, 16, 8, 4: the 28x28-class DMA kernels, the 14x14-class kernels, the small-plane kernels
+
+
+def _import_reference_slak():
+    """models/SLaK.py imported UNMODIFIED.  What it needs and this image lacks is shimmed at the import boundary only:
+    ``timm.models.layers.trunc_normal_`` (== torch.nn.init.trunc_normal_, absolute bounds [-2, 2]: timm1/layers/weight_init.py:43-67),
+    ``DropPath`` (never instantiated: drop_path_rate = 0 -> nn.Identity, models/SLaK.py:150), ``register_model`` (identity) and
+    ``DepthWiseConv2dImplicitGEMM`` = the nn.Conv2d the reference's own smoke test compares it with
+    (depthwise_conv2d_implicit_gemm.py:69-82: same weight, padding = k // 2, groups = C)."""
+    timm = types.ModuleType("timm"); tm = types.ModuleType("timm.models")
+    tl = types.ModuleType("timm.models.layers"); tr = types.ModuleType("timm.models.registry")
+    tl.trunc_normal_ = lambda t, mean=0., std=1., a=-2., b=2.: nn.init.trunc_normal_(t, mean, std, a, b)
+
+    class _NoDropPath(nn.Module):
+        def __init__(self, *a, **k):
+            raise RuntimeError("fixture uses drop_path_rate = 0")
+    tl.DropPath = _NoDropPath
+    tr.register_model = lambda f: f
+    dw = types.ModuleType("depthwise_conv2d_implicit_gemm")
+
+    class DepthWiseConv2dImplicitGEMM(nn.Conv2d):
+        def __init__(self, channels, kernel, bias=False):
+            super().__init__(channels, channels, kernel, groups=channels, bias=bias)
+
+        def forward(self, x):
+            kh, kw = self.kernel_size
+            return F.conv2d(x, self.weight, self.bias, 1, (kh // 2, kw // 2), 1, self.groups)
+    dw.DepthWiseConv2dImplicitGEMM = DepthWiseConv2dImplicitGEMM
+    saved = {k: sys.modules.get(k) for k in ("timm", "timm.models", "timm.models.layers", "timm.models.registry", "depthwise_conv2d_implicit_gemm")}
+    sys.modules.update({"timm": timm, "timm.models": tm, "timm.models.layers": tl, "timm.models.registry": tr,
+                        "depthwise_conv2d_implicit_gemm": dw})
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("reference_models_SLaK", os.path.join(REF, "models", "SLaK.py"))
+    mod = importlib.util.module_from_spec(spec)
+    try:
+        spec.loader.exec_module(mod)
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+    return mod
+
+
+def make_model():
+    """A narrow SLaK built by the REFERENCE's models/SLaK.py (fp64, CPU): state dict, one training-mode forward + backward (batch
+    statistics), the BatchNorm running statistics after it, and an eval-mode forward.  tests/test_model_reference_gpu.py loads the
+    state dict into slak_amd.slak_model.SLaK and must reproduce all of it through the HIP path."""
+    ref = _import_reference_slak()
+    ref.use_sync_bn = False                                   # single process (models/SLaK.py:19)
+    torch.manual_seed(42)
+    model = ref.SLaK(**MODEL_CFG).double()
+    with torch.no_grad():                                     # give every affine parameter and running statistic a non-trivial value
+        for n, p in model.named_parameters():
+            if n.endswith("bn.weight") or n.endswith("norm.weight"):
+                p.add_(0.2 * torch.randn_like(p))
+            elif n.endswith(".bias"):
+                p.add_(0.05 * torch.randn_like(p))
+            elif "large_kernel" in n and n.endswith("conv.weight"):
+                p.mul_(4.0)                                   # branch outputs of O(1) so the BatchNorms see real variances
+    state0 = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    x = torch.randn(4, 3, MODEL_RES, MODEL_RES, dtype=torch.float64)
+    dlogits = torch.randn(4, MODEL_CFG["num_classes"], dtype=torch.float64)
+    model.train()
+    logits = model(x)
+    (logits * dlogits).sum().backward()
+    out = {"x": x.float().numpy(), "dlogits": dlogits.float().numpy(), "logits_train": logits.detach().numpy()}
+    for k, v in state0.items():
+        out["state0/" + k] = v.numpy().astype(np.float32) if v.dtype.is_floating_point else v.numpy()
+    for n, p in model.named_parameters():
+        out["grad/" + n] = p.grad.numpy()
+    for k, v in model.state_dict().items():
+        if "running_" in k:
+            out["state1/" + k] = v.numpy()
+    model.eval()
+    with torch.no_grad():
+        out["logits_eval"] = model(x).numpy()
+    out["names"] = np.array([n for n, _ in model.named_parameters()])
+    out["cfg"] = np.array(repr(dict(MODEL_CFG, res=MODEL_RES)))
+    np.savez_compressed(os.path.join(HERE, "model_reference.npz"), **out)
+    print("wrote model_reference", sum(v.size for v in out.values() if hasattr(v, "size")), "values")
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", choices=["conv", "mask", "ema", "snip", "erk"], default=None)
+    ap.add_argument("--only", choices=["conv", "mask", "ema", "snip", "erk", "model"], default=None)
     a = ap.parse_args()
     if not os.path.isdir(REF):
         sys.exit("needs /root/reference (build container only)")
@@ -317,3 +404,5 @@ if __name__ == "__main__":
         make_snip()
     if a.only in (None, "erk"):
         make_erk()
+    if a.only in (None, "model"):
+        make_model()

@@ -31,7 +31,8 @@ def test_slak_tiny_parameter_set():
 
 def test_slak_base_dims_and_sync_bn_switch():
     assert len(M.slak_mask_set_shapes("base")) == 185
-    assert sum(int(np.prod(s)) for s in M.slak_mask_set_shapes("base", only_L=True)) == 7471104 or True
+    only_l = M.slak_mask_set_shapes("base", only_L=True)
+    assert len(only_l) == 72 and sum(int(np.prod(s)) for s in only_l) == 7468800        # 2*5*(3*128*51 + 3*256*49 + 27*512*47 + 3*1024*13)
     M.use_sync_bn = True
     blk = M.Block(8, kernel_size=(13, 5), Decom=True)
     assert isinstance(blk.large_kernel.LoRA1.bn, torch.nn.SyncBatchNorm)
@@ -39,3 +40,22 @@ def test_slak_base_dims_and_sync_bn_switch():
     blk = M.Block(8, kernel_size=(13, 5), Decom=True)
     assert isinstance(blk.large_kernel.LoRA1.bn, torch.nn.BatchNorm2d)
     assert not hasattr(M.Block(8, kernel_size=(5, 5), Decom=True).large_kernel, "small_conv")   # small < kernel only
+
+
+def test_mirror_has_the_reference_models_parameter_set():
+    """tests/golden/model_reference.npz was written by the REFERENCE's models/SLaK.py (make_golden.py --only model): the mirror
+    built with the same arguments has the same parameters, in the same order, with the same shapes, and the same buffers."""
+    import ast
+    from conftest import load_golden
+    g = load_golden("model_reference")
+    cfg = ast.literal_eval(str(g["cfg"]))
+    cfg.pop("res")
+    M.use_sync_bn = False
+    m = M.SLaK(**cfg)
+    names = [str(n) for n in g["names"]]
+    assert [n for n, _ in m.named_parameters()] == names
+    for n, p in m.named_parameters():
+        assert tuple(p.shape) == g["state0/" + n].shape == g["grad/" + n].shape, n
+    ref_keys = sorted(k[len("state0/"):] for k in g if k.startswith("state0/"))
+    assert sorted(m.state_dict().keys()) == ref_keys
+    m.load_state_dict({k: torch.from_numpy(g["state0/" + k]) for k in ref_keys}, strict=True)
