@@ -119,9 +119,16 @@ def event_time_ms(fn, reps, stream_device):
 
 
 def hot_path_kernels(device, batch, reps, dtype, stages):
-    """Every distinct (stage, kernel, pass) of the dw-conv hot path at the bench shapes, timed alone: the C-ABI entry points
+    """Every distinct launch of the dw-conv hot path at the bench shapes AS THE MODEL RUNS IT, timed alone: the C-ABI entry points
     are called directly on preallocated buffers (the tensor-level wrappers of slak_amd.ops add ~10 us of host work per call,
-    more than the smallest kernels take), HIP events on the launch stream around `reps` back-to-back launches."""
+    more than the smallest kernels take), HIP events on the launch stream around `reps` back-to-back launches.
+    Per block and pass the model runs (slak_amd.block_ops._TriDwConv):
+      forward   : one launch per branch -- or ONE launch for the three (`tri`, where slak_dwconv2d_tri_supported == 1);
+      bwd_data  : branch 1 plain, branches 2 and 3 ACCUMULATING into the same dx (`+acc`: autograd's adds folded in; 3*S*b bytes:
+                  read dy, read dx, write dx) -- or ONE launch for the three;
+      bwd_filter: one launch per branch.
+    Algorithmic bytes: SURVEY.md 8(d) per op -- 2*S*b (+ C*kh*kw*4); a three-branch launch is priced at the per-op figure of the
+    three ops it replaces (3 x 2*S*b), as 8(d) prescribes."""
     from slak_amd import _lib, ops
     L = _lib.lib()
     st = torch.cuda.current_stream(device).cuda_stream
@@ -129,28 +136,45 @@ def hot_path_kernels(device, batch, reps, dtype, stages):
     b = 2 if dtype != torch.float32 else 4
     for si, (C, HW, K, blocks) in enumerate(stages):
         x = torch.randn(batch, C, HW, HW, device=device).to(dtype)
-        dy = torch.randn_like(x)
-        y = torch.empty_like(x)
+        dys = [torch.randn_like(x) for _ in range(3)]
+        ys = [torch.empty_like(x) for _ in range(3)]
         dt = ops._DT[x.dtype]
-        for kname, (kh, kw) in (("Kx5", (K, 5)), ("5xK", (5, K)), ("5x5", (5, 5))):
-            w = torch.randn(C, 1, kh, kw, device=device) * 0.02
+        S = x.numel()
+        shapes = (("Kx5", (K, 5)), ("5xK", (5, K)), ("5x5", (5, 5)))
+        wts = [torch.randn(C, 1, kh, kw, device=device) * 0.02 for _, (kh, kw) in shapes]
+        tri = dtype != torch.float32 and L.slak_dwconv2d_tri_supported(dt, batch, C, HW, HW, K) == 1
+
+        def add(kernel, branch, op, fn, alg_bytes, flop):
+            ms = event_time_ms(fn, reps, device)
+            out.append(dict(stage=si + 1, kernel=kernel, branch=branch, op=op, ms=ms, calls_per_step=blocks, alg_bytes=alg_bytes,
+                            gbs=alg_bytes / ms / 1e6, gflop_nominal=flop / 1e9))
+        wbytes = sum(C * kh * kw * 4 for _, (kh, kw) in shapes)
+        flops3 = sum(2.0 * S * kh * kw for _, (kh, kw) in shapes)
+        if tri:
+            a_tf = (x.data_ptr(), wts[0].data_ptr(), wts[1].data_ptr(), wts[2].data_ptr(), ys[0].data_ptr(), ys[1].data_ptr(), ys[2].data_ptr(), dt, batch, C, HW, HW, K, st)
+            a_td = (dys[0].data_ptr(), dys[1].data_ptr(), dys[2].data_ptr(), wts[0].data_ptr(), wts[1].data_ptr(), wts[2].data_ptr(), ys[0].data_ptr(), dt, batch, C, HW, HW, K, st)
+            add("%dx5+5x%d+5x5" % (K, K), "tri", "fwd", lambda: _lib.check(L.slak_dwconv2d_tri_forward(*a_tf)), 3 * 2 * S * b + wbytes, flops3)
+            add("%dx5+5x%d+5x5" % (K, K), "tri", "bwd_data", lambda: _lib.check(L.slak_dwconv2d_tri_backward_data(*a_td)), 3 * 2 * S * b + wbytes, flops3)
+        for bi, (kname, (kh, kw)) in enumerate(shapes):
+            w = wts[bi]
             dw = torch.empty_like(w)
             dims = (batch, C, HW, HW, kh, kw)
             nb = max(int(L.slak_dwconv2d_workspace_bytes(op, *dims, dt)) for op in (_lib.OP_FWD, _lib.OP_BWD_DATA, _lib.OP_BWD_FILTER))
             ws = torch.empty(max(nb, 16), dtype=torch.uint8, device=device)
-            a_f = (x.data_ptr(), dt, w.data_ptr(), _lib.SLAK_F32, y.data_ptr(), dt) + dims + (ws.data_ptr(), ws.numel(), st)
-            a_d = (dy.data_ptr(), dt, w.data_ptr(), _lib.SLAK_F32, y.data_ptr(), dt) + dims + (ws.data_ptr(), ws.numel(), st)
-            a_w = (dy.data_ptr(), dt, x.data_ptr(), dt, dw.data_ptr()) + dims + (ws.data_ptr(), ws.numel(), st)
-            S = x.numel()
-            for pname, fn, extra in (("fwd", lambda: _lib.check(L.slak_dwconv2d_forward(*a_f)), C * kh * kw * 4),
-                                     ("bwd_data", lambda: _lib.check(L.slak_dwconv2d_backward_data(*a_d)), C * kh * kw * 4),
-                                     ("bwd_filter", lambda: _lib.check(L.slak_dwconv2d_backward_filter(*a_w)), C * kh * kw * 4)):
-                ms = event_time_ms(fn, reps, device)
-                alg_bytes = 2 * S * b + extra                       # 2*S*b (+ C*kh*kw*4)
-                out.append(dict(stage=si + 1, kernel="%dx%d" % (kh, kw), branch=kname, op=pname, ms=ms, calls_per_step=blocks,
-                                alg_bytes=alg_bytes, gbs=alg_bytes / ms / 1e6, gflop_nominal=2.0 * S * kh * kw / 1e9))
+            a_f = (x.data_ptr(), dt, w.data_ptr(), _lib.SLAK_F32, ys[0].data_ptr(), dt) + dims + (ws.data_ptr(), ws.numel(), st)
+            a_d = (dys[0].data_ptr(), dt, w.data_ptr(), _lib.SLAK_F32, ys[0].data_ptr(), dt) + dims + (ws.data_ptr(), ws.numel(), st)
+            a_w = (dys[0].data_ptr(), dt, x.data_ptr(), dt, dw.data_ptr()) + dims + (ws.data_ptr(), ws.numel(), st)
+            kn, flop, wb = "%dx%d" % (kh, kw), 2.0 * S * kh * kw, C * kh * kw * 4
+            if not tri:
+                add(kn, kname, "fwd", lambda: _lib.check(L.slak_dwconv2d_forward(*a_f)), 2 * S * b + wb, flop)
+                acc_ok = bi > 0 and dtype != torch.float32 and L.slak_dwconv2d_backward_data_accumulate(*a_d) == _lib.OK
+                if acc_ok:
+                    add(kn, kname, "bwd_data+acc", lambda: _lib.check(L.slak_dwconv2d_backward_data_accumulate(*a_d)), 3 * S * b + wb, flop)
+                else:
+                    add(kn, kname, "bwd_data", lambda: _lib.check(L.slak_dwconv2d_backward_data(*a_d)), 2 * S * b + wb, flop)
+            add(kn, kname, "bwd_filter", lambda: _lib.check(L.slak_dwconv2d_backward_filter(*a_w)), 2 * S * b + wb, flop)
             del ws, dw
-        del x, dy, y
+        del x, dys, ys
     return out
 
 

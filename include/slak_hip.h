@@ -72,6 +72,15 @@ int slak_dwconv2d_backward_data(const void* dy, int dy_dtype, const void* w, int
                                 int N, int C, int H, int W, int kh, int kw,
                                 void* workspace, size_t workspace_bytes, void* stream);
 
+/* dx += the data gradient (same arguments as slak_dwconv2d_backward_data; dx is read and written).  The three branches of a SLaK
+ * block (models/SLaK.py:92-100) share their input, so autograd adds the three branch gradients with two elementwise passes
+ * (read 2 + write 1 each); accumulating inside the second and third branch's kernel costs one extra read each instead.  The sum is
+ * rounded to the tensor dtype after every accumulation, exactly as a bf16 / fp16 tensor add does.  Kernels that cannot accumulate
+ * return SLAK_ERR_UNSUPPORTED (nothing has been launched): compute into a temporary and add. */
+int slak_dwconv2d_backward_data_accumulate(const void* dy, int dy_dtype, const void* w, int w_dtype, void* dx, int dx_dtype,
+                                           int N, int C, int H, int W, int kh, int kw,
+                                           void* workspace, size_t workspace_bytes, void* stream);
+
 /* dw[c,0,r,s] = sum_{n,p,q} dy[n,c,p,q] * x[n,c,p-kh/2+r,q-kw/2+s], fp32 out, deterministic
  * (no atomics; the reference atomically adds: dwconv2d_direct_epilogue_simt.h:180)
  *                                                                   (backward_filter_fp32.cu:199-263) */
@@ -121,10 +130,13 @@ int slak_mask_checksum(slak_mask_plan_t* plan, unsigned long long* out_host, voi
 
 /* ---- next row: the three branches of one decomposed large-kernel block in ONE launch ----------------------------
  * ReparamLargeKernelConv.forward runs LoRA1 (K x 5), LoRA2 (5 x K) and small_conv (5 x 5) on the same input (models/SLaK.py:82-100).
- * forward: x is read once for the three outputs; backward_data: the three partial input gradients are summed in the accumulator
+ * forward: x is read once for the three outputs; backward_data: the three partial input gradients are summed inside the kernel
  * (autograd would add them with two elementwise passes).  16-bit tensors (dtype = SLAK_BF16 / SLAK_F16), fp32 filters
- * (C,1,K,5), (C,1,5,K), (C,1,5,5); currently the 14x14 class only (W even, 8 <= W <= 14, H <= 14): anything else returns
- * SLAK_ERR_UNSUPPORTED and the caller issues the three slak_dwconv2d_* calls instead. */
+ * (C,1,K,5), (C,1,5,K), (C,1,5,5).  slak_dwconv2d_tri_supported returns 1 for the 14x14 class (W even, 8 <= W <= 14, H <= 14: the
+ * three contributions are summed in the fp32 accumulator and rounded once), 2 for the 56x56 / 28x28 class (16 < H, W <= 64, both in
+ * (16,32] or both in (32,64], H % 4 == W % 4 == 0: every branch's partial gradient is rounded to the tensor dtype, the three are added
+ * in fp32 and rounded again -- one rounding fewer than autograd's two adds), 0 otherwise: then the calls return SLAK_ERR_UNSUPPORTED
+ * and the caller issues the three slak_dwconv2d_* calls instead. */
 int slak_dwconv2d_tri_supported(int dtype, int N, int C, int H, int W, int K);
 int slak_dwconv2d_tri_forward(const void* x, const float* w_v, const float* w_h, const float* w_s, void* y_v, void* y_h, void* y_s,
                               int dtype, int N, int C, int H, int W, int K, void* stream);

@@ -13,6 +13,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libslak_hip.so")
 SLAK_F32, SLAK_F16, SLAK_BF16 = 0, 1, 2
 ALGO_AUTO, ALGO_DIRECT, ALGO_MFMA = 0, 1, 2
 OP_FWD, OP_BWD_DATA, OP_BWD_FILTER = 0, 1, 2
+OK, ERR_INVALID_ARG, ERR_UNSUPPORTED = 0, 1, 2
 
 _lib = None
 
@@ -56,6 +57,7 @@ SIGNATURES = {
     "slak_dwconv2d_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i, _i, _i]),
     "slak_dwconv2d_forward": (_i, _CONV),
     "slak_dwconv2d_backward_data": (_i, _CONV),
+    "slak_dwconv2d_backward_data_accumulate": (_i, _CONV),
     "slak_dwconv2d_backward_filter": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     "slak_mask_plan_create": (_i, [ctypes.POINTER(MaskSegment), _i, ctypes.POINTER(_vp)]),
     "slak_mask_plan_set_grads": (_i, [_vp, ctypes.POINTER(_vp), _vp]),

@@ -5,6 +5,8 @@
 
 (models/SLaK.py:153-166, :253-255).  x bf16 NCHW, z bf16 NHWC; parameters, statistics and the residual stream fp32.
 """
+import os
+
 import torch
 
 from . import _lib
@@ -111,6 +113,10 @@ class _ScaleResidual(torch.autograd.Function):
         return dshortcut, dz, dgamma, None, None
 
 
+accumulate_dgrad = os.environ.get("SLAK_DGRAD_ACC", "1") != "0"     # A/B switch: 0 = three plain launches + two tensor adds
+use_big_tri = os.environ.get("SLAK_BIG_TRI", "0") == "1"      # dev switch: take the one-launch kernels of the 56x56 / 28x28 class where they exist
+
+
 class _TriDwConv(torch.autograd.Function):
     """The three branch convolutions of a decomposed large-kernel block -- LoRA1 (K x 5), LoRA2 (5 x K), small_conv (5 x 5) on the
     same input (models/SLaK.py:82-100) -- as one autograd node.  Where the one-launch kernels exist (slak_dwconv2d_tri_*: the 14x14
@@ -127,8 +133,11 @@ class _TriDwConv(torch.autograd.Function):
             raise RuntimeError("tri_dwconv expects filters (C,1,K,5), (C,1,5,K), (C,1,5,5)")
         L = _lib.lib()
         dt = ops._DT.get(x.dtype)
+        # 1: the one-launch kernels of the 14x14 class.  (2: the one-launch kernels of the 56x56 / 28x28 class exist
+        # (slak_dwconv2d_tri_*) but lose to the per-branch kernels on MI355X -- twelve waves in lockstep, 134 vs 110 us forward at
+        # 128x96x56x56 -- so those planes run three launches, the data gradient accumulating in place.)
         tri = (dt is not None and all(w.dtype == torch.float32 and w.is_contiguous() for w in (wv, wh, ws))
-               and bool(L.slak_dwconv2d_tri_supported(dt, N, C, H, W, K)))
+               and L.slak_dwconv2d_tri_supported(dt, N, C, H, W, K) == (2 if use_big_tri else 1))
         if tri:
             yv, yh, ys = torch.empty_like(x), torch.empty_like(x), torch.empty_like(x)
             with torch.cuda.device(x.device):
@@ -159,8 +168,12 @@ class _TriDwConv(torch.autograd.Function):
                                                                  N, C, H, W, K, _stream(x.device)), "slak_dwconv2d_tri_backward_data")
             else:
                 dx = ops.dwconv2d_backward_data(dyv, wv)
-                dx += ops.dwconv2d_backward_data(dyh, wh)
-                dx += ops.dwconv2d_backward_data(dys, ws)
+                if accumulate_dgrad:
+                    ops.dwconv2d_backward_data_accumulate(dyh, wh, dx)   # autograd's two adds folded into the kernels' copy-out
+                    ops.dwconv2d_backward_data_accumulate(dys, ws, dx)
+                else:
+                    dx += ops.dwconv2d_backward_data(dyh, wh)
+                    dx += ops.dwconv2d_backward_data(dys, ws)
         dwv = ops.dwconv2d_backward_filter(dyv, x, wv) if ctx.needs_input_grad[1] else None
         dwh = ops.dwconv2d_backward_filter(dyh, x, wh) if ctx.needs_input_grad[2] else None
         dws = ops.dwconv2d_backward_filter(dys, x, ws) if ctx.needs_input_grad[3] else None

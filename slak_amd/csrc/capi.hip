@@ -149,6 +149,17 @@ int slak_dwconv2d_backward_data(const void* dy, int dy_dtype, const void* w, int
     return launch_dwconv_direct(dy, dy_dtype, w, w_dtype, dx, dx_dtype, d, /*flip=*/true, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
+int slak_dwconv2d_backward_data_accumulate(const void* dy, int dy_dtype, const void* w, int w_dtype, void* dx, int dx_dtype,
+                                           int N, int C, int H, int W, int kh, int kw,
+                                           void* workspace, size_t workspace_bytes, void* stream) {
+    int rc = check_conv_args(dy, w, dx, dy_dtype, w_dtype, dx_dtype, N, C, H, W, kh, kw);
+    if (rc != SLAK_OK) return rc;
+    ConvDims d{N, C, H, W, kh, kw};
+    if (g_conv_algo != SLAK_ALGO_DIRECT && use_dma() && dwconv_mfma_dma_supported(d, dy_dtype, w_dtype, dx_dtype))
+        return launch_dwconv_mfma_dma(dy, dy_dtype, w, w_dtype, dx, dx_dtype, d, /*flip=*/true, workspace, workspace_bytes, (hipStream_t)stream, /*accumulate=*/true);
+    return SLAK_ERR_UNSUPPORTED;            // the caller computes into a temporary and adds
+}
+
 int slak_dwconv2d_backward_filter(const void* dy, int dy_dtype, const void* x, int x_dtype, float* dw,
                                   int N, int C, int H, int W, int kh, int kw,
                                   void* workspace, size_t workspace_bytes, void* stream) {
@@ -177,21 +188,26 @@ int slak_dwconv2d_backward_filter(const void* dy, int dy_dtype, const void* x, i
 
 
 int slak_dwconv2d_tri_supported(int dtype, int N, int C, int H, int W, int K) {
-    return dwconv_mfma_small_tri_supported(N, C, H, W, K, dtype) ? 1 : 0;
+    if (dwconv_mfma_small_tri_supported(N, C, H, W, K, dtype)) return 1;                                     // 14x14 class: sums in the accumulator
+    return (dwconv_mfma_tri_supported(N, C, H, W, K, dtype, false) && dwconv_mfma_tri_supported(N, C, H, W, K, dtype, true)) ? 2 : 0;   // 56x56 / 28x28 class
 }
 
 int slak_dwconv2d_tri_forward(const void* x, const float* w_v, const float* w_h, const float* w_s, void* y_v, void* y_h, void* y_s,
                               int dtype, int N, int C, int H, int W, int K, void* stream) {
     if (!x || !w_v || !w_h || !w_s || !y_v || !y_h || !y_s) return SLAK_ERR_INVALID_ARG;
     const void* in[3] = {x, x, x}; void* out[3] = {y_v, y_h, y_s}; const float* w[3] = {w_v, w_h, w_s};
-    return launch_dwconv_mfma_small_tri(false, in, out, w, dtype, N, C, H, W, K, (hipStream_t)stream);
+    if (dwconv_mfma_small_tri_supported(N, C, H, W, K, dtype))
+        return launch_dwconv_mfma_small_tri(false, in, out, w, dtype, N, C, H, W, K, (hipStream_t)stream);
+    return launch_dwconv_mfma_tri(false, in, out, w, dtype, N, C, H, W, K, (hipStream_t)stream);
 }
 
 int slak_dwconv2d_tri_backward_data(const void* dy_v, const void* dy_h, const void* dy_s, const float* w_v, const float* w_h,
                                     const float* w_s, void* dx, int dtype, int N, int C, int H, int W, int K, void* stream) {
     if (!dy_v || !dy_h || !dy_s || !w_v || !w_h || !w_s || !dx) return SLAK_ERR_INVALID_ARG;
     const void* in[3] = {dy_v, dy_h, dy_s}; void* out[3] = {dx, dx, dx}; const float* w[3] = {w_v, w_h, w_s};
-    return launch_dwconv_mfma_small_tri(true, in, out, w, dtype, N, C, H, W, K, (hipStream_t)stream);
+    if (dwconv_mfma_small_tri_supported(N, C, H, W, K, dtype))
+        return launch_dwconv_mfma_small_tri(true, in, out, w, dtype, N, C, H, W, K, (hipStream_t)stream);
+    return launch_dwconv_mfma_tri(true, in, out, w, dtype, N, C, H, W, K, (hipStream_t)stream);
 }
 
 }  // extern "C"

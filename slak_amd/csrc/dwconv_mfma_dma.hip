@@ -45,6 +45,7 @@ unsigned long long* g_dma_dbg = nullptr;   // dev hook: slak_debug_set_phase_buf
 struct MfmaDmaParams {
     const void* x; const float* w; void* y;
     int N, C, H, W, kh, kw, flip;
+    int acc;               // y += result instead of y = result (the data gradient of the 2nd / 3rd branch of a block: autograd's add folded in)
     int Wt, Wl, KL, padL;
     int G;                 // planes per group (iteration)
     int tpp;               // 32-lane tiles per plane
@@ -290,6 +291,9 @@ __global__ __launch_bounds__(MF_THREADS, 3) void dwconv_mfma_dma_kernel(const Mf
     const unsigned long long cyc0 = __builtin_readcyclecounter();
 #endif
     char* yg = (char*)p.y + ((size_t)n_begin * p.C + c) * HW * 2;   // HBM address of the current group's first plane
+    u32x4 yold[DMA_NCO];
+#pragma unroll
+    for (int k = 0; k < DMA_NCO; ++k) yold[k] = u32x4{0u, 0u, 0u, 0u};
     int n0 = n_begin;
     for (int it = 0; it < iters; ++it) {
         PH_T0();
@@ -305,7 +309,16 @@ __global__ __launch_bounds__(MF_THREADS, 3) void dwconv_mfma_dma_kernel(const Mf
             char* yp = yg - (size_t)p.G * gplane_b;
 #pragma unroll
             for (int k = 0; k < DMA_NCO; ++k)
-                if (n0 - p.G + co_j[k] < n_end) *(u32x4*)(yp + co_g[k]) = *(const u32x4*)(L + ob_prev + (tid + k * MF_THREADS) * 16);
+                if (n0 - p.G + co_j[k] < n_end) {
+                    u32x4 v = *(const u32x4*)(L + ob_prev + (tid + k * MF_THREADS) * 16);
+                    if (p.acc) v = add_packed<T>(v, yold[k]);
+                    *(u32x4*)(yp + co_g[k]) = v;
+                }
+        }
+        if (p.acc) {                                                  // what y holds for THIS group: fetched now, added one iteration later
+#pragma unroll
+            for (int k = 0; k < DMA_NCO; ++k)
+                if (n0 + co_j[k] < n_end) yold[k] = *(const u32x4*)(yg + co_g[k]);
         }
         PH_ADD(5);
         unsigned img_b;
@@ -392,7 +405,11 @@ __global__ __launch_bounds__(MF_THREADS, 3) void dwconv_mfma_dma_kernel(const Mf
         const unsigned ob_last = lout_b + ((iters - 1) & 1) * out_buf_b;
 #pragma unroll
         for (int k = 0; k < DMA_NCO; ++k)
-            if (n0 - p.G + co_j[k] < n_end) *(u32x4*)(yp + co_g[k]) = *(const u32x4*)(L + ob_last + (tid + k * MF_THREADS) * 16);
+            if (n0 - p.G + co_j[k] < n_end) {
+                u32x4 v = *(const u32x4*)(L + ob_last + (tid + k * MF_THREADS) * 16);
+                if (p.acc) v = add_packed<T>(v, yold[k]);
+                *(u32x4*)(yp + co_g[k]) = v;
+            }
     }
 #ifdef SLAK_DMA_DEBUG
     if (p.dbg && tid == 0) { p.dbg[64 + blockIdx.x * 8 + 2] = __builtin_amdgcn_s_memrealtime(); p.dbg[64 + blockIdx.x * 8 + 7] = __builtin_readcyclecounter() - cyc0; }
@@ -487,7 +504,7 @@ static int launch_dma_t(MfmaDmaParams& p, const ConvDims& d, bool vert, bool ban
 }
 
 int launch_dwconv_mfma_dma(const void* x, int x_dt, const void* w, int w_dt, void* y, int y_dt,
-                           const ConvDims& d, bool flip_filter, void* ws, size_t ws_bytes, hipStream_t st) {
+                           const ConvDims& d, bool flip_filter, void* ws, size_t ws_bytes, hipStream_t st, bool accumulate) {
     (void)ws; (void)ws_bytes;                                 // no workspace: fragments are built from LDS filter windows
     if (!dwconv_mfma_dma_supported(d, x_dt, w_dt, y_dt)) return SLAK_ERR_UNSUPPORTED;
     const bool vert = d.kh > d.kw;
@@ -496,6 +513,7 @@ int launch_dwconv_mfma_dma(const void* x, int x_dt, const void* w, int w_dt, voi
     MfmaDmaParams p;
     fill_dma_params(p, d, vert, MT, KS, 512);
     p.x = x; p.w = (const float*)w; p.y = y; p.flip = flip_filter ? 1 : 0;
+    p.acc = accumulate ? 1 : 0;
     p.dbg = g_dma_dbg;
     // band skipping pays when some (mt, ks) Toeplitz block is empty: filter half-width + 32 < 16*(KS-1)
     const bool band = (MT == 2) && (p.padL + 31 < 16 * (KS - 1));

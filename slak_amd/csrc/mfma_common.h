@@ -46,6 +46,24 @@ template <> __device__ __forceinline__ unsigned pack2<f16_t>(float a, float b) {
     return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_t{a, b}, f16x2_t));
 }
 
+// 8 packed T + 8 packed T, each pair added in fp32 and rounded once (a bf16 / fp16 tensor add, as torch does it)
+template <typename T> __device__ __forceinline__ u32x4 add_packed(u32x4 a, u32x4 b) {
+    u32x4 s;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        float lo, hi;
+        if constexpr (dtype_of<T>::value == SLAK_BF16) {
+            lo = __uint_as_float(a[q] << 16) + __uint_as_float(b[q] << 16);
+            hi = __uint_as_float(a[q] & 0xffff0000u) + __uint_as_float(b[q] & 0xffff0000u);
+        } else {
+            lo = (float)__builtin_bit_cast(_Float16, (uint16_t)(a[q] & 0xffffu)) + (float)__builtin_bit_cast(_Float16, (uint16_t)(b[q] & 0xffffu));
+            hi = (float)__builtin_bit_cast(_Float16, (uint16_t)(a[q] >> 16)) + (float)__builtin_bit_cast(_Float16, (uint16_t)(b[q] >> 16));
+        }
+        s[q] = pack2<T>(lo, hi);
+    }
+    return s;
+}
+
 // lane i <- lane i-1 (0 shifted in) / lane i <- lane i+1
 __device__ __forceinline__ float wave_shr1(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138, 0xf, 0xf, false)); }
 __device__ __forceinline__ float wave_shl1(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130, 0xf, 0xf, false)); }

@@ -73,7 +73,7 @@ int launch_dwconv_mfma_small(const void* x, int x_dt, const void* w, int w_dt, v
 
 bool dwconv_mfma_dma_supported(const ConvDims& d, int x_dt, int w_dt, int y_dt);
 int launch_dwconv_mfma_dma(const void* x, int x_dt, const void* w, int w_dt, void* y, int y_dt,
-                           const ConvDims& d, bool flip_filter, void* ws, size_t ws_bytes, hipStream_t st);
+                           const ConvDims& d, bool flip_filter, void* ws, size_t ws_bytes, hipStream_t st, bool accumulate = false);
 
 bool dwconv_mfma_wide_supported(const ConvDims& d, int x_dt, int w_dt, int y_dt);
 int launch_dwconv_mfma_wide(const void* x, int x_dt, const void* w, int w_dt, void* y, int y_dt,
@@ -89,6 +89,9 @@ int launch_dwconv_mfma_small_dma(const void* x, int x_dt, const void* w, int w_d
 bool dwconv_mfma_small_tri_supported(int N, int C, int H, int W, int K, int dtype);
 int launch_dwconv_mfma_small_tri(bool dgrad, const void* const* in, void* const* out, const float* const* w, int dtype,
                                  int N, int C, int H, int W, int K, hipStream_t st);
+bool dwconv_mfma_tri_supported(int N, int C, int H, int W, int K, int dtype, bool dgrad);
+int launch_dwconv_mfma_tri(bool dgrad, const void* const* in, void* const* out, const float* const* w, int dtype,
+                           int N, int C, int H, int W, int K, hipStream_t st);
 bool dwconv_mfma_wgrad_vrows_supported(const ConvDims& d, int dy_dt, int x_dt);
 size_t dwconv_mfma_wgrad_vrows_workspace(const ConvDims& d);
 int launch_dwconv_mfma_wgrad_vrows(const void* dy, int dy_dt, const void* x, int x_dt, float* dw,

@@ -80,6 +80,25 @@ def dwconv2d_backward_data(dy, w, out_dtype=None):
     return dx
 
 
+def dwconv2d_backward_data_accumulate(dy, w, dx):
+    """dx += data gradient, in place (slak_dwconv2d_backward_data_accumulate); where the kernel for this shape cannot accumulate the
+    gradient goes to a temporary and is added with a tensor add (what autograd does)."""
+    _check_tensor(dy, "grad"); _check_tensor(w, "weight"); _check_tensor(dx, "dx")
+    N, C, H, W, kh, kw = _dims(dy, w)
+    if dx.shape != dy.shape or dx.dtype != dy.dtype:
+        raise RuntimeError("dx and grad must have the same shape and dtype")
+    L = _lib.lib()
+    ws, nb = _workspace(L.slak_dwconv2d_workspace_bytes(_lib.OP_BWD_DATA, N, C, H, W, kh, kw, _dt(dy, "grad")), dy.device)
+    with torch.cuda.device(dy.device):
+        rc = L.slak_dwconv2d_backward_data_accumulate(dy.data_ptr(), _dt(dy, "grad"), w.data_ptr(), _dt(w, "weight"), dx.data_ptr(), _dt(dx, "dx"),
+                                                      N, C, H, W, kh, kw, ws.data_ptr() if ws is not None else None, nb, _stream(dy.device))
+    if rc == _lib.ERR_UNSUPPORTED:
+        dx += dwconv2d_backward_data(dy, w)
+        return dx
+    _lib.check(rc, "slak_dwconv2d_backward_data_accumulate")
+    return dx
+
+
 def dwconv2d_backward_filter(dy, x, w):
     """dw, always float32 (backward_filter_fp16.cu:187)."""
     _check_tensor(dy, "grad"); _check_tensor(x, "input"); _check_tensor(w, "weight")

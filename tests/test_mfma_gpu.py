@@ -163,7 +163,11 @@ def test_mfma_identity_and_adjoint_full_size(mfma_only, gpu):
         assert torch.equal(y, y2)
 
 
-@pytest.mark.parametrize("N,C,H,W,K", [(5, 7, 14, 14, 47), (4, 3, 12, 10, 9), (1, 1, 14, 14, 13), (3, 2, 28, 28, 49), (6, 5, 7, 7, 13)])
+@pytest.mark.parametrize("N,C,H,W,K", [(5, 7, 14, 14, 47), (4, 3, 12, 10, 9), (1, 1, 14, 14, 13), (3, 2, 28, 28, 49), (6, 5, 7, 7, 13),
+                                       # one-launch kernels of the 56x56 / 28x28 class: batch tails, non-square planes, 8-byte-aligned rows, 64x64
+                                       (5, 3, 56, 56, 51), (9, 2, 28, 28, 49), (2, 2, 48, 40, 31), (2, 3, 64, 64, 61), (3, 2, 32, 32, 31),
+                                       (6, 2, 24, 24, 13), (7, 2, 28, 20, 13), (1, 1, 56, 56, 51), (11, 1, 20, 28, 49),
+                                       (3, 2, 96, 96, 61)])
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 def test_tri_dwconv_matches_the_three_branch_convs(N, C, H, W, K, dtype, gpu):
     """block_ops.tri_dwconv (one launch for Kx5 + 5xK + 5x5 on the 14x14 class; three launches elsewhere): outputs are the
@@ -186,9 +190,50 @@ def test_tri_dwconv_matches_the_three_branch_convs(N, C, H, W, K, dtype, gpu):
         assert torch.equal(w.grad, ops.dwconv2d_backward_filter(dy, x.detach(), w.detach()))
     # where the one-launch kernel ran: the summed gradient is rounded ONCE -> the oracle's half-ulp bound holds for the sum
     L = _lib()
-    if L.lib().slak_dwconv2d_tri_supported(L.SLAK_BF16 if dtype == torch.bfloat16 else L.SLAK_F16, N, C, H, W, K):
-        xr = [_round(dy, dtype) for dy in dys]
-        ref = sum(oracle.dwconv2d_bwd_data(d, _round(w.detach(), dtype)) for d, w in zip(xr, ws))
-        _check(x.grad, ref, 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11, "tri dgrad")
+    kind = L.lib().slak_dwconv2d_tri_supported(L.SLAK_BF16 if dtype == torch.bfloat16 else L.SLAK_F16, N, C, H, W, K)
+    if kind == 2:                                                    # the node runs three launches there (accumulating data gradient)
+        kind = 0
+    xr = [_round(dy, dtype) for dy in dys]
+    parts = [oracle.dwconv2d_bwd_data(d, _round(w.detach(), dtype)) for d, w in zip(xr, ws)]
+    ref = sum(parts)
+    ulp = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11
+    if kind == 1:
+        _check(x.grad, ref, ulp, "tri dgrad")
     else:
         assert (H, W) != (14, 14)
+
+
+@pytest.mark.parametrize("N,C,H,W,K", [(5, 3, 56, 56, 51), (9, 2, 28, 28, 49), (2, 2, 48, 40, 31), (7, 2, 28, 20, 13), (3, 2, 96, 96, 61), (4, 3, 14, 14, 47)])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_backward_data_accumulate_is_a_tensor_add_of_the_gradient(N, C, H, W, K, dtype, gpu):
+    """slak_dwconv2d_backward_data_accumulate: dx += grad, rounded like a bf16 / fp16 tensor add -- bit-identical to computing the
+    gradient into a temporary and adding it with torch (shapes whose kernel cannot accumulate take exactly that path)."""
+    ops = _ops()
+    torch.manual_seed(K + N)
+    dy = torch.randn(N, C, H, W, device=gpu).to(dtype)
+    base = torch.randn(N, C, H, W, device=gpu).to(dtype)
+    for kh, kw in ((K, 5), (5, K), (5, 5)):
+        w = torch.randn(C, 1, kh, kw, device=gpu) * 0.05
+        want = base + ops.dwconv2d_backward_data(dy, w)
+        got = ops.dwconv2d_backward_data_accumulate(dy, w, base.clone())
+        assert torch.equal(got, want), (kh, kw, (got.float() - want.float()).abs().max().item())
+
+
+def test_big_tri_kernels_behind_the_dev_switch(gpu):
+    """block_ops.use_big_tri routes the 56x56 / 28x28 class through the one-launch kernels (kept for A/B measurements)."""
+    from slak_amd import block_ops
+    ops = _ops()
+    torch.manual_seed(11)
+    x = torch.randn(5, 3, 56, 56, device=gpu).bfloat16().requires_grad_(True)
+    ws = [(torch.randn(3, 1, kh, kw, device=gpu) * 0.05).requires_grad_(True) for kh, kw in ((51, 5), (5, 51), (5, 5))]
+    dys = [torch.randn(5, 3, 56, 56, device=gpu).bfloat16() for _ in range(3)]
+    block_ops.use_big_tri = True
+    try:
+        ys = block_ops.tri_dwconv(x, *ws)
+        torch.autograd.backward(ys, dys)
+    finally:
+        block_ops.use_big_tri = False
+    for y, w in zip(ys, ws):
+        assert torch.equal(y, ops.dwconv2d_forward(x.detach(), w.detach()))
+    ref = sum(ops.dwconv2d_backward_data(dy, w.detach()).float() for dy, w in zip(dys, ws))
+    assert (x.grad.float() - ref).abs().max().item() <= 2e-2 * max(1.0, ref.abs().max().item())
