@@ -6,6 +6,10 @@
 //                                                         leave the same lane/register map), so the two elementwise adds
 //                                                         autograd would run on the three partial gradients disappear
 // At this size a launch is ~10 us of fixed cost for ~8 us of HBM time, so one launch for three is also what removes most of it.
+// NARROW (W < 8, odd widths included: the 7x7 planes of SLaK's last stage): a row is one 16-byte piece at a 2-byte aligned
+// address (the LDS-DMA takes it: tools/dma_probe.hip), so only the "half 0" lanes fetch; the piece drags in 8 - W elements of the
+// next row (or plane), which are cleared in the fragment registers (two v_and per fragment: nothing foreign, NaN or not, ever
+// reaches an MFMA) and never transposed into x^T; results leave as 2-byte stores (rows of an odd width are not dword aligned).
 #include "mfma_common.h"
 
 namespace slak {
@@ -36,13 +40,13 @@ template <> __device__ __forceinline__ f32x4_t st_mfma16<f16_t>(s16x8 a, s16x8 b
 }
 
 // DGRAD: three inputs, one output, filters rotated by 180 degrees; else one input, three outputs
-template <typename T, bool DGRAD>
+template <typename T, bool DGRAD, bool NARROW>
 __global__ __launch_bounds__(MF_THREADS) void dwconv_mfma_small_tri_kernel(const SmallTriParams p) {
     constexpr int NT = DGRAD ? 3 : 1;                             // input tensors
     constexpr int SLOT = NT * 1024;                               // bytes per ring slot: NT x [2 planes x 16 rows x 32 B]
     // per-wave LDS region (bytes): [64 zero pad][ring][64 zero pad][x^T: 2 planes][64 zero row][3 x filter windows]
     constexpr int RING = 64, XT = RING + ST_NS * SLOT + 64, ZROW = XT + 1024, WIN = ZROW + 64, WAVE_BYTES = WIN + 3 * ST_WINB;
-    constexpr int NSTORE = DGRAD ? 4 : 12;                         // store instructions per complete pair
+    constexpr int NSTORE = (DGRAD ? 4 : 12) * (NARROW ? 2 : 1);    // store instructions per complete pair
     extern __shared__ __attribute__((aligned(16))) uint16_t lds[];
     const int lane = threadIdx.x & 63;
     const int wave = wave_id_uniform();
@@ -83,16 +87,21 @@ __global__ __launch_bounds__(MF_THREADS) void dwconv_mfma_small_tri_kernel(const
     const unsigned gplane_b = (unsigned)(p.C * HW) * 2;
     const int d_pp = lane >> 5, d_row = (lane >> 1) & 15, d_half = lane & 1;
     const unsigned d_src = (unsigned)d_pp * gplane_b + (unsigned)(d_row * p.W) * 2 + (d_half ? (unsigned)(p.W - 8) * 2 : 0u);
-    const bool d_rowok = d_row < p.H;
+    const bool d_rowok = d_row < p.H && (!NARROW || d_half == 0);
     const unsigned lds_wave = (unsigned)(uintptr_t)SLAK_LDS(uint16_t, lds) + wave * WAVE_BYTES;
     const unsigned chan_b = (unsigned)c * (unsigned)HW * 2;
+    const unsigned last_row_b = p.tensor_bytes - (unsigned)(2 * p.W);     // byte offset of the tensor's last image row
     auto issue_pair = [&](int q) {
         const int n0 = n_begin + 2 * q;
         const unsigned gb = (unsigned)n0 * gplane_b + chan_b;
         const unsigned dst = lds_wave + RING + (unsigned)(q % ST_NS) * SLOT;
         if (d_rowok && n0 + d_pp < n_end) {
+            unsigned so = gb + d_src;
+            // NARROW: the piece of the tensor's very last row would end 16 - 2W bytes behind the tensor (the buffer range check
+            // zeroes it, and nothing promises that memory exists): it is fetched that much earlier and shifted into place below
+            if (NARROW && so == last_row_b) so -= (unsigned)(16 - 2 * p.W);
 #pragma unroll
-            for (int t = 0; t < NT; ++t) lds_dma16(gb + d_src, rs[t], __builtin_amdgcn_readfirstlane(dst + t * 1024));
+            for (int t = 0; t < NT; ++t) lds_dma16(so, rs[t], __builtin_amdgcn_readfirstlane(dst + t * 1024));
         }
     };
     for (int q = 0; q < ST_NS - 1 && q < npairs; ++q) issue_pair(q);
@@ -135,6 +144,9 @@ __global__ __launch_bounds__(MF_THREADS) void dwconv_mfma_small_tri_kernel(const
             for (int k = 0; k < 4; ++k) {
                 d[k] = r < MF_TAPS ? src[(r < MF_TAPS ? r : 0) * (ST_WLEN / 2) + k] : 0u;
                 if (!vert && half && 2 * k < 16 - p.W) d[k] = 0u;     // columns already covered by the first half
+                if (NARROW && !vert && !half) {                       // k-slots beyond the row (W < 8): no such input
+                    if (2 * k >= p.W) d[k] = 0u; else if (2 * k + 1 >= p.W) d[k] &= 0xffffu;
+                }
             }
             tf[b][m] = __builtin_bit_cast(s16x8, d);
         }
@@ -146,13 +158,27 @@ __global__ __launch_bounds__(MF_THREADS) void dwconv_mfma_small_tri_kernel(const
     const int g4 = lane >> 4;
     const unsigned trd = (unsigned)((4 * g4 + (l15 >> 2)) * 32 + (l15 & 3) * 8);
     const int xt_row = l15 < 8 ? l15 : l15 - (16 - p.W);
-    const bool twr_ok = l15 < 8 || xt_row >= 8;
+    const bool twr_ok = NARROW ? l15 < p.W : (l15 < 8 || xt_row >= 8);
     const unsigned twr = (unsigned)(XT + xt_row * 32 + g4 * 8);
     const unsigned ooff = (unsigned)(l15 * p.W + 4 * kg) * 2;
     const bool st0 = l15 < p.H && 4 * kg < p.W, st1 = l15 < p.H && 4 * kg + 2 < p.W;
-    auto frag = [&](unsigned base, int m) -> s16x8 {              // MFMA m of a plane whose guarded image starts 64 bytes after `base`
+    // NARROW: what a row's 16-byte piece holds beyond column W-1 belongs to the next row / plane: cleared in the register
+    const unsigned bm2 = 5 < p.W ? 0xffffffffu : (4 < p.W ? 0xffffu : 0u), bm3 = 7 < p.W ? 0xffffffffu : (6 < p.W ? 0xffffu : 0u);
+    auto frag = [&](unsigned base, int m, bool rowmajor) -> s16x8 {   // MFMA m of a plane whose guarded image starts 64 bytes after `base`
         const unsigned a = (m == 2 && rsel) ? zlane : base + xlane + m * 64;
-        return __builtin_bit_cast(s16x8, *(const u32x4*)(L + a));
+        u32x4 v = *(const u32x4*)(L + a);
+        if (NARROW && rowmajor) { v[2] &= bm2; v[3] &= bm3; }
+        return __builtin_bit_cast(s16x8, v);
+    };
+    auto store4 = [&](const f32x4_t& v, const __amdgpu_buffer_rsrc_t& r, unsigned go) {      // 4 consecutive columns of output row l15
+        if constexpr (NARROW) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (l15 < p.H && 4 * kg + j < p.W) __builtin_amdgcn_raw_buffer_store_b16((short)(pack2<T>(v[j], 0.f) & 0xffffu), r, ooff + 2 * j, go, 0);
+        } else {
+            if (st0) __builtin_amdgcn_raw_buffer_store_b32(pack2<T>(v[0], v[1]), r, ooff, go, 0);
+            if (st1) __builtin_amdgcn_raw_buffer_store_b32(pack2<T>(v[2], v[3]), r, ooff + 4, go, 0);
+        }
     };
 
     for (int q = 0; q < npairs; ++q) {
@@ -164,6 +190,26 @@ __global__ __launch_bounds__(MF_THREADS) void dwconv_mfma_small_tri_kernel(const
         __builtin_amdgcn_wave_barrier();
         const int n0 = n_begin + 2 * q;
         const unsigned slot = (unsigned)RING + (unsigned)(q % ST_NS) * SLOT;
+        if (NARROW && c == p.C - 1 && n0 + 1 >= p.N - 1 && n0 <= p.N - 1) {       // (wave-uniform) this pair holds the tensor's last plane
+            const int ppl = p.N - 1 - n0, sh = 8 - p.W;             // its last row arrived `sh` elements late: shift it into place
+            if (lane < NT) {
+                char* rowp = L + slot + lane * 1024 + ppl * 512 + (p.H - 1) * 32;
+                const u32x4 o = *(const u32x4*)rowp;
+                const unsigned oo[6] = {o[0], o[1], o[2], o[3], 0u, 0u};
+                const int wsh = (16 * sh) >> 5, bsh = (16 * sh) & 31;
+                u32x4 nv;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    unsigned lo = 0u, hi = 0u;
+#pragma unroll
+                    for (int j = 0; j < 6; ++j) { if (j == k + wsh) lo = oo[j]; if (j == k + wsh + 1) hi = oo[j]; }
+                    nv[k] = bsh ? ((lo >> bsh) | (hi << (32 - bsh))) : lo;
+                }
+                *(u32x4*)rowp = nv;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+        }
         // vertical branch: its input plane pair (tensor 0) transposed into x^T
         {
             const s16x4 t0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(SLAK_LDS(s16x4, L + slot + trd));
@@ -179,22 +225,16 @@ __global__ __launch_bounds__(MF_THREADS) void dwconv_mfma_small_tri_kernel(const
             f32x4_t av = {0.f, 0.f, 0.f, 0.f}, ah = av, as = av;
 #pragma unroll
             for (int m = 0; m < 3; ++m) {
-                av = st_mfma16<T>(frag(bv + pp * 512, m), tf[0][m], av);       // operands swapped: D^T = X^T-tile x T^T
-                ah = st_mfma16<T>(tf[1][m], frag(bh + pp * 512, m), ah);
-                as = st_mfma16<T>(tf[2][m], frag(bs + pp * 512, m), as);
+                av = st_mfma16<T>(frag(bv + pp * 512, m, false), tf[0][m], av);       // operands swapped: D^T = X^T-tile x T^T
+                ah = st_mfma16<T>(tf[1][m], frag(bh + pp * 512, m, true), ah);
+                as = st_mfma16<T>(tf[2][m], frag(bs + pp * 512, m, true), as);
             }
             const unsigned go = gb + pp * gplane_b;
             if constexpr (DGRAD) {
                 const f32x4_t s = (av + ah) + as;                   // the three partial gradients, added in fp32
-                if (st0) __builtin_amdgcn_raw_buffer_store_b32(pack2<T>(s[0], s[1]), ro[0], ooff, go, 0);
-                if (st1) __builtin_amdgcn_raw_buffer_store_b32(pack2<T>(s[2], s[3]), ro[0], ooff + 4, go, 0);
+                store4(s, ro[0], go);
             } else {
-                if (st0) __builtin_amdgcn_raw_buffer_store_b32(pack2<T>(av[0], av[1]), ro[0], ooff, go, 0);
-                if (st1) __builtin_amdgcn_raw_buffer_store_b32(pack2<T>(av[2], av[3]), ro[0], ooff + 4, go, 0);
-                if (st0) __builtin_amdgcn_raw_buffer_store_b32(pack2<T>(ah[0], ah[1]), ro[1], ooff, go, 0);
-                if (st1) __builtin_amdgcn_raw_buffer_store_b32(pack2<T>(ah[2], ah[3]), ro[1], ooff + 4, go, 0);
-                if (st0) __builtin_amdgcn_raw_buffer_store_b32(pack2<T>(as[0], as[1]), ro[2], ooff, go, 0);
-                if (st1) __builtin_amdgcn_raw_buffer_store_b32(pack2<T>(as[2], as[3]), ro[2], ooff + 4, go, 0);
+                store4(av, ro[0], go); store4(ah, ro[1], go); store4(as, ro[2], go);
             }
         }
         if (q + ST_NS - 1 < npairs) issue_pair(q + ST_NS - 1);
@@ -205,7 +245,8 @@ __global__ __launch_bounds__(MF_THREADS) void dwconv_mfma_small_tri_kernel(const
 static bool fill_tri_params(SmallTriParams& p, int N, int C, int H, int W, int K, int target_wgs) {
     p.N = N; p.C = C; p.H = H; p.W = W; p.K = K;
     if (N <= 0 || C <= 0 || K < 5 || !(K & 1) || K > 63 || K * MF_TAPS > ST_WCH * 64) return false;
-    if (W < 8 || W > 14 || (W & 1) || H > 14 || H < 1) return false;   // both the row-major image and its transpose need guard rows
+    if (H > 14 || H < 1) return false;                                 // both the row-major image and its transpose need guard rows
+    if (W >= 8 ? (W > 14 || (W & 1)) : W < 4) return false;            // 8..14 even: two row halves; 4..7: one piece per row (NARROW)
     const int cblocks = (C + 3) / 4;
     int slices = target_wgs / cblocks; if (slices < 1) slices = 1;
     int per = (N + slices - 1) / slices; per = (per + 1) & ~1;
@@ -222,17 +263,22 @@ bool dwconv_mfma_small_tri_supported(int N, int C, int H, int W, int K, int dtyp
     return fill_tri_params(p, N, C, H, W, K, 768);
 }
 
-template <typename T, bool DGRAD>
-static int launch_tri_t(SmallTriParams& p, hipStream_t st) {
+template <typename T, bool DGRAD, bool NARROW>
+static int launch_tri_tn(SmallTriParams& p, hipStream_t st) {
     constexpr int NT = DGRAD ? 3 : 1;
     constexpr size_t WAVE_BYTES = 64 + ST_NS * NT * 1024 + 64 + 1024 + 64 + 3 * ST_WINB;
-    auto k = dwconv_mfma_small_tri_kernel<T, DGRAD>;
+    auto k = dwconv_mfma_small_tri_kernel<T, DGRAD, NARROW>;
     fill_tri_params(p, p.N, p.C, p.H, p.W, p.K, (DGRAD ? 2 : 3) * mfma_cu_count());   // resident workgroups per CU (LDS)
     const size_t lds = (size_t)MF_WAVES * WAVE_BYTES;
     if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(k, dim3((unsigned)(((p.C + 3) / 4) * p.slices)), dim3(MF_THREADS), lds, st, p);
     SLAK_LAUNCH_CHECK();
     return SLAK_OK;
+}
+
+template <typename T, bool DGRAD>
+static int launch_tri_t(SmallTriParams& p, hipStream_t st) {
+    return p.W < 8 ? launch_tri_tn<T, DGRAD, true>(p, st) : launch_tri_tn<T, DGRAD, false>(p, st);
 }
 
 int launch_dwconv_mfma_small_tri(bool dgrad, const void* const* in, void* const* out, const float* const* w, int dtype,

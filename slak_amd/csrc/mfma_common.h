@@ -206,15 +206,14 @@ __device__ __forceinline__ void lds_dma_run(unsigned voff, v4i_t rsrc, unsigned 
 __device__ __forceinline__ void wg_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
-__device__ __forceinline__ void wait_vmcnt_dyn(int n) {       // n is wave-uniform, 0..31 (anything else waits for everything)
+__device__ __forceinline__ void wait_vmcnt_dyn(int n) {       // n is wave-uniform, 0..63 (anything else waits for everything)
 #define SLAK_VMC(k) case k: wait_vmcnt<k>(); break;
+#define SLAK_VMC8(k) SLAK_VMC(k) SLAK_VMC(k + 1) SLAK_VMC(k + 2) SLAK_VMC(k + 3) SLAK_VMC(k + 4) SLAK_VMC(k + 5) SLAK_VMC(k + 6) SLAK_VMC(k + 7)
     switch (n) {
-        SLAK_VMC(0) SLAK_VMC(1) SLAK_VMC(2) SLAK_VMC(3) SLAK_VMC(4) SLAK_VMC(5) SLAK_VMC(6) SLAK_VMC(7)
-        SLAK_VMC(8) SLAK_VMC(9) SLAK_VMC(10) SLAK_VMC(11) SLAK_VMC(12) SLAK_VMC(13) SLAK_VMC(14) SLAK_VMC(15)
-        SLAK_VMC(16) SLAK_VMC(17) SLAK_VMC(18) SLAK_VMC(19) SLAK_VMC(20) SLAK_VMC(21) SLAK_VMC(22) SLAK_VMC(23)
-        SLAK_VMC(24) SLAK_VMC(25) SLAK_VMC(26) SLAK_VMC(27) SLAK_VMC(28) SLAK_VMC(29) SLAK_VMC(30) SLAK_VMC(31)
+        SLAK_VMC8(0) SLAK_VMC8(8) SLAK_VMC8(16) SLAK_VMC8(24) SLAK_VMC8(32) SLAK_VMC8(40) SLAK_VMC8(48) SLAK_VMC8(56)
         default: wait_vmcnt<0>(); break;
     }
+#undef SLAK_VMC8
 #undef SLAK_VMC
 }
 

@@ -7,7 +7,7 @@ from slak_amd import ops, _lib, block_ops
 dev = torch.device("cuda:0")
 L = _lib.lib()
 bad = 0
-for (N, C, H, W, K) in [(5, 3, 56, 56, 51), (9, 2, 28, 28, 49), (2, 2, 48, 40, 31), (2, 3, 64, 64, 61), (3, 2, 32, 32, 31), (6, 2, 24, 24, 13), (7, 2, 28, 20, 13), (1, 1, 56, 56, 51), (11, 1, 20, 28, 49), (17, 2, 56, 56, 51), (33, 1, 28, 28, 49)]:
+for (N, C, H, W, K) in [(6, 5, 7, 7, 13), (17, 6, 7, 7, 13), (1, 1, 7, 7, 13), (4, 3, 6, 6, 9), (3, 2, 7, 5, 7), (5, 2, 5, 7, 9), (2, 130, 7, 7, 13), (5, 7, 14, 14, 47), (3, 4, 4, 4, 7), (2, 3, 7, 6, 9), (3, 2, 5, 5, 7),  (9, 2, 28, 28, 49), (2, 2, 48, 40, 31), (2, 3, 64, 64, 61), (3, 2, 32, 32, 31), (6, 2, 24, 24, 13), (7, 2, 28, 20, 13), (1, 1, 56, 56, 51), (11, 1, 20, 28, 49), (17, 2, 56, 56, 51), (33, 1, 28, 28, 49)]:
     for dtype in (torch.bfloat16, torch.float16):
         kind = L.slak_dwconv2d_tri_supported(_lib.SLAK_BF16 if dtype == torch.bfloat16 else _lib.SLAK_F16, N, C, H, W, K)
         torch.manual_seed(N + K)
@@ -42,7 +42,7 @@ for (N, C, H, W, K) in [(5, 3, 56, 56, 51), (9, 2, 28, 28, 49), (2, 2, 48, 40, 3
 print("failures:", bad)
 if len(sys.argv) > 1:
     st = torch.cuda.current_stream(dev).cuda_stream
-    for (N, C, H, W, K) in [(128, 96, 56, 56, 51), (128, 192, 28, 28, 49), (128, 384, 14, 14, 47), (64, 192, 48, 48, 59), (64, 384, 24, 24, 57)]:
+    for (N, C, H, W, K) in [(128, 768, 7, 7, 13), (64, 768, 12, 12, 13), (128, 96, 56, 56, 51), (128, 192, 28, 28, 49), (128, 384, 14, 14, 47), (64, 192, 48, 48, 59), (64, 384, 24, 24, 57)]:
         x = torch.randn(N, C, H, W, device=dev).bfloat16(); dys = [torch.randn_like(x) for _ in range(3)]
         ws = [torch.randn(C, 1, kh, kw, device=dev) * 0.02 for kh, kw in ((K, 5), (5, K), (5, 5))]
         ys = [torch.empty_like(x) for _ in range(3)]; dx = torch.empty_like(x)
