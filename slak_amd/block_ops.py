@@ -49,8 +49,57 @@ class _LnNchwToNhwc(torch.autograd.Function):
         with torch.cuda.device(x.device):
             _lib.check(L.slak_ln_nchw_to_nhwc_backward(g.data_ptr(), x.data_ptr(), weight.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
                                                        dx.data_ptr(), dw.data_ptr(), db.data_ptr(), N, C, H * W,
-                                                       ws.data_ptr(), nb, _stream(x.device)), "slak_ln_nchw_to_nhwc_backward")
+                                                       ws.data_ptr() if ws is not None else None, nb, _stream(x.device)), "slak_ln_nchw_to_nhwc_backward")
         return dx, dw, db, None
+
+
+def _scale_residual_fwd(shortcut, z, gamma, sample_scale, emit_lowp):
+    _chk(shortcut, "shortcut"); _chk(z, "z", torch.bfloat16); _chk(gamma, "gamma", torch.float32)
+    N, C, H, W = shortcut.shape
+    if z.shape != (N, H, W, C):
+        raise RuntimeError("z must be (N,H,W,C)")
+    sdt = {torch.float32: _lib.SLAK_F32, torch.bfloat16: _lib.SLAK_BF16}.get(shortcut.dtype)
+    if sdt is None:
+        raise TypeError("shortcut must be float32 or bfloat16")
+    out = torch.empty((N, C, H, W), dtype=torch.float32, device=z.device)
+    out16 = torch.empty((N, C, H, W), dtype=torch.bfloat16, device=z.device) if emit_lowp else None
+    L = _lib.lib()
+    with torch.cuda.device(z.device):
+        _lib.check(L.slak_scale_residual_forward(shortcut.data_ptr(), sdt, z.data_ptr(), gamma.data_ptr(),
+                                                 sample_scale.data_ptr() if sample_scale is not None else None,
+                                                 out.data_ptr(), out16.data_ptr() if emit_lowp else None,
+                                                 N, C, H * W, _stream(z.device)), "slak_scale_residual_forward")
+    return out, out16
+
+
+def _scale_residual_bwd(z, gamma, sample_scale, shortcut_dtype, dout, dout16):
+    """-> (dshortcut, dz, dgamma, colsum of dz over (n, p) = the bias gradient of the Linear that produced z)"""
+    N, H, W, C = z.shape
+    if dout is None:                                   # only the bf16 copy was used downstream
+        dout = torch.zeros((N, C, H, W), dtype=torch.float32, device=z.device)
+    dout = dout.contiguous()
+    if dout.dtype != torch.float32:
+        dout = dout.float()
+    if dout16 is not None:
+        dout16 = dout16.contiguous()
+        if dout16.dtype != torch.bfloat16:
+            dout16 = dout16.to(torch.bfloat16)
+    dsum = torch.empty_like(dout) if dout16 is not None else None
+    dz = torch.empty_like(z)
+    dgamma = torch.empty_like(gamma)
+    dzc = torch.empty_like(gamma)
+    L = _lib.lib()
+    ws, nb = _workspace(L.slak_block_tail_workspace_bytes(N, C, H * W), z.device)
+    with torch.cuda.device(z.device):
+        _lib.check(L.slak_scale_residual_backward(dout.data_ptr(), dout16.data_ptr() if dout16 is not None else None,
+                                                  dsum.data_ptr() if dsum is not None else None, z.data_ptr(), gamma.data_ptr(),
+                                                  sample_scale.data_ptr() if sample_scale is not None else None,
+                                                  dz.data_ptr(), dgamma.data_ptr(), dzc.data_ptr(), N, C, H * W,
+                                                  ws.data_ptr() if ws is not None else None, nb, _stream(z.device)),
+                   "slak_scale_residual_backward")
+    dsc = dsum if dsum is not None else dout
+    dshortcut = dsc if shortcut_dtype == torch.float32 else dsc.to(shortcut_dtype)
+    return dshortcut, dz, dgamma, dzc
 
 
 class _ScaleResidual(torch.autograd.Function):
@@ -59,57 +108,15 @@ class _ScaleResidual(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, shortcut, z, gamma, sample_scale, emit_lowp):
-        _chk(shortcut, "shortcut"); _chk(z, "z", torch.bfloat16); _chk(gamma, "gamma", torch.float32)
-        N, C, H, W = shortcut.shape
-        if z.shape != (N, H, W, C):
-            raise RuntimeError("z must be (N,H,W,C)")
-        sdt = {torch.float32: _lib.SLAK_F32, torch.bfloat16: _lib.SLAK_BF16}.get(shortcut.dtype)
-        if sdt is None:
-            raise TypeError("shortcut must be float32 or bfloat16")
-        out = torch.empty((N, C, H, W), dtype=torch.float32, device=z.device)
-        out16 = torch.empty((N, C, H, W), dtype=torch.bfloat16, device=z.device) if emit_lowp else None
-        L = _lib.lib()
-        with torch.cuda.device(z.device):
-            _lib.check(L.slak_scale_residual_forward(shortcut.data_ptr(), sdt, z.data_ptr(), gamma.data_ptr(),
-                                                     sample_scale.data_ptr() if sample_scale is not None else None,
-                                                     out.data_ptr(), out16.data_ptr() if emit_lowp else None,
-                                                     N, C, H * W, _stream(z.device)), "slak_scale_residual_forward")
+        out, out16 = _scale_residual_fwd(shortcut, z, gamma, sample_scale, emit_lowp)
         ctx.save_for_backward(z, gamma, sample_scale)
         ctx.shortcut_dtype = shortcut.dtype
-        ctx.emit_lowp = emit_lowp
-        if emit_lowp:
-            return out, out16
-        return out
+        return (out, out16) if emit_lowp else out
 
     @staticmethod
     def backward(ctx, dout, dout16=None):
         z, gamma, sample_scale = ctx.saved_tensors
-        N, H, W, C = z.shape
-        if dout is None:                                   # only the bf16 copy was used downstream
-            dout = torch.zeros((N, C, H, W), dtype=torch.float32, device=z.device)
-        dout = dout.contiguous()
-        if dout.dtype != torch.float32:
-            dout = dout.float()
-        if dout16 is not None:
-            dout16 = dout16.contiguous()
-            if dout16.dtype != torch.bfloat16:
-                dout16 = dout16.to(torch.bfloat16)
-        dsum = torch.empty_like(dout) if dout16 is not None else None
-        dz = torch.empty_like(z)
-        dgamma = torch.empty_like(gamma)
-        dzc = torch.empty_like(gamma)
-        L = _lib.lib()
-        ws, nb = _workspace(L.slak_block_tail_workspace_bytes(N, C, H * W), z.device)
-        with torch.cuda.device(z.device):
-            _lib.check(L.slak_scale_residual_backward(dout.data_ptr(), dout16.data_ptr() if dout16 is not None else None,
-                                                      dsum.data_ptr() if dsum is not None else None, z.data_ptr(), gamma.data_ptr(),
-                                                      sample_scale.data_ptr() if sample_scale is not None else None,
-                                                      dz.data_ptr(), dgamma.data_ptr(), dzc.data_ptr(), N, C, H * W,
-                                                      ws.data_ptr(), nb, _stream(z.device)),
-                       "slak_scale_residual_backward")
-        dz._slak_colsum = dzc          # sum of dz over (n, p): the bias gradient of the Linear that produced z (picked up by mlp_splitk)
-        dsc = dsum if dsum is not None else dout
-        dshortcut = dsc if ctx.shortcut_dtype == torch.float32 else dsc.to(ctx.shortcut_dtype)
+        dshortcut, dz, dgamma, _ = _scale_residual_bwd(z, gamma, sample_scale, ctx.shortcut_dtype, dout, dout16)
         return dshortcut, dz, dgamma, None, None
 
 
@@ -295,7 +302,7 @@ class _BranchBN3(torch.autograd.Function):
         sums = torch.empty(C * 6 + 1, dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
             _lib.check(L.slak_bn3_forward_sums(y1.data_ptr(), y2.data_ptr(), y3.data_ptr(), sums.data_ptr(), N, C, P,
-                                               ws.data_ptr(), nb, _stream(dev)), "slak_bn3_forward_sums")
+                                               ws.data_ptr() if ws is not None else None, nb, _stream(dev)), "slak_bn3_forward_sums")
         count = float(N * P)
         count_dev = None
         if group is not None:
@@ -331,7 +338,7 @@ class _BranchBN3(torch.autograd.Function):
         lsums = torch.empty(C * 4, dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
             _lib.check(L.slak_bn3_backward_sums(dout.data_ptr(), y1.data_ptr(), y2.data_ptr(), y3.data_ptr(), lsums.data_ptr(), N, C, P,
-                                                ws.data_ptr(), nb, _stream(dev)), "slak_bn3_backward_sums")
+                                                ws.data_ptr() if ws is not None else None, nb, _stream(dev)), "slak_bn3_backward_sums")
         gsums = lsums
         if ctx.group is not None:
             gsums = lsums.clone()
@@ -413,7 +420,7 @@ class _LnChannelsFirst(torch.autograd.Function):
         with torch.cuda.device(x.device):
             _lib.check(L.slak_ln_channels_first_backward(g.data_ptr(), _SDT[g.dtype], x.data_ptr(), _SDT[x.dtype], weight.data_ptr(), mean.data_ptr(),
                                                          rstd.data_ptr(), dx.data_ptr(), dw.data_ptr(), db.data_ptr(), N, C, H * W,
-                                                         ws.data_ptr(), nb, _stream(x.device)), "slak_ln_channels_first_backward")
+                                                         ws.data_ptr() if ws is not None else None, nb, _stream(x.device)), "slak_ln_channels_first_backward")
         return dx, dw, db, None, None
 
 
@@ -467,6 +474,46 @@ def _refresh_lowp():
 _SPLITK_ROWS = int(_os.environ.get("SLAK_SPLITK_ROWS", "6272"))     # rows per split of the weight-gradient GEMMs (0: one plain GEMM)
 
 
+def _mlp_fwd(t, w1, b1, w2, b2):
+    F = torch.nn.functional
+    w1b, w2b = lowp_param(w1), lowp_param(w2)
+    y1 = F.linear(t, w1b, lowp_param(b1))
+    a = F.gelu(y1)
+    z = F.linear(a, w2b, lowp_param(b2))
+    return z, (t, w1b, y1, a, w2b)
+
+
+def _mlp_bwd(saved, dz, db2=None):
+    """db2: the column sums of dz when the caller already has them (scale_residual's backward produces them for free)."""
+    t, w1b, y1, a, w2b = saved
+    dz2 = dz.reshape(-1, dz.shape[-1])
+    a2 = a.reshape(-1, a.shape[-1]); t2 = t.reshape(-1, t.shape[-1]); y12 = y1.reshape(-1, y1.shape[-1])
+    M = dz2.shape[0]
+    S = max(1, M // _SPLITK_ROWS) if _SPLITK_ROWS > 0 else 1
+    while S > 1 and M % S:
+        S -= 1
+
+    def wgrad(dy, x):
+        if S > 1:
+            return torch.bmm(dy.view(S, M // S, -1).transpose(1, 2), x.view(S, M // S, -1)).sum(0, dtype=torch.float32)
+        return torch.mm(dy.t(), x).float()
+
+    dw2 = wgrad(dz2, a2)
+    if db2 is None:
+        db2 = dz2.sum(0, dtype=torch.float32)
+    dact = torch.mm(dz2, w2b)
+    dy1 = torch.empty_like(dact)
+    db1 = torch.empty(dact.shape[1], dtype=torch.float32, device=dact.device)
+    L = _lib.lib()
+    ws, nb = _workspace(L.slak_gelu_bwd_workspace_bytes(M, dact.shape[1]), dact.device)
+    with torch.cuda.device(dact.device):
+        _lib.check(L.slak_gelu_backward_bias(dact.data_ptr(), y12.data_ptr(), dy1.data_ptr(), db1.data_ptr(), M, dact.shape[1],
+                                             ws.data_ptr() if ws is not None else None, nb, _stream(dact.device)), "slak_gelu_backward_bias")
+    dw1 = wgrad(dy1, t2)
+    dt = torch.mm(dy1, w1b).view_as(t)
+    return dt, dw1, db1, dw2, db2
+
+
 class _MlpSplitK(torch.autograd.Function):
     """pwconv2(gelu(pwconv1(t))) under bf16 autocast (models/SLaK.py:158-160) with (i) both weight gradients as split-K batched
     library GEMMs (see _LinearSplitK) and (ii) the GELU backward fused with pwconv1's bias gradient in one HIP kernel.
@@ -474,44 +521,44 @@ class _MlpSplitK(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, t, w1, b1, w2, b2):
-        F = torch.nn.functional
-        w1b, w2b = lowp_param(w1), lowp_param(w2)
-        y1 = F.linear(t, w1b, lowp_param(b1))
-        a = F.gelu(y1)
-        z = F.linear(a, w2b, lowp_param(b2))
-        ctx.save_for_backward(t, w1b, y1, a, w2b)
+        z, saved = _mlp_fwd(t, w1, b1, w2, b2)
+        ctx.save_for_backward(*saved)
         return z
 
     @staticmethod
     def backward(ctx, dz):
-        t, w1b, y1, a, w2b = ctx.saved_tensors
-        dz2 = dz.reshape(-1, dz.shape[-1])
-        a2 = a.reshape(-1, a.shape[-1]); t2 = t.reshape(-1, t.shape[-1]); y12 = y1.reshape(-1, y1.shape[-1])
-        M = dz2.shape[0]
-        S = max(1, M // _SPLITK_ROWS) if _SPLITK_ROWS > 0 else 1
-        while S > 1 and M % S:
-            S -= 1
+        return _mlp_bwd(ctx.saved_tensors, dz)
 
-        def wgrad(dy, x):
-            if S > 1:
-                return torch.bmm(dy.view(S, M // S, -1).transpose(1, 2), x.view(S, M // S, -1)).sum(0, dtype=torch.float32)
-            return torch.mm(dy.t(), x).float()
 
-        dw2 = wgrad(dz2, a2)
-        db2 = getattr(dz, "_slak_colsum", None)            # scale_residual's backward already has the column sums of dz
-        if db2 is None or db2.shape != (dz2.shape[1],) or db2.dtype != torch.float32:
-            db2 = dz2.sum(0, dtype=torch.float32)
-        dact = torch.mm(dz2, w2b)
-        dy1 = torch.empty_like(dact)
-        db1 = torch.empty(dact.shape[1], dtype=torch.float32, device=dact.device)
-        L = _lib.lib()
-        ws, nb = _workspace(L.slak_gelu_bwd_workspace_bytes(M, dact.shape[1]), dact.device)
-        with torch.cuda.device(dact.device):
-            _lib.check(L.slak_gelu_backward_bias(dact.data_ptr(), y12.data_ptr(), dy1.data_ptr(), db1.data_ptr(), M, dact.shape[1],
-                                                 ws.data_ptr(), nb, _stream(dact.device)), "slak_gelu_backward_bias")
-        dw1 = wgrad(dy1, t2)
-        dt = torch.mm(dy1, w1b).view_as(t)
-        return dt, dw1, db1, dw2, db2
+class _MlpScaleResidual(torch.autograd.Function):
+    """The whole tail of a block behind the LayerNorm as ONE autograd node: z = pwconv2(gelu(pwconv1(t))), out = shortcut +
+    sample_scale * gamma * z (NHWC -> NCHW), optionally with the bf16 copy of `out` for the next block's convs
+    (models/SLaK.py:158-165).  One node because the residual kernel's backward produces, besides dz, the column sums of dz --
+    pwconv2's bias gradient: they go from one half of this backward to the other as a plain local variable (they used to travel as a
+    Python attribute on the dz tensor, which any hook that re-creates the tensor would have dropped)."""
+
+    @staticmethod
+    def forward(ctx, shortcut, t, w1, b1, w2, b2, gamma, sample_scale, emit_lowp):
+        z, saved = _mlp_fwd(t, w1, b1, w2, b2)
+        if z.dtype != torch.bfloat16:
+            z = z.to(torch.bfloat16)
+        z = z.contiguous()
+        out, out16 = _scale_residual_fwd(shortcut, z, gamma, sample_scale, emit_lowp)
+        ctx.save_for_backward(*saved, z, gamma, sample_scale)
+        ctx.shortcut_dtype = shortcut.dtype
+        return (out, out16) if emit_lowp else out
+
+    @staticmethod
+    def backward(ctx, dout, dout16=None):
+        *saved, z, gamma, sample_scale = ctx.saved_tensors
+        dshortcut, dz, dgamma, dzc = _scale_residual_bwd(z, gamma, sample_scale, ctx.shortcut_dtype, dout, dout16)
+        dt, dw1, db1, dw2, db2 = _mlp_bwd(saved, dz, db2=dzc)
+        return dshortcut, dt, dw1, db1, dw2, db2, dgamma, None, None
+
+
+def mlp_scale_residual(shortcut, t, w1, b1, w2, b2, gamma, sample_scale=None, emit_lowp=False):
+    """out (and, with emit_lowp, its bf16 copy) = shortcut + sample_scale * gamma * pwconv2(gelu(pwconv1(t))) -- see _MlpScaleResidual."""
+    return _MlpScaleResidual.apply(shortcut, t, w1, b1, w2, b2, gamma, sample_scale, emit_lowp)
 
 
 def mlp_splitk(t, w1, b1, w2, b2):

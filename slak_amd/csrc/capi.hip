@@ -2,6 +2,7 @@
 // Argument validation lives here; the reference's extension validates almost nothing and exit()s on
 // failure (forward_fp32.cu:173-196).  Every function returns a status code instead.
 #include <stdlib.h>
+#include <atomic>
 #include <mutex>
 #include <string>
 
@@ -10,7 +11,7 @@
 namespace slak {
 static std::mutex g_err_mu;
 static std::string g_last_hip_error = "";
-static int g_conv_algo = SLAK_ALGO_AUTO;
+static std::atomic<int> g_conv_algo{SLAK_ALGO_AUTO};     // process-wide A/B switch (tests); read once per call
 static bool use_small_dma() {                // SLAK_MFMA_SMALL_DMA=0 keeps the channel-blocked small-plane kernel (A/B testing)
     static const bool v = [] { const char* e = getenv("SLAK_MFMA_SMALL_DMA"); return !(e && e[0] == '0'); }();
     return v;

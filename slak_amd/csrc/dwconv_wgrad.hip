@@ -14,6 +14,7 @@
 //   No atomics, no memset, bitwise run-to-run reproducible.  Output is always fp32
 //   (backward_filter_fp16.cu:187).
 #include "slak_common.h"
+#include <stdlib.h>
 #include <mutex>
 
 namespace slak {
@@ -267,6 +268,8 @@ unsigned* wgrad_arrival_counters(int ngroups) {
     static unsigned* buf[MAXDEV] = {};
     static unsigned next[MAXDEV] = {};
     if (ngroups > MAXG) return nullptr;
+    static const bool force_reduce = [] { const char* e = getenv("SLAK_WGRAD_REDUCE"); return e && e[0] == '1'; }();
+    if (force_reduce) return nullptr;                 // SLAK_WGRAD_REDUCE=1: partials + a separate reduce launch (A/B and debugging)
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAXDEV) return nullptr;
     std::lock_guard<std::mutex> lk(mu);

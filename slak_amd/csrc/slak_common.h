@@ -129,7 +129,14 @@ unsigned* wgrad_arrival_counters(int ngroups);      // host; nullptr -> use laun
 __device__ __forceinline__ void wgrad_store_partial(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void wgrad_finish(const float* partial, float* dw, unsigned* counter, int* lds_flag,
                                              int nslices, int C, int c0, int nch, int ntap, int tid, int nthreads) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // my write-through partial stores have been acknowledged (vmcnt(0))
+    // Hand-off form "sc1 payload -> vmcnt(0) -> agent atomic flag; consumer: sc1 (agent-scope) loads" of MI355X_MICROARCH.md
+    // (inter-workgroup visibility, valid forms): the partials were written through to the device coherence point (agent-scope atomic
+    // stores), the explicit s_waitcnt below makes this wave's stores acknowledged before it can reach the barrier (inline asm: the
+    // compiler may drop a fence's own wait when it believes the counter is already zero), the arrival counter is an agent-scope
+    // atomic, and the last arriver reads the partials with agent-scope loads that bypass its L1.  No L2 write-back is needed (an
+    // agent-scope release fence costs one per workgroup: 18 -> 107 us measured).
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0) {
         int last = 1;

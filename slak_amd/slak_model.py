@@ -118,9 +118,10 @@ class ReparamLargeKernelConv(nn.Module):
         if small_kernel is not None and small_kernel < kernel_size:
             self.small_conv = conv_bn(in_channels, out_channels, small_kernel, stride, small_kernel // 2, groups, bn=bn)
 
-    def forward(self, inputs):
+    def forward(self, inputs, lowp=None):
+        """``lowp``: the copy of ``inputs`` in the autocast dtype that the previous block's fused tail wrote alongside its fp32
+        output (Block.emit_lowp) -- an explicit autograd output of that block, handed over by Block.forward."""
         if self.lowp_dwconv and torch.is_autocast_enabled():
-            lowp = getattr(inputs, "_slak_lowp", None)          # bf16 copy the previous block's fused tail wrote alongside (Block.emit_lowp)
             dt = torch.get_autocast_dtype("cuda")
             inputs = lowp if (lowp is not None and lowp.dtype == dt and lowp.shape == inputs.shape) else inputs.to(dt)
         if hasattr(self, 'lkb_reparam'):
@@ -136,7 +137,9 @@ class ReparamLargeKernelConv(nn.Module):
                 out = out + c(inputs)
             return out + self.reparam_bias.to(out.dtype).view(1, -1, 1, 1)
         if (self.fused_bn and self.Decom and hasattr(self, 'small_conv') and inputs.is_cuda and inputs.dtype == torch.bfloat16
-                and hasattr(self.LoRA1, 'bn') and (self.training or not torch.is_grad_enabled())):
+                and hasattr(self.LoRA1, 'bn') and (self.training or not torch.is_grad_enabled())
+                and all(m.bn.track_running_stats and m.bn.running_mean is not None and m.bn.affine
+                        for m in (self.LoRA1, self.LoRA2, self.small_conv))):      # what the fused op reads and updates
             # same arithmetic, the three BatchNorms and the two adds as one HIP op (slak_amd/block_ops.py)
             from . import block_ops
             c1, c2, c3 = self.LoRA1.conv, self.LoRA2.conv, self.small_conv.conv
@@ -210,9 +213,13 @@ class Block(nn.Module):
         self.drop_path = DropPath(drop_path) if drop_path > 0. else nn.Identity()
 
     def forward(self, x):
+        # a block with emit_lowp returns (out, bf16 copy of out); nn.Sequential hands that pair to the next block as its input
+        x, x_lowp = x if isinstance(x, tuple) else (x, None)
         shortcut = x
-        x = self.large_kernel(x)
-        if self.fused_tail and x.is_cuda and x.dtype == torch.bfloat16 and self.gamma is not None and x.shape[1] % 2 == 0:
+        x = self.large_kernel(x, lowp=x_lowp)
+        # the fused tail kernels take even C <= 1024 (tail_args_ok in csrc/block_tail.hip); anything else runs the PyTorch ops below
+        if (self.fused_tail and x.is_cuda and x.dtype == torch.bfloat16 and self.gamma is not None
+                and x.shape[1] % 2 == 0 and x.shape[1] <= 1024):
             return self._forward_fused_tail(shortcut, x)
         x = x.permute(0, 2, 3, 1)
         x = self.pwconv2(self.act(self.pwconv1(self.norm(x))))
@@ -227,9 +234,6 @@ def _block_forward_fused_tail(self, shortcut, x):
     one HIP kernel each (slak_amd/block_ops.py); the two Linear layers and GELU are unchanged."""
     from . import block_ops
     t = block_ops.ln_nchw_to_nhwc(x.contiguous(), self.norm.weight.float(), self.norm.bias.float(), self.norm.eps)
-    z = block_ops.mlp_splitk(t, self.pwconv1.weight, self.pwconv1.bias, self.pwconv2.weight, self.pwconv2.bias)
-    if z.dtype != torch.bfloat16:
-        z = z.to(torch.bfloat16)
     scale = None
     dp = self.drop_path
     if isinstance(dp, DropPath) and dp.drop_prob > 0.0 and self.training:
@@ -237,11 +241,11 @@ def _block_forward_fused_tail(self, shortcut, x):
         scale = torch.empty(x.shape[0], device=x.device, dtype=torch.float32).bernoulli_(keep)
         if keep > 0.0:
             scale.div_(keep)
-    if self.emit_lowp and torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == torch.bfloat16:
-        out, out16 = block_ops.scale_residual(shortcut.contiguous(), z.contiguous(), self.gamma.float(), scale, emit_lowp=True)
-        out._slak_lowp = out16                                  # picked up by the next block's ReparamLargeKernelConv.forward
-        return out
-    return block_ops.scale_residual(shortcut.contiguous(), z.contiguous(), self.gamma.float(), scale)
+    emit = bool(self.emit_lowp and torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == torch.bfloat16)
+    # MLP + gamma + permute + residual as one autograd node; with `emit` it returns (out, bf16 copy of out): both are autograd
+    # outputs, the pair travels to the next block through nn.Sequential (Block.forward unpacks it)
+    return block_ops.mlp_scale_residual(shortcut.contiguous(), t, self.pwconv1.weight, self.pwconv1.bias, self.pwconv2.weight,
+                                        self.pwconv2.bias, self.gamma.float(), scale, emit_lowp=emit)
 
 
 Block._forward_fused_tail = _block_forward_fused_tail

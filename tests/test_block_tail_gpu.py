@@ -122,8 +122,8 @@ def test_two_blocks_with_lowp_handoff_match_reference_composition(C, H, gpu):
             # the handoff really happened: the second block's input carried the bf16 copy
             with torch.autocast("cuda", dtype=torch.bfloat16):
                 mid = seq[0](x)
-            assert getattr(mid, "_slak_lowp", None) is not None and mid._slak_lowp.dtype == torch.bfloat16
-            assert torch.equal(mid._slak_lowp, mid.to(torch.bfloat16))
+            assert isinstance(mid, tuple) and mid[1].dtype == torch.bfloat16      # (out, bf16 copy): both explicit autograd outputs
+            assert torch.equal(mid[1], mid[0].to(torch.bfloat16))
         y.backward(dy)
         outs[mode] = (y.detach(), xi.grad.detach(), seq[0].gamma.grad.clone(), seq[1].gamma.grad.clone(),
                       seq[0].pwconv2.weight.grad.clone(), seq[1].large_kernel.LoRA2.conv.weight.grad.clone())

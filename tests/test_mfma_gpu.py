@@ -237,3 +237,27 @@ def test_big_tri_kernels_behind_the_dev_switch(gpu):
         assert torch.equal(y, ops.dwconv2d_forward(x.detach(), w.detach()))
     ref = sum(ops.dwconv2d_backward_data(dy, w.detach()).float() for dy, w in zip(dys, ws))
     assert (x.grad.float() - ref).abs().max().item() <= 2e-2 * max(1.0, ref.abs().max().item())
+
+
+@pytest.mark.parametrize("N,C,H,W,kh,kw", [(32, 24, 56, 56, 51, 5), (32, 24, 28, 28, 5, 49), (48, 64, 14, 14, 47, 5), (16, 8, 96, 96, 5, 61)])
+def test_weight_gradient_same_shape_on_two_streams_concurrently(N, C, H, W, kh, kw, mfma_only, gpu):
+    """The in-kernel slice reduction (last arriver adds the partials) takes its arrival counters from a rotating pool: launches of the
+    SAME shape running concurrently on two streams must not disturb each other -- every result bit-identical to the serial one."""
+    ops = _ops()
+    torch.manual_seed(5)
+    xs = [torch.randn(N, C, H, W, device=gpu).bfloat16() for _ in range(2)]
+    dys = [torch.randn(N, C, H, W, device=gpu).bfloat16() for _ in range(2)]
+    w = torch.randn(C, 1, kh, kw, device=gpu)
+    want = [ops.dwconv2d_backward_filter(dys[i], xs[i], w) for i in range(2)]
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    got = [[], []]
+    for rep in range(25):
+        for i, s in enumerate(streams):
+            with torch.cuda.stream(s):
+                got[i].append(ops.dwconv2d_backward_filter(dys[i], xs[i], w))
+    for s in streams:
+        s.synchronize()
+    for i in range(2):
+        for g in got[i]:
+            assert torch.equal(g, want[i])
