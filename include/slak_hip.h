@@ -169,6 +169,15 @@ int slak_scale_residual_backward(const float* dout, const void* dout_bf16, float
                                  const float* sample_scale, void* dz_bf16, float* dgamma, float* dz_colsum, int N, int C, int P,
                                  void* workspace, size_t workspace_bytes, void* stream);
 
+/* The pointwise convolutions on the large maps (stage 1-2: M = N*H*W rows of C <= 192 or 4C <= 768 channels against a weight of a few
+ * hundred KB) are HBM streams, not GEMMs: Y[M,N] = X[M,K] . Wt[N,K]^T (+ bias[N]) with both operands K-contiguous ("NT": pwconv1 /
+ * pwconv2 forward take the nn.Linear weight as it is stored, models/SLaK.py:158-160; the data gradients take its transpose), bf16 in
+ * and out, fp32 accumulate; gelu_out (or NULL) receives nn.GELU() of the rounded Y in the same pass.  Covered: K in {96, 192} with
+ * N % 32 == 0, or N in {96, 192} with K % 16 == 0 (no gelu_out); anything else returns SLAK_ERR_UNSUPPORTED (library GEMM). */
+int slak_linear_nt_supported(int M, int N, int K, int gelu);
+int slak_linear_nt(const void* x_bf16, const void* wt_bf16, const void* bias_bf16 /* or NULL */, void* y_bf16, void* gelu_out_bf16 /* or NULL */,
+                   int M, int N, int K, void* stream);
+
 /* GELU backward (exact erf form, nn.GELU()) fused with the bias gradient of the Linear in front of it (models/SLaK.py:158-160):
  * dy1 = dact * gelu'(y1); dbias[col] = sum_rows dy1.  [rows][cols] bf16 contiguous, cols % 8 == 0. */
 size_t slak_gelu_bwd_workspace_bytes(int rows, int cols);

@@ -293,9 +293,9 @@ class _BranchBN3(torch.autograd.Function):
         rmean = [bn.running_mean for bn in bns]; rvar = [bn.running_var for bn in bns]
         eps = float(bns[0].eps)
         momentum = bns[0].momentum
-        for bn in bns:
-            if bn.track_running_stats and bn.num_batches_tracked is not None:
-                bn.num_batches_tracked.add_(1)
+        ctrs = [bn.num_batches_tracked for bn in bns if bn.track_running_stats and bn.num_batches_tracked is not None]
+        if ctrs:
+            torch._foreach_add_(ctrs, 1)                          # one launch for the three counters (54 -> 18 launches per SLaK-T step)
         if momentum is None:                                     # cumulative moving average, as nn.BatchNorm
             momentum = 1.0 / float(bns[0].num_batches_tracked.item())
         ws, nb = _workspace(L.slak_bn3_workspace_bytes(N, C), dev)
@@ -474,12 +474,42 @@ def _refresh_lowp():
 _SPLITK_ROWS = int(_os.environ.get("SLAK_SPLITK_ROWS", "6272"))     # rows per split of the weight-gradient GEMMs (0: one plain GEMM)
 
 
+use_skinny_linear = os.environ.get("SLAK_SKINNY_LINEAR", "1") != "0"      # A/B switch: 0 = every pointwise conv through the library GEMM
+
+
+def linear_nt(x, wt, bias=None, gelu=False):
+    """y = x @ wt.T (+ bias) for bf16 x (..., K), wt (N, K), bias (N,) through slak_linear_nt (the streaming kernels for the skinny
+    shapes of the large maps); with gelu=True returns (y, gelu(y)).  None when the shape is not covered (the caller runs the library GEMM)."""
+    if not (use_skinny_linear and x.is_cuda and x.dtype == torch.bfloat16 and wt.dtype == torch.bfloat16 and x.is_contiguous() and wt.is_contiguous()):
+        return None
+    K = x.shape[-1]
+    N = wt.shape[0]
+    M = x.numel() // K
+    L = _lib.lib()
+    if wt.shape[1] != K or not L.slak_linear_nt_supported(M, N, K, 1 if gelu else 0):
+        return None
+    if bias is not None and (bias.dtype != torch.bfloat16 or not bias.is_contiguous()):
+        return None
+    y = torch.empty(x.shape[:-1] + (N,), dtype=torch.bfloat16, device=x.device)
+    g = torch.empty_like(y) if gelu else None
+    with torch.cuda.device(x.device):
+        _lib.check(L.slak_linear_nt(x.data_ptr(), wt.data_ptr(), bias.data_ptr() if bias is not None else None, y.data_ptr(),
+                                    g.data_ptr() if gelu else None, M, N, K, _stream(x.device)), "slak_linear_nt")
+    return (y, g) if gelu else y
+
+
 def _mlp_fwd(t, w1, b1, w2, b2):
     F = torch.nn.functional
     w1b, w2b = lowp_param(w1), lowp_param(w2)
-    y1 = F.linear(t, w1b, lowp_param(b1))
-    a = F.gelu(y1)
-    z = F.linear(a, w2b, lowp_param(b2))
+    r = linear_nt(t, w1b, lowp_param(b1), gelu=True)            # pwconv1 + GELU in one streaming pass on the large maps
+    if r is not None:
+        y1, a = r
+    else:
+        y1 = F.linear(t, w1b, lowp_param(b1))
+        a = F.gelu(y1)
+    z = linear_nt(a, w2b, lowp_param(b2))
+    if z is None:
+        z = F.linear(a, w2b, lowp_param(b2))
     return z, (t, w1b, y1, a, w2b)
 
 
@@ -501,7 +531,9 @@ def _mlp_bwd(saved, dz, db2=None):
     dw2 = wgrad(dz2, a2)
     if db2 is None:
         db2 = dz2.sum(0, dtype=torch.float32)
-    dact = torch.mm(dz2, w2b)
+    dact = linear_nt(dz2.contiguous(), w2b.t().contiguous())     # dz @ W2: NT against the (small) transposed weight
+    if dact is None:
+        dact = torch.mm(dz2, w2b)
     dy1 = torch.empty_like(dact)
     db1 = torch.empty(dact.shape[1], dtype=torch.float32, device=dact.device)
     L = _lib.lib()
@@ -510,7 +542,8 @@ def _mlp_bwd(saved, dz, db2=None):
         _lib.check(L.slak_gelu_backward_bias(dact.data_ptr(), y12.data_ptr(), dy1.data_ptr(), db1.data_ptr(), M, dact.shape[1],
                                              ws.data_ptr() if ws is not None else None, nb, _stream(dact.device)), "slak_gelu_backward_bias")
     dw1 = wgrad(dy1, t2)
-    dt = torch.mm(dy1, w1b).view_as(t)
+    dt = linear_nt(dy1, w1b.t().contiguous())
+    dt = (dt if dt is not None else torch.mm(dy1, w1b)).view_as(t)
     return dt, dw1, db1, dw2, db2
 
 

@@ -1,0 +1,67 @@
+"""slak_linear_nt (csrc/linear_skinny.hip): the pointwise convolutions of the large maps as streaming kernels.  Checker: the same
+product evaluated in fp64 on the bf16 operands (torch CPU), the result rounded once -- half an ulp of bf16 plus fp32 accumulation
+noise; GELU = nn.GELU() (exact erf) of the ROUNDED pre-activation, as F.gelu of a bf16 tensor computes it."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("M,N,K,gelu", [(401, 384, 96, True), (3136, 384, 96, True), (100, 768, 192, True), (257, 96, 384, False),
+                                        (1000, 192, 768, False), (97, 384, 96, False), (33, 768, 192, False), (64, 96, 96, False),
+                                        (31, 192, 192, True), (129, 64, 96, False)])
+@pytest.mark.parametrize("with_bias", [True, False])
+def test_linear_nt_matches_fp64_product(M, N, K, gelu, with_bias, gpu):
+    from slak_amd import block_ops
+    torch.manual_seed(M + N)
+    x = torch.randn(M, K, device=gpu).bfloat16()
+    wt = (torch.randn(N, K, device=gpu) * 0.1).bfloat16()
+    bias = torch.randn(N, device=gpu).bfloat16() if with_bias else None
+    r = block_ops.linear_nt(x, wt, bias, gelu=gelu)
+    assert r is not None, "shape must be covered"
+    y = r[0] if gelu else r
+    ref = x.double().cpu() @ wt.double().cpu().t()
+    if with_bias:
+        ref = ref + bias.double().cpu()
+    err = (y.double().cpu() - ref).abs()
+    bound = 2.0 ** -8 * ref.abs() + 1e-5 * max(1.0, ref.abs().max().item())
+    assert (err <= bound).all(), float((err - bound).max())
+    if gelu:
+        want = torch.nn.functional.gelu(y.float()).to(torch.bfloat16)          # gelu of the rounded pre-activation, rounded once
+        d = (r[1].float() - want.float()).abs()
+        assert (d <= 2.0 ** -7 * want.float().abs() + 1e-6).all(), d.max().item()      # at most one bf16 ulp (erf implementations differ in the last bit)
+        assert (d == 0).float().mean().item() > 0.98
+
+
+def test_linear_nt_declines_what_it_does_not_cover(gpu):
+    from slak_amd import block_ops
+    x = torch.randn(64, 384, device=gpu).bfloat16()
+    assert block_ops.linear_nt(x, torch.randn(1536, 384, device=gpu).bfloat16()) is None        # stage-3 shape: library GEMM
+    assert block_ops.linear_nt(x.float(), torch.randn(96, 384, device=gpu)) is None
+
+
+def test_mlp_with_skinny_linears_matches_library_path(gpu):
+    """The block MLP through the streaming kernels vs the same autograd node through the library GEMMs: forward and every gradient
+    within bf16 rounding of each other."""
+    from slak_amd import block_ops
+    torch.manual_seed(3)
+    C, M = 96, 2 * 56 * 56
+    t = torch.randn(M, C, device=gpu).bfloat16()
+    w1 = (torch.randn(4 * C, C, device=gpu) * 0.05).requires_grad_(True); b1 = torch.randn(4 * C, device=gpu).requires_grad_(True)
+    w2 = (torch.randn(C, 4 * C, device=gpu) * 0.05).requires_grad_(True); b2 = torch.randn(C, device=gpu).requires_grad_(True)
+    dz = torch.randn(M, C, device=gpu).bfloat16()
+    res = {}
+    for mode in (True, False):
+        block_ops.use_skinny_linear = mode
+        try:
+            ti = t.clone().requires_grad_(True)
+            for p in (w1, b1, w2, b2):
+                p.grad = None
+            z = block_ops.mlp_splitk(ti, w1, b1, w2, b2)
+            z.backward(dz)
+            res[mode] = [z.detach().float(), ti.grad.float(), w1.grad.clone(), b1.grad.clone(), w2.grad.clone(), b2.grad.clone()]
+        finally:
+            block_ops.use_skinny_linear = True
+    for a, b, n in zip(res[True], res[False], ("z", "dt", "dw1", "db1", "dw2", "db2")):
+        scale = max(1.0, b.abs().max().item())
+        assert (a - b).abs().max().item() <= 2e-2 * scale, n

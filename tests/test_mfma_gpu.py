@@ -261,3 +261,31 @@ def test_weight_gradient_same_shape_on_two_streams_concurrently(N, C, H, W, kh, 
     for i in range(2):
         for g in got[i]:
             assert torch.equal(g, want[i])
+
+
+def test_full_size_properties_on_slak_b_and_odd_width_channel_counts(mfma_only, gpu):
+    """BASELINE configs[3] (SLaK-B: C = 128 / 256 / 512 / 1024) and the width-1.3 channel counts of the reference's
+    --width_factor 1.3 recipes (124 / 249 / 499 / 998: not multiples of the 4-channel workgroups) at the per-GPU batch of the
+    configuration: identity filter, adjoint identity <y, dy> = <x, dx> = <w, dw>, and 9 sampled planes against the oracle."""
+    ops = _ops()
+    torch.manual_seed(8)
+    cases = [(64, 128, 56, 56, 51, 5), (64, 256, 28, 28, 5, 49), (64, 512, 14, 14, 47, 5), (64, 1024, 7, 7, 5, 13),
+             (32, 124, 56, 56, 5, 51), (32, 249, 28, 28, 49, 5), (32, 499, 14, 14, 5, 47), (32, 998, 7, 7, 13, 5)]
+    for (N, C, H, W, kh, kw) in cases:
+        x = torch.randn(N, C, H, W, device=gpu).bfloat16()
+        dy = torch.randn(N, C, H, W, device=gpu).bfloat16()
+        w = (torch.randn(C, 1, kh, kw, device=gpu) * 0.02).bfloat16().float()
+        wi = torch.zeros_like(w); wi[:, 0, kh // 2, kw // 2] = 1
+        assert torch.equal(ops.dwconv2d_forward(x, wi), x)
+        y, dx, dw = ops.dwconv2d_forward(x, w), ops.dwconv2d_backward_data(dy, w), ops.dwconv2d_backward_filter(dy, x, w)
+        a = (y.double() * dy.double()).sum().item()
+        b = (dx.double() * x.double()).sum().item()
+        c = (dw.double() * w.double()).sum().item()
+        norm = (y.double().norm() * dy.double().norm()).item()
+        assert abs(a - b) <= 2e-3 * norm and abs(a - c) <= 2e-3 * norm, ((N, C, H, W, kh, kw), a, b, c, norm)
+        g = torch.Generator().manual_seed(C)
+        for _ in range(9):
+            n, ch = int(torch.randint(0, N, (1,), generator=g)), int(torch.randint(0, C, (1,), generator=g))
+            ref = oracle.dwconv2d_fwd(x[n:n + 1, ch:ch + 1].float().cpu().numpy(), w[ch:ch + 1].cpu().numpy())
+            got = y[n, ch].double().cpu().numpy()
+            assert np.abs(got - ref[0, 0]).max() <= LOWP_TOL * max(1.0, np.abs(ref).max())
