@@ -474,7 +474,15 @@ def _refresh_lowp():
 _SPLITK_ROWS = int(_os.environ.get("SLAK_SPLITK_ROWS", "6272"))     # rows per split of the weight-gradient GEMMs (0: one plain GEMM)
 
 
-use_skinny_linear = os.environ.get("SLAK_SKINNY_LINEAR", "1") != "0"      # A/B switch: 0 = every pointwise conv through the library GEMM
+use_skinny_linear = os.environ.get("SLAK_SKINNY_LINEAR", "1") != "0"      # the streaming kernels of csrc/linear_skinny.hip for the stage-1 pointwise convs (-0.16 ms per SLaK-T step same-box vs the TUNED library GEMMs); 0: library GEMMs everywhere
+
+
+def linear_nt_covers(x, N, gelu=False):
+    """Whether slak_linear_nt takes x (..., K) bf16 against a weight with N output features."""
+    if not (use_skinny_linear and x.is_cuda and x.dtype == torch.bfloat16 and x.is_contiguous()):
+        return False
+    K = x.shape[-1]
+    return bool(_lib.lib().slak_linear_nt_supported(x.numel() // K, N, K, 1 if gelu else 0))
 
 
 def linear_nt(x, wt, bias=None, gelu=False):
@@ -531,7 +539,9 @@ def _mlp_bwd(saved, dz, db2=None):
     dw2 = wgrad(dz2, a2)
     if db2 is None:
         db2 = dz2.sum(0, dtype=torch.float32)
-    dact = linear_nt(dz2.contiguous(), w2b.t().contiguous())     # dz @ W2: NT against the (small) transposed weight
+    dact = None
+    if linear_nt_covers(dz2, w2b.shape[1]):
+        dact = linear_nt(dz2, w2b.t().contiguous())              # dz @ W2: NT against the (small) transposed weight
     if dact is None:
         dact = torch.mm(dz2, w2b)
     dy1 = torch.empty_like(dact)
@@ -542,7 +552,7 @@ def _mlp_bwd(saved, dz, db2=None):
         _lib.check(L.slak_gelu_backward_bias(dact.data_ptr(), y12.data_ptr(), dy1.data_ptr(), db1.data_ptr(), M, dact.shape[1],
                                              ws.data_ptr() if ws is not None else None, nb, _stream(dact.device)), "slak_gelu_backward_bias")
     dw1 = wgrad(dy1, t2)
-    dt = linear_nt(dy1, w1b.t().contiguous())
+    dt = linear_nt(dy1, w1b.t().contiguous()) if linear_nt_covers(dy1, w1b.shape[1]) else None
     dt = (dt if dt is not None else torch.mm(dy1, w1b)).view_as(t)
     return dt, dw1, db1, dw2, db2
 

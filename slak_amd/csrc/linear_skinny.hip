@@ -1,29 +1,48 @@
-// slak_amd/csrc/linear_skinny.hip -- the pointwise (1x1) convolutions of a SLaK block on the LARGE maps, where they are not GEMMs in
-// any compute sense: pwconv1 / pwconv2 (models/SLaK.py:158-160) and their data gradients at stage 1-2 multiply a 401,408 x 96
-// (100,352 x 192) activation matrix by a 74 KB (295 KB) weight: 2-12 flop per byte moved, pure HBM streaming.  hipBLASLt's tiles run
-// them at 1.8-2.9 TB/s (tools/time_gemm.py); these kernels stream at the rate of a copy.
+// slak_amd/csrc/linear_skinny.hip -- the pointwise (1x1) convolutions of a SLaK block on the LARGEST map, where they are not GEMMs in
+// any compute sense: pwconv1 / pwconv2 (models/SLaK.py:158-160) and their data gradients at stage 1 of SLaK-T multiply a
+// 401,408 x 96 (x 384) activation matrix by a 74 KB weight: 2-12 flop per byte moved, pure HBM streaming.  hipBLASLt's tiles run them
+// at 1.8-2.8 TB/s (tools/time_gemm.py).
 //
 //   Y[M x N] = X[M x K] . Wt[N x K]^T (+ bias[N]),  optionally  G = gelu(Y)  written alongside (nn.GELU(), exact erf form, evaluated
 //   on the ROUNDED y as autocast does: F.gelu of a bf16 tensor)
 //
-// X, Wt, bias, Y, G bf16, fp32 accumulate.  "NT": both operands K-contiguous, so an MFMA fragment (one row, 8 consecutive k) is one
-// 16-byte load straight from global memory into the operand registers -- no LDS, no barrier; a wave owns 32 rows of X and nothing
-// else, the weight comes from L2 (every wave reads the same few hundred KB).  The operands are swapped (D^T = Wt-tile x X-tile^T) so
-// that a lane holds 4 consecutive output columns of ONE row; two v_permlane32_swap per register pair turn that into 8 consecutive
-// columns = one 16-byte store (row-per-lane 8-byte stores are issue-bound at ~7 B/clk/CU: MI355X_MICROARCH.md, store tail).
-//   * linear_nt_smallk<KS>: K = 16 KS <= 192.  The wave's X fragments stay in registers; it walks the N/32 column tiles.
-//   * linear_nt_smalln<NT>: N = 32 NT <= 192, K a multiple of 16.  NT accumulators; the wave walks K.
+// X, Wt, bias, Y, G bf16, fp32 accumulate, "NT" (both operands K-contiguous).  One persistent 8-wave workgroup per CU:
+//   * the whole weight sits in LDS (74 KB, rows padded to an odd number of 16-byte chunks: row-per-lane ds_read_b128 fragments are
+//     then bank-conflict free), staged once;
+//   * a wave owns 32 rows of X at a time.  Their 96-column block is one LDS-DMA burst (`buffer_load_dwordx4 ... lds`; the padded pitch
+//     is made on the source side: destination chunk q takes source chunk (q / 13) * ld + q % 13, pad chunks are skipped lanes), the
+//     six operand fragments are read into registers, and the NEXT block's DMA is issued right away into the same buffer -- the
+//     registers are the second buffer.  No workgroup barrier after the prologue.
+//   * operands swapped (D^T = Wt-tile x X-tile^T) so that a lane holds 4 consecutive output columns of ONE row; two
+//     v_permlane32_swap per register pair turn that into 8 consecutive columns = one 16-byte store (row-per-lane 8-byte stores are
+//     issue-bound at ~7 B/clk/CU: MI355X_MICROARCH.md, store tail).
+//   (A first version read the fragments straight from global memory, 16 bytes per lane at a 192-byte stride: address-coalescer bound,
+//   no faster than the library.)
+//   linear_nt_k96:  K = 96,  N = 32 NT <= 384  (pwconv1 forward [+ GELU], dz . W2):   walks the N/32 column tiles per row block
+//   linear_nt_n96:  N = 96,  K = 96 NKC <= 384 (pwconv2 forward, dy1 . W1):           three accumulators, walks K in 96-column blocks
 #include "mfma_common.h"
 
 namespace slak {
 
-__device__ __forceinline__ float gelu_erf(float y) { return 0.5f * y * (1.0f + erff(y * 0.70710678118654752440f)); }
+constexpr int LS_WAVES = 8, LS_THREADS = LS_WAVES * 64;
+constexpr int LS_XP = 208;                       // pitch (bytes) of a 96-column block in LDS: 13 chunks
+constexpr int LS_XBUF = 32 * LS_XP;              // one wave's X block: 6,656 B
 
+// nn.GELU() (exact erf form) with erf by Abramowitz-Stegun 7.1.26 (|err| < 1.5e-7 absolute, far below the bf16 rounding of the result;
+// the same evaluation as the backward kernel of block_tail.hip): one exp, one rcp, and the lower tail without cancellation
+// (Phi(x) = poly e / 2 for x < 0).  ocml's erff costs 2-3x as many VALU instructions: the fused pwconv1 kernel was VALU-bound on it.
+__device__ __forceinline__ float gelu_erf(float x) {
+    const float e = __expf(-0.5f * x * x);
+    const float t = __frcp_rn(1.0f + 0.3275911f * (fabsf(x) * 0.70710678118654752f));
+    const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+    const float half = 0.5f * poly * e;
+    return x * (x >= 0.f ? 1.0f - half : half);
+}
 __device__ __forceinline__ float bf16_lo(unsigned v) { return __uint_as_float(v << 16); }
 __device__ __forceinline__ float bf16_hi(unsigned v) { return __uint_as_float(v & 0xffff0000u); }
 
-// One 32 x 32 output tile in registers (lane = row l31, acc[4q + j] = column 8q + 4 lhi + j) -> bias, rounding, optional GELU,
-// 16-byte stores.  `bq[q]` = the lane's four bias values of quad q as two packed dwords are fetched by the caller.
+// One 32 x 32 output tile in registers (lane = row l31, acc[4q + j] = column col0 + 8q + 4 lhi + j) -> bias, rounding, optional GELU,
+// 16-byte stores.
 template <bool GELU>
 __device__ __forceinline__ void store_tile(const f32x16& acc, const uint16_t* __restrict__ bias, uint16_t* __restrict__ Y,
                                            uint16_t* __restrict__ G, size_t row_off, int col0, int lhi, bool row_ok) {
@@ -46,15 +65,12 @@ __device__ __forceinline__ void store_tile(const f32x16& acc, const uint16_t* __
     }
     // lanes l31 (lhi 0) and l31 + 32 (lhi 1) hold the same row: quads (0,1) -> lhi 0 keeps columns 0..7, lhi 1 gets 8..15; quads (2,3)
     // likewise 16..23 / 24..31.  v_permlane32_swap(a, b): a of lanes 32..63 <-> b of lanes 0..31.
-    auto swap = [](unsigned& a, unsigned& b) {
-        asm volatile("v_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
-    };
+    auto swap = [](unsigned& a, unsigned& b) { asm volatile("v_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b)); };
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         swap(py[4 * h + 0], py[4 * h + 2]); swap(py[4 * h + 1], py[4 * h + 3]);
         if constexpr (GELU) { swap(pg[4 * h + 0], pg[4 * h + 2]); swap(pg[4 * h + 1], pg[4 * h + 3]); }
     }
-    // after the swaps: lanes lhi 0: {py[4h], py[4h+1], py[4h+2], py[4h+3]} = columns 16h + 0..7; lanes lhi 1: columns 16h + 8..15
     if (row_ok) {
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
@@ -65,77 +81,201 @@ __device__ __forceinline__ void store_tile(const f32x16& acc, const uint16_t* __
     }
 }
 
-template <int KS, bool GELU>
-__global__ __launch_bounds__(256) void linear_nt_smallk_kernel(const uint16_t* __restrict__ X, const uint16_t* __restrict__ Wt,
-                                                               const uint16_t* __restrict__ bias, uint16_t* __restrict__ Y,
-                                                               uint16_t* __restrict__ G, int M, int N) {
-    constexpr int K = 16 * KS;
-    const int lane = threadIdx.x & 63, l31 = lane & 31, lhi = lane >> 5;
-    const int wave = wave_id_uniform();
-    const int r0 = (blockIdx.x * 4 + wave) * 32;
-    if (r0 >= M) return;
-    const int row = r0 + l31;
-    const bool row_ok = row < M;
-    const uint16_t* xr = X + (size_t)(row_ok ? row : M - 1) * K + lhi * 8;
-    s16x8 xf[KS];
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) xf[ks] = __builtin_bit_cast(s16x8, *(const u32x4*)(xr + ks * 16));
-    const uint16_t* wl = Wt + (size_t)l31 * K + lhi * 8;
-    const size_t row_off = (size_t)row * N;
-    const int ntiles = N >> 5;
-    s16x8 wf[KS];
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) wf[ks] = __builtin_bit_cast(s16x8, *(const u32x4*)(wl + ks * 16));
-    for (int nt = 0; nt < ntiles; ++nt) {
-        f32x16 acc;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-        const uint16_t* wn = wl + (size_t)(nt + 1 < ntiles ? nt + 1 : nt) * 32 * K;     // next tile's fragments stream in behind the MFMAs
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            acc = mfma32<bf16_t>(wf[ks], xf[ks], acc);
-            wf[ks] = __builtin_bit_cast(s16x8, *(const u32x4*)(wn + ks * 16));
-        }
-        store_tile<GELU>(acc, bias, Y, G, row_off, nt * 32, lhi, row_ok);
+// Stage Wt [N][K] (row-major, K*2 bytes per row) into LDS rows of pitch WP bytes.
+__device__ __forceinline__ void stage_weight(char* Lw, const uint16_t* __restrict__ Wt, int N, int K, int WP, int tid, int nthreads) {
+    const int cpr = K >> 3, total = N * cpr;                          // 16-byte chunks per row
+    for (int q = tid; q < total; q += nthreads) {
+        const int r = q / cpr, cc = q - r * cpr;
+        *(u32x4*)(Lw + (size_t)r * WP + cc * 16) = *(const u32x4*)(Wt + (size_t)r * K + cc * 8);
     }
 }
 
-template <int NT>
-__global__ __launch_bounds__(256) void linear_nt_smalln_kernel(const uint16_t* __restrict__ X, const uint16_t* __restrict__ Wt,
-                                                               const uint16_t* __restrict__ bias, uint16_t* __restrict__ Y,
-                                                               int M, int K) {
-    constexpr int N = 32 * NT;
-    const int lane = threadIdx.x & 63, l31 = lane & 31, lhi = lane >> 5;
-    const int wave = wave_id_uniform();
-    const int r0 = (blockIdx.x * 4 + wave) * 32;
-    if (r0 >= M) return;
-    const int row = r0 + l31;
-    const bool row_ok = row < M;
-    const uint16_t* xr = X + (size_t)(row_ok ? row : M - 1) * K + lhi * 8;
-    const uint16_t* wl = Wt + (size_t)l31 * K + lhi * 8;
-    f32x16 acc[NT];
+// DMA of one 32-row x 96-column block of X (row stride ldx elements, starting at element column kc0) into a wave's LDS buffer:
+// destination chunk q = 64 k + lane -> (row q / 13, chunk q % 13); 7 instructions cover the 416 chunks.  Rows >= M are skipped.
+struct XDma {
+    unsigned src[7];                 // source byte offset relative to the block's first element, 0xffffffff = skip
+    int row[7];
+};
+__device__ __forceinline__ void xdma_plan(XDma& d, int lane, unsigned ldx_bytes) {
 #pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
-    const int nks = K >> 4;
-    s16x8 xf = __builtin_bit_cast(s16x8, *(const u32x4*)xr);
-    s16x8 wf[NT];
-#pragma unroll
-    for (int t = 0; t < NT; ++t) wf[t] = __builtin_bit_cast(s16x8, *(const u32x4*)(wl + (size_t)t * 32 * K));
-    for (int ks = 0; ks < nks; ++ks) {
-        const int kn = (ks + 1 < nks ? ks + 1 : ks) * 16;                               // next k-step's fragments stream in behind the MFMAs
-        const s16x8 xn = __builtin_bit_cast(s16x8, *(const u32x4*)(xr + kn));
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            acc[t] = mfma32<bf16_t>(wf[t], xf, acc[t]);
-            wf[t] = __builtin_bit_cast(s16x8, *(const u32x4*)(wl + (size_t)t * 32 * K + kn));
-        }
-        xf = xn;
+    for (int k = 0; k < 7; ++k) {
+        const int q = 64 * k + lane, r = q / 13, cc = q - r * 13;
+        const bool ok = r < 32 && cc < 12;
+        d.src[k] = ok ? (unsigned)r * ldx_bytes + (unsigned)cc * 16u : 0xffffffffu;
+        d.row[k] = r;
     }
-    const size_t row_off = (size_t)row * N;
+}
+__device__ __forceinline__ void xdma_issue(const XDma& d, unsigned base_off, int rows_valid, v4i_t rsrc, unsigned lds_dst) {
 #pragma unroll
-    for (int t = 0; t < NT; ++t) store_tile<false>(acc[t], bias, Y, nullptr, row_off, t * 32, lhi, row_ok);
+    for (int k = 0; k < 7; ++k)
+        if (d.src[k] != 0xffffffffu && d.row[k] < rows_valid) lds_dma16(base_off + d.src[k], rsrc, __builtin_amdgcn_readfirstlane(lds_dst + k * 1024));
+}
+
+constexpr int LK_WAVES = 6, LK_THREADS = LK_WAVES * 64;          // k96: the weight (80 KB) + per-wave X block and out tile leave room for six waves
+constexpr int LK_OP = 144;                                         // pitch (bytes) of a wave's 32 x 64 out tile: 128 + 16
+constexpr int LK_OBUF = 32 * LK_OP;
+
+// packed results of one 32 x 32 tile -> the wave's out tile (columns half*32 ..), 8 bytes per quad
+__device__ __forceinline__ void put_tile(char* ot, const unsigned (&p)[8], int l31, int lhi, int half) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) *(u32x2*)(ot + l31 * LK_OP + half * 64 + (8 * q + 4 * lhi) * 2) = u32x2{p[2 * q], p[2 * q + 1]};
+}
+// the out tile (32 rows x 128 bytes) -> HBM: lane = (row lane/8, 16-byte chunk lane%8): eight FULL 128-byte lines per store instruction
+// (row-per-lane 16-byte stores wrote 32 bytes per row and instruction: 2.6 TB/s, what the library's epilogue reaches too)
+__device__ __forceinline__ void flush_tile(const char* ot, uint16_t* __restrict__ dst, int tm, int M, int N, int col0, int lane) {
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int r = it * 8 + (lane >> 3), c = lane & 7;
+        const u32x4 v = *(const u32x4*)(ot + r * LK_OP + c * 16);
+        const int row = tm * 32 + r;
+        if (row < M) *(u32x4*)(dst + (size_t)row * N + col0 + c * 8) = v;
+    }
+}
+
+template <bool GELU>
+__global__ __launch_bounds__(LK_THREADS, 1) void linear_nt_k96_kernel(const uint16_t* __restrict__ X, const uint16_t* __restrict__ Wt,
+                                                                    const uint16_t* __restrict__ bias, uint16_t* __restrict__ Y,
+                                                                    uint16_t* __restrict__ G, int M, int N, unsigned x_bytes) {
+    constexpr int K = 96, KS = 6;
+    extern __shared__ __attribute__((aligned(16))) uint16_t lds[];
+    char* const L = (char*)lds;
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, lhi = lane >> 5;
+    const int wave = wave_id_uniform();
+    char* const Lw = L;                                               // [N][LS_XP]
+    const unsigned bias_b = (unsigned)N * LS_XP;                      // [N] bf16 (1 KB): bias reads must not touch vmcnt
+    const unsigned xbuf = bias_b + 1024u + (unsigned)wave * LS_XBUF;
+    char* const ot = L + bias_b + 1024u + LK_WAVES * LS_XBUF + wave * LK_OBUF;
+    const unsigned lds_base = (unsigned)(uintptr_t)SLAK_LDS(uint16_t, lds);
+    v4i_t rsrc;
+    {
+        const uint64_t a = (uint64_t)X;
+        rsrc[0] = __builtin_amdgcn_readfirstlane((int)(a & 0xffffffffu)); rsrc[1] = __builtin_amdgcn_readfirstlane((int)((a >> 32) & 0xffffu));
+        rsrc[2] = __builtin_amdgcn_readfirstlane((int)x_bytes); rsrc[3] = 0x00020000;
+    }
+    XDma plan; xdma_plan(plan, lane, K * 2);
+    const int ntiles_m = (M + 31) >> 5, stride = gridDim.x * LK_WAVES;
+    int tm = blockIdx.x * LK_WAVES + wave;
+    if (tm < ntiles_m) xdma_issue(plan, (unsigned)tm * 32u * K * 2u, M - tm * 32, rsrc, lds_base + xbuf);
+    stage_weight(Lw, Wt, N, K, LS_XP, tid, LK_THREADS);
+    for (int i = tid; i < N; i += LK_THREADS) ((uint16_t*)(L + bias_b))[i] = bias ? bias[i] : (uint16_t)0;
+    __syncthreads();                                                  // the only workgroup barrier
+    const uint16_t* const lbias = (const uint16_t*)(L + bias_b);
+    const int npairs = N >> 6;                                        // column tiles are flushed in pairs (64 columns = one 128-byte line per row)
+    const int nst = npairs * 4 * (GELU ? 2 : 1);                      // store instructions of one row block (all issued: every block has a valid row)
+    int pending = 0;
+    const unsigned wlane = (unsigned)l31 * LS_XP + (unsigned)lhi * 16u;
+    auto lsync = [] { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); };
+    for (; tm < ntiles_m; tm += stride) {
+        wait_vmcnt_dyn(pending);                                      // my block has landed: only the stores issued after its DMA may be outstanding
+        __builtin_amdgcn_wave_barrier();
+        s16x8 xf[KS];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) xf[ks] = __builtin_bit_cast(s16x8, *(const u32x4*)(L + xbuf + wlane + ks * 32));
+        lsync();                                                      // every lane has its fragments: the buffer is free
+        pending = nst;
+        const int tn = tm + stride;
+        if (tn < ntiles_m) xdma_issue(plan, (unsigned)tn * 32u * K * 2u, M - tn * 32, rsrc, lds_base + xbuf);
+        for (int pr = 0; pr < npairs; ++pr) {
+            unsigned py[2][8], pg[2][8];
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const int nt = 2 * pr + half;
+                f32x16 acc;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+                const char* wt = Lw + (size_t)nt * 32 * LS_XP + wlane;
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) acc = mfma32<bf16_t>(__builtin_bit_cast(s16x8, *(const u32x4*)(wt + ks * 32)), xf[ks], acc);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const u32x2 bb = *(const u32x2*)(lbias + nt * 32 + 8 * q + 4 * lhi);
+                    const unsigned y01 = pack2<bf16_t>(acc[4 * q + 0] + bf16_lo(bb[0]), acc[4 * q + 1] + bf16_hi(bb[0]));
+                    const unsigned y23 = pack2<bf16_t>(acc[4 * q + 2] + bf16_lo(bb[1]), acc[4 * q + 3] + bf16_hi(bb[1]));
+                    py[half][2 * q] = y01; py[half][2 * q + 1] = y23;
+                    if constexpr (GELU) {
+                        pg[half][2 * q] = pack2<bf16_t>(gelu_erf(bf16_lo(y01)), gelu_erf(bf16_hi(y01)));
+                        pg[half][2 * q + 1] = pack2<bf16_t>(gelu_erf(bf16_lo(y23)), gelu_erf(bf16_hi(y23)));
+                    }
+                }
+            }
+            put_tile(ot, py[0], l31, lhi, 0); put_tile(ot, py[1], l31, lhi, 1);
+            lsync();
+            flush_tile(ot, Y, tm, M, N, pr * 64, lane);
+            if constexpr (GELU) {
+                lsync();                                              // the tile has been read
+                put_tile(ot, pg[0], l31, lhi, 0); put_tile(ot, pg[1], l31, lhi, 1);
+                lsync();
+                flush_tile(ot, G, tm, M, N, pr * 64, lane);
+            }
+            lsync();
+        }
+    }
+}
+
+template <int NKC>                 // K = 96 NKC
+__global__ __launch_bounds__(LS_THREADS, 1) void linear_nt_n96_kernel(const uint16_t* __restrict__ X, const uint16_t* __restrict__ Wt,
+                                                                    const uint16_t* __restrict__ bias, uint16_t* __restrict__ Y,
+                                                                    int M, unsigned x_bytes) {
+    constexpr int N = 96, NT = 3, K = 96 * NKC, KS = 6, WP = K * 2 + 16;
+    extern __shared__ __attribute__((aligned(16))) uint16_t lds[];
+    char* const L = (char*)lds;
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, lhi = lane >> 5;
+    const int wave = wave_id_uniform();
+    char* const Lw = L;                                               // [96][WP]
+    const unsigned bias_b = (unsigned)N * WP;
+    const unsigned xbuf = bias_b + 1024u + (unsigned)wave * LS_XBUF;
+    const unsigned lds_base = (unsigned)(uintptr_t)SLAK_LDS(uint16_t, lds);
+    v4i_t rsrc;
+    {
+        const uint64_t a = (uint64_t)X;
+        rsrc[0] = __builtin_amdgcn_readfirstlane((int)(a & 0xffffffffu)); rsrc[1] = __builtin_amdgcn_readfirstlane((int)((a >> 32) & 0xffffu));
+        rsrc[2] = __builtin_amdgcn_readfirstlane((int)x_bytes); rsrc[3] = 0x00020000;
+    }
+    XDma plan; xdma_plan(plan, lane, K * 2);
+    const int ntiles_m = (M + 31) >> 5, stride = gridDim.x * LS_WAVES;
+    int tm = blockIdx.x * LS_WAVES + wave;
+    if (tm < ntiles_m) xdma_issue(plan, (unsigned)tm * 32u * K * 2u, M - tm * 32, rsrc, lds_base + xbuf);
+    stage_weight(Lw, Wt, N, K, WP, tid, LS_THREADS);
+    for (int i = tid; i < N; i += LS_THREADS) ((uint16_t*)(L + bias_b))[i] = bias ? bias[i] : (uint16_t)0;
+    __syncthreads();
+    const uint16_t* const lbias = (const uint16_t*)(L + bias_b);
+    int pending = 0;
+    const unsigned xlane = (unsigned)l31 * LS_XP + (unsigned)lhi * 16u;
+    const unsigned wlane = (unsigned)l31 * WP + (unsigned)lhi * 16u;
+    for (; tm < ntiles_m; tm += stride) {
+        f32x16 acc[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+#pragma unroll
+        for (int kc = 0; kc < NKC; ++kc) {
+            if (kc == 0) wait_vmcnt_dyn(pending); else wait_vmcnt<0>();   // block kc has landed (kc = 0: the previous rows' 2 NT stores came after its DMA)
+            __builtin_amdgcn_wave_barrier();
+            s16x8 xf[KS];
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) xf[ks] = __builtin_bit_cast(s16x8, *(const u32x4*)(L + xbuf + xlane + ks * 32));
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+            // the next 96-column block of these rows, or the first block of my next rows
+            if (kc + 1 < NKC) xdma_issue(plan, (unsigned)tm * 32u * K * 2u + (unsigned)(kc + 1) * 192u, M - tm * 32, rsrc, lds_base + xbuf);
+            else if (tm + stride < ntiles_m) xdma_issue(plan, (unsigned)(tm + stride) * 32u * K * 2u, M - (tm + stride) * 32, rsrc, lds_base + xbuf);
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const s16x8 wf = __builtin_bit_cast(s16x8, *(const u32x4*)(Lw + (size_t)t * 32 * WP + wlane + kc * 192 + ks * 32));
+                    acc[t] = mfma32<bf16_t>(wf, xf[ks], acc[t]);
+                }
+            }
+        }
+        const int row = tm * 32 + l31;
+        const bool row_ok = row < M;
+        const size_t row_off = (size_t)row * N;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) store_tile<false>(acc[t], lbias, Y, nullptr, row_off, t * 32, lhi, row_ok);
+        pending = 2 * NT;
+    }
 }
 
 }  // namespace slak
@@ -145,31 +285,38 @@ using namespace slak;
 extern "C" {
 
 int slak_linear_nt_supported(int M, int N, int K, int gelu) {
-    if (M <= 0 || N <= 0 || K <= 0 || (long long)M * (N > K ? N : K) >= (1LL << 31)) return 0;
-    if ((K == 96 || K == 192) && N % 32 == 0) return 1;                                   // small K: any N
-    if (!gelu && K % 16 == 0 && (N == 96 || N == 192)) return 1;                          // small N: any K
+    if (M <= 0 || N <= 0 || K <= 0 || (long long)M * (N > K ? N : K) * 2 >= (1LL << 32)) return 0;
+    if (K == 96 && N % 64 == 0 && N <= 384) return 1;                                     // whole weight + six waves' row blocks and out tiles in LDS
+    if (!gelu && N == 96 && (K == 96 || K == 192 || K == 288 || K == 384)) return 1;
     return 0;
 }
 
 int slak_linear_nt(const void* x, const void* wt, const void* bias, void* y, void* gelu_out, int M, int N, int K, void* stream) {
     if (!x || !wt || !y) return SLAK_ERR_INVALID_ARG;
     if (!slak_linear_nt_supported(M, N, K, gelu_out != nullptr)) return SLAK_ERR_UNSUPPORTED;
-    const dim3 grid((unsigned)((M + 127) / 128)), block(256);
     hipStream_t st = (hipStream_t)stream;
     const uint16_t *X = (const uint16_t*)x, *W = (const uint16_t*)wt, *B = (const uint16_t*)bias;
     uint16_t *Y = (uint16_t*)y, *G = (uint16_t*)gelu_out;
-    if (K == 96 || K == 192) {
-        if (K == 96) {
-            if (G) hipLaunchKernelGGL((linear_nt_smallk_kernel<6, true>), grid, block, 0, st, X, W, B, Y, G, M, N);
-            else hipLaunchKernelGGL((linear_nt_smallk_kernel<6, false>), grid, block, 0, st, X, W, B, Y, G, M, N);
+    const int tiles = (M + 31) / 32;
+    int wgs = mfma_cu_count(); if (wgs * LS_WAVES > tiles) wgs = (tiles + LS_WAVES - 1) / LS_WAVES;
+    const unsigned xb = (unsigned)((size_t)M * K * 2);
+    auto set_lds = [](const void* k, size_t lds) { return lds <= 48 * 1024 || hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess; };
+    if (K == 96 && N % 64 == 0) {
+        const size_t lds = (size_t)N * LS_XP + 1024 + (size_t)LK_WAVES * (LS_XBUF + LK_OBUF);
+        int wk = mfma_cu_count(); if (wk * LK_WAVES > tiles) wk = (tiles + LK_WAVES - 1) / LK_WAVES;
+        if (G) {
+            if (!set_lds((const void*)linear_nt_k96_kernel<true>, lds)) return SLAK_ERR_LAUNCH;
+            hipLaunchKernelGGL((linear_nt_k96_kernel<true>), dim3(wk), dim3(LK_THREADS), lds, st, X, W, B, Y, G, M, N, xb);
         } else {
-            if (G) hipLaunchKernelGGL((linear_nt_smallk_kernel<12, true>), grid, block, 0, st, X, W, B, Y, G, M, N);
-            else hipLaunchKernelGGL((linear_nt_smallk_kernel<12, false>), grid, block, 0, st, X, W, B, Y, G, M, N);
+            if (!set_lds((const void*)linear_nt_k96_kernel<false>, lds)) return SLAK_ERR_LAUNCH;
+            hipLaunchKernelGGL((linear_nt_k96_kernel<false>), dim3(wk), dim3(LK_THREADS), lds, st, X, W, B, Y, G, M, N, xb);
         }
-    } else if (N == 96) {
-        hipLaunchKernelGGL((linear_nt_smalln_kernel<3>), grid, block, 0, st, X, W, B, Y, M, K);
     } else {
-        hipLaunchKernelGGL((linear_nt_smalln_kernel<6>), grid, block, 0, st, X, W, B, Y, M, K);
+        const size_t lds = (size_t)96 * (K * 2 + 16) + 1024 + (size_t)LS_WAVES * LS_XBUF;
+#define SLAK_LS_N96(NKC) { if (!set_lds((const void*)linear_nt_n96_kernel<NKC>, lds)) return SLAK_ERR_LAUNCH; \
+                           hipLaunchKernelGGL((linear_nt_n96_kernel<NKC>), dim3(wgs), dim3(LS_THREADS), lds, st, X, W, B, Y, M, xb); }
+        if (K == 96) SLAK_LS_N96(1) else if (K == 192) SLAK_LS_N96(2) else if (K == 288) SLAK_LS_N96(3) else SLAK_LS_N96(4)
+#undef SLAK_LS_N96
     }
     SLAK_LAUNCH_CHECK();
     return SLAK_OK;

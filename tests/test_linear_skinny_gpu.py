@@ -7,12 +7,13 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("M,N,K,gelu", [(401, 384, 96, True), (3136, 384, 96, True), (100, 768, 192, True), (257, 96, 384, False),
-                                        (1000, 192, 768, False), (97, 384, 96, False), (33, 768, 192, False), (64, 96, 96, False),
-                                        (31, 192, 192, True), (129, 64, 96, False)])
+@pytest.mark.parametrize("M,N,K,gelu", [(401, 384, 96, True), (3136, 384, 96, True), (100000, 384, 96, True), (257, 96, 384, False),
+                                        (70001, 96, 384, False), (97, 384, 96, False), (33, 96, 192, False), (64, 96, 96, False),
+                                        (31, 192, 96, True), (129, 64, 96, False), (95, 128, 96, True), (5000, 96, 288, False)])
 @pytest.mark.parametrize("with_bias", [True, False])
 def test_linear_nt_matches_fp64_product(M, N, K, gelu, with_bias, gpu):
     from slak_amd import block_ops
+    block_ops.use_skinny_linear = True
     torch.manual_seed(M + N)
     x = torch.randn(M, K, device=gpu).bfloat16()
     wt = (torch.randn(N, K, device=gpu) * 0.1).bfloat16()
@@ -35,8 +36,10 @@ def test_linear_nt_matches_fp64_product(M, N, K, gelu, with_bias, gpu):
 
 def test_linear_nt_declines_what_it_does_not_cover(gpu):
     from slak_amd import block_ops
+    block_ops.use_skinny_linear = True
     x = torch.randn(64, 384, device=gpu).bfloat16()
     assert block_ops.linear_nt(x, torch.randn(1536, 384, device=gpu).bfloat16()) is None        # stage-3 shape: library GEMM
+    assert block_ops.linear_nt(torch.randn(64, 192, device=gpu).bfloat16(), torch.randn(768, 192, device=gpu).bfloat16()) is None   # stage 2: library GEMM
     assert block_ops.linear_nt(x.float(), torch.randn(96, 384, device=gpu)) is None
 
 

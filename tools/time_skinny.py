@@ -10,7 +10,7 @@ def ev(fn, reps=20):
     for _ in range(reps): fn()
     e1.record(); e1.synchronize()
     return e0.elapsed_time(e1) / reps * 1e3
-for (C, HW) in ((96, 56), (192, 28)):
+for (C, HW) in ((96, 56),):
     M = 128 * HW * HW
     t = torch.randn(M, C, device=dev).bfloat16(); w1 = torch.randn(4 * C, C, device=dev).bfloat16(); b1 = torch.randn(4 * C, device=dev).bfloat16()
     w2 = torch.randn(C, 4 * C, device=dev).bfloat16(); b2 = torch.randn(C, device=dev).bfloat16()
