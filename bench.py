@@ -126,7 +126,7 @@ def hot_path_kernels(device, batch, reps, dtype, stages):
       forward   : one launch per branch -- or ONE launch for the three (`tri`, where slak_dwconv2d_tri_supported == 1);
       bwd_data  : branch 1 plain, branches 2 and 3 ACCUMULATING into the same dx (`+acc`: autograd's adds folded in; 3*S*b bytes:
                   read dy, read dx, write dx) -- or ONE launch for the three;
-      bwd_filter: one launch per branch.
+      bwd_filter: one launch per branch -- or ONE launch for the three (where slak_dwconv2d_tri_filter_workspace_bytes > 0).
     Algorithmic bytes: SURVEY.md 8(d) per op -- 2*S*b (+ C*kh*kw*4); a three-branch launch is priced at the per-op figure of the
     three ops it replaces (3 x 2*S*b), as 8(d) prescribes."""
     from slak_amd import _lib, ops
@@ -150,6 +150,13 @@ def hot_path_kernels(device, batch, reps, dtype, stages):
                             gbs=alg_bytes / ms / 1e6, gflop_nominal=flop / 1e9))
         wbytes = sum(C * kh * kw * 4 for _, (kh, kw) in shapes)
         flops3 = sum(2.0 * S * kh * kw for _, (kh, kw) in shapes)
+        tri_w_nb = int(L.slak_dwconv2d_tri_filter_workspace_bytes(dt, batch, C, HW, HW, K)) if dtype != torch.float32 else 0
+        if tri_w_nb:
+            dws3 = [torch.empty_like(w) for w in wts]
+            ws3 = torch.empty(tri_w_nb, dtype=torch.uint8, device=device)
+            a_tw = (dys[0].data_ptr(), dys[1].data_ptr(), dys[2].data_ptr(), x.data_ptr(), dws3[0].data_ptr(), dws3[1].data_ptr(), dws3[2].data_ptr(),
+                    dt, batch, C, HW, HW, K, ws3.data_ptr(), tri_w_nb, st)
+            add("%dx5+5x%d+5x5" % (K, K), "tri", "bwd_filter", lambda: _lib.check(L.slak_dwconv2d_tri_backward_filter(*a_tw)), 3 * 2 * S * b + wbytes, flops3)
         if tri:
             a_tf = (x.data_ptr(), wts[0].data_ptr(), wts[1].data_ptr(), wts[2].data_ptr(), ys[0].data_ptr(), ys[1].data_ptr(), ys[2].data_ptr(), dt, batch, C, HW, HW, K, st)
             a_td = (dys[0].data_ptr(), dys[1].data_ptr(), dys[2].data_ptr(), wts[0].data_ptr(), wts[1].data_ptr(), wts[2].data_ptr(), ys[0].data_ptr(), dt, batch, C, HW, HW, K, st)
@@ -172,7 +179,8 @@ def hot_path_kernels(device, batch, reps, dtype, stages):
                     add(kn, kname, "bwd_data+acc", lambda: _lib.check(L.slak_dwconv2d_backward_data_accumulate(*a_d)), 3 * S * b + wb, flop)
                 else:
                     add(kn, kname, "bwd_data", lambda: _lib.check(L.slak_dwconv2d_backward_data(*a_d)), 2 * S * b + wb, flop)
-            add(kn, kname, "bwd_filter", lambda: _lib.check(L.slak_dwconv2d_backward_filter(*a_w)), 2 * S * b + wb, flop)
+            if not tri_w_nb:
+                add(kn, kname, "bwd_filter", lambda: _lib.check(L.slak_dwconv2d_backward_filter(*a_w)), 2 * S * b + wb, flop)
             del ws, dw
         del x, dys, ys
     return out

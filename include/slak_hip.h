@@ -143,6 +143,15 @@ int slak_dwconv2d_tri_forward(const void* x, const float* w_v, const float* w_h,
 int slak_dwconv2d_tri_backward_data(const void* dy_v, const void* dy_h, const void* dy_s, const float* w_v, const float* w_h,
                                     const float* w_s, void* dx, int dtype, int N, int C, int H, int W, int K, void* stream);
 
+/* The three weight gradients of a block in one launch (x fetched once; the 5 x K and 5 x 5 branches share their x fragments): dw_v
+ * (C,1,K,5), dw_h (C,1,5,K), dw_s (C,1,5,5), fp32 (backward_filter_fp16.cu:187), bitwise reproducible.  Covered: H <= 14 and W even
+ * 8..14 or 4..7 (the 14x14 and 7x7 stages); slak_dwconv2d_tri_filter_workspace_bytes returns 0 for anything else and the call
+ * SLAK_ERR_UNSUPPORTED (three slak_dwconv2d_backward_filter calls instead). */
+size_t slak_dwconv2d_tri_filter_workspace_bytes(int dtype, int N, int C, int H, int W, int K);
+int slak_dwconv2d_tri_backward_filter(const void* dy_v, const void* dy_h, const void* dy_s, const void* x, float* dw_v, float* dw_h,
+                                      float* dw_s, int dtype, int N, int C, int H, int W, int K,
+                                      void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---------------------------------------------------------------- next row: block tail glue
  * The layout / normalisation / residual steps around the two pointwise GEMMs of a SLaK block
  * (models/SLaK.py:153-166: permute -> LayerNorm -> [pwconv1, GELU, pwconv2] -> gamma -> permute -> shortcut + drop_path),

@@ -121,6 +121,7 @@ class _ScaleResidual(torch.autograd.Function):
 
 
 accumulate_dgrad = os.environ.get("SLAK_DGRAD_ACC", "1") != "0"     # A/B switch: 0 = three plain launches + two tensor adds
+fused_tri_wgrad = os.environ.get("SLAK_TRI_WGRAD", "1") != "0"      # A/B switch: 0 = three weight-gradient launches per block everywhere
 use_big_tri = os.environ.get("SLAK_BIG_TRI", "0") == "1"      # dev switch: take the one-launch kernels of the 56x56 / 28x28 class where they exist
 
 
@@ -181,9 +182,25 @@ class _TriDwConv(torch.autograd.Function):
                 else:
                     dx += ops.dwconv2d_backward_data(dyh, wh)
                     dx += ops.dwconv2d_backward_data(dys, ws)
-        dwv = ops.dwconv2d_backward_filter(dyv, x, wv) if ctx.needs_input_grad[1] else None
-        dwh = ops.dwconv2d_backward_filter(dyh, x, wh) if ctx.needs_input_grad[2] else None
-        dws = ops.dwconv2d_backward_filter(dys, x, ws) if ctx.needs_input_grad[3] else None
+        dwv = dwh = dws = None
+        if all(ctx.needs_input_grad[1:4]) and fused_tri_wgrad and x.dtype in ops._DT:
+            L = _lib.lib()
+            dt = ops._DT[x.dtype]
+            nb = int(L.slak_dwconv2d_tri_filter_workspace_bytes(dt, N, C, H, W, K))
+            if nb:                                               # one launch for the three weight gradients (x fetched once)
+                dwv, dwh, dws = (torch.empty_like(w, dtype=torch.float32) for w in (wv, wh, ws))
+                wsb, nbb = _workspace(nb, x.device)
+                with torch.cuda.device(x.device):
+                    rc = L.slak_dwconv2d_tri_backward_filter(dyv.data_ptr(), dyh.data_ptr(), dys.data_ptr(), x.data_ptr(), dwv.data_ptr(),
+                                                             dwh.data_ptr(), dws.data_ptr(), dt, N, C, H, W, K, wsb.data_ptr(), nbb, _stream(x.device))
+                if rc == _lib.ERR_UNSUPPORTED:
+                    dwv = dwh = dws = None
+                else:
+                    _lib.check(rc, "slak_dwconv2d_tri_backward_filter")
+        if dwv is None:
+            dwv = ops.dwconv2d_backward_filter(dyv, x, wv) if ctx.needs_input_grad[1] else None
+            dwh = ops.dwconv2d_backward_filter(dyh, x, wh) if ctx.needs_input_grad[2] else None
+            dws = ops.dwconv2d_backward_filter(dys, x, ws) if ctx.needs_input_grad[3] else None
         return dx, dwv, dwh, dws
 
 

@@ -1,0 +1,310 @@
+// slak_amd/csrc/dwconv_mfma_small_tri_wgrad.hip -- the weight gradients of the THREE branches of a decomposed large-kernel block
+// (K x 5, 5 x K, 5 x 5 on the same input: models/SLaK.py:82-100) in ONE launch on the small planes (H <= 14; W even 8..14, or
+// 4..7: the 14x14 and 7x7 stages of SLaK), 16-bit activations.  The wave-independent LDS-DMA streaming of
+// dwconv_mfma_small_wgrad_dma.hip (same plane layout: row-major pitch-16 images in pairs, K = 32 = the 2 x 16 image rows of a
+// pair, one v_mfma_f32_16x16x32 per tap and pair, both operands ds_read_b64_tr_b16) with
+//   * x fetched ONCE per plane pair for the three correlations (4 DMA instructions per pair instead of 6);
+//   * the 5 x K and the 5 x 5 branch share their five x fragments (the tap shift runs along the rows for both): 26 transposing reads
+//     per pair instead of 36; the K x 5 branch runs on the transposed pair (dy_v^T, x^T) as in the single-branch kernel;
+//   * fifteen 4-register accumulators per wave over its whole batch slice, three skewed-tile diagonal-sum epilogues, ONE partial
+//     record per (slice, channel) holding the three filters back to back, last-arriver reduction in slice order into the three dw
+//     tensors: bitwise reproducible;
+//   * NARROW (W < 8): one 16-byte piece per row at a 2-byte aligned source; what a piece drags in beyond column W-1 only ever
+//     meets correlation entries of non-existent positions, which the diagonal sums skip; the tensor's last row is fetched early
+//     and shifted into place (see dwconv_mfma_small_tri.hip).
+// At this size a launch is ~10 us of fixed cost: one launch for three removes two of them per block.
+#include "mfma_common.h"
+
+namespace slak {
+
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+
+constexpr int TW_NS = 3;                // ring slots (plane pairs of the four tensors) per wave
+constexpr int TW_SLOT = 4096;           // bytes per slot: [dy_v pair][dy_h pair][dy_s pair][x pair], 1024 each
+constexpr int TW_RING = 64;
+constexpr int TW_T = TW_RING + TW_NS * TW_SLOT + 64;      // [dy_v^T pair 1024][x^T pair 1024]
+constexpr int TW_RES = TW_T + 2048 + 64;                  // res: up to 10 * 63 + 25 floats
+constexpr int TW_RESN = 672;
+constexpr int TW_WAVE_BYTES = TW_RES + TW_RESN * 4;
+static_assert(TW_NS * TW_SLOT >= 16 * 32 * 4, "the diagonal-sum tile aliases the ring");
+
+struct SmallTriWgradParams {
+    const void* dy[3]; const void* x; float* partial; float* dw[3]; unsigned* counters;
+    int N, C, H, W, K;
+    int images_per_slice, slices;
+    unsigned tensor_bytes;
+};
+
+template <typename T> __device__ __forceinline__ f32x4_t tw_mfma16(s16x8 a, s16x8 b, f32x4_t c);
+template <> __device__ __forceinline__ f32x4_t tw_mfma16<bf16_t>(s16x8 a, s16x8 b, f32x4_t c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+}
+template <> __device__ __forceinline__ f32x4_t tw_mfma16<f16_t>(s16x8 a, s16x8 b, f32x4_t c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+}
+
+template <typename T, bool NARROW>
+__global__ __launch_bounds__(MF_THREADS) void dwconv_mfma_small_tri_wgrad_kernel(const SmallTriWgradParams p) {
+    extern __shared__ __attribute__((aligned(16))) uint16_t lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = wave_id_uniform();
+    const int cblocks = (p.C + 3) >> 2;
+    const int cb = blockIdx.x % cblocks, slice = blockIdx.x / cblocks;
+    const int c0 = cb * 4, c = c0 + wave;
+    const int nch = p.C - c0 < 4 ? p.C - c0 : 4;
+    const int n_begin = slice * p.images_per_slice;
+    int n_end = n_begin + p.images_per_slice; if (n_end > p.N) n_end = p.N;
+    const bool live = c < p.C && n_begin < n_end;                // (every wave reaches the finish: it has workgroup barriers)
+    const int npairs = live ? (n_end - n_begin + 1) >> 1 : 0;
+    char* const L = (char*)lds + wave * TW_WAVE_BYTES;           // this wave's private region
+    const int HW = p.H * p.W;
+    const int nt_long = p.K * MF_TAPS, ntot = 2 * nt_long + 25;  // [K x 5][5 x K][5 x 5] back to back
+
+    for (int o = lane * 16; o < TW_WAVE_BYTES; o += 64 * 16) *(u32x4*)(L + o) = u32x4{0u, 0u, 0u, 0u};
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");            // zeros are in place before any DMA can land on them
+
+    // ---- DMA: lane -> (plane of the pair, image row, half of the row: columns 0..7 / W-8..W-1) ------------------------
+    v4i_t rs[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const uint64_t a = (uint64_t)(t < 3 ? p.dy[t] : p.x);
+        rs[t][0] = __builtin_amdgcn_readfirstlane((int)(a & 0xffffffffu)); rs[t][1] = __builtin_amdgcn_readfirstlane((int)((a >> 32) & 0xffffu));
+        rs[t][2] = __builtin_amdgcn_readfirstlane((int)p.tensor_bytes); rs[t][3] = 0x00020000;
+    }
+    const unsigned gplane_b = (unsigned)(p.C * HW) * 2;
+    const int d_pp = lane >> 5, d_row = (lane >> 1) & 15, d_half = lane & 1;
+    const unsigned d_src = (unsigned)d_pp * gplane_b + (unsigned)(d_row * p.W) * 2 + ((!NARROW && d_half) ? (unsigned)(p.W - 8) * 2 : 0u);
+    const bool d_rowok = d_row < p.H && (!NARROW || d_half == 0);
+    const unsigned lds_wave = (unsigned)(uintptr_t)SLAK_LDS(uint16_t, lds) + wave * TW_WAVE_BYTES;
+    const unsigned chan_b = (unsigned)(live ? c : 0) * (unsigned)HW * 2;
+    const unsigned last_row_b = p.tensor_bytes - (unsigned)(2 * p.W);     // byte offset of the tensor's last image row
+    auto issue_pair = [&](int q) {                                // four DMA instructions -> slot q % TW_NS
+        const int n0 = n_begin + 2 * q;
+        const unsigned gb = (unsigned)n0 * gplane_b + chan_b;
+        const unsigned dst = lds_wave + TW_RING + (unsigned)(q % TW_NS) * TW_SLOT;
+        if (d_rowok && n0 + d_pp < n_end) {
+            unsigned so = gb + d_src;
+            if (NARROW && so == last_row_b) so -= (unsigned)(16 - 2 * p.W);     // would end behind the tensor: fetched early, shifted below
+#pragma unroll
+            for (int t = 0; t < 4; ++t) lds_dma16(so, rs[t], __builtin_amdgcn_readfirstlane(dst + t * 1024));
+        }
+    };
+    for (int q = 0; q < TW_NS - 1 && q < npairs; ++q) issue_pair(q);
+
+    // ---- lane constants (see dwconv_mfma_small_wgrad_dma.hip) ----------------------------------------------------------
+    const int g4 = lane >> 4, i16 = lane & 15;
+    const unsigned rd = (unsigned)((g4 >> 1) * 512 + ((g4 & 1) * 8 + (i16 >> 2)) * 32 + (i16 & 3) * 8);
+    const unsigned trd = (unsigned)((4 * g4 + (i16 >> 2)) * 32 + (i16 & 3) * 8);
+    const int t_row = i16 < 8 ? i16 : i16 - (16 - p.W);
+    const bool twr_ok = NARROW ? i16 < p.W : (i16 < 8 || t_row >= 8);
+    const unsigned twr = (unsigned)(t_row * 32 + g4 * 8);
+    auto frag = [&](unsigned addr) -> s16x8 {                     // 8 k of one column: two transposing reads, 4 rows apart
+        const s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(SLAK_LDS(s16x4, L + addr));
+        const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(SLAK_LDS(s16x4, L + addr + 128));
+        return s16x8{v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+    };
+
+    f32x4_t av[MF_TAPS], ah[MF_TAPS], as[MF_TAPS];
+#pragma unroll
+    for (int r = 0; r < MF_TAPS; ++r) { av[r] = f32x4_t{0.f, 0.f, 0.f, 0.f}; ah[r] = av[r]; as[r] = av[r]; }
+
+    for (int q = 0; q < npairs; ++q) {
+        {
+            int dm = npairs - 1 - q; if (dm > TW_NS - 2) dm = TW_NS - 2;
+            wait_vmcnt_dyn(4 * dm);                               // only the DMAs of the pairs behind this one may be outstanding
+        }
+        __builtin_amdgcn_wave_barrier();
+        const int n0 = n_begin + 2 * q;
+        const unsigned slot = (unsigned)TW_RING + (unsigned)(q % TW_NS) * TW_SLOT;
+        if (q == npairs - 1 && ((n_end - n_begin) & 1)) {
+            // odd slice: the second plane of the last pair was not fetched and its rows still hold an older plane: clear them
+            // (32 lanes x 16 bytes per tensor)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) *(u32x4*)(L + slot + 512 + ((lane >> 5) + 2 * t) * 1024 + (lane & 31) * 16) = u32x4{0u, 0u, 0u, 0u};
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (NARROW && c == p.C - 1 && n0 + 1 >= p.N - 1 && n0 <= p.N - 1) {       // (wave-uniform) this pair holds the tensor's last plane
+            const int ppl = p.N - 1 - n0, sh = 8 - p.W;             // its last row arrived `sh` elements late: shift it into place
+            if (lane < 4) {
+                char* rowp = L + slot + lane * 1024 + ppl * 512 + (p.H - 1) * 32;
+                const u32x4 o = *(const u32x4*)rowp;
+                const unsigned oo[6] = {o[0], o[1], o[2], o[3], 0u, 0u};
+                const int wsh = (16 * sh) >> 5, bsh = (16 * sh) & 31;
+                u32x4 nv;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    unsigned lo = 0u, hi = 0u;
+#pragma unroll
+                    for (int j = 0; j < 6; ++j) { if (j == k + wsh) lo = oo[j]; if (j == k + wsh + 1) hi = oo[j]; }
+                    nv[k] = bsh ? ((lo >> bsh) | (hi << (32 - bsh))) : lo;
+                }
+                *(u32x4*)rowp = nv;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+        }
+        // vertical branch: dy_v pair and x pair transposed (tensor 0 and tensor 3 of the slot)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {                             // dy_v plane 0,1 -> T + 0, 512;  x plane 0,1 -> T + 1024, 1536
+            const unsigned src = slot + (k < 2 ? 0u : 3072u) + (k & 1) * 512 + trd;
+            const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16(SLAK_LDS(s16x4, L + src));
+            if (twr_ok) *(s16x4*)(L + TW_T + k * 512 + twr) = v;
+        }
+        const s16x8 a_h = frag(slot + 1024 + rd), a_s = frag(slot + 2048 + rd);
+        const unsigned xb = slot + 3072 - 64 + rd;                // x pair minus two rows: the tap shift is +r rows
+#pragma unroll
+        for (int r = 0; r < MF_TAPS; ++r) {
+            const s16x8 b = frag(xb + r * 32);
+            ah[r] = tw_mfma16<T>(a_h, b, ah[r]);
+            as[r] = tw_mfma16<T>(a_s, b, as[r]);
+        }
+        const s16x8 a_v = frag((unsigned)TW_T + rd);
+        const unsigned xtb = (unsigned)TW_T + 1024 - 64 + rd;
+#pragma unroll
+        for (int r = 0; r < MF_TAPS; ++r) av[r] = tw_mfma16<T>(a_v, frag(xtb + r * 32), av[r]);
+        if (q + TW_NS - 1 < npairs) issue_pair(q + TW_NS - 1);      // into the slot pair q-1 used
+    }
+
+    // ---- diagonal sums, one branch after the other, through the skewed 16 x 32 tile (the ring is dead) ------------------------
+    if (live) {
+        float* tile = (float*)(L + TW_RING);
+        float* res = (float*)(L + TW_RES);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        auto diag = [&](const f32x4_t (&acc)[MF_TAPS], bool vert, int Wt, int KL, int kw, float* out) {
+            const int padL = KL / 2;
+            const int dup = vert ? 0 : 16 - Wt;
+            auto pos = [&](int sl) { return sl < 8 ? sl : sl - dup; };
+            auto valid = [&](int sl) { const int qq = pos(sl); return sl < 8 ? sl < Wt : (qq >= 8 && qq < Wt); };
+            const int pi = pos(i16);
+            const bool vi = valid(i16);
+            *(u32x4*)((char*)tile + lane * 16) = u32x4{0u, 0u, 0u, 0u};
+            *(u32x4*)((char*)tile + 1024 + lane * 16) = u32x4{0u, 0u, 0u, 0u};
+            int wofs[4]; bool wok[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int so = 4 * g4 + e;
+                wok[e] = vi && valid(so);
+                wofs[e] = so * 32 + (pi - pos(so) + 15);
+            }
+            __builtin_amdgcn_wave_barrier();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int r = 0; r < MF_TAPS; ++r) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (wok[e]) tile[wofs[e]] = acc[r][e];
+                __builtin_amdgcn_wave_barrier();
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (lane < 31) {
+                    float v[16];
+#pragma unroll
+                    for (int o = 0; o < 16; ++o) v[o] = tile[o * 32 + lane];       // 16 independent reads, added in order below
+                    float sum = 0.f;
+#pragma unroll
+                    for (int o = 0; o < 16; ++o) sum += v[o];
+                    const int tau = lane - 15 + padL;
+                    if (tau >= 0 && tau < KL) out[vert ? (tau * kw + r) : (r * kw + tau)] = sum;
+                }
+                __builtin_amdgcn_wave_barrier();
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
+        };
+        diag(av, true, p.H, p.K, MF_TAPS, res);
+        diag(ah, false, p.W, p.K, p.K, res + nt_long);
+        diag(as, false, p.W, MF_TAPS, MF_TAPS, res + 2 * nt_long);
+        float* out = p.partial + ((size_t)slice * p.C + c) * ntot;
+        for (int t = lane; t < ntot; t += 64) wgrad_store_partial(&out[t], res[t]);       // taps no diagonal reaches stay 0
+    } else if (c < p.C) {                                         // empty slice: its partial must still be zero
+        float* out = p.partial + ((size_t)slice * p.C + c) * ntot;
+        for (int t = lane; t < ntot; t += 64) wgrad_store_partial(&out[t], 0.f);
+    }
+    // ---- last arriver of the channel block adds the slices in order and scatters into the three dw tensors (see wgrad_finish) ----
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int* lds_flag = (int*)lds;
+    if (tid == 0) {
+        int last = 1;
+        if (p.slices > 1) {
+            const unsigned old = __hip_atomic_fetch_add(p.counters + cb, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            last = old == (unsigned)(p.slices - 1);
+            if (last) __hip_atomic_store(p.counters + cb, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        *lds_flag = last;
+    }
+    __syncthreads();
+    if (!*lds_flag) return;
+    for (int t = tid; t < nch * ntot; t += MF_THREADS) {
+        float s = 0.f;
+        const float* src = p.partial + (size_t)c0 * ntot + t;
+        const size_t stride = (size_t)p.C * ntot;
+        for (int k0 = 0; k0 < p.slices; k0 += 8) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                v[j] = k0 + j < p.slices ? __hip_atomic_load(src + (size_t)(k0 + j) * stride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s += v[j];
+        }
+        const int ch = t / ntot, e = t - ch * ntot;
+        const size_t cc = (size_t)(c0 + ch);
+        if (e < nt_long) p.dw[0][cc * nt_long + e] = s;
+        else if (e < 2 * nt_long) p.dw[1][cc * nt_long + (e - nt_long)] = s;
+        else p.dw[2][cc * 25 + (e - 2 * nt_long)] = s;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+static bool fill_stw_params(SmallTriWgradParams& p, int N, int C, int H, int W, int K, int target_wgs) {
+    p.N = N; p.C = C; p.H = H; p.W = W; p.K = K;
+    if (N <= 0 || C <= 0 || K <= MF_TAPS || !(K & 1) || K > 63) return false;
+    if (H > 14 || H < 1) return false;
+    if (W >= 8 ? (W > 14 || (W & 1)) : W < 4) return false;
+    const int cblocks = (C + 3) / 4;
+    int slices = target_wgs / cblocks; if (slices < 1) slices = 1;
+    int per = (N + slices - 1) / slices; per = (per + 1) & ~1;      // whole pairs
+    if (per < 8) per = 8;
+    if (per > ((N + 1) & ~1)) per = (N + 1) & ~1;
+    p.images_per_slice = per; p.slices = (N + per - 1) / per;
+    p.tensor_bytes = (unsigned)((size_t)N * C * H * W * 2);
+    return (size_t)N * C * H * W * 2 < 0xffffffffull;
+}
+
+bool dwconv_mfma_small_tri_wgrad_supported(int N, int C, int H, int W, int K, int dtype) {
+    if (dtype != SLAK_BF16 && dtype != SLAK_F16) return false;
+    SmallTriWgradParams p;
+    return fill_stw_params(p, N, C, H, W, K, 512);
+}
+
+size_t dwconv_mfma_small_tri_wgrad_workspace(int N, int C, int K) {
+    return align_up((size_t)((N + 7) / 8 + 1) * C * (2 * K * MF_TAPS + 25) * sizeof(float), 256);   // slices <= ceil(N / 8)
+}
+
+template <typename T, bool NARROW>
+static int launch_stw_t(SmallTriWgradParams& p, size_t ws_bytes, hipStream_t st) {
+    auto k = dwconv_mfma_small_tri_wgrad_kernel<T, NARROW>;
+    fill_stw_params(p, p.N, p.C, p.H, p.W, p.K, 2 * mfma_cu_count());
+    if ((size_t)p.slices * p.C * (2 * p.K * MF_TAPS + 25) * sizeof(float) > ws_bytes) return SLAK_ERR_WORKSPACE;
+    const size_t lds = (size_t)MF_WAVES * TW_WAVE_BYTES;
+    if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k, dim3((unsigned)(((p.C + 3) / 4) * p.slices)), dim3(MF_THREADS), lds, st, p);
+    SLAK_LAUNCH_CHECK();
+    return SLAK_OK;
+}
+
+int launch_dwconv_mfma_small_tri_wgrad(const void* const* dy, const void* x, float* const* dw, int dtype,
+                                       int N, int C, int H, int W, int K, void* ws, size_t ws_bytes, hipStream_t st) {
+    if (!dwconv_mfma_small_tri_wgrad_supported(N, C, H, W, K, dtype)) return SLAK_ERR_UNSUPPORTED;
+    if (ws == nullptr) return SLAK_ERR_WORKSPACE;
+    SmallTriWgradParams p;
+    fill_stw_params(p, N, C, H, W, K, 512);
+    for (int b = 0; b < 3; ++b) { p.dy[b] = dy[b]; p.dw[b] = dw[b]; }
+    p.x = x; p.partial = (float*)ws;
+    p.counters = wgrad_arrival_counters((C + 3) / 4);
+    if (!p.counters) return SLAK_ERR_UNSUPPORTED;                 // (the caller runs the three per-branch launches)
+    if (dtype == SLAK_BF16) return W < 8 ? launch_stw_t<bf16_t, true>(p, ws_bytes, st) : launch_stw_t<bf16_t, false>(p, ws_bytes, st);
+    return W < 8 ? launch_stw_t<f16_t, true>(p, ws_bytes, st) : launch_stw_t<f16_t, false>(p, ws_bytes, st);
+}
+
+}  // namespace slak

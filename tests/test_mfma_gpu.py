@@ -289,3 +289,34 @@ def test_full_size_properties_on_slak_b_and_odd_width_channel_counts(mfma_only, 
             ref = oracle.dwconv2d_fwd(x[n:n + 1, ch:ch + 1].float().cpu().numpy(), w[ch:ch + 1].cpu().numpy())
             got = y[n, ch].double().cpu().numpy()
             assert np.abs(got - ref[0, 0]).max() <= LOWP_TOL * max(1.0, np.abs(ref).max())
+
+
+@pytest.mark.parametrize("N,C,H,W,K", [(5, 7, 14, 14, 47), (4, 3, 12, 10, 9), (1, 1, 14, 14, 13), (6, 5, 7, 7, 13), (17, 6, 7, 7, 13), (1, 1, 7, 7, 13),
+                                       (3, 2, 7, 5, 7), (5, 2, 5, 7, 9), (2, 130, 7, 7, 13), (9, 3, 14, 8, 31), (33, 4, 14, 14, 47), (16, 9, 6, 6, 9)])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_tri_weight_gradient_matches_the_three_per_branch_kernels(N, C, H, W, K, dtype, gpu):
+    """slak_dwconv2d_tri_backward_filter (one launch, x fetched once) against the oracle and the per-branch kernels: same fp32
+    accumulation over the batch in a different order -> equal to accumulation noise; deterministic."""
+    from slak_amd import block_ops
+    ops = _ops()
+    torch.manual_seed(N * 7 + K)
+    x = torch.randn(N, C, H, W, device=gpu).to(dtype).requires_grad_(True)
+    ws = [(torch.randn(C, 1, kh, kw, device=gpu) * 0.05).requires_grad_(True) for kh, kw in ((K, 5), (5, K), (5, 5))]
+    dys = [torch.randn(N, C, H, W, device=gpu).to(dtype) for _ in range(3)]
+    got = []
+    for rep in range(2):
+        for w in ws:
+            w.grad = None
+        ys = block_ops.tri_dwconv(x, *ws)
+        torch.autograd.backward(ys, dys)
+        got.append([w.grad.clone() for w in ws])
+    for a, b in zip(*got):
+        assert torch.equal(a, b)                                                      # no atomics, fixed order
+    L = _lib()
+    assert L.lib().slak_dwconv2d_tri_filter_workspace_bytes(L.SLAK_BF16 if dtype == torch.bfloat16 else L.SLAK_F16, N, C, H, W, K) > 0
+    for g, dy, w, (kh, kw) in zip(got[0], dys, ws, ((K, 5), (5, K), (5, 5))):
+        ref = oracle.dwconv2d_bwd_filter(_round(dy, dtype), _round(x.detach(), dtype), kh, kw)
+        err = np.abs(g.double().cpu().numpy() - ref).max()
+        assert err <= 1e-5 * max(1.0, np.abs(ref).max()) * max(1.0, (N * H * W) ** 0.5 / 30), (kh, kw, err)
+        sep = ops.dwconv2d_backward_filter(dy, x.detach(), w.detach())
+        assert (g - sep).abs().max().item() <= 1e-5 * max(1.0, sep.abs().max().item()) * max(1.0, (N * H * W) ** 0.5 / 30)
