@@ -20,6 +20,13 @@ static bool use_vrows() {                    // SLAK_MFMA_VROWS=0 keeps the tran
     static const bool v = [] { const char* e = getenv("SLAK_MFMA_VROWS"); return !(e && e[0] == '0'); }();
     return v;
 }
+static std::atomic<int> g_dense_tri{-1};     // -1: SLAK_DENSE_TRI (default off: measured on par with the per-plane kernels), 0 / 1: slak_debug_set_dense_tri
+static bool use_dense_tri() {
+    const int v = g_dense_tri.load();
+    if (v >= 0) return v != 0;
+    static const bool e = [] { const char* s = getenv("SLAK_DENSE_TRI"); return s && s[0] == '1'; }();
+    return e;
+}
 static bool use_small() {                    // SLAK_MFMA_SMALL=0 keeps the generic register-staged kernel for H,W <= 16 (A/B testing)
     static int v = -1;
     if (v < 0) { const char* e = getenv("SLAK_MFMA_SMALL"); v = (e && e[0] == '0') ? 0 : 1; }
@@ -56,6 +63,8 @@ extern "C" {
 
 /* dev hook (not in the public header): device buffer of 4x8 u64 that workgroup 0 of the DMA conv kernel fills with per-phase cycle counts */
 void slak_debug_set_phase_buffer(void* p) { slak::g_dma_dbg = (unsigned long long*)p; }
+/* dev hook (not in the public header): route planes of <= 64 pixels through the dense-operator three-branch kernels (1), the per-plane ones (0), or follow SLAK_DENSE_TRI (-1) */
+void slak_debug_set_dense_tri(int v) { g_dense_tri = v; }
 
 const char* slak_status_string(int status) {
     switch (status) {
@@ -189,6 +198,7 @@ int slak_dwconv2d_backward_filter(const void* dy, int dy_dtype, const void* x, i
 
 
 int slak_dwconv2d_tri_supported(int dtype, int N, int C, int H, int W, int K) {
+    if (use_dense_tri() && dwconv_mfma_dense_tri_supported(N, C, H, W, K, dtype)) return 1;                  // planes of <= 64 pixels: dense operator, batch as GEMM dimension
     if (dwconv_mfma_small_tri_supported(N, C, H, W, K, dtype)) return 1;                                     // 14x14 class: sums in the accumulator
     return (dwconv_mfma_tri_supported(N, C, H, W, K, dtype, false) && dwconv_mfma_tri_supported(N, C, H, W, K, dtype, true)) ? 2 : 0;   // 56x56 / 28x28 class
 }
@@ -197,6 +207,8 @@ int slak_dwconv2d_tri_forward(const void* x, const float* w_v, const float* w_h,
                               int dtype, int N, int C, int H, int W, int K, void* stream) {
     if (!x || !w_v || !w_h || !w_s || !y_v || !y_h || !y_s) return SLAK_ERR_INVALID_ARG;
     const void* in[3] = {x, x, x}; void* out[3] = {y_v, y_h, y_s}; const float* w[3] = {w_v, w_h, w_s};
+    if (use_dense_tri() && dwconv_mfma_dense_tri_supported(N, C, H, W, K, dtype))
+        return launch_dwconv_mfma_dense_tri(false, in, out, w, dtype, N, C, H, W, K, (hipStream_t)stream);
     if (dwconv_mfma_small_tri_supported(N, C, H, W, K, dtype))
         return launch_dwconv_mfma_small_tri(false, in, out, w, dtype, N, C, H, W, K, (hipStream_t)stream);
     return launch_dwconv_mfma_tri(false, in, out, w, dtype, N, C, H, W, K, (hipStream_t)stream);
@@ -206,6 +218,8 @@ int slak_dwconv2d_tri_backward_data(const void* dy_v, const void* dy_h, const vo
                                     const float* w_s, void* dx, int dtype, int N, int C, int H, int W, int K, void* stream) {
     if (!dy_v || !dy_h || !dy_s || !w_v || !w_h || !w_s || !dx) return SLAK_ERR_INVALID_ARG;
     const void* in[3] = {dy_v, dy_h, dy_s}; void* out[3] = {dx, dx, dx}; const float* w[3] = {w_v, w_h, w_s};
+    if (use_dense_tri() && dwconv_mfma_dense_tri_supported(N, C, H, W, K, dtype))
+        return launch_dwconv_mfma_dense_tri(true, in, out, w, dtype, N, C, H, W, K, (hipStream_t)stream);
     if (dwconv_mfma_small_tri_supported(N, C, H, W, K, dtype))
         return launch_dwconv_mfma_small_tri(true, in, out, w, dtype, N, C, H, W, K, (hipStream_t)stream);
     return launch_dwconv_mfma_tri(true, in, out, w, dtype, N, C, H, W, K, (hipStream_t)stream);

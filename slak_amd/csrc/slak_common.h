@@ -89,6 +89,9 @@ int launch_dwconv_mfma_small_dma(const void* x, int x_dt, const void* w, int w_d
 bool dwconv_mfma_small_tri_supported(int N, int C, int H, int W, int K, int dtype);
 int launch_dwconv_mfma_small_tri(bool dgrad, const void* const* in, void* const* out, const float* const* w, int dtype,
                                  int N, int C, int H, int W, int K, hipStream_t st);
+bool dwconv_mfma_dense_tri_supported(int N, int C, int H, int W, int K, int dtype);
+int launch_dwconv_mfma_dense_tri(bool dgrad, const void* const* in, void* const* out, const float* const* w, int dtype,
+                                 int N, int C, int H, int W, int K, hipStream_t st);
 bool dwconv_mfma_small_tri_wgrad_supported(int N, int C, int H, int W, int K, int dtype);
 size_t dwconv_mfma_small_tri_wgrad_workspace(int N, int C, int K);
 int launch_dwconv_mfma_small_tri_wgrad(const void* const* dy, const void* x, float* const* dw, int dtype,

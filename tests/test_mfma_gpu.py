@@ -320,3 +320,39 @@ def test_tri_weight_gradient_matches_the_three_per_branch_kernels(N, C, H, W, K,
         assert err <= 1e-5 * max(1.0, np.abs(ref).max()) * max(1.0, (N * H * W) ** 0.5 / 30), (kh, kw, err)
         sep = ops.dwconv2d_backward_filter(dy, x.detach(), w.detach())
         assert (g - sep).abs().max().item() <= 1e-5 * max(1.0, sep.abs().max().item()) * max(1.0, (N * H * W) ** 0.5 / 30)
+
+
+@pytest.mark.parametrize("N,C,H,W,K", [(6, 5, 7, 7, 13), (40, 5, 7, 7, 13), (1, 1, 7, 7, 13), (65, 3, 8, 8, 9), (33, 2, 3, 4, 7), (100, 9, 7, 7, 13), (4, 3, 6, 6, 9), (3, 2, 7, 5, 7)])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_dense_operator_three_branch_kernels_behind_the_dev_hook(N, C, H, W, K, dtype, gpu):
+    """dwconv_mfma_dense_tri.hip (planes of <= 64 pixels as a dense per-channel operator with the batch as GEMM dimension; off by
+    default: measured on par with the per-plane kernels at SLaK's sizes) against the oracle: every output rounded once."""
+    import ctypes
+    L = _lib()
+    lib = L.lib()
+    hook = lib.slak_debug_set_dense_tri
+    hook.argtypes = [ctypes.c_int]; hook.restype = None
+    dt = L.SLAK_BF16 if dtype == torch.bfloat16 else L.SLAK_F16
+    torch.manual_seed(N + K)
+    x = torch.randn(N, C, H, W, device=gpu).to(dtype)
+    dys = [torch.randn(N, C, H, W, device=gpu).to(dtype) for _ in range(3)]
+    ws = [torch.randn(C, 1, kh, kw, device=gpu) * 0.05 for kh, kw in ((K, 5), (5, K), (5, 5))]
+    ys = [torch.empty_like(x) for _ in range(3)]
+    dx = torch.empty_like(x)
+    st = torch.cuda.current_stream(gpu).cuda_stream
+    hook(1)
+    try:
+        assert lib.slak_dwconv2d_tri_supported(dt, N, C, H, W, K) == 1
+        L.check(lib.slak_dwconv2d_tri_forward(x.data_ptr(), ws[0].data_ptr(), ws[1].data_ptr(), ws[2].data_ptr(), ys[0].data_ptr(), ys[1].data_ptr(),
+                                              ys[2].data_ptr(), dt, N, C, H, W, K, st))
+        L.check(lib.slak_dwconv2d_tri_backward_data(dys[0].data_ptr(), dys[1].data_ptr(), dys[2].data_ptr(), ws[0].data_ptr(), ws[1].data_ptr(),
+                                                    ws[2].data_ptr(), dx.data_ptr(), dt, N, C, H, W, K, st))
+        torch.cuda.synchronize()
+    finally:
+        hook(-1)
+    ulp = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11
+    xr = _round(x, dtype)
+    for y, w in zip(ys, ws):
+        _check(y, oracle.dwconv2d_fwd(xr, _round(w, dtype)), ulp, "dense fwd")
+    ref = sum(oracle.dwconv2d_bwd_data(_round(dy, dtype), _round(w, dtype)) for dy, w in zip(dys, ws))
+    _check(dx, ref, ulp, "dense dgrad")

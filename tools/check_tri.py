@@ -7,7 +7,7 @@ from slak_amd import ops, _lib, block_ops
 dev = torch.device("cuda:0")
 L = _lib.lib()
 bad = 0
-for (N, C, H, W, K) in [(6, 5, 7, 7, 13), (17, 6, 7, 7, 13), (1, 1, 7, 7, 13), (4, 3, 6, 6, 9), (3, 2, 7, 5, 7), (5, 2, 5, 7, 9), (2, 130, 7, 7, 13), (5, 7, 14, 14, 47), (3, 4, 4, 4, 7), (2, 3, 7, 6, 9), (3, 2, 5, 5, 7),  (9, 2, 28, 28, 49), (2, 2, 48, 40, 31), (2, 3, 64, 64, 61), (3, 2, 32, 32, 31), (6, 2, 24, 24, 13), (7, 2, 28, 20, 13), (1, 1, 56, 56, 51), (11, 1, 20, 28, 49), (17, 2, 56, 56, 51), (33, 1, 28, 28, 49)]:
+for (N, C, H, W, K) in [(6, 5, 7, 7, 13), (17, 6, 7, 7, 13), (1, 1, 7, 7, 13), (4, 3, 6, 6, 9), (3, 2, 7, 5, 7), (5, 2, 5, 7, 9), (2, 130, 7, 7, 13), (5, 7, 14, 14, 47), (3, 4, 4, 4, 7), (2, 3, 7, 6, 9), (3, 2, 5, 5, 7), (40, 5, 7, 7, 13), (65, 3, 8, 8, 9), (33, 2, 3, 4, 7), (100, 9, 7, 7, 13),  (9, 2, 28, 28, 49), (2, 2, 48, 40, 31), (2, 3, 64, 64, 61), (3, 2, 32, 32, 31), (6, 2, 24, 24, 13), (7, 2, 28, 20, 13), (1, 1, 56, 56, 51), (11, 1, 20, 28, 49), (17, 2, 56, 56, 51), (33, 1, 28, 28, 49)]:
     for dtype in (torch.bfloat16, torch.float16):
         kind = L.slak_dwconv2d_tri_supported(_lib.SLAK_BF16 if dtype == torch.bfloat16 else _lib.SLAK_F16, N, C, H, W, K)
         torch.manual_seed(N + K)
