@@ -838,6 +838,10 @@ size_t slak_block_tail_workspace_bytes(int N, int C, int P) {
     return align_up((rows + BT_SLICES) * 2 * C * sizeof(float), 256);
 }
 
+static bool tail_use_reg() {                  // SLAK_TAIL_REG=0 keeps the LDS-tile kernels (A/B testing)
+    static const bool v = [] { const char* e = getenv("SLAK_TAIL_REG"); return !(e && e[0] == '0'); }();
+    return v;
+}
 static int tail_args_ok(int N, int C, int P) {
     if (N <= 0 || C <= 0 || P <= 0) return SLAK_ERR_INVALID_ARG;
     if ((C & 1) || C > 1024) return SLAK_ERR_UNSUPPORTED;
@@ -849,6 +853,10 @@ int slak_ln_nchw_to_nhwc_forward(const void* x, const float* weight, const float
                                  int N, int C, int P, float eps, void* stream) {
     if (!x || !weight || !bias || !y || !mean || !rstd) return SLAK_ERR_INVALID_ARG;
     int rc = tail_args_ok(N, C, P); if (rc) return rc;
+    if (tail_use_reg()) {                               // register-tile kernel (block_tail_reg.hip) where an instantiation exists
+        rc = launch_ln_nchw_to_nhwc_fwd_reg(x, weight, bias, y, mean, rstd, N, C, P, eps, (hipStream_t)stream);
+        if (rc != SLAK_ERR_UNSUPPORTED) return rc;
+    }
     if (C <= 256) {
         const TailDims d = make_dims_pix(N, C, P);
         const size_t lds = (((size_t)C * (d.TP + 2) * 2 + 15) & ~(size_t)15) + (size_t)(BT_THREADS / d.TP) * d.TP * 4 + 2 * d.TP * 4;
@@ -873,6 +881,12 @@ int slak_ln_nchw_to_nhwc_backward(const void* g, const void* x, const float* wei
     if (!g || !x || !weight || !mean || !rstd || !dx || !dweight || !dbias) return SLAK_ERR_INVALID_ARG;
     int rc = tail_args_ok(N, C, P); if (rc) return rc;
     if (!workspace || workspace_bytes < slak_block_tail_workspace_bytes(N, C, P)) return SLAK_ERR_WORKSPACE;
+    if (tail_use_reg()) {
+        int rows = 0; float* part = (float*)workspace;
+        rc = launch_ln_nchw_to_nhwc_bwd_reg(g, x, weight, mean, rstd, dx, part, &rows, N, C, P, (hipStream_t)stream);
+        if (rc == SLAK_OK) return reduce_partials(part, part + (size_t)rows * 2 * C, dweight, dbias, C, rows, 2 * C, (hipStream_t)stream);
+        if (rc != SLAK_ERR_UNSUPPORTED) return rc;
+    }
     if (C <= 256) {
         const TailDims d = make_dims_pix(N, C, P);
         const size_t lds = (((size_t)C * (d.TP + 2) * 2 + 15) & ~(size_t)15) + (((size_t)d.TP * (C + 2) * 2 + 15) & ~(size_t)15) +
@@ -899,6 +913,10 @@ int slak_scale_residual_forward(const void* shortcut, int shortcut_dtype, const 
                                 float* out, void* out_bf16, int N, int C, int P, void* stream) {
     if (!shortcut || !z || !gamma || !out) return SLAK_ERR_INVALID_ARG;
     int rc = tail_args_ok(N, C, P); if (rc) return rc;
+    if (tail_use_reg()) {
+        rc = launch_scale_residual_fwd_reg(shortcut, shortcut_dtype, z, gamma, sample_scale, out, out_bf16, N, C, P, (hipStream_t)stream);
+        if (rc != SLAK_ERR_UNSUPPORTED) return rc;
+    }
     if (C <= 256) {
         const TailDims d = make_dims_pix(N, C, P);
         const size_t lds = (size_t)d.TP * (C + 2) * 2 + 16;
@@ -939,6 +957,12 @@ int slak_scale_residual_backward(const float* dout, const void* dout_bf16, float
     if (!dout || !z || !gamma || !dz || !dgamma || !dz_colsum || (dout_bf16 && !dout_sum)) return SLAK_ERR_INVALID_ARG;
     int rc = tail_args_ok(N, C, P); if (rc) return rc;
     if (!workspace || workspace_bytes < slak_block_tail_workspace_bytes(N, C, P)) return SLAK_ERR_WORKSPACE;
+    if (tail_use_reg()) {
+        int rows = 0; float* part = (float*)workspace;
+        rc = launch_scale_residual_bwd_reg(dout, dout_bf16, dout_sum, z, gamma, sample_scale, dz, part, &rows, N, C, P, (hipStream_t)stream);
+        if (rc == SLAK_OK) return reduce_partials(part, part + (size_t)rows * 2 * C, dgamma, dz_colsum, C, rows, 2 * C, (hipStream_t)stream);
+        if (rc != SLAK_ERR_UNSUPPORTED) return rc;
+    }
     if (C <= 256) {
         const TailDims d = make_dims_pix(N, C, P);
         const size_t lds = (size_t)C * (d.TP + 1) * 4 + (size_t)d.TP * (C + 2) * 2 + 16;

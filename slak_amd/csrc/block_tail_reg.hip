@@ -1,0 +1,523 @@
+// slak_amd/csrc/block_tail_reg.hip -- register-tile versions of the block-tail kernels for C <= 256 (stages 1-2 of SLaK, where most
+// of the block-tail time is): a LANE owns a pixel (or a pixel and half / a quarter of the channels) and keeps its channels in
+// registers, so the NCHW side is plain coalesced 2- / 4-byte accesses along the pixel axis, the per-pixel statistics are register
+// sums (no LDS, no barrier), and only the NHWC side goes through a per-wave LDS tile (rows padded to an odd number of 16-byte chunks:
+// the lane's row is written / read with conflict-free ds_*_b128) to be moved as coalesced 16-byte pieces.  The kernels of
+// block_tail.hip stage BOTH sides in LDS and walk them with 2-byte LDS accesses in three passes: 0.17-0.34 of the HBM roofline.
+#include "slak_common.h"
+#include "mfma_common.h"
+
+namespace slak {
+
+typedef __attribute__((ext_vector_type(4))) unsigned rt_u32x4;
+typedef __attribute__((ext_vector_type(2))) float rt_f32x2;
+typedef __attribute__((ext_vector_type(2))) __bf16 rt_bf16x2;
+__device__ __forceinline__ float rt_lo(unsigned v) { return __uint_as_float(v << 16); }
+__device__ __forceinline__ float rt_hi(unsigned v) { return __uint_as_float(v & 0xffff0000u); }
+__device__ __forceinline__ unsigned rt_pack2(float a, float b) { return __builtin_bit_cast(unsigned, __builtin_convertvector(rt_f32x2{a, b}, rt_bf16x2)); }
+
+// Lane geometry: lane = pixel_pair * G + group.  A lane owns TWO neighbouring pixels (p, p+1: one 4-byte access per bf16 channel row,
+// 8 bytes per fp32 one) and the channels [g*CL, (g+1)*CL) of both; a wave covers PW = 128 / G pixels.  The pixel-pair index sits in the
+// HIGH lane bits so that v_permlane32_swap / v_permlane16_swap fold pixel halves (per-channel sums); the group in the low bits.
+// Needs P even (pairs never straddle the end of an image).
+// All global accesses are raw-buffer operations: descriptor = (image, tile) base with the bytes that remain, lane offset in a VGPR
+// (tile-invariant), channel row in the scalar offset.  Lanes and tile rows past the end of the image read zeros and their stores are
+// dropped by the range check, so there is no per-access predicate and no 64-bit VALU address arithmetic.
+template <int CL, int G> struct RtGeom {
+    static constexpr int C = CL * G, PW = 128 / G, PITCH = C * 2 + 16, CPR = C / 8, NCH = PW * CPR, LDS_WAVE = PW * PITCH;
+    static_assert(CL % 16 == 0 && (G == 1 || G == 2 || G == 4 || G == 8), "lane geometry");
+};
+typedef __amdgpu_buffer_rsrc_t rt_rsrc;
+typedef __attribute__((ext_vector_type(2))) unsigned rt_u32x2;
+__device__ __forceinline__ rt_rsrc rt_buf(const void* p, unsigned bytes) { return __builtin_amdgcn_make_buffer_rsrc((void*)p, 0, (int)bytes, 0x00020000); }
+constexpr unsigned RT_OOB = 0x80000000u;                      // a lane offset no descriptor covers
+
+// sum over the G lanes that share a pixel pair
+template <int G> __device__ __forceinline__ float rt_group_sum(float v) {
+#pragma unroll
+    for (int k = 1; k < G; k <<= 1) v += __shfl_xor(v, k, 64);
+    return v;
+}
+__device__ __forceinline__ void rt_lds_fence() {            // LDS hand-off between the lanes of ONE wave
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+}
+// PW pixel rows of an NHWC tensor (one contiguous run of PW * C elements) -> the wave's padded LDS tile by LDS-DMA (no registers, no
+// ds_write pass): destinations are lane-linear, so destination chunk q = (row q / CD, chunk q % CD) fetches source chunk row * (CD-1) +
+// chunk; the padding chunk of a row and the rows the descriptor does not cover (past the image) are written as zeros by the range check.
+// The plan (per-lane source offsets) is tile-invariant.  Completion: s_waitcnt vmcnt(0), then a wave barrier.
+template <int C, int PW> struct RtDmaPlan { static constexpr int CD = C / 8 + 1, NI = (PW * CD + 63) / 64; unsigned src[NI]; };
+template <int C, int PW> __device__ __forceinline__ void rt_dma_plan(RtDmaPlan<C, PW>& d, int lane) {
+    constexpr int CD = RtDmaPlan<C, PW>::CD;
+#pragma unroll
+    for (int k = 0; k < RtDmaPlan<C, PW>::NI; ++k) {
+        const int q = 64 * k + lane, r = q / CD, cc = q - r * CD;
+        d.src[k] = r >= PW ? 0xffffffffu : (cc < CD - 1 ? (unsigned)(r * (CD - 1) + cc) * 16u : RT_OOB);
+    }
+}
+__device__ __forceinline__ v4i_t rt_desc(const void* p, unsigned bytes) {
+    const unsigned long long a = (unsigned long long)p;
+    return v4i_t{(int)(unsigned)a, (int)((unsigned)(a >> 32) & 0xffffu), (int)bytes, 0x00020000};
+}
+template <int C, int PW> __device__ __forceinline__ void rt_tile_dma(const RtDmaPlan<C, PW>& d, const void* src, unsigned bytes, unsigned lds_dst) {
+    const v4i_t r = rt_desc(src, bytes);
+#pragma unroll
+    for (int k = 0; k < RtDmaPlan<C, PW>::NI; ++k)
+        if (d.src[k] != 0xffffffffu) lds_dma16(d.src[k], r, __builtin_amdgcn_readfirstlane(lds_dst + k * 1024));
+}
+__device__ __forceinline__ void rt_dma_wait() {             // every outstanding memory operation of the wave, then the lanes meet
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+}
+template <int C, int PW> __device__ __forceinline__ void rt_tile_store(const unsigned char* T, rt_rsrc r, int lane) {
+    constexpr int CPR = C / 8, NCH = PW * CPR, PITCH = C * 2 + 16, RINC = 64 / CPR, CINC = 64 % CPR, NK = (NCH + 63) / 64;
+    int row = lane / CPR, cc = lane - row * CPR;
+#pragma unroll
+    for (int k = 0; k < NK; ++k) {
+        if (NCH % 64 == 0 || k * 64 + lane < NCH)
+            __builtin_amdgcn_raw_buffer_store_b128(*(const rt_u32x4*)(T + row * PITCH + cc * 16), r, (unsigned)(k * 64 + lane) * 16u, 0, 0);
+        cc += CINC; row += RINC;
+        if (cc >= CPR) { cc -= CPR; ++row; }
+    }
+}
+// Per-channel sums over the wave's pixels, folded as they come: a0..a3 = the lane's terms of its channels 4m..4m+3; the result register
+// holds, in its 16-lane row r, partial sums of channel 4m + {0,2,1,3}[r] (a quarter of the wave's lanes each).  Two swaps and three adds
+// replace four accumulator registers per lane by one.
+__device__ __forceinline__ float rt_fold4(float a0, float a1, float a2, float a3) {
+    const auto p = __builtin_amdgcn_permlane32_swap(__float_as_uint(a0), __float_as_uint(a1), false, false);   // [a0.lo a1.lo], [a0.hi a1.hi]
+    const auto q = __builtin_amdgcn_permlane32_swap(__float_as_uint(a2), __float_as_uint(a3), false, false);
+    const float s01 = __uint_as_float(p[0]) + __uint_as_float(p[1]);     // lanes 0..31: channel 4m, lanes 32..63: channel 4m+1
+    const float s23 = __uint_as_float(q[0]) + __uint_as_float(q[1]);
+    const auto t = __builtin_amdgcn_permlane16_swap(__float_as_uint(s01), __float_as_uint(s23), false, false);  // rows [a0 b0 a2 b2], [a1 b1 a3 b3]
+    return __uint_as_float(t[0]) + __uint_as_float(t[1]);               // rows: 4m, 4m+2, 4m+1, 4m+3
+}
+// end of the wave's tile loop: finish the fold over the remaining pixel bits of a 16-lane row and write the wave's partial row
+// part[0..C) (first quantity), part[C..2C) (second); f1 applies a per-channel factor to the second.
+template <int CL, int G, typename F1>
+__device__ __forceinline__ void rt_write_partials(float (&acc0)[CL / 4], float (&acc1)[CL / 4], float* __restrict__ part, int lane, F1 f1) {
+    constexpr int C = CL * G;
+    const int g = lane & (G - 1), rowi = lane >> 4;
+    const int cofs = rowi == 0 ? 0 : rowi == 1 ? 2 : rowi == 2 ? 1 : 3;
+#pragma unroll
+    for (int m = 0; m < CL / 4; ++m) {
+        float a = acc0[m], b = acc1[m];
+#pragma unroll
+        for (int k = G; k < 16; k <<= 1) { a += __shfl_xor(a, k, 64); b += __shfl_xor(b, k, 64); }
+        if ((lane & 15) < G) { const int c = g * CL + 4 * m + cofs; part[c] = a; part[C + c] = f1(b, c); }
+    }
+}
+// channel c of a row chunk array t[] (2 bf16 per register)
+#define RT_CH(t, c) (((c) & 1) ? rt_hi((t)[(c) >> 1]) : rt_lo((t)[(c) >> 1]))
+// per-channel parameters staged in LDS behind the four wave tiles; the lane's 4 channels 4m..4m+3
+template <int CL> __device__ __forceinline__ float4 rt_par4(const float* L, int g, int m) { return *(const float4*)(L + g * CL + 4 * m); }
+__device__ __forceinline__ float rt_f4(const float4& v, int k) { return k == 0 ? v.x : k == 1 ? v.y : k == 2 ? v.z : v.w; }
+
+// y[n,p,:] = LN_C(x[n,:,p]) * w + b   (x bf16 NCHW, y bf16 NHWC, statistics fp32, two-pass variance); saves mean, rstd.  One tile per wave.
+template <int CL, int G>
+__global__ __launch_bounds__(256, 2) void ln_nchw_to_nhwc_fwd_reg_kernel(const uint16_t* __restrict__ x, const float* __restrict__ w,
+                                                                        const float* __restrict__ b, uint16_t* __restrict__ y,
+                                                                        float* __restrict__ mean, float* __restrict__ rstd,
+                                                                        int N, int P, float eps, int tiles_per_image, int ntiles) {
+    using GE = RtGeom<CL, G>;
+    constexpr int C = GE::C, PW = GE::PW, PITCH = GE::PITCH;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    float* const Lw = (float*)(smem + 4 * GE::LDS_WAVE);
+    float* const Lb = Lw + C;
+    const bool has_tile = blockIdx.x * 4 + wave < ntiles;                                   // a wave without a tile runs on an empty one (rows = 0)
+    const int tile = has_tile ? blockIdx.x * 4 + wave : 0;
+    unsigned char* const T = smem + wave * GE::LDS_WAVE;
+    const int n = tile / tiles_per_image, p0 = (tile - n * tiles_per_image) * PW;
+    const int pp = lane / G, g = lane & (G - 1);
+    const int rows = has_tile ? min(PW, P - p0) : 0;
+    const unsigned rb = (unsigned)P * 2u;                                                   // bytes per channel row
+    const rt_rsrc rx = rt_buf(x + (size_t)n * C * P + p0, (unsigned)(C * P - p0) * 2u);
+    const unsigned vo = 2 * pp < rows ? (unsigned)(g * CL) * rb + (unsigned)pp * 4u : RT_OOB;
+    unsigned v[CL];                                                                         // (pixel p | pixel p+1) of channel c
+#pragma unroll
+    for (int c = 0; c < CL; ++c) v[c] = __builtin_amdgcn_raw_buffer_load_b32(rx, vo, (unsigned)c * rb, 0);
+    for (int i = threadIdx.x; i < C; i += 256) { Lw[i] = w[i]; Lb[i] = b[i]; }              // behind the tile's loads: one memory latency, not two
+    __syncthreads();
+    float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+    for (int c = 0; c < CL; ++c) { s0 += rt_lo(v[c]); s1 += rt_hi(v[c]); }
+    const float mu0 = rt_group_sum<G>(s0) / (float)C, mu1 = rt_group_sum<G>(s1) / (float)C;
+    float q0 = 0.f, q1 = 0.f;
+#pragma unroll
+    for (int c = 0; c < CL; ++c) { const float a = rt_lo(v[c]) - mu0, d = rt_hi(v[c]) - mu1; q0 += a * a; q1 += d * d; }
+    const float r0 = 1.0f / sqrtf(rt_group_sum<G>(q0) / (float)C + eps), r1 = 1.0f / sqrtf(rt_group_sum<G>(q1) / (float)C + eps);
+    {
+        const unsigned so = (g == 0 && 2 * pp < rows) ? (unsigned)pp * 8u : RT_OOB;
+        __builtin_amdgcn_raw_buffer_store_b64(rt_u32x2{__float_as_uint(mu0), __float_as_uint(mu1)}, rt_buf(mean + (size_t)n * P + p0, (unsigned)(P - p0) * 4u), so, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b64(rt_u32x2{__float_as_uint(r0), __float_as_uint(r1)}, rt_buf(rstd + (size_t)n * P + p0, (unsigned)(P - p0) * 4u), so, 0, 0);
+    }
+#pragma unroll
+    for (int j4 = 0; j4 < CL / 8; ++j4) {
+        rt_u32x4 oa, ob;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const float4 w4 = rt_par4<CL>(Lw, g, 2 * j4 + h), b4 = rt_par4<CL>(Lb, g, 2 * j4 + h);
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int c = j4 * 8 + 4 * h + 2 * k;
+                const float w0 = rt_f4(w4, 2 * k), w1 = rt_f4(w4, 2 * k + 1), b0 = rt_f4(b4, 2 * k), b1 = rt_f4(b4, 2 * k + 1);
+                oa[2 * h + k] = rt_pack2((rt_lo(v[c]) - mu0) * r0 * w0 + b0, (rt_lo(v[c + 1]) - mu0) * r0 * w1 + b1);
+                ob[2 * h + k] = rt_pack2((rt_hi(v[c]) - mu1) * r1 * w0 + b0, (rt_hi(v[c + 1]) - mu1) * r1 * w1 + b1);
+            }
+        }
+        *(rt_u32x4*)(T + (2 * pp) * PITCH + g * (CL * 2) + j4 * 16) = oa;
+        *(rt_u32x4*)(T + (2 * pp + 1) * PITCH + g * (CL * 2) + j4 * 16) = ob;
+    }
+    rt_lds_fence();
+    rt_tile_store<C, PW>(T, rt_buf(y + ((size_t)n * P + p0) * C, (unsigned)rows * C * 2u), lane);
+}
+
+// dx[n,:,p] = rstd * (g*w - mean_C(g*w) - xhat * mean_C(g*w*xhat)) (bf16 NCHW) from g (bf16 NHWC), x (bf16 NCHW);
+// part[wave][0..C) = sum_p g * xhat, [C..2C) = sum_p g over the wave's tiles.  Persistent waves (accumulators live in registers).
+template <int CL, int G>
+__global__ __launch_bounds__(256, 2) void ln_nchw_to_nhwc_bwd_reg_kernel(const uint16_t* __restrict__ gy, const uint16_t* __restrict__ x,
+                                                                        const float* __restrict__ w, const float* __restrict__ mean,
+                                                                        const float* __restrict__ rstd, uint16_t* __restrict__ dx,
+                                                                        float* __restrict__ part, int N, int P, int tiles_per_image, int ntiles) {
+    using GE = RtGeom<CL, G>;
+    constexpr int C = GE::C, PW = GE::PW, PITCH = GE::PITCH;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    float* const Lw = (float*)(smem + 4 * GE::LDS_WAVE);
+    bool staged = false;                                                       // w -> LDS behind the first tile's loads (each wave meets the barrier once)
+    unsigned char* const T = smem + wave * GE::LDS_WAVE;
+    const unsigned lds_T = (unsigned)(uintptr_t)SLAK_LDS(unsigned char, smem) + (unsigned)wave * GE::LDS_WAVE;
+    RtDmaPlan<C, PW> plan; rt_dma_plan(plan, lane);
+    const int pp = lane / G, g = lane & (G - 1);
+    const unsigned rb = (unsigned)P * 2u;
+    float accw[CL / 4], accb[CL / 4];
+#pragma unroll
+    for (int m = 0; m < CL / 4; ++m) { accw[m] = 0.f; accb[m] = 0.f; }
+    const int gwave = blockIdx.x * 4 + wave, nwaves = gridDim.x * 4;
+    for (int tile = gwave; tile < ntiles; tile += nwaves) {
+        const int n = tile / tiles_per_image, p0 = (tile - n * tiles_per_image) * PW;
+        const int rows = min(PW, P - p0);
+        rt_tile_dma<C, PW>(plan, gy + ((size_t)n * P + p0) * C, (unsigned)rows * C * 2u, lds_T);
+        const rt_rsrc rx = rt_buf(x + (size_t)n * C * P + p0, (unsigned)(C * P - p0) * 2u);
+        const bool valid = 2 * pp < rows;
+        const unsigned vo = valid ? (unsigned)(g * CL) * rb + (unsigned)pp * 4u : RT_OOB;
+        unsigned xv[CL];
+#pragma unroll
+        for (int c = 0; c < CL; ++c) xv[c] = __builtin_amdgcn_raw_buffer_load_b32(rx, vo, (unsigned)c * rb, 0);
+        const unsigned so = valid ? (unsigned)pp * 8u : RT_OOB;
+        const rt_u32x2 mu2 = __builtin_amdgcn_raw_buffer_load_b64(rt_buf(mean + (size_t)n * P + p0, (unsigned)(P - p0) * 4u), so, 0, 0);
+        const rt_u32x2 r2 = __builtin_amdgcn_raw_buffer_load_b64(rt_buf(rstd + (size_t)n * P + p0, (unsigned)(P - p0) * 4u), so, 0, 0);
+        const float mu0 = __uint_as_float(mu2[0]), mu1 = __uint_as_float(mu2[1]), r0 = __uint_as_float(r2[0]), r1 = __uint_as_float(r2[1]);
+        if (!staged) { for (int i = threadIdx.x; i < C; i += 256) Lw[i] = w[i]; __syncthreads(); staged = true; }
+        rt_dma_wait();
+        // g is read from the LDS tile in both passes (rows past the image were written as zeros: g = 0 there); x stays packed in registers
+        const unsigned char* const ra = T + (2 * pp) * PITCH + g * (CL * 2);
+        float s10 = 0.f, s11 = 0.f, s20 = 0.f, s21 = 0.f;
+#pragma unroll
+        for (int j4 = 0; j4 < CL / 8; ++j4) {
+            const rt_u32x4 ta = *(const rt_u32x4*)(ra + j4 * 16), tb = *(const rt_u32x4*)(ra + PITCH + j4 * 16);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const float4 w4 = rt_par4<CL>(Lw, g, 2 * j4 + h);
+#pragma unroll
+                for (int k4 = 0; k4 < 4; ++k4) {
+                    const int k = 4 * h + k4, c = 8 * j4 + k;
+                    const float gw0 = RT_CH(ta, k) * rt_f4(w4, k4), gw1 = RT_CH(tb, k) * rt_f4(w4, k4);
+                    s10 += gw0; s11 += gw1;
+                    s20 += gw0 * ((rt_lo(xv[c]) - mu0) * r0); s21 += gw1 * ((rt_hi(xv[c]) - mu1) * r1);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);                                  // one octet's LDS reads and unpacked values live at a time
+        }
+        const float m10 = rt_group_sum<G>(s10) / (float)C, m11 = rt_group_sum<G>(s11) / (float)C;
+        const float m20 = rt_group_sum<G>(s20) / (float)C, m21 = rt_group_sum<G>(s21) / (float)C;
+        // second pass from the PACKED registers again: without this the compiler keeps the unpacked fp32 values of the first pass alive
+#pragma unroll
+        for (int c = 0; c < CL; ++c) asm volatile("" : "+v"(xv[c]));
+        const rt_rsrc rdx = rt_buf(dx + (size_t)n * C * P + p0, (unsigned)(C * P - p0) * 2u);
+#pragma unroll
+        for (int j4 = 0; j4 < CL / 8; ++j4) {
+            const rt_u32x4 ta = *(const rt_u32x4*)(ra + j4 * 16), tb = *(const rt_u32x4*)(ra + PITCH + j4 * 16);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const float4 w4 = rt_par4<CL>(Lw, g, 2 * j4 + h);
+                float tw[4], ts[4];
+#pragma unroll
+                for (int k4 = 0; k4 < 4; ++k4) {
+                    const int k = 4 * h + k4, c = 8 * j4 + k;
+                    const float wc = rt_f4(w4, k4);
+                    const float g0 = RT_CH(ta, k), g1 = RT_CH(tb, k);
+                    const float xh0 = (rt_lo(xv[c]) - mu0) * r0, xh1 = (rt_hi(xv[c]) - mu1) * r1;
+                    __builtin_amdgcn_raw_buffer_store_b32(rt_pack2(r0 * (g0 * wc - m10 - xh0 * m20), r1 * (g1 * wc - m11 - xh1 * m21)), rdx, vo, (unsigned)c * rb, 0);
+                    tw[k4] = g0 * xh0 + g1 * xh1; ts[k4] = g0 + g1;
+                }
+                accw[2 * j4 + h] += rt_fold4(tw[0], tw[1], tw[2], tw[3]);
+                accb[2 * j4 + h] += rt_fold4(ts[0], ts[1], ts[2], ts[3]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        rt_lds_fence();                                                        // tile consumed: the next iteration's DMA may overwrite it
+    }
+    if (!staged) { for (int i = threadIdx.x; i < C; i += 256) Lw[i] = w[i]; __syncthreads(); }       // a wave without tiles still stages its share
+    rt_write_partials<CL, G>(accw, accb, part + (size_t)gwave * 2 * C, lane, [](float a, int) { return a; });
+}
+
+// out[n,c,p] (fp32 NCHW) = shortcut[n,c,p] + scale[n] * gamma[c] * z[n,p,c] (bf16 NHWC); optional bf16 copy of out.  One tile per wave.
+template <int CL, int G, typename Tsc>
+__global__ __launch_bounds__(256, 2) void scale_residual_fwd_reg_kernel(const Tsc* __restrict__ sc, const uint16_t* __restrict__ z,
+                                                                       const float* __restrict__ gamma, const float* __restrict__ scale,
+                                                                       float* __restrict__ out, uint16_t* __restrict__ out16,
+                                                                       int N, int P, int tiles_per_image, int ntiles) {
+    using GE = RtGeom<CL, G>;
+    constexpr int C = GE::C, PW = GE::PW, PITCH = GE::PITCH;
+    constexpr bool SC32 = sizeof(Tsc) == 4;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    float* const Lg = (float*)(smem + 4 * GE::LDS_WAVE);
+    const bool has_tile = blockIdx.x * 4 + wave < ntiles;                                   // a wave without a tile runs on an empty one (rows = 0)
+    const int tile = has_tile ? blockIdx.x * 4 + wave : 0;
+    unsigned char* const T = smem + wave * GE::LDS_WAVE;
+    const int n = tile / tiles_per_image, p0 = (tile - n * tiles_per_image) * PW;
+    const int pp = lane / G, g = lane & (G - 1);
+    const int rows = has_tile ? min(PW, P - p0) : 0;
+    {
+        RtDmaPlan<C, PW> plan; rt_dma_plan(plan, lane);
+        rt_tile_dma<C, PW>(plan, z + ((size_t)n * P + p0) * C, (unsigned)rows * C * 2u,
+                           (unsigned)(uintptr_t)SLAK_LDS(unsigned char, smem) + (unsigned)wave * GE::LDS_WAVE);
+    }
+    const float sn = scale ? scale[n] : 1.0f;
+    const unsigned P1 = (unsigned)P;
+    const bool valid = 2 * pp < rows;
+    const unsigned e0 = (unsigned)(g * CL) * P1 + 2u * (unsigned)pp;                     // element offset of the lane's first pixel
+    const unsigned vo4 = valid ? e0 * 4u : RT_OOB, vo2 = valid ? e0 * 2u : RT_OOB;
+    const rt_rsrc rsc = rt_buf(sc + (size_t)n * C * P + p0, (unsigned)(C * P - p0) * (unsigned)sizeof(Tsc));
+    const rt_rsrc ro = rt_buf(out + (size_t)n * C * P + p0, (unsigned)(C * P - p0) * 4u);
+    const rt_rsrc ro16 = rt_buf(out16 ? out16 + (size_t)n * C * P + p0 : nullptr, out16 ? (unsigned)(C * P - p0) * 2u : 0u);
+    float sx[CL], sy[CL];                        // every channel row of the lane in flight at once (one memory latency for the whole tile)
+#pragma unroll
+    for (int c = 0; c < CL; ++c) {
+        if constexpr (SC32) { const rt_u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rsc, vo4, (unsigned)c * P1 * 4u, 0); sx[c] = __uint_as_float(v[0]); sy[c] = __uint_as_float(v[1]); }
+        else { const unsigned v = __builtin_amdgcn_raw_buffer_load_b32(rsc, vo2, (unsigned)c * P1 * 2u, 0); sx[c] = rt_lo(v); sy[c] = rt_hi(v); }
+    }
+    for (int i = threadIdx.x; i < C; i += 256) Lg[i] = gamma[i];
+    __syncthreads();
+    rt_dma_wait();
+#pragma unroll
+    for (int j4 = 0; j4 < CL / 8; ++j4) {
+        const rt_u32x4 ta = *(const rt_u32x4*)(T + (2 * pp) * PITCH + g * (CL * 2) + j4 * 16);
+        const rt_u32x4 tb = *(const rt_u32x4*)(T + (2 * pp + 1) * PITCH + g * (CL * 2) + j4 * 16);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const float4 g4 = rt_par4<CL>(Lg, g, 2 * j4 + h);
+#pragma unroll
+            for (int k4 = 0; k4 < 4; ++k4) {
+                const int k = 4 * h + k4, c = j4 * 8 + k;
+                const float gm = rt_f4(g4, k4) * sn;
+                const float ox = sx[c] + gm * RT_CH(ta, k), oy = sy[c] + gm * RT_CH(tb, k);
+                __builtin_amdgcn_raw_buffer_store_b64(rt_u32x2{__float_as_uint(ox), __float_as_uint(oy)}, ro, vo4, (unsigned)c * P1 * 4u, 0);
+                if (out16) __builtin_amdgcn_raw_buffer_store_b32(rt_pack2(ox, oy), ro16, vo2, (unsigned)c * P1 * 2u, 0);
+            }
+        }
+    }
+}
+
+// dz[n,p,c] (bf16 NHWC) = scale[n] * gamma[c] * d[n,c,p], d = dout (fp32 NCHW) [+ dout16 (bf16 NCHW), the sum written to dsum];
+// part[wave][0..C) = sum scale * d * z, [C..2C) = gamma * sum scale * d.  Persistent waves; z and dz share the wave's LDS tile.
+template <int CL, int G>
+__global__ __launch_bounds__(256, 2) void scale_residual_bwd_reg_kernel(const float* __restrict__ dout, const uint16_t* __restrict__ dout16,
+                                                                       float* __restrict__ dsum, const uint16_t* __restrict__ z,
+                                                                       const float* __restrict__ gamma, const float* __restrict__ scale,
+                                                                       uint16_t* __restrict__ dz, float* __restrict__ part,
+                                                                       int N, int P, int tiles_per_image, int ntiles) {
+    using GE = RtGeom<CL, G>;
+    constexpr int C = GE::C, PW = GE::PW, PITCH = GE::PITCH;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    float* const Lg = (float*)(smem + 4 * GE::LDS_WAVE);
+    bool staged = false;                                                       // gamma -> LDS behind the first tile's loads
+    unsigned char* const T = smem + wave * GE::LDS_WAVE;
+    const unsigned lds_T = (unsigned)(uintptr_t)SLAK_LDS(unsigned char, smem) + (unsigned)wave * GE::LDS_WAVE;
+    RtDmaPlan<C, PW> plan; rt_dma_plan(plan, lane);
+    const int pp = lane / G, g = lane & (G - 1);
+    const unsigned P1 = (unsigned)P;
+    float accg[CL / 4], accs[CL / 4];
+#pragma unroll
+    for (int m = 0; m < CL / 4; ++m) { accg[m] = 0.f; accs[m] = 0.f; }
+    const int gwave = blockIdx.x * 4 + wave, nwaves = gridDim.x * 4;
+    for (int tile = gwave; tile < ntiles; tile += nwaves) {
+        const int n = tile / tiles_per_image, p0 = (tile - n * tiles_per_image) * PW;
+        const int rows = min(PW, P - p0);
+        rt_tile_dma<C, PW>(plan, z + ((size_t)n * P + p0) * C, (unsigned)rows * C * 2u, lds_T);
+        const float sn = scale ? scale[n] : 1.0f;
+        const bool valid = 2 * pp < rows;
+        const unsigned e0 = (unsigned)(g * CL) * P1 + 2u * (unsigned)pp;
+        const unsigned vo4 = valid ? e0 * 4u : RT_OOB, vo2 = valid ? e0 * 2u : RT_OOB;
+        const rt_rsrc rd = rt_buf(dout + (size_t)n * C * P + p0, (unsigned)(C * P - p0) * 4u);
+        const rt_rsrc rd16 = rt_buf(dout16 ? dout16 + (size_t)n * C * P + p0 : nullptr, dout16 ? (unsigned)(C * P - p0) * 2u : 0u);
+        const rt_rsrc rds = rt_buf(dout16 ? dsum + (size_t)n * C * P + p0 : nullptr, dout16 ? (unsigned)(C * P - p0) * 4u : 0u);
+        rt_u32x2 dv[CL]; unsigned dh[CL];        // every channel row of the lane in flight at once
+#pragma unroll
+        for (int c = 0; c < CL; ++c) {
+            dv[c] = __builtin_amdgcn_raw_buffer_load_b64(rd, vo4, (unsigned)c * P1 * 4u, 0);                       // lanes past the image: zeros
+            dh[c] = dout16 ? __builtin_amdgcn_raw_buffer_load_b32(rd16, vo2, (unsigned)c * P1 * 2u, 0) : 0u;
+        }
+        if (!staged) { for (int i = threadIdx.x; i < C; i += 256) Lg[i] = gamma[i]; __syncthreads(); staged = true; }
+        rt_dma_wait();
+#pragma unroll
+        for (int j4 = 0; j4 < CL / 8; ++j4) {
+            unsigned char* const tpa = T + (2 * pp) * PITCH + g * (CL * 2) + j4 * 16;
+            unsigned char* const tpb = tpa + PITCH;
+            const rt_u32x4 ta = *(const rt_u32x4*)tpa, tb = *(const rt_u32x4*)tpb;       // rows past the image: zeros
+            float d0[8], d1[8], tg[8], ts[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const unsigned c = (unsigned)(j4 * 8 + k);
+                float vx = __uint_as_float(dv[c][0]), vy = __uint_as_float(dv[c][1]);
+                if (dout16) {
+                    vx += rt_lo(dh[c]); vy += rt_hi(dh[c]);
+                    __builtin_amdgcn_raw_buffer_store_b64(rt_u32x2{__float_as_uint(vx), __float_as_uint(vy)}, rds, vo4, c * P1 * 4u, 0);
+                }
+                d0[k] = vx * sn; d1[k] = vy * sn;                                       // the per-image scale goes into the terms: a wave's tiles span images
+                tg[k] = d0[k] * RT_CH(ta, k) + d1[k] * RT_CH(tb, k);
+                ts[k] = d0[k] + d1[k];
+            }
+            rt_u32x4 oa, ob;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const float4 g4 = rt_par4<CL>(Lg, g, 2 * j4 + h);
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    oa[2 * h + k] = rt_pack2(rt_f4(g4, 2 * k) * d0[4 * h + 2 * k], rt_f4(g4, 2 * k + 1) * d0[4 * h + 2 * k + 1]);
+                    ob[2 * h + k] = rt_pack2(rt_f4(g4, 2 * k) * d1[4 * h + 2 * k], rt_f4(g4, 2 * k + 1) * d1[4 * h + 2 * k + 1]);
+                }
+            }
+            *(rt_u32x4*)tpa = oa; *(rt_u32x4*)tpb = ob;
+            accg[2 * j4] += rt_fold4(tg[0], tg[1], tg[2], tg[3]);
+            accg[2 * j4 + 1] += rt_fold4(tg[4], tg[5], tg[6], tg[7]);
+            accs[2 * j4] += rt_fold4(ts[0], ts[1], ts[2], ts[3]);
+            accs[2 * j4 + 1] += rt_fold4(ts[4], ts[5], ts[6], ts[7]);
+        }
+        rt_lds_fence();
+        rt_tile_store<C, PW>(T, rt_buf(dz + ((size_t)n * P + p0) * C, (unsigned)rows * C * 2u), lane);
+        rt_lds_fence();
+    }
+    if (!staged) { for (int i = threadIdx.x; i < C; i += 256) Lg[i] = gamma[i]; __syncthreads(); }   // a wave without tiles
+    rt_write_partials<CL, G>(accg, accs, part + (size_t)gwave * 2 * C, lane, [Lg](float a, int c) { return a * Lg[c]; });
+}
+
+// ---- host side ---------------------------------------------------------------------------------------------------------------
+template <typename K> static int rt_persistent_grid(K k, size_t lds, int ntiles) {
+    static thread_local int per_cu = 0, cus = 0;                       // one (kernel, lds) pair per instantiation of this template
+    if (per_cu == 0) {
+        int dev = 0; hipDeviceProp_t prop;
+        cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
+        int nb = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k, 256, lds) != hipSuccess || nb < 1) nb = 1;
+        per_cu = nb;
+    }
+    int grid = per_cu * cus; if (grid > 2048) grid = 2048;             // <= 8192 partial rows (slak_block_tail_workspace_bytes)
+    const int need = (ntiles + 3) / 4;
+    return need < grid ? need : grid;
+}
+template <typename K> static int rt_set_lds(K k, size_t lds) {
+    return (lds > 48 * 1024 && hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) ? 1 : 0;
+}
+
+template <int CL, int G>
+static int launch_ln_fwd_reg(const uint16_t* x, const float* w, const float* b, uint16_t* y, float* mean, float* rstd, int N, int P, float eps, hipStream_t st) {
+    using GE = RtGeom<CL, G>;
+    const int tpi = (P + GE::PW - 1) / GE::PW, ntiles = N * tpi;
+    const size_t lds = (size_t)4 * GE::LDS_WAVE + (size_t)2 * GE::C * sizeof(float);
+    auto k = ln_nchw_to_nhwc_fwd_reg_kernel<CL, G>;
+    if (rt_set_lds(k, lds)) return SLAK_ERR_LAUNCH;
+    hipLaunchKernelGGL(k, dim3((unsigned)((ntiles + 3) / 4)), dim3(256), lds, st, x, w, b, y, mean, rstd, N, P, eps, tpi, ntiles);
+    SLAK_LAUNCH_CHECK();
+    return SLAK_OK;
+}
+template <int CL, int G>
+static int launch_ln_bwd_reg(const uint16_t* g, const uint16_t* x, const float* w, const float* mean, const float* rstd, uint16_t* dx, float* part,
+                             int* rows, int N, int P, hipStream_t st) {
+    using GE = RtGeom<CL, G>;
+    const int tpi = (P + GE::PW - 1) / GE::PW, ntiles = N * tpi;
+    const size_t lds = (size_t)4 * GE::LDS_WAVE + (size_t)2 * GE::C * sizeof(float);
+    auto k = ln_nchw_to_nhwc_bwd_reg_kernel<CL, G>;
+    if (rt_set_lds(k, lds)) return SLAK_ERR_LAUNCH;
+    const int grid = rt_persistent_grid(k, lds, ntiles);
+    hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(256), lds, st, g, x, w, mean, rstd, dx, part, N, P, tpi, ntiles);
+    SLAK_LAUNCH_CHECK();
+    *rows = grid * 4;
+    return SLAK_OK;
+}
+template <int CL, int G, typename Tsc>
+static int launch_sr_fwd_reg(const Tsc* sc, const uint16_t* z, const float* gamma, const float* scale, float* out, uint16_t* out16, int N, int P, hipStream_t st) {
+    using GE = RtGeom<CL, G>;
+    const int tpi = (P + GE::PW - 1) / GE::PW, ntiles = N * tpi;
+    const size_t lds = (size_t)4 * GE::LDS_WAVE + (size_t)2 * GE::C * sizeof(float);
+    auto k = scale_residual_fwd_reg_kernel<CL, G, Tsc>;
+    if (rt_set_lds(k, lds)) return SLAK_ERR_LAUNCH;
+    hipLaunchKernelGGL(k, dim3((unsigned)((ntiles + 3) / 4)), dim3(256), lds, st, sc, z, gamma, scale, out, out16, N, P, tpi, ntiles);
+    SLAK_LAUNCH_CHECK();
+    return SLAK_OK;
+}
+template <int CL, int G>
+static int launch_sr_bwd_reg(const float* dout, const uint16_t* dout16, float* dsum, const uint16_t* z, const float* gamma, const float* scale,
+                             uint16_t* dz, float* part, int* rows, int N, int P, hipStream_t st) {
+    using GE = RtGeom<CL, G>;
+    const int tpi = (P + GE::PW - 1) / GE::PW, ntiles = N * tpi;
+    const size_t lds = (size_t)4 * GE::LDS_WAVE + (size_t)2 * GE::C * sizeof(float);
+    auto k = scale_residual_bwd_reg_kernel<CL, G>;
+    if (rt_set_lds(k, lds)) return SLAK_ERR_LAUNCH;
+    const int grid = rt_persistent_grid(k, lds, ntiles);
+    hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(256), lds, st, dout, dout16, dsum, z, gamma, scale, dz, part, N, P, tpi, ntiles);
+    SLAK_LAUNCH_CHECK();
+    *rows = grid * 4;
+    return SLAK_OK;
+}
+
+// The instantiations: (channels per lane, lanes per pixel) per channel count.  SLAK_ERR_UNSUPPORTED = none for this C (the caller
+// runs the LDS-tile kernels of block_tail.hip).
+#define SLAK_RT_DISPATCH(C, CALL)                 \
+    if (P & 1) return SLAK_ERR_UNSUPPORTED;       \
+    switch (C) {                                  \
+        case 64: { CALL(32, 2); }                 \
+        case 96: { CALL(48, 2); }                 \
+        case 128: { CALL(64, 2); }                \
+        case 192: { CALL(48, 4); }                \
+        case 256: { CALL(64, 4); }                \
+        case 384: { CALL(48, 8); }                \
+        case 512: { CALL(64, 8); }                \
+        default: return SLAK_ERR_UNSUPPORTED;     \
+    }
+
+int launch_ln_nchw_to_nhwc_fwd_reg(const void* x, const float* w, const float* b, void* y, float* mean, float* rstd, int N, int C, int P, float eps, hipStream_t st) {
+#define CALL(CL, G) return launch_ln_fwd_reg<CL, G>((const uint16_t*)x, w, b, (uint16_t*)y, mean, rstd, N, P, eps, st)
+    SLAK_RT_DISPATCH(C, CALL)
+#undef CALL
+}
+int launch_ln_nchw_to_nhwc_bwd_reg(const void* g, const void* x, const float* w, const float* mean, const float* rstd, void* dx, float* part, int* rows,
+                                   int N, int C, int P, hipStream_t st) {
+#define CALL(CL, G) return launch_ln_bwd_reg<CL, G>((const uint16_t*)g, (const uint16_t*)x, w, mean, rstd, (uint16_t*)dx, part, rows, N, P, st)
+    SLAK_RT_DISPATCH(C, CALL)
+#undef CALL
+}
+int launch_scale_residual_fwd_reg(const void* sc, int sc_dtype, const void* z, const float* gamma, const float* scale, float* out, void* out16,
+                                  int N, int C, int P, hipStream_t st) {
+    if (sc_dtype == SLAK_F32) {
+#define CALL(CL, G) return launch_sr_fwd_reg<CL, G, float>((const float*)sc, (const uint16_t*)z, gamma, scale, out, (uint16_t*)out16, N, P, st)
+        SLAK_RT_DISPATCH(C, CALL)
+#undef CALL
+    } else if (sc_dtype == SLAK_BF16) {
+#define CALL(CL, G) return launch_sr_fwd_reg<CL, G, bf16_t>((const bf16_t*)sc, (const uint16_t*)z, gamma, scale, out, (uint16_t*)out16, N, P, st)
+        SLAK_RT_DISPATCH(C, CALL)
+#undef CALL
+    }
+    return SLAK_ERR_UNSUPPORTED;
+}
+int launch_scale_residual_bwd_reg(const float* dout, const void* dout16, float* dsum, const void* z, const float* gamma, const float* scale, void* dz,
+                                  float* part, int* rows, int N, int C, int P, hipStream_t st) {
+#define CALL(CL, G) return launch_sr_bwd_reg<CL, G>(dout, (const uint16_t*)dout16, dsum, (const uint16_t*)z, gamma, scale, (uint16_t*)dz, part, rows, N, P, st)
+    SLAK_RT_DISPATCH(C, CALL)
+#undef CALL
+}
+
+}  // namespace slak

@@ -65,7 +65,8 @@ __device__ __forceinline__ void store_tile(const f32x16& acc, const uint16_t* __
     }
     // lanes l31 (lhi 0) and l31 + 32 (lhi 1) hold the same row: quads (0,1) -> lhi 0 keeps columns 0..7, lhi 1 gets 8..15; quads (2,3)
     // likewise 16..23 / 24..31.  v_permlane32_swap(a, b): a of lanes 32..63 <-> b of lanes 0..31.
-    auto swap = [](unsigned& a, unsigned& b) { asm volatile("v_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b)); };
+    // (the builtin, not inline asm: the compiler then inserts the wait states the swap needs after a VALU write of its operands)
+    auto swap = [](unsigned& a, unsigned& b) { const auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false); a = r[0]; b = r[1]; };
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         swap(py[4 * h + 0], py[4 * h + 2]); swap(py[4 * h + 1], py[4 * h + 3]);

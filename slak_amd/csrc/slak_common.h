@@ -173,4 +173,12 @@ __device__ __forceinline__ void wgrad_finish(const float* partial, float* dw, un
 }
 #endif
 
+// block_tail_reg.hip: register-tile block-tail kernels (C <= 256 classes); SLAK_ERR_UNSUPPORTED = no instantiation for C
+int launch_ln_nchw_to_nhwc_fwd_reg(const void* x, const float* w, const float* b, void* y, float* mean, float* rstd, int N, int C, int P, float eps, hipStream_t st);
+int launch_ln_nchw_to_nhwc_bwd_reg(const void* g, const void* x, const float* w, const float* mean, const float* rstd, void* dx, float* part, int* rows,
+                                   int N, int C, int P, hipStream_t st);       // *rows = partial rows written ([rows][2C]); the caller reduces them
+int launch_scale_residual_fwd_reg(const void* sc, int sc_dtype, const void* z, const float* gamma, const float* scale, float* out, void* out16,
+                                  int N, int C, int P, hipStream_t st);
+int launch_scale_residual_bwd_reg(const float* dout, const void* dout16, float* dsum, const void* z, const float* gamma, const float* scale, void* dz,
+                                  float* part, int* rows, int N, int C, int P, hipStream_t st);
 }  // namespace slak
