@@ -187,6 +187,14 @@ int slak_linear_nt_supported(int M, int N, int K, int gelu);
 int slak_linear_nt(const void* x_bf16, const void* wt_bf16, const void* bias_bf16 /* or NULL */, void* y_bf16, void* gelu_out_bf16 /* or NULL */,
                    int M, int N, int K, void* stream);
 
+/* Weight gradient of the pointwise Linear layers (models/SLaK.py:117-118 pwconv1 / pwconv2; autograd's dW = dY^T X):
+ * d[N1][N2] (fp32) = x1^T x2 over the M rows of x1 [M][N1] and x2 [M][N2] (bf16, row-major), fp32 accumulate, summed in a fixed
+ * order (deterministic).  Covered: N1 and N2 multiples of 192, or one of them 96 and the other a multiple of 384 (the ConvNeXt widths
+ * 96 * 2^k and their 4x expansions); M >= 32; anything else returns SLAK_ERR_UNSUPPORTED (library GEMM). */
+int slak_linear_wgrad_supported(int M, int N1, int N2);
+size_t slak_linear_wgrad_workspace_bytes(int M, int N1, int N2);
+int slak_linear_wgrad(const void* x1_bf16, const void* x2_bf16, float* d, int M, int N1, int N2, void* workspace, size_t workspace_bytes, void* stream);
+
 /* GELU backward (exact erf form, nn.GELU()) fused with the bias gradient of the Linear in front of it (models/SLaK.py:158-160):
  * dy1 = dact * gelu'(y1); dbias[col] = sum_rows dy1.  [rows][cols] bf16 contiguous, cols % 8 == 0. */
 size_t slak_gelu_bwd_workspace_bytes(int rows, int cols);

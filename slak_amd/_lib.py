@@ -95,6 +95,9 @@ SIGNATURES = {
     "slak_dwconv2d_tri_backward_filter": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     "slak_linear_nt_supported": (_i, [_i, _i, _i, _i]),
     "slak_linear_nt": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    "slak_linear_wgrad_supported": (_i, [_i, _i, _i]),
+    "slak_linear_wgrad_workspace_bytes": (_sz, [_i, _i, _i]),
+    "slak_linear_wgrad": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _sz, _vp]),
     "slak_scale_residual_forward": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "slak_scale_residual_backward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _sz, _vp]),
 }

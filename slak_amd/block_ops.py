@@ -273,9 +273,10 @@ class _LinearSplitK(torch.autograd.Function):
         S = max(1, M // 6272)
         while S > 1 and M % S:
             S -= 1
-        if S > 1:
+        dw = linear_wgrad(dy2.contiguous(), x2.contiguous()) if dy2.dtype == torch.bfloat16 and x2.dtype == torch.bfloat16 else None
+        if dw is None and S > 1:
             dw = torch.bmm(dy2.view(S, M // S, -1).transpose(1, 2), x2.view(S, M // S, -1)).sum(0, dtype=torch.float32)
-        else:
+        elif dw is None:
             dw = torch.mm(dy2.t(), x2).float()
         db = dy2.sum(0, dtype=torch.float32) if ctx.has_bias else None
         return dx, dw, db
@@ -494,6 +495,26 @@ _SPLITK_ROWS = int(_os.environ.get("SLAK_SPLITK_ROWS", "6272"))     # rows per s
 use_skinny_linear = os.environ.get("SLAK_SKINNY_LINEAR", "1") != "0"      # the streaming kernels of csrc/linear_skinny.hip for the stage-1 pointwise convs (-0.16 ms per SLaK-T step same-box vs the TUNED library GEMMs); 0: library GEMMs everywhere
 
 
+use_linear_wgrad = os.environ.get("SLAK_LINEAR_WGRAD", "1") != "0"        # csrc/linear_wgrad.hip for the pointwise weight gradients; 0: the library's split-K batched GEMM
+
+
+def linear_wgrad(dy, x):
+    """dW (fp32, [N1][N2]) = dy^T x for bf16 dy [M][N1], x [M][N2] through slak_linear_wgrad; None when the shape is not covered."""
+    if not (use_linear_wgrad and dy.is_cuda and dy.dtype == torch.bfloat16 and x.dtype == torch.bfloat16 and dy.is_contiguous() and x.is_contiguous()):
+        return None
+    M, N1 = dy.shape
+    N2 = x.shape[1]
+    L = _lib.lib()
+    if x.shape[0] != M or not L.slak_linear_wgrad_supported(M, N1, N2):
+        return None
+    d = torch.empty((N1, N2), dtype=torch.float32, device=dy.device)
+    ws, nb = _workspace(L.slak_linear_wgrad_workspace_bytes(M, N1, N2), dy.device)
+    with torch.cuda.device(dy.device):
+        _lib.check(L.slak_linear_wgrad(dy.data_ptr(), x.data_ptr(), d.data_ptr(), M, N1, N2, ws.data_ptr() if ws is not None else None, nb,
+                                       _stream(dy.device)), "slak_linear_wgrad")
+    return d
+
+
 def linear_nt_covers(x, N, gelu=False):
     """Whether slak_linear_nt takes x (..., K) bf16 against a weight with N output features."""
     if not (use_skinny_linear and x.is_cuda and x.dtype == torch.bfloat16 and x.is_contiguous()):
@@ -549,6 +570,9 @@ def _mlp_bwd(saved, dz, db2=None):
         S -= 1
 
     def wgrad(dy, x):
+        d = linear_wgrad(dy, x)
+        if d is not None:
+            return d
         if S > 1:
             return torch.bmm(dy.view(S, M // S, -1).transpose(1, 2), x.view(S, M // S, -1)).sum(0, dtype=torch.float32)
         return torch.mm(dy.t(), x).float()

@@ -181,4 +181,8 @@ int launch_scale_residual_fwd_reg(const void* sc, int sc_dtype, const void* z, c
                                   int N, int C, int P, hipStream_t st);
 int launch_scale_residual_bwd_reg(const float* dout, const void* dout16, float* dsum, const void* z, const float* gamma, const float* scale, void* dz,
                                   float* part, int* rows, int N, int C, int P, hipStream_t st);
+// linear_wgrad.hip: D[N1][N2] (fp32) = X1^T X2 over M rows (the pointwise Linear weight gradient)
+bool linear_wgrad_supported(int M, int N1, int N2);
+size_t linear_wgrad_workspace(int M, int N1, int N2);
+int launch_linear_wgrad(const void* x1, const void* x2, float* d, int M, int N1, int N2, void* ws, size_t ws_bytes, hipStream_t st);
 }  // namespace slak

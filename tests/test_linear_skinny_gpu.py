@@ -68,3 +68,31 @@ def test_mlp_with_skinny_linears_matches_library_path(gpu):
     for a, b, n in zip(res[True], res[False], ("z", "dt", "dw1", "db1", "dw2", "db2")):
         scale = max(1.0, b.abs().max().item())
         assert (a - b).abs().max().item() <= 2e-2 * scale, n
+
+
+WGRAD_SHAPES = [(6272, 384, 96), (6272, 96, 384), (3136, 768, 192), (3136, 192, 768), (1568, 1536, 384), (1568, 384, 1536), (784, 3072, 768),
+                (1000, 384, 96), (777, 192, 192), (32, 192, 384), (128 * 196, 1536, 384)]
+
+
+@pytest.mark.parametrize("M,N1,N2", WGRAD_SHAPES)
+def test_linear_wgrad_matches_fp32(M, N1, N2, gpu):
+    """slak_linear_wgrad = dY^T X in fp32 (models/SLaK.py:117-118 weight gradients): bf16 products are exact in fp32, so the only
+    difference from the fp64 reference is fp32 summation order: 1e-5 of the result's scale."""
+    from slak_amd import block_ops
+    torch.manual_seed(M + N1)
+    dy = torch.randn(M, N1, device=gpu).bfloat16()
+    x = (torch.randn(M, N2, device=gpu) + 0.25).bfloat16()
+    d = block_ops.linear_wgrad(dy, x)
+    assert d is not None and d.dtype == torch.float32 and d.shape == (N1, N2)
+    ref = dy.double().t() @ x.double()
+    err = (d.double() - ref).abs().max().item()
+    assert err <= 1e-5 * ref.abs().max().item() + 1e-6, err
+    d2 = block_ops.linear_wgrad(dy, x)
+    assert torch.equal(d, d2), "fixed summation order: bitwise repeatable"
+
+
+def test_linear_wgrad_unsupported_shapes_fall_back(gpu):
+    from slak_amd import block_ops, _lib
+    L = _lib.lib()
+    assert not L.slak_linear_wgrad_supported(4096, 128, 512) and not L.slak_linear_wgrad_supported(16, 384, 96)
+    assert block_ops.linear_wgrad(torch.zeros(4096, 128, device=gpu).bfloat16(), torch.zeros(4096, 512, device=gpu).bfloat16()) is None
