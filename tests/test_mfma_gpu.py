@@ -172,7 +172,7 @@ def test_mfma_identity_and_adjoint_full_size(mfma_only, gpu):
 def test_tri_dwconv_matches_the_three_branch_convs(N, C, H, W, K, dtype, gpu):
     """block_ops.tri_dwconv (one launch for Kx5 + 5xK + 5x5 on the 14x14 class; three launches elsewhere): outputs are the
     per-branch kernels' outputs bit for bit, the input gradient is their sum (added in fp32 before the single rounding), the
-    weight gradients are the per-branch ones."""
+    weight gradients are the per-branch ones (up to fp32 summation order where the one-launch weight-gradient kernel runs)."""
     from slak_amd import block_ops
     ops = _ops()
     torch.manual_seed(N + K)
@@ -187,7 +187,10 @@ def test_tri_dwconv_matches_the_three_branch_convs(N, C, H, W, K, dtype, gpu):
     scale = max(1.0, ref_dx.abs().max().item())
     assert (x.grad.float() - ref_dx).abs().max().item() <= 2e-2 * scale
     for dy, w in zip(dys, ws):
-        assert torch.equal(w.grad, ops.dwconv2d_backward_filter(dy, x.detach(), w.detach()))
+        # the one-launch weight gradient (slak_dwconv2d_tri_backward_filter) sums the same fp32 products in another order than the
+        # per-branch kernel: equal up to fp32 summation order, bit-identical where the three per-branch launches run
+        ref = ops.dwconv2d_backward_filter(dy, x.detach(), w.detach())
+        assert (w.grad - ref).abs().max().item() <= 1e-5 * max(1.0, ref.abs().max().item())
     # where the one-launch kernel ran: the summed gradient is rounded ONCE -> the oracle's half-ulp bound holds for the sum
     L = _lib()
     kind = L.lib().slak_dwconv2d_tri_supported(L.SLAK_BF16 if dtype == torch.bfloat16 else L.SLAK_F16, N, C, H, W, K)
