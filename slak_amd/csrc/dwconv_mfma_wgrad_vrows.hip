@@ -3,18 +3,15 @@
 //
 //   G_r[o, i] = sum_{n,u} dY[o, u] * X[i, u + r - 2]      (o, i = image rows, u = image columns)      dw[tau, r] = sum_o G_r[o, o+tau-padL]
 // The contraction index u runs along image rows, so both MFMA operands are plain 16-byte reads of 8 consecutive elements of a
-// row -- if the shifted operand X[i, u + s] is available at a 4-byte aligned address for every tap shift s = -2..2.  Even
-// shifts are whole dwords (the fragment is a selection of four dwords out of three aligned 16-byte chunks held in registers:
-// 4-byte LDS reads at a 16-byte-multiple lane stride are four-way bank conflicted and are avoided entirely, see the k-loop);
-// for the odd ones a SECOND copy of the plane, shifted by one element, is fetched by the DMA itself:
-// `buffer_load_dwordx4 ... lds` accepts a 2-byte-aligned source (tools/dma_probe.hip, shift = 1), so copy c1[j] = x[j-1]
-// costs one more L2->LDS transfer and no LDS pass.  (dwconv_mfma_wgrad_dma.hip transposes both planes LDS->LDS for this case
-// and spends twice the horizontal kernel's time per plane doing it.)
+// row, and the shifted operand X[i, u + s] of tap shift s = -2..2 is formed IN REGISTERS from the lane's previous / current / next
+// aligned 16-byte chunks: even shifts are a selection of four of their dwords, odd shifts four v_alignbit_b32 (a 16-bit funnel shift
+// of neighbouring dwords) -- 8 VALU instructions per k-step beside 5 MFMAs.  (4-byte LDS reads at a 16-byte-multiple lane stride are
+// four-way bank conflicted and are avoided entirely; round 1 fetched a SECOND, one-element-shifted copy of the plane by DMA for the
+// odd taps: half again the L2->LDS volume and LDS space for -4 % of the kernel time.  dwconv_mfma_wgrad_dma.hip transposes both
+// planes LDS->LDS for this case and spends twice the horizontal kernel's time doing it.)
 // LDS image of a plane: rows of CPR 16-byte chunks (W/8 data chunks + pad, CPR odd: conflict-free row-per-lane reads); the
 // pad chunks are never written, so X[i, -2..-1] and X[i, W..W+1] read zeros and dY is zero for the k beyond W.  Each lane
 // of a DMA instruction fetches ONE chunk (row = g / CPR, chunk = g % CPR of its global lane number g; pad lanes inactive).
-// The two elements a shifted copy drags in from the neighbouring row (c1[0] = x[row-1][W-1], c1[W+1] = x[row+1][0]) are
-// masked in the fragments of the two taps that can touch them.
 // Everything else -- per-tap accumulators in registers over the slice, diagonal sums through a skewed per-wave tile,
 // write-through partials, last-arriver reduction -- is dwconv_mfma_wgrad_dma.hip's.
 #include "mfma_common.h"
@@ -23,6 +20,7 @@ namespace slak {
 
 constexpr int VR_NB_DEFAULT = 2;        // ring depth: the next nb-1 planes stream in while the current one is consumed (env SLAK_VROWS_NB)
 constexpr int VR_MAX_IPW = 8;           // DMA instructions per wave per plane (upper bound)
+constexpr int VR_COPIES = 2;            // plane images per slot: dY, X
 
 struct WgradRowsParams {
     const void* dy; const void* x; float* partial; float* dw; unsigned* counters;
@@ -33,6 +31,7 @@ struct WgradRowsParams {
     int planes_per_wg, slices;
     int nb;                // ring depth (slots)
     unsigned tensor_bytes;
+    int dbg;               // SLAK_VROWS_DBG (timing experiments): 1 = no k-loop, 2 = no DMA, 4 = no epilogue
 };
 
 template <typename T>
@@ -43,7 +42,7 @@ __global__ __launch_bounds__(MF_THREADS, 3) void dwconv_mfma_wgrad_vrows_kernel(
     const int HW = p.H * p.W, ntap = p.kh * p.kw;
     const unsigned PB = (unsigned)p.CPR * 16;                     // row pitch (bytes)
     const unsigned copy_b = (unsigned)p.ipc * 1024;               // one plane copy (whole DMA instructions)
-    const unsigned slot_b = 3 * copy_b;                           // [dY][X][X shifted by one element]
+    const unsigned slot_b = VR_COPIES * copy_b;                   // [dY][X]
     const unsigned ring_b = 64;                                   // 64 zero bytes in front: "row -1" of the first plane
     unsigned live_b = (unsigned)p.nb * slot_b; if (live_b < MF_WAVES * 32 * 64 * 4) live_b = MF_WAVES * 32 * 64 * 4;   // >= the epilogue scratch
     float* dwl = (float*)(LB + ring_b + live_b);                  // [MF_WAVES][ntap]
@@ -69,7 +68,7 @@ __global__ __launch_bounds__(MF_THREADS, 3) void dwconv_mfma_wgrad_vrows_kernel(
         rs_x[0] = __builtin_amdgcn_readfirstlane((int)(b & 0xffffffffu)); rs_x[1] = __builtin_amdgcn_readfirstlane((int)((b >> 32) & 0xffffu));
         rs_x[2] = rs_dy[2]; rs_x[3] = 0x00020000;
     }
-    const int ninstr = 3 * p.ipc, DC = p.W / 8;
+    const int ninstr = VR_COPIES * p.ipc, DC = p.W / 8;
     int ins_src[VR_MAX_IPW]; unsigned ins_dst[VR_MAX_IPW]; int ins_t[VR_MAX_IPW]; bool ins_ok[VR_MAX_IPW];
 #pragma unroll
     for (int k = 0; k < VR_MAX_IPW; ++k) {
@@ -78,8 +77,8 @@ __global__ __launch_bounds__(MF_THREADS, 3) void dwconv_mfma_wgrad_vrows_kernel(
         const int t = live ? id / p.ipc : 0, ii = live ? id - t * p.ipc : 0;
         const int g = ii * 64 + lane, row = g / p.CPR, piece = g - row * p.CPR;
         ins_t[k] = live ? t : -1;
-        ins_ok[k] = live && row < p.H && piece < (t == 2 ? DC + 1 : DC);      // the shifted copy needs one more chunk for x[W-1]
-        ins_src[k] = row * p.W * 2 + piece * 16 - (t == 2 ? 2 : 0);            // (bytes from the plane start; -2: c1[j] = x[j-1])
+        ins_ok[k] = live && row < p.H && piece < DC;
+        ins_src[k] = row * p.W * 2 + piece * 16;                               // (bytes from the plane start)
         ins_dst[k] = (unsigned)t * copy_b + (unsigned)ii * 1024;
     }
     const unsigned lds_base = (unsigned)(uintptr_t)SLAK_LDS(uint16_t, lds);
@@ -91,10 +90,8 @@ __global__ __launch_bounds__(MF_THREADS, 3) void dwconv_mfma_wgrad_vrows_kernel(
 #pragma unroll
         for (int k = 0; k < VR_MAX_IPW; ++k) {
             if (ins_t[k] >= 0) {                                      // wave-uniform
-                int off = (int)gbase + ins_src[k];
-                if (off < 0) off = 0;                                 // first chunk of the whole tensor: fetched unshifted, fixed up below
-                if (off + 16 > (int)p.tensor_bytes) off = (int)p.tensor_bytes - 16;   // last chunk of the shifted copy: likewise
-                if (ins_ok[k]) {
+                const int off = (int)gbase + ins_src[k];
+                if (ins_ok[k] && !(p.dbg & 2)) {
                     if (ins_t[k] == 0) lds_dma16((unsigned)off, rs_dy, __builtin_amdgcn_readfirstlane(slot + ins_dst[k]));
                     else lds_dma16((unsigned)off, rs_x, __builtin_amdgcn_readfirstlane(slot + ins_dst[k]));
                 }
@@ -114,20 +111,16 @@ __global__ __launch_bounds__(MF_THREADS, 3) void dwconv_mfma_wgrad_vrows_kernel(
 
     // ---- fragment addresses: lane -> image row (o resp. i), 8 consecutive k = columns 16*ks + 8*lhi .. +7 -------------------
     const unsigned a_off = (unsigned)(mt * 32 + l31) * PB + lhi * 16;               // dY copy
-    const unsigned x_off = copy_b + (unsigned)(nt * 32 + l31) * PB + lhi * 16;      // X copy (c0); c1 = + copy_b
-    // the two stray elements of the shifted copy: tap 1 (s = -1) reads c1[u]: u = 0 is x[row-1][W-1] -> k-step 0, lhi 0,
-    // element 0; tap 3 (s = +1) reads c1[u + 2]: u = W-1 is x[row+1][0] -> k-step (W-1)/16, lhi ((W-1)%16)/8, element 7
-    const unsigned m_first = lhi == 0 ? 0xffff0000u : 0xffffffffu;
-    const int ks_last = (p.W - 1) >> 4;
-    const unsigned m_last = lhi == (((p.W - 1) & 15) >> 3) ? 0x0000ffffu : 0xffffffffu;
+    const unsigned x_off = copy_b + (unsigned)(nt * 32 + l31) * PB + lhi * 16;      // X copy
     // Fragments are assembled from ALIGNED 16-byte reads only.  A lane's addresses are a multiple of 16 bytes apart from its neighbours'
     // (one image row per lane), so a 4-byte ds_read hits 16 of the 64 banks: four-way conflicts, 8 cycles per wave instruction against
     // 4 for a conflict-free b128 that moves four times the data (the first version fetched the +-2 taps with four b32 reads each and
     // spent 5/6 of its LDS time on them).  A tap shift of 2 elements is exactly one dword, so with the previous / current / next
     // chunk in registers every tap is a selection of four dwords:
-    //   s=-2: {P.w, C.x, C.y, C.z}   s=0: C   s=+2: {C.y, C.z, C.w, N.x}        (P, C, N: chunks of the X copy)
-    //   s=-1: C1                              s=+1: {C1.y, C1.z, C1.w, N1.x}      (C1, N1: chunks of the copy shifted by one element)
-    // and P of the next k-step is N of this one.
+    //   s=-2: {P.w, C.x, C.y, C.z}   s=0: C   s=+2: {C.y, C.z, C.w, N.x}        (P, C, N: the lane's previous / own / next chunk of X)
+    // an odd shift is the 16-bit funnel shift of neighbouring dwords (v_alignbit_b32 hi, lo, 16 = {lo.hi16, hi.lo16}):
+    //   s=-1: {P.w:C.x, C.x:C.y, C.y:C.z, C.z:C.w}                  s=+1: {C.x:C.y, C.y:C.z, C.z:C.w, C.w:N.x}
+    // The pad chunk at the end of every row (zeros) is P of a row's first chunk and N of its last.
     auto rdq = [&](unsigned addr) -> u32x4 { return *(const u32x4*)(LB + addr); };
     auto rd16 = [&](unsigned addr) -> s16x8 { return __builtin_bit_cast(s16x8, rdq(addr)); };
     auto frag = [](unsigned d0, unsigned d1, unsigned d2, unsigned d3) -> s16x8 { return __builtin_bit_cast(s16x8, u32x4{d0, d1, d2, d3}); };
@@ -138,57 +131,41 @@ __global__ __launch_bounds__(MF_THREADS, 3) void dwconv_mfma_wgrad_vrows_kernel(
         wg_barrier();                                             // everyone's have; everyone is done with the slot refilled next
         issue_plane(it + p.nb - 1);                               // streams in while this and the following planes are consumed
         const unsigned slot = ring_b + (unsigned)(it % p.nb) * slot_b;
-        if (n_begin + it == 0 && c == 0) {
-            // the very first chunk of the tensor could not be fetched from offset -2: it landed unshifted -> shift it by hand
-            if (tid == 0) {
-                uint16_t* q = (uint16_t*)(LB + slot + 2 * copy_b);
-                for (int e = 7; e > 0; --e) q[e] = q[e - 1];
-                q[0] = 0;
-            }
-            wg_barrier();
-        }
-        if (n_begin + it == p.N - 1 && c == p.C - 1) {
-            // ... and the very last chunk of the shifted copy (it would read past the tensor): it landed as x[W-8..W-1] of the last
-            // row; the copy needs x[W-1] in its first element (the rest of that chunk is never used unmasked)
-            if (tid == 0) {
-                uint16_t* q = (uint16_t*)(LB + slot + 2 * copy_b + (unsigned)(p.H - 1) * PB + (unsigned)(p.W / 8) * 16);
-                q[0] = q[7];
-            }
-            wg_barrier();
-        }
+        if (p.dbg & 1) continue;
         const unsigned ab = slot + a_off, xb = slot + x_off;
         // k-loop, pinned software pipeline: the five 16-byte reads of the next k-step are issued one behind each of this k-step's MFMAs
-        const unsigned c1b = xb + copy_b;
+        auto sh = [](unsigned hi, unsigned lo) -> unsigned { return __builtin_amdgcn_alignbit(hi, lo, 16); };
+        auto taps = [&](s16x8 (&b)[NG], const u32x4& P, const u32x4& C, const u32x4& N) {
+            b[0] = frag(P[3], C[0], C[1], C[2]);
+            b[1] = frag(sh(C[0], P[3]), sh(C[1], C[0]), sh(C[2], C[1]), sh(C[3], C[2]));
+            b[2] = __builtin_bit_cast(s16x8, C);
+            b[3] = frag(sh(C[1], C[0]), sh(C[2], C[1]), sh(C[3], C[2]), sh(N[0], C[3]));
+            b[4] = frag(C[1], C[2], C[3], N[0]);
+        };
         s16x8 a = rd16(ab), b[NG];
-        u32x4 P = rdq(xb - 16), C = rdq(xb), N = rdq(xb + 16), C1 = rdq(c1b), N1 = rdq(c1b + 16);
-        C1[0] &= m_first;
-        if (ks_last == 0) N1[0] &= m_last;
-        b[0] = frag(P[3], C[0], C[1], C[2]); b[1] = __builtin_bit_cast(s16x8, C1); b[2] = __builtin_bit_cast(s16x8, C);
-        b[3] = frag(C1[1], C1[2], C1[3], N1[0]); b[4] = frag(C[1], C[2], C[3], N[0]);
+        {
+            const u32x4 P = rdq(xb - 16), C = rdq(xb), N = rdq(xb + 16);
+            taps(b, P, C, N);
+        }
         __builtin_amdgcn_sched_barrier(0);
         for (int ks = 0; ks < p.KS; ++ks) {
             const int kn = ks + 1 < p.KS ? ks + 1 : ks;            // last k-step: re-read (discarded)
-            const unsigned xo = xb + (unsigned)kn * 32, co = c1b + (unsigned)kn * 32;
+            const unsigned xo = xb + (unsigned)kn * 32;
             const s16x8 an = rd16(ab + (unsigned)kn * 32);
             __builtin_amdgcn_sched_barrier(0);
             acc[0] = mfma32<T>(a, b[0], acc[0]);
-            const u32x4 Cn = rdq(xo);
+            const u32x4 Pn = rdq(xo - 16);
             __builtin_amdgcn_sched_barrier(0);
             acc[1] = mfma32<T>(a, b[1], acc[1]);
-            const u32x4 Nn = rdq(xo + 16);
+            const u32x4 Cn = rdq(xo);
             __builtin_amdgcn_sched_barrier(0);
             acc[2] = mfma32<T>(a, b[2], acc[2]);
-            u32x4 C1n = rdq(co);
+            const u32x4 Nn = rdq(xo + 16);
             __builtin_amdgcn_sched_barrier(0);
             acc[3] = mfma32<T>(a, b[3], acc[3]);
-            u32x4 N1n = rdq(co + 16);
             __builtin_amdgcn_sched_barrier(0);
             acc[4] = mfma32<T>(a, b[4], acc[4]);
-            if (kn == ks_last) N1n[0] &= m_last;
-            b[0] = frag(N[3], Cn[0], Cn[1], Cn[2]);               // this k-step's N is the next one's P
-            b[1] = __builtin_bit_cast(s16x8, C1n); b[2] = __builtin_bit_cast(s16x8, Cn);
-            b[3] = frag(C1n[1], C1n[2], C1n[3], N1n[0]); b[4] = frag(Cn[1], Cn[2], Cn[3], Nn[0]);
-            N = Nn;
+            taps(b, Pn, Cn, Nn);
             a = an;
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -196,6 +173,7 @@ __global__ __launch_bounds__(MF_THREADS, 3) void dwconv_mfma_wgrad_vrows_kernel(
     wait_vmcnt<0>();
     __syncthreads();                                              // the ring is dead: its space becomes the diagonal-sum scratch
 
+    if (p.dbg & 4) return;
     // ---- diagonal sums through a skewed per-wave tile (see dwconv_mfma_wgrad_dma.hip) -----------------------------------------
     float* mine = dwl + wave * ntap;
     float* tile = scratch + wave * (32 * 64);
@@ -243,7 +221,7 @@ static bool fill_vrows_params(WgradRowsParams& p, const ConvDims& d, int residen
     p.CPR = d.W / 8 + 1; if (!(p.CPR & 1)) ++p.CPR;                   // odd number of 16-byte chunks per row, >= 1 pad chunk
     p.ipc = (d.H * p.CPR + 63) / 64;
     p.KS = (d.W + 15) / 16;
-    if ((3 * p.ipc + MF_WAVES - 1) / MF_WAVES > VR_MAX_IPW) return false;
+    if ((VR_COPIES * p.ipc + MF_WAVES - 1) / MF_WAVES > VR_MAX_IPW) return false;
     int slices = resident_wgs / d.C; if (slices < 1) slices = 1;
     if (slices > d.N) slices = d.N;
     const int per = (d.N + slices - 1) / slices;
@@ -251,11 +229,12 @@ static bool fill_vrows_params(WgradRowsParams& p, const ConvDims& d, int residen
     p.tensor_bytes = (unsigned)((size_t)d.N * d.C * d.H * d.W * 2);
     static const int nb_env = [] { const char* e = getenv("SLAK_VROWS_NB"); const int v = e ? atoi(e) : VR_NB_DEFAULT; return v < 2 ? 2 : (v > 4 ? 4 : v); }();
     p.nb = nb_env;
+    { static const int dbg = [] { const char* e = getenv("SLAK_VROWS_DBG"); return e ? atoi(e) : 0; }(); p.dbg = dbg; }
     return (size_t)d.N * d.C * d.H * d.W * 2 < 0x7fffffffull;         // (signed source offsets in the DMA plan)
 }
 
 static size_t vrows_lds_bytes(const WgradRowsParams& p) {
-    size_t live = (size_t)p.nb * 3 * p.ipc * 1024, scratch = (size_t)MF_WAVES * 32 * 64 * 4;
+    size_t live = (size_t)p.nb * VR_COPIES * p.ipc * 1024, scratch = (size_t)MF_WAVES * 32 * 64 * 4;
     if (live < scratch) live = scratch;
     return 64 + live + (size_t)MF_WAVES * p.kh * p.kw * 4 + 32;
 }
