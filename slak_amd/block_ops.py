@@ -294,6 +294,42 @@ def _ptr3(ts):
     return arr
 
 
+class BnCounterPool:
+    """The step counters (``num_batches_tracked``) of many BatchNorms as views of ONE int64 tensor that is bumped by a single launch per
+    forward pass (nn.BatchNorm / the reference bump one 0-dim tensor per BatchNorm: 54 launches per SLaK-T step; ``torch._foreach_add_``
+    takes its slow path for them).  Each BatchNorm keeps its own 0-dim ``num_batches_tracked`` buffer (state-dict layout unchanged); the
+    owner (slak_model.SLaK) calls ``begin_forward()`` once per training forward, the fused BatchNorm op calls ``bump_once()``.  A buffer
+    that stopped being a view (``module.to()`` re-creates buffers) is simply not covered any more and is bumped the ordinary way."""
+
+    def __init__(self, bns):
+        self.bns = list(bns)
+        self.flat = torch.stack([bn.num_batches_tracked.detach().reshape(()) for bn in self.bns]).contiguous()
+        for i, bn in enumerate(self.bns):
+            bn._buffers["num_batches_tracked"] = self.flat[i]
+            bn._slak_ctr_pool = self
+            bn._slak_ctr_index = i
+        self.generation = 0
+        self.bumped = -1
+
+    def _is_view(self, bn):
+        t = bn._buffers.get("num_batches_tracked")
+        return t is not None and t.device == self.flat.device and t.data_ptr() == self.flat.data_ptr() + 8 * bn._slak_ctr_index
+
+    def covers(self, bns):
+        return all(getattr(bn, "_slak_ctr_pool", None) is self and self._is_view(bn) for bn in bns)
+
+    def intact(self):
+        return self._is_view(self.bns[0]) and self._is_view(self.bns[-1])
+
+    def begin_forward(self):
+        self.generation += 1
+
+    def bump_once(self):
+        if self.bumped != self.generation:
+            self.flat.add_(1)
+            self.bumped = self.generation
+
+
 class _BranchBN3(torch.autograd.Function):
     """Training-mode batch statistics (cross-rank when ``group`` is given: one all-reduce of 6C+1 floats forward and 4C backward,
     instead of SyncBatchNorm's three all_gathers + three all_reduces per block), running-stat update, fused scale/shift/add."""
@@ -312,8 +348,11 @@ class _BranchBN3(torch.autograd.Function):
         eps = float(bns[0].eps)
         momentum = bns[0].momentum
         ctrs = [bn.num_batches_tracked for bn in bns if bn.track_running_stats and bn.num_batches_tracked is not None]
-        if ctrs:
-            torch._foreach_add_(ctrs, 1)                          # one launch for the three counters (54 -> 18 launches per SLaK-T step)
+        pool = getattr(bns[0], "_slak_ctr_pool", None)
+        if pool is not None and len(ctrs) == len(bns) and pool.covers(bns):
+            pool.bump_once()                                      # every pooled counter of the model in one launch per forward pass
+        elif ctrs:
+            torch._foreach_add_(ctrs, 1)
         if momentum is None:                                     # cumulative moving average, as nn.BatchNorm
             momentum = 1.0 / float(bns[0].num_batches_tracked.item())
         ws, nb = _workspace(L.slak_bn3_workspace_bytes(N, C), dev)

@@ -301,7 +301,25 @@ class SLaK(nn.Module):
                 m.merge_kernel()
         return self
 
+    def _begin_counters(self):
+        """One launch per training forward for all the step counters of the blocks' fused BatchNorms (block_ops.BnCounterPool)."""
+        from . import block_ops
+        pool = getattr(self, "_bn_pool", None)
+        if pool is None or not pool.intact():
+            bns = []
+            for m in self.modules():
+                if (isinstance(m, ReparamLargeKernelConv) and m.fused_bn and m.Decom and hasattr(m, "small_conv") and hasattr(m.LoRA1, "bn")):
+                    trio = [m.LoRA1.bn, m.LoRA2.bn, m.small_conv.bn]
+                    if all(b.track_running_stats and b.num_batches_tracked is not None and b.num_batches_tracked.is_cuda for b in trio):
+                        bns += trio
+            pool = block_ops.BnCounterPool(bns) if bns and len({b.num_batches_tracked.device for b in bns}) == 1 else None
+            object.__setattr__(self, "_bn_pool", pool)           # (not a submodule / buffer: stays out of state_dict)
+        if pool is not None:
+            pool.begin_forward()
+
     def forward_features(self, x):
+        if self.training and x.is_cuda:
+            self._begin_counters()
         for i in range(4):
             x = self.stages[i](self.downsample_layers[i](x))
         return self.norm(x.mean([-2, -1]))

@@ -233,3 +233,36 @@ def test_lowp_weight_cache_follows_optimizer_and_mask_updates(gpu):
         assert torch.equal(z1, z1_ref) and not torch.equal(z0, z1)
     finally:
         block_ops.cache_lowp_weights = False
+
+
+def test_bn_counter_pool_counts_like_batchnorm(gpu):
+    """block_ops.BnCounterPool: every fused BatchNorm's num_batches_tracked advances by one per training forward (as nn.BatchNorm's
+    does), stays a 0-dim entry of the state dict, survives load_state_dict, and falls back to per-tensor bumps after module.to()."""
+    from slak_amd import slak_model
+    slak_model.ReparamLargeKernelConv.fused_bn = True
+    try:
+        torch.manual_seed(0)
+        m = slak_model.SLaK(in_chans=3, num_classes=4, depths=[1, 1, 1, 1], dims=[16, 32, 32, 32], drop_path_rate=0.0, kernel_size=(13, 13, 7, 7, 5),
+                            Decom=True, bn=True, lowp_dwconv=True).to(gpu).train()
+        x = torch.randn(2, 3, 224, 224, device=gpu)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            for _ in range(3):
+                m(x).sum().backward()
+        ctrs = {k: v for k, v in m.state_dict().items() if k.endswith("num_batches_tracked")}
+        assert len(ctrs) == 12 and all(v.dim() == 0 and int(v) == 3 for v in ctrs.values())
+        assert m._bn_pool is not None and m._bn_pool.flat.numel() == 12
+        sd = {k: (v + 5 if k.endswith("num_batches_tracked") else v) for k, v in m.state_dict().items()}
+        m.load_state_dict(sd)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            m(x).sum().backward()
+        assert all(int(v) == 9 for k, v in m.state_dict().items() if k.endswith("num_batches_tracked"))
+        m = m.to(gpu)                                            # same device: buffers keep their storage
+        m.float()                                                # re-creates nothing for int64 buffers either; a real move would: emulate it
+        for mod in m.modules():
+            if isinstance(mod, torch.nn.BatchNorm2d):
+                mod._buffers["num_batches_tracked"] = mod.num_batches_tracked.clone()
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            m(x).sum().backward()
+        assert all(int(v) == 10 for k, v in m.state_dict().items() if k.endswith("num_batches_tracked"))
+    finally:
+        slak_model.ReparamLargeKernelConv.fused_bn = False
