@@ -21,6 +21,10 @@
 //   linear_nt_k96:  K = 96,  N = 32 NT <= 384  (pwconv1 forward [+ GELU], dz . W2):   walks the N/32 column tiles per row block
 //   linear_nt_n96:  N = 96,  K = 96 NKC <= 384 (pwconv2 forward, dy1 . W1):           three accumulators, walks K in 96-column blocks
 #include "mfma_common.h"
+#include <cmath>
+#include <cstring>
+#include <mutex>
+#include <vector>
 
 namespace slak {
 
@@ -37,6 +41,30 @@ __device__ __forceinline__ float gelu_erf(float x) {
     const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
     const float half = 0.5f * poly * e;
     return x * (x >= 0.f ? 1.0f - half : half);
+}
+// GELU of a bf16 VALUE by table: the fused pwconv1 kernel applies nn.GELU() to the ROUNDED pre-activation, a bf16 number, and returns a
+// bf16 number -- a function on 65,536 points.  Below |x| = 2^-9 GELU(x) rounds to x/2, above 16 to x (x > 0) or -0; the table covers
+// 2^-18 <= |x| < 16 (22 exponents x 128 mantissas x 2 signs = 5,632 entries, 11 KB of LDS: what is left beside the weight) so that a
+// whole wave is almost never outside it and takes the short path: four integer VALU instructions + one 2-byte LDS read per element
+// against ~30 fp32 instructions with exp and rcp for gelu_erf.  The table holds the correctly rounded value (host, double precision).
+// The kernel was VALU-bound on the evaluation: 275 us with gelu_erf, 162 us with none, per 154 M elements.
+constexpr unsigned GL_LO = 109u << 7, GL_N = 22u << 7;             // first table magnitude (2^-18), entries per sign
+constexpr int GL_BYTES = 2 * (int)GL_N * 2;
+__device__ __forceinline__ unsigned gelu_lut(const uint16_t* __restrict__ T, unsigned b) {      // b: bf16 bits (upper 16 bits of the register zero)
+    const unsigned mag = b & 0x7fffu, neg = b >> 15;
+    const unsigned idx = mag - GL_LO;                             // wraps for |x| < 2^-9
+    const bool in = idx < GL_N;
+    const unsigned t = T[(in ? idx : 0u) + neg * GL_N];
+    const unsigned small = mag >= 0x100u ? b - 0x80u : (b & 0x8000u);                           // x / 2 (exact; subnormal inputs: signed zero)
+    const unsigned big = neg ? (mag > 0x7f7fu ? (b | 0x40u) : 0x8000u) : b;                     // x, -0, NaN for -inf / NaN
+    return in ? t : (mag < GL_LO ? small : big);
+}
+__device__ __forceinline__ unsigned gelu_lut2(const uint16_t* __restrict__ T, unsigned pair) {
+    const unsigned lo = pair & 0xffffu, hi = pair >> 16;
+    const unsigned il = (lo & 0x7fffu) - GL_LO, ih = (hi & 0x7fffu) - GL_LO;
+    if (__builtin_amdgcn_ballot_w64(il >= GL_N || ih >= GL_N) == 0)                               // (wave-uniform) everything inside the table
+        return (unsigned)T[il + (lo >> 15) * GL_N] | ((unsigned)T[ih + (hi >> 15) * GL_N] << 16);
+    return gelu_lut(T, lo) | (gelu_lut(T, hi) << 16);
 }
 __device__ __forceinline__ float bf16_lo(unsigned v) { return __uint_as_float(v << 16); }
 __device__ __forceinline__ float bf16_hi(unsigned v) { return __uint_as_float(v & 0xffff0000u); }
@@ -136,7 +164,8 @@ __device__ __forceinline__ void flush_tile(const char* ot, uint16_t* __restrict_
 template <bool GELU>
 __global__ __launch_bounds__(LK_THREADS, 1) void linear_nt_k96_kernel(const uint16_t* __restrict__ X, const uint16_t* __restrict__ Wt,
                                                                     const uint16_t* __restrict__ bias, uint16_t* __restrict__ Y,
-                                                                    uint16_t* __restrict__ G, int M, int N, unsigned x_bytes) {
+                                                                    uint16_t* __restrict__ G, int M, int N, unsigned x_bytes,
+                                                                    const uint16_t* __restrict__ gelu_table) {
     constexpr int K = 96, KS = 6;
     extern __shared__ __attribute__((aligned(16))) uint16_t lds[];
     char* const L = (char*)lds;
@@ -159,6 +188,8 @@ __global__ __launch_bounds__(LK_THREADS, 1) void linear_nt_k96_kernel(const uint
     if (tm < ntiles_m) xdma_issue(plan, (unsigned)tm * 32u * K * 2u, M - tm * 32, rsrc, lds_base + xbuf);
     stage_weight(Lw, Wt, N, K, LS_XP, tid, LK_THREADS);
     for (int i = tid; i < N; i += LK_THREADS) ((uint16_t*)(L + bias_b))[i] = bias ? bias[i] : (uint16_t)0;
+    const uint16_t* const glut = (const uint16_t*)(L + bias_b + 1024u + LK_WAVES * (LS_XBUF + LK_OBUF));
+    if constexpr (GELU) for (int i = tid; i < GL_BYTES / 16; i += LK_THREADS) ((u32x4*)glut)[i] = ((const u32x4*)gelu_table)[i];
     __syncthreads();                                                  // the only workgroup barrier
     const uint16_t* const lbias = (const uint16_t*)(L + bias_b);
     const int npairs = N >> 6;                                        // column tiles are flushed in pairs (64 columns = one 128-byte line per row)
@@ -193,10 +224,7 @@ __global__ __launch_bounds__(LK_THREADS, 1) void linear_nt_k96_kernel(const uint
                     const unsigned y01 = pack2<bf16_t>(acc[4 * q + 0] + bf16_lo(bb[0]), acc[4 * q + 1] + bf16_hi(bb[0]));
                     const unsigned y23 = pack2<bf16_t>(acc[4 * q + 2] + bf16_lo(bb[1]), acc[4 * q + 3] + bf16_hi(bb[1]));
                     py[half][2 * q] = y01; py[half][2 * q + 1] = y23;
-                    if constexpr (GELU) {
-                        pg[half][2 * q] = pack2<bf16_t>(gelu_erf(bf16_lo(y01)), gelu_erf(bf16_hi(y01)));
-                        pg[half][2 * q + 1] = pack2<bf16_t>(gelu_erf(bf16_lo(y23)), gelu_erf(bf16_hi(y23)));
-                    }
+                    if constexpr (GELU) { pg[half][2 * q] = gelu_lut2(glut, y01); pg[half][2 * q + 1] = gelu_lut2(glut, y23); }
                 }
             }
             put_tile(ot, py[0], l31, lhi, 0); put_tile(ot, py[1], l31, lhi, 1);
@@ -283,6 +311,32 @@ __global__ __launch_bounds__(LS_THREADS, 1) void linear_nt_n96_kernel(const uint
 
 using namespace slak;
 
+// the GELU table of gelu_lut in device memory (one copy per device, built on first use): entry [sign * GL_N + (mag - GL_LO)] = bf16(GELU(x))
+static const uint16_t* gelu_table_device() {
+    static std::mutex mu;
+    static const uint16_t* tab[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    std::lock_guard<std::mutex> lock(mu);
+    if (tab[dev]) return tab[dev];
+    std::vector<uint16_t> h(2 * GL_N);
+    for (unsigned sgn = 0; sgn < 2; ++sgn)
+        for (unsigned i = 0; i < GL_N; ++i) {
+            const uint32_t bits = ((sgn << 15) | (GL_LO + i)) << 16;
+            float xf; memcpy(&xf, &bits, 4);
+            const double x = xf, g = 0.5 * x * erfc(-x * 0.70710678118654752440);
+            const float gf = (float)g;
+            uint32_t u; memcpy(&u, &gf, 4);
+            u += 0x7fffu + ((u >> 16) & 1u);                      // round to nearest even
+            h[sgn * GL_N + i] = (uint16_t)(u >> 16);
+        }
+    void* d = nullptr;
+    if (hipMalloc(&d, h.size() * 2) != hipSuccess) return nullptr;
+    if (hipMemcpy(d, h.data(), h.size() * 2, hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(d); return nullptr; }
+    tab[dev] = (const uint16_t*)d;
+    return tab[dev];
+}
+
 extern "C" {
 
 int slak_linear_nt_supported(int M, int N, int K, int gelu) {
@@ -303,14 +357,16 @@ int slak_linear_nt(const void* x, const void* wt, const void* bias, void* y, voi
     const unsigned xb = (unsigned)((size_t)M * K * 2);
     auto set_lds = [](const void* k, size_t lds) { return lds <= 48 * 1024 || hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess; };
     if (K == 96 && N % 64 == 0) {
-        const size_t lds = (size_t)N * LS_XP + 1024 + (size_t)LK_WAVES * (LS_XBUF + LK_OBUF);
+        const size_t lds = (size_t)N * LS_XP + 1024 + (size_t)LK_WAVES * (LS_XBUF + LK_OBUF) + (G ? GL_BYTES : 0);
+        const uint16_t* lut = G ? gelu_table_device() : nullptr;
+        if (G && !lut) return SLAK_ERR_LAUNCH;
         int wk = mfma_cu_count(); if (wk * LK_WAVES > tiles) wk = (tiles + LK_WAVES - 1) / LK_WAVES;
         if (G) {
             if (!set_lds((const void*)linear_nt_k96_kernel<true>, lds)) return SLAK_ERR_LAUNCH;
-            hipLaunchKernelGGL((linear_nt_k96_kernel<true>), dim3(wk), dim3(LK_THREADS), lds, st, X, W, B, Y, G, M, N, xb);
+            hipLaunchKernelGGL((linear_nt_k96_kernel<true>), dim3(wk), dim3(LK_THREADS), lds, st, X, W, B, Y, G, M, N, xb, lut);
         } else {
             if (!set_lds((const void*)linear_nt_k96_kernel<false>, lds)) return SLAK_ERR_LAUNCH;
-            hipLaunchKernelGGL((linear_nt_k96_kernel<false>), dim3(wk), dim3(LK_THREADS), lds, st, X, W, B, Y, G, M, N, xb);
+            hipLaunchKernelGGL((linear_nt_k96_kernel<false>), dim3(wk), dim3(LK_THREADS), lds, st, X, W, B, Y, G, M, N, xb, lut);
         }
     } else {
         const size_t lds = (size_t)96 * (K * 2 + 16) + 1024 + (size_t)LS_WAVES * LS_XBUF;
