@@ -11,7 +11,7 @@
 // per direction: a workgroup owns (image n, TP consecutive pixels, all C channels), stages the tile in LDS and transposes
 // through it, so that both the NCHW side (lanes along pixels) and the NHWC side (lanes along channels) are coalesced.
 // LDS pitches are odd in dwords, so row and column walks are both conflict-free.  Per-channel gradient sums (dweight, dbias,
-// dgamma) are written as per-tile partials and added in a fixed order by block_tail_reduce (deterministic, no atomics).
+// dgamma) are written as per-tile partials and added in a fixed order by block_tail_reduce1 (deterministic, no atomics).
 // Activations bf16 (autocast), statistics / residual stream / parameters fp32.
 #include "slak_common.h"
 
@@ -744,38 +744,36 @@ __global__ __launch_bounds__(BT_THREADS) void gelu_bwd_bias_kernel(const uint16_
     }
 }
 
-// Column sums of part[ntiles][width] in a fixed order.  gridDim.y slices of the tile range; with one slice the result goes
-// to out0[j] (j < split) / out1[j - split], with several to out0[slice][width] (a second launch adds the slices).
-__global__ void block_tail_reduce(const float* __restrict__ part, float* __restrict__ out0, float* __restrict__ out1, int split,
-                                  int ntiles, int width) {
-    __shared__ float acc[8][64];
-    const int j = blockIdx.x * 64 + (threadIdx.x & 63), r = threadIdx.x >> 6;       // 8 rows of 64 columns
-    const int chunk = (ntiles + gridDim.y - 1) / gridDim.y;
-    const int t0 = blockIdx.y * chunk, t1 = (t0 + chunk < ntiles) ? t0 + chunk : ntiles;
-    float s = 0.f;
-    if (j < width) for (int t = t0 + r; t < t1; t += 8) s += part[(size_t)t * width + j];
-    acc[r][threadIdx.x & 63] = s;
+constexpr int BT_SLICES = 64;                                   // (workspace head-room kept for older callers' layouts)
+// Column sums of part[ntiles][width] in ONE launch, fixed order: a workgroup owns 32 columns, its 32 row groups add rows g, g + 32, ...
+// (four independent partial sums per thread so that the loads pipeline), the groups are added in order through LDS.  The round-1
+// two-pass version (64 slices, then the slices) cost two ~5 us launches per reduction: 116 launches per SLaK-T step.
+__global__ __launch_bounds__(1024) void block_tail_reduce1(const float* __restrict__ part, float* __restrict__ out0, float* __restrict__ out1, int split,
+                                                           int ntiles, int width) {
+    __shared__ float acc[32][33];
+    const int cx = threadIdx.x & 31, g = threadIdx.x >> 5;
+    const int j = blockIdx.x * 32 + cx;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (j < width) {
+        const float* p = part + j;
+        int t = g;
+        for (; t + 96 < ntiles; t += 128) {
+            s0 += p[(size_t)t * width]; s1 += p[(size_t)(t + 32) * width]; s2 += p[(size_t)(t + 64) * width]; s3 += p[(size_t)(t + 96) * width];
+        }
+        for (; t < ntiles; t += 32) s0 += p[(size_t)t * width];
+    }
+    acc[g][cx] = (s0 + s1) + (s2 + s3);
     __syncthreads();
-    if (r == 0 && j < width) {
+    if (g == 0 && j < width) {
         float t = 0.f;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) t += acc[k][threadIdx.x & 63];
-        if (gridDim.y > 1) out0[(size_t)blockIdx.y * width + j] = t;
-        else if (j < split) out0[j] = t;
-        else out1[j - split] = t;
+        for (int k = 0; k < 32; ++k) t += acc[k][cx];
+        if (j < split) out0[j] = t; else out1[j - split] = t;
     }
 }
-
-constexpr int BT_SLICES = 64;
 static int reduce_partials(const float* part, float* tmp, float* out0, float* out1, int split, int ntiles, int width, hipStream_t st) {
-    const int slices = ntiles >= 8 * BT_SLICES ? BT_SLICES : 1;
-    const dim3 g1((unsigned)((width + 63) / 64), (unsigned)slices);
-    if (slices > 1) {
-        hipLaunchKernelGGL(block_tail_reduce, g1, dim3(512), 0, st, part, tmp, (float*)nullptr, width, ntiles, width);
-        hipLaunchKernelGGL(block_tail_reduce, dim3((unsigned)((width + 63) / 64), 1), dim3(512), 0, st, (const float*)tmp, out0, out1, split, slices, width);
-    } else {
-        hipLaunchKernelGGL(block_tail_reduce, g1, dim3(512), 0, st, part, out0, out1, split, ntiles, width);
-    }
+    (void)tmp;
+    hipLaunchKernelGGL(block_tail_reduce1, dim3((unsigned)((width + 31) / 32)), dim3(1024), 0, st, part, out0, out1, split, ntiles, width);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { set_last_hip_error(e); return SLAK_ERR_LAUNCH; }
     return SLAK_OK;

@@ -91,19 +91,27 @@ __device__ __forceinline__ float rt_fold4(float a0, float a1, float a2, float a3
     const auto t = __builtin_amdgcn_permlane16_swap(__float_as_uint(s01), __float_as_uint(s23), false, false);  // rows [a0 b0 a2 b2], [a1 b1 a3 b3]
     return __uint_as_float(t[0]) + __uint_as_float(t[1]);               // rows: 4m, 4m+2, 4m+1, 4m+3
 }
-// end of the wave's tile loop: finish the fold over the remaining pixel bits of a 16-lane row and write the wave's partial row
-// part[0..C) (first quantity), part[C..2C) (second); f1 applies a per-channel factor to the second.
+// end of the tile loops: finish the fold over the remaining pixel bits of a 16-lane row, add the workgroup's four waves through LDS (the
+// tile area: everyone is done with it) and write ONE partial row per workgroup: part[0..C) (first quantity), part[C..2C) (second); f1
+// applies a per-channel factor to the second.  Every wave of the workgroup must call this (two workgroup barriers).
 template <int CL, int G, typename F1>
-__device__ __forceinline__ void rt_write_partials(float (&acc0)[CL / 4], float (&acc1)[CL / 4], float* __restrict__ part, int lane, F1 f1) {
+__device__ __forceinline__ void rt_write_partials(float (&acc0)[CL / 4], float (&acc1)[CL / 4], float* __restrict__ part, float* L, int wave, int lane, F1 f1) {
     constexpr int C = CL * G;
     const int g = lane & (G - 1), rowi = lane >> 4;
     const int cofs = rowi == 0 ? 0 : rowi == 1 ? 2 : rowi == 2 ? 1 : 3;
+    __syncthreads();
+    float* const mine = L + wave * 2 * C;
 #pragma unroll
     for (int m = 0; m < CL / 4; ++m) {
         float a = acc0[m], b = acc1[m];
 #pragma unroll
         for (int k = G; k < 16; k <<= 1) { a += __shfl_xor(a, k, 64); b += __shfl_xor(b, k, 64); }
-        if ((lane & 15) < G) { const int c = g * CL + 4 * m + cofs; part[c] = a; part[C + c] = f1(b, c); }
+        if ((lane & 15) < G) { const int c = g * CL + 4 * m + cofs; mine[c] = a; mine[C + c] = b; }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * C; i += 256) {
+        const float v = ((L[i] + L[2 * C + i]) + L[4 * C + i]) + L[6 * C + i];
+        part[i] = i < C ? v : f1(v, i - C);
     }
 }
 // channel c of a row chunk array t[] (2 bf16 per register)
@@ -259,7 +267,7 @@ __global__ __launch_bounds__(256, 2) void ln_nchw_to_nhwc_bwd_reg_kernel(const u
         rt_lds_fence();                                                        // tile consumed: the next iteration's DMA may overwrite it
     }
     if (!staged) { for (int i = threadIdx.x; i < C; i += 256) Lw[i] = w[i]; __syncthreads(); }       // a wave without tiles still stages its share
-    rt_write_partials<CL, G>(accw, accb, part + (size_t)gwave * 2 * C, lane, [](float a, int) { return a; });
+    rt_write_partials<CL, G>(accw, accb, part + (size_t)blockIdx.x * 2 * C, (float*)smem, wave, lane, [](float a, int) { return a; });
 }
 
 // out[n,c,p] (fp32 NCHW) = shortcut[n,c,p] + scale[n] * gamma[c] * z[n,p,c] (bf16 NHWC); optional bf16 copy of out.  One tile per wave.
@@ -402,7 +410,7 @@ __global__ __launch_bounds__(256, 2) void scale_residual_bwd_reg_kernel(const fl
         rt_lds_fence();
     }
     if (!staged) { for (int i = threadIdx.x; i < C; i += 256) Lg[i] = gamma[i]; __syncthreads(); }   // a wave without tiles
-    rt_write_partials<CL, G>(accg, accs, part + (size_t)gwave * 2 * C, lane, [Lg](float a, int c) { return a * Lg[c]; });
+    rt_write_partials<CL, G>(accg, accs, part + (size_t)blockIdx.x * 2 * C, (float*)smem, wave, lane, [gamma](float a, int c) { return a * gamma[c]; });
 }
 
 // ---- host side ---------------------------------------------------------------------------------------------------------------
@@ -445,7 +453,7 @@ static int launch_ln_bwd_reg(const uint16_t* g, const uint16_t* x, const float* 
     const int grid = rt_persistent_grid(k, lds, ntiles);
     hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(256), lds, st, g, x, w, mean, rstd, dx, part, N, P, tpi, ntiles);
     SLAK_LAUNCH_CHECK();
-    *rows = grid * 4;
+    *rows = grid;
     return SLAK_OK;
 }
 template <int CL, int G, typename Tsc>
@@ -470,7 +478,7 @@ static int launch_sr_bwd_reg(const float* dout, const uint16_t* dout16, float* d
     const int grid = rt_persistent_grid(k, lds, ntiles);
     hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(256), lds, st, dout, dout16, dsum, z, gamma, scale, dz, part, N, P, tpi, ntiles);
     SLAK_LAUNCH_CHECK();
-    *rows = grid * 4;
+    *rows = grid;
     return SLAK_OK;
 }
 
