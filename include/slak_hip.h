@@ -178,6 +178,19 @@ int slak_scale_residual_backward(const float* dout, const void* dout_bf16, float
                                  const float* sample_scale, void* dz_bf16, float* dgamma, float* dz_colsum, int N, int C, int P,
                                  void* workspace, size_t workspace_bytes, void* stream);
 
+/* Downsample layers (models/SLaK.py:285-311: LayerNorm(C, data_format="channels_first") -> Conv2d(C, C', kernel_size=2, stride=2)).  The
+ * kernel/stride-2 convolution is a GEMM on non-overlapping 2x2 patches; slak_ln_patch_forward normalises the fp32 NCHW input over C and
+ * writes the result (rounded to bf16, as autocast's cast in front of the conv does) directly as that GEMM's operand
+ *     a[n][ho * (W/2) + wo][(kh * 2 + kw) * C + c] = LN(x)[n, c, 2 ho + kh, 2 wo + kw],
+ * so the conv is Y[n] = Wp . a[n]^T (batched library GEMM, NCHW result, Wp[co][(kh*2+kw)*C + c] = weight[co, c, kh, kw]) with no im2col,
+ * layout transposes or casts; _backward takes dL/da in the same layout.  C in {64, 96, 128, 192, 256, 384, 512}, H and W even. */
+int slak_ln_patch_supported(int N, int C, int H, int W);
+int slak_ln_patch_forward(const float* x, const float* weight, const float* bias, void* a_bf16, float* mean, float* rstd,
+                          int N, int C, int H, int W, float eps, void* stream);
+int slak_ln_patch_backward(const void* g_bf16, const float* x, const float* weight, const float* mean, const float* rstd,
+                           float* dx, float* dweight, float* dbias, int N, int C, int H, int W,
+                           void* workspace /* slak_block_tail_workspace_bytes(N, C, H*W) */, size_t workspace_bytes, void* stream);
+
 /* The pointwise convolutions on the large maps (stage 1-2: M = N*H*W rows of C <= 192 or 4C <= 768 channels against a weight of a few
  * hundred KB) are HBM streams, not GEMMs: Y[M,N] = X[M,K] . Wt[N,K]^T (+ bias[N]) with both operands K-contiguous ("NT": pwconv1 /
  * pwconv2 forward take the nn.Linear weight as it is stored, models/SLaK.py:158-160; the data gradients take its transpose), bf16 in

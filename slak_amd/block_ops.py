@@ -486,6 +486,72 @@ def ln_channels_first(x, weight, bias, eps=1e-6, out_dtype=torch.float32):
 
 
 # ------------------------------------------------------------------------------------------------------------------
+# Downsample layers (models/SLaK.py:285-311): LayerNorm(channels_first) -> Conv2d(kernel_size=2, stride=2) as ONE LayerNorm kernel that
+# writes the conv's GEMM operand (the 2x2 patch matrix, bf16) + batched library GEMMs that produce / consume NCHW directly: no MIOpen
+# implicit-GEMM launch, no NCHW<->NHWC transposes around it, no fp32 -> bf16 cast of the LayerNorm output.
+def ln_patch_covers(x):
+    if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.is_contiguous()):
+        return False
+    N, C, H, W = x.shape
+    return bool(_lib.lib().slak_ln_patch_supported(N, C, H, W))
+
+
+class _DownsampleLnConv(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, ln_w, ln_b, conv_w, conv_b, eps):
+        _chk(x, "x", torch.float32); _chk(ln_w, "ln weight", torch.float32); _chk(ln_b, "ln bias", torch.float32)
+        N, C, H, W = x.shape
+        Co = conv_w.shape[0]
+        P4 = (H // 2) * (W // 2)
+        a = torch.empty((N, P4, 4 * C), dtype=torch.bfloat16, device=x.device)
+        mean = torch.empty((N, H * W), dtype=torch.float32, device=x.device)
+        rstd = torch.empty_like(mean)
+        L = _lib.lib()
+        with torch.cuda.device(x.device):
+            _lib.check(L.slak_ln_patch_forward(x.data_ptr(), ln_w.data_ptr(), ln_b.data_ptr(), a.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                                               N, C, H, W, float(eps), _stream(x.device)), "slak_ln_patch_forward")
+        wp = conv_w.detach().permute(0, 2, 3, 1).reshape(Co, 4 * C).to(torch.bfloat16)       # Wp[co][(kh*2+kw)*C + c]
+        if conv_b is not None:                                                                  # bias inside the GEMM (fp32 accumulate, one rounding)
+            y = torch.baddbmm(conv_b.detach().to(torch.bfloat16).view(1, Co, 1).expand(N, Co, P4), wp.unsqueeze(0).expand(N, Co, 4 * C), a.transpose(1, 2))
+        else:
+            y = torch.matmul(wp, a.transpose(1, 2))                                            # [N, Co, P4]: NCHW
+        ctx.save_for_backward(x, ln_w, mean, rstd, a, wp)
+        ctx.has_bias = conv_b is not None
+        return y.view(N, Co, H // 2, W // 2)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, ln_w, mean, rstd, a, wp = ctx.saved_tensors
+        N, C, H, W = x.shape
+        Co = wp.shape[0]
+        P4 = (H // 2) * (W // 2)
+        dy = dy.contiguous()
+        if dy.dtype != torch.bfloat16:
+            dy = dy.to(torch.bfloat16)
+        dy3 = dy.view(N, Co, P4)
+        da = torch.matmul(dy3.transpose(1, 2), wp)                                             # [N, P4, 4C]: dL/da in the patch layout
+        dyt = dy3.permute(1, 0, 2).reshape(Co, N * P4)                                         # (one copy: the reduction runs over n and the pixels)
+        dwp = torch.mm(dyt, a.view(N * P4, 4 * C)).float()
+        dconv_w = dwp.view(Co, 2, 2, C).permute(0, 3, 1, 2).contiguous()
+        dconv_b = dy3.sum((0, 2), dtype=torch.float32) if ctx.has_bias else None
+        dx = torch.empty_like(x)
+        dlw = torch.empty_like(ln_w); dlb = torch.empty_like(ln_w)
+        L = _lib.lib()
+        ws, nb = _workspace(L.slak_block_tail_workspace_bytes(N, C, H * W), x.device)
+        da = da.contiguous()
+        with torch.cuda.device(x.device):
+            _lib.check(L.slak_ln_patch_backward(da.data_ptr(), x.data_ptr(), ln_w.data_ptr(), mean.data_ptr(), rstd.data_ptr(), dx.data_ptr(),
+                                                dlw.data_ptr(), dlb.data_ptr(), N, C, H, W, ws.data_ptr() if ws is not None else None, nb,
+                                                _stream(x.device)), "slak_ln_patch_backward")
+        return dx, dlw, dlb, dconv_w, dconv_b, None
+
+
+def downsample_ln_conv(x, ln_w, ln_b, conv_w, conv_b, eps=1e-6):
+    """conv2d(LN_channels_first(x), conv_w, conv_b, stride=2) for a 2x2 kernel, fp32 NCHW x -> bf16 NCHW (what autocast returns)."""
+    return _DownsampleLnConv.apply(x, ln_w, ln_b, conv_w, conv_b, eps)
+
+
+# ------------------------------------------------------------------------------------------------------------------
 import os as _os
 import weakref as _weakref
 

@@ -907,6 +907,29 @@ int slak_ln_nchw_to_nhwc_backward(const void* g, const void* x, const float* wei
     return reduce_partials(part, part + (size_t)grid * 2 * C, dweight, dbias, C, grid, 2 * C, (hipStream_t)stream);
 }
 
+// LayerNorm(channels_first) of the downsample layers fused with the layout the following Conv2d(k = 2, stride 2) wants as a GEMM operand
+int slak_ln_patch_supported(int N, int C, int H, int W) {
+    if (N <= 0 || H <= 0 || W <= 0 || ((H | W) & 1) || tail_args_ok(N, C, H * W)) return 0;
+    return C == 64 || C == 96 || C == 128 || C == 192 || C == 256 || C == 384 || C == 512;
+}
+int slak_ln_patch_forward(const float* x, const float* weight, const float* bias, void* a_bf16, float* mean, float* rstd,
+                          int N, int C, int H, int W, float eps, void* stream) {
+    if (!x || !weight || !bias || !a_bf16 || !mean || !rstd) return SLAK_ERR_INVALID_ARG;
+    if (!slak_ln_patch_supported(N, C, H, W)) return SLAK_ERR_UNSUPPORTED;
+    return launch_ln_patch_fwd_reg(x, weight, bias, a_bf16, mean, rstd, N, C, H, W, eps, (hipStream_t)stream);
+}
+int slak_ln_patch_backward(const void* g_bf16, const float* x, const float* weight, const float* mean, const float* rstd,
+                           float* dx, float* dweight, float* dbias, int N, int C, int H, int W,
+                           void* workspace, size_t workspace_bytes, void* stream) {
+    if (!g_bf16 || !x || !weight || !mean || !rstd || !dx || !dweight || !dbias) return SLAK_ERR_INVALID_ARG;
+    if (!slak_ln_patch_supported(N, C, H, W)) return SLAK_ERR_UNSUPPORTED;
+    if (!workspace || workspace_bytes < slak_block_tail_workspace_bytes(N, C, H * W)) return SLAK_ERR_WORKSPACE;
+    int rows = 0; float* part = (float*)workspace;
+    const int rc = launch_ln_patch_bwd_reg(g_bf16, x, weight, mean, rstd, dx, part, &rows, N, C, H, W, (hipStream_t)stream);
+    if (rc != SLAK_OK) return rc;
+    return reduce_partials(part, part + (size_t)rows * 2 * C, dweight, dbias, C, rows, 2 * C, (hipStream_t)stream);
+}
+
 int slak_scale_residual_forward(const void* shortcut, int shortcut_dtype, const void* z, const float* gamma, const float* sample_scale,
                                 float* out, void* out_bf16, int N, int C, int P, void* stream) {
     if (!shortcut || !z || !gamma || !out) return SLAK_ERR_INVALID_ARG;

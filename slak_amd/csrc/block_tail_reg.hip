@@ -114,18 +114,65 @@ __device__ __forceinline__ void rt_write_partials(float (&acc0)[CL / 4], float (
         part[i] = i < C ? v : f1(v, i - C);
     }
 }
+// The NCHW operand of the LayerNorm kernels: bf16 (one dword = the lane's two pixels of a channel) or fp32 (two dwords)
+template <bool F32> struct RtX;
+template <> struct RtX<false> {
+    typedef unsigned reg; static constexpr unsigned EB = 2;
+    static __device__ __forceinline__ reg load(rt_rsrc r, unsigned vo, unsigned so) { return __builtin_amdgcn_raw_buffer_load_b32(r, vo, so, 0); }
+    static __device__ __forceinline__ float p0(reg v) { return rt_lo(v); }
+    static __device__ __forceinline__ float p1(reg v) { return rt_hi(v); }
+    static __device__ __forceinline__ void store(rt_rsrc r, unsigned vo, unsigned so, float a, float b) { __builtin_amdgcn_raw_buffer_store_b32(rt_pack2(a, b), r, vo, so, 0); }
+    static __device__ __forceinline__ void opaque(reg& v) { asm volatile("" : "+v"(v)); }
+};
+template <> struct RtX<true> {
+    typedef rt_u32x2 reg; static constexpr unsigned EB = 4;
+    static __device__ __forceinline__ reg load(rt_rsrc r, unsigned vo, unsigned so) { return __builtin_amdgcn_raw_buffer_load_b64(r, vo, so, 0); }
+    static __device__ __forceinline__ float p0(reg v) { return __uint_as_float(v[0]); }
+    static __device__ __forceinline__ float p1(reg v) { return __uint_as_float(v[1]); }
+    static __device__ __forceinline__ void store(rt_rsrc r, unsigned vo, unsigned so, float a, float b) { __builtin_amdgcn_raw_buffer_store_b64(rt_u32x2{__float_as_uint(a), __float_as_uint(b)}, r, vo, so, 0); }
+    static __device__ __forceinline__ void opaque(reg& v) { asm volatile("" : "+v"(v)); }
+};
+// PATCH mode (the downsample layers, models/SLaK.py:285-311: LayerNorm(channels_first) -> Conv2d(k = 2, stride 2)): the NHWC side is the
+// conv's patch matrix A[n][ho * Wo + wo][(kh * 2 + kw) * C + c] -- pixel (h, w)'s C-vector is the segment (h & 1, w & 1) of row (h/2, w/2),
+// still one contiguous run of C elements, so only the row address of a tile row changes.  Byte offset inside the image's [P/4][4C] matrix:
+template <int C> __device__ __forceinline__ unsigned rt_patch_off(int p, int W) {
+    const int h = p / W, w = p - h * W;
+    return (unsigned)((((h >> 1) * (W >> 1) + (w >> 1)) * 4 + (h & 1) * 2 + (w & 1)) * (C * 2));
+}
+template <int C, int PW> __device__ __forceinline__ void rt_dma_plan_patch(RtDmaPlan<C, PW>& d, int lane, int p0, int W, int rows) {
+    constexpr int CD = RtDmaPlan<C, PW>::CD;
+#pragma unroll
+    for (int k = 0; k < RtDmaPlan<C, PW>::NI; ++k) {
+        const int q = 64 * k + lane, r = q / CD, cc = q - r * CD;
+        d.src[k] = r >= PW ? 0xffffffffu : ((cc < CD - 1 && r < rows) ? rt_patch_off<C>(p0 + r, W) + (unsigned)cc * 16u : RT_OOB);
+    }
+}
+template <int C, int PW> __device__ __forceinline__ void rt_tile_store_patch(const unsigned char* T, rt_rsrc r, int p0, int W, int rows, int lane) {
+    constexpr int CPR = C / 8, NCH = PW * CPR, PITCH = C * 2 + 16, RINC = 64 / CPR, CINC = 64 % CPR, NK = (NCH + 63) / 64;
+    int row = lane / CPR, cc = lane - row * CPR;
+#pragma unroll
+    for (int k = 0; k < NK; ++k) {
+        if ((NCH % 64 == 0 || k * 64 + lane < NCH) && row < rows)
+            __builtin_amdgcn_raw_buffer_store_b128(*(const rt_u32x4*)(T + row * PITCH + cc * 16), r, rt_patch_off<C>(p0 + row, W) + (unsigned)cc * 16u, 0, 0);
+        cc += CINC; row += RINC;
+        if (cc >= CPR) { cc -= CPR; ++row; }
+    }
+}
 // channel c of a row chunk array t[] (2 bf16 per register)
 #define RT_CH(t, c) (((c) & 1) ? rt_hi((t)[(c) >> 1]) : rt_lo((t)[(c) >> 1]))
 // per-channel parameters staged in LDS behind the four wave tiles; the lane's 4 channels 4m..4m+3
 template <int CL> __device__ __forceinline__ float4 rt_par4(const float* L, int g, int m) { return *(const float4*)(L + g * CL + 4 * m); }
 __device__ __forceinline__ float rt_f4(const float4& v, int k) { return k == 0 ? v.x : k == 1 ? v.y : k == 2 ? v.z : v.w; }
 
-// y[n,p,:] = LN_C(x[n,:,p]) * w + b   (x bf16 NCHW, y bf16 NHWC, statistics fp32, two-pass variance); saves mean, rstd.  One tile per wave.
-template <int CL, int G>
-__global__ __launch_bounds__(256, 2) void ln_nchw_to_nhwc_fwd_reg_kernel(const uint16_t* __restrict__ x, const float* __restrict__ w,
+// y[n,p,:] = LN_C(x[n,:,p]) * w + b   (x bf16 or fp32 NCHW, y bf16 NHWC or patch matrix, statistics fp32, two-pass variance); saves mean,
+// rstd.  One tile per wave.  Wimg: image width (PATCH mode only).
+template <int CL, int G, bool XF32 = false, bool PATCH = false>
+__global__ __launch_bounds__(256, 2) void ln_nchw_to_nhwc_fwd_reg_kernel(const void* __restrict__ xin, const float* __restrict__ w,
                                                                         const float* __restrict__ b, uint16_t* __restrict__ y,
                                                                         float* __restrict__ mean, float* __restrict__ rstd,
-                                                                        int N, int P, float eps, int tiles_per_image, int ntiles) {
+                                                                        int N, int P, float eps, int tiles_per_image, int ntiles, int Wimg) {
+    using XR = RtX<XF32>;
+    const char* const x = (const char*)xin;
     using GE = RtGeom<CL, G>;
     constexpr int C = GE::C, PW = GE::PW, PITCH = GE::PITCH;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -138,21 +185,21 @@ __global__ __launch_bounds__(256, 2) void ln_nchw_to_nhwc_fwd_reg_kernel(const u
     const int n = tile / tiles_per_image, p0 = (tile - n * tiles_per_image) * PW;
     const int pp = lane / G, g = lane & (G - 1);
     const int rows = has_tile ? min(PW, P - p0) : 0;
-    const unsigned rb = (unsigned)P * 2u;                                                   // bytes per channel row
-    const rt_rsrc rx = rt_buf(x + (size_t)n * C * P + p0, (unsigned)(C * P - p0) * 2u);
-    const unsigned vo = 2 * pp < rows ? (unsigned)(g * CL) * rb + (unsigned)pp * 4u : RT_OOB;
-    unsigned v[CL];                                                                         // (pixel p | pixel p+1) of channel c
+    const unsigned rb = (unsigned)P * XR::EB;                                               // bytes per channel row
+    const rt_rsrc rx = rt_buf(x + ((size_t)n * C * P + p0) * XR::EB, (unsigned)(C * P - p0) * XR::EB);
+    const unsigned vo = 2 * pp < rows ? (unsigned)(g * CL) * rb + (unsigned)pp * 2u * XR::EB : RT_OOB;
+    typename XR::reg v[CL];                                                                 // (pixel p, pixel p+1) of channel c
 #pragma unroll
-    for (int c = 0; c < CL; ++c) v[c] = __builtin_amdgcn_raw_buffer_load_b32(rx, vo, (unsigned)c * rb, 0);
+    for (int c = 0; c < CL; ++c) v[c] = XR::load(rx, vo, (unsigned)c * rb);
     for (int i = threadIdx.x; i < C; i += 256) { Lw[i] = w[i]; Lb[i] = b[i]; }              // behind the tile's loads: one memory latency, not two
     __syncthreads();
     float s0 = 0.f, s1 = 0.f;
 #pragma unroll
-    for (int c = 0; c < CL; ++c) { s0 += rt_lo(v[c]); s1 += rt_hi(v[c]); }
+    for (int c = 0; c < CL; ++c) { s0 += XR::p0(v[c]); s1 += XR::p1(v[c]); }
     const float mu0 = rt_group_sum<G>(s0) / (float)C, mu1 = rt_group_sum<G>(s1) / (float)C;
     float q0 = 0.f, q1 = 0.f;
 #pragma unroll
-    for (int c = 0; c < CL; ++c) { const float a = rt_lo(v[c]) - mu0, d = rt_hi(v[c]) - mu1; q0 += a * a; q1 += d * d; }
+    for (int c = 0; c < CL; ++c) { const float a = XR::p0(v[c]) - mu0, d = XR::p1(v[c]) - mu1; q0 += a * a; q1 += d * d; }
     const float r0 = 1.0f / sqrtf(rt_group_sum<G>(q0) / (float)C + eps), r1 = 1.0f / sqrtf(rt_group_sum<G>(q1) / (float)C + eps);
     {
         const unsigned so = (g == 0 && 2 * pp < rows) ? (unsigned)pp * 8u : RT_OOB;
@@ -169,24 +216,27 @@ __global__ __launch_bounds__(256, 2) void ln_nchw_to_nhwc_fwd_reg_kernel(const u
             for (int k = 0; k < 2; ++k) {
                 const int c = j4 * 8 + 4 * h + 2 * k;
                 const float w0 = rt_f4(w4, 2 * k), w1 = rt_f4(w4, 2 * k + 1), b0 = rt_f4(b4, 2 * k), b1 = rt_f4(b4, 2 * k + 1);
-                oa[2 * h + k] = rt_pack2((rt_lo(v[c]) - mu0) * r0 * w0 + b0, (rt_lo(v[c + 1]) - mu0) * r0 * w1 + b1);
-                ob[2 * h + k] = rt_pack2((rt_hi(v[c]) - mu1) * r1 * w0 + b0, (rt_hi(v[c + 1]) - mu1) * r1 * w1 + b1);
+                oa[2 * h + k] = rt_pack2((XR::p0(v[c]) - mu0) * r0 * w0 + b0, (XR::p0(v[c + 1]) - mu0) * r0 * w1 + b1);
+                ob[2 * h + k] = rt_pack2((XR::p1(v[c]) - mu1) * r1 * w0 + b0, (XR::p1(v[c + 1]) - mu1) * r1 * w1 + b1);
             }
         }
         *(rt_u32x4*)(T + (2 * pp) * PITCH + g * (CL * 2) + j4 * 16) = oa;
         *(rt_u32x4*)(T + (2 * pp + 1) * PITCH + g * (CL * 2) + j4 * 16) = ob;
     }
     rt_lds_fence();
-    rt_tile_store<C, PW>(T, rt_buf(y + ((size_t)n * P + p0) * C, (unsigned)rows * C * 2u), lane);
+    if constexpr (PATCH) rt_tile_store_patch<C, PW>(T, rt_buf(y + (size_t)n * P * C, has_tile ? (unsigned)P * C * 2u : 0u), p0, Wimg, rows, lane);
+    else rt_tile_store<C, PW>(T, rt_buf(y + ((size_t)n * P + p0) * C, (unsigned)rows * C * 2u), lane);
 }
 
-// dx[n,:,p] = rstd * (g*w - mean_C(g*w) - xhat * mean_C(g*w*xhat)) (bf16 NCHW) from g (bf16 NHWC), x (bf16 NCHW);
-// part[wave][0..C) = sum_p g * xhat, [C..2C) = sum_p g over the wave's tiles.  Persistent waves (accumulators live in registers).
-template <int CL, int G>
-__global__ __launch_bounds__(256, 2) void ln_nchw_to_nhwc_bwd_reg_kernel(const uint16_t* __restrict__ gy, const uint16_t* __restrict__ x,
+// dx[n,:,p] = rstd * (g*w - mean_C(g*w) - xhat * mean_C(g*w*xhat)) (NCHW, bf16 or fp32 like x) from g (bf16 NHWC or patch matrix), x;
+// part[workgroup][0..C) = sum_p g * xhat, [C..2C) = sum_p g over its tiles.  Persistent waves (accumulators live in registers).
+template <int CL, int G, bool XF32 = false, bool PATCH = false>
+__global__ __launch_bounds__(256, 2) void ln_nchw_to_nhwc_bwd_reg_kernel(const uint16_t* __restrict__ gy, const void* __restrict__ xin,
                                                                         const float* __restrict__ w, const float* __restrict__ mean,
-                                                                        const float* __restrict__ rstd, uint16_t* __restrict__ dx,
-                                                                        float* __restrict__ part, int N, int P, int tiles_per_image, int ntiles) {
+                                                                        const float* __restrict__ rstd, void* __restrict__ dxout,
+                                                                        float* __restrict__ part, int N, int P, int tiles_per_image, int ntiles, int Wimg) {
+    using XR = RtX<XF32>;
+    const char* const x = (const char*)xin; char* const dx = (char*)dxout;
     using GE = RtGeom<CL, G>;
     constexpr int C = GE::C, PW = GE::PW, PITCH = GE::PITCH;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -197,7 +247,7 @@ __global__ __launch_bounds__(256, 2) void ln_nchw_to_nhwc_bwd_reg_kernel(const u
     const unsigned lds_T = (unsigned)(uintptr_t)SLAK_LDS(unsigned char, smem) + (unsigned)wave * GE::LDS_WAVE;
     RtDmaPlan<C, PW> plan; rt_dma_plan(plan, lane);
     const int pp = lane / G, g = lane & (G - 1);
-    const unsigned rb = (unsigned)P * 2u;
+    const unsigned rb = (unsigned)P * XR::EB;
     float accw[CL / 4], accb[CL / 4];
 #pragma unroll
     for (int m = 0; m < CL / 4; ++m) { accw[m] = 0.f; accb[m] = 0.f; }
@@ -205,13 +255,14 @@ __global__ __launch_bounds__(256, 2) void ln_nchw_to_nhwc_bwd_reg_kernel(const u
     for (int tile = gwave; tile < ntiles; tile += nwaves) {
         const int n = tile / tiles_per_image, p0 = (tile - n * tiles_per_image) * PW;
         const int rows = min(PW, P - p0);
-        rt_tile_dma<C, PW>(plan, gy + ((size_t)n * P + p0) * C, (unsigned)rows * C * 2u, lds_T);
-        const rt_rsrc rx = rt_buf(x + (size_t)n * C * P + p0, (unsigned)(C * P - p0) * 2u);
+        if constexpr (PATCH) { rt_dma_plan_patch(plan, lane, p0, Wimg, rows); rt_tile_dma<C, PW>(plan, gy + (size_t)n * P * C, (unsigned)P * C * 2u, lds_T); }
+        else rt_tile_dma<C, PW>(plan, gy + ((size_t)n * P + p0) * C, (unsigned)rows * C * 2u, lds_T);
+        const rt_rsrc rx = rt_buf(x + ((size_t)n * C * P + p0) * XR::EB, (unsigned)(C * P - p0) * XR::EB);
         const bool valid = 2 * pp < rows;
-        const unsigned vo = valid ? (unsigned)(g * CL) * rb + (unsigned)pp * 4u : RT_OOB;
-        unsigned xv[CL];
+        const unsigned vo = valid ? (unsigned)(g * CL) * rb + (unsigned)pp * 2u * XR::EB : RT_OOB;
+        typename XR::reg xv[CL];
 #pragma unroll
-        for (int c = 0; c < CL; ++c) xv[c] = __builtin_amdgcn_raw_buffer_load_b32(rx, vo, (unsigned)c * rb, 0);
+        for (int c = 0; c < CL; ++c) xv[c] = XR::load(rx, vo, (unsigned)c * rb);
         const unsigned so = valid ? (unsigned)pp * 8u : RT_OOB;
         const rt_u32x2 mu2 = __builtin_amdgcn_raw_buffer_load_b64(rt_buf(mean + (size_t)n * P + p0, (unsigned)(P - p0) * 4u), so, 0, 0);
         const rt_u32x2 r2 = __builtin_amdgcn_raw_buffer_load_b64(rt_buf(rstd + (size_t)n * P + p0, (unsigned)(P - p0) * 4u), so, 0, 0);
@@ -232,7 +283,7 @@ __global__ __launch_bounds__(256, 2) void ln_nchw_to_nhwc_bwd_reg_kernel(const u
                     const int k = 4 * h + k4, c = 8 * j4 + k;
                     const float gw0 = RT_CH(ta, k) * rt_f4(w4, k4), gw1 = RT_CH(tb, k) * rt_f4(w4, k4);
                     s10 += gw0; s11 += gw1;
-                    s20 += gw0 * ((rt_lo(xv[c]) - mu0) * r0); s21 += gw1 * ((rt_hi(xv[c]) - mu1) * r1);
+                    s20 += gw0 * ((XR::p0(xv[c]) - mu0) * r0); s21 += gw1 * ((XR::p1(xv[c]) - mu1) * r1);
                 }
             }
             __builtin_amdgcn_sched_barrier(0);                                  // one octet's LDS reads and unpacked values live at a time
@@ -241,8 +292,8 @@ __global__ __launch_bounds__(256, 2) void ln_nchw_to_nhwc_bwd_reg_kernel(const u
         const float m20 = rt_group_sum<G>(s20) / (float)C, m21 = rt_group_sum<G>(s21) / (float)C;
         // second pass from the PACKED registers again: without this the compiler keeps the unpacked fp32 values of the first pass alive
 #pragma unroll
-        for (int c = 0; c < CL; ++c) asm volatile("" : "+v"(xv[c]));
-        const rt_rsrc rdx = rt_buf(dx + (size_t)n * C * P + p0, (unsigned)(C * P - p0) * 2u);
+        for (int c = 0; c < CL; ++c) XR::opaque(xv[c]);
+        const rt_rsrc rdx = rt_buf(dx + ((size_t)n * C * P + p0) * XR::EB, (unsigned)(C * P - p0) * XR::EB);
 #pragma unroll
         for (int j4 = 0; j4 < CL / 8; ++j4) {
             const rt_u32x4 ta = *(const rt_u32x4*)(ra + j4 * 16), tb = *(const rt_u32x4*)(ra + PITCH + j4 * 16);
@@ -255,8 +306,8 @@ __global__ __launch_bounds__(256, 2) void ln_nchw_to_nhwc_bwd_reg_kernel(const u
                     const int k = 4 * h + k4, c = 8 * j4 + k;
                     const float wc = rt_f4(w4, k4);
                     const float g0 = RT_CH(ta, k), g1 = RT_CH(tb, k);
-                    const float xh0 = (rt_lo(xv[c]) - mu0) * r0, xh1 = (rt_hi(xv[c]) - mu1) * r1;
-                    __builtin_amdgcn_raw_buffer_store_b32(rt_pack2(r0 * (g0 * wc - m10 - xh0 * m20), r1 * (g1 * wc - m11 - xh1 * m21)), rdx, vo, (unsigned)c * rb, 0);
+                    const float xh0 = (XR::p0(xv[c]) - mu0) * r0, xh1 = (XR::p1(xv[c]) - mu1) * r1;
+                    XR::store(rdx, vo, (unsigned)c * rb, r0 * (g0 * wc - m10 - xh0 * m20), r1 * (g1 * wc - m11 - xh1 * m21));
                     tw[k4] = g0 * xh0 + g1 * xh1; ts[k4] = g0 + g1;
                 }
                 accw[2 * j4 + h] += rt_fold4(tw[0], tw[1], tw[2], tw[3]);
@@ -431,27 +482,27 @@ template <typename K> static int rt_set_lds(K k, size_t lds) {
     return (lds > 48 * 1024 && hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) ? 1 : 0;
 }
 
-template <int CL, int G>
-static int launch_ln_fwd_reg(const uint16_t* x, const float* w, const float* b, uint16_t* y, float* mean, float* rstd, int N, int P, float eps, hipStream_t st) {
+template <int CL, int G, bool XF32 = false, bool PATCH = false>
+static int launch_ln_fwd_reg(const void* x, const float* w, const float* b, uint16_t* y, float* mean, float* rstd, int N, int P, float eps, hipStream_t st, int Wimg = 0) {
     using GE = RtGeom<CL, G>;
     const int tpi = (P + GE::PW - 1) / GE::PW, ntiles = N * tpi;
     const size_t lds = (size_t)4 * GE::LDS_WAVE + (size_t)2 * GE::C * sizeof(float);
-    auto k = ln_nchw_to_nhwc_fwd_reg_kernel<CL, G>;
+    auto k = ln_nchw_to_nhwc_fwd_reg_kernel<CL, G, XF32, PATCH>;
     if (rt_set_lds(k, lds)) return SLAK_ERR_LAUNCH;
-    hipLaunchKernelGGL(k, dim3((unsigned)((ntiles + 3) / 4)), dim3(256), lds, st, x, w, b, y, mean, rstd, N, P, eps, tpi, ntiles);
+    hipLaunchKernelGGL(k, dim3((unsigned)((ntiles + 3) / 4)), dim3(256), lds, st, x, w, b, y, mean, rstd, N, P, eps, tpi, ntiles, Wimg);
     SLAK_LAUNCH_CHECK();
     return SLAK_OK;
 }
-template <int CL, int G>
-static int launch_ln_bwd_reg(const uint16_t* g, const uint16_t* x, const float* w, const float* mean, const float* rstd, uint16_t* dx, float* part,
-                             int* rows, int N, int P, hipStream_t st) {
+template <int CL, int G, bool XF32 = false, bool PATCH = false>
+static int launch_ln_bwd_reg(const uint16_t* g, const void* x, const float* w, const float* mean, const float* rstd, void* dx, float* part,
+                             int* rows, int N, int P, hipStream_t st, int Wimg = 0) {
     using GE = RtGeom<CL, G>;
     const int tpi = (P + GE::PW - 1) / GE::PW, ntiles = N * tpi;
     const size_t lds = (size_t)4 * GE::LDS_WAVE + (size_t)2 * GE::C * sizeof(float);
-    auto k = ln_nchw_to_nhwc_bwd_reg_kernel<CL, G>;
+    auto k = ln_nchw_to_nhwc_bwd_reg_kernel<CL, G, XF32, PATCH>;
     if (rt_set_lds(k, lds)) return SLAK_ERR_LAUNCH;
     const int grid = rt_persistent_grid(k, lds, ntiles);
-    hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(256), lds, st, g, x, w, mean, rstd, dx, part, N, P, tpi, ntiles);
+    hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(256), lds, st, g, x, w, mean, rstd, dx, part, N, P, tpi, ntiles, Wimg);
     SLAK_LAUNCH_CHECK();
     *rows = grid;
     return SLAK_OK;
@@ -505,6 +556,22 @@ int launch_ln_nchw_to_nhwc_fwd_reg(const void* x, const float* w, const float* b
 int launch_ln_nchw_to_nhwc_bwd_reg(const void* g, const void* x, const float* w, const float* mean, const float* rstd, void* dx, float* part, int* rows,
                                    int N, int C, int P, hipStream_t st) {
 #define CALL(CL, G) return launch_ln_bwd_reg<CL, G>((const uint16_t*)g, (const uint16_t*)x, w, mean, rstd, (uint16_t*)dx, part, rows, N, P, st)
+    SLAK_RT_DISPATCH(C, CALL)
+#undef CALL
+}
+// LayerNorm(channels_first) of an fp32 NCHW tensor written as the bf16 patch matrix of a 2x2 / stride-2 convolution, and its backward
+int launch_ln_patch_fwd_reg(const float* x, const float* w, const float* b, void* a, float* mean, float* rstd, int N, int C, int H, int W, float eps, hipStream_t st) {
+    const int P = H * W;
+    if ((H | W) & 1) return SLAK_ERR_UNSUPPORTED;
+#define CALL(CL, G) return (launch_ln_fwd_reg<CL, G, true, true>(x, w, b, (uint16_t*)a, mean, rstd, N, P, eps, st, W))
+    SLAK_RT_DISPATCH(C, CALL)
+#undef CALL
+}
+int launch_ln_patch_bwd_reg(const void* g, const float* x, const float* w, const float* mean, const float* rstd, float* dx, float* part, int* rows,
+                            int N, int C, int H, int W, hipStream_t st) {
+    const int P = H * W;
+    if ((H | W) & 1) return SLAK_ERR_UNSUPPORTED;
+#define CALL(CL, G) return (launch_ln_bwd_reg<CL, G, true, true>((const uint16_t*)g, x, w, mean, rstd, dx, part, rows, N, P, st, W))
     SLAK_RT_DISPATCH(C, CALL)
 #undef CALL
 }

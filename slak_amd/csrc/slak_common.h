@@ -177,6 +177,9 @@ __device__ __forceinline__ void wgrad_finish(const float* partial, float* dw, un
 int launch_ln_nchw_to_nhwc_fwd_reg(const void* x, const float* w, const float* b, void* y, float* mean, float* rstd, int N, int C, int P, float eps, hipStream_t st);
 int launch_ln_nchw_to_nhwc_bwd_reg(const void* g, const void* x, const float* w, const float* mean, const float* rstd, void* dx, float* part, int* rows,
                                    int N, int C, int P, hipStream_t st);       // *rows = partial rows written ([rows][2C]); the caller reduces them
+int launch_ln_patch_fwd_reg(const float* x, const float* w, const float* b, void* a, float* mean, float* rstd, int N, int C, int H, int W, float eps, hipStream_t st);
+int launch_ln_patch_bwd_reg(const void* g, const float* x, const float* w, const float* mean, const float* rstd, float* dx, float* part, int* rows,
+                            int N, int C, int H, int W, hipStream_t st);
 int launch_scale_residual_fwd_reg(const void* sc, int sc_dtype, const void* z, const float* gamma, const float* scale, float* out, void* out16,
                                   int N, int C, int P, hipStream_t st);
 int launch_scale_residual_bwd_reg(const float* dout, const void* dout16, float* dsum, const void* z, const float* gamma, const float* scale, void* dz,

@@ -321,11 +321,23 @@ class SLaK(nn.Module):
         if self.training and x.is_cuda:
             self._begin_counters()
         for i in range(4):
-            x = self.stages[i](self.downsample_layers[i](x))
+            ds = self.downsample_layers[i]
+            if (self.fused_downsample and i > 0 and x.is_cuda and x.dtype == torch.float32 and torch.is_autocast_enabled()
+                    and isinstance(ds[0], LayerNorm) and ds[0].data_format == "channels_first" and isinstance(ds[1], nn.Conv2d)
+                    and ds[1].kernel_size == (2, 2) and ds[1].stride == (2, 2) and ds[1].padding == (0, 0) and ds[1].groups == 1):
+                from . import block_ops                           # LayerNorm + the 2x2 / stride-2 conv as one LN kernel + library GEMMs
+                xc = x.contiguous()
+                if block_ops.ln_patch_covers(xc):
+                    x = self.stages[i](block_ops.downsample_ln_conv(xc, ds[0].weight, ds[0].bias, ds[1].weight, ds[1].bias, ds[0].eps))
+                    continue
+            x = self.stages[i](ds(x))
         return self.norm(x.mean([-2, -1]))
 
     def forward(self, x):
         return self.head(self.forward_features(x))
+
+
+SLaK.fused_downsample = False                # downsample layers as LN-to-patch-matrix kernel + library GEMMs (block_ops.downsample_ln_conv)
 
 
 _VARIANTS = {

@@ -266,3 +266,35 @@ def test_bn_counter_pool_counts_like_batchnorm(gpu):
         assert all(int(v) == 10 for k, v in m.state_dict().items() if k.endswith("num_batches_tracked"))
     finally:
         slak_model.ReparamLargeKernelConv.fused_bn = False
+
+
+@pytest.mark.parametrize("N,C,Co,H,W", [(3, 96, 192, 56, 56), (2, 192, 384, 28, 28), (5, 384, 768, 14, 14), (2, 64, 96, 12, 20), (1, 128, 256, 6, 10),
+                                         (2, 256, 64, 8, 8), (1, 512, 64, 4, 6)])
+def test_downsample_ln_conv_matches_reference_modules(N, C, Co, H, W, gpu):
+    """block_ops.downsample_ln_conv = Conv2d(k=2, s=2)(LayerNorm_channels_first(x)) of models/SLaK.py:285-311 under bf16 autocast: the
+    LayerNorm in fp32, its output and the conv weight rounded to bf16, fp32 accumulation.  Checked against the same ops in fp64 on the
+    bf16-rounded operands (forward: output rounding; gradients: bf16 GEMM results, 2^-7 of the tensor's scale)."""
+    from slak_amd import block_ops
+    torch.manual_seed(C + H)
+    x = (torch.randn(N, C, H, W, device=gpu) * 1.5 + 0.2).requires_grad_(True)
+    lw = (torch.randn(C, device=gpu) * 0.3 + 1).requires_grad_(True); lb = (torch.randn(C, device=gpu) * 0.1).requires_grad_(True)
+    cw = (torch.randn(Co, C, 2, 2, device=gpu) * 0.05).requires_grad_(True); cb = (torch.randn(Co, device=gpu) * 0.1).requires_grad_(True)
+    dy = torch.randn(N, Co, H // 2, W // 2, device=gpu).bfloat16()
+    assert block_ops.ln_patch_covers(x.detach())
+    y = block_ops.downsample_ln_conv(x, lw, lb, cw, cb, 1e-6)
+    assert y.dtype == torch.bfloat16 and y.shape == (N, Co, H // 2, W // 2)
+    y.backward(dy)
+    xr = x.detach().double().requires_grad_(True); lwr = lw.detach().double().requires_grad_(True); lbr = lb.detach().double().requires_grad_(True)
+    cwr = cw.detach().double().requires_grad_(True); cbr = cb.detach().double().requires_grad_(True)
+    u = xr.mean(1, keepdim=True); s = (xr - u).pow(2).mean(1, keepdim=True)
+    t = lwr[:, None, None] * ((xr - u) / torch.sqrt(s + 1e-6)) + lbr[:, None, None]
+    t16 = t + (t.detach().float().bfloat16().double() - t.detach())                         # value rounded to bf16, gradient straight through
+    w16 = cwr + (cwr.detach().float().bfloat16().double() - cwr.detach())
+    yr = F.conv2d(t16, w16, cbr.detach().float().bfloat16().double() + (cbr - cbr.detach()), stride=2)
+    yr.backward(dy.double())
+    _close(y, yr, 2.0 ** -8 * 1.05, "y")
+    _close(x.grad, xr.grad, 2.0 ** -7, "dx")
+    _close(cw.grad, cwr.grad, 2.0 ** -7, "dconv_w")
+    _close(cb.grad, cbr.grad, 1e-3, "dconv_b")
+    _close(lw.grad, lwr.grad, 2.0 ** -7, "dln_w")
+    _close(lb.grad, lbr.grad, 2.0 ** -7, "dln_b")

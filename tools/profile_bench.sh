@@ -7,5 +7,5 @@ rm -rf /tmp/pb && rocprofv3 --kernel-trace --stats -d /tmp/pb -o bench -- python
 grep '^{' /tmp/pb.log | tail -1 > $R/gpurun_out/sum/bench_under_rocprof.json
 DB=$(find /tmp/pb -name "*.db" | head -1)
 python $R/tools/rocpd_summary.py $DB --top 70 > $R/gpurun_out/sum/bench_kernel_stats.txt
-python $R/tools/step_breakdown.py $DB --top 45 > $R/gpurun_out/sum/step_breakdown.txt
+python $R/tools/step_breakdown.py $DB --top 130 > $R/gpurun_out/sum/step_breakdown.txt
 head -16 $R/gpurun_out/sum/step_breakdown.txt
