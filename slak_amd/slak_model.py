@@ -237,10 +237,12 @@ def _block_forward_fused_tail(self, shortcut, x):
     scale = None
     dp = self.drop_path
     if isinstance(dp, DropPath) and dp.drop_prob > 0.0 and self.training:
-        keep = 1.0 - dp.drop_prob
-        scale = torch.empty(x.shape[0], device=x.device, dtype=torch.float32).bernoulli_(keep)
-        if keep > 0.0:
-            scale.div_(keep)
+        scale = self.__dict__.pop("_pending_scale", None)        # drawn for all blocks at once by SLaK.forward_features
+        if scale is None or scale.shape[0] != x.shape[0] or scale.device != x.device:
+            keep = 1.0 - dp.drop_prob
+            scale = torch.empty(x.shape[0], device=x.device, dtype=torch.float32).bernoulli_(keep)
+            if keep > 0.0:
+                scale.div_(keep)
     emit = bool(self.emit_lowp and torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == torch.bfloat16)
     # MLP + gamma + permute + residual as one autograd node; with `emit` it returns (out, bf16 copy of out): both are autograd
     # outputs, the pair travels to the next block through nn.Sequential (Block.forward unpacks it)
@@ -317,9 +319,25 @@ class SLaK(nn.Module):
         if pool is not None:
             pool.begin_forward()
 
+    def _draw_drop_path(self, x):
+        """The per-sample stochastic-depth scales of every block in three launches (one uniform draw for all blocks) instead of two per
+        block; same distribution as DropPath's bernoulli_(keep) / keep, handed to the fused block tails through Block._pending_scale."""
+        blocks = [b for st in self.stages for b in st if isinstance(b, Block) and b.fused_tail
+                  and isinstance(b.drop_path, DropPath) and 0.0 < b.drop_path.drop_prob < 1.0]
+        if not blocks:
+            return
+        keeps = getattr(self, "_dp_keeps", None)
+        if keeps is None or keeps.device != x.device or keeps.shape[0] != len(blocks):
+            keeps = torch.tensor([1.0 - b.drop_path.drop_prob for b in blocks], dtype=torch.float32, device=x.device).view(-1, 1)
+            object.__setattr__(self, "_dp_keeps", keeps)
+        scales = (torch.rand(len(blocks), x.shape[0], device=x.device) < keeps).float() / keeps
+        for i, b in enumerate(blocks):
+            b.__dict__["_pending_scale"] = scales[i]
+
     def forward_features(self, x):
         if self.training and x.is_cuda:
             self._begin_counters()
+            self._draw_drop_path(x)
         for i in range(4):
             ds = self.downsample_layers[i]
             if (self.fused_downsample and i > 0 and x.is_cuda and x.dtype == torch.float32 and torch.is_autocast_enabled()
