@@ -36,7 +36,7 @@ def ops_of(db, counter):
 def main():
     fetch_db, write_db = sys.argv[1], sys.argv[2]
     f, w = ops_of(fetch_db, "FETCH_SIZE"), ops_of(write_db, "WRITE_SIZE")
-    assert len(f) == len(w) == 4 * 3 * 3 * 3, (len(f), len(w))
+    assert len(f) == len(w) == 4 * 3 * 3 * 3 + 2 * 2 * 3 + 2 * 3 * 3, (len(f), len(w))
     out = {}
     i = 0
     print("%-28s %14s %14s %14s %14s %8s" % ("op", "alg bytes", "2*FETCH", "WRITE", "HBM bytes", "HBM/alg"))
@@ -56,6 +56,33 @@ def main():
                 key = "s%d_%dx%d_%s" % (si + 1, kh, kw, name)
                 out[key] = {"hbm_bytes_per_launch": rd + wr, "read_bytes_2xFETCH_SIZE": rd, "write_bytes_WRITE_SIZE": wr, "alg_bytes": alg}
                 print("%-28s %14d %14.0f %14.0f %14.0f %8.2f" % (key, alg, rd, wr, rd + wr, (rd + wr) / alg))
+    # the launches as the model runs them (second part of tools/pmc_workload.py); byte prices as bench.py's hot_path (SURVEY 8d per-op bytes)
+    def put(key, alg, v):
+        rd = statistics.median(a for a, b in v); wr = statistics.median(b for a, b in v)
+        out[key] = {"hbm_bytes_per_launch": rd + wr, "read_bytes_2xFETCH_SIZE": rd, "write_bytes_WRITE_SIZE": wr, "alg_bytes": alg}
+        print("%-28s %14d %14.0f %14.0f %14.0f %8.2f" % (key, alg, rd, wr, rd + wr, (rd + wr) / alg))
+    for si, (C, H, K) in enumerate(STAGES[:2]):
+        S = 128 * C * H * H
+        for (kh, kw) in ((5, K), (5, 5)):
+            v = []
+            for rep in range(3):
+                assert f[i][0] == "conv" and w[i][0] == "conv", (i, f[i], w[i])
+                v.append((2.0 * f[i][1] * 1024, w[i][1] * 1024)); i += 1
+            put("s%d_%dx%d_bwd_data+acc" % (si + 1, kh, kw), 3 * S * 2 + C * kh * kw * 4, v)
+    for si, (C, H, K) in enumerate(STAGES):
+        if si < 2:
+            continue
+        S = 128 * C * H * H
+        alg = 3 * 2 * S * 2 + C * (2 * K * 5 + 25) * 4
+        vals = {"fwd": [], "bwd_data": [], "bwd_filter": []}
+        for rep in range(3):
+            for name in ("fwd", "bwd_data", "bwd_filter"):
+                kind = "wgrad" if name == "bwd_filter" else "conv"
+                assert f[i][0] == kind and w[i][0] == kind, (i, f[i], w[i])
+                vals[name].append((2.0 * f[i][1] * 1024, w[i][1] * 1024)); i += 1
+        for name, v in vals.items():
+            put("s%d_%dx5+5x%d+5x5_%s" % (si + 1, K, K, name), alg, v)
+    assert i == len(f)
     path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "pmc_traffic.json")
     with open(path, "w") as fh:
         json.dump(out, fh, indent=1, sort_keys=True)

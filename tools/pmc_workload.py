@@ -1,4 +1,6 @@
-"""Workload for the rocprofv3 PMC passes: every SLaK-T dw-conv kernel shape (bf16, N=128), 3 launches each.
+"""Workload for the rocprofv3 PMC passes: every SLaK-T dw-conv kernel shape (bf16, N=128), 3 launches each, then the launches as the
+model runs them that the per-branch list does not contain: the accumulating data gradient (stages 1-2) and the three-branch launches
+(stages 3-4: forward, data gradient, weight gradient).
     rocprofv3 --pmc FETCH_SIZE --kernel-trace -d gpurun_out/pmc_fetch -o pmc -- python tools/pmc_workload.py
     rocprofv3 --pmc WRITE_SIZE --kernel-trace -d gpurun_out/pmc_write -o pmc -- python tools/pmc_workload.py
 then tools/pmc_traffic.py turns the two databases into profiles/pmc_traffic.json."""
@@ -15,3 +17,21 @@ for (C, H, K) in ((96, 56, 51), (192, 28, 49), (384, 14, 47), (768, 7, 13)):
         for _ in range(3):
             ops.dwconv2d_forward(x, w); ops.dwconv2d_backward_data(dy, w); ops.dwconv2d_backward_filter(dy, x, w)
         torch.cuda.synchronize()
+
+# ---- the launches of a training step that are not in the per-branch list above (tools/pmc_traffic.py reads them in this order) ----
+from slak_amd import block_ops
+for (C, H, K) in ((96, 56, 51), (192, 28, 49)):
+    dy = torch.randn(128, C, H, H, device=dev).bfloat16(); dx = torch.randn_like(dy)
+    for (kh, kw) in ((5, K), (5, 5)):
+        w = torch.randn(C, 1, kh, kw, device=dev) * 0.02
+        for _ in range(3):
+            ops.dwconv2d_backward_data_accumulate(dy, w, dx)
+        torch.cuda.synchronize()
+for (C, H, K) in ((384, 14, 47), (768, 7, 13)):
+    x = torch.randn(128, C, H, H, device=dev).bfloat16().requires_grad_(True)
+    ws = [(torch.randn(C, 1, kh, kw, device=dev) * 0.02).requires_grad_(True) for kh, kw in ((K, 5), (5, K), (5, 5))]
+    dys = [torch.randn(128, C, H, H, device=dev).bfloat16() for _ in range(3)]
+    for _ in range(3):
+        ys = block_ops.tri_dwconv(x, *ws)                       # one launch
+        torch.autograd.backward(ys, dys)                        # one data-gradient launch, one weight-gradient launch
+    torch.cuda.synchronize()

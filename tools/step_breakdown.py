@@ -22,6 +22,9 @@ def cat(n):
     if "slak::adamw" in n or "slak::ema" in n: return "optimizer"
     if "slak::dwconv" in n or "toeplitz" in n: return "slak dwconv"
     if "slak::ln_" in n or "slak::scale_res" in n or "block_tail" in n: return "slak block tail"
+    if "slak::linear_" in n or "slak::gelu_" in n: return "slak pointwise (linear_nt, linear_wgrad, gelu_bwd)"
+    if "slak::bn3" in n: return "slak branch BatchNorm (bn3)"
+    if "slak::mask" in n: return "slak mask step"
     if "slak::" in n: return "slak other"
     if n.startswith("Cijk"): return "hipblaslt gemm"
     if "BatchNorm" in n or "batch_norm" in n: return "batchnorm"
