@@ -14,6 +14,10 @@
 // dgamma) are written as per-tile partials and added in a fixed order by block_tail_reduce1 (deterministic, no atomics).
 // Activations bf16 (autocast), statistics / residual stream / parameters fp32.
 #include "slak_common.h"
+#include <cmath>
+#include <cstring>
+#include <mutex>
+#include <vector>
 
 namespace slak {
 
@@ -683,14 +687,52 @@ __global__ __launch_bounds__(BT_THREADS) void ln_cf_bwd_kernel(const Tg* __restr
 
 // ===== GELU backward fused with the bias gradient of the Linear in front of it: dy1 = dact * gelu'(y1) (exact erf form, like
 // nn.GELU()), part[wg][col] = sum over the workgroup's rows of dy1.  [rows][cols] bf16, cols % 8 == 0.  Thread <-> 8 columns. =====
+// gelu'(x) = Phi(x) + x phi(x) of a bf16 VALUE by table (the pre-activation y1 is a stored bf16 tensor): 2^-18 <= |x| < 16 is
+// 22 exponents x 128 mantissas x 2 signs fp32 entries (22 KB of LDS, correctly rounded on the host in double precision); below, the
+// linear term 0.5 + x phi(0) is exact to fp32; above, 1 (x > 0) or 0.  One LDS gather + a handful of integer instructions instead of
+// exp + rcp + a degree-5 polynomial: the evaluation was 0.4 ms of the kernel's 1.74 ms per SLaK-T step.
+constexpr unsigned GD_LO = 109u << 7, GD_N = 22u << 7;
+constexpr int GD_BYTES = 2 * (int)GD_N * 4;
+__device__ __forceinline__ float gelu_grad_lut(const float* __restrict__ T, unsigned b) {       // b: bf16 bits
+    const unsigned mag = b & 0x7fffu, neg = b >> 15;
+    const unsigned idx = mag - GD_LO;
+    const bool in = idx < GD_N;
+    const float t = T[(in ? idx : 0u) + neg * GD_N];
+    const float x = __uint_as_float(b << 16);
+    const float lo = 0.5f + 0.79788456080286536f * x;              // |x| < 2^-18 (also +-0, subnormals)
+    const float hi = mag > 0x7f80u ? x : (neg ? 0.0f : 1.0f);      // |x| >= 16, +-inf; NaN propagates
+    return in ? t : (mag < GD_LO ? lo : hi);
+}
+__device__ __forceinline__ void gelu_bwd8(const float* __restrict__ T, const uint4& gv, const uint4& yv, uint4& ov, float (&acc)[8]) {
+    const unsigned gw[4] = {gv.x, gv.y, gv.z, gv.w}, yw[4] = {yv.x, yv.y, yv.z, yv.w};
+    unsigned ow[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        float o[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const float g = bf2f((uint16_t)(h ? gw[k] >> 16 : gw[k] & 0xffff));
+            o[h] = g * gelu_grad_lut(T, h ? yw[k] >> 16 : yw[k] & 0xffffu);
+        }
+        ow[k] = bt_pack2(o[0], o[1]);
+        // the bias gradient sums the ROUNDED values (what dy1.sum(0) over the stored tensor gives)
+        acc[2 * k] += bf2f((uint16_t)(ow[k] & 0xffff)); acc[2 * k + 1] += bf2f((uint16_t)(ow[k] >> 16));
+    }
+    ov = uint4{ow[0], ow[1], ow[2], ow[3]};
+}
 __global__ __launch_bounds__(BT_THREADS) void gelu_bwd_bias_kernel(const uint16_t* __restrict__ dact, const uint16_t* __restrict__ y1,
                                                                  uint16_t* __restrict__ dy1, float* __restrict__ part,
-                                                                 int rows, int cols, int rows_per_wg) {
-    // threads as (row lane ry, column chunk cx): narrow matrices (cols = 384) still use the whole workgroup
+                                                                 int rows, int cols, int rows_per_wg, const float* __restrict__ table) {
+    // threads as (row lane ry, column chunk cx): narrow matrices (cols = 384) still use the whole workgroup; the workgroup size is
+    // chosen by the launcher (64..256) so that ccn * nry covers it (cols = 768, 1536, 3072: 192 threads instead of 3/4 of 256)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    float* red = (float*)smem;                                   // [nry][cols]
+    float* const T = (float*)smem;                               // gelu' table, then red[nry][cols]
+    float* red = (float*)(smem + GD_BYTES);
+    const int nthr = blockDim.x;
+    for (int i = threadIdx.x; i < GD_BYTES / 16; i += nthr) ((uint4*)T)[i] = ((const uint4*)table)[i];
+    __syncthreads();
     const int cchunks = cols / 8;
-    const int ccn = cchunks < BT_THREADS ? cchunks : BT_THREADS, nry = BT_THREADS / ccn;
+    const int ccn = cchunks < nthr ? cchunks : nthr, nry = nthr / ccn;
     const int ry = threadIdx.x / ccn, cx = threadIdx.x - ry * ccn;
     const int r0 = blockIdx.x * rows_per_wg;
     int r1 = r0 + rows_per_wg; if (r1 > rows) r1 = rows;
@@ -698,32 +740,19 @@ __global__ __launch_bounds__(BT_THREADS) void gelu_bwd_bias_kernel(const uint16_
         const int cc = cc0 + cx;
         float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         if (ry < nry && cc < cchunks) {
-            for (int r = r0 + ry; r < r1; r += nry) {
-                const size_t off = (size_t)r * cols + cc * 8;
-                const uint4 gv = *(const uint4*)(dact + off), yv = *(const uint4*)(y1 + off);
-                const unsigned gw[4] = {gv.x, gv.y, gv.z, gv.w}, yw[4] = {yv.x, yv.y, yv.z, yv.w};
-                unsigned ow[4];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    float o[2];
-#pragma unroll
-                    for (int h = 0; h < 2; ++h) {
-                        const float g = bf2f((uint16_t)(h ? gw[k] >> 16 : gw[k] & 0xffff)), x = bf2f((uint16_t)(h ? yw[k] >> 16 : yw[k] & 0xffff));
-                        // erf(x/sqrt2) by Abramowitz-Stegun 7.1.26 (|err| < 1.5e-7, far below bf16 output rounding); it shares
-                        // exp(-x^2/2) with the density term, so the whole derivative costs one exp and one rcp
-                        const float e = __expf(-0.5f * x * x);
-                        const float zabs = fabsf(x) * 0.70710678118654752f;
-                        const float t = __frcp_rn(1.0f + 0.3275911f * zabs);
-                        const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
-                        const float erf_abs = 1.0f - poly * e;
-                        const float cdf = 0.5f * (1.0f + copysignf(erf_abs, x));
-                        o[h] = g * (cdf + x * 0.39894228040143268f * e);
-                    }
-                    ow[k] = bt_pack2(o[0], o[1]);
-                    // the bias gradient sums the ROUNDED values (what dy1.sum(0) over the stored tensor gives)
-                    acc[2 * k] += bf2f((uint16_t)(ow[k] & 0xffff)); acc[2 * k + 1] += bf2f((uint16_t)(ow[k] >> 16));
-                }
-                *(uint4*)(dy1 + off) = uint4{ow[0], ow[1], ow[2], ow[3]};
+            int r = r0 + ry;
+            for (; r + nry < r1; r += 2 * nry) {                   // two rows in flight per thread
+                const size_t o0 = (size_t)r * cols + cc * 8, o1 = o0 + (size_t)nry * cols;
+                const uint4 g0 = *(const uint4*)(dact + o0), y0 = *(const uint4*)(y1 + o0), g1 = *(const uint4*)(dact + o1), y1v = *(const uint4*)(y1 + o1);
+                uint4 v0, v1;
+                gelu_bwd8(T, g0, y0, v0, acc); gelu_bwd8(T, g1, y1v, v1, acc);
+                *(uint4*)(dy1 + o0) = v0; *(uint4*)(dy1 + o1) = v1;
+            }
+            if (r < r1) {
+                const size_t o0 = (size_t)r * cols + cc * 8;
+                uint4 v0;
+                gelu_bwd8(T, *(const uint4*)(dact + o0), *(const uint4*)(y1 + o0), v0, acc);
+                *(uint4*)(dy1 + o0) = v0;
             }
         }
         __syncthreads();                                         // previous pass's partials have been consumed
@@ -821,6 +850,29 @@ static int tail_grid(const TailDims& d, size_t lds) {                  // persis
 static int set_lds(const void* k, size_t lds) {
     if (lds > 48 * 1024) return hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess ? 0 : 1;
     return 0;
+}
+
+// the table of gelu_grad_lut in device memory (one copy per device, built on first use): entry [sign * GD_N + (mag - GD_LO)]
+static const float* gelu_grad_table_device() {
+    static std::mutex mu;
+    static const float* tab[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    std::lock_guard<std::mutex> lock(mu);
+    if (tab[dev]) return tab[dev];
+    std::vector<float> h(2 * GD_N);
+    for (unsigned sgn = 0; sgn < 2; ++sgn)
+        for (unsigned i = 0; i < GD_N; ++i) {
+            const uint32_t bits = ((sgn << 15) | (GD_LO + i)) << 16;
+            float xf; memcpy(&xf, &bits, 4);
+            const double x = xf;
+            h[sgn * GD_N + i] = (float)(0.5 * erfc(-x * 0.70710678118654752440) + x * 0.39894228040143267794 * exp(-0.5 * x * x));
+        }
+    void* d = nullptr;
+    if (hipMalloc(&d, h.size() * 4) != hipSuccess) return nullptr;
+    if (hipMemcpy(d, h.data(), h.size() * 4, hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(d); return nullptr; }
+    tab[dev] = (const float*)d;
+    return tab[dev];
 }
 
 }  // namespace slak
@@ -1079,11 +1131,20 @@ int slak_gelu_backward_bias(const void* dact, const void* y1, void* dy1, float* 
     int rpw = (rows + nwg - 1) / nwg; if (rpw < 8) rpw = 8;
     nwg = (rows + rpw - 1) / rpw;
     float* part = (float*)workspace;
-    const int cchunks = cols / 8, ccn = cchunks < BT_THREADS ? cchunks : BT_THREADS;
-    const size_t lds = (size_t)(BT_THREADS / ccn) * cols * sizeof(float) + 16;
+    const int cchunks = cols / 8;
+    int threads = BT_THREADS; double best = -1.0;                  // workgroup size with the fewest idle lanes over the column passes
+    for (int t = 64; t <= BT_THREADS; t += 64) {
+        const int ccn_t = cchunks < t ? cchunks : t, passes = (cchunks + ccn_t - 1) / ccn_t;
+        const double util = (double)cchunks * (t / ccn_t) / ((double)passes * t);   // useful thread slots / all thread slots
+        if (util > best + 1e-9 || (util > best - 1e-9 && t > threads)) { best = util; threads = t; }
+    }
+    const int ccn = cchunks < threads ? cchunks : threads;
+    const size_t lds = (size_t)GD_BYTES + (size_t)(threads / ccn) * cols * sizeof(float) + 16;
+    const float* table = gelu_grad_table_device();
+    if (!table) return SLAK_ERR_LAUNCH;
     if (set_lds((const void*)gelu_bwd_bias_kernel, lds)) return SLAK_ERR_LAUNCH;
-    hipLaunchKernelGGL(gelu_bwd_bias_kernel, dim3((unsigned)nwg), dim3(BT_THREADS), lds, (hipStream_t)stream,
-                       (const uint16_t*)dact, (const uint16_t*)y1, (uint16_t*)dy1, part, rows, cols, rpw);
+    hipLaunchKernelGGL(gelu_bwd_bias_kernel, dim3((unsigned)nwg), dim3((unsigned)threads), lds, (hipStream_t)stream,
+                       (const uint16_t*)dact, (const uint16_t*)y1, (uint16_t*)dy1, part, rows, cols, rpw, table);
     SLAK_LAUNCH_CHECK();
     return reduce_partials(part, part + (size_t)nwg * cols, dbias, dbias, cols, nwg, cols, (hipStream_t)stream);
 }
