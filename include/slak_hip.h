@@ -243,6 +243,15 @@ int slak_bn3_backward_apply(const void* dout, const void* y1, const void* y2, co
                             const float* stats, const float* const* gamma_host3,
                             float* bcoef /*[C][9]*/, float* dgamma /*[3][C]*/, float* dbeta /*[3][C]*/,
                             void* dy1, void* dy2, void* dy3, int N, int C, int P, void* stream);
+/* Single-process training step of the same op (no all-reduce between the statistics and the apply pass: the slice reduction and the
+ * finalise step share a launch).  Same arithmetic and side effects as _forward_sums + _forward_apply(training = 1) resp.
+ * _backward_sums + _backward_apply with global_sums = local_sums, count = N * P. */
+int slak_bn3_forward_local(const void* y1, const void* y2, const void* y3, const float* const* gamma, const float* const* beta,
+                           float* const* running_mean, float* const* running_var, float eps, float momentum, int update_running,
+                           float* coef, float* stats, void* out, int N, int C, int P, void* workspace, size_t workspace_bytes, void* stream);
+int slak_bn3_backward_local(const void* dout, const void* y1, const void* y2, const void* y3, const float* stats, const float* const* gamma,
+                            float* bcoef, float* dgamma, float* dbeta, void* dy1, void* dy2, void* dy3, int N, int C, int P,
+                            void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------- next row: mask-aware optimizer step and EMA
  * One launch over ALL tensors each.  Descriptor arrays live in HOST memory at plan creation (device pointers inside); plans own their

@@ -356,6 +356,20 @@ class _BranchBN3(torch.autograd.Function):
         if momentum is None:                                     # cumulative moving average, as nn.BatchNorm
             momentum = 1.0 / float(bns[0].num_batches_tracked.item())
         ws, nb = _workspace(L.slak_bn3_workspace_bytes(N, C), dev)
+        if group is None:                                        # single process: sums, finalise and apply without the exchange step (3 launches)
+            coef = torch.empty(C * 4, dtype=torch.float32, device=dev)
+            stats = torch.empty(C * 6, dtype=torch.float32, device=dev)
+            out = torch.empty_like(y1)
+            with torch.cuda.device(dev):
+                _lib.check(L.slak_bn3_forward_local(y1.data_ptr(), y2.data_ptr(), y3.data_ptr(), _ptr3(gam), _ptr3(bet), _ptr3(rmean), _ptr3(rvar),
+                                                    eps, float(momentum), 1 if bns[0].track_running_stats else 0, coef.data_ptr(), stats.data_ptr(),
+                                                    out.data_ptr(), N, C, P, ws.data_ptr() if ws is not None else None, nb, _stream(dev)),
+                           "slak_bn3_forward_local")
+            ctx.save_for_backward(y1, y2, y3, g1, g2, g3, stats)
+            ctx.group = None
+            ctx.count = float(N * P)
+            ctx.count_dev = None
+            return out
         sums = torch.empty(C * 6 + 1, dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
             _lib.check(L.slak_bn3_forward_sums(y1.data_ptr(), y2.data_ptr(), y3.data_ptr(), sums.data_ptr(), N, C, P,
@@ -392,6 +406,16 @@ class _BranchBN3(torch.autograd.Function):
             dout = dout.to(torch.bfloat16)
         L = _lib.lib()
         ws, nb = _workspace(L.slak_bn3_workspace_bytes(N, C), dev)
+        if ctx.group is None:
+            bcoef = torch.empty(C * 9, dtype=torch.float32, device=dev)
+            dgamma = torch.empty(3, C, dtype=torch.float32, device=dev)
+            dbeta = torch.empty(3, C, dtype=torch.float32, device=dev)
+            d1, d2, d3 = torch.empty_like(y1), torch.empty_like(y2), torch.empty_like(y3)
+            with torch.cuda.device(dev):
+                _lib.check(L.slak_bn3_backward_local(dout.data_ptr(), y1.data_ptr(), y2.data_ptr(), y3.data_ptr(), stats.data_ptr(), _ptr3([g1, g2, g3]),
+                                                     bcoef.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), d1.data_ptr(), d2.data_ptr(), d3.data_ptr(),
+                                                     N, C, P, ws.data_ptr() if ws is not None else None, nb, _stream(dev)), "slak_bn3_backward_local")
+            return d1, d2, d3, dgamma[0], dbeta[0], dgamma[1], dbeta[1], dgamma[2], dbeta[2], None, None
         lsums = torch.empty(C * 4, dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
             _lib.check(L.slak_bn3_backward_sums(dout.data_ptr(), y1.data_ptr(), y2.data_ptr(), y3.data_ptr(), lsums.data_ptr(), N, C, P,

@@ -117,6 +117,48 @@ __global__ __launch_bounds__(BN_THREADS) void bn3_rowsums_bwd(const uint16_t* __
     }
 }
 
+// Channel-slice sums (round 2; the row-sum kernels above reduce every (n, c) row on its own -- 36 shuffles per row -- and leave N partial
+// rows per channel): a wavefront owns channel c and the images [s*per, (s+1)*per) of the batch; its lanes stride over the (image, 16-byte
+// chunk) pairs of that slice and keep plain per-lane sums, reduced ONCE at the end: part[(s*C + c)*K + k].  K = 6 (forward: sum y_b,
+// sum y_b^2) or 4 (backward: sum dout, sum dout*y_b).
+template <bool BWD>
+__global__ __launch_bounds__(BN_THREADS) void bn3_chansums(const uint16_t* __restrict__ dout, const uint16_t* __restrict__ y1,
+                                                         const uint16_t* __restrict__ y2, const uint16_t* __restrict__ y3,
+                                                         float* __restrict__ part, int N, int C, int P, int S, int per) {
+    constexpr int K = BWD ? 4 : 6;
+    const int lane = threadIdx.x & 63, wv = blockIdx.x * (BN_THREADS / 64) + (threadIdx.x >> 6);
+    if (wv >= C * S) return;
+    const int c = wv % C, sl = wv / C;
+    const int n0 = sl * per, n1 = min(n0 + per, N);
+    const int vec = (P & 7) == 0 ? 2 : ((P & 3) == 0 ? 1 : 0);
+    const int cpr = (P + 7) / 8;                                   // 16-byte chunks per row
+    float s[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    int n = n0, ch = lane;
+    while (ch >= cpr) { ch -= cpr; ++n; }
+    while (n < n1) {
+        const size_t base = ((size_t)n * C + c) * P;
+        float a[8], b[8], d[8];
+        load8(y1 + base, ch * 8, P, vec, a); load8(y2 + base, ch * 8, P, vec, b); load8(y3 + base, ch * 8, P, vec, d);
+        if constexpr (BWD) {
+            float g[8];
+            load8(dout + base, ch * 8, P, vec, g);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { s[0] += g[e]; s[1] += g[e] * a[e]; s[2] += g[e] * b[e]; s[3] += g[e] * d[e]; }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { s[0] += a[e]; s[1] += a[e] * a[e]; s[2] += b[e]; s[3] += b[e] * b[e]; s[4] += d[e]; s[5] += d[e] * d[e]; }
+        }
+        ch += 64;
+        while (ch >= cpr) { ch -= cpr; ++n; }
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) { const float t = bn_wave_sum(s[k]); if (lane == 0) part[((size_t)sl * C + c) * K + k] = t; }
+}
+static void bn_slices(int N, int C, int* S, int* per) {            // ~16384 wavefronts (a full machine of eight per SIMD, twice over), whole images per slice
+    int s = 16384 / C; if (s < 1) s = 1; if (s > N) s = N;
+    *per = (N + s - 1) / s; *S = (N + *per - 1) / *per;
+}
+
 // sums[c][k] = sum_n rows[(n*C + c)][k]: one wavefront per channel, lanes over n, fixed butterfly order (deterministic)
 __global__ __launch_bounds__(64) void bn3_colreduce(const float* __restrict__ rows, float* __restrict__ sums, int N, int C, int K) {
     const int c = blockIdx.x, lane = threadIdx.x;
@@ -221,6 +263,68 @@ __global__ void bn3_finalize_bwd(const float* __restrict__ gsums, const float* _
     }
 }
 
+// Single-process path: the slice reduction and the finalise step of a channel in one wavefront (no all-reduce in between): one launch
+// instead of bn3_colreduce + bn3_finalize_*.
+__global__ __launch_bounds__(64) void bn3_colreduce_finalize_fwd(const float* __restrict__ rows, int S, Bn3Params bp, float* __restrict__ coef,
+                                                               float* __restrict__ stats, int C, float count, float eps, float momentum,
+                                                               int update_running) {
+    const int c = blockIdx.x, lane = threadIdx.x;
+    float s[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int n = lane; n < S; n += 64) {
+        const float* r = rows + ((size_t)n * C + c) * 6;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) s[k] += r[k];
+    }
+#pragma unroll
+    for (int k = 0; k < 6; ++k) s[k] = bn_wave_sum(s[k]);
+    if (lane != 0) return;
+    float shift = 0.f;
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+        const float mean = s[2 * b] / count;
+        float var = s[2 * b + 1] / count - mean * mean;
+        var = var > 0.f ? var : 0.f;
+        const float inv = 1.0f / sqrtf(var + eps);
+        const float sc = bp.gamma[b][c] * inv;
+        coef[c * 4 + b] = sc;
+        shift += bp.beta[b][c] - mean * sc;
+        stats[c * 6 + 2 * b] = mean; stats[c * 6 + 2 * b + 1] = inv;
+        if (update_running) {
+            const float unb = count > 1.f ? var * count / (count - 1.f) : var;
+            bp.running_mean[b][c] = (1.f - momentum) * bp.running_mean[b][c] + momentum * mean;
+            bp.running_var[b][c] = (1.f - momentum) * bp.running_var[b][c] + momentum * unb;
+        }
+    }
+    coef[c * 4 + 3] = shift;
+}
+__global__ __launch_bounds__(64) void bn3_colreduce_finalize_bwd(const float* __restrict__ rows, int S, const float* __restrict__ stats, Bn3Params bp,
+                                                               float* __restrict__ bcoef, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                               int C, float count) {
+    const int c = blockIdx.x, lane = threadIdx.x;
+    float s[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int n = lane; n < S; n += 64) {
+        const float* r = rows + ((size_t)n * C + c) * 4;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) s[k] += r[k];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) s[k] = bn_wave_sum(s[k]);
+    if (lane != 0) return;
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+        const float mean = stats[c * 6 + 2 * b], inv = stats[c * 6 + 2 * b + 1], g = bp.gamma[b][c];
+        const float gd = s[0], gdy = s[1 + b];
+        const float dgam = inv * (gdy - mean * gd);
+        const float A = g * inv;
+        const float B = -g * inv * inv * dgam / count;
+        bcoef[(c * 3 + b) * 3 + 0] = A;
+        bcoef[(c * 3 + b) * 3 + 1] = B;
+        bcoef[(c * 3 + b) * 3 + 2] = -A * gd / count - B * mean;
+        dgamma[b * C + c] = dgam;
+        dbeta[b * C + c] = gd;
+    }
+}
+
 // dy_b[r][p] = A_b*dout + B_b*y_b + C_b
 __global__ __launch_bounds__(BN_THREADS) void bn3_apply_bwd(const uint16_t* __restrict__ dout, const uint16_t* __restrict__ y1,
                                                           const uint16_t* __restrict__ y2, const uint16_t* __restrict__ y3,
@@ -285,10 +389,32 @@ int slak_bn3_forward_sums(const void* y1, const void* y2, const void* y3, float*
     int rc = bn_args_ok(N, C, P); if (rc) return rc;
     if (!workspace || workspace_bytes < slak_bn3_workspace_bytes(N, C)) return SLAK_ERR_WORKSPACE;
     float* rows = (float*)workspace;
+    int S, per; bn_slices(N, C, &S, &per);
+    hipLaunchKernelGGL(bn3_chansums<false>, dim3((unsigned)((C * S + BN_THREADS / 64 - 1) / (BN_THREADS / 64))), dim3(BN_THREADS), 0, (hipStream_t)stream,
+                       (const uint16_t*)nullptr, (const uint16_t*)y1, (const uint16_t*)y2, (const uint16_t*)y3, rows, N, C, P, S, per);
+    hipLaunchKernelGGL(bn3_colreduce, dim3(C), dim3(64), 0, (hipStream_t)stream, (const float*)rows, local_sums, S, C, 6);
+    SLAK_LAUNCH_CHECK();
+    return SLAK_OK;
+}
+
+/* Single-process training forward (no statistics exchange between the sums and the apply pass): three launches. */
+int slak_bn3_forward_local(const void* y1, const void* y2, const void* y3, const float* const* gamma, const float* const* beta,
+                           float* const* running_mean, float* const* running_var, float eps, float momentum, int update_running,
+                           float* coef, float* stats, void* out, int N, int C, int P, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!y1 || !y2 || !y3 || !gamma || !beta || !running_mean || !running_var || !coef || !stats || !out) return SLAK_ERR_INVALID_ARG;
+    int rc = bn_args_ok(N, C, P); if (rc) return rc;
+    if (!workspace || workspace_bytes < slak_bn3_workspace_bytes(N, C)) return SLAK_ERR_WORKSPACE;
+    Bn3Params bp;
+    for (int b = 0; b < 3; ++b) { bp.gamma[b] = gamma[b]; bp.beta[b] = beta[b]; bp.running_mean[b] = running_mean[b]; bp.running_var[b] = running_var[b]; }
+    float* rows = (float*)workspace;
+    int S, per; bn_slices(N, C, &S, &per);
+    hipLaunchKernelGGL(bn3_chansums<false>, dim3((unsigned)((C * S + BN_THREADS / 64 - 1) / (BN_THREADS / 64))), dim3(BN_THREADS), 0, (hipStream_t)stream,
+                       (const uint16_t*)nullptr, (const uint16_t*)y1, (const uint16_t*)y2, (const uint16_t*)y3, rows, N, C, P, S, per);
+    hipLaunchKernelGGL(bn3_colreduce_finalize_fwd, dim3(C), dim3(64), 0, (hipStream_t)stream, (const float*)rows, S, bp, coef, stats, C,
+                       (float)((double)N * P), eps, momentum, update_running);
     const int R = N * C;
-    hipLaunchKernelGGL(bn3_rowsums_fwd, dim3(bn_grid(R, P)), dim3(BN_THREADS), 0, (hipStream_t)stream,
-                       (const uint16_t*)y1, (const uint16_t*)y2, (const uint16_t*)y3, rows, R, P, bn_lpr(P));
-    hipLaunchKernelGGL(bn3_colreduce, dim3(C), dim3(64), 0, (hipStream_t)stream, (const float*)rows, local_sums, N, C, 6);
+    hipLaunchKernelGGL(bn3_apply_fwd, dim3(bn_grid(R, P)), dim3(BN_THREADS), 0, (hipStream_t)stream,
+                       (const uint16_t*)y1, (const uint16_t*)y2, (const uint16_t*)y3, (const float*)coef, (uint16_t*)out, R, C, P, bn_lpr(P));
     SLAK_LAUNCH_CHECK();
     return SLAK_OK;
 }
@@ -323,10 +449,33 @@ int slak_bn3_backward_sums(const void* dout, const void* y1, const void* y2, con
     int rc = bn_args_ok(N, C, P); if (rc) return rc;
     if (!workspace || workspace_bytes < slak_bn3_workspace_bytes(N, C)) return SLAK_ERR_WORKSPACE;
     float* rows = (float*)workspace;
+    int S, per; bn_slices(N, C, &S, &per);
+    hipLaunchKernelGGL(bn3_chansums<true>, dim3((unsigned)((C * S + BN_THREADS / 64 - 1) / (BN_THREADS / 64))), dim3(BN_THREADS), 0, (hipStream_t)stream,
+                       (const uint16_t*)dout, (const uint16_t*)y1, (const uint16_t*)y2, (const uint16_t*)y3, rows, N, C, P, S, per);
+    hipLaunchKernelGGL(bn3_colreduce, dim3(C), dim3(64), 0, (hipStream_t)stream, (const float*)rows, local_sums, S, C, 4);
+    SLAK_LAUNCH_CHECK();
+    return SLAK_OK;
+}
+
+/* Single-process backward: three launches. */
+int slak_bn3_backward_local(const void* dout, const void* y1, const void* y2, const void* y3, const float* stats, const float* const* gamma,
+                            float* bcoef, float* dgamma, float* dbeta, void* dy1, void* dy2, void* dy3, int N, int C, int P,
+                            void* workspace, size_t workspace_bytes, void* stream) {
+    if (!dout || !y1 || !y2 || !y3 || !stats || !gamma || !bcoef || !dgamma || !dbeta || !dy1 || !dy2 || !dy3) return SLAK_ERR_INVALID_ARG;
+    int rc = bn_args_ok(N, C, P); if (rc) return rc;
+    if (!workspace || workspace_bytes < slak_bn3_workspace_bytes(N, C)) return SLAK_ERR_WORKSPACE;
+    Bn3Params bp;
+    for (int b = 0; b < 3; ++b) { bp.gamma[b] = gamma[b]; bp.beta[b] = nullptr; bp.running_mean[b] = nullptr; bp.running_var[b] = nullptr; }
+    float* rows = (float*)workspace;
+    int S, per; bn_slices(N, C, &S, &per);
+    hipLaunchKernelGGL(bn3_chansums<true>, dim3((unsigned)((C * S + BN_THREADS / 64 - 1) / (BN_THREADS / 64))), dim3(BN_THREADS), 0, (hipStream_t)stream,
+                       (const uint16_t*)dout, (const uint16_t*)y1, (const uint16_t*)y2, (const uint16_t*)y3, rows, N, C, P, S, per);
+    hipLaunchKernelGGL(bn3_colreduce_finalize_bwd, dim3(C), dim3(64), 0, (hipStream_t)stream, (const float*)rows, S, stats, bp, bcoef, dgamma, dbeta, C,
+                       (float)((double)N * P));
     const int R = N * C;
-    hipLaunchKernelGGL(bn3_rowsums_bwd, dim3(bn_grid(R, P)), dim3(BN_THREADS), 0, (hipStream_t)stream,
-                       (const uint16_t*)dout, (const uint16_t*)y1, (const uint16_t*)y2, (const uint16_t*)y3, rows, R, P, bn_lpr(P));
-    hipLaunchKernelGGL(bn3_colreduce, dim3(C), dim3(64), 0, (hipStream_t)stream, (const float*)rows, local_sums, N, C, 4);
+    hipLaunchKernelGGL(bn3_apply_bwd, dim3(bn_grid(R, P)), dim3(BN_THREADS), 0, (hipStream_t)stream,
+                       (const uint16_t*)dout, (const uint16_t*)y1, (const uint16_t*)y2, (const uint16_t*)y3, (const float*)bcoef,
+                       (uint16_t*)dy1, (uint16_t*)dy2, (uint16_t*)dy3, R, C, P, bn_lpr(P));
     SLAK_LAUNCH_CHECK();
     return SLAK_OK;
 }
