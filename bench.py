@@ -320,6 +320,7 @@ def main():
     M.Block.fused_tail = not a.no_fused_tail and not a.fp32_dwconv    # HIP glue kernels around the pointwise GEMMs
     M.ReparamLargeKernelConv.fused_bn = not a.no_fused_bn and not a.fp32_dwconv   # branch BatchNorms + adds as one HIP op
     M.LayerNorm.fused_cf = not a.no_fused_tail                     # channels_first LayerNorm of stem/downsample as one HIP kernel
+    M.SLaK.fused_stem = os.environ.get("SLAK_FUSED_STEM", "1") != "0"
     M.SLaK.fused_downsample = not a.no_fused_tail and os.environ.get("SLAK_FUSED_DOWNSAMPLE", "1") != "0"   # LN -> 2x2/s2 conv as LN-to-patch kernel + library GEMMs
     M.ReparamLargeKernelConv.fused_tri = M.ReparamLargeKernelConv.fused_bn and not a.no_fused_tri   # three branch convs as one autograd node
     from slak_amd import block_ops

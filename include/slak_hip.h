@@ -191,6 +191,11 @@ int slak_ln_patch_backward(const void* g_bf16, const float* x, const float* weig
                            float* dx, float* dweight, float* dbias, int N, int C, int H, int W,
                            void* workspace /* slak_block_tail_workspace_bytes(N, C, H*W) */, size_t workspace_bytes, void* stream);
 
+/* Stem (models/SLaK.py:276-279: Conv2d(in_chans, C, kernel_size=4, stride=4) on the fp32 image): the 4x4 patches as the bf16 GEMM operand
+ * a[n][ho * (W/4) + wo][(c * 4 + kh) * 4 + kw] = x[n, c, 4 ho + kh, 4 wo + kw]; the conv is Y[n] = weight.view(C, in_chans*16) . a[n]^T (NCHW).
+ * H and W multiples of 4. */
+int slak_stem_patchify(const float* x, void* a_bf16, int N, int Cin, int H, int W, void* stream);
+
 /* The pointwise convolutions on the large maps (stage 1-2: M = N*H*W rows of C <= 192 or 4C <= 768 channels against a weight of a few
  * hundred KB) are HBM streams, not GEMMs: Y[M,N] = X[M,K] . Wt[N,K]^T (+ bias[N]) with both operands K-contiguous ("NT": pwconv1 /
  * pwconv2 forward take the nn.Linear weight as it is stored, models/SLaK.py:158-160; the data gradients take its transpose), bf16 in

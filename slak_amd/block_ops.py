@@ -570,6 +570,46 @@ class _DownsampleLnConv(torch.autograd.Function):
         return dx, dlw, dlb, dconv_w, dconv_b, None
 
 
+class _StemConv(torch.autograd.Function):
+    """Conv2d(in_chans, C, kernel_size=4, stride=4) of the fp32 input image under bf16 autocast as patch matrix + batched GEMMs (NCHW result)."""
+
+    @staticmethod
+    def forward(ctx, x, conv_w, conv_b):
+        _chk(x, "x", torch.float32)
+        N, Ci, H, W = x.shape
+        Co = conv_w.shape[0]
+        P16 = (H // 4) * (W // 4)
+        a = torch.empty((N, P16, Ci * 16), dtype=torch.bfloat16, device=x.device)
+        L = _lib.lib()
+        with torch.cuda.device(x.device):
+            _lib.check(L.slak_stem_patchify(x.data_ptr(), a.data_ptr(), N, Ci, H, W, _stream(x.device)), "slak_stem_patchify")
+        wp = conv_w.detach().reshape(Co, Ci * 16).to(torch.bfloat16)
+        if conv_b is not None:
+            y = torch.baddbmm(conv_b.detach().to(torch.bfloat16).view(1, Co, 1).expand(N, Co, P16), wp.unsqueeze(0).expand(N, Co, Ci * 16), a.transpose(1, 2))
+        else:
+            y = torch.matmul(wp, a.transpose(1, 2))
+        ctx.save_for_backward(a)
+        ctx.shape = (Co, Ci, conv_b is not None)
+        return y.view(N, Co, H // 4, W // 4)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (a,) = ctx.saved_tensors
+        Co, Ci, has_bias = ctx.shape
+        N, P16, K = a.shape
+        dy = dy.contiguous()
+        if dy.dtype != torch.bfloat16:
+            dy = dy.to(torch.bfloat16)
+        dy3 = dy.view(N, Co, P16)
+        dw = torch.bmm(dy3, a).sum(0, dtype=torch.float32).view(Co, Ci, 4, 4)          # per-image products (K = P16 each), fp32 sum over the batch
+        db = dy3.sum((0, 2), dtype=torch.float32) if has_bias else None
+        return None, dw, db
+
+
+def stem_conv(x, conv_w, conv_b):
+    return _StemConv.apply(x, conv_w, conv_b)
+
+
 def downsample_ln_conv(x, ln_w, ln_b, conv_w, conv_b, eps=1e-6):
     """conv2d(LN_channels_first(x), conv_w, conv_b, stride=2) for a 2x2 kernel, fp32 NCHW x -> bf16 NCHW (what autocast returns)."""
     return _DownsampleLnConv.apply(x, ln_w, ln_b, conv_w, conv_b, eps)

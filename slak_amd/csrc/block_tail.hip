@@ -852,6 +852,22 @@ static int set_lds(const void* k, size_t lds) {
     return 0;
 }
 
+// Stem (models/SLaK.py:276-279: Conv2d(in_chans, C, kernel_size=4, stride=4)): the non-overlapping 4x4 patches of the fp32 NCHW image as the
+// bf16 GEMM operand a[n][ho * Wo + wo][(c * 4 + kh) * 4 + kw] (the conv weight's own (c, kh, kw) order).  Thread <-> one (patch, c, kh):
+// a 16-byte read of four pixels, an 8-byte write; writes are fully coalesced (96 bytes per patch, patches contiguous).
+__global__ __launch_bounds__(256) void stem_patchify_kernel(const float* __restrict__ x, uint16_t* __restrict__ a, int N, int Cin, int H, int W) {
+    const int Ho = H / 4, Wo = W / 4, J = Cin * 4;
+    const long long total = (long long)N * Ho * Wo * J;
+    for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long long)gridDim.x * 256) {
+        const int j = (int)(t % J); const long long pt = t / J;
+        const int wo = (int)(pt % Wo); const long long q = pt / Wo;
+        const int ho = (int)(q % Ho), n = (int)(q / Ho);
+        const int c = j >> 2, kh = j & 3;
+        const float4 v = *(const float4*)(x + (((size_t)n * Cin + c) * H + 4 * ho + kh) * W + 4 * wo);
+        *(uint2*)(a + (size_t)t * 4) = uint2{bt_pack2(v.x, v.y), bt_pack2(v.z, v.w)};
+    }
+}
+
 // the table of gelu_grad_lut in device memory (one copy per device, built on first use): entry [sign * GD_N + (mag - GD_LO)]
 static const float* gelu_grad_table_device() {
     static std::mutex mu;
@@ -980,6 +996,17 @@ int slak_ln_patch_backward(const void* g_bf16, const float* x, const float* weig
     const int rc = launch_ln_patch_bwd_reg(g_bf16, x, weight, mean, rstd, dx, part, &rows, N, C, H, W, (hipStream_t)stream);
     if (rc != SLAK_OK) return rc;
     return reduce_partials(part, part + (size_t)rows * 2 * C, dweight, dbias, C, rows, 2 * C, (hipStream_t)stream);
+}
+
+int slak_stem_patchify(const float* x, void* a_bf16, int N, int Cin, int H, int W, void* stream) {
+    if (!x || !a_bf16) return SLAK_ERR_INVALID_ARG;
+    if (N <= 0 || Cin <= 0 || H <= 0 || W <= 0) return SLAK_ERR_INVALID_ARG;
+    if ((H & 3) || (W & 3) || (long long)N * Cin * H * W >= (1LL << 40)) return SLAK_ERR_UNSUPPORTED;
+    const long long total = (long long)N * (H / 4) * (W / 4) * Cin * 4;
+    long long g = (total + 255) / 256; if (g > 65536) g = 65536;
+    hipLaunchKernelGGL(stem_patchify_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, x, (uint16_t*)a_bf16, N, Cin, H, W);
+    SLAK_LAUNCH_CHECK();
+    return SLAK_OK;
 }
 
 int slak_scale_residual_forward(const void* shortcut, int shortcut_dtype, const void* z, const float* gamma, const float* sample_scale,

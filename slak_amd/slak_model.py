@@ -348,6 +348,12 @@ class SLaK(nn.Module):
                 if block_ops.ln_patch_covers(xc):
                     x = self.stages[i](block_ops.downsample_ln_conv(xc, ds[0].weight, ds[0].bias, ds[1].weight, ds[1].bias, ds[0].eps))
                     continue
+            if (self.fused_downsample and self.fused_stem and i == 0 and x.is_cuda and x.dtype == torch.float32 and torch.is_autocast_enabled() and not x.requires_grad
+                    and isinstance(ds[0], nn.Conv2d) and ds[0].kernel_size == (4, 4) and ds[0].stride == (4, 4) and ds[0].padding == (0, 0)
+                    and ds[0].groups == 1 and x.shape[2] % 4 == 0 and x.shape[3] % 4 == 0):
+                from . import block_ops                           # stem conv as patch matrix + library GEMMs (no MIOpen launch, no layout transposes)
+                x = self.stages[i](ds[1](block_ops.stem_conv(x.contiguous(), ds[0].weight, ds[0].bias)))
+                continue
             x = self.stages[i](ds(x))
         return self.norm(x.mean([-2, -1]))
 
@@ -355,6 +361,7 @@ class SLaK(nn.Module):
         return self.head(self.forward_features(x))
 
 
+SLaK.fused_stem = True                       # (with fused_downsample) the stem conv as patch matrix + library GEMMs (block_ops.stem_conv)
 SLaK.fused_downsample = False                # downsample layers as LN-to-patch-matrix kernel + library GEMMs (block_ops.downsample_ln_conv)
 
 

@@ -298,3 +298,23 @@ def test_downsample_ln_conv_matches_reference_modules(N, C, Co, H, W, gpu):
     _close(cb.grad, cbr.grad, 1e-3, "dconv_b")
     _close(lw.grad, lwr.grad, 2.0 ** -7, "dln_w")
     _close(lb.grad, lbr.grad, 2.0 ** -7, "dln_b")
+
+
+@pytest.mark.parametrize("N,Ci,Co,H,W", [(3, 3, 96, 224, 224), (2, 3, 128, 64, 96), (2, 4, 32, 8, 12)])
+def test_stem_conv_matches_conv2d(N, Ci, Co, H, W, gpu):
+    """block_ops.stem_conv = Conv2d(k=4, s=4) of models/SLaK.py:276-279 under bf16 autocast (input and weight rounded to bf16, fp32 accumulate)."""
+    from slak_amd import block_ops
+    torch.manual_seed(Co + H)
+    x = torch.randn(N, Ci, H, W, device=gpu)
+    cw = (torch.randn(Co, Ci, 4, 4, device=gpu) * 0.1).requires_grad_(True); cb = (torch.randn(Co, device=gpu) * 0.1).requires_grad_(True)
+    dy = torch.randn(N, Co, H // 4, W // 4, device=gpu).bfloat16()
+    y = block_ops.stem_conv(x, cw, cb)
+    assert y.dtype == torch.bfloat16 and y.shape == (N, Co, H // 4, W // 4)
+    y.backward(dy)
+    cwr = cw.detach().double().requires_grad_(True); cbr = cb.detach().double().requires_grad_(True)
+    w16 = cwr + (cwr.detach().float().bfloat16().double() - cwr.detach())
+    yr = F.conv2d(x.bfloat16().double(), w16, cbr.detach().float().bfloat16().double() + (cbr - cbr.detach()), stride=4)
+    yr.backward(dy.double())
+    _close(y, yr, 2.0 ** -8 * 1.05, "y")
+    _close(cw.grad, cwr.grad, 2.0 ** -7, "dconv_w")
+    _close(cb.grad, cbr.grad, 1e-3, "dconv_b")
