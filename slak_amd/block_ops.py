@@ -554,8 +554,11 @@ class _DownsampleLnConv(torch.autograd.Function):
             dy = dy.to(torch.bfloat16)
         dy3 = dy.view(N, Co, P4)
         da = torch.matmul(dy3.transpose(1, 2), wp)                                             # [N, P4, 4C]: dL/da in the patch layout
-        dyt = dy3.permute(1, 0, 2).reshape(Co, N * P4)                                         # (one copy: the reduction runs over n and the pixels)
-        dwp = torch.mm(dyt, a.view(N * P4, 4 * C)).float()
+        # weight gradient: the reduction runs over n and the pixels -> dY in pixel-major order (one copy), then the row-reduction GEMM kernel
+        # (the library's heuristic picks 64x64 macro tiles for K = N*P': 0.24 / 0.11 / 0.05 ms for the three layers against ~0.04 each)
+        dwp = linear_wgrad(dy3.transpose(1, 2).reshape(N * P4, Co), a.view(N * P4, 4 * C))
+        if dwp is None:
+            dwp = torch.mm(dy3.permute(1, 0, 2).reshape(Co, N * P4), a.view(N * P4, 4 * C)).float()
         dconv_w = dwp.view(Co, 2, 2, C).permute(0, 3, 1, 2).contiguous()
         dconv_b = dy3.sum((0, 2), dtype=torch.float32) if ctx.has_bias else None
         dx = torch.empty_like(x)
