@@ -64,60 +64,7 @@ __device__ __forceinline__ void store8(uint16_t* __restrict__ row, int p, int P,
     }
 }
 
-// rows[r][0..5] = sum y1, sum y1^2, sum y2, sum y2^2, sum y3, sum y3^2 over the P elements of row r
-__global__ __launch_bounds__(BN_THREADS) void bn3_rowsums_fwd(const uint16_t* __restrict__ y1, const uint16_t* __restrict__ y2,
-                                                            const uint16_t* __restrict__ y3, float* __restrict__ rows, int R, int P, int LPR) {
-    const int lane = threadIdx.x & 63, wv = blockIdx.x * (BN_THREADS / 64) + (threadIdx.x >> 6), nw = gridDim.x * (BN_THREADS / 64);
-    const int vec = (P & 7) == 0 ? 2 : ((P & 3) == 0 ? 1 : 0);
-    const int rpw = 64 / LPR, sub = lane / LPR, sl = lane - sub * LPR;      // rows per wavefront, my row slot, my lane in the row
-    for (int r0 = wv * rpw; r0 < R; r0 += nw * rpw) {
-        const int r = r0 + sub;
-        const bool rok = r < R;
-        const size_t base = (size_t)(rok ? r : 0) * P;
-        float s[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        for (int p = sl * 8; rok && p < P; p += LPR * 8) {
-            float a[8], b[8], c[8];
-            load8(y1 + base, p, P, vec, a); load8(y2 + base, p, P, vec, b); load8(y3 + base, p, P, vec, c);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) { s[0] += a[e]; s[1] += a[e] * a[e]; s[2] += b[e]; s[3] += b[e] * b[e]; s[4] += c[e]; s[5] += c[e] * c[e]; }
-        }
-#pragma unroll
-        for (int k = 0; k < 6; ++k) s[k] = bn_seg_sum(s[k], LPR);
-        if (rok && sl == 0) {
-#pragma unroll
-            for (int k = 0; k < 6; ++k) rows[(size_t)r * 6 + k] = s[k];
-        }
-    }
-}
-
-// rows[r][0..3] = sum dout, sum dout*y1, sum dout*y2, sum dout*y3
-__global__ __launch_bounds__(BN_THREADS) void bn3_rowsums_bwd(const uint16_t* __restrict__ dout, const uint16_t* __restrict__ y1,
-                                                            const uint16_t* __restrict__ y2, const uint16_t* __restrict__ y3,
-                                                            float* __restrict__ rows, int R, int P, int LPR) {
-    const int lane = threadIdx.x & 63, wv = blockIdx.x * (BN_THREADS / 64) + (threadIdx.x >> 6), nw = gridDim.x * (BN_THREADS / 64);
-    const int vec = (P & 7) == 0 ? 2 : ((P & 3) == 0 ? 1 : 0);
-    const int rpw = 64 / LPR, sub = lane / LPR, sl = lane - sub * LPR;
-    for (int r0 = wv * rpw; r0 < R; r0 += nw * rpw) {
-        const int r = r0 + sub;
-        const bool rok = r < R;
-        const size_t base = (size_t)(rok ? r : 0) * P;
-        float s[4] = {0.f, 0.f, 0.f, 0.f};
-        for (int p = sl * 8; rok && p < P; p += LPR * 8) {
-            float g[8], a[8], b[8], c[8];
-            load8(dout + base, p, P, vec, g); load8(y1 + base, p, P, vec, a); load8(y2 + base, p, P, vec, b); load8(y3 + base, p, P, vec, c);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) { s[0] += g[e]; s[1] += g[e] * a[e]; s[2] += g[e] * b[e]; s[3] += g[e] * c[e]; }
-        }
-#pragma unroll
-        for (int k = 0; k < 4; ++k) s[k] = bn_seg_sum(s[k], LPR);
-        if (rok && sl == 0) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) rows[(size_t)r * 4 + k] = s[k];
-        }
-    }
-}
-
-// Channel-slice sums (round 2; the row-sum kernels above reduce every (n, c) row on its own -- 36 shuffles per row -- and leave N partial
+// Channel-slice sums (round 2; the round-1 row-sum kernels reduced every (n, c) row on its own -- 36 shuffles per row -- and left N partial
 // rows per channel): a wavefront owns channel c and the images [s*per, (s+1)*per) of the batch; its lanes stride over the (image, 16-byte
 // chunk) pairs of that slice and keep plain per-lane sums, reduced ONCE at the end: part[(s*C + c)*K + k].  K = 6 (forward: sum y_b,
 // sum y_b^2) or 4 (backward: sum dout, sum dout*y_b).
