@@ -140,6 +140,13 @@ int slak_mask_checksum(slak_mask_plan_t* plan, unsigned long long* out_host, voi
 int slak_dwconv2d_tri_supported(int dtype, int N, int C, int H, int W, int K);
 int slak_dwconv2d_tri_forward(const void* x, const float* w_v, const float* w_h, const float* w_s, void* y_v, void* y_h, void* y_s,
                               int dtype, int N, int C, int H, int W, int K, void* stream);
+/* slak_dwconv2d_tri_forward that also leaves the batch statistics of the three branch BatchNorms (models/SLaK.py:92-95: conv -> bn per
+ * branch): stats[rows][C][6] = partial sums (sum y_v, sum y_v^2, sum y_h, sum y_h^2, sum y_s, sum y_s^2) of the STORED (rounded) outputs per
+ * (row, channel); rows = slak_dwconv2d_tri_stats_rows(...) (0: no such kernel for the shape; bf16 only).  slak_bn3_forward_local takes them in
+ * place of its own pass over the three tensors. */
+int slak_dwconv2d_tri_stats_rows(int dtype, int N, int C, int H, int W, int K);
+int slak_dwconv2d_tri_forward_stats(const void* x, const float* w_v, const float* w_h, const float* w_s, void* y_v, void* y_h, void* y_s,
+                                    float* stats, int dtype, int N, int C, int H, int W, int K, void* stream);
 int slak_dwconv2d_tri_backward_data(const void* dy_v, const void* dy_h, const void* dy_s, const float* w_v, const float* w_h,
                                     const float* w_s, void* dx, int dtype, int N, int C, int H, int W, int K, void* stream);
 
@@ -264,7 +271,8 @@ int slak_bn3_backward_apply(const void* dout, const void* y1, const void* y2, co
  * _backward_sums + _backward_apply with global_sums = local_sums, count = N * P. */
 int slak_bn3_forward_local(const void* y1, const void* y2, const void* y3, const float* const* gamma, const float* const* beta,
                            float* const* running_mean, float* const* running_var, float eps, float momentum, int update_running,
-                           float* coef, float* stats, void* out, int N, int C, int P, void* workspace, size_t workspace_bytes, void* stream);
+                           float* coef, float* stats, void* out, int N, int C, int P, void* workspace, size_t workspace_bytes, void* stream,
+                           const float* pre_sums /* NULL, or [pre_rows][C][6] partial sums from slak_dwconv2d_tri_forward_stats */, int pre_rows);
 int slak_bn3_backward_local(const void* dout, const void* y1, const void* y2, const void* y3, const float* stats, const float* const* gamma,
                             float* bcoef, float* dgamma, float* dbeta, void* dy1, void* dy2, void* dy3, int N, int C, int P,
                             void* workspace, size_t workspace_bytes, void* stream);

@@ -132,7 +132,7 @@ class _TriDwConv(torch.autograd.Function):
     per-branch kernels run and the gradients are added here.  Weight gradients always come from the per-branch kernels."""
 
     @staticmethod
-    def forward(ctx, x, wv, wh, ws):
+    def forward(ctx, x, wv, wh, ws, want_stats=False):
         from . import ops
         _chk(x, "input")
         N, C, H, W = x.shape
@@ -146,20 +146,33 @@ class _TriDwConv(torch.autograd.Function):
         # 128x96x56x56 -- so those planes run three launches, the data gradient accumulating in place.)
         tri = (dt is not None and all(w.dtype == torch.float32 and w.is_contiguous() for w in (wv, wh, ws))
                and L.slak_dwconv2d_tri_supported(dt, N, C, H, W, K) == (2 if use_big_tri else 1))
+        stats = None
         if tri:
             yv, yh, ys = torch.empty_like(x), torch.empty_like(x), torch.empty_like(x)
+            rows = int(L.slak_dwconv2d_tri_stats_rows(dt, N, C, H, W, K)) if (want_stats == 2 and bn_stats_in_conv) else 0
             with torch.cuda.device(x.device):
-                _lib.check(L.slak_dwconv2d_tri_forward(x.data_ptr(), wv.data_ptr(), wh.data_ptr(), ws.data_ptr(), yv.data_ptr(),
-                                                       yh.data_ptr(), ys.data_ptr(), dt, N, C, H, W, K, _stream(x.device)),
-                           "slak_dwconv2d_tri_forward")
+                if rows > 0:                                     # the launch also leaves the branch BatchNorms' batch statistics
+                    stats = torch.empty((rows, C, 6), dtype=torch.float32, device=x.device)
+                    _lib.check(L.slak_dwconv2d_tri_forward_stats(x.data_ptr(), wv.data_ptr(), wh.data_ptr(), ws.data_ptr(), yv.data_ptr(),
+                                                                 yh.data_ptr(), ys.data_ptr(), stats.data_ptr(), dt, N, C, H, W, K, _stream(x.device)),
+                               "slak_dwconv2d_tri_forward_stats")
+                else:
+                    _lib.check(L.slak_dwconv2d_tri_forward(x.data_ptr(), wv.data_ptr(), wh.data_ptr(), ws.data_ptr(), yv.data_ptr(),
+                                                           yh.data_ptr(), ys.data_ptr(), dt, N, C, H, W, K, _stream(x.device)),
+                               "slak_dwconv2d_tri_forward")
         else:
             yv, yh, ys = ops.dwconv2d_forward(x, wv), ops.dwconv2d_forward(x, wh), ops.dwconv2d_forward(x, ws)
         ctx.save_for_backward(x, wv, wh, ws)
         ctx.tri = tri
+        if want_stats:
+            if stats is None:
+                stats = torch.empty(0, device=x.device)
+            ctx.mark_non_differentiable(stats)
+            return yv, yh, ys, stats
         return yv, yh, ys
 
     @staticmethod
-    def backward(ctx, dyv, dyh, dys):
+    def backward(ctx, dyv, dyh, dys, _dstats=None):
         from . import ops
         x, wv, wh, ws = ctx.saved_tensors
         N, C, H, W = x.shape
@@ -201,12 +214,17 @@ class _TriDwConv(torch.autograd.Function):
             dwv = ops.dwconv2d_backward_filter(dyv, x, wv) if ctx.needs_input_grad[1] else None
             dwh = ops.dwconv2d_backward_filter(dyh, x, wh) if ctx.needs_input_grad[2] else None
             dws = ops.dwconv2d_backward_filter(dys, x, ws) if ctx.needs_input_grad[3] else None
-        return dx, dwv, dwh, dws
+        return dx, dwv, dwh, dws, None
 
 
-def tri_dwconv(x, w_vertical, w_horizontal, w_small):
-    """(y_v, y_h, y_s) = depthwise conv of x with the (C,1,K,5), (C,1,5,K) and (C,1,5,5) filters (stride 1, 'same' padding)."""
-    return _TriDwConv.apply(x, w_vertical, w_horizontal, w_small)
+bn_stats_in_conv = os.environ.get("SLAK_BN_STATS_IN_CONV", "1") != "0"   # three-branch forward launches also leave the branch BatchNorms' batch sums
+
+
+def tri_dwconv(x, w_vertical, w_horizontal, w_small, want_stats=False):
+    """(y_v, y_h, y_s) = depthwise conv of x with the (C,1,K,5), (C,1,5,K) and (C,1,5,5) filters (stride 1, 'same' padding).
+    want_stats (1 or 2): a fourth result; with 2 it holds the partial batch sums [rows][C][6] of the stored outputs for
+    branch_bn3(..., stats=) where the launch produces them, otherwise it is an empty tensor."""
+    return _TriDwConv.apply(x, w_vertical, w_horizontal, w_small, want_stats)
 
 
 def tri_dwconv_sum(x, w_vertical, w_horizontal, w_small, bias=None):
@@ -335,7 +353,7 @@ class _BranchBN3(torch.autograd.Function):
     instead of SyncBatchNorm's three all_gathers + three all_reduces per block), running-stat update, fused scale/shift/add."""
 
     @staticmethod
-    def forward(ctx, y1, y2, y3, g1, b1, g2, b2, g3, b3, bns, group):
+    def forward(ctx, y1, y2, y3, g1, b1, g2, b2, g3, b3, bns, group, pre=None):
         import torch.distributed as dist
         for t, n in ((y1, "y1"), (y2, "y2"), (y3, "y3")):
             _chk(t, n, torch.bfloat16)
@@ -363,7 +381,8 @@ class _BranchBN3(torch.autograd.Function):
             with torch.cuda.device(dev):
                 _lib.check(L.slak_bn3_forward_local(y1.data_ptr(), y2.data_ptr(), y3.data_ptr(), _ptr3(gam), _ptr3(bet), _ptr3(rmean), _ptr3(rvar),
                                                     eps, float(momentum), 1 if bns[0].track_running_stats else 0, coef.data_ptr(), stats.data_ptr(),
-                                                    out.data_ptr(), N, C, P, ws.data_ptr() if ws is not None else None, nb, _stream(dev)),
+                                                    out.data_ptr(), N, C, P, ws.data_ptr() if ws is not None else None, nb, _stream(dev),
+                                                    pre.data_ptr() if pre is not None else None, int(pre.shape[0]) if pre is not None else 0),
                            "slak_bn3_forward_local")
             ctx.save_for_backward(y1, y2, y3, g1, g2, g3, stats)
             ctx.group = None
@@ -415,7 +434,7 @@ class _BranchBN3(torch.autograd.Function):
                 _lib.check(L.slak_bn3_backward_local(dout.data_ptr(), y1.data_ptr(), y2.data_ptr(), y3.data_ptr(), stats.data_ptr(), _ptr3([g1, g2, g3]),
                                                      bcoef.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), d1.data_ptr(), d2.data_ptr(), d3.data_ptr(),
                                                      N, C, P, ws.data_ptr() if ws is not None else None, nb, _stream(dev)), "slak_bn3_backward_local")
-            return d1, d2, d3, dgamma[0], dbeta[0], dgamma[1], dbeta[1], dgamma[2], dbeta[2], None, None
+            return d1, d2, d3, dgamma[0], dbeta[0], dgamma[1], dbeta[1], dgamma[2], dbeta[2], None, None, None
         lsums = torch.empty(C * 4, dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
             _lib.check(L.slak_bn3_backward_sums(dout.data_ptr(), y1.data_ptr(), y2.data_ptr(), y3.data_ptr(), lsums.data_ptr(), N, C, P,
@@ -434,10 +453,10 @@ class _BranchBN3(torch.autograd.Function):
                                                  stats.data_ptr(), _ptr3([g1, g2, g3]),
                                                  bcoef.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(),
                                                  d1.data_ptr(), d2.data_ptr(), d3.data_ptr(), N, C, P, _stream(dev)), "slak_bn3_backward_apply")
-        return d1, d2, d3, dgamma[0], dbeta[0], dgamma[1], dbeta[1], dgamma[2], dbeta[2], None, None
+        return d1, d2, d3, dgamma[0], dbeta[0], dgamma[1], dbeta[1], dgamma[2], dbeta[2], None, None, None
 
 
-def branch_bn3(y1, y2, y3, bn1, bn2, bn3):
+def branch_bn3(y1, y2, y3, bn1, bn2, bn3, stats=None):
     """``bn1(y1) + bn2(y2) + bn3(y3)`` for three nn.BatchNorm2d / nn.SyncBatchNorm modules (their parameters and buffers are used and
     updated in place).  Training: batch statistics (synchronised across the default/``process_group`` ranks for SyncBatchNorm);
     eval: running statistics."""
@@ -449,7 +468,9 @@ def branch_bn3(y1, y2, y3, bn1, bn2, bn3):
             pg = bn1.process_group if bn1.process_group is not None else dist.group.WORLD
             if dist.get_world_size(pg) > 1:
                 group = pg
-        return _BranchBN3.apply(y1, y2, y3, bn1.weight, bn1.bias, bn2.weight, bn2.bias, bn3.weight, bn3.bias, bns, group)
+        pre = stats if (stats is not None and stats.dim() == 3 and stats.shape[0] > 0 and group is None and stats.shape[1:] == (y1.shape[1], 6)
+                        and stats.dtype == torch.float32 and stats.is_contiguous()) else None
+        return _BranchBN3.apply(y1, y2, y3, bn1.weight, bn1.bias, bn2.weight, bn2.bias, bn3.weight, bn3.bias, bns, group, pre)
     # eval: one apply pass with coefficients from the running statistics (no autograd needed for the statistics)
     N, C, H, W = y1.shape
     L = _lib.lib()

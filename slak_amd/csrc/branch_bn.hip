@@ -347,17 +347,23 @@ int slak_bn3_forward_sums(const void* y1, const void* y2, const void* y3, float*
 /* Single-process training forward (no statistics exchange between the sums and the apply pass): three launches. */
 int slak_bn3_forward_local(const void* y1, const void* y2, const void* y3, const float* const* gamma, const float* const* beta,
                            float* const* running_mean, float* const* running_var, float eps, float momentum, int update_running,
-                           float* coef, float* stats, void* out, int N, int C, int P, void* workspace, size_t workspace_bytes, void* stream) {
+                           float* coef, float* stats, void* out, int N, int C, int P, void* workspace, size_t workspace_bytes, void* stream,
+                           const float* pre_sums, int pre_rows) {
     if (!y1 || !y2 || !y3 || !gamma || !beta || !running_mean || !running_var || !coef || !stats || !out) return SLAK_ERR_INVALID_ARG;
+    if (pre_sums && pre_rows <= 0) return SLAK_ERR_INVALID_ARG;
     int rc = bn_args_ok(N, C, P); if (rc) return rc;
     if (!workspace || workspace_bytes < slak_bn3_workspace_bytes(N, C)) return SLAK_ERR_WORKSPACE;
     Bn3Params bp;
     for (int b = 0; b < 3; ++b) { bp.gamma[b] = gamma[b]; bp.beta[b] = beta[b]; bp.running_mean[b] = running_mean[b]; bp.running_var[b] = running_var[b]; }
-    float* rows = (float*)workspace;
-    int S, per; bn_slices(N, C, &S, &per);
-    hipLaunchKernelGGL(bn3_chansums<false>, dim3((unsigned)((C * S + BN_THREADS / 64 - 1) / (BN_THREADS / 64))), dim3(BN_THREADS), 0, (hipStream_t)stream,
-                       (const uint16_t*)nullptr, (const uint16_t*)y1, (const uint16_t*)y2, (const uint16_t*)y3, rows, N, C, P, S, per);
-    hipLaunchKernelGGL(bn3_colreduce_finalize_fwd, dim3(C), dim3(64), 0, (hipStream_t)stream, (const float*)rows, S, bp, coef, stats, C,
+    const float* rows = pre_sums;
+    int S = pre_rows, per;
+    if (!pre_sums) {                                               // the producer did not leave the sums: one read pass over the three tensors
+        bn_slices(N, C, &S, &per);
+        hipLaunchKernelGGL(bn3_chansums<false>, dim3((unsigned)((C * S + BN_THREADS / 64 - 1) / (BN_THREADS / 64))), dim3(BN_THREADS), 0, (hipStream_t)stream,
+                           (const uint16_t*)nullptr, (const uint16_t*)y1, (const uint16_t*)y2, (const uint16_t*)y3, (float*)workspace, N, C, P, S, per);
+        rows = (const float*)workspace;
+    }
+    hipLaunchKernelGGL(bn3_colreduce_finalize_fwd, dim3(C), dim3(64), 0, (hipStream_t)stream, rows, S, bp, coef, stats, C,
                        (float)((double)N * P), eps, momentum, update_running);
     const int R = N * C;
     hipLaunchKernelGGL(bn3_apply_fwd, dim3(bn_grid(R, P)), dim3(BN_THREADS), 0, (hipStream_t)stream,

@@ -214,6 +214,21 @@ int slak_dwconv2d_tri_forward(const void* x, const float* w_v, const float* w_h,
     return launch_dwconv_mfma_tri(false, in, out, w, dtype, N, C, H, W, K, (hipStream_t)stream);
 }
 
+/* The forward three-branch launch that also leaves the branch BatchNorms' batch statistics: stats[rows][C][6] = per (row, channel) partial
+ * sums (sum y_v, sum y_v^2, sum y_h, sum y_h^2, sum y_s, sum y_s^2) of the stored (rounded) outputs; rows = slak_dwconv2d_tri_stats_rows(...)
+ * (0: this shape has no such kernel -- use slak_dwconv2d_tri_forward).  bf16 only. */
+int slak_dwconv2d_tri_stats_rows(int dtype, int N, int C, int H, int W, int K) {
+    if (use_dense_tri()) return 0;
+    return dwconv_mfma_small_tri_stats_rows(N, C, H, W, K, dtype);
+}
+int slak_dwconv2d_tri_forward_stats(const void* x, const float* w_v, const float* w_h, const float* w_s, void* y_v, void* y_h, void* y_s,
+                                    float* stats, int dtype, int N, int C, int H, int W, int K, void* stream) {
+    if (!x || !w_v || !w_h || !w_s || !y_v || !y_h || !y_s || !stats) return SLAK_ERR_INVALID_ARG;
+    if (slak_dwconv2d_tri_stats_rows(dtype, N, C, H, W, K) <= 0) return SLAK_ERR_UNSUPPORTED;
+    const void* in[3] = {x, x, x}; void* out[3] = {y_v, y_h, y_s}; const float* w[3] = {w_v, w_h, w_s};
+    return launch_dwconv_mfma_small_tri(false, in, out, w, dtype, N, C, H, W, K, (hipStream_t)stream, stats);
+}
+
 int slak_dwconv2d_tri_backward_data(const void* dy_v, const void* dy_h, const void* dy_s, const float* w_v, const float* w_h,
                                     const float* w_s, void* dx, int dtype, int N, int C, int H, int W, int K, void* stream) {
     if (!dy_v || !dy_h || !dy_s || !w_v || !w_h || !w_s || !dx) return SLAK_ERR_INVALID_ARG;

@@ -11,6 +11,7 @@
 // next row (or plane), which are cleared in the fragment registers (two v_and per fragment: nothing foreign, NaN or not, ever
 // reaches an MFMA) and never transposed into x^T; results leave as 2-byte stores (rows of an odd width are not dword aligned).
 #include "mfma_common.h"
+#include <type_traits>
 
 namespace slak {
 
@@ -29,7 +30,8 @@ struct SmallTriParams {
     int N, C, H, W, K, flip;
     int images_per_slice, slices;
     unsigned tensor_bytes;
-};
+    float* stats;                        // forward only, or NULL: [slices][C][6] = per (slice, channel) sum y_b, sum y_b^2 of the ROUNDED outputs
+};                                       // (the batch statistics of the three branch BatchNorms, models/SLaK.py:92-95: saves their read pass)
 
 template <typename T> __device__ __forceinline__ f32x4_t st_mfma16(s16x8 a, s16x8 b, f32x4_t c);
 template <> __device__ __forceinline__ f32x4_t st_mfma16<bf16_t>(s16x8 a, s16x8 b, f32x4_t c) {
@@ -181,6 +183,14 @@ __global__ __launch_bounds__(MF_THREADS) void dwconv_mfma_small_tri_kernel(const
         }
     };
 
+    float bsum[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    auto stat4 = [&](const f32x4_t& v, int b) {                   // what store4 stores, as the BatchNorm statistics see it
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float r = __uint_as_float((pack2<T>(v[j], 0.f) & 0xffffu) << 16);
+            if (l15 < p.H && 4 * kg + j < p.W) { bsum[2 * b] += r; bsum[2 * b + 1] += r * r; }
+        }
+    };
     for (int q = 0; q < npairs; ++q) {
         {
             const int st = (q < ST_NS - 2 ? q : ST_NS - 2) * NSTORE;
@@ -235,9 +245,21 @@ __global__ __launch_bounds__(MF_THREADS) void dwconv_mfma_small_tri_kernel(const
                 store4(s, ro[0], go);
             } else {
                 store4(av, ro[0], go); store4(ah, ro[1], go); store4(as, ro[2], go);
+                if constexpr (sizeof(T) == 2 && std::is_same<T, bf16_t>::value) { if (p.stats) { stat4(av, 0); stat4(ah, 1); stat4(as, 2); } }
             }
         }
         if (q + ST_NS - 1 < npairs) issue_pair(q + ST_NS - 1);
+    }
+    if constexpr (!DGRAD) {
+        if (p.stats) {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+                float v = bsum[k];
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+                if (lane == 0) p.stats[((size_t)slice * p.C + c) * 6 + k] = v;
+            }
+        }
     }
 }
 
@@ -281,10 +303,19 @@ static int launch_tri_t(SmallTriParams& p, hipStream_t st) {
     return p.W < 8 ? launch_tri_tn<T, DGRAD, true>(p, st) : launch_tri_tn<T, DGRAD, false>(p, st);
 }
 
+// rows of the forward kernel's statistics output ([rows][C][6]); 0 = the kernel does not take the shape
+int dwconv_mfma_small_tri_stats_rows(int N, int C, int H, int W, int K, int dtype) {
+    if (dtype != SLAK_BF16 || !dwconv_mfma_small_tri_supported(N, C, H, W, K, dtype)) return 0;
+    SmallTriParams p;
+    fill_tri_params(p, N, C, H, W, K, 3 * mfma_cu_count());
+    return p.slices;
+}
+
 int launch_dwconv_mfma_small_tri(bool dgrad, const void* const* in, void* const* out, const float* const* w, int dtype,
-                                 int N, int C, int H, int W, int K, hipStream_t st) {
+                                 int N, int C, int H, int W, int K, hipStream_t st, float* stats) {
     if (!dwconv_mfma_small_tri_supported(N, C, H, W, K, dtype)) return SLAK_ERR_UNSUPPORTED;
     SmallTriParams p;
+    p.stats = dgrad ? nullptr : stats;
     fill_tri_params(p, N, C, H, W, K, 768);
     for (int i = 0; i < 3; ++i) { p.in[i] = in[dgrad ? i : 0]; p.out[i] = out[dgrad ? 0 : i]; p.w[i] = w[i]; }
     p.flip = dgrad ? 1 : 0;

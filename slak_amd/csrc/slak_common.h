@@ -88,7 +88,8 @@ int launch_dwconv_mfma_small_dma(const void* x, int x_dt, const void* w, int w_d
                                  const ConvDims& d, bool flip_filter, hipStream_t st);
 bool dwconv_mfma_small_tri_supported(int N, int C, int H, int W, int K, int dtype);
 int launch_dwconv_mfma_small_tri(bool dgrad, const void* const* in, void* const* out, const float* const* w, int dtype,
-                                 int N, int C, int H, int W, int K, hipStream_t st);
+                                 int N, int C, int H, int W, int K, hipStream_t st, float* stats = nullptr);
+int dwconv_mfma_small_tri_stats_rows(int N, int C, int H, int W, int K, int dtype);
 bool dwconv_mfma_dense_tri_supported(int N, int C, int H, int W, int K, int dtype);
 int launch_dwconv_mfma_dense_tri(bool dgrad, const void* const* in, void* const* out, const float* const* w, int dtype,
                                  int N, int C, int H, int W, int K, hipStream_t st);

@@ -145,9 +145,10 @@ class ReparamLargeKernelConv(nn.Module):
             c1, c2, c3 = self.LoRA1.conv, self.LoRA2.conv, self.small_conv.conv
             if (self.fused_tri and c1.bias is None and c2.bias is None and c3.bias is None and tuple(c3.kernel_size) == (5, 5)
                     and c1.kernel_size[1] == 5 and c2.kernel_size[0] == 5 and c1.kernel_size[0] == c2.kernel_size[1] and c1.kernel_size[0] > 5):
-                y1, y2, y3 = block_ops.tri_dwconv(inputs.contiguous(), c1.weight, c2.weight, c3.weight)     # one autograd node for the three branches
-            else:
-                y1, y2, y3 = c1(inputs), c2(inputs), c3(inputs)
+                # one autograd node for the three branches; in training its forward launch also leaves the BatchNorms' batch sums
+                y1, y2, y3, st = block_ops.tri_dwconv(inputs.contiguous(), c1.weight, c2.weight, c3.weight, want_stats=2 if self.training else 1)
+                return block_ops.branch_bn3(y1, y2, y3, self.LoRA1.bn, self.LoRA2.bn, self.small_conv.bn, stats=st)
+            y1, y2, y3 = c1(inputs), c2(inputs), c3(inputs)
             return block_ops.branch_bn3(y1, y2, y3, self.LoRA1.bn, self.LoRA2.bn, self.small_conv.bn)
         if self.Decom:
             out = self.LoRA1(inputs) + self.LoRA2(inputs)
