@@ -140,6 +140,11 @@ int slak_mask_checksum(slak_mask_plan_t* plan, unsigned long long* out_host, voi
 int slak_dwconv2d_tri_supported(int dtype, int N, int C, int H, int W, int K);
 int slak_dwconv2d_tri_forward(const void* x, const float* w_v, const float* w_h, const float* w_s, void* y_v, void* y_h, void* y_s,
                               int dtype, int N, int C, int H, int W, int K, void* stream);
+/* slak_dwconv2d_forward that also leaves the batch statistics of the BatchNorm behind the conv (models/SLaK.py:38-47: conv -> bn):
+ * stats[rows][C][2] = partial (sum y, sum y^2) of the stored outputs per (row, channel); *stats_rows = rows written; the caller provides room
+ * for 4 N rows.  Only the LDS-DMA ring kernel (56 x 56 / 28 x 28 class, bf16) gathers them: SLAK_ERR_UNSUPPORTED otherwise. */
+int slak_dwconv2d_forward_stats(const void* x, int x_dtype, const void* w, int w_dtype, void* y, int y_dtype, float* stats, int stats_capacity_rows,
+                                int* stats_rows, int N, int C, int H, int W, int kh, int kw, void* stream);
 /* slak_dwconv2d_tri_forward that also leaves the batch statistics of the three branch BatchNorms (models/SLaK.py:92-95: conv -> bn per
  * branch): stats[rows][C][6] = partial sums (sum y_v, sum y_v^2, sum y_h, sum y_h^2, sum y_s, sum y_s^2) of the STORED (rounded) outputs per
  * (row, channel); rows = slak_dwconv2d_tri_stats_rows(...) (0: no such kernel for the shape; bf16 only).  slak_bn3_forward_local takes them in
@@ -272,7 +277,10 @@ int slak_bn3_backward_apply(const void* dout, const void* y1, const void* y2, co
 int slak_bn3_forward_local(const void* y1, const void* y2, const void* y3, const float* const* gamma, const float* const* beta,
                            float* const* running_mean, float* const* running_var, float eps, float momentum, int update_running,
                            float* coef, float* stats, void* out, int N, int C, int P, void* workspace, size_t workspace_bytes, void* stream,
-                           const float* pre_sums /* NULL, or [pre_rows][C][6] partial sums from slak_dwconv2d_tri_forward_stats */, int pre_rows);
+                           const float* const* pre_sums /* NULL, or 3 device pointers: branch b's partial sums, element (row, c, k) at
+                                                           pre_sums[b][(row * C + c) * pre_stride + k], k = 0 (sum), 1 (sum of squares) */,
+                           const int* pre_rows /* rows per branch */, int pre_stride /* 6: one slak_dwconv2d_tri_forward_stats array, pointers offset
+                                                           by 0, 2, 4 floats; 2: three slak_dwconv2d_forward_stats arrays */);
 int slak_bn3_backward_local(const void* dout, const void* y1, const void* y2, const void* y3, const float* stats, const float* const* gamma,
                             float* bcoef, float* dgamma, float* dbeta, void* dy1, void* dy2, void* dy3, int N, int C, int P,
                             void* workspace, size_t workspace_bytes, void* stream);

@@ -81,7 +81,8 @@ SIGNATURES = {
     "slak_bn3_backward_sums": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _sz, _vp]),
     "slak_bn3_backward_apply": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _d, _vp, _vp, ctypes.POINTER(_vp), _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "slak_bn3_forward_local": (_i, [_vp, _vp, _vp, ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(_vp),
-                                    ctypes.c_float, ctypes.c_float, _i, _vp, _vp, _vp, _i, _i, _i, _vp, _sz, _vp, _vp, _i]),
+                                    ctypes.c_float, ctypes.c_float, _i, _vp, _vp, _vp, _i, _i, _i, _vp, _sz, _vp, ctypes.POINTER(_vp), ctypes.POINTER(_i), _i]),
+    "slak_dwconv2d_forward_stats": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, ctypes.POINTER(_i), _i, _i, _i, _i, _i, _i, _vp]),
     "slak_dwconv2d_tri_stats_rows": (_i, [_i, _i, _i, _i, _i, _i]),
     "slak_dwconv2d_tri_forward_stats": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "slak_bn3_backward_local": (_i, [_vp, _vp, _vp, _vp, _vp, ctypes.POINTER(_vp), _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _sz, _vp]),

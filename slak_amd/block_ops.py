@@ -5,6 +5,7 @@
 
 (models/SLaK.py:153-166, :253-255).  x bf16 NCHW, z bf16 NHWC; parameters, statistics and the residual stream fp32.
 """
+import ctypes
 import os
 
 import torch
@@ -160,19 +161,28 @@ class _TriDwConv(torch.autograd.Function):
                     _lib.check(L.slak_dwconv2d_tri_forward(x.data_ptr(), wv.data_ptr(), wh.data_ptr(), ws.data_ptr(), yv.data_ptr(),
                                                            yh.data_ptr(), ys.data_ptr(), dt, N, C, H, W, K, _stream(x.device)),
                                "slak_dwconv2d_tri_forward")
+        elif want_stats == 2 and bn_stats_in_conv:               # per-branch launches that gather their BatchNorm's sums in the copy-out
+            (yv, sv), (yh, sh), (ys, ss) = ops.dwconv2d_forward_stats(x, wv), ops.dwconv2d_forward_stats(x, wh), ops.dwconv2d_forward_stats(x, ws)
+            if sv is not None and sh is not None and ss is not None:
+                stats = (sv, sh, ss)
         else:
             yv, yh, ys = ops.dwconv2d_forward(x, wv), ops.dwconv2d_forward(x, wh), ops.dwconv2d_forward(x, ws)
         ctx.save_for_backward(x, wv, wh, ws)
         ctx.tri = tri
         if want_stats:
+            # the sums travel as three non-differentiable outputs: one [rows][C][6] array (three-branch launch) seen through three offsets,
+            # three [rows_b][C][2] arrays (per-branch launches), or three empty tensors
             if stats is None:
-                stats = torch.empty(0, device=x.device)
-            ctx.mark_non_differentiable(stats)
-            return yv, yh, ys, stats
+                e = torch.empty(0, device=x.device)
+                stats = (e, e.clone(), e.clone())
+            elif not isinstance(stats, tuple):
+                stats = (stats, stats[:, :, 2:], stats[:, :, 4:])
+            ctx.mark_non_differentiable(*stats)
+            return (yv, yh, ys) + tuple(stats)
         return yv, yh, ys
 
     @staticmethod
-    def backward(ctx, dyv, dyh, dys, _dstats=None):
+    def backward(ctx, dyv, dyh, dys, *_dstats):
         from . import ops
         x, wv, wh, ws = ctx.saved_tensors
         N, C, H, W = x.shape
@@ -222,9 +232,10 @@ bn_stats_in_conv = os.environ.get("SLAK_BN_STATS_IN_CONV", "1") != "0"   # three
 
 def tri_dwconv(x, w_vertical, w_horizontal, w_small, want_stats=False):
     """(y_v, y_h, y_s) = depthwise conv of x with the (C,1,K,5), (C,1,5,K) and (C,1,5,5) filters (stride 1, 'same' padding).
-    want_stats (1 or 2): a fourth result; with 2 it holds the partial batch sums [rows][C][6] of the stored outputs for
-    branch_bn3(..., stats=) where the launch produces them, otherwise it is an empty tensor."""
-    return _TriDwConv.apply(x, w_vertical, w_horizontal, w_small, want_stats)
+    want_stats (1 or 2): a fourth result, a triple of tensors for branch_bn3(..., stats=); with 2 they hold the partial batch sums of the
+    stored outputs where the launches gather them (views [rows][C][>=2]: sum, sum of squares in the first two columns), otherwise they are empty."""
+    r = _TriDwConv.apply(x, w_vertical, w_horizontal, w_small, want_stats)
+    return (r[0], r[1], r[2], tuple(r[3:])) if want_stats else r
 
 
 def tri_dwconv_sum(x, w_vertical, w_horizontal, w_small, bias=None):
@@ -382,7 +393,9 @@ class _BranchBN3(torch.autograd.Function):
                 _lib.check(L.slak_bn3_forward_local(y1.data_ptr(), y2.data_ptr(), y3.data_ptr(), _ptr3(gam), _ptr3(bet), _ptr3(rmean), _ptr3(rvar),
                                                     eps, float(momentum), 1 if bns[0].track_running_stats else 0, coef.data_ptr(), stats.data_ptr(),
                                                     out.data_ptr(), N, C, P, ws.data_ptr() if ws is not None else None, nb, _stream(dev),
-                                                    pre.data_ptr() if pre is not None else None, int(pre.shape[0]) if pre is not None else 0),
+                                                    _ptr3(list(pre)) if pre is not None else None,
+                                                    (ctypes.c_int * 3)(*[int(t.shape[0]) for t in pre]) if pre is not None else None,
+                                                    int(pre[0].stride(1)) if pre is not None else 0),
                            "slak_bn3_forward_local")
             ctx.save_for_backward(y1, y2, y3, g1, g2, g3, stats)
             ctx.group = None
@@ -468,8 +481,11 @@ def branch_bn3(y1, y2, y3, bn1, bn2, bn3, stats=None):
             pg = bn1.process_group if bn1.process_group is not None else dist.group.WORLD
             if dist.get_world_size(pg) > 1:
                 group = pg
-        pre = stats if (stats is not None and stats.dim() == 3 and stats.shape[0] > 0 and group is None and stats.shape[1:] == (y1.shape[1], 6)
-                        and stats.dtype == torch.float32 and stats.is_contiguous()) else None
+        pre = None
+        if (stats is not None and group is None and len(stats) == 3
+                and all(t.dim() == 3 and t.shape[0] > 0 and t.shape[1] == y1.shape[1] and t.dtype == torch.float32 and t.stride(2) == 1
+                        and t.stride(0) == t.shape[1] * t.stride(1) for t in stats) and len({t.stride(1) for t in stats}) == 1):
+            pre = tuple(stats)
         return _BranchBN3.apply(y1, y2, y3, bn1.weight, bn1.bias, bn2.weight, bn2.bias, bn3.weight, bn3.bias, bns, group, pre)
     # eval: one apply pass with coefficients from the running statistics (no autograd needed for the statistics)
     N, C, H, W = y1.shape

@@ -212,16 +212,18 @@ __global__ void bn3_finalize_bwd(const float* __restrict__ gsums, const float* _
 
 // Single-process path: the slice reduction and the finalise step of a channel in one wavefront (no all-reduce in between): one launch
 // instead of bn3_colreduce + bn3_finalize_*.
-__global__ __launch_bounds__(64) void bn3_colreduce_finalize_fwd(const float* __restrict__ rows, int S, Bn3Params bp, float* __restrict__ coef,
+struct Bn3Pre { const float* rows[3]; int S[3]; int stride; };       // branch b's partial (sum, sum of squares) at rows[b][(n * C + c) * stride + {0, 1}]
+__global__ __launch_bounds__(64) void bn3_colreduce_finalize_fwd(const Bn3Pre pre, Bn3Params bp, float* __restrict__ coef,
                                                                float* __restrict__ stats, int C, float count, float eps, float momentum,
                                                                int update_running) {
     const int c = blockIdx.x, lane = threadIdx.x;
     float s[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    for (int n = lane; n < S; n += 64) {
-        const float* r = rows + ((size_t)n * C + c) * 6;
 #pragma unroll
-        for (int k = 0; k < 6; ++k) s[k] += r[k];
-    }
+    for (int b = 0; b < 3; ++b)
+        for (int n = lane; n < pre.S[b]; n += 64) {
+            const float* r = pre.rows[b] + ((size_t)n * C + c) * pre.stride;
+            s[2 * b] += r[0]; s[2 * b + 1] += r[1];
+        }
 #pragma unroll
     for (int k = 0; k < 6; ++k) s[k] = bn_wave_sum(s[k]);
     if (lane != 0) return;
@@ -348,22 +350,26 @@ int slak_bn3_forward_sums(const void* y1, const void* y2, const void* y3, float*
 int slak_bn3_forward_local(const void* y1, const void* y2, const void* y3, const float* const* gamma, const float* const* beta,
                            float* const* running_mean, float* const* running_var, float eps, float momentum, int update_running,
                            float* coef, float* stats, void* out, int N, int C, int P, void* workspace, size_t workspace_bytes, void* stream,
-                           const float* pre_sums, int pre_rows) {
+                           const float* const* pre_sums, const int* pre_rows, int pre_stride) {
     if (!y1 || !y2 || !y3 || !gamma || !beta || !running_mean || !running_var || !coef || !stats || !out) return SLAK_ERR_INVALID_ARG;
-    if (pre_sums && pre_rows <= 0) return SLAK_ERR_INVALID_ARG;
+    if (pre_sums && (!pre_rows || pre_stride < 2 || !pre_sums[0] || !pre_sums[1] || !pre_sums[2] || pre_rows[0] <= 0 || pre_rows[1] <= 0 || pre_rows[2] <= 0))
+        return SLAK_ERR_INVALID_ARG;
     int rc = bn_args_ok(N, C, P); if (rc) return rc;
     if (!workspace || workspace_bytes < slak_bn3_workspace_bytes(N, C)) return SLAK_ERR_WORKSPACE;
     Bn3Params bp;
     for (int b = 0; b < 3; ++b) { bp.gamma[b] = gamma[b]; bp.beta[b] = beta[b]; bp.running_mean[b] = running_mean[b]; bp.running_var[b] = running_var[b]; }
-    const float* rows = pre_sums;
-    int S = pre_rows, per;
-    if (!pre_sums) {                                               // the producer did not leave the sums: one read pass over the three tensors
-        bn_slices(N, C, &S, &per);
+    Bn3Pre pre;
+    if (pre_sums) {
+        for (int b = 0; b < 3; ++b) { pre.rows[b] = pre_sums[b]; pre.S[b] = pre_rows[b]; }
+        pre.stride = pre_stride;
+    } else {                                                       // the producers did not leave the sums: one read pass over the three tensors
+        int S, per; bn_slices(N, C, &S, &per);
         hipLaunchKernelGGL(bn3_chansums<false>, dim3((unsigned)((C * S + BN_THREADS / 64 - 1) / (BN_THREADS / 64))), dim3(BN_THREADS), 0, (hipStream_t)stream,
                            (const uint16_t*)nullptr, (const uint16_t*)y1, (const uint16_t*)y2, (const uint16_t*)y3, (float*)workspace, N, C, P, S, per);
-        rows = (const float*)workspace;
+        for (int b = 0; b < 3; ++b) { pre.rows[b] = (const float*)workspace + 2 * b; pre.S[b] = S; }
+        pre.stride = 6;
     }
-    hipLaunchKernelGGL(bn3_colreduce_finalize_fwd, dim3(C), dim3(64), 0, (hipStream_t)stream, rows, S, bp, coef, stats, C,
+    hipLaunchKernelGGL(bn3_colreduce_finalize_fwd, dim3(C), dim3(64), 0, (hipStream_t)stream, pre, bp, coef, stats, C,
                        (float)((double)N * P), eps, momentum, update_running);
     const int R = N * C;
     hipLaunchKernelGGL(bn3_apply_fwd, dim3(bn_grid(R, P)), dim3(BN_THREADS), 0, (hipStream_t)stream,

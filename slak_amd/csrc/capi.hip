@@ -229,6 +229,20 @@ int slak_dwconv2d_tri_forward_stats(const void* x, const float* w_v, const float
     return launch_dwconv_mfma_small_tri(false, in, out, w, dtype, N, C, H, W, K, (hipStream_t)stream, stats);
 }
 
+/* slak_dwconv2d_forward that also leaves the batch statistics of the BatchNorm behind the conv (models/SLaK.py:38-47 conv -> bn):
+ * stats[rows][C][2] = partial (sum y, sum y^2) of the stored outputs; *stats_rows = rows written (<= 4 N = the capacity the caller must
+ * provide).  Only the LDS-DMA ring kernel (56 x 56 / 28 x 28 class) gathers them; SLAK_ERR_UNSUPPORTED otherwise (use slak_dwconv2d_forward). */
+int slak_dwconv2d_forward_stats(const void* x, int x_dtype, const void* w, int w_dtype, void* y, int y_dtype, float* stats, int stats_capacity_rows,
+                                int* stats_rows, int N, int C, int H, int W, int kh, int kw, void* stream) {
+    int rc = check_conv_args(x, w, y, x_dtype, w_dtype, y_dtype, N, C, H, W, kh, kw);
+    if (rc != SLAK_OK) return rc;
+    if (!stats || !stats_rows) return SLAK_ERR_INVALID_ARG;
+    ConvDims d{N, C, H, W, kh, kw};
+    if (g_conv_algo == SLAK_ALGO_DIRECT || !use_dma() || x_dtype != SLAK_BF16 || !dwconv_mfma_dma_supported(d, x_dtype, w_dtype, y_dtype)) return SLAK_ERR_UNSUPPORTED;
+    return launch_dwconv_mfma_dma(x, x_dtype, w, w_dtype, y, y_dtype, d, /*flip=*/false, nullptr, 0, (hipStream_t)stream, /*accumulate=*/false,
+                                  stats, stats_capacity_rows, stats_rows);
+}
+
 int slak_dwconv2d_tri_backward_data(const void* dy_v, const void* dy_h, const void* dy_s, const float* w_v, const float* w_h,
                                     const float* w_s, void* dx, int dtype, int N, int C, int H, int W, int K, void* stream) {
     if (!dy_v || !dy_h || !dy_s || !w_v || !w_h || !w_s || !dx) return SLAK_ERR_INVALID_ARG;

@@ -31,6 +31,7 @@
 // SIMD keep its issue port ~95 % busy), so everything that does not change between groups -- fragment row offsets, epilogue
 // offsets and predicates, copy-out and transpose maps -- is computed once per workgroup and kept in registers.
 #include "mfma_common.h"
+#include <type_traits>
 
 namespace slak {
 
@@ -60,7 +61,8 @@ struct MfmaDmaParams {
     int tr_pp, tr_cbs;     // transpose blocks per plane, per 4-row band
     unsigned tensor_bytes;
     unsigned long long* dbg;
-};
+    float* stats;          // forward only, or NULL: [slices * 4][C][2] = per (slice, wave, channel) sum y, sum y^2 of the stored outputs
+};                         // (batch statistics of the branch's BatchNorm, models/SLaK.py:92-95, gathered in the copy-out: saves a read pass)
 
 constexpr int DMA_NCO = 2;              // 16-byte copy-out chunks per thread per group (upper bound)
 constexpr int DMA_NTR = 4;              // transpose blocks (4 rows x 16 cols) per lane group per group of planes (upper bound)
@@ -294,6 +296,21 @@ __global__ __launch_bounds__(MF_THREADS, 3) void dwconv_mfma_dma_kernel(const Mf
     u32x4 yold[DMA_NCO];
 #pragma unroll
     for (int k = 0; k < DMA_NCO; ++k) yold[k] = u32x4{0u, 0u, 0u, 0u};
+    float bs1 = 0.f, bs2 = 0.f;                                       // p.stats: sums over the chunks this thread copies out
+    auto stat8 = [&](const u32x4& v) {                               // v_dot2c_f32_bf16 with a ZERO addend (its addend is aligned with truncation), adds kept apart
+        if constexpr (std::is_same<T, bf16_t>::value) {
+            const bf16x2_t one = __builtin_bit_cast(bf16x2_t, 0x3f803f80u);
+            // (elements copied to scalars first: bit-casting v[i] directly made hipcc reuse element 0's result for all four)
+            const unsigned d0 = v.x, d1 = v.y, d2 = v.z, d3 = v.w;
+            const bf16x2_t x0 = __builtin_bit_cast(bf16x2_t, d0), x1 = __builtin_bit_cast(bf16x2_t, d1), x2 = __builtin_bit_cast(bf16x2_t, d2), x3 = __builtin_bit_cast(bf16x2_t, d3);
+            float a0 = __builtin_amdgcn_fdot2_f32_bf16(x0, one, 0.f, false), a1 = __builtin_amdgcn_fdot2_f32_bf16(x1, one, 0.f, false);
+            float a2 = __builtin_amdgcn_fdot2_f32_bf16(x2, one, 0.f, false), a3 = __builtin_amdgcn_fdot2_f32_bf16(x3, one, 0.f, false);
+            float q0 = __builtin_amdgcn_fdot2_f32_bf16(x0, x0, 0.f, false), q1 = __builtin_amdgcn_fdot2_f32_bf16(x1, x1, 0.f, false);
+            float q2 = __builtin_amdgcn_fdot2_f32_bf16(x2, x2, 0.f, false), q3 = __builtin_amdgcn_fdot2_f32_bf16(x3, x3, 0.f, false);
+            asm("" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(q0), "+v"(q1), "+v"(q2), "+v"(q3));
+            bs1 += (a0 + a1) + (a2 + a3); bs2 += (q0 + q1) + (q2 + q3);
+        }
+    };
     int n0 = n_begin;
     for (int it = 0; it < iters; ++it) {
         PH_T0();
@@ -312,6 +329,7 @@ __global__ __launch_bounds__(MF_THREADS, 3) void dwconv_mfma_dma_kernel(const Mf
                 if (n0 - p.G + co_j[k] < n_end) {
                     u32x4 v = *(const u32x4*)(L + ob_prev + (tid + k * MF_THREADS) * 16);
                     if (p.acc) v = add_packed<T>(v, yold[k]);
+                    if (p.stats) stat8(v);
                     *(u32x4*)(yp + co_g[k]) = v;
                 }
         }
@@ -408,8 +426,14 @@ __global__ __launch_bounds__(MF_THREADS, 3) void dwconv_mfma_dma_kernel(const Mf
             if (n0 - p.G + co_j[k] < n_end) {
                 u32x4 v = *(const u32x4*)(L + ob_last + (tid + k * MF_THREADS) * 16);
                 if (p.acc) v = add_packed<T>(v, yold[k]);
+                if (p.stats) stat8(v);
                 *(u32x4*)(yp + co_g[k]) = v;
             }
+    }
+    if (p.stats) {                                                    // one partial row per wave
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { bs1 += __shfl_xor(bs1, o, 64); bs2 += __shfl_xor(bs2, o, 64); }
+        if (lane == 0) { float* r = p.stats + (((size_t)slice * MF_WAVES + wave) * p.C + c) * 2; r[0] = bs1; r[1] = bs2; }
     }
 #ifdef SLAK_DMA_DEBUG
     if (p.dbg && tid == 0) { p.dbg[64 + blockIdx.x * 8 + 2] = __builtin_amdgcn_s_memrealtime(); p.dbg[64 + blockIdx.x * 8 + 7] = __builtin_readcyclecounter() - cyc0; }
@@ -504,7 +528,8 @@ static int launch_dma_t(MfmaDmaParams& p, const ConvDims& d, bool vert, bool ban
 }
 
 int launch_dwconv_mfma_dma(const void* x, int x_dt, const void* w, int w_dt, void* y, int y_dt,
-                           const ConvDims& d, bool flip_filter, void* ws, size_t ws_bytes, hipStream_t st, bool accumulate) {
+                           const ConvDims& d, bool flip_filter, void* ws, size_t ws_bytes, hipStream_t st, bool accumulate,
+                           float* stats, int stats_capacity_rows, int* stats_rows) {
     (void)ws; (void)ws_bytes;                                 // no workspace: fragments are built from LDS filter windows
     if (!dwconv_mfma_dma_supported(d, x_dt, w_dt, y_dt)) return SLAK_ERR_UNSUPPORTED;
     const bool vert = d.kh > d.kw;
@@ -515,10 +540,15 @@ int launch_dwconv_mfma_dma(const void* x, int x_dt, const void* w, int w_dt, voi
     p.x = x; p.w = (const float*)w; p.y = y; p.flip = flip_filter ? 1 : 0;
     p.acc = accumulate ? 1 : 0;
     p.dbg = g_dma_dbg;
+    p.stats = (stats && !accumulate && !flip_filter) ? stats : nullptr;
+    if (p.stats && (stats_capacity_rows < MF_WAVES * d.N || !stats_rows)) return SLAK_ERR_WORKSPACE;   // slices <= N
     // band skipping pays when some (mt, ks) Toeplitz block is empty: filter half-width + 32 < 16*(KS-1)
     const bool band = (MT == 2) && (p.padL + 31 < 16 * (KS - 1));
-    if (x_dt == SLAK_BF16) return cls == 2 ? launch_dma_t<bf16_t, 2, 4>(p, d, vert, band, st) : launch_dma_t<bf16_t, 1, 2>(p, d, vert, false, st);
-    return cls == 2 ? launch_dma_t<f16_t, 2, 4>(p, d, vert, band, st) : launch_dma_t<f16_t, 1, 2>(p, d, vert, false, st);
+    int rc;
+    if (x_dt == SLAK_BF16) rc = cls == 2 ? launch_dma_t<bf16_t, 2, 4>(p, d, vert, band, st) : launch_dma_t<bf16_t, 1, 2>(p, d, vert, false, st);
+    else rc = cls == 2 ? launch_dma_t<f16_t, 2, 4>(p, d, vert, band, st) : launch_dma_t<f16_t, 1, 2>(p, d, vert, false, st);
+    if (rc == SLAK_OK && p.stats) *stats_rows = MF_WAVES * p.slices;
+    return rc;
 }
 
 }  // namespace slak

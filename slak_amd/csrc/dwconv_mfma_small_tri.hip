@@ -184,11 +184,16 @@ __global__ __launch_bounds__(MF_THREADS) void dwconv_mfma_small_tri_kernel(const
     };
 
     float bsum[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    auto stat4 = [&](const f32x4_t& v, int b) {                   // what store4 stores, as the BatchNorm statistics see it
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float r = __uint_as_float((pack2<T>(v[j], 0.f) & 0xffffu) << 16);
-            if (l15 < p.H && 4 * kg + j < p.W) { bsum[2 * b] += r; bsum[2 * b + 1] += r * r; }
+    auto stat4 = [&](const f32x4_t& v, int b) {                   // what store4 stores, as the BatchNorm statistics see it (14 x 14 class: W even)
+        if constexpr (std::is_same<T, bf16_t>::value) {
+            const bf16x2_t one = __builtin_bit_cast(bf16x2_t, 0x3f803f80u);
+            const bf16x2_t p01 = __builtin_bit_cast(bf16x2_t, st0 ? pack2<T>(v[0], v[1]) : 0u), p23 = __builtin_bit_cast(bf16x2_t, st1 ? pack2<T>(v[2], v[3]) : 0u);
+            // v_dot2c_f32_bf16 with a ZERO addend (its addend is aligned with truncation), the adds kept apart from it by the empty asm
+            float t0 = __builtin_amdgcn_fdot2_f32_bf16(p01, one, 0.f, false), t1 = __builtin_amdgcn_fdot2_f32_bf16(p23, one, 0.f, false);
+            float t2 = __builtin_amdgcn_fdot2_f32_bf16(p01, p01, 0.f, false), t3 = __builtin_amdgcn_fdot2_f32_bf16(p23, p23, 0.f, false);
+            asm("" : "+v"(t0), "+v"(t1), "+v"(t2), "+v"(t3));
+            bsum[2 * b] += t0 + t1;
+            bsum[2 * b + 1] += t2 + t3;
         }
     };
     for (int q = 0; q < npairs; ++q) {
@@ -245,12 +250,12 @@ __global__ __launch_bounds__(MF_THREADS) void dwconv_mfma_small_tri_kernel(const
                 store4(s, ro[0], go);
             } else {
                 store4(av, ro[0], go); store4(ah, ro[1], go); store4(as, ro[2], go);
-                if constexpr (sizeof(T) == 2 && std::is_same<T, bf16_t>::value) { if (p.stats) { stat4(av, 0); stat4(ah, 1); stat4(as, 2); } }
+                if constexpr (!NARROW && std::is_same<T, bf16_t>::value) { if (p.stats) { stat4(av, 0); stat4(ah, 1); stat4(as, 2); } }
             }
         }
         if (q + ST_NS - 1 < npairs) issue_pair(q + ST_NS - 1);
     }
-    if constexpr (!DGRAD) {
+    if constexpr (!DGRAD && !NARROW) {
         if (p.stats) {
 #pragma unroll
             for (int k = 0; k < 6; ++k) {
@@ -305,7 +310,8 @@ static int launch_tri_t(SmallTriParams& p, hipStream_t st) {
 
 // rows of the forward kernel's statistics output ([rows][C][6]); 0 = the kernel does not take the shape
 int dwconv_mfma_small_tri_stats_rows(int N, int C, int H, int W, int K, int dtype) {
-    if (dtype != SLAK_BF16 || !dwconv_mfma_small_tri_supported(N, C, H, W, K, dtype)) return 0;
+    if (dtype != SLAK_BF16 || W < 8 || !dwconv_mfma_small_tri_supported(N, C, H, W, K, dtype)) return 0;   // (7 x 7 planes: the kernel is bound by
+                                                                                                            // instructions per plane: the sums cost more than bn3's pass)
     SmallTriParams p;
     fill_tri_params(p, N, C, H, W, K, 3 * mfma_cu_count());
     return p.slices;

@@ -73,7 +73,8 @@ int launch_dwconv_mfma_small(const void* x, int x_dt, const void* w, int w_dt, v
 
 bool dwconv_mfma_dma_supported(const ConvDims& d, int x_dt, int w_dt, int y_dt);
 int launch_dwconv_mfma_dma(const void* x, int x_dt, const void* w, int w_dt, void* y, int y_dt,
-                           const ConvDims& d, bool flip_filter, void* ws, size_t ws_bytes, hipStream_t st, bool accumulate = false);
+                           const ConvDims& d, bool flip_filter, void* ws, size_t ws_bytes, hipStream_t st, bool accumulate = false,
+                           float* stats = nullptr, int stats_capacity_rows = 0, int* stats_rows = nullptr);
 
 bool dwconv_mfma_wide_supported(const ConvDims& d, int x_dt, int w_dt, int y_dt);
 int launch_dwconv_mfma_wide(const void* x, int x_dt, const void* w, int w_dt, void* y, int y_dt,

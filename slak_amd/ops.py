@@ -67,6 +67,27 @@ def dwconv2d_forward(x, w, out_dtype=None):
     return y
 
 
+def dwconv2d_forward_stats(x, w):
+    """(y, stats): dwconv2d_forward that also returns the partial batch sums [rows][C][2] (sum y, sum y^2 of the stored outputs) for the
+    BatchNorm behind the conv; stats is None where the launch does not gather them (y is then the plain forward)."""
+    import ctypes
+    _check_tensor(x, "input"); _check_tensor(w, "weight")
+    N, C, H, W, kh, kw = _dims(x, w)
+    L = _lib.lib()
+    if x.dtype == torch.bfloat16 and w.dtype == torch.float32:
+        y = torch.empty_like(x)
+        stats = torch.empty((4 * N, C, 2), dtype=torch.float32, device=x.device)
+        rows = ctypes.c_int(0)
+        with torch.cuda.device(x.device):
+            rc = L.slak_dwconv2d_forward_stats(x.data_ptr(), _dt(x, "input"), w.data_ptr(), _dt(w, "weight"), y.data_ptr(), _dt(y, "output"),
+                                               stats.data_ptr(), 4 * N, ctypes.byref(rows), N, C, H, W, kh, kw, _stream(x.device))
+        if rc == _lib.OK:
+            return y, stats[:rows.value]
+        if rc != _lib.ERR_UNSUPPORTED:
+            _lib.check(rc, "slak_dwconv2d_forward_stats")
+    return dwconv2d_forward(x, w), None
+
+
 def dwconv2d_backward_data(dy, w, out_dtype=None):
     _check_tensor(dy, "grad"); _check_tensor(w, "weight")
     N, C, H, W, kh, kw = _dims(dy, w)
