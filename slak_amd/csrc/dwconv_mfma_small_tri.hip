@@ -12,6 +12,7 @@
 // reaches an MFMA) and never transposed into x^T; results leave as 2-byte stores (rows of an odd width are not dword aligned).
 #include "mfma_common.h"
 #include <type_traits>
+#include <stdlib.h>
 
 namespace slak {
 
@@ -269,6 +270,262 @@ __global__ __launch_bounds__(MF_THREADS) void dwconv_mfma_small_tri_kernel(const
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// QUAD: planes of at most 7 x 7 (SLaK's last stage) -- FOUR planes (images n0..n0+3 of one channel) per MFMA tile.
+// The kernel above spends one 16 x 16 x 32 tile on a 7 x 7 plane: 8 % of the tile, 24 two-byte store instructions and one
+// 196-byte DMA per plane pair -- the wave is bound by the latency of its few small memory instructions (0.2 of the HBM
+// roofline).  Here a 16-row x 32-byte LDS tile holds four planes:
+//     rows 0..6  bytes 0..15 : plane 0     bytes 16..31 : plane 2          (a row = one 16-byte piece, as NARROW above)
+//     rows 7, 8  zero guard (never written)
+//     rows 9..15 bytes 0..15 : plane 1     bytes 16..31 : plane 3
+// followed by two zero rows.  The Toeplitz operands are block diagonal (a plane only meets its own taps), indices on BOTH
+// tile axes carry the 9-row pitch (x^T is written with it), so all three branches leave D[M = (byte half, column)][N = (row block, row)]
+// in one lane / register map.  Per four planes: one DMA per input tensor, nine MFMAs, and 4 two-byte stores per output tensor
+// whose invalid lanes are dropped by the buffer range check (no exec masking).
+// Zero operands do not stop NaN / Inf: a non-finite value in one plane reaches the other planes of its tile (0 x Inf = NaN).
+// The outputs of such a step are non-finite in the reference as well (the loss sees every plane), only not in the same places.
+constexpr int SQ_TILE = 512 + 64;       // bytes: 16 rows x 32 + two zero guard rows
+constexpr unsigned SQ_OOB = 0x80000000u;
+
+template <typename T, bool DGRAD>
+__global__ __launch_bounds__(MF_THREADS) void dwconv_mfma_small_quad_kernel(const SmallTriParams p) {
+    constexpr int NT = DGRAD ? 3 : 1;                             // input tensors
+    constexpr int NS = DGRAD ? 4 : 6;                             // ring slots (quads) per wave
+    constexpr int SLOT = NT * SQ_TILE;
+    // per-wave LDS region (bytes): [64 zero][ring of tiles, each with its guard][x^T tile][64 zero row][3 x filter windows]
+    constexpr int RING = 64, XT = RING + NS * SLOT, ZROW = XT + 512, WIN = ZROW + 64, WAVE_BYTES = WIN + 3 * ST_WINB;
+    constexpr int NSTORE = DGRAD ? 4 : 12;                        // store instructions per quad
+    static_assert((NS - 2) * (NSTORE + NT) <= 63, "vmcnt is a 6-bit counter");
+    extern __shared__ __attribute__((aligned(16))) uint16_t lds[];
+    const int lane = threadIdx.x & 63;
+    const int wave = wave_id_uniform();
+    const int cblocks = (p.C + 3) >> 2;
+    const int cb = blockIdx.x % cblocks, slice = blockIdx.x / cblocks;
+    const int c = cb * 4 + wave;
+    const int n_begin = slice * p.images_per_slice;
+    int n_end = n_begin + p.images_per_slice; if (n_end > p.N) n_end = p.N;
+    if (c >= p.C || n_begin >= n_end) return;                     // no workgroup barrier anywhere: waves may leave
+    const int nquads = (n_end - n_begin + 3) >> 2;
+    char* const L = (char*)lds + wave * WAVE_BYTES;
+    const int HW = p.H * p.W;
+
+    // ---- filters (three branches), zero fill ------------------------------------------------------------------
+    const int ntap = p.K * MF_TAPS;
+    float wv[ST_WCH], wh[ST_WCH], wsm = 0.f;
+#pragma unroll
+    for (int k = 0; k < ST_WCH; ++k) {
+        const int e = lane + 64 * k;
+        wv[k] = e < ntap ? p.w[0][(size_t)c * ntap + e] : 0.f;
+        wh[k] = e < ntap ? p.w[1][(size_t)c * ntap + e] : 0.f;
+    }
+    if (lane < 25) wsm = p.w[2][(size_t)c * 25 + lane];
+    for (int o = lane * 16; o < WAVE_BYTES; o += 64 * 16) *(u32x4*)(L + o) = u32x4{0u, 0u, 0u, 0u};
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");            // zeros are in place before any DMA can land on them
+
+    // ---- DMA: lane (< 32) -> (tile row, byte half) = (row block ab, image row, plane pair) ----------------------------
+    v4i_t rs[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const uint64_t a = (uint64_t)p.in[t];
+        rs[t][0] = __builtin_amdgcn_readfirstlane((int)(a & 0xffffffffu)); rs[t][1] = __builtin_amdgcn_readfirstlane((int)((a >> 32) & 0xffffu));
+        rs[t][2] = __builtin_amdgcn_readfirstlane((int)p.tensor_bytes); rs[t][3] = 0x00020000;
+    }
+    __amdgpu_buffer_rsrc_t ro[3];
+#pragma unroll
+    for (int t = 0; t < (DGRAD ? 1 : 3); ++t) ro[t] = __builtin_amdgcn_make_buffer_rsrc(p.out[t], 0, (int)p.tensor_bytes, 0x00020000);
+    const unsigned gplane_b = (unsigned)(p.C * HW) * 2;
+    const int d_r = lane >> 1, d_half = lane & 1, d_ab = d_r >= 9 ? 1 : 0, d_row = d_r - 9 * d_ab;
+    const int d_pl = d_ab + 2 * d_half;                           // plane of the quad
+    const bool d_ok = lane < 32 && d_r != 7 && d_r != 8 && d_row < p.H;
+    const unsigned d_src = (unsigned)d_pl * gplane_b + (unsigned)(d_row * p.W) * 2;
+    const unsigned lds_wave = (unsigned)(uintptr_t)SLAK_LDS(uint16_t, lds) + wave * WAVE_BYTES;
+    const unsigned chan_b = (unsigned)c * (unsigned)HW * 2;
+    const unsigned last_row_b = p.tensor_bytes - (unsigned)(2 * p.W);     // byte offset of the tensor's last image row
+    auto issue_quad = [&](int q) {
+        const int n0 = n_begin + 4 * q;
+        const unsigned gb = (unsigned)n0 * gplane_b + chan_b;
+        const unsigned dst = lds_wave + RING + (unsigned)(q % NS) * SLOT;
+        if (d_ok && n0 + d_pl < n_end) {
+            unsigned so = gb + d_src;
+            // the piece of the tensor's very last row would end 16 - 2W bytes behind the tensor: fetched that much earlier, shifted into place below
+            if (so == last_row_b) so -= (unsigned)(16 - 2 * p.W);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) lds_dma16(so, rs[t], __builtin_amdgcn_readfirstlane(dst + t * SQ_TILE));
+        }
+    };
+    for (int q = 0; q < NS - 1 && q < nquads; ++q) issue_quad(q);
+
+    // ---- filter windows: branch b at WIN + b*ST_WINB, two copies one element apart ---------------------------------------
+    auto put = [&](int b, int r, int t, int KL, float v) {        // short tap r, long tap t of branch b
+        if (p.flip) { r = MF_TAPS - 1 - r; t = KL - 1 - t; }
+        const uint16_t h = cvt_to_bits(v, (T*)nullptr);
+        uint16_t* win = (uint16_t*)(L + WIN + b * ST_WINB);
+        win[r * ST_WLEN + ST_WZP + t] = h;
+        win[MF_TAPS * ST_WLEN + r * ST_WLEN + ST_WZP + t - 1] = h;
+    };
+#pragma unroll
+    for (int k = 0; k < ST_WCH; ++k) {
+        const int e = lane + 64 * k;
+        if (e < ntap) {
+            put(0, e % MF_TAPS, e / MF_TAPS, p.K, wv[k]);        // (K,5): element [t][r]
+            put(1, e / p.K, e - (e / p.K) * p.K, p.K, wh[k]);    // (5,K): element [r][t]
+        }
+    }
+    if (lane < 25) put(2, lane / 5, lane % 5, 5, wsm);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    // block-diagonal Toeplitz fragments: lane -> (o = l15: 9-pitch index of the output position, kg -> tap-in-pair rsel, byte half = 8 k-slots)
+    const int l15 = lane & 15, kg = lane >> 4, rsel = kg >> 1, half = kg & 1;
+    const int oblk = l15 >= 9 ? 1 : 0;                            // block of the lane's 9-pitch index
+    s16x8 tf[3][3];
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+        const bool vert = b == 0;
+        const int padL = (b == 2 ? 5 : p.K) / 2;
+        // vertical: k-slot s = 8*half + e is the tile ROW (9-pitch, like o): tap s - o; others: k-slot e is column e of the plane pair `half`
+        const int a = ST_WZP + (vert ? 8 * half - l15 : -(l15 - 9 * oblk)) + padL;
+        const int par = a & 1;
+        const unsigned* src = (const unsigned*)(L + WIN + b * ST_WINB + par * MF_TAPS * ST_WLEN * 2) + ((a - par) >> 1);
+        const bool keep = half == oblk;                           // a plane meets only its own taps
+#pragma unroll
+        for (int m = 0; m < 3; ++m) {
+            const int r = 2 * m + rsel;
+            u32x4 d;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                d[k] = (keep && r < MF_TAPS) ? src[(r < MF_TAPS ? r : 0) * (ST_WLEN / 2) + k] : 0u;
+                if (!vert) {                                      // k-slots beyond the row (W < 8): no such input
+                    if (2 * k >= p.W) d[k] = 0u; else if (2 * k + 1 >= p.W) d[k] &= 0xffffu;
+                }
+            }
+            tf[b][m] = __builtin_bit_cast(s16x8, d);
+        }
+    }
+
+    // ---- lane constants of the loop ---------------------------------------------------------------------------------
+    const unsigned xlane = (unsigned)(l15 * 32 + rsel * 32 + half * 16);
+    const unsigned zlane = (unsigned)ZROW + half * 16;
+    const int g4 = lane >> 4;
+    const unsigned trd = (unsigned)((4 * g4 + (l15 >> 2)) * 32 + (l15 & 3) * 8);
+    const bool twr_ok = (l15 & 7) < p.W;                          // (the 8th element of a piece belongs to the next row / plane)
+    const unsigned twr = (unsigned)(XT + ((l15 >> 3) * 9 + (l15 & 7)) * 32 + g4 * 8);
+    const unsigned bm2 = 5 < p.W ? 0xffffffffu : (4 < p.W ? 0xffffu : 0u), bm3 = 7 < p.W ? 0xffffffffu : (6 < p.W ? 0xffffu : 0u);
+    auto frag = [&](unsigned base, int m, bool rowmajor) -> s16x8 {   // MFMA m of a tile that starts 64 bytes after `base`
+        const unsigned a = (m == 2 && rsel) ? zlane : base + xlane + m * 64;
+        u32x4 v = *(const u32x4*)(L + a);
+        if (rowmajor) { v[2] &= bm2; v[3] &= bm3; }
+        return __builtin_bit_cast(s16x8, v);
+    };
+    // result element j of the lane: N = l15 = (row block, row), M = 4*kg + j = (byte half, column), both with the 9 pitch
+    const int o_row = l15 - 9 * oblk;
+    const bool o_nok = l15 != 7 && l15 != 8 && o_row < p.H;
+    unsigned vo[4]; int o_pl[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int m = 4 * kg + j, hf = m >= 9 ? 1 : 0, col = m - 9 * hf;
+        o_pl[j] = oblk + 2 * hf;
+        vo[j] = (o_nok && m != 7 && m != 8 && col < p.W) ? (unsigned)o_pl[j] * gplane_b + (unsigned)(o_row * p.W + col) * 2 : SQ_OOB;
+    }
+
+    for (int q = 0; q < nquads; ++q) {
+        {
+            const int st = (q < NS - 2 ? q : NS - 2) * NSTORE;
+            int dm = nquads - 1 - q; if (dm > NS - 2) dm = NS - 2;
+            wait_vmcnt_dyn(st + dm * NT);
+        }
+        __builtin_amdgcn_wave_barrier();
+        const int n0 = n_begin + 4 * q;
+        const unsigned slot = (unsigned)RING + (unsigned)(q % NS) * SLOT;
+        if (c == p.C - 1 && n0 + 3 >= p.N - 1 && n0 <= p.N - 1) {   // (wave-uniform) this quad holds the tensor's last plane
+            const int ppl = p.N - 1 - n0, sh = 8 - p.W;             // its last row arrived `sh` elements late: shift it into place
+            if (lane < NT) {
+                char* rowp = L + slot + lane * SQ_TILE + ((ppl & 1) * 9 + p.H - 1) * 32 + (ppl >> 1) * 16;
+                const u32x4 o = *(const u32x4*)rowp;
+                const unsigned oo[6] = {o[0], o[1], o[2], o[3], 0u, 0u};
+                const int wsh = (16 * sh) >> 5, bsh = (16 * sh) & 31;
+                u32x4 nv;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    unsigned lo = 0u, hi = 0u;
+#pragma unroll
+                    for (int j = 0; j < 6; ++j) { if (j == k + wsh) lo = oo[j]; if (j == k + wsh + 1) hi = oo[j]; }
+                    nv[k] = bsh ? ((lo >> bsh) | (hi << (32 - bsh))) : lo;
+                }
+                *(u32x4*)rowp = nv;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+        }
+        // vertical branch: its input tile (tensor 0) transposed into x^T, rows at the 9 pitch
+        {
+            const s16x4 t0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(SLAK_LDS(s16x4, L + slot + trd));
+            if (twr_ok) *(s16x4*)(L + twr) = t0;
+        }
+        const unsigned bv = (unsigned)XT - 64;
+        const unsigned bh = slot + (DGRAD ? (unsigned)SQ_TILE : 0u) - 64, bs = slot + (DGRAD ? 2u * SQ_TILE : 0u) - 64;
+        f32x4_t av = {0.f, 0.f, 0.f, 0.f}, ah = av, as = av;
+#pragma unroll
+        for (int m = 0; m < 3; ++m) {
+            av = st_mfma16<T>(frag(bv, m, false), tf[0][m], av);                  // operands swapped: D^T = X^T-tile x T^T
+            ah = st_mfma16<T>(tf[1][m], frag(bh, m, true), ah);
+            as = st_mfma16<T>(tf[2][m], frag(bs, m, true), as);
+        }
+        const unsigned go = (unsigned)n0 * gplane_b + chan_b;
+        unsigned so[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) so[j] = vo[j];
+        if (n0 + 4 > n_end) {                                       // (wave-uniform) the slice ends inside the quad: planes that do not exist
+#pragma unroll
+            for (int j = 0; j < 4; ++j) if (n0 + o_pl[j] >= n_end) so[j] = SQ_OOB;
+        }
+        auto store4 = [&](const f32x4_t& v, const __amdgpu_buffer_rsrc_t& r) {    // lanes with nothing to store carry SQ_OOB: dropped by the range check
+            const unsigned p01 = pack2<T>(v[0], v[1]), p23 = pack2<T>(v[2], v[3]);
+            __builtin_amdgcn_raw_buffer_store_b16((short)(p01 & 0xffffu), r, so[0], go, 0);
+            __builtin_amdgcn_raw_buffer_store_b16((short)(p01 >> 16), r, so[1], go, 0);
+            __builtin_amdgcn_raw_buffer_store_b16((short)(p23 & 0xffffu), r, so[2], go, 0);
+            __builtin_amdgcn_raw_buffer_store_b16((short)(p23 >> 16), r, so[3], go, 0);
+        };
+        if constexpr (DGRAD) {
+            const f32x4_t s = (av + ah) + as;                       // the three partial gradients, added in fp32
+            store4(s, ro[0]);
+        } else {
+            store4(av, ro[0]); store4(ah, ro[1]); store4(as, ro[2]);
+        }
+        if (q + NS - 1 < nquads) issue_quad(q + NS - 1);
+    }
+}
+
+static bool quad_enabled() {                   // SLAK_SMALL_QUAD=0 keeps the one-plane-per-tile kernel on 7 x 7 (A/B testing)
+    static const bool v = [] { const char* e = getenv("SLAK_SMALL_QUAD"); return !(e && e[0] == '0'); }();
+    return v;
+}
+static bool fill_quad_params(SmallTriParams& p, int N, int C, int H, int W, int K, int target_wgs) {
+    p.N = N; p.C = C; p.H = H; p.W = W; p.K = K;
+    if (N <= 0 || C <= 0 || K < 5 || !(K & 1) || K > 63 || K * MF_TAPS > ST_WCH * 64) return false;
+    if (H > 7 || H < 1 || W > 7 || W < 4) return false;
+    const int cblocks = (C + 3) / 4;
+    int slices = target_wgs / cblocks; if (slices < 1) slices = 1;
+    int per = (N + slices - 1) / slices; per = (per + 3) & ~3;
+    if (per < 8) per = 8;
+    if (per > ((N + 3) & ~3)) per = (N + 3) & ~3;
+    p.images_per_slice = per; p.slices = (N + per - 1) / per;
+    p.tensor_bytes = (unsigned)((size_t)N * C * H * W * 2);
+    return (size_t)(N + 3) * C * H * W * 2 < 0x80000000ull;              // offsets of a quad's missing planes stay below SQ_OOB
+}
+template <typename T, bool DGRAD>
+static int launch_quad_t(SmallTriParams& p, hipStream_t st) {
+    constexpr int NT = DGRAD ? 3 : 1, NS = DGRAD ? 4 : 6;
+    constexpr size_t WAVE_BYTES = 64 + NS * NT * SQ_TILE + 512 + 64 + 3 * ST_WINB;
+    auto k = dwconv_mfma_small_quad_kernel<T, DGRAD>;
+    const size_t lds = (size_t)MF_WAVES * WAVE_BYTES;
+    int per_cu = (int)((160 * 1024) / lds); if (per_cu > 8) per_cu = 8;
+    fill_quad_params(p, p.N, p.C, p.H, p.W, p.K, per_cu * mfma_cu_count());   // resident workgroups per CU (LDS)
+    if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k, dim3((unsigned)(((p.C + 3) / 4) * p.slices)), dim3(MF_THREADS), lds, st, p);
+    SLAK_LAUNCH_CHECK();
+    return SLAK_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------
 static bool fill_tri_params(SmallTriParams& p, int N, int C, int H, int W, int K, int target_wgs) {
     p.N = N; p.C = C; p.H = H; p.W = W; p.K = K;
     if (N <= 0 || C <= 0 || K < 5 || !(K & 1) || K > 63 || K * MF_TAPS > ST_WCH * 64) return false;
@@ -325,6 +582,11 @@ int launch_dwconv_mfma_small_tri(bool dgrad, const void* const* in, void* const*
     fill_tri_params(p, N, C, H, W, K, 768);
     for (int i = 0; i < 3; ++i) { p.in[i] = in[dgrad ? i : 0]; p.out[i] = out[dgrad ? 0 : i]; p.w[i] = w[i]; }
     p.flip = dgrad ? 1 : 0;
+    if (quad_enabled() && fill_quad_params(p, N, C, H, W, K, 768)) {       // planes of at most 7 x 7: four per tile
+        if (dtype == SLAK_BF16) return dgrad ? launch_quad_t<bf16_t, true>(p, st) : launch_quad_t<bf16_t, false>(p, st);
+        return dgrad ? launch_quad_t<f16_t, true>(p, st) : launch_quad_t<f16_t, false>(p, st);
+    }
+    fill_tri_params(p, N, C, H, W, K, 768);
     if (dtype == SLAK_BF16) return dgrad ? launch_tri_t<bf16_t, true>(p, st) : launch_tri_t<bf16_t, false>(p, st);
     return dgrad ? launch_tri_t<f16_t, true>(p, st) : launch_tri_t<f16_t, false>(p, st);
 }

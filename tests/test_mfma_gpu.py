@@ -325,6 +325,41 @@ def test_tri_weight_gradient_matches_the_three_per_branch_kernels(N, C, H, W, K,
         assert (g - sep).abs().max().item() <= 1e-5 * max(1.0, sep.abs().max().item()) * max(1.0, (N * H * W) ** 0.5 / 30)
 
 
+@pytest.mark.parametrize("N,C,H,W,K", [(6, 5, 7, 7, 13), (40, 5, 7, 7, 13), (1, 1, 7, 7, 13), (2, 1, 7, 7, 13), (3, 4, 7, 7, 5), (33, 2, 3, 4, 7), (100, 9, 7, 7, 13),
+                                       (4, 3, 6, 6, 9), (3, 2, 7, 5, 7), (7, 3, 5, 7, 31), (129, 2, 7, 7, 13), (8, 8, 7, 6, 13), (128, 16, 7, 7, 13)])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_four_planes_per_tile_three_branch_kernels_on_planes_up_to_7x7(N, C, H, W, K, dtype, gpu):
+    """dwconv_mfma_small_quad_kernel (dwconv_mfma_small_tri.hip: four planes of one channel per MFMA tile, block-diagonal Toeplitz
+    operands) through slak_dwconv2d_tri_forward / _backward_data against the oracle: every output rounded once; batch tails of
+    1..3 planes, H < 7, W = 4..7, channel tails, kernels longer than the plane, the tensor's last row (fetched early and shifted)."""
+    L = _lib()
+    lib = L.lib()
+    dt = L.SLAK_BF16 if dtype == torch.bfloat16 else L.SLAK_F16
+    torch.manual_seed(N + K + H)
+    x = torch.randn(N, C, H, W, device=gpu).to(dtype)
+    dys = [torch.randn(N, C, H, W, device=gpu).to(dtype) for _ in range(3)]
+    ws = [torch.randn(C, 1, kh, kw, device=gpu) * 0.05 for kh, kw in ((K, 5), (5, K), (5, 5))]
+    # guard elements behind the tensors: nothing may be written there
+    ybuf = [torch.full((x.numel() + 64,), 7.0, device=gpu, dtype=dtype) for _ in range(4)]
+    ys = [b[:x.numel()].view_as(x) for b in ybuf[:3]]
+    dx = ybuf[3][:x.numel()].view_as(x)
+    st = torch.cuda.current_stream(gpu).cuda_stream
+    assert lib.slak_dwconv2d_tri_supported(dt, N, C, H, W, K) == 1
+    L.check(lib.slak_dwconv2d_tri_forward(x.data_ptr(), ws[0].data_ptr(), ws[1].data_ptr(), ws[2].data_ptr(), ys[0].data_ptr(), ys[1].data_ptr(),
+                                          ys[2].data_ptr(), dt, N, C, H, W, K, st))
+    L.check(lib.slak_dwconv2d_tri_backward_data(dys[0].data_ptr(), dys[1].data_ptr(), dys[2].data_ptr(), ws[0].data_ptr(), ws[1].data_ptr(),
+                                                ws[2].data_ptr(), dx.data_ptr(), dt, N, C, H, W, K, st))
+    torch.cuda.synchronize()
+    ulp = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11
+    xr = _round(x, dtype)
+    for y, w in zip(ys, ws):
+        _check(y, oracle.dwconv2d_fwd(xr, _round(w, dtype)), ulp, "quad fwd")
+    ref = sum(oracle.dwconv2d_bwd_data(_round(dy, dtype), _round(w, dtype)) for dy, w in zip(dys, ws))
+    _check(dx, ref, ulp, "quad dgrad")
+    for b in ybuf:
+        assert (b[x.numel():] == 7.0).all()
+
+
 @pytest.mark.parametrize("N,C,H,W,K", [(6, 5, 7, 7, 13), (40, 5, 7, 7, 13), (1, 1, 7, 7, 13), (65, 3, 8, 8, 9), (33, 2, 3, 4, 7), (100, 9, 7, 7, 13), (4, 3, 6, 6, 9), (3, 2, 7, 5, 7)])
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 def test_dense_operator_three_branch_kernels_behind_the_dev_hook(N, C, H, W, K, dtype, gpu):
