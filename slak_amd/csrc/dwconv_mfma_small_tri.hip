@@ -270,45 +270,91 @@ __global__ __launch_bounds__(MF_THREADS) void dwconv_mfma_small_tri_kernel(const
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// QUAD: planes of at most 7 x 7 (SLaK's last stage) -- FOUR planes (images n0..n0+3 of one channel) per MFMA tile.
-// The kernel above spends one 16 x 16 x 32 tile on a 7 x 7 plane: 8 % of the tile, 24 two-byte store instructions and one
-// 196-byte DMA per plane pair -- the wave is bound by the latency of its few small memory instructions (0.2 of the HBM
-// roofline).  Here a 16-row x 32-byte LDS tile holds four planes:
-//     rows 0..6  bytes 0..15 : plane 0     bytes 16..31 : plane 2          (a row = one 16-byte piece, as NARROW above)
-//     rows 7, 8  zero guard (never written)
+// QUAD: planes of at most 7 x 7 (SLaK's last stage) -- FOUR planes (images of one channel) per MFMA tile, eight per loop step.
+// The kernel above spends one 16 x 16 x 32 tile on a 7 x 7 plane (8 % of it), and its memory instructions are the texture unit's
+// worst case: 16-byte DMA pieces at 2-byte aligned addresses (~50 cycles per instruction) and two-byte stores (~20 cycles each,
+// 24 per plane pair): 0.2 of the HBM roofline.  Here a 16-row x 32-byte LDS tile holds four planes:
+//     rows 0..6  bytes 0..15 : plane 0     bytes 16..31 : plane 2          (a row = one 16-byte piece, elements >= W cleared)
+//     rows 7, 8  zero guard
 //     rows 9..15 bytes 0..15 : plane 1     bytes 16..31 : plane 3
 // followed by two zero rows.  The Toeplitz operands are block diagonal (a plane only meets its own taps), indices on BOTH
 // tile axes carry the 9-row pitch (x^T is written with it), so all three branches leave D[M = (byte half, column)][N = (row block, row)]
-// in one lane / register map.  Per four planes: one DMA per input tensor, nine MFMAs, and 4 two-byte stores per output tensor
-// whose invalid lanes are dropped by the buffer range check (no exec masking).
+// in one lane / register map: nine MFMAs per four planes.
+//   in:  every lane loads the four dword-ALIGNED dwords that cover one image row (one buffer_load_dwordx4 per tensor for the 56
+//        rows of eight planes), v_alignbit moves the row to bit 0, the next row's elements behind column W-1 are cleared, one
+//        ds_write_b128 puts the piece in place; two octets are in flight per wave (two register sets);
+//   out: the results are written into LDS in the planes' own (contiguous) layout, shifted so that the dword-aligned 16-byte
+//        chunks of a plane in HBM are 16-byte aligned in LDS: one buffer_store_dwordx4 (lane -> plane, chunk) and one two-byte
+//        store (the element in front of / behind the chunks) per output tensor and eight planes, instead of 32 two-byte stores.
+// Lanes with nothing to load or store carry an out-of-range offset (buffer range check: zeros in, dropped out): no exec masking.
 // Zero operands do not stop NaN / Inf: a non-finite value in one plane reaches the other planes of its tile (0 x Inf = NaN).
 // The outputs of such a step are non-finite in the reference as well (the loss sees every plane), only not in the same places.
 constexpr int SQ_TILE = 512 + 64;       // bytes: 16 rows x 32 + two zero guard rows
 constexpr unsigned SQ_OOB = 0x80000000u;
+template <bool DGRAD> struct SqLds {
+    static constexpr int NT = DGRAD ? 3 : 1, NO = DGRAD ? 1 : 3;
+    // per-wave bytes: [64 zero][NT x 2 tiles, each with its guard][x^T tile][64 zero row][NO x 8 planes x 128: results, plane layout]
+    static constexpr int IN = 64, XT = IN + NT * 2 * SQ_TILE, ZROW = XT + 512, OUT = ZROW + 64, END = OUT + NO * 1024;
+    static constexpr int WAVE_BYTES = END > 3 * ST_WINB ? END : 3 * ST_WINB;     // the filter windows (set-up only) alias all of it
+};
 
-template <typename T, bool DGRAD>
+// DW: some plane has whole dwords left behind its 16-byte chunks (not 7 x 7: 98 = 6 x 16 + 2 bytes)
+template <typename T, bool DGRAD, bool DW>
 __global__ __launch_bounds__(MF_THREADS) void dwconv_mfma_small_quad_kernel(const SmallTriParams p) {
-    constexpr int NT = DGRAD ? 3 : 1;                             // input tensors
-    constexpr int NS = DGRAD ? 4 : 6;                             // ring slots (quads) per wave
-    constexpr int SLOT = NT * SQ_TILE;
-    // per-wave LDS region (bytes): [64 zero][ring of tiles, each with its guard][x^T tile][64 zero row][3 x filter windows]
-    constexpr int RING = 64, XT = RING + NS * SLOT, ZROW = XT + 512, WIN = ZROW + 64, WAVE_BYTES = WIN + 3 * ST_WINB;
-    constexpr int NSTORE = DGRAD ? 4 : 12;                        // store instructions per quad
-    static_assert((NS - 2) * (NSTORE + NT) <= 63, "vmcnt is a 6-bit counter");
+    using LY = SqLds<DGRAD>;
+    constexpr int NT = LY::NT, NO = LY::NO, IN = LY::IN, XT = LY::XT, ZROW = LY::ZROW, OUT = LY::OUT, WAVE_BYTES = LY::WAVE_BYTES;
     extern __shared__ __attribute__((aligned(16))) uint16_t lds[];
     const int lane = threadIdx.x & 63;
     const int wave = wave_id_uniform();
     const int cblocks = (p.C + 3) >> 2;
     const int cb = blockIdx.x % cblocks, slice = blockIdx.x / cblocks;
     const int c = cb * 4 + wave;
-    const int n_begin = slice * p.images_per_slice;
+    const int n_begin = slice * p.images_per_slice;               // (a multiple of 8)
     int n_end = n_begin + p.images_per_slice; if (n_end > p.N) n_end = p.N;
     if (c >= p.C || n_begin >= n_end) return;                     // no workgroup barrier anywhere: waves may leave
-    const int nquads = (n_end - n_begin + 3) >> 2;
+    const int noct = (n_end - n_begin + 7) >> 3;
     char* const L = (char*)lds + wave * WAVE_BYTES;
     const int HW = p.H * p.W;
+    const unsigned gplane_b = (unsigned)(p.C * HW) * 2;
+    const unsigned chan_b = (unsigned)c * (unsigned)HW * 2;
 
-    // ---- filters (three branches), zero fill ------------------------------------------------------------------
+    // ---- loads: lane -> (tile of the octet, tile row, byte half) = (plane, image row); the first two octets leave right away ----
+    __amdgpu_buffer_rsrc_t ri[NT], ro[NO];
+    // (load range: up to the end of the dword that holds the tensor's last element -- the check is per dword, and an aligned dword
+    // that holds a valid element lies inside the allocation)
+#pragma unroll
+    for (int t = 0; t < NT; ++t) ri[t] = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.in[t]), 0, (int)((p.tensor_bytes + 3u) & ~3u), 0x00020000);
+#pragma unroll
+    for (int t = 0; t < NO; ++t) ro[t] = __builtin_amdgcn_make_buffer_rsrc(p.out[t], 0, (int)p.tensor_bytes, 0x00020000);
+    const int d_r = (lane >> 1) & 15, d_half = lane & 1, d_ab = d_r >= 9 ? 1 : 0, d_row = d_r - 9 * d_ab;
+    const int d_pl = 4 * (lane >> 5) + d_ab + 2 * d_half;         // plane of the octet
+    const bool d_ok = d_r != 7 && d_r != 8 && d_row < p.H;
+    const unsigned d_row_b = chan_b + (unsigned)d_pl * gplane_b + (unsigned)(d_row * p.W) * 2;
+    const unsigned d_sh = (d_row_b & 2u) * 8u;                    // the row starts in the upper half of its first dword (8 | n_begin: the same for every octet)
+    const unsigned d_dst = (unsigned)IN + (unsigned)((lane >> 5) * SQ_TILE + (lane & 31) * 16);
+    const unsigned bm2 = 5 < p.W ? 0xffffffffu : (4 < p.W ? 0xffffu : 0u), bm3 = 7 < p.W ? 0xffffffffu : (6 < p.W ? 0xffffu : 0u);
+    auto load_oct = [&](int q, u32x4 (&R)[NT]) {                  // (an octet behind the slice loads nothing: one instruction count on every path)
+        const int n0 = n_begin + 8 * q;
+        const unsigned a = (d_ok && n0 + d_pl < n_end) ? (((unsigned)n0 * gplane_b + d_row_b) & ~3u) : SQ_OOB;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) R[t] = __builtin_amdgcn_raw_buffer_load_b128(ri[t], a, 0, 0);
+    };
+    auto stage = [&](const u32x4 (&R)[NT]) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            u32x4 v;
+            v[0] = __builtin_amdgcn_alignbit(R[t][1], R[t][0], d_sh);
+            v[1] = __builtin_amdgcn_alignbit(R[t][2], R[t][1], d_sh);
+            v[2] = __builtin_amdgcn_alignbit(R[t][3], R[t][2], d_sh) & bm2;
+            v[3] = __builtin_amdgcn_alignbit(0u, R[t][3], d_sh) & bm3;
+            *(u32x4*)(L + d_dst + t * 2 * SQ_TILE) = v;
+        }
+    };
+    u32x4 R0[NT], R1[NT];
+    load_oct(0, R0);
+    load_oct(1, R1);
+
+    // ---- filters (three branches) -> windows: branch b at b*ST_WINB, two copies one element apart -----------------------------
     const int ntap = p.K * MF_TAPS;
     float wv[ST_WCH], wh[ST_WCH], wsm = 0.f;
 #pragma unroll
@@ -319,46 +365,12 @@ __global__ __launch_bounds__(MF_THREADS) void dwconv_mfma_small_quad_kernel(cons
     }
     if (lane < 25) wsm = p.w[2][(size_t)c * 25 + lane];
     for (int o = lane * 16; o < WAVE_BYTES; o += 64 * 16) *(u32x4*)(L + o) = u32x4{0u, 0u, 0u, 0u};
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");            // zeros are in place before any DMA can land on them
-
-    // ---- DMA: lane (< 32) -> (tile row, byte half) = (row block ab, image row, plane pair) ----------------------------
-    v4i_t rs[NT];
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        const uint64_t a = (uint64_t)p.in[t];
-        rs[t][0] = __builtin_amdgcn_readfirstlane((int)(a & 0xffffffffu)); rs[t][1] = __builtin_amdgcn_readfirstlane((int)((a >> 32) & 0xffffu));
-        rs[t][2] = __builtin_amdgcn_readfirstlane((int)p.tensor_bytes); rs[t][3] = 0x00020000;
-    }
-    __amdgpu_buffer_rsrc_t ro[3];
-#pragma unroll
-    for (int t = 0; t < (DGRAD ? 1 : 3); ++t) ro[t] = __builtin_amdgcn_make_buffer_rsrc(p.out[t], 0, (int)p.tensor_bytes, 0x00020000);
-    const unsigned gplane_b = (unsigned)(p.C * HW) * 2;
-    const int d_r = lane >> 1, d_half = lane & 1, d_ab = d_r >= 9 ? 1 : 0, d_row = d_r - 9 * d_ab;
-    const int d_pl = d_ab + 2 * d_half;                           // plane of the quad
-    const bool d_ok = lane < 32 && d_r != 7 && d_r != 8 && d_row < p.H;
-    const unsigned d_src = (unsigned)d_pl * gplane_b + (unsigned)(d_row * p.W) * 2;
-    const unsigned lds_wave = (unsigned)(uintptr_t)SLAK_LDS(uint16_t, lds) + wave * WAVE_BYTES;
-    const unsigned chan_b = (unsigned)c * (unsigned)HW * 2;
-    const unsigned last_row_b = p.tensor_bytes - (unsigned)(2 * p.W);     // byte offset of the tensor's last image row
-    auto issue_quad = [&](int q) {
-        const int n0 = n_begin + 4 * q;
-        const unsigned gb = (unsigned)n0 * gplane_b + chan_b;
-        const unsigned dst = lds_wave + RING + (unsigned)(q % NS) * SLOT;
-        if (d_ok && n0 + d_pl < n_end) {
-            unsigned so = gb + d_src;
-            // the piece of the tensor's very last row would end 16 - 2W bytes behind the tensor: fetched that much earlier, shifted into place below
-            if (so == last_row_b) so -= (unsigned)(16 - 2 * p.W);
-#pragma unroll
-            for (int t = 0; t < NT; ++t) lds_dma16(so, rs[t], __builtin_amdgcn_readfirstlane(dst + t * SQ_TILE));
-        }
-    };
-    for (int q = 0; q < NS - 1 && q < nquads; ++q) issue_quad(q);
-
-    // ---- filter windows: branch b at WIN + b*ST_WINB, two copies one element apart ---------------------------------------
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
     auto put = [&](int b, int r, int t, int KL, float v) {        // short tap r, long tap t of branch b
         if (p.flip) { r = MF_TAPS - 1 - r; t = KL - 1 - t; }
         const uint16_t h = cvt_to_bits(v, (T*)nullptr);
-        uint16_t* win = (uint16_t*)(L + WIN + b * ST_WINB);
+        uint16_t* win = (uint16_t*)(L + b * ST_WINB);
         win[r * ST_WLEN + ST_WZP + t] = h;
         win[MF_TAPS * ST_WLEN + r * ST_WLEN + ST_WZP + t - 1] = h;
     };
@@ -384,7 +396,7 @@ __global__ __launch_bounds__(MF_THREADS) void dwconv_mfma_small_quad_kernel(cons
         // vertical: k-slot s = 8*half + e is the tile ROW (9-pitch, like o): tap s - o; others: k-slot e is column e of the plane pair `half`
         const int a = ST_WZP + (vert ? 8 * half - l15 : -(l15 - 9 * oblk)) + padL;
         const int par = a & 1;
-        const unsigned* src = (const unsigned*)(L + WIN + b * ST_WINB + par * MF_TAPS * ST_WLEN * 2) + ((a - par) >> 1);
+        const unsigned* src = (const unsigned*)(L + b * ST_WINB + par * MF_TAPS * ST_WLEN * 2) + ((a - par) >> 1);
         const bool keep = half == oblk;                           // a plane meets only its own taps
 #pragma unroll
         for (int m = 0; m < 3; ++m) {
@@ -400,97 +412,97 @@ __global__ __launch_bounds__(MF_THREADS) void dwconv_mfma_small_quad_kernel(cons
             tf[b][m] = __builtin_bit_cast(s16x8, d);
         }
     }
+    asm volatile("" : "+v"(tf[0][0]), "+v"(tf[0][1]), "+v"(tf[0][2]), "+v"(tf[1][0]), "+v"(tf[1][1]), "+v"(tf[1][2]), "+v"(tf[2][0]), "+v"(tf[2][1]), "+v"(tf[2][2]));
+    __builtin_amdgcn_wave_barrier();                              // the fragments are in registers: the windows give way to the tiles
+    for (int o = lane * 16; o < WAVE_BYTES; o += 64 * 16) *(u32x4*)(L + o) = u32x4{0u, 0u, 0u, 0u};
 
     // ---- lane constants of the loop ---------------------------------------------------------------------------------
     const unsigned xlane = (unsigned)(l15 * 32 + rsel * 32 + half * 16);
     const unsigned zlane = (unsigned)ZROW + half * 16;
     const int g4 = lane >> 4;
     const unsigned trd = (unsigned)((4 * g4 + (l15 >> 2)) * 32 + (l15 & 3) * 8);
-    const bool twr_ok = (l15 & 7) < p.W;                          // (the 8th element of a piece belongs to the next row / plane)
+    const bool twr_ok = (l15 & 7) < p.W;
     const unsigned twr = (unsigned)(XT + ((l15 >> 3) * 9 + (l15 & 7)) * 32 + g4 * 8);
-    const unsigned bm2 = 5 < p.W ? 0xffffffffu : (4 < p.W ? 0xffffu : 0u), bm3 = 7 < p.W ? 0xffffffffu : (6 < p.W ? 0xffffu : 0u);
-    auto frag = [&](unsigned base, int m, bool rowmajor) -> s16x8 {   // MFMA m of a tile that starts 64 bytes after `base`
+    auto frag = [&](unsigned base, int m) -> s16x8 {              // MFMA m of a tile that starts 64 bytes after `base`
         const unsigned a = (m == 2 && rsel) ? zlane : base + xlane + m * 64;
-        u32x4 v = *(const u32x4*)(L + a);
-        if (rowmajor) { v[2] &= bm2; v[3] &= bm3; }
-        return __builtin_bit_cast(s16x8, v);
+        return __builtin_bit_cast(s16x8, *(const u32x4*)(L + a));
     };
-    // result element j of the lane: N = l15 = (row block, row), M = 4*kg + j = (byte half, column), both with the 9 pitch
-    const int o_row = l15 - 9 * oblk;
+    // result element j of the lane: N = l15 = (row block, row), M = 4*kg + j = (byte half, column), both with the 9 pitch.
+    // It goes to LDS offset plane*128 + 16 + 2*(row*W + col) - a, a = the plane's HBM start modulo 4 (0 or 2)
+    const int o_row = l15 - 9 * oblk, o_pl = oblk + 2 * (kg >> 1);                  // (valid elements of kg 0,1 / 2,3 lie in byte half 0 / 1)
     const bool o_nok = l15 != 7 && l15 != 8 && o_row < p.H;
-    unsigned vo[4]; int o_pl[4];
+    const unsigned o_a = ((unsigned)o_pl * gplane_b + chan_b) & 2u;                 // (4 * gplane_b = 0 mod 8: the same for both tiles)
+    unsigned wo[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int m = 4 * kg + j, hf = m >= 9 ? 1 : 0, col = m - 9 * hf;
-        o_pl[j] = oblk + 2 * hf;
-        vo[j] = (o_nok && m != 7 && m != 8 && col < p.W) ? (unsigned)o_pl[j] * gplane_b + (unsigned)(o_row * p.W + col) * 2 : SQ_OOB;
+        const bool ok = o_nok && m != 7 && m != 8 && col < p.W;
+        wo[j] = (unsigned)OUT + (unsigned)o_pl * 128u + (ok ? 16u + (unsigned)(o_row * p.W + col) * 2u - o_a : 116u + 2u * j);   // (116..: unused bytes of the plane's slot)
     }
+    // stores: lane -> (plane of the octet, chunk slot)
+    const int s_pl = lane >> 3, s_k = lane & 7;
+    const unsigned s_g = (unsigned)s_pl * gplane_b + chan_b;                        // the plane's first byte (without the octet's base)
+    const unsigned s_a = s_g & 2u, s_len = (unsigned)HW * 2u - s_a, s_nch = s_len >> 4, s_rest = s_len & 15u;
+    const unsigned sc_g = (unsigned)s_k < s_nch ? s_g + s_a + 16u * s_k : SQ_OOB;
+    const unsigned sc_l = (unsigned)OUT + (unsigned)s_pl * 128u + 16u + 16u * s_k;
+    const unsigned sd_g = (unsigned)s_k < (s_rest >> 2) ? s_g + s_a + 16u * s_nch + 4u * s_k : SQ_OOB;
+    const unsigned sd_l = (unsigned)OUT + (unsigned)s_pl * 128u + 16u + 16u * s_nch + 4u * (s_k & 3);
+    const bool s_head = s_k == 0 && s_a == 2u, s_tail = s_k == 1 && (s_rest & 2u);
+    const unsigned ss_g = s_head ? s_g : (s_tail ? s_g + (unsigned)HW * 2u - 2u : SQ_OOB);
+    const unsigned ss_l = (unsigned)OUT + (unsigned)s_pl * 128u + (s_head ? 14u : 16u + (unsigned)HW * 2u - 2u - s_a);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
 
-    for (int q = 0; q < nquads; ++q) {
-        {
-            const int st = (q < NS - 2 ? q : NS - 2) * NSTORE;
-            int dm = nquads - 1 - q; if (dm > NS - 2) dm = NS - 2;
-            wait_vmcnt_dyn(st + dm * NT);
-        }
-        __builtin_amdgcn_wave_barrier();
-        const int n0 = n_begin + 4 * q;
-        const unsigned slot = (unsigned)RING + (unsigned)(q % NS) * SLOT;
-        if (c == p.C - 1 && n0 + 3 >= p.N - 1 && n0 <= p.N - 1) {   // (wave-uniform) this quad holds the tensor's last plane
-            const int ppl = p.N - 1 - n0, sh = 8 - p.W;             // its last row arrived `sh` elements late: shift it into place
-            if (lane < NT) {
-                char* rowp = L + slot + lane * SQ_TILE + ((ppl & 1) * 9 + p.H - 1) * 32 + (ppl >> 1) * 16;
-                const u32x4 o = *(const u32x4*)rowp;
-                const unsigned oo[6] = {o[0], o[1], o[2], o[3], 0u, 0u};
-                const int wsh = (16 * sh) >> 5, bsh = (16 * sh) & 31;
-                u32x4 nv;
+    auto octet = [&](int q, u32x4 (&R)[NT]) {
+        stage(R);                                                 // (the LDS queue is in order: the reads of the octet before are behind us)
+        load_oct(q + 2, R);                                       // (every path issues the same memory instructions: the compiler's vmcnt
+        const int n0 = n_begin + 8 * q;                           //  bookkeeping stays exact; an octet behind the slice stores nothing)
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    unsigned lo = 0u, hi = 0u;
-#pragma unroll
-                    for (int j = 0; j < 6; ++j) { if (j == k + wsh) lo = oo[j]; if (j == k + wsh + 1) hi = oo[j]; }
-                    nv[k] = bsh ? ((lo >> bsh) | (hi << (32 - bsh))) : lo;
-                }
-                *(u32x4*)rowp = nv;
+        for (int tt = 0; tt < 2; ++tt) {
+            if (n0 + 4 * tt >= n_end) break;                        // (wave-uniform) the slice ends before this tile
+            const unsigned tile = (unsigned)IN + tt * SQ_TILE;
+            {                                                       // vertical branch: its input tile (tensor 0) transposed into x^T, rows at the 9 pitch
+                const s16x4 t0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(SLAK_LDS(s16x4, L + tile + trd));
+                if (twr_ok) *(s16x4*)(L + twr) = t0;
             }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_wave_barrier();
-        }
-        // vertical branch: its input tile (tensor 0) transposed into x^T, rows at the 9 pitch
-        {
-            const s16x4 t0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(SLAK_LDS(s16x4, L + slot + trd));
-            if (twr_ok) *(s16x4*)(L + twr) = t0;
-        }
-        const unsigned bv = (unsigned)XT - 64;
-        const unsigned bh = slot + (DGRAD ? (unsigned)SQ_TILE : 0u) - 64, bs = slot + (DGRAD ? 2u * SQ_TILE : 0u) - 64;
-        f32x4_t av = {0.f, 0.f, 0.f, 0.f}, ah = av, as = av;
+            const unsigned bv = (unsigned)XT - 64;
+            const unsigned bh = tile + (DGRAD ? 2u * SQ_TILE : 0u) - 64, bs = tile + (DGRAD ? 4u * SQ_TILE : 0u) - 64;
+            f32x4_t av = {0.f, 0.f, 0.f, 0.f}, ah = av, as = av;
 #pragma unroll
-        for (int m = 0; m < 3; ++m) {
-            av = st_mfma16<T>(frag(bv, m, false), tf[0][m], av);                  // operands swapped: D^T = X^T-tile x T^T
-            ah = st_mfma16<T>(tf[1][m], frag(bh, m, true), ah);
-            as = st_mfma16<T>(tf[2][m], frag(bs, m, true), as);
+            for (int m = 0; m < 3; ++m) {
+                av = st_mfma16<T>(frag(bv, m), tf[0][m], av);                     // operands swapped: D^T = X^T-tile x T^T
+                ah = st_mfma16<T>(tf[1][m], frag(bh, m), ah);
+                as = st_mfma16<T>(tf[2][m], frag(bs, m), as);
+            }
+            auto put4 = [&](const f32x4_t& v, int t) {              // into the planes' own layout (elements that do not exist: spare bytes of the slot)
+                const unsigned p01 = pack2<T>(v[0], v[1]), p23 = pack2<T>(v[2], v[3]);
+                char* base = L + t * 1024 + tt * 512;
+                *(uint16_t*)(base + wo[0]) = (uint16_t)(p01 & 0xffffu);
+                *(uint16_t*)(base + wo[1]) = (uint16_t)(p01 >> 16);
+                *(uint16_t*)(base + wo[2]) = (uint16_t)(p23 & 0xffffu);
+                *(uint16_t*)(base + wo[3]) = (uint16_t)(p23 >> 16);
+            };
+            if constexpr (DGRAD) {
+                const f32x4_t s = (av + ah) + as;                   // the three partial gradients, added in fp32
+                put4(s, 0);
+            } else {
+                put4(av, 0); put4(ah, 1); put4(as, 2);
+            }
         }
-        const unsigned go = (unsigned)n0 * gplane_b + chan_b;
-        unsigned so[4];
+        const unsigned go = (unsigned)n0 * gplane_b;
+        unsigned gc = sc_g, gd = sd_g, gs = ss_g;
+        if (n0 + s_pl >= n_end) { gc = SQ_OOB; gd = SQ_OOB; gs = SQ_OOB; }                      // planes behind the slice
 #pragma unroll
-        for (int j = 0; j < 4; ++j) so[j] = vo[j];
-        if (n0 + 4 > n_end) {                                       // (wave-uniform) the slice ends inside the quad: planes that do not exist
-#pragma unroll
-            for (int j = 0; j < 4; ++j) if (n0 + o_pl[j] >= n_end) so[j] = SQ_OOB;
+        for (int t = 0; t < NO; ++t) {
+            const u32x4 v = *(const u32x4*)(L + t * 1024 + sc_l);
+            __builtin_amdgcn_raw_buffer_store_b128(v, ro[t], gc, go, 0);
+            if constexpr (DW) __builtin_amdgcn_raw_buffer_store_b32(*(const unsigned*)(L + t * 1024 + sd_l), ro[t], gd, go, 0);
+            __builtin_amdgcn_raw_buffer_store_b16((short)*(const uint16_t*)(L + t * 1024 + ss_l), ro[t], gs, go, 0);
         }
-        auto store4 = [&](const f32x4_t& v, const __amdgpu_buffer_rsrc_t& r) {    // lanes with nothing to store carry SQ_OOB: dropped by the range check
-            const unsigned p01 = pack2<T>(v[0], v[1]), p23 = pack2<T>(v[2], v[3]);
-            __builtin_amdgcn_raw_buffer_store_b16((short)(p01 & 0xffffu), r, so[0], go, 0);
-            __builtin_amdgcn_raw_buffer_store_b16((short)(p01 >> 16), r, so[1], go, 0);
-            __builtin_amdgcn_raw_buffer_store_b16((short)(p23 & 0xffffu), r, so[2], go, 0);
-            __builtin_amdgcn_raw_buffer_store_b16((short)(p23 >> 16), r, so[3], go, 0);
-        };
-        if constexpr (DGRAD) {
-            const f32x4_t s = (av + ah) + as;                       // the three partial gradients, added in fp32
-            store4(s, ro[0]);
-        } else {
-            store4(av, ro[0]); store4(ah, ro[1]); store4(as, ro[2]);
-        }
-        if (q + NS - 1 < nquads) issue_quad(q + NS - 1);
+    };
+    for (int q = 0; q < noct; q += 2) {
+        octet(q, R0);
+        octet(q + 1, R1);
     }
 }
 
@@ -504,21 +516,20 @@ static bool fill_quad_params(SmallTriParams& p, int N, int C, int H, int W, int 
     if (H > 7 || H < 1 || W > 7 || W < 4) return false;
     const int cblocks = (C + 3) / 4;
     int slices = target_wgs / cblocks; if (slices < 1) slices = 1;
-    int per = (N + slices - 1) / slices; per = (per + 3) & ~3;
-    if (per < 8) per = 8;
-    if (per > ((N + 3) & ~3)) per = (N + 3) & ~3;
+    int per = (N + slices - 1) / slices; per = (per + 7) & ~7;      // whole octets
+    if (per > ((N + 7) & ~7)) per = (N + 7) & ~7;
     p.images_per_slice = per; p.slices = (N + per - 1) / per;
     p.tensor_bytes = (unsigned)((size_t)N * C * H * W * 2);
-    return (size_t)(N + 3) * C * H * W * 2 < 0x80000000ull;              // offsets of a quad's missing planes stay below SQ_OOB
+    return (size_t)(N + 7) * C * H * W * 2 < 0x80000000ull;              // offsets of an octet's missing planes stay below SQ_OOB
 }
 template <typename T, bool DGRAD>
 static int launch_quad_t(SmallTriParams& p, hipStream_t st) {
-    constexpr int NT = DGRAD ? 3 : 1, NS = DGRAD ? 4 : 6;
-    constexpr size_t WAVE_BYTES = 64 + NS * NT * SQ_TILE + 512 + 64 + 3 * ST_WINB;
-    auto k = dwconv_mfma_small_quad_kernel<T, DGRAD>;
-    const size_t lds = (size_t)MF_WAVES * WAVE_BYTES;
-    int per_cu = (int)((160 * 1024) / lds); if (per_cu > 8) per_cu = 8;
-    fill_quad_params(p, p.N, p.C, p.H, p.W, p.K, per_cu * mfma_cu_count());   // resident workgroups per CU (LDS)
+    const unsigned pb = (unsigned)(p.H * p.W) * 2u;
+    const bool dw = (pb & 15u) >= 4u || ((pb - 2u) & 15u) >= 4u;
+    auto k = dw ? dwconv_mfma_small_quad_kernel<T, DGRAD, true> : dwconv_mfma_small_quad_kernel<T, DGRAD, false>;
+    const size_t lds = (size_t)MF_WAVES * SqLds<DGRAD>::WAVE_BYTES;
+    static const int wgs_per_cu = [] { const char* e = getenv("SLAK_SQ_WGS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 4; }();
+    fill_quad_params(p, p.N, p.C, p.H, p.W, p.K, wgs_per_cu * mfma_cu_count());
     if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(k, dim3((unsigned)(((p.C + 3) / 4) * p.slices)), dim3(MF_THREADS), lds, st, p);
     SLAK_LAUNCH_CHECK();

@@ -14,6 +14,7 @@
 //     and shifted into place (see dwconv_mfma_small_tri.hip).
 // At this size a launch is ~10 us of fixed cost: one launch for three removes two of them per block.
 #include "mfma_common.h"
+#include <stdlib.h>
 
 namespace slak {
 
@@ -33,6 +34,7 @@ struct SmallTriWgradParams {
     int N, C, H, W, K;
     int images_per_slice, slices;
     unsigned tensor_bytes;
+    int dbg;                             // dev switches of the quad kernel (SLAK_QW_DBG): 1 no compute, 2 no DMA, 4 no diagonal sums, 8 no octets
 };
 
 template <typename T> __device__ __forceinline__ f32x4_t tw_mfma16(s16x8 a, s16x8 b, f32x4_t c);
@@ -256,6 +258,228 @@ __global__ __launch_bounds__(MF_THREADS) void dwconv_mfma_small_tri_wgrad_kernel
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// QUAD: planes of at most 7 x 7 -- EIGHT planes of one channel per MFMA (layout of dwconv_mfma_small_quad_kernel,
+// dwconv_mfma_small_tri.hip: a 16-row x 32-byte tile holds four planes, rows 7 / 8 and two rows behind it are zero guards;
+// K = 32 = the 2 x 16 rows of two such tiles).  The correlation tile C_r[dy position][x position] then holds two valid 7 x 7
+// diagonal blocks (the two plane sets of a tile axis) whose diagonals are summed together; the off-diagonal blocks (products of
+// different planes) are skipped by the diagonal sums.  Per eight planes: 15 MFMAs (plane-pair kernel: 60).
+// Rows of 2W bytes start at 2-byte aligned addresses; the LDS-DMA takes those only through the texture unit's slow path (measured
+// ~50 cycles per instruction for 28 pieces: 10.9 of the kernel's 27.6 us).  So the rows travel through registers: every lane loads
+// the four dword-ALIGNED dwords that cover its row (one buffer_load_dwordx4 per tensor for the 56 rows of an octet), v_alignbit
+// moves the row to bit 0, the elements behind column W-1 (the next row's) are cleared, and one ds_write_b128 puts the piece in
+// place.  Two octets are in flight per wave (two register sets); a lane of a plane or row that does not exist loads through an
+// out-of-range offset and writes zeros, which also keeps the guard rows zero.
+constexpr int QW_TILE = 512 + 64;
+constexpr int QW_TEN = 2 * QW_TILE;     // two tiles (an octet of planes) of one tensor
+constexpr int QW_SLOT = 4 * QW_TEN;     // [dy_v][dy_h][dy_s][x]
+constexpr int QW_T = TW_RING + QW_SLOT;                   // [dy_v^T: 2 x 512][64 zero][x^T tile 0][64 zero][x^T tile 1][64 zero]
+constexpr int QW_XT = QW_T + 1024 + 64;
+constexpr int QW_RES = QW_XT + 2 * QW_TILE;
+constexpr int QW_WAVE_BYTES = QW_RES + TW_RESN * 4;
+constexpr unsigned QW_OOB = 0x80000000u;
+static_assert(QW_SLOT >= 16 * 32 * 4, "the diagonal-sum tile aliases the slot");
+
+template <typename T>
+__global__ __launch_bounds__(MF_THREADS) void dwconv_mfma_small_quad_wgrad_kernel(const SmallTriWgradParams p) {
+    extern __shared__ __attribute__((aligned(16))) uint16_t lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = wave_id_uniform();
+    const int cblocks = (p.C + 3) >> 2;
+    const int cb = blockIdx.x % cblocks, slice = blockIdx.x / cblocks;
+    const int c0 = cb * 4, c = c0 + wave;
+    const int nch = p.C - c0 < 4 ? p.C - c0 : 4;
+    const int n_begin = slice * p.images_per_slice;               // (a multiple of 8)
+    int n_end = n_begin + p.images_per_slice; if (n_end > p.N) n_end = p.N;
+    const bool live = c < p.C && n_begin < n_end;                // (every wave reaches the finish: it has workgroup barriers)
+    const int noct = (live && !(p.dbg & 8)) ? (n_end - n_begin + 7) >> 3 : 0;
+    char* const L = (char*)lds + wave * QW_WAVE_BYTES;
+    const int HW = p.H * p.W;
+    const int nt_long = p.K * MF_TAPS, ntot = 2 * nt_long + 25;  // [K x 5][5 x K][5 x 5] back to back
+
+    for (int o = lane * 16; o < QW_WAVE_BYTES; o += 64 * 16) *(u32x4*)(L + o) = u32x4{0u, 0u, 0u, 0u};
+
+    // ---- loads: lane -> (tile of the octet, tile row, byte half) = (plane, image row) ------------------------------------
+    __amdgpu_buffer_rsrc_t rs[4];
+#pragma unroll
+    // (range: up to the end of the dword that holds the tensor's last element -- the check is per dword, and an aligned dword that
+    // holds a valid element lies inside the allocation)
+    for (int t = 0; t < 4; ++t) rs[t] = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(t < 3 ? p.dy[t] : p.x), 0, (int)((p.tensor_bytes + 3u) & ~3u), 0x00020000);
+    const unsigned gplane_b = (unsigned)(p.C * HW) * 2;
+    const int d_r = (lane >> 1) & 15, d_half = lane & 1, d_ab = d_r >= 9 ? 1 : 0, d_row = d_r - 9 * d_ab;
+    const int d_pl = 4 * (lane >> 5) + d_ab + 2 * d_half;         // plane of the octet
+    const bool d_ok = d_r != 7 && d_r != 8 && d_row < p.H;
+    const unsigned d_row_b = (unsigned)(live ? c : 0) * (unsigned)HW * 2 + (unsigned)d_pl * gplane_b + (unsigned)(d_row * p.W) * 2;
+    const unsigned d_sh = (d_row_b & 2u) * 8u;                    // the row starts in the upper half of its first dword (8 | n_begin: the same for every octet)
+    const unsigned d_dst = (unsigned)TW_RING + (unsigned)((lane >> 5) * QW_TILE + (lane & 31) * 16);
+    const unsigned bm2 = 5 < p.W ? 0xffffffffu : (4 < p.W ? 0xffffu : 0u), bm3 = 7 < p.W ? 0xffffffffu : (6 < p.W ? 0xffffu : 0u);
+    auto load_oct = [&](int q, u32x4 (&R)[4]) {
+        const int n0 = n_begin + 8 * q;
+        // (an octet behind the slice loads nothing: the instruction count per step stays fixed)
+        const unsigned a = (d_ok && n0 + d_pl < n_end && !(p.dbg & 2)) ? (((unsigned)n0 * gplane_b + d_row_b) & ~3u) : QW_OOB;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) R[t] = __builtin_amdgcn_raw_buffer_load_b128(rs[t], a, 0, 0);      // dwords behind the tensor: 0
+    };
+    auto stage = [&](const u32x4 (&R)[4]) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            u32x4 v;
+            v[0] = __builtin_amdgcn_alignbit(R[t][1], R[t][0], d_sh);
+            v[1] = __builtin_amdgcn_alignbit(R[t][2], R[t][1], d_sh);
+            v[2] = __builtin_amdgcn_alignbit(R[t][3], R[t][2], d_sh) & bm2;
+            v[3] = __builtin_amdgcn_alignbit(0u, R[t][3], d_sh) & bm3;
+            *(u32x4*)(L + d_dst + t * QW_TEN) = v;
+        }
+    };
+    u32x4 R0[4], R1[4];
+    load_oct(0, R0);
+    load_oct(1, R1);
+
+    // ---- lane constants ------------------------------------------------------------------------------------------------
+    const int g4 = lane >> 4, i16 = lane & 15;
+    const unsigned rdr = (unsigned)(((g4 & 1) * 8 + (i16 >> 2)) * 32 + (i16 & 3) * 8);
+    const unsigned rdq = (unsigned)((g4 >> 1) * QW_TILE) + rdr;   // k-half -> tile of the octet (tiles QW_TILE apart)
+    const unsigned rdt = (unsigned)((g4 >> 1) * 512) + rdr;       // dy_v^T tiles are 512 apart
+    const unsigned trd = (unsigned)((4 * g4 + (i16 >> 2)) * 32 + (i16 & 3) * 8);
+    const bool twr_ok = (i16 & 7) < p.W;
+    const unsigned twr = (unsigned)(((i16 >> 3) * 9 + (i16 & 7)) * 32 + g4 * 8);   // transposed tiles carry the 9-row pitch as well
+    auto frag = [&](unsigned addr) -> s16x8 {                     // 8 k of one column: two transposing reads, 4 rows apart
+        const s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(SLAK_LDS(s16x4, L + addr));
+        const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(SLAK_LDS(s16x4, L + addr + 128));
+        return s16x8{v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+    };
+
+    f32x4_t av[MF_TAPS], ah[MF_TAPS], as[MF_TAPS];
+#pragma unroll
+    for (int r = 0; r < MF_TAPS; ++r) { av[r] = f32x4_t{0.f, 0.f, 0.f, 0.f}; ah[r] = av[r]; as[r] = av[r]; }
+
+    constexpr unsigned slot = TW_RING;
+    auto octet = [&](int q, u32x4 (&R)[4]) {
+        stage(R);                                                 // (the LDS queue is in order: the reads of octet q-1 are behind us)
+        load_oct(q + 2, R);                                       // unconditional: the compiler's vmcnt bookkeeping needs one count on every path
+        if (q >= noct || (p.dbg & 1)) return;
+        // vertical branch: the dy_v tiles and the x tiles transposed (tensor 0 and tensor 3 of the slot)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const unsigned src = slot + (k < 2 ? 0u : 3u * QW_TEN) + (k & 1) * QW_TILE + trd;
+            const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16(SLAK_LDS(s16x4, L + src));
+            if (twr_ok) *(s16x4*)(L + (k < 2 ? QW_T + (k & 1) * 512 : QW_XT + (k & 1) * QW_TILE) + twr) = v;
+        }
+        const s16x8 a_h = frag(slot + QW_TEN + rdq), a_s = frag(slot + 2 * QW_TEN + rdq);
+        const unsigned xb = slot + 3 * QW_TEN - 64 + rdq;         // x tiles minus two rows: the tap shift is +r rows
+#pragma unroll
+        for (int r = 0; r < MF_TAPS; ++r) {
+            const s16x8 b = frag(xb + r * 32);
+            ah[r] = tw_mfma16<T>(a_h, b, ah[r]);
+            as[r] = tw_mfma16<T>(a_s, b, as[r]);
+        }
+        const s16x8 a_v = frag((unsigned)QW_T + rdt);
+        const unsigned xtb = (unsigned)QW_XT - 64 + rdq;
+#pragma unroll
+        for (int r = 0; r < MF_TAPS; ++r) av[r] = tw_mfma16<T>(a_v, frag(xtb + r * 32), av[r]);
+    };
+    for (int q = 0; q < noct; q += 2) {
+        octet(q, R0);
+        octet(q + 1, R1);
+    }
+
+    // ---- diagonal sums of the two valid blocks, one branch after the other, through the skewed 16 x 32 tile (the slot is dead) ----
+    if (live) {
+        float* tile = (float*)(L + TW_RING);
+        float* res = (float*)(L + QW_RES);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        auto diag = [&](const f32x4_t (&acc)[MF_TAPS], bool vert, int Wt, int KL, int kw, float* out) {
+            const int padL = KL / 2;
+            // slot -> (block, position): tile rows carry the 9 pitch (vertical branch: positions are rows), byte halves the 8 pitch
+            auto blk = [&](int sl) { return vert ? (sl >= 9 ? 1 : 0) : (sl >> 3); };
+            auto pos = [&](int sl) { return vert ? sl - 9 * (sl >= 9 ? 1 : 0) : (sl & 7); };
+            auto valid = [&](int sl) { return (!vert || (sl != 7 && sl != 8)) && pos(sl) < Wt; };
+            const int pi = pos(i16);
+            const bool vi = valid(i16);
+            *(u32x4*)((char*)tile + lane * 16) = u32x4{0u, 0u, 0u, 0u};
+            *(u32x4*)((char*)tile + 1024 + lane * 16) = u32x4{0u, 0u, 0u, 0u};
+            int wofs[4]; bool wok[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int so = 4 * g4 + e;
+                wok[e] = vi && valid(so) && blk(so) == blk(i16);  // (the off-diagonal blocks are products of different planes)
+                wofs[e] = so * 32 + (pi - pos(so) + 15);
+            }
+            __builtin_amdgcn_wave_barrier();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int r = 0; r < MF_TAPS; ++r) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (wok[e]) tile[wofs[e]] = acc[r][e];
+                __builtin_amdgcn_wave_barrier();
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (lane < 31) {
+                    float v[16];
+#pragma unroll
+                    for (int o = 0; o < 16; ++o) v[o] = tile[o * 32 + lane];       // 16 independent reads, added in order below
+                    float sum = 0.f;
+#pragma unroll
+                    for (int o = 0; o < 16; ++o) sum += v[o];
+                    const int tau = lane - 15 + padL;
+                    if (tau >= 0 && tau < KL) out[vert ? (tau * kw + r) : (r * kw + tau)] = sum;
+                }
+                __builtin_amdgcn_wave_barrier();
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
+        };
+        if (!(p.dbg & 4)) {
+        diag(av, true, p.H, p.K, MF_TAPS, res);
+        diag(ah, false, p.W, p.K, p.K, res + nt_long);
+        diag(as, false, p.W, MF_TAPS, MF_TAPS, res + 2 * nt_long);
+        }
+        float* out = p.partial + ((size_t)slice * p.C + c) * ntot;
+        for (int t = lane; t < ntot; t += 64) wgrad_store_partial(&out[t], res[t]);       // taps no diagonal reaches stay 0
+    } else if (c < p.C) {                                         // empty slice: its partial must still be zero
+        float* out = p.partial + ((size_t)slice * p.C + c) * ntot;
+        for (int t = lane; t < ntot; t += 64) wgrad_store_partial(&out[t], 0.f);
+    }
+    // ---- last arriver of the channel block adds the slices in order and scatters into the three dw tensors (see wgrad_finish) ----
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int* lds_flag = (int*)lds;
+    if (tid == 0) {
+        int last = 1;
+        if (p.slices > 1) {
+            const unsigned old = __hip_atomic_fetch_add(p.counters + cb, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            last = old == (unsigned)(p.slices - 1);
+            if (last) __hip_atomic_store(p.counters + cb, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        *lds_flag = last;
+    }
+    __syncthreads();
+    if (!*lds_flag) return;
+    for (int t = tid; t < nch * ntot; t += MF_THREADS) {
+        float s = 0.f;
+        const float* src = p.partial + (size_t)c0 * ntot + t;
+        const size_t stride = (size_t)p.C * ntot;
+        for (int k0 = 0; k0 < p.slices; k0 += 8) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                v[j] = k0 + j < p.slices ? __hip_atomic_load(src + (size_t)(k0 + j) * stride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s += v[j];
+        }
+        const int ch = t / ntot, e = t - ch * ntot;
+        const size_t cc = (size_t)(c0 + ch);
+        if (e < nt_long) p.dw[0][cc * nt_long + e] = s;
+        else if (e < 2 * nt_long) p.dw[1][cc * nt_long + (e - nt_long)] = s;
+        else p.dw[2][cc * 25 + (e - 2 * nt_long)] = s;
+    }
+}
+
+static bool quad_wgrad_enabled() {             // SLAK_SMALL_QUAD=0 keeps the plane-pair kernel on 7 x 7 (A/B testing)
+    static const bool v = [] { const char* e = getenv("SLAK_SMALL_QUAD"); return !(e && e[0] == '0'); }();
+    return v;
+}
+
+// ------------------------------------------------------------------------------------------------------------
 static bool fill_stw_params(SmallTriWgradParams& p, int N, int C, int H, int W, int K, int target_wgs) {
     p.N = N; p.C = C; p.H = H; p.W = W; p.K = K;
     if (N <= 0 || C <= 0 || K <= MF_TAPS || !(K & 1) || K > 63) return false;
@@ -281,6 +505,23 @@ size_t dwconv_mfma_small_tri_wgrad_workspace(int N, int C, int K) {
     return align_up((size_t)((N + 7) / 8 + 1) * C * (2 * K * MF_TAPS + 25) * sizeof(float), 256);   // slices <= ceil(N / 8)
 }
 
+template <typename T>
+static int launch_qw_t(SmallTriWgradParams& p, size_t ws_bytes, hipStream_t st) {
+    auto k = dwconv_mfma_small_quad_wgrad_kernel<T>;
+    static const int wgs_per_cu = [] { const char* e = getenv("SLAK_QW_WGS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 2; }();
+    fill_stw_params(p, p.N, p.C, p.H, p.W, p.K, wgs_per_cu * mfma_cu_count());
+    int per = (p.images_per_slice + 7) & ~7;                        // whole octets
+    if (per > ((p.N + 7) & ~7)) per = (p.N + 7) & ~7;
+    p.images_per_slice = per; p.slices = (p.N + per - 1) / per;
+    if ((size_t)(p.N + 7) * p.C * p.H * p.W * 2 >= 0xffffffffull) return SLAK_ERR_UNSUPPORTED;
+    if ((size_t)p.slices * p.C * (2 * p.K * MF_TAPS + 25) * sizeof(float) > ws_bytes) return SLAK_ERR_WORKSPACE;
+    const size_t lds = (size_t)MF_WAVES * QW_WAVE_BYTES;
+    if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k, dim3((unsigned)(((p.C + 3) / 4) * p.slices)), dim3(MF_THREADS), lds, st, p);
+    SLAK_LAUNCH_CHECK();
+    return SLAK_OK;
+}
+
 template <typename T, bool NARROW>
 static int launch_stw_t(SmallTriWgradParams& p, size_t ws_bytes, hipStream_t st) {
     auto k = dwconv_mfma_small_tri_wgrad_kernel<T, NARROW>;
@@ -301,8 +542,11 @@ int launch_dwconv_mfma_small_tri_wgrad(const void* const* dy, const void* x, flo
     fill_stw_params(p, N, C, H, W, K, 512);
     for (int b = 0; b < 3; ++b) { p.dy[b] = dy[b]; p.dw[b] = dw[b]; }
     p.x = x; p.partial = (float*)ws;
+    { static const int dbg = [] { const char* e = getenv("SLAK_QW_DBG"); return e ? atoi(e) : 0; }(); p.dbg = dbg; }
     p.counters = wgrad_arrival_counters((C + 3) / 4);
     if (!p.counters) return SLAK_ERR_UNSUPPORTED;                 // (the caller runs the three per-branch launches)
+    if (H <= 7 && W <= 7 && quad_wgrad_enabled())                 // planes of at most 7 x 7: eight per MFMA
+        return dtype == SLAK_BF16 ? launch_qw_t<bf16_t>(p, ws_bytes, st) : launch_qw_t<f16_t>(p, ws_bytes, st);
     if (dtype == SLAK_BF16) return W < 8 ? launch_stw_t<bf16_t, true>(p, ws_bytes, st) : launch_stw_t<bf16_t, false>(p, ws_bytes, st);
     return W < 8 ? launch_stw_t<f16_t, true>(p, ws_bytes, st) : launch_stw_t<f16_t, false>(p, ws_bytes, st);
 }

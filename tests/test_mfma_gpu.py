@@ -295,7 +295,9 @@ def test_full_size_properties_on_slak_b_and_odd_width_channel_counts(mfma_only, 
 
 
 @pytest.mark.parametrize("N,C,H,W,K", [(5, 7, 14, 14, 47), (4, 3, 12, 10, 9), (1, 1, 14, 14, 13), (6, 5, 7, 7, 13), (17, 6, 7, 7, 13), (1, 1, 7, 7, 13),
-                                       (3, 2, 7, 5, 7), (5, 2, 5, 7, 9), (2, 130, 7, 7, 13), (9, 3, 14, 8, 31), (33, 4, 14, 14, 47), (16, 9, 6, 6, 9)])
+                                       (3, 2, 7, 5, 7), (5, 2, 5, 7, 9), (2, 130, 7, 7, 13), (9, 3, 14, 8, 31), (33, 4, 14, 14, 47), (16, 9, 6, 6, 9),
+                                       # eight planes per MFMA (planes up to 7 x 7): batch tails 1..7, H < 7, W < 7, a long batch
+                                       (8, 3, 7, 7, 13), (9, 2, 7, 7, 13), (15, 2, 7, 7, 13), (128, 8, 7, 7, 13), (11, 3, 5, 7, 9), (23, 2, 7, 6, 7), (131, 2, 6, 6, 13), (12, 2, 4, 4, 7)])
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 def test_tri_weight_gradient_matches_the_three_per_branch_kernels(N, C, H, W, K, dtype, gpu):
     """slak_dwconv2d_tri_backward_filter (one launch, x fetched once) against the oracle and the per-branch kernels: same fp32

@@ -18,3 +18,14 @@ for what, fn in (("tri fwd 7x7", tf), ("tri dgrad 7x7", td)):
     for _ in range(50): fn()
     e1.record(); torch.cuda.synchronize()
     print("quad=%s" % os.environ.get("SLAK_SMALL_QUAD", "1"), what, "%.1f us" % (e0.elapsed_time(e1) / 50 * 1e3))
+dws = [torch.empty_like(w) for w in ws]
+wsb = L.slak_dwconv2d_tri_filter_workspace_bytes(_lib.SLAK_BF16, N, C, H, W, K)
+wsp = torch.empty(max(int(wsb), 16), dtype=torch.uint8, device=dev)
+def tw(): _lib.check(L.slak_dwconv2d_tri_backward_filter(dys[0].data_ptr(), dys[1].data_ptr(), dys[2].data_ptr(), x.data_ptr(), dws[0].data_ptr(), dws[1].data_ptr(), dws[2].data_ptr(), _lib.SLAK_BF16, N, C, H, W, K, wsp.data_ptr(), int(wsb), st))
+for _ in range(5): tw()
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(50): tw()
+e1.record(); torch.cuda.synchronize()
+print("quad=%s" % os.environ.get("SLAK_SMALL_QUAD", "1"), "tri wgrad 7x7", "%.1f us" % (e0.elapsed_time(e1) / 50 * 1e3))
