@@ -453,6 +453,7 @@ __global__ __launch_bounds__(MF_THREADS) void dwconv_mfma_small_quad_kernel(cons
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
 
+    float bsum[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};              // forward with p.stats: sum y_b, sum y_b^2 of what this wave stores (bf16)
     auto octet = [&](int q, u32x4 (&R)[NT]) {
         stage(R);                                                 // (the LDS queue is in order: the reads of the octet before are behind us)
         load_oct(q + 2, R);                                       // (every path issues the same memory instructions: the compiler's vmcnt
@@ -496,19 +497,56 @@ __global__ __launch_bounds__(MF_THREADS) void dwconv_mfma_small_quad_kernel(cons
         for (int t = 0; t < NO; ++t) {
             const u32x4 v = *(const u32x4*)(L + t * 1024 + sc_l);
             __builtin_amdgcn_raw_buffer_store_b128(v, ro[t], gc, go, 0);
-            if constexpr (DW) __builtin_amdgcn_raw_buffer_store_b32(*(const unsigned*)(L + t * 1024 + sd_l), ro[t], gd, go, 0);
-            __builtin_amdgcn_raw_buffer_store_b16((short)*(const uint16_t*)(L + t * 1024 + ss_l), ro[t], gs, go, 0);
+            unsigned dwv = 0u;
+            if constexpr (DW) { dwv = *(const unsigned*)(L + t * 1024 + sd_l); __builtin_amdgcn_raw_buffer_store_b32(dwv, ro[t], gd, go, 0); }
+            const uint16_t hs = *(const uint16_t*)(L + t * 1024 + ss_l);
+            __builtin_amdgcn_raw_buffer_store_b16((short)hs, ro[t], gs, go, 0);
+            if constexpr (!DGRAD && std::is_same<T, bf16_t>::value) {
+                if (p.stats) {                                      // (wave-uniform) the BatchNorm statistics of exactly the stored values
+                    const bf16x2_t one = __builtin_bit_cast(bf16x2_t, 0x3f803f80u);
+                    const unsigned d0 = v.x, d1 = v.y, d2 = v.z, d3 = v.w;        // (scalars first: see stat8 in dwconv_mfma_dma.hip)
+                    const bf16x2_t x0 = __builtin_bit_cast(bf16x2_t, d0), x1 = __builtin_bit_cast(bf16x2_t, d1), x2 = __builtin_bit_cast(bf16x2_t, d2), x3 = __builtin_bit_cast(bf16x2_t, d3);
+                    float a0 = __builtin_amdgcn_fdot2_f32_bf16(x0, one, 0.f, false), a1 = __builtin_amdgcn_fdot2_f32_bf16(x1, one, 0.f, false);
+                    float a2 = __builtin_amdgcn_fdot2_f32_bf16(x2, one, 0.f, false), a3 = __builtin_amdgcn_fdot2_f32_bf16(x3, one, 0.f, false);
+                    float q0 = __builtin_amdgcn_fdot2_f32_bf16(x0, x0, 0.f, false), q1 = __builtin_amdgcn_fdot2_f32_bf16(x1, x1, 0.f, false);
+                    float q2 = __builtin_amdgcn_fdot2_f32_bf16(x2, x2, 0.f, false), q3 = __builtin_amdgcn_fdot2_f32_bf16(x3, x3, 0.f, false);
+                    asm("" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(q0), "+v"(q1), "+v"(q2), "+v"(q3));
+                    const float e = __uint_as_float((unsigned)hs << 16);
+                    const bool cok = gc != SQ_OOB, sok = gs != SQ_OOB;
+                    bsum[2 * t] += (cok ? (a0 + a1) + (a2 + a3) : 0.f) + (sok ? e : 0.f);
+                    bsum[2 * t + 1] += (cok ? (q0 + q1) + (q2 + q3) : 0.f) + (sok ? e * e : 0.f);
+                    if constexpr (DW) {                             // the whole dwords behind the plane's 16-byte chunks
+                        const float lo = __uint_as_float(dwv << 16), hi = __uint_as_float(dwv & 0xffff0000u);
+                        if (gd != SQ_OOB) { bsum[2 * t] += lo + hi; bsum[2 * t + 1] += lo * lo + hi * hi; }
+                    }
+                }
+            }
         }
     };
     for (int q = 0; q < noct; q += 2) {
         octet(q, R0);
         octet(q + 1, R1);
     }
+    if constexpr (!DGRAD) {
+        if (p.stats) {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+                float v = bsum[k];
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+                if (lane == 0) p.stats[((size_t)slice * p.C + c) * 6 + k] = v;
+            }
+        }
+    }
 }
 
 static bool quad_enabled() {                   // SLAK_SMALL_QUAD=0 keeps the one-plane-per-tile kernel on 7 x 7 (A/B testing)
     static const bool v = [] { const char* e = getenv("SLAK_SMALL_QUAD"); return !(e && e[0] == '0'); }();
     return v;
+}
+static int quad_target_wgs() {                 // workgroups the launch aims at (dev: SLAK_SQ_WGS per CU)
+    static const int wgs_per_cu = [] { const char* e = getenv("SLAK_SQ_WGS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 4; }();
+    return wgs_per_cu * mfma_cu_count();
 }
 static bool fill_quad_params(SmallTriParams& p, int N, int C, int H, int W, int K, int target_wgs) {
     p.N = N; p.C = C; p.H = H; p.W = W; p.K = K;
@@ -528,8 +566,7 @@ static int launch_quad_t(SmallTriParams& p, hipStream_t st) {
     const bool dw = (pb & 15u) >= 4u || ((pb - 2u) & 15u) >= 4u;
     auto k = dw ? dwconv_mfma_small_quad_kernel<T, DGRAD, true> : dwconv_mfma_small_quad_kernel<T, DGRAD, false>;
     const size_t lds = (size_t)MF_WAVES * SqLds<DGRAD>::WAVE_BYTES;
-    static const int wgs_per_cu = [] { const char* e = getenv("SLAK_SQ_WGS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 4; }();
-    fill_quad_params(p, p.N, p.C, p.H, p.W, p.K, wgs_per_cu * mfma_cu_count());
+    fill_quad_params(p, p.N, p.C, p.H, p.W, p.K, quad_target_wgs());
     if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(k, dim3((unsigned)(((p.C + 3) / 4) * p.slices)), dim3(MF_THREADS), lds, st, p);
     SLAK_LAUNCH_CHECK();
@@ -578,9 +615,10 @@ static int launch_tri_t(SmallTriParams& p, hipStream_t st) {
 
 // rows of the forward kernel's statistics output ([rows][C][6]); 0 = the kernel does not take the shape
 int dwconv_mfma_small_tri_stats_rows(int N, int C, int H, int W, int K, int dtype) {
-    if (dtype != SLAK_BF16 || W < 8 || !dwconv_mfma_small_tri_supported(N, C, H, W, K, dtype)) return 0;   // (7 x 7 planes: the kernel is bound by
-                                                                                                            // instructions per plane: the sums cost more than bn3's pass)
+    if (dtype != SLAK_BF16 || !dwconv_mfma_small_tri_supported(N, C, H, W, K, dtype)) return 0;
     SmallTriParams p;
+    if (quad_enabled() && fill_quad_params(p, N, C, H, W, K, quad_target_wgs())) return p.slices;      // planes up to 7 x 7: sums in the store phase
+    if (W < 8) return 0;                                               // (one plane per tile: bound by instructions per plane, the sums cost more than bn3's pass)
     fill_tri_params(p, N, C, H, W, K, 3 * mfma_cu_count());
     return p.slices;
 }

@@ -27,7 +27,7 @@ constexpr int TW_T = TW_RING + TW_NS * TW_SLOT + 64;      // [dy_v^T pair 1024][
 constexpr int TW_RES = TW_T + 2048 + 64;                  // res: up to 10 * 63 + 25 floats
 constexpr int TW_RESN = 672;
 constexpr int TW_WAVE_BYTES = TW_RES + TW_RESN * 4;
-static_assert(TW_NS * TW_SLOT >= 16 * 32 * 4, "the diagonal-sum tile aliases the ring");
+static_assert(TW_NS * TW_SLOT >= 5 * 16 * 32 * 4, "the diagonal-sum tiles alias the ring");
 
 struct SmallTriWgradParams {
     const void* dy[3]; const void* x; float* partial; float* dw[3]; unsigned* counters;
@@ -43,6 +43,44 @@ template <> __device__ __forceinline__ f32x4_t tw_mfma16<bf16_t>(s16x8 a, s16x8 
 }
 template <> __device__ __forceinline__ f32x4_t tw_mfma16<f16_t>(s16x8 a, s16x8 b, f32x4_t c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+}
+
+// Diagonal sums of the five per-tap correlation tiles of a branch in ONE pass: tile = 5 x [16][32] floats of the wave's (dead)
+// streaming area.  Every accumulator entry (o, i) of tap r that takes part lands on row o, column pos(i) - pos(o) + 15 of tile r; lane
+// (r, column) then adds its column's 16 rows top to bottom (fixed order: reproducible) and hands the sum to `emit`.  One write
+// phase and one read phase per branch (the per-tap version synchronised ten times per branch: its LDS latencies were 4.6 us of
+// the 7 x 7 launch's 20).
+constexpr int TW_DIAG_BYTES = MF_TAPS * 16 * 32 * 4;
+template <typename F>
+__device__ __forceinline__ void tw_diag5(float* tile, int lane, const f32x4_t (&acc)[MF_TAPS], const bool (&wok)[4], const int (&wofs)[4], F&& emit) {
+#pragma unroll
+    for (int k = 0; k < TW_DIAG_BYTES / 1024; ++k) *(u32x4*)((char*)tile + (k * 64 + lane) * 16) = u32x4{0u, 0u, 0u, 0u};
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int r = 0; r < MF_TAPS; ++r) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (wok[e]) tile[r * 512 + wofs[e]] = acc[r][e];
+    }
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int idx = lane + 64 * k;                            // (tap, column): 5 x 31
+        if (idx < MF_TAPS * 31) {
+            const int r = idx / 31, col = idx - r * 31;
+            float v[16];
+#pragma unroll
+            for (int o = 0; o < 16; ++o) v[o] = tile[r * 512 + o * 32 + col];      // 16 independent reads, added in order below
+            float sum = 0.f;
+#pragma unroll
+            for (int o = 0; o < 16; ++o) sum += v[o];
+            emit(r, col, sum);
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 }
 
 template <typename T, bool NARROW>
@@ -180,8 +218,6 @@ __global__ __launch_bounds__(MF_THREADS) void dwconv_mfma_small_tri_wgrad_kernel
             auto valid = [&](int sl) { const int qq = pos(sl); return sl < 8 ? sl < Wt : (qq >= 8 && qq < Wt); };
             const int pi = pos(i16);
             const bool vi = valid(i16);
-            *(u32x4*)((char*)tile + lane * 16) = u32x4{0u, 0u, 0u, 0u};
-            *(u32x4*)((char*)tile + 1024 + lane * 16) = u32x4{0u, 0u, 0u, 0u};
             int wofs[4]; bool wok[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -189,28 +225,10 @@ __global__ __launch_bounds__(MF_THREADS) void dwconv_mfma_small_tri_wgrad_kernel
                 wok[e] = vi && valid(so);
                 wofs[e] = so * 32 + (pi - pos(so) + 15);
             }
-            __builtin_amdgcn_wave_barrier();
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-            for (int r = 0; r < MF_TAPS; ++r) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    if (wok[e]) tile[wofs[e]] = acc[r][e];
-                __builtin_amdgcn_wave_barrier();
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                if (lane < 31) {
-                    float v[16];
-#pragma unroll
-                    for (int o = 0; o < 16; ++o) v[o] = tile[o * 32 + lane];       // 16 independent reads, added in order below
-                    float sum = 0.f;
-#pragma unroll
-                    for (int o = 0; o < 16; ++o) sum += v[o];
-                    const int tau = lane - 15 + padL;
-                    if (tau >= 0 && tau < KL) out[vert ? (tau * kw + r) : (r * kw + tau)] = sum;
-                }
-                __builtin_amdgcn_wave_barrier();
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            }
+            tw_diag5(tile, lane, acc, wok, wofs, [&](int r, int col, float sum) {
+                const int tau = col - 15 + padL;
+                if (tau >= 0 && tau < KL) out[vert ? (tau * kw + r) : (r * kw + tau)] = sum;
+            });
         };
         diag(av, true, p.H, p.K, MF_TAPS, res);
         diag(ah, false, p.W, p.K, p.K, res + nt_long);
@@ -274,10 +292,10 @@ constexpr int QW_TEN = 2 * QW_TILE;     // two tiles (an octet of planes) of one
 constexpr int QW_SLOT = 4 * QW_TEN;     // [dy_v][dy_h][dy_s][x]
 constexpr int QW_T = TW_RING + QW_SLOT;                   // [dy_v^T: 2 x 512][64 zero][x^T tile 0][64 zero][x^T tile 1][64 zero]
 constexpr int QW_XT = QW_T + 1024 + 64;
-constexpr int QW_RES = QW_XT + 2 * QW_TILE;
+constexpr int QW_RES = QW_XT + 2 * QW_TILE > TW_RING + 5 * 16 * 32 * 4 ? QW_XT + 2 * QW_TILE : TW_RING + 5 * 16 * 32 * 4;   // (the diagonal-sum tiles alias what lies in front)
 constexpr int QW_WAVE_BYTES = QW_RES + TW_RESN * 4;
 constexpr unsigned QW_OOB = 0x80000000u;
-static_assert(QW_SLOT >= 16 * 32 * 4, "the diagonal-sum tile aliases the slot");
+
 
 template <typename T>
 __global__ __launch_bounds__(MF_THREADS) void dwconv_mfma_small_quad_wgrad_kernel(const SmallTriWgradParams p) {
@@ -395,8 +413,6 @@ __global__ __launch_bounds__(MF_THREADS) void dwconv_mfma_small_quad_wgrad_kerne
             auto valid = [&](int sl) { return (!vert || (sl != 7 && sl != 8)) && pos(sl) < Wt; };
             const int pi = pos(i16);
             const bool vi = valid(i16);
-            *(u32x4*)((char*)tile + lane * 16) = u32x4{0u, 0u, 0u, 0u};
-            *(u32x4*)((char*)tile + 1024 + lane * 16) = u32x4{0u, 0u, 0u, 0u};
             int wofs[4]; bool wok[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -404,28 +420,10 @@ __global__ __launch_bounds__(MF_THREADS) void dwconv_mfma_small_quad_wgrad_kerne
                 wok[e] = vi && valid(so) && blk(so) == blk(i16);  // (the off-diagonal blocks are products of different planes)
                 wofs[e] = so * 32 + (pi - pos(so) + 15);
             }
-            __builtin_amdgcn_wave_barrier();
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-            for (int r = 0; r < MF_TAPS; ++r) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    if (wok[e]) tile[wofs[e]] = acc[r][e];
-                __builtin_amdgcn_wave_barrier();
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                if (lane < 31) {
-                    float v[16];
-#pragma unroll
-                    for (int o = 0; o < 16; ++o) v[o] = tile[o * 32 + lane];       // 16 independent reads, added in order below
-                    float sum = 0.f;
-#pragma unroll
-                    for (int o = 0; o < 16; ++o) sum += v[o];
-                    const int tau = lane - 15 + padL;
-                    if (tau >= 0 && tau < KL) out[vert ? (tau * kw + r) : (r * kw + tau)] = sum;
-                }
-                __builtin_amdgcn_wave_barrier();
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            }
+            tw_diag5(tile, lane, acc, wok, wofs, [&](int r, int col, float sum) {
+                const int tau = col - 15 + padL;
+                if (tau >= 0 && tau < KL) out[vert ? (tau * kw + r) : (r * kw + tau)] = sum;
+            });
         };
         if (!(p.dbg & 4)) {
         diag(av, true, p.H, p.K, MF_TAPS, res);

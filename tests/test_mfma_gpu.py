@@ -399,7 +399,9 @@ def test_dense_operator_three_branch_kernels_behind_the_dev_hook(N, C, H, W, K, 
 
 
 @pytest.mark.parametrize("N,C,H,W,K", [(128, 32, 14, 14, 47), (6, 3, 14, 10, 13), (33, 8, 12, 14, 31),
-                                       (5, 3, 56, 56, 51), (9, 2, 28, 28, 49), (2, 2, 48, 40, 31), (130, 2, 28, 28, 13)])
+                                       (5, 3, 56, 56, 51), (9, 2, 28, 28, 49), (2, 2, 48, 40, 31), (130, 2, 28, 28, 13),
+                                       # planes up to 7 x 7: sums gathered in the store phase of the eight-planes-per-step kernel
+                                       (128, 16, 7, 7, 13), (9, 5, 7, 7, 13), (11, 3, 5, 6, 9), (1, 1, 7, 7, 13), (20, 2, 4, 4, 7)])
 def test_tri_forward_batch_sums_are_the_sums_of_the_stored_outputs(N, C, H, W, K, gpu):
     """slak_dwconv2d_tri_forward_stats / slak_dwconv2d_forward_stats: the partial sums the forward launches leave for the branch BatchNorms
     (models/SLaK.py:92-95) add up to sum y_b and sum y_b^2 of the three stored bf16 outputs (fp32 summation order aside), and the outputs
