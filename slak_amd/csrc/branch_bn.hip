@@ -11,6 +11,7 @@
 //             apply:  dy_b = A_b[c]*dout + B_b[c]*y_b + C_b[c]     (the BatchNorm backward is affine in (dout, y_b) per channel)
 // The tensors are treated as [N*C rows][P = H*W columns]: one wavefront per row with vector loads and a wavefront-wide
 // reduction; per-channel sums add the N rows of a channel in a fixed order (deterministic).  All HBM-bound.
+#include <stdlib.h>
 #include "slak_common.h"
 
 namespace slak {
@@ -102,7 +103,8 @@ __global__ __launch_bounds__(BN_THREADS) void bn3_chansums(const uint16_t* __res
     for (int k = 0; k < K; ++k) { const float t = bn_wave_sum(s[k]); if (lane == 0) part[((size_t)sl * C + c) * K + k] = t; }
 }
 static void bn_slices(int N, int C, int* S, int* per) {            // ~16384 wavefronts (a full machine of eight per SIMD, twice over), whole images per slice
-    int s = 16384 / C; if (s < 1) s = 1; if (s > N) s = N;
+    static const int waves = [] { const char* e = getenv("SLAK_BN_WAVES"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 16384; }();
+    int s = waves / C; if (s < 1) s = 1; if (s > N) s = N;
     *per = (N + s - 1) / s; *S = (N + *per - 1) / *per;
 }
 

@@ -214,6 +214,40 @@ def test_mlp_splitk_matches_torch(M, C, gpu):
         _close(got, ref, 2e-2, n)
 
 
+@pytest.mark.parametrize("M,cols", [(6272, 384), (777, 768), (25, 1536), (8, 3072), (1, 8), (4100, 96)])
+def test_gelu_backward_bias_on_every_input_class(M, cols, gpu):
+    """slak_gelu_backward_bias: dy1 = dact * gelu'(y1) (erf form, nn.GELU()) rounded once to bf16, dbias = column sums of the STORED
+    dy1.  Most elements take the table path (2^-18 <= |x| < 16); zeros, tiny, huge, infinite and NaN pre-activations take the general one
+    (a wave with one such element re-evaluates its eight columns): both against fp64, row tails and the software pipeline's odd counts."""
+    from slak_amd import block_ops, _lib
+    L = _lib.lib()
+    torch.manual_seed(M + cols)
+    y1 = torch.randn(M, cols, device=gpu)
+    if M * cols >= 64:
+        flat = y1.view(-1)
+        sp = torch.tensor([0.0, -0.0, 1e-7, -1e-7, 3e-6, -3.9e-6, 15.9, -15.9, 16.0, -16.0, 40.0, -1e30, float("inf"), float("-inf"), float("nan")], device=gpu)
+        idx = torch.randperm(flat.numel(), device=gpu)[:sp.numel() * 3]
+        flat[idx] = sp.repeat(3)
+    y1 = y1.bfloat16()
+    dact = torch.randn(M, cols, device=gpu).bfloat16()
+    dy1 = torch.empty_like(dact); db = torch.empty(cols, device=gpu)
+    ws, nb = block_ops._workspace(L.slak_gelu_bwd_workspace_bytes(M, cols), gpu)
+    st = torch.cuda.current_stream(gpu).cuda_stream
+    _lib.check(L.slak_gelu_backward_bias(dact.data_ptr(), y1.data_ptr(), dy1.data_ptr(), db.data_ptr(), M, cols, ws.data_ptr(), nb, st), "gelu")
+    torch.cuda.synchronize()
+    x = y1.double()
+    gp = 0.5 * (1.0 + torch.erf(x / 2.0 ** 0.5)) + x * torch.exp(-0.5 * x * x) / (2.0 * torch.pi) ** 0.5
+    gp = torch.where(torch.isinf(x), (x > 0).double(), gp)           # the limit (inf * 0 in the formula): what the kernel returns
+    ref = dact.double() * gp
+    fin = torch.isfinite(ref)
+    assert torch.equal(torch.isnan(dy1), torch.isnan(ref.bfloat16()))
+    err = (dy1.double() - ref)[fin].abs(); tol = (ref[fin].abs() * 2.0 ** -8 + 1e-30) * 1.01
+    assert bool((err <= tol).all()), float((err / tol).max())
+    colfin = torch.isfinite(dy1.double().sum(0))
+    got, want = db.double()[colfin], dy1.double().sum(0)[colfin]
+    assert (got - want).abs().max().item() <= 1e-5 * max(1.0, want.abs().max().item()) * max(1.0, M ** 0.5 / 30)
+
+
 def test_lowp_weight_cache_follows_optimizer_and_mask_updates(gpu):
     """block_ops.cache_lowp_weights: the bf16 copies of the Linear weights must follow in-place updates that bump the tensor
     version (optimizer steps, torch._C._increment_version after the mask kernels) -- refreshed in one multi-tensor copy."""
