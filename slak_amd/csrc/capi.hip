@@ -113,7 +113,7 @@ size_t slak_dwconv2d_workspace_bytes(int op, int N, int C, int H, int W, int kh,
     if (N <= 0 || C <= 0 || H <= 0 || W <= 0 || kh <= 0 || kw <= 0) return 0;
     ConvDims d{N, C, H, W, kh, kw};
     if (op == 0 || op == 1) { size_t a = dwconv_direct_workspace(d), b = dwconv_mfma_workspace(d), c = dwconv_mfma_small_workspace(d); a = a > b ? a : b; return a > c ? a : c; }
-    if (op == 2) { size_t a = dwconv_wgrad_workspace(d), b = dwconv_mfma_wgrad_workspace(d), c = dwconv_mfma_wgrad_dma_workspace(d), e = dwconv_mfma_small_wgrad_workspace(d), f = dwconv_mfma_small_wgrad_dma_workspace(d), g = dwconv_mfma_wgrad_vrows_workspace(d), h = dwconv_mfma_wide_wgrad_workspace(d); a = a > g ? a : g; a = a > h ? a : h; a = a > b ? a : b; a = a > c ? a : c; a = a > e ? a : e; return a > f ? a : f; }
+    if (op == 2) { size_t a = dwconv_wgrad_workspace(d), b = dwconv_mfma_wgrad_workspace(d), c = dwconv_mfma_wgrad_dma_workspace(d), e = dwconv_mfma_small_wgrad_workspace(d), f = dwconv_mfma_small_wgrad_dma_workspace(d), g = dwconv_mfma_wgrad_vrows_workspace(d), h = dwconv_mfma_wide_wgrad_workspace(d), i = dwconv_mfma_wgrad_vwave_workspace(d); a = a > i ? a : i; a = a > g ? a : g; a = a > h ? a : h; a = a > b ? a : b; a = a > c ? a : c; a = a > e ? a : e; return a > f ? a : f; }
     return 0;
 }
 
@@ -184,6 +184,10 @@ int slak_dwconv2d_backward_filter(const void* dy, int dy_dtype, const void* x, i
         return launch_dwconv_mfma_small_wgrad(dy, dy_dtype, x, x_dtype, dw, d, workspace, workspace_bytes, (hipStream_t)stream);
     if (g_conv_algo != SLAK_ALGO_DIRECT && use_dma() && use_vrows() && dwconv_mfma_wgrad_vrows_supported(d, dy_dtype, x_dtype)) {
         const int rc = launch_dwconv_mfma_wgrad_vrows(dy, dy_dtype, x, x_dtype, dw, d, workspace, workspace_bytes, (hipStream_t)stream);
+        if (rc != SLAK_ERR_UNSUPPORTED) return rc;
+    }
+    if (g_conv_algo != SLAK_ALGO_DIRECT && use_dma() && dwconv_mfma_wgrad_vwave_supported(d, dy_dtype, x_dtype)) {     // vertical, planes of <= 32 rows
+        const int rc = launch_dwconv_mfma_wgrad_vwave(dy, dy_dtype, x, x_dtype, dw, d, workspace, workspace_bytes, (hipStream_t)stream);
         if (rc != SLAK_ERR_UNSUPPORTED) return rc;
     }
     if (g_conv_algo != SLAK_ALGO_DIRECT && use_dma() && dwconv_mfma_wgrad_dma_supported(d, dy_dtype, x_dtype))

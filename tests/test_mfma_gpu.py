@@ -65,6 +65,9 @@ SHAPES = [
     (5, 3, 12, 16, 5, 13), (5, 3, 16, 12, 13, 5), (3, 9, 14, 16, 5, 31),
     # vertical weight gradient by row reads + shifted copy: first and last chunk of the tensor, non-square planes, narrow planes
     (3, 2, 56, 56, 51, 5), (1, 1, 40, 48, 31, 5), (2, 2, 64, 16, 51, 5), (2, 3, 36, 24, 35, 5),
+    # vertical weight gradient, one plane per wave (planes of <= 32 rows, rows that are not whole 16-byte pieces): wave tails (N % 4),
+    # slice tails, the tensor's last row, every piece count, kernels longer than the plane
+    (9, 3, 28, 28, 49, 5), (1, 1, 28, 28, 49, 5), (6, 2, 32, 32, 31, 5), (13, 2, 15, 16, 13, 5), (5, 3, 20, 24, 21, 5), (130, 2, 28, 28, 49, 5),
     # wide maps (64 < long axis <= 128: banded Toeplitz, strip walk, padded-pitch plane DMA): BASELINE configs[4] stage 1 (96x96,
     # 61-tap), the 128x128 planes of the 512 px segmentation crops, non-square / non-multiple-of-32 maps, single plane
     (3, 2, 96, 96, 5, 61), (3, 2, 96, 96, 61, 5), (2, 3, 96, 96, 5, 5), (2, 2, 128, 128, 5, 61), (2, 2, 128, 128, 61, 5),
@@ -93,6 +96,23 @@ def test_mfma_forward_dgrad_wgrad_vs_oracle(N, C, H, W, kh, kw, dtype, mfma_only
     err = np.abs(dw.double().cpu().numpy() - ref).max()
     assert err <= 1e-5 * max(1.0, np.abs(ref).max()) * max(1.0, (N * H * W) ** 0.5 / 30), err    # fp32 accumulation only
     assert torch.equal(dw, ops.dwconv2d_backward_filter(dy, x, w))                                 # no atomics
+
+
+@pytest.mark.parametrize("N,C,H,W,kh", [(5, 3, 20, 18, 21), (7, 2, 24, 22, 63), (3, 5, 30, 26, 7), (9, 3, 17, 30, 9), (33, 2, 28, 28, 49), (4, 1, 32, 16, 13)])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_vertical_weight_gradient_one_plane_per_wave(N, C, H, W, kh, dtype, gpu):
+    """dwconv_mfma_wgrad_vwave_kernel (K x 5 on planes of <= 32 rows; rows travel through registers as dword-aligned 16-byte pieces)
+    on widths whose last piece holds 1, 3 or 4 dwords of the row, against the oracle; reproducible bit for bit."""
+    ops = _ops()
+    torch.manual_seed(N * 31 + W)
+    x = torch.randn(N, C, H, W, device=gpu).to(dtype)
+    dy = torch.randn(N, C, H, W, device=gpu).to(dtype)
+    w = torch.randn(C, 1, kh, 5, device=gpu) * 0.05
+    dw = ops.dwconv2d_backward_filter(dy, x, w)
+    ref = oracle.dwconv2d_bwd_filter(_round(dy, dtype), _round(x, dtype), kh, 5)
+    err = np.abs(dw.double().cpu().numpy() - ref).max()
+    assert err <= 1e-5 * max(1.0, np.abs(ref).max()) * max(1.0, (N * H * W) ** 0.5 / 30), err
+    assert torch.equal(dw, ops.dwconv2d_backward_filter(dy, x, w))
 
 
 def test_mfma_is_what_auto_runs_for_lowp(gpu):
