@@ -126,9 +126,10 @@ def hot_path_kernels(device, batch, reps, dtype, stages):
       forward   : one launch per branch -- or ONE launch for the three (`tri`, where slak_dwconv2d_tri_supported == 1);
       bwd_data  : branch 1 plain, branches 2 and 3 ACCUMULATING into the same dx (`+acc`: autograd's adds folded in; 3*S*b bytes:
                   read dy, read dx, write dx) -- or ONE launch for the three;
-      bwd_filter: one launch per branch -- or ONE launch for the three (where slak_dwconv2d_tri_filter_workspace_bytes > 0).
-    Algorithmic bytes: SURVEY.md 8(d) per op -- 2*S*b (+ C*kh*kw*4); a three-branch launch is priced at the per-op figure of the
-    three ops it replaces (3 x 2*S*b), as 8(d) prescribes."""
+      bwd_filter: one launch per branch -- or ONE launch for the three (where slak_dwconv2d_tri_filter_workspace_bytes > 0), or ONE for
+                  the K x 5 and the 5 x 5 branch (`pair`, where slak_dwconv2d_pair_filter_workspace_bytes > 0) beside the 5 x K launch.
+    Algorithmic bytes: SURVEY.md 8(d) per op -- 2*S*b (+ C*kh*kw*4); a three-branch (two-branch) launch is priced at the per-op figure
+    of the three (two) ops it replaces (3 x 2*S*b, 2 x 2*S*b), as 8(d) prescribes."""
     from slak_amd import _lib, ops
     L = _lib.lib()
     st = torch.cuda.current_stream(device).cuda_stream
@@ -162,6 +163,16 @@ def hot_path_kernels(device, batch, reps, dtype, stages):
             a_td = (dys[0].data_ptr(), dys[1].data_ptr(), dys[2].data_ptr(), wts[0].data_ptr(), wts[1].data_ptr(), wts[2].data_ptr(), ys[0].data_ptr(), dt, batch, C, HW, HW, K, st)
             add("%dx5+5x%d+5x5" % (K, K), "tri", "fwd", lambda: _lib.check(L.slak_dwconv2d_tri_forward(*a_tf)), 3 * 2 * S * b + wbytes, flops3)
             add("%dx5+5x%d+5x5" % (K, K), "tri", "bwd_data", lambda: _lib.check(L.slak_dwconv2d_tri_backward_data(*a_td)), 3 * 2 * S * b + wbytes, flops3)
+        pair_nb = int(L.slak_dwconv2d_pair_filter_workspace_bytes(dt, batch, C, HW, HW, K)) if (dtype != torch.float32 and not tri_w_nb) else 0
+        if pair_nb:
+            dwp = [torch.empty_like(wts[0]), torch.empty_like(wts[2])]
+            wsp = torch.empty(pair_nb, dtype=torch.uint8, device=device)
+            a_pw = (dys[0].data_ptr(), dys[2].data_ptr(), x.data_ptr(), dwp[0].data_ptr(), dwp[1].data_ptr(), dt, batch, C, HW, HW, K, wsp.data_ptr(), pair_nb, st)
+            if L.slak_dwconv2d_pair_backward_filter(*a_pw) == _lib.OK:
+                add("%dx5+5x5" % K, "pair", "bwd_filter", lambda: _lib.check(L.slak_dwconv2d_pair_backward_filter(*a_pw)),
+                    2 * 2 * S * b + C * (K * 5 + 25) * 4, 2.0 * S * (K * 5 + 25))
+            else:
+                pair_nb = 0
         for bi, (kname, (kh, kw)) in enumerate(shapes):
             w = wts[bi]
             dw = torch.empty_like(w)
@@ -179,7 +190,7 @@ def hot_path_kernels(device, batch, reps, dtype, stages):
                     add(kn, kname, "bwd_data+acc", lambda: _lib.check(L.slak_dwconv2d_backward_data_accumulate(*a_d)), 3 * S * b + wb, flop)
                 else:
                     add(kn, kname, "bwd_data", lambda: _lib.check(L.slak_dwconv2d_backward_data(*a_d)), 2 * S * b + wb, flop)
-            if not tri_w_nb:
+            if not tri_w_nb and not (pair_nb and bi != 1):
                 add(kn, kname, "bwd_filter", lambda: _lib.check(L.slak_dwconv2d_backward_filter(*a_w)), 2 * S * b + wb, flop)
             del ws, dw
         del x, dys, ys

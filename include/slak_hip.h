@@ -164,6 +164,14 @@ int slak_dwconv2d_tri_backward_filter(const void* dy_v, const void* dy_h, const 
                                       float* dw_s, int dtype, int N, int C, int H, int W, int K,
                                       void* workspace, size_t workspace_bytes, void* stream);
 
+/* The K x 5 and the 5 x 5 weight gradient of a block in one launch, for the planes the three-branch launch does not cover (round 2:
+ * 15 <= H <= 32, W even 16..32 -- the 28 x 28 stage): the 5 x 5 correlation is the K x 5 one with its own dY, so x is fetched and
+ * column-shifted once for both.  dw_v (C,1,K,5), dw_s (C,1,5,5), fp32, bitwise reproducible.  slak_dwconv2d_pair_filter_workspace_bytes
+ * returns 0 and the call SLAK_ERR_UNSUPPORTED elsewhere (two slak_dwconv2d_backward_filter calls instead). */
+size_t slak_dwconv2d_pair_filter_workspace_bytes(int dtype, int N, int C, int H, int W, int K);
+int slak_dwconv2d_pair_backward_filter(const void* dy_v, const void* dy_s, const void* x, float* dw_v, float* dw_s,
+                                       int dtype, int N, int C, int H, int W, int K, void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---------------------------------------------------------------- next row: block tail glue
  * The layout / normalisation / residual steps around the two pointwise GEMMs of a SLaK block
  * (models/SLaK.py:153-166: permute -> LayerNorm -> [pwconv1, GELU, pwconv2] -> gamma -> permute -> shortcut + drop_path),

@@ -98,6 +98,8 @@ SIGNATURES = {
     "slak_dwconv2d_tri_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "slak_dwconv2d_tri_backward_data": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "slak_dwconv2d_tri_filter_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i]),
+    "slak_dwconv2d_pair_filter_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i]),
+    "slak_dwconv2d_pair_backward_filter": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     "slak_dwconv2d_tri_backward_filter": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     "slak_stem_patchify": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "slak_ln_patch_supported": (_i, [_i, _i, _i, _i]),

@@ -220,6 +220,21 @@ class _TriDwConv(torch.autograd.Function):
                     dwv = dwh = dws = None
                 else:
                     _lib.check(rc, "slak_dwconv2d_tri_backward_filter")
+        if dwv is None and ctx.needs_input_grad[1] and ctx.needs_input_grad[3] and fused_tri_wgrad and x.dtype in ops._DT:
+            L = _lib.lib()
+            dt = ops._DT[x.dtype]
+            nb = int(L.slak_dwconv2d_pair_filter_workspace_bytes(dt, N, C, H, W, K))
+            if nb:                                               # K x 5 and 5 x 5 in one launch (x fetched and shifted once)
+                dwv, dws = (torch.empty_like(w, dtype=torch.float32) for w in (wv, ws))
+                wsb, nbb = _workspace(nb, x.device)
+                with torch.cuda.device(x.device):
+                    rc = L.slak_dwconv2d_pair_backward_filter(dyv.data_ptr(), dys.data_ptr(), x.data_ptr(), dwv.data_ptr(), dws.data_ptr(),
+                                                              dt, N, C, H, W, K, wsb.data_ptr(), nbb, _stream(x.device))
+                if rc == _lib.ERR_UNSUPPORTED:
+                    dwv = dws = None
+                else:
+                    _lib.check(rc, "slak_dwconv2d_pair_backward_filter")
+                    dwh = ops.dwconv2d_backward_filter(dyh, x, wh) if ctx.needs_input_grad[2] else None
         if dwv is None:
             dwv = ops.dwconv2d_backward_filter(dyv, x, wv) if ctx.needs_input_grad[1] else None
             dwh = ops.dwconv2d_backward_filter(dyh, x, wh) if ctx.needs_input_grad[2] else None

@@ -16,6 +16,10 @@ static bool use_small_dma() {                // SLAK_MFMA_SMALL_DMA=0 keeps the 
     static const bool v = [] { const char* e = getenv("SLAK_MFMA_SMALL_DMA"); return !(e && e[0] == '0'); }();
     return v;
 }
+static bool use_vrows_pair() {               // SLAK_VROWS_PAIR=0: the 56 x 56 class keeps separate K x 5 and 5 x 5 weight-gradient launches (A/B testing)
+    static const bool v = [] { const char* e = getenv("SLAK_VROWS_PAIR"); return !(e && e[0] == '0'); }();
+    return v;
+}
 static bool use_vrows() {                    // SLAK_MFMA_VROWS=0 keeps the transposing vertical weight-gradient kernel (A/B testing)
     static const bool v = [] { const char* e = getenv("SLAK_MFMA_VROWS"); return !(e && e[0] == '0'); }();
     return v;
@@ -32,6 +36,7 @@ static bool use_small() {                    // SLAK_MFMA_SMALL=0 keeps the gene
     if (v < 0) { const char* e = getenv("SLAK_MFMA_SMALL"); v = (e && e[0] == '0') ? 0 : 1; }
     return v != 0;
 }
+static constexpr int MF_TAPS_HOST = 5;        // the short side the MFMA kernels are written for
 static bool use_dma() {                      // SLAK_MFMA_DMA=0 keeps the register-staged MFMA kernels (A/B testing)
     static int v = -1;
     if (v < 0) { const char* e = getenv("SLAK_MFMA_DMA"); v = (e && e[0] == '0') ? 0 : 1; }
@@ -268,6 +273,26 @@ int slak_dwconv2d_tri_backward_filter(const void* dy_v, const void* dy_h, const 
     if (!dy_v || !dy_h || !dy_s || !x || !dw_v || !dw_h || !dw_s) return SLAK_ERR_INVALID_ARG;
     const void* dy[3] = {dy_v, dy_h, dy_s}; float* dw[3] = {dw_v, dw_h, dw_s};
     return launch_dwconv_mfma_small_tri_wgrad(dy, x, dw, dtype, N, C, H, W, K, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+/* The K x 5 and the 5 x 5 weight gradient of a block in ONE launch where the three-branch launch above does not reach (x and its five
+ * column-shifted operands are shared: the 5 x 5 correlation is the K x 5 one with its own dY).  0 / SLAK_ERR_UNSUPPORTED: two calls. */
+size_t slak_dwconv2d_pair_filter_workspace_bytes(int dtype, int N, int C, int H, int W, int K) {
+    ConvDims d{N, C, H, W, K, MF_TAPS_HOST};
+    if (dwconv_mfma_wgrad_vwave_supported(d, dtype, dtype)) return dwconv_mfma_wgrad_vwave_workspace(d);
+    if (use_vrows() && use_vrows_pair() && dwconv_mfma_wgrad_vrows_supported(d, dtype, dtype)) return dwconv_mfma_wgrad_vrows_workspace(d);
+    return 0;
+}
+int slak_dwconv2d_pair_backward_filter(const void* dy_v, const void* dy_s, const void* x, float* dw_v, float* dw_s,
+                                       int dtype, int N, int C, int H, int W, int K, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!dy_v || !dy_s || !x || !dw_v || !dw_s) return SLAK_ERR_INVALID_ARG;
+    if (N <= 0 || C <= 0 || H <= 0 || W <= 0 || K <= 5) return SLAK_ERR_INVALID_ARG;
+    ConvDims d{N, C, H, W, K, MF_TAPS_HOST};
+    if (g_conv_algo != SLAK_ALGO_DIRECT && use_dma() && dwconv_mfma_wgrad_vwave_supported(d, dtype, dtype))
+        return launch_dwconv_mfma_wgrad_vwave(dy_v, dtype, x, dtype, dw_v, d, workspace, workspace_bytes, (hipStream_t)stream, dy_s, dw_s);
+    if (g_conv_algo != SLAK_ALGO_DIRECT && use_dma() && use_vrows() && use_vrows_pair() && dwconv_mfma_wgrad_vrows_supported(d, dtype, dtype))
+        return launch_dwconv_mfma_wgrad_vrows(dy_v, dtype, x, dtype, dw_v, d, workspace, workspace_bytes, (hipStream_t)stream, dy_s, dw_s);
+    return SLAK_ERR_UNSUPPORTED;
 }
 
 }  // extern "C"

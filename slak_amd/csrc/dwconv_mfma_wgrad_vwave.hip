@@ -25,6 +25,7 @@ constexpr unsigned VW_OOB = 0x80000000u;
 
 struct WgradWaveParams {
     const void* dy; const void* x; float* partial; float* dw; unsigned* counters;
+    const void* dy2; float* dw2;      // PAIR: the 5 x 5 branch of the same block (its dY, its dw): shares x and the five shifted operands
     int N, C, H, W, kh, kw, KL, padL;
     int DC;                // 16-byte pieces per image row: ceil(W / 8) (<= 4)
     int CPR;               // 16-byte chunks per LDS row (odd, >= DC + 1)
@@ -33,12 +34,14 @@ struct WgradWaveParams {
     unsigned tensor_bytes;
 };
 
-template <typename T>
+// PAIR: dw (K x 5) and dw2 (5 x 5) of one block in one launch -- G_r[o, i] of the small branch is the same correlation with its own dY,
+// so x is fetched and shifted once for both (five more MFMAs per k-step, a third plane copy in the slot)
+template <typename T, bool PAIR>
 __global__ __launch_bounds__(MF_THREADS, 2) void dwconv_mfma_wgrad_vwave_kernel(const WgradWaveParams p) {
     constexpr int NG = MF_TAPS;
     extern __shared__ __attribute__((aligned(16))) uint16_t lds[];
     char* const LB = (char*)lds;
-    const int HW = p.H * p.W, ntap = p.kh * p.kw;
+    const int HW = p.H * p.W, ntap1 = p.kh * p.kw, ntap = ntap1 + (PAIR ? MF_TAPS * MF_TAPS : 0);
     const unsigned PB = (unsigned)p.CPR * 16;                     // LDS row pitch (bytes)
     const unsigned copy_b = 32u * PB;                             // one plane copy: 32 rows (rows >= H stay zero)
     constexpr unsigned WAVE_B = 64 + 32 * 64 * 4;                 // per wave: [64 zero][slot: dY copy, X copy | epilogue tile 32 x 64 floats]
@@ -57,6 +60,7 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dwconv_mfma_wgrad_vwave_kernel(
     // ---- loads: lane -> pieces g = lane + 64 j of a plane copy: (row, piece) = (g / DC, g % DC) -----------------------------
     __amdgpu_buffer_rsrc_t rs_dy = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.dy), 0, (int)p.tensor_bytes, 0x00020000);
     __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.x), 0, (int)p.tensor_bytes, 0x00020000);
+    __amdgpu_buffer_rsrc_t rs_d2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(PAIR ? p.dy2 : p.dy), 0, (int)p.tensor_bytes, 0x00020000);
     unsigned l_src[VW_MAXJ], l_dst[VW_MAXJ], l_m[VW_MAXJ][4];
 #pragma unroll
     for (int j = 0; j < VW_MAXJ; ++j) {
@@ -69,7 +73,7 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dwconv_mfma_wgrad_vwave_kernel(
         for (int d = 0; d < 4; ++d) l_m[j][d] = nv >= 2 * d + 2 ? 0xffffffffu : (nv == 2 * d + 1 ? 0xffffu : 0u);
     }
     const unsigned chan_b = (unsigned)c * (unsigned)HW * 2, gplane_b = (unsigned)(p.C * HW) * 2;
-    struct Regs { u32x4 a[VW_MAXJ], x[VW_MAXJ]; };
+    struct Regs { u32x4 a[VW_MAXJ], x[VW_MAXJ], a2[PAIR ? VW_MAXJ : 1]; };
     auto load_plane = [&](int k, Regs& R) {                       // (a plane behind the wave's share loads nothing: one instruction count on every path)
         const unsigned gb = (unsigned)(n_begin + wave + MF_WAVES * k) * gplane_b + chan_b;
 #pragma unroll
@@ -77,6 +81,7 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dwconv_mfma_wgrad_vwave_kernel(
             const unsigned a = (k < np && l_src[j] != VW_OOB) ? gb + l_src[j] : VW_OOB;
             R.a[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_dy, a, 0, 0);
             R.x[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, a, 0, 0);
+            if constexpr (PAIR) R.a2[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_d2, a, 0, 0);
         }
     };
     auto stage = [&](const Regs& R) {
@@ -85,6 +90,7 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dwconv_mfma_wgrad_vwave_kernel(
             if (l_src[j] != VW_OOB) {                               // (rows >= H of the image are never written: zero)
                 *(u32x4*)(L + l_dst[j]) = u32x4{R.a[j][0] & l_m[j][0], R.a[j][1] & l_m[j][1], R.a[j][2] & l_m[j][2], R.a[j][3] & l_m[j][3]};
                 *(u32x4*)(L + copy_b + l_dst[j]) = u32x4{R.x[j][0] & l_m[j][0], R.x[j][1] & l_m[j][1], R.x[j][2] & l_m[j][2], R.x[j][3] & l_m[j][3]};
+                if constexpr (PAIR) *(u32x4*)(L + 2 * copy_b + l_dst[j]) = u32x4{R.a2[j][0] & l_m[j][0], R.a2[j][1] & l_m[j][1], R.a2[j][2] & l_m[j][2], R.a2[j][3] & l_m[j][3]};
             }
         }
     };
@@ -92,11 +98,11 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dwconv_mfma_wgrad_vwave_kernel(
     load_plane(0, R0);
     load_plane(1, R1);
 
-    f32x16 acc[NG];
+    f32x16 acc[NG], acc2[PAIR ? NG : 1];
 #pragma unroll
     for (int g = 0; g < NG; ++g)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) acc[g][i] = 0.f;
+        for (int i = 0; i < 16; ++i) { acc[g][i] = 0.f; if constexpr (PAIR) acc2[g][i] = 0.f; }
 
     // ---- fragment addresses: lane -> image row (o resp. i), 8 consecutive k = columns 16*ks + 8*lhi .. +7 -------------------
     const unsigned a_off = 64u + (unsigned)l31 * PB + lhi * 16;               // dY copy
@@ -113,11 +119,18 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dwconv_mfma_wgrad_vwave_kernel(
             const unsigned xo = x_off + (unsigned)ks * 32;
             // (P of a row's first chunk is the pad chunk of the row above -- the 64 zero bytes for row 0 --, N of its last its own pad chunk)
             const u32x4 P = rdq(xo - 16), C = rdq(xo), N = rdq(xo + 16);
-            acc[0] = mfma32<T>(a, frag(P[3], C[0], C[1], C[2]), acc[0]);                                               // s = -2
-            acc[1] = mfma32<T>(a, frag(sh(C[0], P[3]), sh(C[1], C[0]), sh(C[2], C[1]), sh(C[3], C[2])), acc[1]);       // s = -1
-            acc[2] = mfma32<T>(a, __builtin_bit_cast(s16x8, C), acc[2]);                                               // s = 0
-            acc[3] = mfma32<T>(a, frag(sh(C[1], C[0]), sh(C[2], C[1]), sh(C[3], C[2]), sh(N[0], C[3])), acc[3]);       // s = +1
-            acc[4] = mfma32<T>(a, frag(C[1], C[2], C[3], N[0]), acc[4]);                                               // s = +2
+            const s16x8 b0 = frag(P[3], C[0], C[1], C[2]);                                                             // s = -2
+            const s16x8 b1 = frag(sh(C[0], P[3]), sh(C[1], C[0]), sh(C[2], C[1]), sh(C[3], C[2]));                     // s = -1
+            const s16x8 b2 = __builtin_bit_cast(s16x8, C);                                                             // s = 0
+            const s16x8 b3 = frag(sh(C[1], C[0]), sh(C[2], C[1]), sh(C[3], C[2]), sh(N[0], C[3]));                     // s = +1
+            const s16x8 b4 = frag(C[1], C[2], C[3], N[0]);                                                             // s = +2
+            acc[0] = mfma32<T>(a, b0, acc[0]); acc[1] = mfma32<T>(a, b1, acc[1]); acc[2] = mfma32<T>(a, b2, acc[2]);
+            acc[3] = mfma32<T>(a, b3, acc[3]); acc[4] = mfma32<T>(a, b4, acc[4]);
+            if constexpr (PAIR) {
+                const s16x8 a2 = __builtin_bit_cast(s16x8, rdq(a_off + 2 * copy_b + (unsigned)ks * 32));
+                acc2[0] = mfma32<T>(a2, b0, acc2[0]); acc2[1] = mfma32<T>(a2, b1, acc2[1]); acc2[2] = mfma32<T>(a2, b2, acc2[2]);
+                acc2[3] = mfma32<T>(a2, b3, acc2[3]); acc2[4] = mfma32<T>(a2, b4, acc2[4]);
+            }
         }
     };
     for (int k = 0; k < np; k += 2) {
@@ -136,25 +149,27 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dwconv_mfma_wgrad_vwave_kernel(
     const bool col_ok = l31 < p.H;
     const int o_max = p.H;
     float* wr = tile + (4 * lhi) * 64 + (l31 - 4 * lhi + 31);
-#pragma unroll
-    for (int g = 0; g < NG; ++g) {
-        if (col_ok) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                if ((r & 3) + 8 * (r >> 2) + 4 * lhi < o_max) wr[((r & 3) + 8 * (r >> 2)) * 63] = acc[g][r];
-        }
-        __builtin_amdgcn_wave_barrier();
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (lane < 63) {
-            float part[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int o = 0; o < 32; ++o) part[o & 3] += tile[o * 64 + lane];
-            const int tau = lane - 31 + p.padL;
-            if (tau >= 0 && tau < p.KL) mine[tau * p.kw + g] = (part[0] + part[1]) + (part[2] + part[3]);
-        }
-        __builtin_amdgcn_wave_barrier();
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    // (written out twice instead of a lambda over the accumulator array: taking its address costs registers in the plane loop)
+#define SLAK_VW_DIAG(AC, KL_, PADL_, OUT_)                                                                                             \
+    _Pragma("unroll") for (int g = 0; g < NG; ++g) {                                                                                   \
+        if (col_ok) {                                                                                                                  \
+            _Pragma("unroll") for (int r = 0; r < 16; ++r)                                                                             \
+                if ((r & 3) + 8 * (r >> 2) + 4 * lhi < o_max) wr[((r & 3) + 8 * (r >> 2)) * 63] = AC[g][r];                            \
+        }                                                                                                                              \
+        __builtin_amdgcn_wave_barrier();                                                                                               \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                                             \
+        if (lane < 63) {                                                                                                               \
+            float part[4] = {0.f, 0.f, 0.f, 0.f};                                                                                      \
+            _Pragma("unroll") for (int o = 0; o < 32; ++o) part[o & 3] += tile[o * 64 + lane];                                         \
+            const int tau = lane - 31 + (PADL_);                                                                                       \
+            if (tau >= 0 && tau < (KL_)) (OUT_)[tau * MF_TAPS + g] = (part[0] + part[1]) + (part[2] + part[3]);                        \
+        }                                                                                                                              \
+        __builtin_amdgcn_wave_barrier();                                                                                               \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                                             \
     }
+    SLAK_VW_DIAG(acc, p.KL, p.padL, mine)
+    if constexpr (PAIR) { SLAK_VW_DIAG(acc2, MF_TAPS, MF_TAPS / 2, mine + ntap1) }      // (every tile entry is rewritten by each tap: no re-zeroing)
+#undef SLAK_VW_DIAG
     __syncthreads();
     for (int t = tid; t < ntap; t += MF_THREADS) {
         float s = dwl[t];
@@ -162,7 +177,7 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dwconv_mfma_wgrad_vwave_kernel(
         for (int w = 1; w < MF_WAVES; ++w) s += dwl[w * ntap + t];
         wgrad_store_partial(&p.partial[((size_t)slice * p.C + c) * ntap + t], s);
     }
-    wgrad_finish(p.partial, p.dw, p.counters + c, (int*)lds, p.slices, p.C, c, 1, ntap, tid, MF_THREADS);
+    wgrad_finish(p.partial, p.dw, p.counters + c, (int*)lds, p.slices, p.C, c, 1, ntap, tid, MF_THREADS, PAIR ? p.dw2 : nullptr, ntap1);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -179,7 +194,7 @@ static bool fill_vwave_params(WgradWaveParams& p, const ConvDims& d, int residen
     p.CPR = p.DC + 1; if (!(p.CPR & 1)) ++p.CPR;                      // odd: conflict-free row-per-lane 16-byte reads
     p.KS = (d.W + 15) / 16;
     if (32 * p.DC > 64 * VW_MAXJ) return false;
-    if (2u * 32u * (unsigned)p.CPR * 16u > 32u * 64u * 4u) return false;                // the two copies fit the wave's slot
+    if (3u * 32u * (unsigned)p.CPR * 16u > 32u * 64u * 4u) return false;                // the (up to) three copies fit the wave's slot
     int slices = resident_wgs / d.C; if (slices < 1) slices = 1;
     int per = (d.N + slices - 1) / slices; per = (per + MF_WAVES - 1) / MF_WAVES * MF_WAVES;      // whole rounds of the four waves
     if (per < 2 * MF_WAVES) per = 2 * MF_WAVES;
@@ -187,7 +202,7 @@ static bool fill_vwave_params(WgradWaveParams& p, const ConvDims& d, int residen
     p.tensor_bytes = (unsigned)((size_t)d.N * d.C * d.H * d.W * 2);
     return (size_t)d.N * d.C * d.H * d.W * 2 < 0x80000000ull;
 }
-static size_t vwave_lds_bytes(const WgradWaveParams& p) { return (size_t)MF_WAVES * (64 + 32 * 64 * 4) + (size_t)MF_WAVES * p.kh * p.kw * 4 + 32; }
+static size_t vwave_lds_bytes(const WgradWaveParams& p) { return (size_t)MF_WAVES * (64 + 32 * 64 * 4) + (size_t)MF_WAVES * (p.kh * p.kw + MF_TAPS * MF_TAPS) * 4 + 32; }
 
 bool dwconv_mfma_wgrad_vwave_supported(const ConvDims& d, int dy_dt, int x_dt) {
     if (!vwave_enabled() || dy_dt != x_dt || (x_dt != SLAK_BF16 && x_dt != SLAK_F16)) return false;
@@ -196,31 +211,33 @@ bool dwconv_mfma_wgrad_vwave_supported(const ConvDims& d, int dy_dt, int x_dt) {
 }
 
 size_t dwconv_mfma_wgrad_vwave_workspace(const ConvDims& d) {
-    return align_up((size_t)((d.N + 2 * MF_WAVES - 1) / (2 * MF_WAVES) + 1) * d.C * d.kh * d.kw * sizeof(float), 256);     // slices <= ceil(N / 8)
+    return align_up((size_t)((d.N + 2 * MF_WAVES - 1) / (2 * MF_WAVES) + 1) * d.C * (d.kh * d.kw + MF_TAPS * MF_TAPS) * sizeof(float), 256);     // slices <= ceil(N / 8); PAIR records
 }
 
-template <typename T>
+template <typename T, bool PAIR>
 static int launch_vwave_t(WgradWaveParams& p, const ConvDims& d, size_t ws_bytes, hipStream_t st) {
-    auto k = dwconv_mfma_wgrad_vwave_kernel<T>;
-    static const int wgs_per_cu = [] { const char* e = getenv("SLAK_VWAVE_WGS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 3; }();
+    auto k = dwconv_mfma_wgrad_vwave_kernel<T, PAIR>;
+    static const int wgs_per_cu = [] { const char* e = getenv("SLAK_VWAVE_WGS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 2; }();
     fill_vwave_params(p, d, wgs_per_cu * mfma_cu_count());
     const size_t lds = vwave_lds_bytes(p);
     if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if ((size_t)p.slices * d.C * d.kh * d.kw * sizeof(float) > ws_bytes) return SLAK_ERR_WORKSPACE;
+    if ((size_t)p.slices * d.C * (d.kh * d.kw + (PAIR ? MF_TAPS * MF_TAPS : 0)) * sizeof(float) > ws_bytes) return SLAK_ERR_WORKSPACE;
     hipLaunchKernelGGL(k, dim3((unsigned)(p.C * p.slices)), dim3(MF_THREADS), lds, st, p);
     SLAK_LAUNCH_CHECK();
     return SLAK_OK;
 }
 
+// dy2 / dw2 != nullptr: the 5 x 5 branch's weight gradient in the same launch
 int launch_dwconv_mfma_wgrad_vwave(const void* dy, int dy_dt, const void* x, int x_dt, float* dw,
-                                   const ConvDims& d, void* ws, size_t ws_bytes, hipStream_t st) {
+                                   const ConvDims& d, void* ws, size_t ws_bytes, hipStream_t st, const void* dy2, float* dw2) {
     if (!dwconv_mfma_wgrad_vwave_supported(d, dy_dt, x_dt)) return SLAK_ERR_UNSUPPORTED;
     if (ws == nullptr) return SLAK_ERR_WORKSPACE;
     WgradWaveParams p;
-    p.dy = dy; p.x = x; p.partial = (float*)ws; p.dw = dw;
+    p.dy = dy; p.x = x; p.partial = (float*)ws; p.dw = dw; p.dy2 = dy2; p.dw2 = dw2;
     p.counters = wgrad_arrival_counters(d.C);
     if (!p.counters) return SLAK_ERR_UNSUPPORTED;
-    return x_dt == SLAK_BF16 ? launch_vwave_t<bf16_t>(p, d, ws_bytes, st) : launch_vwave_t<f16_t>(p, d, ws_bytes, st);
+    if (dy2 && dw2) return x_dt == SLAK_BF16 ? launch_vwave_t<bf16_t, true>(p, d, ws_bytes, st) : launch_vwave_t<f16_t, true>(p, d, ws_bytes, st);
+    return x_dt == SLAK_BF16 ? launch_vwave_t<bf16_t, false>(p, d, ws_bytes, st) : launch_vwave_t<f16_t, false>(p, d, ws_bytes, st);
 }
 
 }  // namespace slak

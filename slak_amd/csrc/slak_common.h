@@ -104,11 +104,11 @@ int launch_dwconv_mfma_tri(bool dgrad, const void* const* in, void* const* out, 
 bool dwconv_mfma_wgrad_vwave_supported(const ConvDims& d, int dy_dt, int x_dt);
 size_t dwconv_mfma_wgrad_vwave_workspace(const ConvDims& d);
 int launch_dwconv_mfma_wgrad_vwave(const void* dy, int dy_dt, const void* x, int x_dt, float* dw,
-                                   const ConvDims& d, void* ws, size_t ws_bytes, hipStream_t st);
+                                   const ConvDims& d, void* ws, size_t ws_bytes, hipStream_t st, const void* dy2 = nullptr, float* dw2 = nullptr);
 bool dwconv_mfma_wgrad_vrows_supported(const ConvDims& d, int dy_dt, int x_dt);
 size_t dwconv_mfma_wgrad_vrows_workspace(const ConvDims& d);
 int launch_dwconv_mfma_wgrad_vrows(const void* dy, int dy_dt, const void* x, int x_dt, float* dw,
-                                   const ConvDims& d, void* ws, size_t ws_bytes, hipStream_t st);
+                                   const ConvDims& d, void* ws, size_t ws_bytes, hipStream_t st, const void* dy2 = nullptr, float* dw2 = nullptr);
 bool dwconv_mfma_small_wgrad_dma_supported(const ConvDims& d, int dy_dt, int x_dt);
 size_t dwconv_mfma_small_wgrad_dma_workspace(const ConvDims& d);
 int launch_dwconv_mfma_small_wgrad_dma(const void* dy, int dy_dt, const void* x, int x_dt, float* dw,
@@ -140,8 +140,10 @@ unsigned* wgrad_arrival_counters(int ngroups);      // host; nullptr -> use laun
 // so "arriving" needs no L2 write-back -- an agent-scope release fence costs a whole-L2 flush per workgroup on gfx942/gfx950
 // (measured: 18 -> 107 us for the 14x14 weight gradient).
 __device__ __forceinline__ void wgrad_store_partial(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// dw2 != nullptr: a channel's record of ntap floats holds TWO filters back to back (ntap1 taps of dw, then ntap - ntap1 of dw2)
 __device__ __forceinline__ void wgrad_finish(const float* partial, float* dw, unsigned* counter, int* lds_flag,
-                                             int nslices, int C, int c0, int nch, int ntap, int tid, int nthreads) {
+                                             int nslices, int C, int c0, int nch, int ntap, int tid, int nthreads,
+                                             float* dw2 = nullptr, int ntap1 = 0) {
     // Hand-off form "sc1 payload -> vmcnt(0) -> agent atomic flag; consumer: sc1 (agent-scope) loads" of MI355X_MICROARCH.md
     // (inter-workgroup visibility, valid forms): the partials were written through to the device coherence point (agent-scope atomic
     // stores), the explicit s_waitcnt below makes this wave's stores acknowledged before it can reach the barrier (inline asm: the
@@ -174,7 +176,11 @@ __device__ __forceinline__ void wgrad_finish(const float* partial, float* dw, un
 #pragma unroll
             for (int j = 0; j < 8; ++j) s += v[j];
         }
-        dw[(size_t)c0 * ntap + t] = s;
+        if (dw2 == nullptr) dw[(size_t)c0 * ntap + t] = s;
+        else {
+            const int ch = t / ntap, e = t - ch * ntap;
+            if (e < ntap1) dw[(size_t)(c0 + ch) * ntap1 + e] = s; else dw2[(size_t)(c0 + ch) * (ntap - ntap1) + (e - ntap1)] = s;
+        }
     }
 }
 #endif

@@ -36,7 +36,7 @@ def ops_of(db, counter):
 def main():
     fetch_db, write_db = sys.argv[1], sys.argv[2]
     f, w = ops_of(fetch_db, "FETCH_SIZE"), ops_of(write_db, "WRITE_SIZE")
-    assert len(f) == len(w) == 4 * 3 * 3 * 3 + 2 * 2 * 3 + 2 * 3 * 3, (len(f), len(w))
+    assert len(f) == len(w) == 4 * 3 * 3 * 3 + 2 * 2 * 3 + 2 * 3 * 3 + 2 * 3, (len(f), len(w))
     out = {}
     i = 0
     print("%-28s %14s %14s %14s %14s %8s" % ("op", "alg bytes", "2*FETCH", "WRITE", "HBM bytes", "HBM/alg"))
@@ -82,6 +82,13 @@ def main():
                 vals[name].append((2.0 * f[i][1] * 1024, w[i][1] * 1024)); i += 1
         for name, v in vals.items():
             put("s%d_%dx5+5x%d+5x5_%s" % (si + 1, K, K, name), alg, v)
+    for si, (C, H, K) in enumerate(STAGES[:2]):                  # K x 5 + 5 x 5 weight gradients in one launch: priced at the two ops it replaces
+        S = 128 * C * H * H
+        v = []
+        for rep in range(3):
+            assert f[i][0] == "wgrad" and w[i][0] == "wgrad", (i, f[i], w[i])
+            v.append((2.0 * f[i][1] * 1024, w[i][1] * 1024)); i += 1
+        put("s%d_%dx5+5x5_bwd_filter" % (si + 1, K), 2 * 2 * S * 2 + C * (K * 5 + 25) * 4, v)
     assert i == len(f)
     path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "pmc_traffic.json")
     with open(path, "w") as fh:
