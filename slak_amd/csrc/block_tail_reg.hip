@@ -5,6 +5,7 @@
 // the lane's row is written / read with conflict-free ds_*_b128) to be moved as coalesced 16-byte pieces.  The kernels of
 // block_tail.hip stage BOTH sides in LDS and walk them with 2-byte LDS accesses in three passes: 0.17-0.34 of the HBM roofline.
 #include "slak_common.h"
+#include <stdlib.h>
 #include "mfma_common.h"
 
 namespace slak {
@@ -533,6 +534,10 @@ static int launch_sr_bwd_reg(const float* dout, const uint16_t* dout16, float* d
     return SLAK_OK;
 }
 
+static bool rt_wide_lanes() {                // SLAK_RT_WIDE=0: C = 384 keeps 48 channels per lane on 8 lanes per pixel pair (A/B testing)
+    static const bool v = [] { const char* e = getenv("SLAK_RT_WIDE"); return !(e && e[0] == '0'); }();
+    return v;
+}
 // The instantiations: (channels per lane, lanes per pixel) per channel count.  SLAK_ERR_UNSUPPORTED = none for this C (the caller
 // runs the LDS-tile kernels of block_tail.hip).
 #define SLAK_RT_DISPATCH(C, CALL)                 \
@@ -579,6 +584,9 @@ int launch_scale_residual_fwd_reg(const void* sc, int sc_dtype, const void* z, c
                                   int N, int C, int P, hipStream_t st) {
     if (sc_dtype == SLAK_F32) {
 #define CALL(CL, G) return launch_sr_fwd_reg<CL, G, float>((const float*)sc, (const uint16_t*)z, gamma, scale, out, (uint16_t*)out16, N, P, st)
+        // C = 384: 96 channels per lane on 4 lanes per pixel pair double the length of a wave's NCHW row segments (64 -> 128 bytes); the
+        // forward residual kernel is the one of the four whose registers allow it without spilling
+        if (C == 384 && !(P & 1) && rt_wide_lanes()) { CALL(96, 4); }
         SLAK_RT_DISPATCH(C, CALL)
 #undef CALL
     } else if (sc_dtype == SLAK_BF16) {
