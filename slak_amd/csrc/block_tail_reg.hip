@@ -381,6 +381,42 @@ __global__ __launch_bounds__(256, 2) void scale_residual_fwd_reg_kernel(const Ts
     }
 }
 
+// The same for SMALL planes (P <= 256: the 14 x 14 stage).  In the lane geometry above a wave covers 128 / G pixels -- 16 on C = 384 --, so
+// each of its channel-row accesses is a 64-byte run of the fp32 NCHW tensors that carry 10 of the kernel's 12 bytes per element (measured:
+// 3.2 TB/s against 5.7 on the 56 x 56 stage).  Here a wave takes CW channels of ONE image over 64 pixel pairs: a channel row is read and
+// written as one 512-byte run (256 for the bf16 copy), and the lane fetches the CW channels of its two pixels of z as 16-byte pieces
+// straight into registers (no LDS tile, no barrier).  Same arithmetic, same rounding.
+template <int CW>
+__global__ __launch_bounds__(256) void scale_residual_fwd_chan_kernel(const float* __restrict__ sc, const uint16_t* __restrict__ z,
+                                                                      const float* __restrict__ gamma, const float* __restrict__ scale,
+                                                                      float* __restrict__ out, uint16_t* __restrict__ out16,
+                                                                      int C, int P, int rounds, int nunits) {
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int unit = blockIdx.x * 4 + wave;                       // (image, channel group, round of 64 pixel pairs)
+    if (unit >= nunits) return;
+    const int groups = C / CW;
+    const int rd = unit % rounds, t = unit / rounds, cg = t % groups, n = t / groups;
+    const int pair = rd * 64 + lane;
+    if (2 * pair >= P) return;                                    // (no barrier in the kernel: lanes may leave)
+    const float sn = scale ? scale[n] : 1.0f;
+    const uint16_t* zp = z + ((size_t)n * P + 2 * pair) * C + cg * CW;
+    rt_u32x4 za[CW / 8], zb[CW / 8];
+#pragma unroll
+    for (int j = 0; j < CW / 8; ++j) { za[j] = *(const rt_u32x4*)(zp + j * 8); zb[j] = *(const rt_u32x4*)(zp + C + j * 8); }
+    const size_t row0 = ((size_t)n * C + cg * CW) * P + 2 * pair;
+    float sx[CW], sy[CW];
+#pragma unroll
+    for (int c = 0; c < CW; ++c) { const float2 v = *(const float2*)(sc + row0 + (size_t)c * P); sx[c] = v.x; sy[c] = v.y; }
+    const float* gp = gamma + cg * CW;
+#pragma unroll
+    for (int c = 0; c < CW; ++c) {
+        const float gm = gp[c] * sn;                              // (wave-uniform: a scalar load)
+        const float ox = sx[c] + gm * RT_CH(za[c >> 3], c & 7), oy = sy[c] + gm * RT_CH(zb[c >> 3], c & 7);
+        *(float2*)(out + row0 + (size_t)c * P) = float2{ox, oy};
+        if (out16) *(unsigned*)(out16 + row0 + (size_t)c * P) = rt_pack2(ox, oy);
+    }
+}
+
 // dz[n,p,c] (bf16 NHWC) = scale[n] * gamma[c] * d[n,c,p], d = dout (fp32 NCHW) [+ dout16 (bf16 NCHW), the sum written to dsum];
 // part[wave][0..C) = sum scale * d * z, [C..2C) = gamma * sum scale * d.  Persistent waves; z and dz share the wave's LDS tile.
 template <int CL, int G>
@@ -465,6 +501,82 @@ __global__ __launch_bounds__(256, 2) void scale_residual_bwd_reg_kernel(const fl
     rt_write_partials<CL, G>(accg, accs, part + (size_t)blockIdx.x * 2 * C, (float*)smem, wave, lane, [gamma](float a, int c) { return a * gamma[c]; });
 }
 
+// The backward residual step for SMALL planes, a wave per (image, CW channels, 64 pixel pairs) like scale_residual_fwd_chan_kernel: the
+// fp32 gradient rows (10 of the 14 bytes per element with the bf16 second stream and the summed output) move as 512-byte runs, z and dz
+// as 16-byte pieces from / to registers.  The wave holds ALL of its channels' pixels of the round, so the per-channel sums are one fold
+// over the wave (rt_fold4 + four shuffles) and land in row (image, round) of the partial matrix: columns of the wave's channels only.
+template <int CW>
+__global__ __launch_bounds__(256) void scale_residual_bwd_chan_kernel(const float* __restrict__ dout, const uint16_t* __restrict__ dout16,
+                                                                      float* __restrict__ dsum, const uint16_t* __restrict__ z,
+                                                                      const float* __restrict__ gamma, const float* __restrict__ scale,
+                                                                      uint16_t* __restrict__ dz, float* __restrict__ part,
+                                                                      int C, int P, int rounds, int nunits) {
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int unit = blockIdx.x * 4 + wave;                       // (image, channel group, round of 64 pixel pairs)
+    if (unit >= nunits) return;                                   // (no workgroup barrier in the kernel)
+    const int groups = C / CW;
+    const int rd = unit % rounds, t = unit / rounds, cg = t % groups, n = t / groups;
+    const int pair = rd * 64 + lane;
+    const bool valid = 2 * pair < P;
+    const float sn = scale ? scale[n] : 1.0f;
+    const size_t zoff = ((size_t)n * P + 2 * pair) * C + cg * CW;
+    const size_t row0 = ((size_t)n * C + cg * CW) * P + 2 * pair;
+    rt_u32x4 za[CW / 8], zb[CW / 8];
+    float vx[CW], vy[CW];
+    if (valid) {
+#pragma unroll
+        for (int j = 0; j < CW / 8; ++j) { za[j] = *(const rt_u32x4*)(z + zoff + j * 8); zb[j] = *(const rt_u32x4*)(z + zoff + C + j * 8); }
+#pragma unroll
+        for (int c = 0; c < CW; ++c) { const float2 v = *(const float2*)(dout + row0 + (size_t)c * P); vx[c] = v.x; vy[c] = v.y; }
+        if (dout16) {
+#pragma unroll
+            for (int c = 0; c < CW; ++c) {
+                const unsigned h = *(const unsigned*)(dout16 + row0 + (size_t)c * P);
+                vx[c] += rt_lo(h); vy[c] += rt_hi(h);
+                *(float2*)(dsum + row0 + (size_t)c * P) = float2{vx[c], vy[c]};
+            }
+        }
+    } else {                                                       // lanes past the image contribute zeros to the sums
+#pragma unroll
+        for (int j = 0; j < CW / 8; ++j) { za[j] = rt_u32x4{0u, 0u, 0u, 0u}; zb[j] = za[j]; }
+#pragma unroll
+        for (int c = 0; c < CW; ++c) { vx[c] = 0.f; vy[c] = 0.f; }
+    }
+    const float* gp = gamma + cg * CW;
+    float accg[CW / 4], accs[CW / 4];
+#pragma unroll
+    for (int j = 0; j < CW / 8; ++j) {
+        float d0[8], d1[8], tg[8], ts[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int c = j * 8 + k;
+            d0[k] = vx[c] * sn; d1[k] = vy[c] * sn;
+            tg[k] = d0[k] * RT_CH(za[j], k) + d1[k] * RT_CH(zb[j], k);
+            ts[k] = d0[k] + d1[k];
+        }
+        rt_u32x4 oa, ob;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float g0 = gp[j * 8 + 2 * k], g1 = gp[j * 8 + 2 * k + 1];       // (wave-uniform: scalar loads)
+            oa[k] = rt_pack2(g0 * d0[2 * k], g1 * d0[2 * k + 1]);
+            ob[k] = rt_pack2(g0 * d1[2 * k], g1 * d1[2 * k + 1]);
+        }
+        if (valid) { *(rt_u32x4*)(dz + zoff + j * 8) = oa; *(rt_u32x4*)(dz + zoff + C + j * 8) = ob; }
+        accg[2 * j] = rt_fold4(tg[0], tg[1], tg[2], tg[3]); accg[2 * j + 1] = rt_fold4(tg[4], tg[5], tg[6], tg[7]);
+        accs[2 * j] = rt_fold4(ts[0], ts[1], ts[2], ts[3]); accs[2 * j + 1] = rt_fold4(ts[4], ts[5], ts[6], ts[7]);
+    }
+    // 16-lane row r of the wave holds channel 4m + {0,2,1,3}[r]: finish over the row's lanes, lane 0 of the row writes
+    const int rowi = lane >> 4, cofs = rowi == 0 ? 0 : rowi == 1 ? 2 : rowi == 2 ? 1 : 3;
+    float* const prow = part + (size_t)(n * rounds + rd) * 2 * C + cg * CW;
+#pragma unroll
+    for (int m = 0; m < CW / 4; ++m) {
+        float a = accg[m], b = accs[m];
+#pragma unroll
+        for (int k = 1; k < 16; k <<= 1) { a += __shfl_xor(a, k, 64); b += __shfl_xor(b, k, 64); }
+        if ((lane & 15) == 0) { const int c = 4 * m + cofs; prow[c] = a; prow[C + c] = b * gp[c]; }
+    }
+}
+
 // ---- host side ---------------------------------------------------------------------------------------------------------------
 template <typename K> static int rt_persistent_grid(K k, size_t lds, int ntiles) {
     static thread_local int per_cu = 0, cus = 0;                       // one (kernel, lds) pair per instantiation of this template
@@ -534,6 +646,27 @@ static int launch_sr_bwd_reg(const float* dout, const uint16_t* dout16, float* d
     return SLAK_OK;
 }
 
+static bool rt_chan_waves() {                // SLAK_RT_CHAN=0: small planes keep the pixel-tile residual kernel (A/B testing)
+    static const bool v = [] { const char* e = getenv("SLAK_RT_CHAN"); return !(e && e[0] == '0'); }();
+    return v;
+}
+template <int CW>
+static int launch_sr_fwd_chan(const float* sc, const uint16_t* z, const float* gamma, const float* scale, float* out, uint16_t* out16, int N, int C, int P, hipStream_t st) {
+    const int rounds = (P / 2 + 63) / 64, nunits = N * (C / CW) * rounds;
+    hipLaunchKernelGGL(scale_residual_fwd_chan_kernel<CW>, dim3((unsigned)((nunits + 3) / 4)), dim3(256), 0, st, sc, z, gamma, scale, out, out16, C, P, rounds, nunits);
+    SLAK_LAUNCH_CHECK();
+    return SLAK_OK;
+}
+template <int CW>
+static int launch_sr_bwd_chan(const float* dout, const uint16_t* dout16, float* dsum, const uint16_t* z, const float* gamma, const float* scale,
+                              uint16_t* dz, float* part, int* rows, int N, int C, int P, hipStream_t st) {
+    const int rounds = (P / 2 + 63) / 64, nunits = N * (C / CW) * rounds;
+    hipLaunchKernelGGL(scale_residual_bwd_chan_kernel<CW>, dim3((unsigned)((nunits + 3) / 4)), dim3(256), 0, st, dout, dout16, dsum, z, gamma, scale, dz, part,
+                       C, P, rounds, nunits);
+    SLAK_LAUNCH_CHECK();
+    *rows = N * rounds;
+    return SLAK_OK;
+}
 static bool rt_wide_lanes() {                // SLAK_RT_WIDE=0: C = 384 keeps 48 channels per lane on 8 lanes per pixel pair (A/B testing)
     static const bool v = [] { const char* e = getenv("SLAK_RT_WIDE"); return !(e && e[0] == '0'); }();
     return v;
@@ -586,6 +719,10 @@ int launch_scale_residual_fwd_reg(const void* sc, int sc_dtype, const void* z, c
 #define CALL(CL, G) return launch_sr_fwd_reg<CL, G, float>((const float*)sc, (const uint16_t*)z, gamma, scale, out, (uint16_t*)out16, N, P, st)
         // C = 384: 96 channels per lane on 4 lanes per pixel pair double the length of a wave's NCHW row segments (64 -> 128 bytes); the
         // forward residual kernel is the one of the four whose registers allow it without spilling
+        if (!(P & 1) && P <= 256 && rt_chan_waves()) {              // small planes: a wave per (image, channel group)
+            if (C % 48 == 0) return launch_sr_fwd_chan<48>((const float*)sc, (const uint16_t*)z, gamma, scale, out, (uint16_t*)out16, N, C, P, st);
+            if (C % 64 == 0) return launch_sr_fwd_chan<64>((const float*)sc, (const uint16_t*)z, gamma, scale, out, (uint16_t*)out16, N, C, P, st);
+        }
         if (C == 384 && !(P & 1) && rt_wide_lanes()) { CALL(96, 4); }
         SLAK_RT_DISPATCH(C, CALL)
 #undef CALL
@@ -598,6 +735,10 @@ int launch_scale_residual_fwd_reg(const void* sc, int sc_dtype, const void* z, c
 }
 int launch_scale_residual_bwd_reg(const float* dout, const void* dout16, float* dsum, const void* z, const float* gamma, const float* scale, void* dz,
                                   float* part, int* rows, int N, int C, int P, hipStream_t st) {
+    if (!(P & 1) && P <= 256 && (long long)N * ((P / 2 + 63) / 64) <= 8192 && rt_chan_waves()) {     // small planes: a wave per (image, channel group); rows <= the workspace's 8192
+        if (C % 24 == 0) return launch_sr_bwd_chan<24>(dout, (const uint16_t*)dout16, dsum, (const uint16_t*)z, gamma, scale, (uint16_t*)dz, part, rows, N, C, P, st);
+        if (C % 32 == 0) return launch_sr_bwd_chan<32>(dout, (const uint16_t*)dout16, dsum, (const uint16_t*)z, gamma, scale, (uint16_t*)dz, part, rows, N, C, P, st);
+    }
 #define CALL(CL, G) return launch_sr_bwd_reg<CL, G>(dout, (const uint16_t*)dout16, dsum, (const uint16_t*)z, gamma, scale, (uint16_t*)dz, part, rows, N, P, st)
     SLAK_RT_DISPATCH(C, CALL)
 #undef CALL

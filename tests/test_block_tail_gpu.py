@@ -9,7 +9,10 @@ import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
 
-SHAPES = [(3, 96, 56, 56), (5, 192, 28, 28), (4, 384, 14, 14), (7, 768, 7, 7), (2, 64, 9, 11), (1, 130, 5, 3), (2, 256, 20, 20)]
+SHAPES = [(3, 96, 56, 56), (5, 192, 28, 28), (4, 384, 14, 14), (7, 768, 7, 7), (2, 64, 9, 11), (1, 130, 5, 3), (2, 256, 20, 20),
+          # small planes: the residual kernels that give a wave (image, channel group, 64 pixel pairs) -- SLaK-B's 512 channels, a partly
+          # filled round, exactly two rounds
+          (3, 512, 14, 14), (2, 48, 4, 6), (2, 96, 16, 16)]
 
 
 def _close(a, b, rel, what):
@@ -67,6 +70,32 @@ def test_scale_residual_matches_torch(N, C, H, W, sc_dtype, with_scale, gpu):
     sc2 = sc.detach().clone().requires_grad_(True); z2 = z.detach().clone().requires_grad_(True); g2 = gamma.detach().clone().requires_grad_(True)
     block_ops.scale_residual(sc2, z2, g2, scale).backward(dout)
     assert torch.equal(g2.grad, gamma.grad)
+
+
+@pytest.mark.parametrize("N,C,H,W", [(4, 384, 14, 14), (3, 512, 14, 14), (2, 96, 16, 16), (5, 192, 28, 28)])
+def test_scale_residual_with_bf16_copy_and_second_gradient_stream(N, C, H, W, gpu):
+    """What a training step runs between two blocks: the forward also writes the bf16 copy of its output, the backward adds the gradient
+    of that copy (bf16) to the fp32 one and returns the sum as the shortcut gradient (block_ops._scale_residual_fwd / _bwd)."""
+    from slak_amd import block_ops
+    torch.manual_seed(C + H)
+    sc = torch.randn(N, C, H, W, device=gpu); z = torch.randn(N, H, W, C, device=gpu).bfloat16(); gamma = torch.randn(C, device=gpu) * 0.3
+    scale = (torch.rand(N, device=gpu) > 0.3).float() / 0.7
+    dout = torch.randn(N, C, H, W, device=gpu); d16 = torch.randn(N, C, H, W, device=gpu).bfloat16()
+    with torch.no_grad():
+        r = block_ops._scale_residual_fwd(sc, z, gamma, scale, True)
+        out, out16 = r[0], r[1]
+        ref = sc.double() + (gamma.double() * z.double()).permute(0, 3, 1, 2) * scale.double().view(N, 1, 1, 1)
+        _close(out, ref, 1e-6, "out")
+        assert torch.equal(out16, out.bfloat16())
+        b = block_ops._scale_residual_bwd(z, gamma, scale, sc.dtype, dout, d16)
+    d = dout.double() + d16.double()
+    dsum, dz, dgamma, dzc = b
+    _close(dsum, d, 1e-6, "dshortcut")
+    ds = d * scale.double().view(N, 1, 1, 1)
+    dz_ref = (ds * gamma.double().view(1, C, 1, 1)).permute(0, 2, 3, 1)
+    _close(dz, dz_ref, 2.0 ** -8 * 1.01, "dz")
+    _close(dgamma, (ds.permute(0, 2, 3, 1) * z.double()).sum((0, 1, 2)), 1e-4, "dgamma")
+    _close(dzc, dz_ref.sum((0, 1, 2)), 1e-4, "column sums of dz")
 
 
 def test_block_with_fused_tail_matches_reference_composition(gpu):

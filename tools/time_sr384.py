@@ -17,4 +17,4 @@ with torch.no_grad():
     for _ in range(50): run()
     e1.record(); torch.cuda.synchronize()
     us = e0.elapsed_time(e1) / 50 * 1e3
-    print("wide=%s sr fwd C384 14x14: %.1f us  (%.2f TB/s of 12 B/el, host overhead included)" % (os.environ.get("SLAK_RT_WIDE", "1"), us, N * C * H * H * 12 / us / 1e6))
+    print("chan=%s wide=%s sr fwd C384 14x14: %.1f us  (%.2f TB/s of 12 B/el, host overhead included)" % (os.environ.get("SLAK_RT_CHAN", "1"), os.environ.get("SLAK_RT_WIDE", "1"), us, N * C * H * H * 12 / us / 1e6))
