@@ -577,6 +577,130 @@ __global__ __launch_bounds__(256) void scale_residual_bwd_chan_kernel(const floa
     }
 }
 
+// LayerNorm forward / backward for SMALL planes in the same mapping: a WORKGROUP per (image, 64 pixel pairs) with one wave per group of
+// CW channels (<= 8 waves), so the bf16 NCHW rows move as 256-byte runs; the per-pixel statistics over C are the sum of the waves'
+// partials through LDS (one workgroup barrier per statistic), the per-channel sums of the backward one fold over the wave.
+template <int CW>
+__global__ __launch_bounds__(512) void ln_nchw_to_nhwc_fwd_chan_kernel(const uint16_t* __restrict__ x, const float* __restrict__ w, const float* __restrict__ b,
+                                                                       uint16_t* __restrict__ y, float* __restrict__ mean, float* __restrict__ rstd,
+                                                                       int C, int P, int rounds, float eps) {
+    __shared__ float2 red[2][8][64];
+    const int lane = threadIdx.x & 63, cg = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), nw = (int)(blockDim.x >> 6);
+    const int rd = blockIdx.x % rounds, n = blockIdx.x / rounds;
+    const int pair = rd * 64 + lane;
+    const bool valid = 2 * pair < P;
+    const size_t row0 = ((size_t)n * C + cg * CW) * P + 2 * pair, yoff = ((size_t)n * P + 2 * pair) * C + cg * CW;
+    unsigned v[CW];                                               // (pixel p, pixel p+1) of channel c
+#pragma unroll
+    for (int c = 0; c < CW; ++c) v[c] = valid ? *(const unsigned*)(x + row0 + (size_t)c * P) : 0u;
+    float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+    for (int c = 0; c < CW; ++c) { s0 += rt_lo(v[c]); s1 += rt_hi(v[c]); }
+    // (each pass unpacks from the PACKED registers again: otherwise the compiler keeps the unpacked fp32 values of a pass alive)
+#pragma unroll
+    for (int c = 0; c < CW; ++c) asm volatile("" : "+v"(v[c]));
+    red[0][cg][lane] = float2{s0, s1};
+    __syncthreads();
+    float t0 = 0.f, t1 = 0.f;
+    for (int k = 0; k < nw; ++k) { const float2 q = red[0][k][lane]; t0 += q.x; t1 += q.y; }
+    const float mu0 = t0 / (float)C, mu1 = t1 / (float)C;
+    float q0 = 0.f, q1 = 0.f;
+#pragma unroll
+    for (int c = 0; c < CW; ++c) { const float a = rt_lo(v[c]) - mu0, d = rt_hi(v[c]) - mu1; q0 += a * a; q1 += d * d; }
+#pragma unroll
+    for (int c = 0; c < CW; ++c) asm volatile("" : "+v"(v[c]));
+    red[1][cg][lane] = float2{q0, q1};
+    __syncthreads();
+    t0 = 0.f; t1 = 0.f;
+    for (int k = 0; k < nw; ++k) { const float2 q = red[1][k][lane]; t0 += q.x; t1 += q.y; }
+    const float r0 = 1.0f / sqrtf(t0 / (float)C + eps), r1 = 1.0f / sqrtf(t1 / (float)C + eps);
+    if (!valid) return;
+    if (cg == 0) { *(float2*)(mean + (size_t)n * P + 2 * pair) = float2{mu0, mu1}; *(float2*)(rstd + (size_t)n * P + 2 * pair) = float2{r0, r1}; }
+    const float* wp = w + cg * CW; const float* bp = b + cg * CW;  // (wave-uniform: scalar loads)
+#pragma unroll
+    for (int j = 0; j < CW / 8; ++j) {
+        rt_u32x4 oa, ob;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int c = j * 8 + 2 * k;
+            const float w0 = wp[c], w1 = wp[c + 1], b0 = bp[c], b1 = bp[c + 1];
+            oa[k] = rt_pack2((rt_lo(v[c]) - mu0) * r0 * w0 + b0, (rt_lo(v[c + 1]) - mu0) * r0 * w1 + b1);
+            ob[k] = rt_pack2((rt_hi(v[c]) - mu1) * r1 * w0 + b0, (rt_hi(v[c + 1]) - mu1) * r1 * w1 + b1);
+        }
+        *(rt_u32x4*)(y + yoff + j * 8) = oa; *(rt_u32x4*)(y + yoff + C + j * 8) = ob;
+    }
+}
+
+template <int CW>
+__global__ __launch_bounds__(512) void ln_nchw_to_nhwc_bwd_chan_kernel(const uint16_t* __restrict__ gy, const uint16_t* __restrict__ x, const float* __restrict__ w,
+                                                                       const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                                       uint16_t* __restrict__ dx, float* __restrict__ part, int C, int P, int rounds) {
+    __shared__ float4 red[8][64];
+    const int lane = threadIdx.x & 63, cg = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), nw = (int)(blockDim.x >> 6);
+    const int rd = blockIdx.x % rounds, n = blockIdx.x / rounds;
+    const int pair = rd * 64 + lane;
+    const bool valid = 2 * pair < P;
+    const size_t row0 = ((size_t)n * C + cg * CW) * P + 2 * pair, goff = ((size_t)n * P + 2 * pair) * C + cg * CW;
+    unsigned xv[CW];
+    rt_u32x4 ga[CW / 8], gb[CW / 8];
+    float mu0 = 0.f, mu1 = 0.f, r0 = 0.f, r1 = 0.f;
+    if (valid) {
+#pragma unroll
+        for (int j = 0; j < CW / 8; ++j) { ga[j] = *(const rt_u32x4*)(gy + goff + j * 8); gb[j] = *(const rt_u32x4*)(gy + goff + C + j * 8); }
+#pragma unroll
+        for (int c = 0; c < CW; ++c) xv[c] = *(const unsigned*)(x + row0 + (size_t)c * P);
+        const float2 m2 = *(const float2*)(mean + (size_t)n * P + 2 * pair), s2 = *(const float2*)(rstd + (size_t)n * P + 2 * pair);
+        mu0 = m2.x; mu1 = m2.y; r0 = s2.x; r1 = s2.y;
+    } else {                                                       // lanes past the image contribute zeros everywhere
+#pragma unroll
+        for (int j = 0; j < CW / 8; ++j) { ga[j] = rt_u32x4{0u, 0u, 0u, 0u}; gb[j] = ga[j]; }
+#pragma unroll
+        for (int c = 0; c < CW; ++c) xv[c] = 0u;
+    }
+    const float* wp = w + cg * CW;                                 // (wave-uniform: scalar loads)
+    float s10 = 0.f, s11 = 0.f, s20 = 0.f, s21 = 0.f;
+#pragma unroll
+    for (int c = 0; c < CW; ++c) {
+        const float gw0 = RT_CH(ga[c >> 3], c & 7) * wp[c], gw1 = RT_CH(gb[c >> 3], c & 7) * wp[c];
+        s10 += gw0; s11 += gw1;
+        s20 += gw0 * ((rt_lo(xv[c]) - mu0) * r0); s21 += gw1 * ((rt_hi(xv[c]) - mu1) * r1);
+    }
+#pragma unroll
+    for (int c = 0; c < CW; ++c) asm volatile("" : "+v"(xv[c]));
+#pragma unroll
+    for (int j = 0; j < CW / 8; ++j) { asm volatile("" : "+v"(ga[j])); asm volatile("" : "+v"(gb[j])); }
+    red[cg][lane] = float4{s10, s11, s20, s21};
+    __syncthreads();
+    float4 t = float4{0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < nw; ++k) { const float4 q = red[k][lane]; t.x += q.x; t.y += q.y; t.z += q.z; t.w += q.w; }
+    const float m10 = t.x / (float)C, m11 = t.y / (float)C, m20 = t.z / (float)C, m21 = t.w / (float)C;
+    float accw[CW / 4], accb[CW / 4];
+#pragma unroll
+    for (int j = 0; j < CW / 8; ++j) {
+        float tw[8], ts[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int c = j * 8 + k;
+            const float wc = wp[c];
+            const float g0 = RT_CH(ga[j], k), g1 = RT_CH(gb[j], k);
+            const float xh0 = (rt_lo(xv[c]) - mu0) * r0, xh1 = (rt_hi(xv[c]) - mu1) * r1;
+            if (valid) *(unsigned*)(dx + row0 + (size_t)c * P) = rt_pack2(r0 * (g0 * wc - m10 - xh0 * m20), r1 * (g1 * wc - m11 - xh1 * m21));
+            tw[k] = g0 * xh0 + g1 * xh1; ts[k] = g0 + g1;
+        }
+        accw[2 * j] = rt_fold4(tw[0], tw[1], tw[2], tw[3]); accw[2 * j + 1] = rt_fold4(tw[4], tw[5], tw[6], tw[7]);
+        accb[2 * j] = rt_fold4(ts[0], ts[1], ts[2], ts[3]); accb[2 * j + 1] = rt_fold4(ts[4], ts[5], ts[6], ts[7]);
+    }
+    const int rowi = lane >> 4, cofs = rowi == 0 ? 0 : rowi == 1 ? 2 : rowi == 2 ? 1 : 3;
+    float* const prow = part + (size_t)(n * rounds + rd) * 2 * C + cg * CW;
+#pragma unroll
+    for (int m = 0; m < CW / 4; ++m) {
+        float a = accw[m], bb = accb[m];
+#pragma unroll
+        for (int k = 1; k < 16; k <<= 1) { a += __shfl_xor(a, k, 64); bb += __shfl_xor(bb, k, 64); }
+        if ((lane & 15) == 0) { const int c = 4 * m + cofs; prow[c] = a; prow[C + c] = bb; }
+    }
+}
+
 // ---- host side ---------------------------------------------------------------------------------------------------------------
 template <typename K> static int rt_persistent_grid(K k, size_t lds, int ntiles) {
     static thread_local int per_cu = 0, cus = 0;                       // one (kernel, lds) pair per instantiation of this template
@@ -667,6 +791,29 @@ static int launch_sr_bwd_chan(const float* dout, const uint16_t* dout16, float* 
     *rows = N * rounds;
     return SLAK_OK;
 }
+template <int CW>
+static int launch_ln_fwd_chan(const uint16_t* x, const float* w, const float* b, uint16_t* y, float* mean, float* rstd, int N, int C, int P, float eps, hipStream_t st) {
+    const int rounds = (P / 2 + 63) / 64;
+    hipLaunchKernelGGL(ln_nchw_to_nhwc_fwd_chan_kernel<CW>, dim3((unsigned)(N * rounds)), dim3((unsigned)(C / CW * 64)), 0, st, x, w, b, y, mean, rstd, C, P, rounds, eps);
+    SLAK_LAUNCH_CHECK();
+    return SLAK_OK;
+}
+template <int CW>
+static int launch_ln_bwd_chan(const uint16_t* g, const uint16_t* x, const float* w, const float* mean, const float* rstd, uint16_t* dx, float* part, int* rows,
+                              int N, int C, int P, hipStream_t st) {
+    const int rounds = (P / 2 + 63) / 64;
+    hipLaunchKernelGGL(ln_nchw_to_nhwc_bwd_chan_kernel<CW>, dim3((unsigned)(N * rounds)), dim3((unsigned)(C / CW * 64)), 0, st, g, x, w, mean, rstd, dx, part, C, P, rounds);
+    SLAK_LAUNCH_CHECK();
+    *rows = N * rounds;
+    return SLAK_OK;
+}
+// small planes: channels per wave of the workgroup-per-(image, round) LayerNorm kernels (at most 8 waves); 0 = not covered
+static int rt_ln_chan_cw(int C, int P, int N) {
+    if ((P & 1) || P > 256 || (long long)N * ((P / 2 + 63) / 64) > 8192 || !rt_chan_waves()) return 0;
+    if (C % 48 == 0 && C / 48 <= 8) return 48;
+    if (C % 64 == 0 && C / 64 <= 8) return 64;
+    return 0;
+}
 static bool rt_wide_lanes() {                // SLAK_RT_WIDE=0: C = 384 keeps 48 channels per lane on 8 lanes per pixel pair (A/B testing)
     static const bool v = [] { const char* e = getenv("SLAK_RT_WIDE"); return !(e && e[0] == '0'); }();
     return v;
@@ -687,12 +834,18 @@ static bool rt_wide_lanes() {                // SLAK_RT_WIDE=0: C = 384 keeps 48
     }
 
 int launch_ln_nchw_to_nhwc_fwd_reg(const void* x, const float* w, const float* b, void* y, float* mean, float* rstd, int N, int C, int P, float eps, hipStream_t st) {
+    { const int cw = rt_ln_chan_cw(C, P, N);
+      if (cw == 48) return launch_ln_fwd_chan<48>((const uint16_t*)x, w, b, (uint16_t*)y, mean, rstd, N, C, P, eps, st);
+      if (cw == 64) return launch_ln_fwd_chan<64>((const uint16_t*)x, w, b, (uint16_t*)y, mean, rstd, N, C, P, eps, st); }
 #define CALL(CL, G) return launch_ln_fwd_reg<CL, G>((const uint16_t*)x, w, b, (uint16_t*)y, mean, rstd, N, P, eps, st)
     SLAK_RT_DISPATCH(C, CALL)
 #undef CALL
 }
 int launch_ln_nchw_to_nhwc_bwd_reg(const void* g, const void* x, const float* w, const float* mean, const float* rstd, void* dx, float* part, int* rows,
                                    int N, int C, int P, hipStream_t st) {
+    { const int cw = rt_ln_chan_cw(C, P, N);
+      if (cw == 48) return launch_ln_bwd_chan<48>((const uint16_t*)g, (const uint16_t*)x, w, mean, rstd, (uint16_t*)dx, part, rows, N, C, P, st);
+      if (cw == 64) return launch_ln_bwd_chan<64>((const uint16_t*)g, (const uint16_t*)x, w, mean, rstd, (uint16_t*)dx, part, rows, N, C, P, st); }
 #define CALL(CL, G) return launch_ln_bwd_reg<CL, G>((const uint16_t*)g, (const uint16_t*)x, w, mean, rstd, (uint16_t*)dx, part, rows, N, P, st)
     SLAK_RT_DISPATCH(C, CALL)
 #undef CALL
