@@ -701,6 +701,203 @@ __global__ __launch_bounds__(512) void ln_nchw_to_nhwc_bwd_chan_kernel(const uin
     }
 }
 
+// ---- ODD plane sizes (P = 49: the 7 x 7 stage) in the same mapping, ONE pixel per lane (pixel pairs would start channel rows of the
+// bf16 tensors at 2-byte aligned dwords).  Channel rows are 196-byte (fp32) / 98-byte (bf16) runs instead of the 4 / 2 bytes per lane and
+// row the LDS-tile kernels of block_tail.hip end up with on this stage (0.1-0.2 of the HBM roofline).
+__device__ __forceinline__ float rt_ld16(const uint16_t* p) { return __uint_as_float((unsigned)*p << 16); }
+__device__ __forceinline__ uint16_t rt_bf(float v) { return (uint16_t)(rt_pack2(v, 0.f) & 0xffffu); }
+
+template <int CW>
+__global__ __launch_bounds__(256) void scale_residual_fwd_chan1_kernel(const float* __restrict__ sc, const uint16_t* __restrict__ z,
+                                                                       const float* __restrict__ gamma, const float* __restrict__ scale,
+                                                                       float* __restrict__ out, uint16_t* __restrict__ out16,
+                                                                       int C, int P, int rounds, int nunits) {
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int unit = blockIdx.x * 4 + wave;                       // (image, channel group, round of 64 pixels)
+    if (unit >= nunits) return;
+    const int groups = C / CW;
+    const int rd = unit % rounds, t = unit / rounds, cg = t % groups, n = t / groups;
+    const int px = rd * 64 + lane;
+    if (px >= P) return;
+    const float sn = scale ? scale[n] : 1.0f;
+    const uint16_t* zp = z + ((size_t)n * P + px) * C + cg * CW;
+    rt_u32x4 za[CW / 8];
+#pragma unroll
+    for (int j = 0; j < CW / 8; ++j) za[j] = *(const rt_u32x4*)(zp + j * 8);
+    const size_t row0 = ((size_t)n * C + cg * CW) * P + px;
+    float sx[CW];
+#pragma unroll
+    for (int c = 0; c < CW; ++c) sx[c] = sc[row0 + (size_t)c * P];
+    const float* gp = gamma + cg * CW;
+#pragma unroll
+    for (int c = 0; c < CW; ++c) {
+        const float o = sx[c] + (gp[c] * sn) * RT_CH(za[c >> 3], c & 7);
+        out[row0 + (size_t)c * P] = o;
+        if (out16) out16[row0 + (size_t)c * P] = rt_bf(o);
+    }
+}
+
+template <int CW>
+__global__ __launch_bounds__(256) void scale_residual_bwd_chan1_kernel(const float* __restrict__ dout, const uint16_t* __restrict__ dout16,
+                                                                       float* __restrict__ dsum, const uint16_t* __restrict__ z,
+                                                                       const float* __restrict__ gamma, const float* __restrict__ scale,
+                                                                       uint16_t* __restrict__ dz, float* __restrict__ part,
+                                                                       int C, int P, int rounds, int nunits) {
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int unit = blockIdx.x * 4 + wave;
+    if (unit >= nunits) return;
+    const int groups = C / CW;
+    const int rd = unit % rounds, t = unit / rounds, cg = t % groups, n = t / groups;
+    const int px = rd * 64 + lane;
+    const bool valid = px < P;
+    const float sn = scale ? scale[n] : 1.0f;
+    const size_t zoff = ((size_t)n * P + px) * C + cg * CW;
+    const size_t row0 = ((size_t)n * C + cg * CW) * P + px;
+    rt_u32x4 za[CW / 8];
+    float vx[CW];
+    if (valid) {
+#pragma unroll
+        for (int j = 0; j < CW / 8; ++j) za[j] = *(const rt_u32x4*)(z + zoff + j * 8);
+#pragma unroll
+        for (int c = 0; c < CW; ++c) vx[c] = dout[row0 + (size_t)c * P];
+        if (dout16) {
+#pragma unroll
+            for (int c = 0; c < CW; ++c) { vx[c] += rt_ld16(dout16 + row0 + (size_t)c * P); dsum[row0 + (size_t)c * P] = vx[c]; }
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < CW / 8; ++j) za[j] = rt_u32x4{0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int c = 0; c < CW; ++c) vx[c] = 0.f;
+    }
+    const float* gp = gamma + cg * CW;
+    float accg[CW / 4], accs[CW / 4];
+#pragma unroll
+    for (int j = 0; j < CW / 8; ++j) {
+        float d0[8], tg[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { d0[k] = vx[j * 8 + k] * sn; tg[k] = d0[k] * RT_CH(za[j], k); }
+        rt_u32x4 oa;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) oa[k] = rt_pack2(gp[j * 8 + 2 * k] * d0[2 * k], gp[j * 8 + 2 * k + 1] * d0[2 * k + 1]);
+        if (valid) *(rt_u32x4*)(dz + zoff + j * 8) = oa;
+        accg[2 * j] = rt_fold4(tg[0], tg[1], tg[2], tg[3]); accg[2 * j + 1] = rt_fold4(tg[4], tg[5], tg[6], tg[7]);
+        accs[2 * j] = rt_fold4(d0[0], d0[1], d0[2], d0[3]); accs[2 * j + 1] = rt_fold4(d0[4], d0[5], d0[6], d0[7]);
+    }
+    const int rowi = lane >> 4, cofs = rowi == 0 ? 0 : rowi == 1 ? 2 : rowi == 2 ? 1 : 3;
+    float* const prow = part + (size_t)(n * rounds + rd) * 2 * C + cg * CW;
+#pragma unroll
+    for (int m = 0; m < CW / 4; ++m) {
+        float a = accg[m], b = accs[m];
+#pragma unroll
+        for (int k = 1; k < 16; k <<= 1) { a += __shfl_xor(a, k, 64); b += __shfl_xor(b, k, 64); }
+        if ((lane & 15) == 0) { const int c = 4 * m + cofs; prow[c] = a; prow[C + c] = b * gp[c]; }
+    }
+}
+
+template <int CW>
+__global__ __launch_bounds__(1024) void ln_nchw_to_nhwc_fwd_chan1_kernel(const uint16_t* __restrict__ x, const float* __restrict__ w, const float* __restrict__ b,
+                                                                         uint16_t* __restrict__ y, float* __restrict__ mean, float* __restrict__ rstd,
+                                                                         int C, int P, int rounds, float eps) {
+    __shared__ float red[2][16][64];
+    const int lane = threadIdx.x & 63, cg = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), nw = (int)(blockDim.x >> 6);
+    const int rd = blockIdx.x % rounds, n = blockIdx.x / rounds;
+    const int px = rd * 64 + lane;
+    const bool valid = px < P;
+    const size_t row0 = ((size_t)n * C + cg * CW) * P + px, yoff = ((size_t)n * P + px) * C + cg * CW;
+    float v[CW];
+#pragma unroll
+    for (int c = 0; c < CW; ++c) v[c] = valid ? rt_ld16(x + row0 + (size_t)c * P) : 0.f;
+    float s0 = 0.f;
+#pragma unroll
+    for (int c = 0; c < CW; ++c) s0 += v[c];
+    red[0][cg][lane] = s0;
+    __syncthreads();
+    float t0 = 0.f;
+    for (int k = 0; k < nw; ++k) t0 += red[0][k][lane];
+    const float mu0 = t0 / (float)C;
+    float q0 = 0.f;
+#pragma unroll
+    for (int c = 0; c < CW; ++c) { const float a = v[c] - mu0; q0 += a * a; }
+    red[1][cg][lane] = q0;
+    __syncthreads();
+    t0 = 0.f;
+    for (int k = 0; k < nw; ++k) t0 += red[1][k][lane];
+    const float r0 = 1.0f / sqrtf(t0 / (float)C + eps);
+    if (!valid) return;
+    if (cg == 0) { mean[(size_t)n * P + px] = mu0; rstd[(size_t)n * P + px] = r0; }
+    const float* wp = w + cg * CW; const float* bp = b + cg * CW;
+#pragma unroll
+    for (int j = 0; j < CW / 8; ++j) {
+        rt_u32x4 oa;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int c = j * 8 + 2 * k;
+            oa[k] = rt_pack2((v[c] - mu0) * r0 * wp[c] + bp[c], (v[c + 1] - mu0) * r0 * wp[c + 1] + bp[c + 1]);
+        }
+        *(rt_u32x4*)(y + yoff + j * 8) = oa;
+    }
+}
+
+template <int CW>
+__global__ __launch_bounds__(1024) void ln_nchw_to_nhwc_bwd_chan1_kernel(const uint16_t* __restrict__ gy, const uint16_t* __restrict__ x, const float* __restrict__ w,
+                                                                         const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                                         uint16_t* __restrict__ dx, float* __restrict__ part, int C, int P, int rounds) {
+    __shared__ float2 red[16][64];
+    const int lane = threadIdx.x & 63, cg = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), nw = (int)(blockDim.x >> 6);
+    const int rd = blockIdx.x % rounds, n = blockIdx.x / rounds;
+    const int px = rd * 64 + lane;
+    const bool valid = px < P;
+    const size_t row0 = ((size_t)n * C + cg * CW) * P + px, goff = ((size_t)n * P + px) * C + cg * CW;
+    float xh[CW];                                                  // normalised x
+    rt_u32x4 ga[CW / 8];
+    float r0 = 0.f;
+    if (valid) {
+#pragma unroll
+        for (int j = 0; j < CW / 8; ++j) ga[j] = *(const rt_u32x4*)(gy + goff + j * 8);
+        const float mu0 = mean[(size_t)n * P + px]; r0 = rstd[(size_t)n * P + px];
+#pragma unroll
+        for (int c = 0; c < CW; ++c) xh[c] = (rt_ld16(x + row0 + (size_t)c * P) - mu0) * r0;
+    } else {
+#pragma unroll
+        for (int j = 0; j < CW / 8; ++j) ga[j] = rt_u32x4{0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int c = 0; c < CW; ++c) xh[c] = 0.f;
+    }
+    const float* wp = w + cg * CW;
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int c = 0; c < CW; ++c) { const float gw = RT_CH(ga[c >> 3], c & 7) * wp[c]; s1 += gw; s2 += gw * xh[c]; }
+    red[cg][lane] = float2{s1, s2};
+    __syncthreads();
+    float t1 = 0.f, t2 = 0.f;
+    for (int k = 0; k < nw; ++k) { const float2 q = red[k][lane]; t1 += q.x; t2 += q.y; }
+    const float m1 = t1 / (float)C, m2 = t2 / (float)C;
+    float accw[CW / 4], accb[CW / 4];
+#pragma unroll
+    for (int j = 0; j < CW / 8; ++j) {
+        float tw[8], ts[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int c = j * 8 + k;
+            const float g0 = RT_CH(ga[j], k);
+            if (valid) dx[row0 + (size_t)c * P] = rt_bf(r0 * (g0 * wp[c] - m1 - xh[c] * m2));
+            tw[k] = g0 * xh[c]; ts[k] = g0;
+        }
+        accw[2 * j] = rt_fold4(tw[0], tw[1], tw[2], tw[3]); accw[2 * j + 1] = rt_fold4(tw[4], tw[5], tw[6], tw[7]);
+        accb[2 * j] = rt_fold4(ts[0], ts[1], ts[2], ts[3]); accb[2 * j + 1] = rt_fold4(ts[4], ts[5], ts[6], ts[7]);
+    }
+    const int rowi = lane >> 4, cofs = rowi == 0 ? 0 : rowi == 1 ? 2 : rowi == 2 ? 1 : 3;
+    float* const prow = part + (size_t)(n * rounds + rd) * 2 * C + cg * CW;
+#pragma unroll
+    for (int m = 0; m < CW / 4; ++m) {
+        float a = accw[m], bb = accb[m];
+#pragma unroll
+        for (int k = 1; k < 16; k <<= 1) { a += __shfl_xor(a, k, 64); bb += __shfl_xor(bb, k, 64); }
+        if ((lane & 15) == 0) { const int c = 4 * m + cofs; prow[c] = a; prow[C + c] = bb; }
+    }
+}
+
 // ---- host side ---------------------------------------------------------------------------------------------------------------
 template <typename K> static int rt_persistent_grid(K k, size_t lds, int ntiles) {
     static thread_local int per_cu = 0, cus = 0;                       // one (kernel, lds) pair per instantiation of this template
@@ -807,6 +1004,13 @@ static int launch_ln_bwd_chan(const uint16_t* g, const uint16_t* x, const float*
     *rows = N * rounds;
     return SLAK_OK;
 }
+// odd plane sizes: one pixel per lane; channels per wave (the LayerNorm kernels: at most 16 waves); 0 = not covered
+static int rt_chan1_cw(int C, int P, int N, int max_waves) {
+    if (!(P & 1) || P > 256 || (long long)N * ((P + 63) / 64) > 8192 || !rt_chan_waves()) return 0;
+    if (C % 48 == 0 && C / 48 <= max_waves) return 48;
+    if (C % 32 == 0 && C / 32 <= max_waves) return 32;
+    return 0;
+}
 // small planes: channels per wave of the workgroup-per-(image, round) LayerNorm kernels (at most 8 waves); 0 = not covered
 static int rt_ln_chan_cw(int C, int P, int N) {
     if ((P & 1) || P > 256 || (long long)N * ((P / 2 + 63) / 64) > 8192 || !rt_chan_waves()) return 0;
@@ -834,6 +1038,9 @@ static bool rt_wide_lanes() {                // SLAK_RT_WIDE=0: C = 384 keeps 48
     }
 
 int launch_ln_nchw_to_nhwc_fwd_reg(const void* x, const float* w, const float* b, void* y, float* mean, float* rstd, int N, int C, int P, float eps, hipStream_t st) {
+    { const int cw1 = rt_chan1_cw(C, P, N, 16), rounds = (P + 63) / 64;
+      if (cw1 == 48) { hipLaunchKernelGGL(ln_nchw_to_nhwc_fwd_chan1_kernel<48>, dim3((unsigned)(N * rounds)), dim3((unsigned)(C / 48 * 64)), 0, st, (const uint16_t*)x, w, b, (uint16_t*)y, mean, rstd, C, P, rounds, eps); SLAK_LAUNCH_CHECK(); return SLAK_OK; }
+      if (cw1 == 32) { hipLaunchKernelGGL(ln_nchw_to_nhwc_fwd_chan1_kernel<32>, dim3((unsigned)(N * rounds)), dim3((unsigned)(C / 32 * 64)), 0, st, (const uint16_t*)x, w, b, (uint16_t*)y, mean, rstd, C, P, rounds, eps); SLAK_LAUNCH_CHECK(); return SLAK_OK; } }
     { const int cw = rt_ln_chan_cw(C, P, N);
       if (cw == 48) return launch_ln_fwd_chan<48>((const uint16_t*)x, w, b, (uint16_t*)y, mean, rstd, N, C, P, eps, st);
       if (cw == 64) return launch_ln_fwd_chan<64>((const uint16_t*)x, w, b, (uint16_t*)y, mean, rstd, N, C, P, eps, st); }
@@ -843,6 +1050,9 @@ int launch_ln_nchw_to_nhwc_fwd_reg(const void* x, const float* w, const float* b
 }
 int launch_ln_nchw_to_nhwc_bwd_reg(const void* g, const void* x, const float* w, const float* mean, const float* rstd, void* dx, float* part, int* rows,
                                    int N, int C, int P, hipStream_t st) {
+    { const int cw1 = rt_chan1_cw(C, P, N, 16), rounds = (P + 63) / 64;
+      if (cw1 == 48) { hipLaunchKernelGGL(ln_nchw_to_nhwc_bwd_chan1_kernel<48>, dim3((unsigned)(N * rounds)), dim3((unsigned)(C / 48 * 64)), 0, st, (const uint16_t*)g, (const uint16_t*)x, w, mean, rstd, (uint16_t*)dx, part, C, P, rounds); SLAK_LAUNCH_CHECK(); *rows = N * rounds; return SLAK_OK; }
+      if (cw1 == 32) { hipLaunchKernelGGL(ln_nchw_to_nhwc_bwd_chan1_kernel<32>, dim3((unsigned)(N * rounds)), dim3((unsigned)(C / 32 * 64)), 0, st, (const uint16_t*)g, (const uint16_t*)x, w, mean, rstd, (uint16_t*)dx, part, C, P, rounds); SLAK_LAUNCH_CHECK(); *rows = N * rounds; return SLAK_OK; } }
     { const int cw = rt_ln_chan_cw(C, P, N);
       if (cw == 48) return launch_ln_bwd_chan<48>((const uint16_t*)g, (const uint16_t*)x, w, mean, rstd, (uint16_t*)dx, part, rows, N, C, P, st);
       if (cw == 64) return launch_ln_bwd_chan<64>((const uint16_t*)g, (const uint16_t*)x, w, mean, rstd, (uint16_t*)dx, part, rows, N, C, P, st); }
@@ -872,6 +1082,9 @@ int launch_scale_residual_fwd_reg(const void* sc, int sc_dtype, const void* z, c
 #define CALL(CL, G) return launch_sr_fwd_reg<CL, G, float>((const float*)sc, (const uint16_t*)z, gamma, scale, out, (uint16_t*)out16, N, P, st)
         // C = 384: 96 channels per lane on 4 lanes per pixel pair double the length of a wave's NCHW row segments (64 -> 128 bytes); the
         // forward residual kernel is the one of the four whose registers allow it without spilling
+        { const int cw1 = rt_chan1_cw(C, P, N, 1 << 20), rounds = (P + 63) / 64;      // odd planes: one pixel per lane
+          if (cw1 == 48) { const int nu = N * (C / 48) * rounds; hipLaunchKernelGGL(scale_residual_fwd_chan1_kernel<48>, dim3((unsigned)((nu + 3) / 4)), dim3(256), 0, st, (const float*)sc, (const uint16_t*)z, gamma, scale, out, (uint16_t*)out16, C, P, rounds, nu); SLAK_LAUNCH_CHECK(); return SLAK_OK; }
+          if (cw1 == 32) { const int nu = N * (C / 32) * rounds; hipLaunchKernelGGL(scale_residual_fwd_chan1_kernel<32>, dim3((unsigned)((nu + 3) / 4)), dim3(256), 0, st, (const float*)sc, (const uint16_t*)z, gamma, scale, out, (uint16_t*)out16, C, P, rounds, nu); SLAK_LAUNCH_CHECK(); return SLAK_OK; } }
         if (!(P & 1) && P <= 256 && rt_chan_waves()) {              // small planes: a wave per (image, channel group)
             if (C % 48 == 0) return launch_sr_fwd_chan<48>((const float*)sc, (const uint16_t*)z, gamma, scale, out, (uint16_t*)out16, N, C, P, st);
             if (C % 64 == 0) return launch_sr_fwd_chan<64>((const float*)sc, (const uint16_t*)z, gamma, scale, out, (uint16_t*)out16, N, C, P, st);
@@ -888,6 +1101,9 @@ int launch_scale_residual_fwd_reg(const void* sc, int sc_dtype, const void* z, c
 }
 int launch_scale_residual_bwd_reg(const float* dout, const void* dout16, float* dsum, const void* z, const float* gamma, const float* scale, void* dz,
                                   float* part, int* rows, int N, int C, int P, hipStream_t st) {
+    { const int cw1 = rt_chan1_cw(C, P, N, 1 << 20), rounds = (P + 63) / 64;          // odd planes: one pixel per lane
+      if (cw1 == 48) { const int nu = N * (C / 48) * rounds; hipLaunchKernelGGL(scale_residual_bwd_chan1_kernel<48>, dim3((unsigned)((nu + 3) / 4)), dim3(256), 0, st, dout, (const uint16_t*)dout16, dsum, (const uint16_t*)z, gamma, scale, (uint16_t*)dz, part, C, P, rounds, nu); SLAK_LAUNCH_CHECK(); *rows = N * rounds; return SLAK_OK; }
+      if (cw1 == 32) { const int nu = N * (C / 32) * rounds; hipLaunchKernelGGL(scale_residual_bwd_chan1_kernel<32>, dim3((unsigned)((nu + 3) / 4)), dim3(256), 0, st, dout, (const uint16_t*)dout16, dsum, (const uint16_t*)z, gamma, scale, (uint16_t*)dz, part, C, P, rounds, nu); SLAK_LAUNCH_CHECK(); *rows = N * rounds; return SLAK_OK; } }
     if (!(P & 1) && P <= 256 && (long long)N * ((P / 2 + 63) / 64) <= 8192 && rt_chan_waves()) {     // small planes: a wave per (image, channel group); rows <= the workspace's 8192
         if (C % 24 == 0) return launch_sr_bwd_chan<24>(dout, (const uint16_t*)dout16, dsum, (const uint16_t*)z, gamma, scale, (uint16_t*)dz, part, rows, N, C, P, st);
         if (C % 32 == 0) return launch_sr_bwd_chan<32>(dout, (const uint16_t*)dout16, dsum, (const uint16_t*)z, gamma, scale, (uint16_t*)dz, part, rows, N, C, P, st);

@@ -12,7 +12,9 @@ pytestmark = pytest.mark.gpu
 SHAPES = [(3, 96, 56, 56), (5, 192, 28, 28), (4, 384, 14, 14), (7, 768, 7, 7), (2, 64, 9, 11), (1, 130, 5, 3), (2, 256, 20, 20),
           # small planes: the residual kernels that give a wave (image, channel group, 64 pixel pairs) -- SLaK-B's 512 channels, a partly
           # filled round, exactly two rounds
-          (3, 512, 14, 14), (2, 48, 4, 6), (2, 96, 16, 16)]
+          (3, 512, 14, 14), (2, 48, 4, 6), (2, 96, 16, 16),
+          # odd plane sizes (one pixel per lane): SLaK-B's last stage; (7, 768, 7, 7) and (2, 64, 9, 11: two rounds) above take the same kernels
+          (3, 1024, 7, 7)]
 
 
 def _close(a, b, rel, what):
@@ -72,7 +74,7 @@ def test_scale_residual_matches_torch(N, C, H, W, sc_dtype, with_scale, gpu):
     assert torch.equal(g2.grad, gamma.grad)
 
 
-@pytest.mark.parametrize("N,C,H,W", [(4, 384, 14, 14), (3, 512, 14, 14), (2, 96, 16, 16), (5, 192, 28, 28)])
+@pytest.mark.parametrize("N,C,H,W", [(4, 384, 14, 14), (3, 512, 14, 14), (2, 96, 16, 16), (5, 192, 28, 28), (7, 768, 7, 7), (2, 64, 9, 11)])
 def test_scale_residual_with_bf16_copy_and_second_gradient_stream(N, C, H, W, gpu):
     """What a training step runs between two blocks: the forward also writes the bf16 copy of its output, the backward adds the gradient
     of that copy (bf16) to the fp32 one and returns the sum as the shortcut gradient (block_ops._scale_residual_fwd / _bwd)."""
