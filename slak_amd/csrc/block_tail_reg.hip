@@ -381,7 +381,7 @@ __global__ __launch_bounds__(256, 2) void scale_residual_fwd_reg_kernel(const Ts
     }
 }
 
-// The same for SMALL planes (P <= 256: the 14 x 14 stage).  In the lane geometry above a wave covers 128 / G pixels -- 16 on C = 384 --, so
+// The same for SMALL planes (P <= 256 by default: the 14 x 14 stage).  In the lane geometry above a wave covers 128 / G pixels -- 16 on C = 384 --, so
 // each of its channel-row accesses is a 64-byte run of the fp32 NCHW tensors that carry 10 of the kernel's 12 bytes per element (measured:
 // 3.2 TB/s against 5.7 on the 56 x 56 stage).  Here a wave takes CW channels of ONE image over 64 pixel pairs: a channel row is read and
 // written as one 512-byte run (256 for the bf16 copy), and the lane fetches the CW channels of its two pixels of z as 16-byte pieces
@@ -967,6 +967,10 @@ static int launch_sr_bwd_reg(const float* dout, const uint16_t* dout16, float* d
     return SLAK_OK;
 }
 
+static int rt_chan_max_p() {                 // largest plane (pixels) the channel-group kernels take (dev: SLAK_RT_CHAN_MAXP)
+    static const int v = [] { const char* e = getenv("SLAK_RT_CHAN_MAXP"); const int x = e ? atoi(e) : 0; return x > 0 ? x : 256; }();
+    return v;
+}
 static bool rt_chan_waves() {                // SLAK_RT_CHAN=0: small planes keep the pixel-tile residual kernel (A/B testing)
     static const bool v = [] { const char* e = getenv("SLAK_RT_CHAN"); return !(e && e[0] == '0'); }();
     return v;
@@ -1006,14 +1010,14 @@ static int launch_ln_bwd_chan(const uint16_t* g, const uint16_t* x, const float*
 }
 // odd plane sizes: one pixel per lane; channels per wave (the LayerNorm kernels: at most 16 waves); 0 = not covered
 static int rt_chan1_cw(int C, int P, int N, int max_waves) {
-    if (!(P & 1) || P > 256 || (long long)N * ((P + 63) / 64) > 8192 || !rt_chan_waves()) return 0;
+    if (!(P & 1) || P > rt_chan_max_p() || (long long)N * ((P + 63) / 64) > 8192 || !rt_chan_waves()) return 0;
     if (C % 48 == 0 && C / 48 <= max_waves) return 48;
     if (C % 32 == 0 && C / 32 <= max_waves) return 32;
     return 0;
 }
 // small planes: channels per wave of the workgroup-per-(image, round) LayerNorm kernels (at most 8 waves); 0 = not covered
 static int rt_ln_chan_cw(int C, int P, int N) {
-    if ((P & 1) || P > 256 || (long long)N * ((P / 2 + 63) / 64) > 8192 || !rt_chan_waves()) return 0;
+    if ((P & 1) || P > rt_chan_max_p() || (long long)N * ((P / 2 + 63) / 64) > 8192 || !rt_chan_waves()) return 0;
     if (C % 48 == 0 && C / 48 <= 8) return 48;
     if (C % 64 == 0 && C / 64 <= 8) return 64;
     return 0;
@@ -1085,7 +1089,7 @@ int launch_scale_residual_fwd_reg(const void* sc, int sc_dtype, const void* z, c
         { const int cw1 = rt_chan1_cw(C, P, N, 1 << 20), rounds = (P + 63) / 64;      // odd planes: one pixel per lane
           if (cw1 == 48) { const int nu = N * (C / 48) * rounds; hipLaunchKernelGGL(scale_residual_fwd_chan1_kernel<48>, dim3((unsigned)((nu + 3) / 4)), dim3(256), 0, st, (const float*)sc, (const uint16_t*)z, gamma, scale, out, (uint16_t*)out16, C, P, rounds, nu); SLAK_LAUNCH_CHECK(); return SLAK_OK; }
           if (cw1 == 32) { const int nu = N * (C / 32) * rounds; hipLaunchKernelGGL(scale_residual_fwd_chan1_kernel<32>, dim3((unsigned)((nu + 3) / 4)), dim3(256), 0, st, (const float*)sc, (const uint16_t*)z, gamma, scale, out, (uint16_t*)out16, C, P, rounds, nu); SLAK_LAUNCH_CHECK(); return SLAK_OK; } }
-        if (!(P & 1) && P <= 256 && rt_chan_waves()) {              // small planes: a wave per (image, channel group)
+        if (!(P & 1) && P <= rt_chan_max_p() && rt_chan_waves()) {              // small planes: a wave per (image, channel group)
             if (C % 48 == 0) return launch_sr_fwd_chan<48>((const float*)sc, (const uint16_t*)z, gamma, scale, out, (uint16_t*)out16, N, C, P, st);
             if (C % 64 == 0) return launch_sr_fwd_chan<64>((const float*)sc, (const uint16_t*)z, gamma, scale, out, (uint16_t*)out16, N, C, P, st);
         }
@@ -1104,7 +1108,7 @@ int launch_scale_residual_bwd_reg(const float* dout, const void* dout16, float* 
     { const int cw1 = rt_chan1_cw(C, P, N, 1 << 20), rounds = (P + 63) / 64;          // odd planes: one pixel per lane
       if (cw1 == 48) { const int nu = N * (C / 48) * rounds; hipLaunchKernelGGL(scale_residual_bwd_chan1_kernel<48>, dim3((unsigned)((nu + 3) / 4)), dim3(256), 0, st, dout, (const uint16_t*)dout16, dsum, (const uint16_t*)z, gamma, scale, (uint16_t*)dz, part, C, P, rounds, nu); SLAK_LAUNCH_CHECK(); *rows = N * rounds; return SLAK_OK; }
       if (cw1 == 32) { const int nu = N * (C / 32) * rounds; hipLaunchKernelGGL(scale_residual_bwd_chan1_kernel<32>, dim3((unsigned)((nu + 3) / 4)), dim3(256), 0, st, dout, (const uint16_t*)dout16, dsum, (const uint16_t*)z, gamma, scale, (uint16_t*)dz, part, C, P, rounds, nu); SLAK_LAUNCH_CHECK(); *rows = N * rounds; return SLAK_OK; } }
-    if (!(P & 1) && P <= 256 && (long long)N * ((P / 2 + 63) / 64) <= 8192 && rt_chan_waves()) {     // small planes: a wave per (image, channel group); rows <= the workspace's 8192
+    if (!(P & 1) && P <= rt_chan_max_p() && (long long)N * ((P / 2 + 63) / 64) <= 8192 && rt_chan_waves()) {     // small planes: a wave per (image, channel group); rows <= the workspace's 8192
         if (C % 24 == 0) return launch_sr_bwd_chan<24>(dout, (const uint16_t*)dout16, dsum, (const uint16_t*)z, gamma, scale, (uint16_t*)dz, part, rows, N, C, P, st);
         if (C % 32 == 0) return launch_sr_bwd_chan<32>(dout, (const uint16_t*)dout16, dsum, (const uint16_t*)z, gamma, scale, (uint16_t*)dz, part, rows, N, C, P, st);
     }
