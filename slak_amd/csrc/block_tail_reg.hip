@@ -577,60 +577,10 @@ __global__ __launch_bounds__(256) void scale_residual_bwd_chan_kernel(const floa
     }
 }
 
-// LayerNorm forward / backward for SMALL planes in the same mapping: a WORKGROUP per (image, 64 pixel pairs) with one wave per group of
-// CW channels (<= 8 waves), so the bf16 NCHW rows move as 256-byte runs; the per-pixel statistics over C are the sum of the waves'
-// partials through LDS (one workgroup barrier per statistic), the per-channel sums of the backward one fold over the wave.
-template <int CW>
-__global__ __launch_bounds__(512) void ln_nchw_to_nhwc_fwd_chan_kernel(const uint16_t* __restrict__ x, const float* __restrict__ w, const float* __restrict__ b,
-                                                                       uint16_t* __restrict__ y, float* __restrict__ mean, float* __restrict__ rstd,
-                                                                       int C, int P, int rounds, float eps) {
-    __shared__ float2 red[2][8][64];
-    const int lane = threadIdx.x & 63, cg = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), nw = (int)(blockDim.x >> 6);
-    const int rd = blockIdx.x % rounds, n = blockIdx.x / rounds;
-    const int pair = rd * 64 + lane;
-    const bool valid = 2 * pair < P;
-    const size_t row0 = ((size_t)n * C + cg * CW) * P + 2 * pair, yoff = ((size_t)n * P + 2 * pair) * C + cg * CW;
-    unsigned v[CW];                                               // (pixel p, pixel p+1) of channel c
-#pragma unroll
-    for (int c = 0; c < CW; ++c) v[c] = valid ? *(const unsigned*)(x + row0 + (size_t)c * P) : 0u;
-    float s0 = 0.f, s1 = 0.f;
-#pragma unroll
-    for (int c = 0; c < CW; ++c) { s0 += rt_lo(v[c]); s1 += rt_hi(v[c]); }
-    // (each pass unpacks from the PACKED registers again: otherwise the compiler keeps the unpacked fp32 values of a pass alive)
-#pragma unroll
-    for (int c = 0; c < CW; ++c) asm volatile("" : "+v"(v[c]));
-    red[0][cg][lane] = float2{s0, s1};
-    __syncthreads();
-    float t0 = 0.f, t1 = 0.f;
-    for (int k = 0; k < nw; ++k) { const float2 q = red[0][k][lane]; t0 += q.x; t1 += q.y; }
-    const float mu0 = t0 / (float)C, mu1 = t1 / (float)C;
-    float q0 = 0.f, q1 = 0.f;
-#pragma unroll
-    for (int c = 0; c < CW; ++c) { const float a = rt_lo(v[c]) - mu0, d = rt_hi(v[c]) - mu1; q0 += a * a; q1 += d * d; }
-#pragma unroll
-    for (int c = 0; c < CW; ++c) asm volatile("" : "+v"(v[c]));
-    red[1][cg][lane] = float2{q0, q1};
-    __syncthreads();
-    t0 = 0.f; t1 = 0.f;
-    for (int k = 0; k < nw; ++k) { const float2 q = red[1][k][lane]; t0 += q.x; t1 += q.y; }
-    const float r0 = 1.0f / sqrtf(t0 / (float)C + eps), r1 = 1.0f / sqrtf(t1 / (float)C + eps);
-    if (!valid) return;
-    if (cg == 0) { *(float2*)(mean + (size_t)n * P + 2 * pair) = float2{mu0, mu1}; *(float2*)(rstd + (size_t)n * P + 2 * pair) = float2{r0, r1}; }
-    const float* wp = w + cg * CW; const float* bp = b + cg * CW;  // (wave-uniform: scalar loads)
-#pragma unroll
-    for (int j = 0; j < CW / 8; ++j) {
-        rt_u32x4 oa, ob;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int c = j * 8 + 2 * k;
-            const float w0 = wp[c], w1 = wp[c + 1], b0 = bp[c], b1 = bp[c + 1];
-            oa[k] = rt_pack2((rt_lo(v[c]) - mu0) * r0 * w0 + b0, (rt_lo(v[c + 1]) - mu0) * r0 * w1 + b1);
-            ob[k] = rt_pack2((rt_hi(v[c]) - mu1) * r1 * w0 + b0, (rt_hi(v[c + 1]) - mu1) * r1 * w1 + b1);
-        }
-        *(rt_u32x4*)(y + yoff + j * 8) = oa; *(rt_u32x4*)(y + yoff + C + j * 8) = ob;
-    }
-}
-
+// LayerNorm backward for SMALL planes in the same mapping: a WORKGROUP per (image, 64 pixel pairs) with one wave per group of CW channels
+// (<= 8 waves), so the bf16 NCHW rows move as 256-byte runs; the per-pixel sums over C are the sum of the waves' partials through LDS (one
+// workgroup barrier), the per-channel sums one fold over the wave.  (The forward in this mapping measured slower inside a training step than
+// the pixel-tile kernel, 16.7 vs 14.9 us on 384 x 14 x 14 -- its input was just written and is cache resident -- and was dropped.)
 template <int CW>
 __global__ __launch_bounds__(512) void ln_nchw_to_nhwc_bwd_chan_kernel(const uint16_t* __restrict__ gy, const uint16_t* __restrict__ x, const float* __restrict__ w,
                                                                        const float* __restrict__ mean, const float* __restrict__ rstd,
@@ -993,13 +943,6 @@ static int launch_sr_bwd_chan(const float* dout, const uint16_t* dout16, float* 
     return SLAK_OK;
 }
 template <int CW>
-static int launch_ln_fwd_chan(const uint16_t* x, const float* w, const float* b, uint16_t* y, float* mean, float* rstd, int N, int C, int P, float eps, hipStream_t st) {
-    const int rounds = (P / 2 + 63) / 64;
-    hipLaunchKernelGGL(ln_nchw_to_nhwc_fwd_chan_kernel<CW>, dim3((unsigned)(N * rounds)), dim3((unsigned)(C / CW * 64)), 0, st, x, w, b, y, mean, rstd, C, P, rounds, eps);
-    SLAK_LAUNCH_CHECK();
-    return SLAK_OK;
-}
-template <int CW>
 static int launch_ln_bwd_chan(const uint16_t* g, const uint16_t* x, const float* w, const float* mean, const float* rstd, uint16_t* dx, float* part, int* rows,
                               int N, int C, int P, hipStream_t st) {
     const int rounds = (P / 2 + 63) / 64;
@@ -1045,12 +988,6 @@ int launch_ln_nchw_to_nhwc_fwd_reg(const void* x, const float* w, const float* b
     { const int cw1 = rt_chan1_cw(C, P, N, 16), rounds = (P + 63) / 64;
       if (cw1 == 48) { hipLaunchKernelGGL(ln_nchw_to_nhwc_fwd_chan1_kernel<48>, dim3((unsigned)(N * rounds)), dim3((unsigned)(C / 48 * 64)), 0, st, (const uint16_t*)x, w, b, (uint16_t*)y, mean, rstd, C, P, rounds, eps); SLAK_LAUNCH_CHECK(); return SLAK_OK; }
       if (cw1 == 32) { hipLaunchKernelGGL(ln_nchw_to_nhwc_fwd_chan1_kernel<32>, dim3((unsigned)(N * rounds)), dim3((unsigned)(C / 32 * 64)), 0, st, (const uint16_t*)x, w, b, (uint16_t*)y, mean, rstd, C, P, rounds, eps); SLAK_LAUNCH_CHECK(); return SLAK_OK; } }
-    // (even planes: inside a training step the pixel-tile kernel is the faster forward, 14.9 vs 16.7 us on 384 x 14 x 14 -- its input was just
-    // written and is cache resident; the workgroup-per-round version stays behind SLAK_RT_CHAN_LNFWD=1)
-    { static const bool on = [] { const char* e = getenv("SLAK_RT_CHAN_LNFWD"); return e && e[0] == '1'; }();
-      const int cw = on ? rt_ln_chan_cw(C, P, N) : 0;
-      if (cw == 48) return launch_ln_fwd_chan<48>((const uint16_t*)x, w, b, (uint16_t*)y, mean, rstd, N, C, P, eps, st);
-      if (cw == 64) return launch_ln_fwd_chan<64>((const uint16_t*)x, w, b, (uint16_t*)y, mean, rstd, N, C, P, eps, st); }
 #define CALL(CL, G) return launch_ln_fwd_reg<CL, G>((const uint16_t*)x, w, b, (uint16_t*)y, mean, rstd, N, P, eps, st)
     SLAK_RT_DISPATCH(C, CALL)
 #undef CALL
