@@ -14,6 +14,7 @@
 //     and shifted into place (see dwconv_mfma_small_tri.hip).
 // At this size a launch is ~10 us of fixed cost: one launch for three removes two of them per block.
 #include "mfma_common.h"
+#include <type_traits>
 #include <stdlib.h>
 
 namespace slak {
@@ -292,7 +293,7 @@ constexpr int QW_TEN = 2 * QW_TILE;     // two tiles (an octet of planes) of one
 constexpr int QW_SLOT = 4 * QW_TEN;     // [dy_v][dy_h][dy_s][x]
 constexpr int QW_T = TW_RING + QW_SLOT;                   // [dy_v^T: 2 x 512][64 zero][x^T tile 0][64 zero][x^T tile 1][64 zero]
 constexpr int QW_XT = QW_T + 1024 + 64;
-constexpr int QW_RES = QW_XT + 2 * QW_TILE > TW_RING + 5 * 16 * 32 * 4 ? QW_XT + 2 * QW_TILE : TW_RING + 5 * 16 * 32 * 4;   // (the diagonal-sum tiles alias what lies in front)
+constexpr int QW_RES = QW_XT + 2 * QW_TILE;
 constexpr int QW_WAVE_BYTES = QW_RES + TW_RESN * 4;
 constexpr unsigned QW_OOB = 0x80000000u;
 
@@ -402,34 +403,50 @@ __global__ __launch_bounds__(MF_THREADS) void dwconv_mfma_small_quad_wgrad_kerne
 
     // ---- diagonal sums of the two valid blocks, one branch after the other, through the skewed 16 x 32 tile (the slot is dead) ----
     if (live) {
-        float* tile = (float*)(L + TW_RING);
         float* res = (float*)(L + QW_RES);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // Diagonal sums WITHOUT the skewed LDS tile: inside a valid block the slot difference of an entry IS its diagonal (both tile axes carry
+        // the same pitch), and |d| <= 6 < 8, so rotating every accumulator row left by its own row index (DPP row_ror: e by immediate, 4 * g4
+        // per 16-lane row through row masks) lines diagonal d up in lane d mod 16; four adds over the registers, two over the rows.  The LDS-tile
+        // version (tw_diag5) was latency bound: 4 of this launch's 20 us.
+        auto ror = [](float v, auto ctrl) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x120 + decltype(ctrl)::value, 0xf, 0xf, false)); };
         auto diag = [&](const f32x4_t (&acc)[MF_TAPS], bool vert, int Wt, int KL, int kw, float* out) {
             const int padL = KL / 2;
             // slot -> (block, position): tile rows carry the 9 pitch (vertical branch: positions are rows), byte halves the 8 pitch
             auto blk = [&](int sl) { return vert ? (sl >= 9 ? 1 : 0) : (sl >> 3); };
             auto pos = [&](int sl) { return vert ? sl - 9 * (sl >= 9 ? 1 : 0) : (sl & 7); };
             auto valid = [&](int sl) { return (!vert || (sl != 7 && sl != 8)) && pos(sl) < Wt; };
-            const int pi = pos(i16);
             const bool vi = valid(i16);
-            int wofs[4]; bool wok[4];
+            bool wok[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int so = 4 * g4 + e;
-                wok[e] = vi && valid(so) && blk(so) == blk(i16);  // (the off-diagonal blocks are products of different planes)
-                wofs[e] = so * 32 + (pi - pos(so) + 15);
+            for (int e = 0; e < 4; ++e) { const int so = 4 * g4 + e; wok[e] = vi && valid(so) && blk(so) == blk(i16); }   // (off-diagonal blocks: products of different planes)
+            const int d = i16 < 8 ? i16 : i16 - 16;               // the diagonal that ends up in this lane
+            const int tau = d + padL;
+            const bool emit = lane < 16 && i16 != 8 && tau >= 0 && tau < KL;
+#pragma unroll
+            for (int r = 0; r < MF_TAPS; ++r) {
+                // element (row so = 4 g4 + e, slot j) -> lane (j - so) mod 16: a left rotation by so = a right rotation by 16 - so
+                float t = wok[0] ? acc[r][0] : 0.f;
+                t += ror(wok[1] ? acc[r][1] : 0.f, std::integral_constant<int, 15>{});
+                t += ror(wok[2] ? acc[r][2] : 0.f, std::integral_constant<int, 14>{});
+                t += ror(wok[3] ? acc[r][3] : 0.f, std::integral_constant<int, 13>{});
+                int ti = __float_as_int(t);
+                ti = __builtin_amdgcn_update_dpp(ti, ti, 0x120 + 12, 0x2, 0xf, false);     // 16-lane row 1: left by 4
+                ti = __builtin_amdgcn_update_dpp(ti, ti, 0x120 + 8, 0x4, 0xf, false);      // row 2: left by 8
+                ti = __builtin_amdgcn_update_dpp(ti, ti, 0x120 + 4, 0x8, 0xf, false);      // row 3: left by 12
+                t = __int_as_float(ti);
+                t += __shfl_xor(t, 16, 64);
+                t += __shfl_xor(t, 32, 64);
+                if (emit) out[vert ? (tau * kw + r) : (r * kw + tau)] = t;
             }
-            tw_diag5(tile, lane, acc, wok, wofs, [&](int r, int col, float sum) {
-                const int tau = col - 15 + padL;
-                if (tau >= 0 && tau < KL) out[vert ? (tau * kw + r) : (r * kw + tau)] = sum;
-            });
         };
         if (!(p.dbg & 4)) {
         diag(av, true, p.H, p.K, MF_TAPS, res);
         diag(ah, false, p.W, p.K, p.K, res + nt_long);
         diag(as, false, p.W, MF_TAPS, MF_TAPS, res + 2 * nt_long);
         }
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         float* out = p.partial + ((size_t)slice * p.C + c) * ntot;
         for (int t = lane; t < ntot; t += 64) wgrad_store_partial(&out[t], res[t]);       // taps no diagonal reaches stay 0
     } else if (c < p.C) {                                         // empty slice: its partial must still be zero
