@@ -231,7 +231,38 @@ __global__ __launch_bounds__(MF_THREADS) void dwconv_mfma_small_tri_wgrad_kernel
                 if (tau >= 0 && tau < KL) out[vert ? (tau * kw + r) : (r * kw + tau)] = sum;
             });
         };
-        diag(av, true, p.H, p.K, MF_TAPS, res);
+        {   // vertical branch: its positions are the image rows, slot = position, so an entry's diagonal is its slot difference: rotating every
+            // accumulator row left by its own index (DPP row_ror) lines the diagonals up in the lanes -- d >= 0 and d < 0 apart (|d| <= 13
+            // wraps around 16 lanes) -- without the skewed LDS tile (which is latency bound: a third of the 4 us the three branches' sums cost)
+            auto ror = [](float v, auto ctrl) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x120 + decltype(ctrl)::value, 0xf, 0xf, false)); };
+            auto rows = [](float v) {
+                int ti = __float_as_int(v);
+                ti = __builtin_amdgcn_update_dpp(ti, ti, 0x120 + 12, 0x2, 0xf, false);     // 16-lane row 1: left by 4
+                ti = __builtin_amdgcn_update_dpp(ti, ti, 0x120 + 8, 0x4, 0xf, false);      // row 2: left by 8
+                ti = __builtin_amdgcn_update_dpp(ti, ti, 0x120 + 4, 0x8, 0xf, false);      // row 3: left by 12
+                float t = __int_as_float(ti);
+                t += __shfl_xor(t, 16, 64);
+                t += __shfl_xor(t, 32, 64);
+                return t;
+            };
+            const int padL = p.K / 2;
+            bool okp[4], okn[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const int so = 4 * g4 + e; const bool ok = i16 < p.H && so < p.H; okp[e] = ok && i16 >= so; okn[e] = ok && i16 < so; }
+            const int tp = i16 + padL, tn = i16 - 16 + padL;
+#pragma unroll
+            for (int r = 0; r < MF_TAPS; ++r) {
+                float a = okp[0] ? av[r][0] : 0.f, b = okn[0] ? av[r][0] : 0.f;
+                a += ror(okp[1] ? av[r][1] : 0.f, std::integral_constant<int, 15>{}); b += ror(okn[1] ? av[r][1] : 0.f, std::integral_constant<int, 15>{});
+                a += ror(okp[2] ? av[r][2] : 0.f, std::integral_constant<int, 14>{}); b += ror(okn[2] ? av[r][2] : 0.f, std::integral_constant<int, 14>{});
+                a += ror(okp[3] ? av[r][3] : 0.f, std::integral_constant<int, 13>{}); b += ror(okn[3] ? av[r][3] : 0.f, std::integral_constant<int, 13>{});
+                a = rows(a); b = rows(b);
+                if (lane < 16 && tp < p.K) res[tp * MF_TAPS + r] = a;          // d = lane >= 0
+                if (lane < 16 && tn >= 0 && tn < p.K) res[tn * MF_TAPS + r] = b;  // d = lane - 16 < 0
+            }
+            __builtin_amdgcn_wave_barrier();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
         diag(ah, false, p.W, p.K, p.K, res + nt_long);
         diag(as, false, p.W, MF_TAPS, MF_TAPS, res + 2 * nt_long);
         float* out = p.partial + ((size_t)slice * p.C + c) * ntot;
@@ -523,7 +554,7 @@ size_t dwconv_mfma_small_tri_wgrad_workspace(int N, int C, int K) {
 template <typename T>
 static int launch_qw_t(SmallTriWgradParams& p, size_t ws_bytes, hipStream_t st) {
     auto k = dwconv_mfma_small_quad_wgrad_kernel<T>;
-    static const int wgs_per_cu = [] { const char* e = getenv("SLAK_QW_WGS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 2; }();
+    static const int wgs_per_cu = [] { const char* e = getenv("SLAK_QW_WGS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 3; }();
     fill_stw_params(p, p.N, p.C, p.H, p.W, p.K, wgs_per_cu * mfma_cu_count());
     int per = (p.images_per_slice + 7) & ~7;                        // whole octets
     if (per > ((p.N + 7) & ~7)) per = (p.N + 7) & ~7;
