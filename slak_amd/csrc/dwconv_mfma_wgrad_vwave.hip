@@ -36,14 +36,19 @@ struct WgradWaveParams {
 
 // PAIR: dw (K x 5) and dw2 (5 x 5) of one block in one launch -- G_r[o, i] of the small branch is the same correlation with its own dY,
 // so x is fetched and shifted once for both (five more MFMAs per k-step, a third plane copy in the slot)
-template <typename T, bool PAIR>
+// HORIZ: the horizontal kernels (5 x K) in the same frame.  G_r[o, i] = sum_{n,y} dY[y, o] * X[y + r - 2, i] (o, i = image columns): the
+// contraction runs over image ROWS, so both operands are column gathers -- two ds_read_b64_tr_b16 per fragment on an image of 64-byte
+// rows (two zero rows above and below X for the tap shift, which is a row offset here) -- and dw[r, tau] = sum_o G_r[o, o + tau - padL].
+template <typename T, bool PAIR, bool HORIZ>
 __global__ __launch_bounds__(MF_THREADS, 2) void dwconv_mfma_wgrad_vwave_kernel(const WgradWaveParams p) {
+    static_assert(!(PAIR && HORIZ), "the 5 x 5 branch rides with the vertical one");
     constexpr int NG = MF_TAPS;
     extern __shared__ __attribute__((aligned(16))) uint16_t lds[];
     char* const LB = (char*)lds;
     const int HW = p.H * p.W, ntap1 = p.kh * p.kw, ntap = ntap1 + (PAIR ? MF_TAPS * MF_TAPS : 0);
-    const unsigned PB = (unsigned)p.CPR * 16;                     // LDS row pitch (bytes)
-    const unsigned copy_b = 32u * PB;                             // one plane copy: 32 rows (rows >= H stay zero)
+    const unsigned PB = HORIZ ? 64u : (unsigned)p.CPR * 16;       // LDS row pitch (bytes); HORIZ: 64 (the conflict-free pitch of the transposing reads)
+    const unsigned row0_b = HORIZ ? 128u : 0u;                    // HORIZ: two zero rows in front of the image (and two behind)
+    const unsigned copy_b = (HORIZ ? 36u : 32u) * PB;             // one plane copy: 32 rows (rows >= H stay zero)
     constexpr unsigned WAVE_B = 64 + 32 * 64 * 4;                 // per wave: [64 zero][slot: dY copy, X copy | epilogue tile 32 x 64 floats]
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, lhi = lane >> 5;
     const int wave = wave_id_uniform();
@@ -68,7 +73,7 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dwconv_mfma_wgrad_vwave_kernel(
         const bool ok = row < p.H;
         const int nv = p.W - piece * 8;                             // elements of the piece inside the row (the rest is the next row's)
         l_src[j] = ok ? (unsigned)(row * p.W + piece * 8) * 2 : VW_OOB;
-        l_dst[j] = 64u + (unsigned)(row < 32 ? row : 0) * PB + (unsigned)piece * 16;
+        l_dst[j] = 64u + row0_b + (unsigned)(row < 32 ? row : 0) * PB + (unsigned)piece * 16;
 #pragma unroll
         for (int d = 0; d < 4; ++d) l_m[j][d] = nv >= 2 * d + 2 ? 0xffffffffu : (nv == 2 * d + 1 ? 0xffffu : 0u);
     }
@@ -114,6 +119,25 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dwconv_mfma_wgrad_vwave_kernel(
         stage(R);                                                 // (the LDS queue is in order: the reads of the plane before are behind us)
         load_plane(k + 2, R);
         if (k >= np) return;
+        if constexpr (HORIZ) {
+            // lane -> column (o resp. i) = l31, 8 consecutive k = image rows 16*ks + 8*lhi .. +7: two transposing reads of four rows each
+            // (a 16-lane group reads rows +0..3 of 16 columns; lane i16 supplies row i16 / 4, columns 4 * (i16 % 4) .. +3 and receives column i16)
+            const int i16 = lane & 15, gq = lane >> 4;
+            const unsigned tr = 64u + row0_b + (unsigned)(8 * lhi + (i16 >> 2)) * PB + (unsigned)(16 * (gq & 1) + 4 * (i16 & 3)) * 2;
+            auto tr2 = [&](unsigned addr) -> s16x8 {
+                const s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(SLAK_LDS(s16x4, L + addr));
+                const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(SLAK_LDS(s16x4, L + addr + 4 * PB));
+                return s16x8{v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+            };
+            const int nks = (p.H + 15) / 16;
+            for (int ks = 0; ks < nks; ++ks) {
+                const unsigned base = tr + (unsigned)ks * 16 * PB;
+                const s16x8 a = tr2(base);
+#pragma unroll
+                for (int r = 0; r < NG; ++r) acc[r] = mfma32<T>(a, tr2(copy_b + base + (unsigned)r * PB - 2 * PB), acc[r]);
+            }
+            return;
+        }
         for (int ks = 0; ks < p.KS; ++ks) {
             const s16x8 a = __builtin_bit_cast(s16x8, rdq(a_off + (unsigned)ks * 32));
             const unsigned xo = x_off + (unsigned)ks * 32;
@@ -146,8 +170,8 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dwconv_mfma_wgrad_vwave_kernel(
     for (int i = lane; i < 32 * 64 / 4; i += 64) ((u32x4*)tile)[i] = u32x4{0u, 0u, 0u, 0u};
     __builtin_amdgcn_wave_barrier();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    const bool col_ok = l31 < p.H;
-    const int o_max = p.H;
+    const bool col_ok = l31 < (HORIZ ? p.W : p.H);
+    const int o_max = HORIZ ? p.W : p.H;
     float* wr = tile + (4 * lhi) * 64 + (l31 - 4 * lhi + 31);
     // (written out twice instead of a lambda over the accumulator array: taking its address costs registers in the plane loop)
 #define SLAK_VW_DIAG(AC, KL_, PADL_, OUT_)                                                                                             \
@@ -162,7 +186,7 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dwconv_mfma_wgrad_vwave_kernel(
             float part[4] = {0.f, 0.f, 0.f, 0.f};                                                                                      \
             _Pragma("unroll") for (int o = 0; o < 32; ++o) part[o & 3] += tile[o * 64 + lane];                                         \
             const int tau = lane - 31 + (PADL_);                                                                                       \
-            if (tau >= 0 && tau < (KL_)) (OUT_)[tau * MF_TAPS + g] = (part[0] + part[1]) + (part[2] + part[3]);                        \
+            if (tau >= 0 && tau < (KL_)) (OUT_)[HORIZ ? g * (KL_) + tau : tau * MF_TAPS + g] = (part[0] + part[1]) + (part[2] + part[3]); \
         }                                                                                                                              \
         __builtin_amdgcn_wave_barrier();                                                                                               \
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                                             \
@@ -181,14 +205,20 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dwconv_mfma_wgrad_vwave_kernel(
 }
 
 // ------------------------------------------------------------------------------------------------------------
+static bool hwave_enabled() {                  // SLAK_MFMA_HWAVE=0 keeps the stack kernel for the 5 x K weight gradient on these planes (A/B testing)
+    static const bool v = [] { const char* e = getenv("SLAK_MFMA_HWAVE"); return !(e && e[0] == '0'); }();
+    return v;
+}
 static bool vwave_enabled() {                  // SLAK_MFMA_VWAVE=0 keeps the transposing kernel on these planes (A/B testing)
     static const bool v = [] { const char* e = getenv("SLAK_MFMA_VWAVE"); return !(e && e[0] == '0'); }();
     return v;
 }
 static bool fill_vwave_params(WgradWaveParams& p, const ConvDims& d, int resident_wgs) {
     p.N = d.N; p.C = d.C; p.H = d.H; p.W = d.W; p.kh = d.kh; p.kw = d.kw;
-    p.KL = d.kh; p.padL = p.KL / 2;
-    if (d.kw != MF_TAPS || d.kh <= d.kw || d.kh > 63 || !(d.kh & 1)) return false;
+    const bool horiz = d.kh == MF_TAPS && d.kw > MF_TAPS;
+    p.KL = horiz ? d.kw : d.kh; p.padL = p.KL / 2;
+    if (horiz) { if (d.kw > 63 || !(d.kw & 1)) return false; }
+    else if (d.kw != MF_TAPS || d.kh <= d.kw || d.kh > 63 || !(d.kh & 1)) return false;
     if (d.H < 15 || d.H > 32 || (d.W & 1) || d.W < 16 || d.W > 32) return false;      // (smaller planes: the plane-pair kernels)
     p.DC = (d.W + 7) / 8;
     p.CPR = p.DC + 1; if (!(p.CPR & 1)) ++p.CPR;                      // odd: conflict-free row-per-lane 16-byte reads
@@ -206,6 +236,7 @@ static size_t vwave_lds_bytes(const WgradWaveParams& p) { return (size_t)MF_WAVE
 
 bool dwconv_mfma_wgrad_vwave_supported(const ConvDims& d, int dy_dt, int x_dt) {
     if (!vwave_enabled() || dy_dt != x_dt || (x_dt != SLAK_BF16 && x_dt != SLAK_F16)) return false;
+    if (d.kh == MF_TAPS && d.kw > MF_TAPS && !hwave_enabled()) return false;
     WgradWaveParams p;
     return fill_vwave_params(p, d, 512);
 }
@@ -214,9 +245,9 @@ size_t dwconv_mfma_wgrad_vwave_workspace(const ConvDims& d) {
     return align_up((size_t)((d.N + 2 * MF_WAVES - 1) / (2 * MF_WAVES) + 1) * d.C * (d.kh * d.kw + MF_TAPS * MF_TAPS) * sizeof(float), 256);     // slices <= ceil(N / 8); PAIR records
 }
 
-template <typename T, bool PAIR>
+template <typename T, bool PAIR, bool HORIZ = false>
 static int launch_vwave_t(WgradWaveParams& p, const ConvDims& d, size_t ws_bytes, hipStream_t st) {
-    auto k = dwconv_mfma_wgrad_vwave_kernel<T, PAIR>;
+    auto k = HORIZ ? dwconv_mfma_wgrad_vwave_kernel<T, false, true> : dwconv_mfma_wgrad_vwave_kernel<T, PAIR, false>;
     static const int wgs_per_cu = [] { const char* e = getenv("SLAK_VWAVE_WGS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 2; }();
     fill_vwave_params(p, d, wgs_per_cu * mfma_cu_count());
     const size_t lds = vwave_lds_bytes(p);
@@ -236,6 +267,11 @@ int launch_dwconv_mfma_wgrad_vwave(const void* dy, int dy_dt, const void* x, int
     p.dy = dy; p.x = x; p.partial = (float*)ws; p.dw = dw; p.dy2 = dy2; p.dw2 = dw2;
     p.counters = wgrad_arrival_counters(d.C);
     if (!p.counters) return SLAK_ERR_UNSUPPORTED;
+    const bool horiz = d.kh == MF_TAPS && d.kw > MF_TAPS;
+    if (horiz) {
+        if (dy2 || dw2) return SLAK_ERR_UNSUPPORTED;
+        return x_dt == SLAK_BF16 ? launch_vwave_t<bf16_t, false, true>(p, d, ws_bytes, st) : launch_vwave_t<f16_t, false, true>(p, d, ws_bytes, st);
+    }
     if (dy2 && dw2) return x_dt == SLAK_BF16 ? launch_vwave_t<bf16_t, true>(p, d, ws_bytes, st) : launch_vwave_t<f16_t, true>(p, d, ws_bytes, st);
     return x_dt == SLAK_BF16 ? launch_vwave_t<bf16_t, false>(p, d, ws_bytes, st) : launch_vwave_t<f16_t, false>(p, d, ws_bytes, st);
 }

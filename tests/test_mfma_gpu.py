@@ -100,16 +100,18 @@ def test_mfma_forward_dgrad_wgrad_vs_oracle(N, C, H, W, kh, kw, dtype, mfma_only
 
 @pytest.mark.parametrize("N,C,H,W,kh", [(5, 3, 20, 18, 21), (7, 2, 24, 22, 63), (3, 5, 30, 26, 7), (9, 3, 17, 30, 9), (33, 2, 28, 28, 49), (4, 1, 32, 16, 13)])
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-def test_vertical_weight_gradient_one_plane_per_wave(N, C, H, W, kh, dtype, gpu):
-    """dwconv_mfma_wgrad_vwave_kernel (K x 5 on planes of <= 32 rows; rows travel through registers as dword-aligned 16-byte pieces)
-    on widths whose last piece holds 1, 3 or 4 dwords of the row, against the oracle; reproducible bit for bit."""
+@pytest.mark.parametrize("horizontal", [False, True])
+def test_vertical_weight_gradient_one_plane_per_wave(N, C, H, W, kh, dtype, horizontal, gpu):
+    """dwconv_mfma_wgrad_vwave_kernel (K x 5, and 5 x K with transposing reads, on planes of <= 32 rows; rows travel through registers as
+    dword-aligned 16-byte pieces) on widths whose last piece holds 1, 3 or 4 dwords of the row, against the oracle; reproducible bit for bit."""
     ops = _ops()
     torch.manual_seed(N * 31 + W)
     x = torch.randn(N, C, H, W, device=gpu).to(dtype)
     dy = torch.randn(N, C, H, W, device=gpu).to(dtype)
-    w = torch.randn(C, 1, kh, 5, device=gpu) * 0.05
+    kh, kw = (5, kh) if horizontal else (kh, 5)
+    w = torch.randn(C, 1, kh, kw, device=gpu) * 0.05
     dw = ops.dwconv2d_backward_filter(dy, x, w)
-    ref = oracle.dwconv2d_bwd_filter(_round(dy, dtype), _round(x, dtype), kh, 5)
+    ref = oracle.dwconv2d_bwd_filter(_round(dy, dtype), _round(x, dtype), kh, kw)
     err = np.abs(dw.double().cpu().numpy() - ref).max()
     assert err <= 1e-5 * max(1.0, np.abs(ref).max()) * max(1.0, (N * H * W) ** 0.5 / 30), err
     assert torch.equal(dw, ops.dwconv2d_backward_filter(dy, x, w))
