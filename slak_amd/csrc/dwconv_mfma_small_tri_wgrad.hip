@@ -264,6 +264,46 @@ __global__ __launch_bounds__(MF_THREADS) void dwconv_mfma_small_tri_wgrad_kernel
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
         diag(ah, false, p.W, p.K, p.K, res + nt_long);
+        if (!NARROW && p.W == 14) {
+            // 5 x 5 branch on 14-wide planes by rotations as well: column slots 0..7 hold columns 0..7, slots 10..15 columns 8..13 (the row's
+            // second 16-byte piece starts at column 6), so an entry's diagonal is its slot difference, minus 2 where the x slot is in the
+            // upper half and the dY slot in the lower, plus 2 the other way round.  The halves of the dY slots are whole 16-lane rows (4 g4 + e),
+            // so the correction is one more row-masked rotation of the partial sums of the lower / upper x slots; only |d| <= 2 is needed.
+            auto ror = [](float v, auto ctrl) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x120 + decltype(ctrl)::value, 0xf, 0xf, false)); };
+            auto rows = [](float v) {                              // 16-lane row g4: left by 4 g4
+                int ti = __float_as_int(v);
+                ti = __builtin_amdgcn_update_dpp(ti, ti, 0x120 + 12, 0x2, 0xf, false);
+                ti = __builtin_amdgcn_update_dpp(ti, ti, 0x120 + 8, 0x4, 0xf, false);
+                ti = __builtin_amdgcn_update_dpp(ti, ti, 0x120 + 4, 0x8, 0xf, false);
+                return __int_as_float(ti);
+            };
+            auto vslot = [](int sl) { return sl < 8 || sl >= 10; };
+            bool oklo[4], okhi[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const bool ok = vslot(i16) && vslot(4 * g4 + e); oklo[e] = ok && i16 < 8; okhi[e] = ok && i16 >= 8; }
+            const int d = i16 < 8 ? i16 : i16 - 16, tau = d + 2;
+            const bool emit = lane < 16 && tau >= 0 && tau < MF_TAPS;
+            float* const out = res + 2 * nt_long;
+#pragma unroll
+            for (int r = 0; r < MF_TAPS; ++r) {
+                float lo = oklo[0] ? as[r][0] : 0.f, hi = okhi[0] ? as[r][0] : 0.f;
+                lo += ror(oklo[1] ? as[r][1] : 0.f, std::integral_constant<int, 15>{}); hi += ror(okhi[1] ? as[r][1] : 0.f, std::integral_constant<int, 15>{});
+                lo += ror(oklo[2] ? as[r][2] : 0.f, std::integral_constant<int, 14>{}); hi += ror(okhi[2] ? as[r][2] : 0.f, std::integral_constant<int, 14>{});
+                lo += ror(oklo[3] ? as[r][3] : 0.f, std::integral_constant<int, 13>{}); hi += ror(okhi[3] ? as[r][3] : 0.f, std::integral_constant<int, 13>{});
+                lo = rows(lo); hi = rows(hi);
+                // dY slots of rows 0, 1 are the lower half, of rows 2, 3 the upper: upper x slots against lower dY slots sit 2 lanes too high,
+                // lower x slots against upper dY slots 2 lanes too low
+                int hi_i = __float_as_int(hi), lo_i = __float_as_int(lo);
+                hi_i = __builtin_amdgcn_update_dpp(hi_i, hi_i, 0x120 + 14, 0x3, 0xf, false);    // rows 0, 1: left by 2
+                lo_i = __builtin_amdgcn_update_dpp(lo_i, lo_i, 0x120 + 2, 0xc, 0xf, false);     // rows 2, 3: right by 2
+                float t = __int_as_float(hi_i) + __int_as_float(lo_i);
+                t += __shfl_xor(t, 16, 64);
+                t += __shfl_xor(t, 32, 64);
+                if (emit) out[r * MF_TAPS + tau] = t;
+            }
+            __builtin_amdgcn_wave_barrier();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        } else
         diag(as, false, p.W, MF_TAPS, MF_TAPS, res + 2 * nt_long);
         float* out = p.partial + ((size_t)slice * p.C + c) * ntot;
         for (int t = lane; t < ntot; t += 64) wgrad_store_partial(&out[t], res[t]);       // taps no diagonal reaches stay 0
