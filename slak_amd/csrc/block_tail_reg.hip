@@ -4,6 +4,8 @@
 // sums (no LDS, no barrier), and only the NHWC side goes through a per-wave LDS tile (rows padded to an odd number of 16-byte chunks:
 // the lane's row is written / read with conflict-free ds_*_b128) to be moved as coalesced 16-byte pieces.  The kernels of
 // block_tail.hip stage BOTH sides in LDS and walk them with 2-byte LDS accesses in three passes: 0.17-0.34 of the HBM roofline.
+// Small planes (P <= 256: the 14 x 14 and 7 x 7 stages) take a second family further down (`*_chan_kernel`, `*_chan1_kernel`): a wave per (image,
+// channel group, 64 pixel pairs or pixels) -- the pixel tiles of this geometry shrink to 16 pixels per wave on C = 384, i.e. 64-byte NCHW runs.
 #include "slak_common.h"
 #include <stdlib.h>
 #include "mfma_common.h"

@@ -1,5 +1,6 @@
-// slak_amd/csrc/dwconv_mfma_wgrad_vwave.hip -- MFMA weight gradient of the VERTICAL kernels (K x 5) on planes of at most 32 rows
-// (the 28 x 28 stage of SLaK: 49 x 5), one plane per WAVE and step, nothing transposed, no workgroup barrier in the loop.
+// slak_amd/csrc/dwconv_mfma_wgrad_vwave.hip -- MFMA weight gradients on planes of at most 32 rows (the 28 x 28 stage of SLaK), one plane per
+// WAVE and step, no workgroup barrier in the loop: the VERTICAL kernels (K x 5; PAIR: the block's 5 x 5 kernel in the same launch) with
+// nothing transposed, and (HORIZ) the horizontal kernels (5 x K) with transposing LDS reads.  The vertical case:
 //
 //   G_r[o, i] = sum_{n,u} dY[o, u] * X[i, u + r - 2]      (o, i = image rows, u = image columns)      dw[tau, r] = sum_o G_r[o, o+tau-padL]
 // The arithmetic is dwconv_mfma_wgrad_vrows.hip's: the contraction index u runs along image rows, both operands are plain 16-byte LDS
