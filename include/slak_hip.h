@@ -262,20 +262,26 @@ int slak_ln_channels_first_backward(const void* g, int g_dtype, const void* x, i
 /* ---------------------------------------------------------------- next row: branch BatchNorms + adds
  * out = BN1(y1) + BN2(y2) + BN3(y3) of ReparamLargeKernelConv (models/SLaK.py:38-47, :92-95) as one statistics pass, a per-channel
  * finalise and one apply pass; backward likewise (dy_b is affine in (dout, y_b) per channel).  y_b, out, dout, dy_b: bf16 NCHW,
- * P = H*W.  The *_sums calls return THIS RANK's per-channel sums; under SyncBatchNorm the caller all-reduces them (6C / 4C floats,
- * one collective per block instead of three gathers) and passes the global sums and the global element count to the *_apply calls
- * (`count`, or `count_dev` -- a device float, e.g. the all-reduced count -- when non-NULL: no host synchronisation). */
+ * P = H*W.  The *_sums calls return THIS RANK's per-channel sums; under SyncBatchNorm the caller all-reduces them (6C doubles / 4C
+ * floats, one collective per block and direction instead of three gathers) and passes the global sums and the global element count to the
+ * *_apply calls (`count`, or `count_dev` -- a device double, e.g. the all-reduced count -- when non-NULL: no host synchronisation).
+ * Round 3: the forward statistics are CENTRED -- slice sums of (y - k) with k the slice's first element, combined as doubles; raw fp32
+ * rows from the conv launches (pre_sums) are added in double and a channel with mean^2 > 1024 var is re-measured by a two-pass read --
+ * so the variance survives |mean| / std of 1e3 and more (nn.BatchNorm2d's Welford statistics do); the backward sums are the centred
+ * products sum dout * (y_b - mean_b). */
 size_t slak_bn3_workspace_bytes(int N, int C);
-int slak_bn3_forward_sums(const void* y1, const void* y2, const void* y3, float* local_sums /*[C][6]*/, int N, int C, int P,
-                          void* workspace, size_t workspace_bytes, void* stream);
-int slak_bn3_forward_apply(const void* y1, const void* y2, const void* y3, const float* global_sums, double count, const float* count_dev,
+int slak_bn3_forward_sums(const void* y1, const void* y2, const void* y3, double* local_sums /*[C][6]: sum y_b, sum y_b^2*/, int N, int C, int P,
+                          void* workspace, size_t workspace_bytes, void* stream,
+                          const float* const* pre_sums /* NULL or as in slak_bn3_forward_local */, const int* pre_rows, int pre_stride);
+int slak_bn3_forward_apply(const void* y1, const void* y2, const void* y3, const double* global_sums, double count, const double* count_dev,
                            const float* const* gamma_host3, const float* const* beta_host3, float* const* running_mean_host3,
                            float* const* running_var_host3, float eps, float momentum, int training, int update_running,
                            float* coef /*[C][4]*/, float* stats /*[C][6]*/, void* out, int N, int C, int P, void* stream);
-int slak_bn3_backward_sums(const void* dout, const void* y1, const void* y2, const void* y3, float* local_sums /*[C][4]*/,
+int slak_bn3_backward_sums(const void* dout, const void* y1, const void* y2, const void* y3, const float* stats /*[C][6] of the forward*/,
+                           float* local_sums /*[C][4]: sum dout, sum dout*(y_b - mean_b)*/,
                            int N, int C, int P, void* workspace, size_t workspace_bytes, void* stream);
 int slak_bn3_backward_apply(const void* dout, const void* y1, const void* y2, const void* y3, const float* global_sums,
-                            const float* local_sums, double count, const float* count_dev /* device count overrides `count` */,
+                            const float* local_sums, double count, const double* count_dev /* device count overrides `count` */,
                             const float* stats, const float* const* gamma_host3,
                             float* bcoef /*[C][9]*/, float* dgamma /*[3][C]*/, float* dbeta /*[3][C]*/,
                             void* dy1, void* dy2, void* dy3, int N, int C, int P, void* stream);

@@ -75,10 +75,10 @@ SIGNATURES = {
     "slak_ema_update": (_i, [_vp, _d, _vp]),
     "slak_ema_plan_destroy": (_i, [_vp]),
     "slak_bn3_workspace_bytes": (_sz, [_i, _i]),
-    "slak_bn3_forward_sums": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _sz, _vp]),
+    "slak_bn3_forward_sums": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _sz, _vp, ctypes.POINTER(_vp), ctypes.POINTER(_i), _i]),
     "slak_bn3_forward_apply": (_i, [_vp, _vp, _vp, _vp, _d, _vp, ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(_vp),
                                     ctypes.c_float, ctypes.c_float, _i, _i, _vp, _vp, _vp, _i, _i, _i, _vp]),
-    "slak_bn3_backward_sums": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _sz, _vp]),
+    "slak_bn3_backward_sums": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _sz, _vp]),
     "slak_bn3_backward_apply": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _d, _vp, _vp, ctypes.POINTER(_vp), _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "slak_bn3_forward_local": (_i, [_vp, _vp, _vp, ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(_vp),
                                     ctypes.c_float, ctypes.c_float, _i, _vp, _vp, _vp, _i, _i, _i, _vp, _sz, _vp, ctypes.POINTER(_vp), ctypes.POINTER(_i), _i]),

@@ -142,11 +142,11 @@ class _TriDwConv(torch.autograd.Function):
             raise RuntimeError("tri_dwconv expects filters (C,1,K,5), (C,1,5,K), (C,1,5,5)")
         L = _lib.lib()
         dt = ops._DT.get(x.dtype)
-        # 1: the one-launch kernels of the 14x14 class.  (2: the one-launch kernels of the 56x56 / 28x28 class exist
-        # (slak_dwconv2d_tri_*) but lose to the per-branch kernels on MI355X -- twelve waves in lockstep, 134 vs 110 us forward at
-        # 128x96x56x56 -- so those planes run three launches, the data gradient accumulating in place.)
-        tri = (dt is not None and all(w.dtype == torch.float32 and w.is_contiguous() for w in (wv, wh, ws))
-               and L.slak_dwconv2d_tri_supported(dt, N, C, H, W, K) == (2 if use_big_tri else 1))
+        # 1: one-launch kernels that win (14x14 / 7x7 class; round 3: the four-wave-team kernels of the 56x56 / 28x28 class).
+        # 2: the round-2 twelve-wave kernels of the 56x56 / 28x28 class (lost to three launches: dev switch only).
+        kind = L.slak_dwconv2d_tri_supported(dt, N, C, H, W, K) if dt is not None else 0
+        tri = (all(w.dtype == torch.float32 and w.is_contiguous() for w in (wv, wh, ws))
+               and (kind == 1 or (use_big_tri and kind == 2)))
         stats = None
         if tri:
             yv, yh, ys = torch.empty_like(x), torch.empty_like(x), torch.empty_like(x)
@@ -266,8 +266,9 @@ def tri_dwconv_sum(x, w_vertical, w_horizontal, w_small, bias=None):
         L = _lib.lib()
         dt = ops._DT.get(x.dtype)
         ws = [w.detach().float().contiguous() for w in (w_vertical, w_horizontal, w_small)]
-        if (dt is not None and ws[0].shape == (C, 1, K, 5) and ws[1].shape == (C, 1, 5, K) and ws[2].shape == (C, 1, 5, 5)
-                and bool(L.slak_dwconv2d_tri_supported(dt, N, C, H, W, K))):
+        kind = L.slak_dwconv2d_tri_supported(dt, N, C, H, W, K) if dt is not None else 0
+        if (ws[0].shape == (C, 1, K, 5) and ws[1].shape == (C, 1, 5, K) and ws[2].shape == (C, 1, 5, 5)
+                and (kind == 1 or (use_big_tri and kind == 2))):          # the same policy as the training node
             fl = [w.flip(2, 3).contiguous() for w in ws]
             y = torch.empty_like(x)
             with torch.cuda.device(x.device):
@@ -342,8 +343,10 @@ class BnCounterPool:
     """The step counters (``num_batches_tracked``) of many BatchNorms as views of ONE int64 tensor that is bumped by a single launch per
     forward pass (nn.BatchNorm / the reference bump one 0-dim tensor per BatchNorm: 54 launches per SLaK-T step; ``torch._foreach_add_``
     takes its slow path for them).  Each BatchNorm keeps its own 0-dim ``num_batches_tracked`` buffer (state-dict layout unchanged); the
-    owner (slak_model.SLaK) calls ``begin_forward()`` once per training forward, the fused BatchNorm op calls ``bump_once()``.  A buffer
-    that stopped being a view (``module.to()`` re-creates buffers) is simply not covered any more and is bumped the ordinary way."""
+    owner (slak_model.SLaK) brackets a training forward with ``begin_forward()`` / ``end_forward()``; inside it the first fused BatchNorm op
+    to call ``bump_once()`` bumps every counter, the others find it done.  OUTSIDE such a forward (a stage or a block called on its own, a
+    feature extractor, a second sub-forward) ``bump_once()`` returns False and the op bumps just its own three counters the ordinary way.
+    A buffer that stopped being a view (``module.to()`` re-creates buffers) is not covered any more and is bumped the ordinary way too."""
 
     def __init__(self, bns):
         self.bns = list(bns)
@@ -352,8 +355,8 @@ class BnCounterPool:
             bn._buffers["num_batches_tracked"] = self.flat[i]
             bn._slak_ctr_pool = self
             bn._slak_ctr_index = i
-        self.generation = 0
-        self.bumped = -1
+        self.active = False       # inside a forward that the owner manages
+        self.pending = False      # ... whose one bump has not happened yet
 
     def _is_view(self, bn):
         t = bn._buffers.get("num_batches_tracked")
@@ -366,12 +369,27 @@ class BnCounterPool:
         return self._is_view(self.bns[0]) and self._is_view(self.bns[-1])
 
     def begin_forward(self):
-        self.generation += 1
+        self.active = True
+        self.pending = True
+
+    def end_forward(self):
+        self.active = False
+        self.pending = False
 
     def bump_once(self):
-        if self.bumped != self.generation:
+        """True: the counters of this forward are taken care of (by this call or an earlier one); False: not in a managed forward."""
+        if not self.active:
+            return False
+        if self.pending:
             self.flat.add_(1)
-            self.bumped = self.generation
+            self.pending = False
+        return True
+
+
+def _sync_bn_all_reduce(buf, group):
+    """The SyncBatchNorm statistics exchange of one block and direction (6C + 1 doubles forward, 4C floats backward)."""
+    import torch.distributed as dist
+    dist.all_reduce(buf, group=group)
 
 
 class _BranchBN3(torch.autograd.Function):
@@ -393,8 +411,8 @@ class _BranchBN3(torch.autograd.Function):
         momentum = bns[0].momentum
         ctrs = [bn.num_batches_tracked for bn in bns if bn.track_running_stats and bn.num_batches_tracked is not None]
         pool = getattr(bns[0], "_slak_ctr_pool", None)
-        if pool is not None and len(ctrs) == len(bns) and pool.covers(bns):
-            pool.bump_once()                                      # every pooled counter of the model in one launch per forward pass
+        if pool is not None and len(ctrs) == len(bns) and pool.covers(bns) and pool.bump_once():
+            pass                                                  # every pooled counter of the model in one launch per managed forward pass
         elif ctrs:
             torch._foreach_add_(ctrs, 1)
         if momentum is None:                                     # cumulative moving average, as nn.BatchNorm
@@ -417,15 +435,17 @@ class _BranchBN3(torch.autograd.Function):
             ctx.count = float(N * P)
             ctx.count_dev = None
             return out
-        sums = torch.empty(C * 6 + 1, dtype=torch.float32, device=dev)
+        sums = torch.empty(C * 6 + 1, dtype=torch.float64, device=dev)      # sum y_b, sum y_b^2 per channel as doubles + the element count
+        pre_args = ((_ptr3(list(pre)), (ctypes.c_int * 3)(*[int(t.shape[0]) for t in pre]), int(pre[0].stride(1))) if pre is not None
+                    else (None, None, 0))                                 # the conv launches' rows feed the exchange buffer: no read pass
         with torch.cuda.device(dev):
             _lib.check(L.slak_bn3_forward_sums(y1.data_ptr(), y2.data_ptr(), y3.data_ptr(), sums.data_ptr(), N, C, P,
-                                               ws.data_ptr() if ws is not None else None, nb, _stream(dev)), "slak_bn3_forward_sums")
+                                               ws.data_ptr() if ws is not None else None, nb, _stream(dev), *pre_args), "slak_bn3_forward_sums")
         count = float(N * P)
         count_dev = None
         if group is not None:
             sums[C * 6:].fill_(count)
-            dist.all_reduce(sums, group=group)
+            _sync_bn_all_reduce(sums, group)
             count_dev = sums[C * 6:]                                 # global element count, stays on the device (no host sync)
         coef = torch.empty(C * 4, dtype=torch.float32, device=dev)
         stats = torch.empty(C * 6, dtype=torch.float32, device=dev)
@@ -465,12 +485,12 @@ class _BranchBN3(torch.autograd.Function):
             return d1, d2, d3, dgamma[0], dbeta[0], dgamma[1], dbeta[1], dgamma[2], dbeta[2], None, None, None
         lsums = torch.empty(C * 4, dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
-            _lib.check(L.slak_bn3_backward_sums(dout.data_ptr(), y1.data_ptr(), y2.data_ptr(), y3.data_ptr(), lsums.data_ptr(), N, C, P,
+            _lib.check(L.slak_bn3_backward_sums(dout.data_ptr(), y1.data_ptr(), y2.data_ptr(), y3.data_ptr(), stats.data_ptr(), lsums.data_ptr(), N, C, P,
                                                 ws.data_ptr() if ws is not None else None, nb, _stream(dev)), "slak_bn3_backward_sums")
         gsums = lsums
         if ctx.group is not None:
             gsums = lsums.clone()
-            dist.all_reduce(gsums, group=ctx.group)
+            _sync_bn_all_reduce(gsums, ctx.group)
         bcoef = torch.empty(C * 9, dtype=torch.float32, device=dev)
         dgamma = torch.empty(3, C, dtype=torch.float32, device=dev)
         dbeta = torch.empty(3, C, dtype=torch.float32, device=dev)
@@ -497,7 +517,7 @@ def branch_bn3(y1, y2, y3, bn1, bn2, bn3, stats=None):
             if dist.get_world_size(pg) > 1:
                 group = pg
         pre = None
-        if (stats is not None and group is None and len(stats) == 3
+        if (stats is not None and len(stats) == 3          # (SyncBatchNorm too: the rows feed the all-reduce buffer)
                 and all(t.dim() == 3 and t.shape[0] > 0 and t.shape[1] == y1.shape[1] and t.dtype == torch.float32 and t.stride(2) == 1
                         and t.stride(0) == t.shape[1] * t.stride(1) for t in stats) and len({t.stride(1) for t in stats}) == 1):
             pre = tuple(stats)

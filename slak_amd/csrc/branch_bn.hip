@@ -67,13 +67,18 @@ __device__ __forceinline__ void store8(uint16_t* __restrict__ row, int p, int P,
 
 // Channel-slice sums (round 2; the round-1 row-sum kernels reduced every (n, c) row on its own -- 36 shuffles per row -- and left N partial
 // rows per channel): a wavefront owns channel c and the images [s*per, (s+1)*per) of the batch; its lanes stride over the (image, 16-byte
-// chunk) pairs of that slice and keep plain per-lane sums, reduced ONCE at the end: part[(s*C + c)*K + k].  K = 6 (forward: sum y_b,
-// sum y_b^2) or 4 (backward: sum dout, sum dout*y_b).
+// chunk) pairs of that slice and keep plain per-lane sums, reduced ONCE at the end.
+//   forward  (K = 9): part[(s*C + c)*9 + 3b + {0,1,2}] = k_b, sum (y_b - k_b), sum (y_b - k_b)^2 with the SHIFT k_b = the slice's first
+//            element of the channel (round 3): E[y^2] - mean^2 on raw fp32 sums loses (mean/std)^2 * 1e-6 of the variance -- everything at
+//            mean/std ~ 1e3 -- while shifted sums lose only ((mean_slice - k)/std)^2 * 1e-6; the slices are combined in double
+//            (bn3_local_stats) as sums of y and y^2, which 53 bits carry to mean/std ~ 1e6;
+//   backward (K = 4): part[..] = sum dout, sum dout * (y_b - mean_b): the centred product, so dgamma = invstd * sum needs no
+//            "sum dout*y - mean * sum dout" cancellation either.
 template <bool BWD>
 __global__ __launch_bounds__(BN_THREADS) void bn3_chansums(const uint16_t* __restrict__ dout, const uint16_t* __restrict__ y1,
                                                          const uint16_t* __restrict__ y2, const uint16_t* __restrict__ y3,
-                                                         float* __restrict__ part, int N, int C, int P, int S, int per) {
-    constexpr int K = BWD ? 4 : 6;
+                                                         const float* __restrict__ stats, float* __restrict__ part, int N, int C, int P, int S, int per) {
+    constexpr int K = BWD ? 4 : 9;
     const int lane = threadIdx.x & 63, wv = blockIdx.x * (BN_THREADS / 64) + (threadIdx.x >> 6);
     if (wv >= C * S) return;
     const int c = wv % C, sl = wv / C;
@@ -81,26 +86,41 @@ __global__ __launch_bounds__(BN_THREADS) void bn3_chansums(const uint16_t* __res
     const int vec = (P & 7) == 0 ? 2 : ((P & 3) == 0 ? 1 : 0);
     const int cpr = (P + 7) / 8;                                   // 16-byte chunks per row
     float s[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float k1, k2, k3;                                              // forward: the slice's shift; backward: the batch means
+    if constexpr (BWD) { k1 = stats[c * 6]; k2 = stats[c * 6 + 2]; k3 = stats[c * 6 + 4]; }
+    else { const size_t b0 = ((size_t)n0 * C + c) * P; k1 = bnf(y1[b0]); k2 = bnf(y2[b0]); k3 = bnf(y3[b0]); }
     int n = n0, ch = lane;
     while (ch >= cpr) { ch -= cpr; ++n; }
     while (n < n1) {
         const size_t base = ((size_t)n * C + c) * P;
         float a[8], b[8], d[8];
         load8(y1 + base, ch * 8, P, vec, a); load8(y2 + base, ch * 8, P, vec, b); load8(y3 + base, ch * 8, P, vec, d);
+        const int nv = min(8, P - ch * 8);                         // elements of this chunk inside the row (load8 pads with zeros)
         if constexpr (BWD) {
             float g[8];
-            load8(dout + base, ch * 8, P, vec, g);
+            load8(dout + base, ch * 8, P, vec, g);                 // g = 0 beyond the row: the padded products vanish
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { s[0] += g[e]; s[1] += g[e] * a[e]; s[2] += g[e] * b[e]; s[3] += g[e] * d[e]; }
+            for (int e = 0; e < 8; ++e) { s[0] += g[e]; s[1] += g[e] * (a[e] - k1); s[2] += g[e] * (b[e] - k2); s[3] += g[e] * (d[e] - k3); }
         } else {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { s[0] += a[e]; s[1] += a[e] * a[e]; s[2] += b[e]; s[3] += b[e] * b[e]; s[4] += d[e]; s[5] += d[e] * d[e]; }
+            for (int e = 0; e < 8; ++e) {
+                const bool in = e < nv;
+                const float da = in ? a[e] - k1 : 0.f, db = in ? b[e] - k2 : 0.f, dd = in ? d[e] - k3 : 0.f;
+                s[0] += da; s[1] += da * da; s[2] += db; s[3] += db * db; s[4] += dd; s[5] += dd * dd;
+            }
         }
         ch += 64;
         while (ch >= cpr) { ch -= cpr; ++n; }
     }
+    float* o = part + ((size_t)sl * C + c) * K;
+    if constexpr (BWD) {
 #pragma unroll
-    for (int k = 0; k < K; ++k) { const float t = bn_wave_sum(s[k]); if (lane == 0) part[((size_t)sl * C + c) * K + k] = t; }
+        for (int k = 0; k < 4; ++k) { const float t = bn_wave_sum(s[k]); if (lane == 0) o[k] = t; }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) s[k] = bn_wave_sum(s[k]);
+        if (lane == 0) { o[0] = k1; o[1] = s[0]; o[2] = s[1]; o[3] = k2; o[4] = s[2]; o[5] = s[3]; o[6] = k3; o[7] = s[4]; o[8] = s[5]; }
+    }
 }
 static void bn_slices(int N, int C, int* S, int* per) {            // ~16384 wavefronts (a full machine of eight per SIMD, twice over), whole images per slice
     static const int waves = [] { const char* e = getenv("SLAK_BN_WAVES"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 16384; }();
@@ -119,36 +139,51 @@ __global__ __launch_bounds__(64) void bn3_colreduce(const float* __restrict__ ro
     for (int k = 0; k < K; ++k) { const float t = bn_wave_sum(s[k]); if (lane == 0) sums[c * K + k] = t; }
 }
 
-// Forward finalise.  sums[c][6] are GLOBAL sums (after the SyncBN all-reduce), count = global N*P.
-// coef[c][0..3] = scale_1, scale_2, scale_3, shift;  stats[c][0..5] = mean_b, invstd_b (saved for backward);
-// running stats updated in place like nn.BatchNorm2d (momentum, unbiased variance).
+__device__ __forceinline__ double bn_wave_sum_d(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// Forward finalise of ONE channel from sums in double (sd[2b] = sum y_b, sd[2b+1] = sum y_b^2 over `count` elements, this rank's or
+// -- after the SyncBatchNorm all-reduce -- everybody's): coef[c][0..3] = scale_1, scale_2, scale_3, shift;  stats[c][0..5] = mean_b,
+// invstd_b (saved for backward); running stats updated in place like nn.BatchNorm2d (momentum, unbiased variance).
 struct Bn3Params {
     const float* gamma[3]; const float* beta[3];
     float* running_mean[3]; float* running_var[3];
 };
-__global__ void bn3_finalize_fwd(const float* __restrict__ sums, Bn3Params bp, float* __restrict__ coef, float* __restrict__ stats,
-                                 int C, float count, const float* __restrict__ count_dev, float eps, float momentum, int update_running) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    if (count_dev) count = *count_dev;                             // all-reduced element count (SyncBatchNorm), stays on the device
+__device__ __forceinline__ void bn3_finalize_channel(const double (&sd)[6], double count, int c, const Bn3Params& bp, float* __restrict__ coef,
+                                                     float* __restrict__ stats, float eps, float momentum, int update_running) {
     float shift = 0.f;
 #pragma unroll
     for (int b = 0; b < 3; ++b) {
-        const float mean = sums[c * 6 + 2 * b] / count;
-        float var = sums[c * 6 + 2 * b + 1] / count - mean * mean;
-        var = var > 0.f ? var : 0.f;
+        const double meand = sd[2 * b] / count;
+        double vard = sd[2 * b + 1] / count - meand * meand;
+        vard = vard > 0.0 ? vard : 0.0;
+        const float mean = (float)meand, var = (float)vard;
         const float inv = 1.0f / sqrtf(var + eps);
         const float sc = bp.gamma[b][c] * inv;
         coef[c * 4 + b] = sc;
         shift += bp.beta[b][c] - mean * sc;
         stats[c * 6 + 2 * b] = mean; stats[c * 6 + 2 * b + 1] = inv;
         if (update_running) {
-            const float unb = count > 1.f ? var * count / (count - 1.f) : var;
+            const float unb = count > 1.0 ? (float)(vard * count / (count - 1.0)) : var;
             bp.running_mean[b][c] = (1.f - momentum) * bp.running_mean[b][c] + momentum * mean;
             bp.running_var[b][c] = (1.f - momentum) * bp.running_var[b][c] + momentum * unb;
         }
     }
     coef[c * 4 + 3] = shift;
+}
+// sums[C][6] doubles: GLOBAL sums (after the SyncBatchNorm all-reduce); count_dev: the all-reduced element count (a device double)
+__global__ void bn3_finalize_fwd(const double* __restrict__ sums, Bn3Params bp, float* __restrict__ coef, float* __restrict__ stats,
+                                 int C, double count, const double* __restrict__ count_dev, float eps, float momentum, int update_running) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    if (count_dev) count = *count_dev;                             // stays on the device: no host synchronisation
+    double sd[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) sd[k] = sums[c * 6 + k];
+    bn3_finalize_channel(sd, count, c, bp, coef, stats, eps, momentum, update_running);
 }
 // Eval mode: coefficients from the running statistics
 __global__ void bn3_finalize_eval(Bn3Params bp, float* __restrict__ coef, int C, float eps) {
@@ -187,66 +222,93 @@ __global__ __launch_bounds__(BN_THREADS) void bn3_apply_fwd(const uint16_t* __re
     }
 }
 
-// Backward finalise.  sums[c][4] GLOBAL: sum dout, sum dout*y_b.  stats[c][6] = mean_b, invstd_b.
-// dgamma_b = invstd_b*(sum dout*y_b - mean_b*sum dout), dbeta_b = sum dout (LOCAL sums give the local parameter gradients that DDP
+// Backward finalise.  sums[c][4] GLOBAL: sum dout, sum dout*(y_b - mean_b).  stats[c][6] = mean_b, invstd_b.
+// dgamma_b = invstd_b * sum dout*(y_b - mean_b), dbeta_b = sum dout (LOCAL sums give the local parameter gradients that DDP
 // then all-reduces, exactly like SyncBatchNorm: the caller passes local sums for the gradients and global sums for the coefficients).
 // bcoef[c][b][0..2] = A, B, C0 with dy_b = A*dout + B*y_b + C0.
 __global__ void bn3_finalize_bwd(const float* __restrict__ gsums, const float* __restrict__ lsums, const float* __restrict__ stats,
                                  Bn3Params bp, float* __restrict__ bcoef, float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                 int C, float count, const float* __restrict__ count_dev) {
+                                 int C, float count, const double* __restrict__ count_dev) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
-    if (count_dev) count = *count_dev;
+    if (count_dev) count = (float)*count_dev;
 #pragma unroll
     for (int b = 0; b < 3; ++b) {
         const float mean = stats[c * 6 + 2 * b], inv = stats[c * 6 + 2 * b + 1], g = bp.gamma[b][c];
-        const float gd = gsums[c * 4], gdy = gsums[c * 4 + 1 + b];
-        const float dgam_g = inv * (gdy - mean * gd);                    // global dgamma (for the input gradient)
+        const float gd = gsums[c * 4], gdy = gsums[c * 4 + 1 + b];      // gdy = sum dout * (y_b - mean_b): centred in bn3_chansums<true>
+        const float dgam_g = inv * gdy;                                  // global dgamma (for the input gradient)
         const float A = g * inv;
         const float B = -g * inv * inv * dgam_g / count;
         bcoef[(c * 3 + b) * 3 + 0] = A;
         bcoef[(c * 3 + b) * 3 + 1] = B;
         bcoef[(c * 3 + b) * 3 + 2] = -A * gd / count - B * mean;
-        dgamma[b * C + c] = inv * (lsums[c * 4 + 1 + b] - mean * lsums[c * 4]);
+        dgamma[b * C + c] = inv * lsums[c * 4 + 1 + b];
         dbeta[b * C + c] = lsums[c * 4];
     }
 }
 
-// Single-process path: the slice reduction and the finalise step of a channel in one wavefront (no all-reduce in between): one launch
-// instead of bn3_colreduce + bn3_finalize_*.
-struct Bn3Pre { const float* rows[3]; int S[3]; int stride; };       // branch b's partial (sum, sum of squares) at rows[b][(n * C + c) * stride + {0, 1}]
-__global__ __launch_bounds__(64) void bn3_colreduce_finalize_fwd(const Bn3Pre pre, Bn3Params bp, float* __restrict__ coef,
-                                                               float* __restrict__ stats, int C, float count, float eps, float momentum,
-                                                               int update_running) {
+// This rank's per-channel sums in double from the partial records -- one wavefront per channel:
+//   shifted records (bn3_chansums<false>: k, sum (y-k), sum (y-k)^2 per slice): exact to double via mean_p = k + S'/n_p,
+//       M2_p = Q' - S'^2/n_p (centred: no cancellation), sum y = n_p mean_p, sum y^2 = M2_p + n_p mean_p^2;
+//   raw records (sum y, sum y^2 in fp32, gathered by the conv launches in their copy-out): added in double; fp32 accumulation inside a
+//       record has already lost (mean/std)^2 * ~1e-6 of the variance, so when mean^2 > 1024 var (never on a normalised network's
+//       branch outputs; harmless below) the channel is RE-MEASURED here: sum (y - mean), sum (y - mean)^2 in a second read of its
+//       planes -- the two-pass algorithm, slow (one wavefront, N*P elements) but exact, instead of a wrong variance.
+// FINAL: single process -- finalise in the same launch (no all-reduce in between); otherwise lsum[c][6] doubles for the exchange.
+struct Bn3Pre { const float* rows[3]; int S[3]; int stride; int shifted; int per; };
+template <bool FINAL>
+__global__ __launch_bounds__(64) void bn3_local_stats(const Bn3Pre pre, const uint16_t* __restrict__ y1, const uint16_t* __restrict__ y2,
+                                                    const uint16_t* __restrict__ y3, int N, int C, int P, double* __restrict__ lsum,
+                                                    Bn3Params bp, float* __restrict__ coef, float* __restrict__ stats, float eps, float momentum,
+                                                    int update_running) {
     const int c = blockIdx.x, lane = threadIdx.x;
-    float s[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int b = 0; b < 3; ++b)
-        for (int n = lane; n < pre.S[b]; n += 64) {
-            const float* r = pre.rows[b] + ((size_t)n * C + c) * pre.stride;
-            s[2 * b] += r[0]; s[2 * b + 1] += r[1];
-        }
-#pragma unroll
-    for (int k = 0; k < 6; ++k) s[k] = bn_wave_sum(s[k]);
-    if (lane != 0) return;
-    float shift = 0.f;
+    const double count = (double)N * P;
+    double sd[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
 #pragma unroll
     for (int b = 0; b < 3; ++b) {
-        const float mean = s[2 * b] / count;
-        float var = s[2 * b + 1] / count - mean * mean;
-        var = var > 0.f ? var : 0.f;
-        const float inv = 1.0f / sqrtf(var + eps);
-        const float sc = bp.gamma[b][c] * inv;
-        coef[c * 4 + b] = sc;
-        shift += bp.beta[b][c] - mean * sc;
-        stats[c * 6 + 2 * b] = mean; stats[c * 6 + 2 * b + 1] = inv;
-        if (update_running) {
-            const float unb = count > 1.f ? var * count / (count - 1.f) : var;
-            bp.running_mean[b][c] = (1.f - momentum) * bp.running_mean[b][c] + momentum * mean;
-            bp.running_var[b][c] = (1.f - momentum) * bp.running_var[b][c] + momentum * unb;
+        double S = 0.0, Q = 0.0;
+        for (int n = lane; n < pre.S[b]; n += 64) {
+            const float* r = pre.rows[b] + ((size_t)n * C + c) * pre.stride;
+            if (pre.shifted) {
+                const int n0 = n * pre.per, n1 = min(n0 + pre.per, N);
+                const double np = (double)(n1 - n0) * P, k = r[0], s1 = r[1], q1 = r[2];
+                const double mean_p = k + s1 / np, m2 = q1 - s1 * s1 / np;
+                S += np * mean_p; Q += (m2 > 0.0 ? m2 : 0.0) + np * mean_p * mean_p;
+            } else { S += (double)r[0]; Q += (double)r[1]; }
         }
+        S = bn_wave_sum_d(S); Q = bn_wave_sum_d(Q);
+        if (!pre.shifted) {
+            const double mean = S / count, var = Q / count - mean * mean;
+            if (mean * mean > 1024.0 * var) {                        // wave-uniform (all lanes hold the reduced sums)
+                const uint16_t* y = b == 0 ? y1 : (b == 1 ? y2 : y3);
+                const float mf = (float)mean;
+                const int vec = (P & 7) == 0 ? 2 : ((P & 3) == 0 ? 1 : 0), cpr = (P + 7) / 8;
+                double D1 = 0.0, D2 = 0.0;
+                for (int n = 0; n < N; ++n) {
+                    const size_t base = ((size_t)n * C + c) * P;
+                    float d1 = 0.f, d2 = 0.f;
+                    for (int ch = lane; ch < cpr; ch += 64) {
+                        float v[8];
+                        load8(y + base, ch * 8, P, vec, v);
+                        const int nv = min(8, P - ch * 8);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) { const float d = e < nv ? v[e] - mf : 0.f; d1 += d; d2 += d * d; }
+                    }
+                    D1 += d1; D2 += d2;
+                }
+                D1 = bn_wave_sum_d(D1); D2 = bn_wave_sum_d(D2);
+                const double mean2 = (double)mf + D1 / count, m2 = D2 - D1 * D1 / count;
+                S = count * mean2; Q = (m2 > 0.0 ? m2 : 0.0) + count * mean2 * mean2;
+            }
+        }
+        sd[2 * b] = S; sd[2 * b + 1] = Q;
     }
-    coef[c * 4 + 3] = shift;
+    if (lane != 0) return;
+    if constexpr (FINAL) bn3_finalize_channel(sd, count, c, bp, coef, stats, eps, momentum, update_running);
+    else {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) lsum[c * 6 + k] = sd[k];
+    }
 }
 __global__ __launch_bounds__(64) void bn3_colreduce_finalize_bwd(const float* __restrict__ rows, int S, const float* __restrict__ stats, Bn3Params bp,
                                                                float* __restrict__ bcoef, float* __restrict__ dgamma, float* __restrict__ dbeta,
@@ -264,8 +326,8 @@ __global__ __launch_bounds__(64) void bn3_colreduce_finalize_bwd(const float* __
 #pragma unroll
     for (int b = 0; b < 3; ++b) {
         const float mean = stats[c * 6 + 2 * b], inv = stats[c * 6 + 2 * b + 1], g = bp.gamma[b][c];
-        const float gd = s[0], gdy = s[1 + b];
-        const float dgam = inv * (gdy - mean * gd);
+        const float gd = s[0], gdy = s[1 + b];                          // sum dout * (y_b - mean_b)
+        const float dgam = inv * gdy;
         const float A = g * inv;
         const float B = -g * inv * inv * dgam / count;
         bcoef[(c * 3 + b) * 3 + 0] = A;
@@ -324,8 +386,8 @@ using namespace slak;
 
 extern "C" {
 
-/* scratch: rows[N*C][6] + sums[C][6] */
-size_t slak_bn3_workspace_bytes(int N, int C) { return (N <= 0 || C <= 0) ? 0 : align_up(((size_t)N * C * 6 + (size_t)C * 6) * sizeof(float), 256); }
+/* scratch: slice records rows[N*C][9] (forward: shift, shifted sum, shifted sum of squares per branch; backward uses [N*C][4]) */
+size_t slak_bn3_workspace_bytes(int N, int C) { return (N <= 0 || C <= 0) ? 0 : align_up(((size_t)N * C * 9 + (size_t)C * 6) * sizeof(float), 256); }
 
 static int bn_args_ok(int N, int C, int P) {
     if (N <= 0 || C <= 0 || P <= 0) return SLAK_ERR_INVALID_ARG;
@@ -333,17 +395,37 @@ static int bn_args_ok(int N, int C, int P) {
     return SLAK_OK;
 }
 
-/* local_sums[C][6] = per-channel sums of y_b and y_b^2 over this rank's batch */
-int slak_bn3_forward_sums(const void* y1, const void* y2, const void* y3, float* local_sums, int N, int C, int P,
-                          void* workspace, size_t workspace_bytes, void* stream) {
-    if (!y1 || !y2 || !y3 || !local_sums) return SLAK_ERR_INVALID_ARG;
+static bool bn_pre_ok(const float* const* pre_sums, const int* pre_rows, int pre_stride) {
+    return !pre_sums || (pre_rows && pre_stride >= 2 && pre_sums[0] && pre_sums[1] && pre_sums[2] && pre_rows[0] > 0 && pre_rows[1] > 0 && pre_rows[2] > 0);
+}
+/* the partial records bn3_local_stats reads: the conv launches' raw rows, or (NULL) a read pass that leaves shifted slice records */
+static void bn_make_pre(Bn3Pre& pre, const float* const* pre_sums, const int* pre_rows, int pre_stride, const void* y1, const void* y2, const void* y3,
+                        int N, int C, int P, void* workspace, hipStream_t st) {
+    if (pre_sums) {
+        for (int b = 0; b < 3; ++b) { pre.rows[b] = pre_sums[b]; pre.S[b] = pre_rows[b]; }
+        pre.stride = pre_stride; pre.shifted = 0; pre.per = 0;
+    } else {
+        int S, per; bn_slices(N, C, &S, &per);
+        hipLaunchKernelGGL(bn3_chansums<false>, dim3((unsigned)((C * S + BN_THREADS / 64 - 1) / (BN_THREADS / 64))), dim3(BN_THREADS), 0, st,
+                           (const uint16_t*)nullptr, (const uint16_t*)y1, (const uint16_t*)y2, (const uint16_t*)y3, (const float*)nullptr, (float*)workspace,
+                           N, C, P, S, per);
+        for (int b = 0; b < 3; ++b) { pre.rows[b] = (const float*)workspace + 3 * b; pre.S[b] = S; }
+        pre.stride = 9; pre.shifted = 1; pre.per = per;
+    }
+}
+
+/* local_sums[C][6] DOUBLES = per-channel sum y_b, sum y_b^2 over this rank's batch (exact to double: shifted slice sums, or the conv
+ * launches' rows `pre_sums` with a two-pass re-measurement of channels whose raw sums cannot carry the variance). */
+int slak_bn3_forward_sums(const void* y1, const void* y2, const void* y3, double* local_sums, int N, int C, int P,
+                          void* workspace, size_t workspace_bytes, void* stream, const float* const* pre_sums, const int* pre_rows, int pre_stride) {
+    if (!y1 || !y2 || !y3 || !local_sums || !bn_pre_ok(pre_sums, pre_rows, pre_stride)) return SLAK_ERR_INVALID_ARG;
     int rc = bn_args_ok(N, C, P); if (rc) return rc;
     if (!workspace || workspace_bytes < slak_bn3_workspace_bytes(N, C)) return SLAK_ERR_WORKSPACE;
-    float* rows = (float*)workspace;
-    int S, per; bn_slices(N, C, &S, &per);
-    hipLaunchKernelGGL(bn3_chansums<false>, dim3((unsigned)((C * S + BN_THREADS / 64 - 1) / (BN_THREADS / 64))), dim3(BN_THREADS), 0, (hipStream_t)stream,
-                       (const uint16_t*)nullptr, (const uint16_t*)y1, (const uint16_t*)y2, (const uint16_t*)y3, rows, N, C, P, S, per);
-    hipLaunchKernelGGL(bn3_colreduce, dim3(C), dim3(64), 0, (hipStream_t)stream, (const float*)rows, local_sums, S, C, 6);
+    Bn3Pre pre;
+    bn_make_pre(pre, pre_sums, pre_rows, pre_stride, y1, y2, y3, N, C, P, workspace, (hipStream_t)stream);
+    Bn3Params bp{};
+    hipLaunchKernelGGL(bn3_local_stats<false>, dim3(C), dim3(64), 0, (hipStream_t)stream, pre, (const uint16_t*)y1, (const uint16_t*)y2, (const uint16_t*)y3,
+                       N, C, P, local_sums, bp, (float*)nullptr, (float*)nullptr, 0.f, 0.f, 0);
     SLAK_LAUNCH_CHECK();
     return SLAK_OK;
 }
@@ -354,25 +436,15 @@ int slak_bn3_forward_local(const void* y1, const void* y2, const void* y3, const
                            float* coef, float* stats, void* out, int N, int C, int P, void* workspace, size_t workspace_bytes, void* stream,
                            const float* const* pre_sums, const int* pre_rows, int pre_stride) {
     if (!y1 || !y2 || !y3 || !gamma || !beta || !running_mean || !running_var || !coef || !stats || !out) return SLAK_ERR_INVALID_ARG;
-    if (pre_sums && (!pre_rows || pre_stride < 2 || !pre_sums[0] || !pre_sums[1] || !pre_sums[2] || pre_rows[0] <= 0 || pre_rows[1] <= 0 || pre_rows[2] <= 0))
-        return SLAK_ERR_INVALID_ARG;
+    if (!bn_pre_ok(pre_sums, pre_rows, pre_stride)) return SLAK_ERR_INVALID_ARG;
     int rc = bn_args_ok(N, C, P); if (rc) return rc;
     if (!workspace || workspace_bytes < slak_bn3_workspace_bytes(N, C)) return SLAK_ERR_WORKSPACE;
     Bn3Params bp;
     for (int b = 0; b < 3; ++b) { bp.gamma[b] = gamma[b]; bp.beta[b] = beta[b]; bp.running_mean[b] = running_mean[b]; bp.running_var[b] = running_var[b]; }
     Bn3Pre pre;
-    if (pre_sums) {
-        for (int b = 0; b < 3; ++b) { pre.rows[b] = pre_sums[b]; pre.S[b] = pre_rows[b]; }
-        pre.stride = pre_stride;
-    } else {                                                       // the producers did not leave the sums: one read pass over the three tensors
-        int S, per; bn_slices(N, C, &S, &per);
-        hipLaunchKernelGGL(bn3_chansums<false>, dim3((unsigned)((C * S + BN_THREADS / 64 - 1) / (BN_THREADS / 64))), dim3(BN_THREADS), 0, (hipStream_t)stream,
-                           (const uint16_t*)nullptr, (const uint16_t*)y1, (const uint16_t*)y2, (const uint16_t*)y3, (float*)workspace, N, C, P, S, per);
-        for (int b = 0; b < 3; ++b) { pre.rows[b] = (const float*)workspace + 2 * b; pre.S[b] = S; }
-        pre.stride = 6;
-    }
-    hipLaunchKernelGGL(bn3_colreduce_finalize_fwd, dim3(C), dim3(64), 0, (hipStream_t)stream, pre, bp, coef, stats, C,
-                       (float)((double)N * P), eps, momentum, update_running);
+    bn_make_pre(pre, pre_sums, pre_rows, pre_stride, y1, y2, y3, N, C, P, workspace, (hipStream_t)stream);
+    hipLaunchKernelGGL(bn3_local_stats<true>, dim3(C), dim3(64), 0, (hipStream_t)stream, pre, (const uint16_t*)y1, (const uint16_t*)y2, (const uint16_t*)y3,
+                       N, C, P, (double*)nullptr, bp, coef, stats, eps, momentum, update_running);
     const int R = N * C;
     hipLaunchKernelGGL(bn3_apply_fwd, dim3(bn_grid(R, P)), dim3(BN_THREADS), 0, (hipStream_t)stream,
                        (const uint16_t*)y1, (const uint16_t*)y2, (const uint16_t*)y3, (const float*)coef, (uint16_t*)out, R, C, P, bn_lpr(P));
@@ -380,9 +452,9 @@ int slak_bn3_forward_local(const void* y1, const void* y2, const void* y3, const
     return SLAK_OK;
 }
 
-/* gamma/beta/running_*: arrays of 3 device pointers (host memory).  training != 0: statistics from global_sums / count, running stats
- * updated; training == 0: running statistics (global_sums ignored).  Writes coef[C][4], stats[C][6] and out. */
-int slak_bn3_forward_apply(const void* y1, const void* y2, const void* y3, const float* global_sums, double count, const float* count_dev,
+/* gamma/beta/running_*: arrays of 3 device pointers (host memory).  training != 0: statistics from global_sums ([C][6] DOUBLES) / count,
+ * running stats updated; training == 0: running statistics (global_sums ignored).  Writes coef[C][4], stats[C][6] and out. */
+int slak_bn3_forward_apply(const void* y1, const void* y2, const void* y3, const double* global_sums, double count, const double* count_dev,
                            const float* const* gamma, const float* const* beta, float* const* running_mean, float* const* running_var,
                            float eps, float momentum, int training, int update_running,
                            float* coef, float* stats, void* out, int N, int C, int P, void* stream) {
@@ -393,7 +465,7 @@ int slak_bn3_forward_apply(const void* y1, const void* y2, const void* y3, const
     for (int b = 0; b < 3; ++b) { bp.gamma[b] = gamma[b]; bp.beta[b] = beta[b]; bp.running_mean[b] = running_mean[b]; bp.running_var[b] = running_var[b]; }
     if (training)
         hipLaunchKernelGGL(bn3_finalize_fwd, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, global_sums, bp, coef, stats, C,
-                           (float)count, count_dev, eps, momentum, update_running);
+                           count, count_dev, eps, momentum, update_running);
     else
         hipLaunchKernelGGL(bn3_finalize_eval, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, bp, coef, C, eps);
     const int R = N * C;
@@ -403,16 +475,16 @@ int slak_bn3_forward_apply(const void* y1, const void* y2, const void* y3, const
     return SLAK_OK;
 }
 
-/* local_sums[C][4] = sum dout, sum dout*y_b over this rank's batch */
-int slak_bn3_backward_sums(const void* dout, const void* y1, const void* y2, const void* y3, float* local_sums, int N, int C, int P,
+/* local_sums[C][4] = sum dout, sum dout*(y_b - mean_b) over this rank's batch; stats = the forward's [C][6] (mean_b, invstd_b) */
+int slak_bn3_backward_sums(const void* dout, const void* y1, const void* y2, const void* y3, const float* stats, float* local_sums, int N, int C, int P,
                            void* workspace, size_t workspace_bytes, void* stream) {
-    if (!dout || !y1 || !y2 || !y3 || !local_sums) return SLAK_ERR_INVALID_ARG;
+    if (!dout || !y1 || !y2 || !y3 || !stats || !local_sums) return SLAK_ERR_INVALID_ARG;
     int rc = bn_args_ok(N, C, P); if (rc) return rc;
     if (!workspace || workspace_bytes < slak_bn3_workspace_bytes(N, C)) return SLAK_ERR_WORKSPACE;
     float* rows = (float*)workspace;
     int S, per; bn_slices(N, C, &S, &per);
     hipLaunchKernelGGL(bn3_chansums<true>, dim3((unsigned)((C * S + BN_THREADS / 64 - 1) / (BN_THREADS / 64))), dim3(BN_THREADS), 0, (hipStream_t)stream,
-                       (const uint16_t*)dout, (const uint16_t*)y1, (const uint16_t*)y2, (const uint16_t*)y3, rows, N, C, P, S, per);
+                       (const uint16_t*)dout, (const uint16_t*)y1, (const uint16_t*)y2, (const uint16_t*)y3, stats, rows, N, C, P, S, per);
     hipLaunchKernelGGL(bn3_colreduce, dim3(C), dim3(64), 0, (hipStream_t)stream, (const float*)rows, local_sums, S, C, 4);
     SLAK_LAUNCH_CHECK();
     return SLAK_OK;
@@ -430,7 +502,7 @@ int slak_bn3_backward_local(const void* dout, const void* y1, const void* y2, co
     float* rows = (float*)workspace;
     int S, per; bn_slices(N, C, &S, &per);
     hipLaunchKernelGGL(bn3_chansums<true>, dim3((unsigned)((C * S + BN_THREADS / 64 - 1) / (BN_THREADS / 64))), dim3(BN_THREADS), 0, (hipStream_t)stream,
-                       (const uint16_t*)dout, (const uint16_t*)y1, (const uint16_t*)y2, (const uint16_t*)y3, rows, N, C, P, S, per);
+                       (const uint16_t*)dout, (const uint16_t*)y1, (const uint16_t*)y2, (const uint16_t*)y3, stats, rows, N, C, P, S, per);
     hipLaunchKernelGGL(bn3_colreduce_finalize_bwd, dim3(C), dim3(64), 0, (hipStream_t)stream, (const float*)rows, S, stats, bp, bcoef, dgamma, dbeta, C,
                        (float)((double)N * P));
     const int R = N * C;
@@ -443,7 +515,7 @@ int slak_bn3_backward_local(const void* dout, const void* y1, const void* y2, co
 
 /* dgamma, dbeta: [3][C] (local gradients); bcoef scratch [C][9]; dy1..3 outputs */
 int slak_bn3_backward_apply(const void* dout, const void* y1, const void* y2, const void* y3, const float* global_sums,
-                            const float* local_sums, double count, const float* count_dev, const float* stats, const float* const* gamma,
+                            const float* local_sums, double count, const double* count_dev, const float* stats, const float* const* gamma,
                             float* bcoef, float* dgamma, float* dbeta, void* dy1, void* dy2, void* dy3, int N, int C, int P, void* stream) {
     if (!dout || !y1 || !y2 || !y3 || !global_sums || !local_sums || !stats || !gamma || !bcoef || !dgamma || !dbeta || !dy1 || !dy2 || !dy3)
         return SLAK_ERR_INVALID_ARG;

@@ -209,6 +209,7 @@ int slak_dwconv2d_backward_filter(const void* dy, int dy_dtype, const void* x, i
 int slak_dwconv2d_tri_supported(int dtype, int N, int C, int H, int W, int K) {
     if (use_dense_tri() && dwconv_mfma_dense_tri_supported(N, C, H, W, K, dtype)) return 1;                  // planes of <= 64 pixels: dense operator, batch as GEMM dimension
     if (dwconv_mfma_small_tri_supported(N, C, H, W, K, dtype)) return 1;                                     // 14x14 class: sums in the accumulator
+    if (dwconv_mfma_team_tri_supported(N, C, H, W, K, dtype, false) && dwconv_mfma_team_tri_supported(N, C, H, W, K, dtype, true)) return 1;   // 56x56 / 28x28 class: four-wave teams
     return (dwconv_mfma_tri_supported(N, C, H, W, K, dtype, false) && dwconv_mfma_tri_supported(N, C, H, W, K, dtype, true)) ? 2 : 0;   // 56x56 / 28x28 class
 }
 
@@ -220,6 +221,8 @@ int slak_dwconv2d_tri_forward(const void* x, const float* w_v, const float* w_h,
         return launch_dwconv_mfma_dense_tri(false, in, out, w, dtype, N, C, H, W, K, (hipStream_t)stream);
     if (dwconv_mfma_small_tri_supported(N, C, H, W, K, dtype))
         return launch_dwconv_mfma_small_tri(false, in, out, w, dtype, N, C, H, W, K, (hipStream_t)stream);
+    if (dwconv_mfma_team_tri_supported(N, C, H, W, K, dtype, false))
+        return launch_dwconv_mfma_team_tri(false, in, out, w, dtype, N, C, H, W, K, (hipStream_t)stream);
     return launch_dwconv_mfma_tri(false, in, out, w, dtype, N, C, H, W, K, (hipStream_t)stream);
 }
 
@@ -228,14 +231,17 @@ int slak_dwconv2d_tri_forward(const void* x, const float* w_v, const float* w_h,
  * (0: this shape has no such kernel -- use slak_dwconv2d_tri_forward).  bf16 only. */
 int slak_dwconv2d_tri_stats_rows(int dtype, int N, int C, int H, int W, int K) {
     if (use_dense_tri()) return 0;
-    return dwconv_mfma_small_tri_stats_rows(N, C, H, W, K, dtype);
+    if (dwconv_mfma_small_tri_supported(N, C, H, W, K, dtype)) return dwconv_mfma_small_tri_stats_rows(N, C, H, W, K, dtype);
+    return dwconv_mfma_team_tri_stats_rows(N, C, H, W, K, dtype);
 }
 int slak_dwconv2d_tri_forward_stats(const void* x, const float* w_v, const float* w_h, const float* w_s, void* y_v, void* y_h, void* y_s,
                                     float* stats, int dtype, int N, int C, int H, int W, int K, void* stream) {
     if (!x || !w_v || !w_h || !w_s || !y_v || !y_h || !y_s || !stats) return SLAK_ERR_INVALID_ARG;
     if (slak_dwconv2d_tri_stats_rows(dtype, N, C, H, W, K) <= 0) return SLAK_ERR_UNSUPPORTED;
     const void* in[3] = {x, x, x}; void* out[3] = {y_v, y_h, y_s}; const float* w[3] = {w_v, w_h, w_s};
-    return launch_dwconv_mfma_small_tri(false, in, out, w, dtype, N, C, H, W, K, (hipStream_t)stream, stats);
+    if (dwconv_mfma_small_tri_supported(N, C, H, W, K, dtype))
+        return launch_dwconv_mfma_small_tri(false, in, out, w, dtype, N, C, H, W, K, (hipStream_t)stream, stats);
+    return launch_dwconv_mfma_team_tri(false, in, out, w, dtype, N, C, H, W, K, (hipStream_t)stream, stats);
 }
 
 /* slak_dwconv2d_forward that also leaves the batch statistics of the BatchNorm behind the conv (models/SLaK.py:38-47 conv -> bn):
@@ -260,6 +266,8 @@ int slak_dwconv2d_tri_backward_data(const void* dy_v, const void* dy_h, const vo
         return launch_dwconv_mfma_dense_tri(true, in, out, w, dtype, N, C, H, W, K, (hipStream_t)stream);
     if (dwconv_mfma_small_tri_supported(N, C, H, W, K, dtype))
         return launch_dwconv_mfma_small_tri(true, in, out, w, dtype, N, C, H, W, K, (hipStream_t)stream);
+    if (dwconv_mfma_team_tri_supported(N, C, H, W, K, dtype, true))
+        return launch_dwconv_mfma_team_tri(true, in, out, w, dtype, N, C, H, W, K, (hipStream_t)stream);
     return launch_dwconv_mfma_tri(true, in, out, w, dtype, N, C, H, W, K, (hipStream_t)stream);
 }
 

@@ -101,6 +101,10 @@ int launch_dwconv_mfma_small_tri_wgrad(const void* const* dy, const void* x, flo
 bool dwconv_mfma_tri_supported(int N, int C, int H, int W, int K, int dtype, bool dgrad);
 int launch_dwconv_mfma_tri(bool dgrad, const void* const* in, void* const* out, const float* const* w, int dtype,
                            int N, int C, int H, int W, int K, hipStream_t st);
+bool dwconv_mfma_team_tri_supported(int N, int C, int H, int W, int K, int dtype, bool dgrad);
+int dwconv_mfma_team_tri_stats_rows(int N, int C, int H, int W, int K, int dtype);
+int launch_dwconv_mfma_team_tri(bool dgrad, const void* const* in, void* const* out, const float* const* w, int dtype,
+                                int N, int C, int H, int W, int K, hipStream_t st, float* stats = nullptr);
 bool dwconv_mfma_wgrad_vwave_supported(const ConvDims& d, int dy_dt, int x_dt);
 size_t dwconv_mfma_wgrad_vwave_workspace(const ConvDims& d);
 int launch_dwconv_mfma_wgrad_vwave(const void* dy, int dy_dt, const void* x, int x_dt, float* dw,

@@ -214,20 +214,44 @@ class Block(nn.Module):
         self.drop_path = DropPath(drop_path) if drop_path > 0. else nn.Identity()
 
     def forward(self, x):
-        # a block with emit_lowp returns (out, bf16 copy of out); nn.Sequential hands that pair to the next block as its input
-        x, x_lowp = x if isinstance(x, tuple) else (x, None)
+        """Tensor in, Tensor out -- what hooks, FLOPs counters and feature extractors see (models/SLaK.py:153-166)."""
+        return self.forward_pair(x, None)[0]
+
+    def forward_pair(self, x, x_lowp=None):
+        """(out, out_lowp): ``out_lowp`` is the copy of ``out`` in the autocast dtype that the fused tail writes alongside its fp32 output
+        when ``emit_lowp`` is set (None otherwise), ``x_lowp`` the previous block's.  Only ``_Stage.forward`` threads the pair from block
+        to block; it never leaves a stage."""
         shortcut = x
         x = self.large_kernel(x, lowp=x_lowp)
         # the fused tail kernels take even C <= 1024 (tail_args_ok in csrc/block_tail.hip); anything else runs the PyTorch ops below
         if (self.fused_tail and x.is_cuda and x.dtype == torch.bfloat16 and self.gamma is not None
                 and x.shape[1] % 2 == 0 and x.shape[1] <= 1024):
-            return self._forward_fused_tail(shortcut, x)
+            r = self._forward_fused_tail(shortcut, x)
+            return r if isinstance(r, tuple) else (r, None)
+        self.__dict__.pop("_pending_scale", None)               # drawn for the fused tail only
         x = x.permute(0, 2, 3, 1)
         x = self.pwconv2(self.act(self.pwconv1(self.norm(x))))
         if self.gamma is not None:
             x = self.gamma * x
         x = x.permute(0, 3, 1, 2)
-        return shortcut + self.drop_path(x)
+        return shortcut + self.drop_path(x), None
+
+
+class _Stage(nn.Sequential):
+    """A stage of blocks (models/SLaK.py:201-206 builds an nn.Sequential; this IS one: same state-dict keys, indexing, iteration).  Its
+    forward hands each block's low-precision output copy to the next block explicitly, so every module boundary carries a Tensor.  A block
+    with forward (pre-)hooks is called through ``__call__`` like any module -- the hooks see tensors -- and simply gets no hand-off."""
+
+    def forward(self, x):
+        import torch.nn.modules.module as _m
+        global_hooks = bool(_m._global_forward_hooks or _m._global_forward_pre_hooks or getattr(_m, "_global_forward_hooks_always_called", None))
+        lowp = None
+        for blk in self:
+            if isinstance(blk, Block) and not (global_hooks or blk._forward_hooks or blk._forward_pre_hooks):
+                x, lowp = blk.forward_pair(x, lowp)
+            else:
+                x, lowp = blk(x), None
+        return x
 
 
 def _block_forward_fused_tail(self, shortcut, x):
@@ -246,7 +270,7 @@ def _block_forward_fused_tail(self, shortcut, x):
                 scale.div_(keep)
     emit = bool(self.emit_lowp and torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == torch.bfloat16)
     # MLP + gamma + permute + residual as one autograd node; with `emit` it returns (out, bf16 copy of out): both are autograd
-    # outputs, the pair travels to the next block through nn.Sequential (Block.forward unpacks it)
+    # outputs, the pair travels to the next block through _Stage.forward (Block.forward_pair)
     return block_ops.mlp_scale_residual(shortcut.contiguous(), t, self.pwconv1.weight, self.pwconv1.bias, self.pwconv2.weight,
                                         self.pwconv2.bias, self.gamma.float(), scale, emit_lowp=emit)
 
@@ -276,7 +300,7 @@ class SLaK(nn.Module):
         self.stages = nn.ModuleList()
         at = 0
         for i in range(4):
-            self.stages.append(nn.Sequential(*[
+            self.stages.append(_Stage(*[
                 Block(dims[i], drop_path=rates[at + j], layer_scale_init_value=layer_scale_init_value,
                       kernel_size=(self.kernel_size[i], self.kernel_size[-1]), Decom=Decom, bn=bn, lowp_dwconv=lowp_dwconv)
                 for j in range(depths[i])]))
@@ -336,9 +360,22 @@ class SLaK(nn.Module):
             b.__dict__["_pending_scale"] = scales[i]
 
     def forward_features(self, x):
-        if self.training and x.is_cuda:
+        managed = self.training and x.is_cuda
+        if managed:
             self._begin_counters()
             self._draw_drop_path(x)
+        try:
+            return self._forward_features(x)
+        finally:
+            if managed:                                           # nothing of this forward outlives it: deepcopy / torch.save(model) stay clean
+                pool = getattr(self, "_bn_pool", None)
+                if pool is not None:
+                    pool.end_forward()
+                for st in self.stages:
+                    for b in st:
+                        b.__dict__.pop("_pending_scale", None)
+
+    def _forward_features(self, x):
         for i in range(4):
             ds = self.downsample_layers[i]
             if (self.fused_downsample and i > 0 and x.is_cuda and x.dtype == torch.float32 and torch.is_autocast_enabled()

@@ -1,0 +1,269 @@
+"""The launches the train step actually makes for a decomposed block (models/SLaK.py:82-100) -- one launch for several branches --
+called THROUGH THE C ABI and compared with the C ORACLE directly (not with their sibling HIP kernels):
+
+    slak_dwconv2d_pair_backward_filter   K x 5 and 5 x 5 weight gradient in one launch (56 x 56 / 28 x 28 class)
+    slak_dwconv2d_tri_forward[_stats]    the three branch outputs in one launch
+    slak_dwconv2d_tri_backward_data      the summed input gradient in one launch
+    slak_dwconv2d_tri_backward_filter    the three weight gradients in one launch (14 x 14 / 7 x 7 class)
+
+Small shapes are checked exhaustively; the shapes bench.py times (BASELINE configs[1], [3], [4] at their per-GPU batch) are run at full
+size and checked on a sample of >= 9 channels (first, last and seeded picks): the oracle works channel by channel, so a channel subset
+of the operands is an exact restatement of those channels' results.  Operands are rounded to the activation dtype before they reach
+the oracle (the kernels round the fp32 filter like autocast does): what is left is one output rounding + fp32 accumulation noise.
+"""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def _L():
+    from slak_amd import _lib
+    return _lib
+
+
+def _st(dev):
+    return ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+
+
+def _dt(dtype):
+    L = _L()
+    return L.SLAK_BF16 if dtype == torch.bfloat16 else L.SLAK_F16
+
+
+def _r(t, dtype):
+    return t.to(dtype).float().cpu().numpy()
+
+
+def _filters(C, K, dev, seed):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return [(torch.randn(C, 1, kh, kw, generator=g) * 0.05).to(dev) for kh, kw in ((K, 5), (5, K), (5, 5))]
+
+
+def _sample_channels(C, n=9, seed=0):
+    if C <= n:
+        return list(range(C))
+    rng = np.random.default_rng(seed)
+    picks = {0, C - 1} | set(int(v) for v in rng.choice(np.arange(1, C - 1), size=n - 2, replace=False))
+    return sorted(picks)
+
+
+def _check_lowp(got, ref, dtype, what):
+    ulp = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11
+    got = got.detach().double().cpu().numpy()
+    scale = max(1.0, float(np.abs(ref).max()))
+    err = np.abs(got - ref)
+    assert err.max() <= 1e-2 * scale, "%s: max err %.3e (scale %.3e)" % (what, err.max(), scale)      # north star, bf16
+    bound = ulp * np.abs(ref) + 5e-6 * scale                                                        # half an output ulp + accumulation
+    assert (err <= bound).all(), "%s: exceeds the rounding bound by %.3e" % (what, float((err - bound).max()))
+
+
+def _check_dw(got, ref, n_terms, what):
+    err = np.abs(got.double().cpu().numpy() - ref).max()
+    assert err <= 1e-5 * max(1.0, np.abs(ref).max()) * max(1.0, n_terms ** 0.5 / 30), "%s: %.3e" % (what, err)
+
+
+def _pair_wgrad(dyv, dys, x, K):
+    L = _L(); lib = L.lib()
+    N, C, H, W = x.shape
+    dt = _dt(x.dtype)
+    nb = int(lib.slak_dwconv2d_pair_filter_workspace_bytes(dt, N, C, H, W, K))
+    if nb == 0:
+        return None
+    ws = torch.empty(nb, dtype=torch.uint8, device=x.device)
+    dwv = torch.empty(C, 1, K, 5, dtype=torch.float32, device=x.device)
+    dws = torch.empty(C, 1, 5, 5, dtype=torch.float32, device=x.device)
+    L.check(lib.slak_dwconv2d_pair_backward_filter(dyv.data_ptr(), dys.data_ptr(), x.data_ptr(), dwv.data_ptr(), dws.data_ptr(), dt,
+                                                   N, C, H, W, K, ws.data_ptr(), nb, _st(x.device)), "pair_backward_filter")
+    return dwv, dws
+
+
+def _tri_fwd(x, ws, K, stats=False):
+    L = _L(); lib = L.lib()
+    N, C, H, W = x.shape
+    dt = _dt(x.dtype)
+    ys = [torch.empty_like(x) for _ in range(3)]
+    if stats:
+        rows = int(lib.slak_dwconv2d_tri_stats_rows(dt, N, C, H, W, K))
+        if rows <= 0:
+            return None, None
+        st = torch.zeros(rows, C, 6, dtype=torch.float32, device=x.device)
+        L.check(lib.slak_dwconv2d_tri_forward_stats(x.data_ptr(), ws[0].data_ptr(), ws[1].data_ptr(), ws[2].data_ptr(), ys[0].data_ptr(),
+                                                    ys[1].data_ptr(), ys[2].data_ptr(), st.data_ptr(), dt, N, C, H, W, K, _st(x.device)), "tri_forward_stats")
+        return ys, st
+    L.check(lib.slak_dwconv2d_tri_forward(x.data_ptr(), ws[0].data_ptr(), ws[1].data_ptr(), ws[2].data_ptr(), ys[0].data_ptr(),
+                                          ys[1].data_ptr(), ys[2].data_ptr(), dt, N, C, H, W, K, _st(x.device)), "tri_forward")
+    return ys, None
+
+
+def _tri_dgrad(dys, ws, K):
+    L = _L(); lib = L.lib()
+    N, C, H, W = dys[0].shape
+    dx = torch.empty_like(dys[0])
+    L.check(lib.slak_dwconv2d_tri_backward_data(dys[0].data_ptr(), dys[1].data_ptr(), dys[2].data_ptr(), ws[0].data_ptr(), ws[1].data_ptr(),
+                                                ws[2].data_ptr(), dx.data_ptr(), _dt(dx.dtype), N, C, H, W, K, _st(dx.device)), "tri_backward_data")
+    return dx
+
+
+def _tri_wgrad(dys, x, K):
+    L = _L(); lib = L.lib()
+    N, C, H, W = x.shape
+    dt = _dt(x.dtype)
+    nb = int(lib.slak_dwconv2d_tri_filter_workspace_bytes(dt, N, C, H, W, K))
+    if nb == 0:
+        return None
+    ws = torch.empty(nb, dtype=torch.uint8, device=x.device)
+    dws = [torch.empty(C, 1, kh, kw, dtype=torch.float32, device=x.device) for kh, kw in ((K, 5), (5, K), (5, 5))]
+    L.check(lib.slak_dwconv2d_tri_backward_filter(dys[0].data_ptr(), dys[1].data_ptr(), dys[2].data_ptr(), x.data_ptr(), dws[0].data_ptr(),
+                                                  dws[1].data_ptr(), dws[2].data_ptr(), dt, N, C, H, W, K, ws.data_ptr(), nb, _st(x.device)), "tri_backward_filter")
+    return dws
+
+
+# ------------------------------------------------------------------------------------------------ small shapes, every channel
+PAIR_SMALL = [(5, 3, 56, 56, 51), (3, 2, 56, 56, 51), (1, 1, 56, 56, 51), (9, 3, 28, 28, 49), (1, 1, 28, 28, 49), (11, 2, 28, 28, 49),
+              (2, 2, 64, 16, 51), (2, 3, 36, 24, 35), (1, 1, 40, 48, 31), (6, 2, 32, 32, 31), (5, 3, 20, 24, 21), (13, 2, 15, 16, 13),
+              (4, 3, 24, 24, 57), (3, 2, 48, 48, 59), (3, 1, 64, 64, 61)]
+
+
+@pytest.mark.parametrize("N,C,H,W,K", PAIR_SMALL)
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_pair_backward_filter_vs_oracle(N, C, H, W, K, dtype, gpu):
+    torch.manual_seed(N * 100 + H + K)
+    x = torch.randn(N, C, H, W, device=gpu).to(dtype)
+    dyv, dys = (torch.randn(N, C, H, W, device=gpu).to(dtype) for _ in range(2))
+    r = _pair_wgrad(dyv, dys, x, K)
+    if r is None:
+        pytest.skip("no two-branch weight-gradient launch for this shape (two launches run)")
+    dwv, dws = r
+    xr = _r(x, dtype)
+    _check_dw(dwv, oracle.dwconv2d_bwd_filter(_r(dyv, dtype), xr, K, 5), N * H * W, "dw Kx5")
+    _check_dw(dws, oracle.dwconv2d_bwd_filter(_r(dys, dtype), xr, 5, 5), N * H * W, "dw 5x5")
+    again = _pair_wgrad(dyv, dys, x, K)
+    assert torch.equal(dwv, again[0]) and torch.equal(dws, again[1])        # fixed-order slice reduction, no atomics on the data
+
+
+TRI_SMALL = [(5, 7, 14, 14, 47), (4, 3, 12, 10, 9), (1, 1, 14, 14, 13), (6, 5, 7, 7, 13), (17, 6, 7, 7, 13), (3, 9, 14, 14, 47), (9, 4, 12, 12, 13),
+             (5, 3, 56, 56, 51), (1, 1, 56, 56, 51), (7, 2, 56, 56, 51), (9, 2, 28, 28, 49), (1, 1, 28, 28, 49), (11, 3, 28, 28, 49),
+             (2, 2, 48, 40, 31), (2, 3, 64, 64, 61), (3, 2, 32, 32, 31), (6, 2, 24, 24, 13), (5, 2, 24, 24, 57), (7, 2, 28, 20, 13), (3, 2, 48, 48, 59)]
+
+
+@pytest.mark.parametrize("N,C,H,W,K", TRI_SMALL)
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_tri_forward_and_backward_data_vs_oracle(N, C, H, W, K, dtype, gpu):
+    L = _L()
+    if not L.lib().slak_dwconv2d_tri_supported(_dt(dtype), N, C, H, W, K):
+        pytest.skip("no three-branch launch for this shape")
+    torch.manual_seed(N * 100 + H + K)
+    x = torch.randn(N, C, H, W, device=gpu).to(dtype)
+    dys = [torch.randn(N, C, H, W, device=gpu).to(dtype) for _ in range(3)]
+    ws = _filters(C, K, gpu, K + C)
+    wr = [_r(w, dtype) for w in ws]
+    ys, _ = _tri_fwd(x, ws, K)
+    xr = _r(x, dtype)
+    for y, w, name in zip(ys, wr, ("Kx5", "5xK", "5x5")):
+        _check_lowp(y, oracle.dwconv2d_fwd(xr, w), dtype, "tri fwd " + name)
+    dx = _tri_dgrad(dys, ws, K)
+    parts = [oracle.dwconv2d_bwd_data(_r(d, dtype), w) for d, w in zip(dys, wr)]
+    ref = sum(parts)
+    got = dx.detach().double().cpu().numpy()
+    scale = max(1.0, float(np.abs(ref).max()))
+    ulp = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11
+    assert np.abs(got - ref).max() <= 1e-2 * scale
+    # a kernel may round each branch's partial once before the fp32 sum is rounded (what autograd's tensor adds do); one that adds in its
+    # accumulator rounds only the sum: half an ulp of every value that is rounded, plus accumulation noise
+    bound = ulp * (np.abs(ref) + sum(np.abs(p) for p in parts)) + 5e-6 * scale
+    assert (np.abs(got - ref) <= bound).all(), float((np.abs(got - ref) - bound).max())
+
+
+@pytest.mark.parametrize("N,C,H,W,K", [(5, 7, 14, 14, 47), (6, 5, 7, 7, 13), (17, 6, 7, 7, 13), (4, 3, 12, 10, 9), (9, 4, 12, 12, 13), (1, 1, 14, 14, 13)])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_tri_backward_filter_vs_oracle(N, C, H, W, K, dtype, gpu):
+    torch.manual_seed(N + K)
+    x = torch.randn(N, C, H, W, device=gpu).to(dtype)
+    dys = [torch.randn(N, C, H, W, device=gpu).to(dtype) for _ in range(3)]
+    dws = _tri_wgrad(dys, x, K)
+    if dws is None:
+        pytest.skip("no three-branch weight-gradient launch for this shape")
+    xr = _r(x, dtype)
+    for dw, dy, (kh, kw) in zip(dws, dys, ((K, 5), (5, K), (5, 5))):
+        _check_dw(dw, oracle.dwconv2d_bwd_filter(_r(dy, dtype), xr, kh, kw), N * H * W, "dw %dx%d" % (kh, kw))
+
+
+# ------------------------------------------------------------------------------------------------ the shapes bench.py times, sampled channels
+BENCH_PAIR = [(128, 96, 56, 56, 51), (128, 192, 28, 28, 49),             # BASELINE configs[1] / [2] stages 1, 2
+              (64, 128, 56, 56, 51), (64, 256, 28, 28, 49),              # configs[3] SLaK-B
+              (64, 192, 48, 48, 59), (64, 384, 24, 24, 57)]              # configs[4] 61 x 61 at 384 px, stages 2, 3
+BENCH_TRI = [(128, 96, 56, 56, 51), (128, 192, 28, 28, 49), (128, 384, 14, 14, 47), (128, 768, 7, 7, 13),
+             (64, 128, 56, 56, 51), (64, 512, 14, 14, 47), (64, 1024, 7, 7, 13),
+             (64, 192, 48, 48, 59), (64, 384, 24, 24, 57), (64, 768, 12, 12, 13)]
+
+
+@pytest.mark.parametrize("N,C,H,W,K", BENCH_PAIR)
+def test_pair_backward_filter_at_bench_shapes(N, C, H, W, K, gpu):
+    dtype = torch.bfloat16
+    torch.manual_seed(K)
+    x = torch.randn(N, C, H, W, device=gpu).to(dtype)
+    dyv, dys = (torch.randn(N, C, H, W, device=gpu).to(dtype) for _ in range(2))
+    r = _pair_wgrad(dyv, dys, x, K)
+    if r is None:
+        pytest.skip("no two-branch weight-gradient launch for this shape")
+    dwv, dws = r
+    ch = _sample_channels(C, 9, seed=K)
+    xr = _r(x[:, ch], dtype)
+    _check_dw(dwv[ch], oracle.dwconv2d_bwd_filter(_r(dyv[:, ch], dtype), xr, K, 5), N * H * W, "dw Kx5")
+    _check_dw(dws[ch], oracle.dwconv2d_bwd_filter(_r(dys[:, ch], dtype), xr, 5, 5), N * H * W, "dw 5x5")
+    # size-independent property on ALL channels: with dy = x the centre tap of both gradients is sum x^2 per channel
+    dwv2, dws2 = _pair_wgrad(x, x, x, K)
+    e = (x.double() ** 2).sum(dim=(0, 2, 3))
+    assert (dwv2[:, 0, K // 2, 2].double() - e).abs().max().item() <= 1e-4 * e.max().item()
+    assert (dws2[:, 0, 2, 2].double() - e).abs().max().item() <= 1e-4 * e.max().item()
+
+
+@pytest.mark.parametrize("N,C,H,W,K", BENCH_TRI)
+def test_tri_launches_at_bench_shapes(N, C, H, W, K, gpu):
+    dtype = torch.bfloat16
+    L = _L()
+    if not L.lib().slak_dwconv2d_tri_supported(_dt(dtype), N, C, H, W, K):
+        pytest.skip("no three-branch launch for this shape")
+    torch.manual_seed(K + 1)
+    x = torch.randn(N, C, H, W, device=gpu).to(dtype)
+    dys = [torch.randn(N, C, H, W, device=gpu).to(dtype) for _ in range(3)]
+    ws = _filters(C, K, gpu, K)
+    ch = _sample_channels(C, 9, seed=K)
+    wr = [_r(w[ch], dtype) for w in ws]
+    xr = _r(x[:, ch], dtype)
+    ys, _ = _tri_fwd(x, ws, K)
+    for y, w, name in zip(ys, wr, ("Kx5", "5xK", "5x5")):
+        _check_lowp(y[:, ch], oracle.dwconv2d_fwd(xr, w), dtype, "tri fwd " + name)
+    ys2, st = _tri_fwd(x, ws, K, stats=True)
+    if ys2 is not None:                                                   # the statistics variant stores the same outputs
+        for a, b in zip(ys, ys2):
+            assert torch.equal(a, b)
+        s = st.double().sum(dim=0)                                       # [C][6]
+        for b, y in enumerate(ys2):
+            yd = y.double()
+            s1, s2 = yd.sum(dim=(0, 2, 3)), (yd * yd).sum(dim=(0, 2, 3))
+            assert (s[:, 2 * b] - s1).abs().max().item() <= 1e-4 * max(1.0, s2.max().item() ** 0.5 * (N * H * W) ** 0.5)
+            assert (s[:, 2 * b + 1] - s2).abs().max().item() <= 1e-4 * s2.max().item()
+    dx = _tri_dgrad(dys, ws, K)
+    ref = sum(oracle.dwconv2d_bwd_data(_r(d[:, ch], dtype), w) for d, w in zip(dys, wr))
+    got = dx[:, ch].double().cpu().numpy()
+    scale = max(1.0, float(np.abs(ref).max()))
+    assert np.abs(got - ref).max() <= 1e-2 * scale
+    # identity filters on ALL channels: forward returns x three times, the data gradient the sum of its inputs rounded like tensor adds
+    wi = [torch.zeros_like(w) for w in ws]
+    wi[0][:, 0, K // 2, 2] = 1; wi[1][:, 0, 2, K // 2] = 1; wi[2][:, 0, 2, 2] = 1
+    yi, _ = _tri_fwd(x, wi, K)
+    assert all(torch.equal(y, x) for y in yi)
+    dxi = _tri_dgrad(dys, wi, K).float()
+    want = dys[0].float() + dys[1].float() + dys[2].float()
+    assert (dxi - want).abs().max().item() <= 2.0 ** -7 * max(1.0, want.abs().max().item())
+    dws = _tri_wgrad(dys, x, K)
+    if dws is not None:
+        for dw, dy, (kh, kw) in zip(dws, dys, ((K, 5), (5, K), (5, 5))):
+            _check_dw(dw[ch], oracle.dwconv2d_bwd_filter(_r(dy[:, ch], dtype), xr, kh, kw), N * H * W, "dw %dx%d" % (kh, kw))

@@ -74,18 +74,15 @@ def test_pybind_entry_points_match_the_ctypes_path_and_the_oracle(N, C, H, W, kh
 
 
 @pytest.mark.gpu
-@pytest.mark.skipif(not os.path.isdir(REF_EXT_DIR), reason="reference checkout not present on the GPU box")
 def test_reference_module_runs_on_it(gpu):
+    """The reference's own depthwise_conv2d_implicit_gemm.py on the compiled module: from /root/reference where it exists, from the
+    bytecode oracle/ref_modules.build() left under oracle/_ref/ on the GPU box (more shapes: tests/test_reference_modules_gpu.py)."""
+    from oracle import ref_modules
     _ext()
-    sys.path.insert(0, REF_EXT_DIR)
-    try:
-        sys.modules.pop("depthwise_conv2d_implicit_gemm", None)
-        ref = importlib.import_module("depthwise_conv2d_implicit_gemm")
-        m = ref.DepthWiseConv2dImplicitGEMM(6, (51, 5)).to(gpu)
-        x = torch.randn(2, 6, 28, 28, device=gpu, requires_grad=True)
-        y = m(x); y.mean().backward()
-        want = torch.nn.functional.conv2d(x.detach().cpu().double(), m.weight.detach().cpu().double(), None, 1, (25, 2), 1, 6)
-        assert (y.detach().cpu().double() - want).abs().max().item() <= 1e-4
-    finally:
-        sys.path.remove(REF_EXT_DIR)
-        sys.modules.pop("depthwise_conv2d_implicit_gemm", None)
+    from slak_amd import build
+    ref = ref_modules.load_dwconv_module(os.path.dirname(build.pybind_path()))
+    m = ref.DepthWiseConv2dImplicitGEMM(6, (51, 5)).to(gpu)
+    x = torch.randn(2, 6, 28, 28, device=gpu, requires_grad=True)
+    y = m(x); y.mean().backward()
+    want = torch.nn.functional.conv2d(x.detach().cpu().double(), m.weight.detach().cpu().double(), None, 1, (25, 2), 1, 6)
+    assert (y.detach().cpu().double() - want).abs().max().item() <= 1e-4
