@@ -5,8 +5,11 @@
 //   forward : x travels HBM -> LDS once, three outputs are written (4 plane passes over HBM instead of 6 per block);
 //   dgrad   : the three dy planes are fetched, ONE dx is written: dx = sum_b corr(dy_b, rot180(w_b)) -- autograd's two elementwise
 //             adds on the per-branch gradients disappear (4 plane passes instead of 3 launches x (read dy [+ read dx] + write dx)).
-// A workgroup is a TEAM of four waves that owns one channel and a slice of the batch; TWO teams per CU (<= 256 registers, <= 80 KB
-// LDS each) whose phases interleave.  Every wave carries the same number of MFMAs per group of planes:
+// A TEAM of four waves owns one channel and a slice of the batch; a workgroup is TWO teams (<= 256 registers, <= 80 KB LDS each: one
+// workgroup per CU) that share nothing but the workgroup barrier -- and through it run in ANTI-PHASE: between two barriers one team
+// computes (matrix pipe) while the other moves data (HBM, LDS), then they swap.  (Two independent four-wave workgroups per CU fell
+// into lockstep -- both computing, then both moving data: 115 us = 50 MFMA + 65 IO with nothing overlapped; a start-up stagger was
+// absorbed by the first wait for data.)  Every wave carries the same number of MFMAs per group of planes:
 //   * 56x56 class (planes of 2 x 2 tiles, one plane per group): wave (g, mt) computes the two tiles (mt, sub 0 / 1) of the vertical
 //     (g = 0) or the horizontal (g = 1) branch -- 40 MFMAs -- and tile (mt, sub = g) of the 5 x 5 branch -- 15 (band): 55 each;
 //   * 28x28 class (one tile per plane, four planes per group): wave w computes the three branches of plane w: 30 MFMAs each; in the
@@ -26,6 +29,8 @@
 #include "mfma_common.h"
 
 namespace slak {
+
+extern unsigned long long* g_dma_dbg;    // dev hook: slak_debug_set_phase_buffer()
 
 constexpr int TT_WAVES = 4;
 constexpr int TT_THREADS = TT_WAVES * 64;
@@ -49,61 +54,122 @@ struct TeamParams {
     int chunks_pp;         // 16-byte chunks per plane (HW/8)
     int ppp;               // LDS-DMA pieces (64 chunks) per plane
     int plane_lds;         // LDS elements from one plane of a ring slot to the next (HW + 2W guard rows)
-    int tslot_elems;       // LDS elements of one tensor's part of a ring slot
+    int tslot_elems;       // LDS elements of one tensor's part of a ring slot (guarded image)
+    int t0_elems, t0_plane, t0_first;   // tensor 0's part, plane stride and first-plane offset: the guarded image (forward) or -- dgrad, where dy of the
+                           // vertical branch is only ever transposed -- the bare planes (no guard rows: 448 bytes per slot that buy the third ring slot)
     int NT;                // tensors in a slot: 1 (forward) or 3 (dgrad)
     int NB;                // ring depth in groups
     int PT;                // pitch of the transposed image
     int xt_rows;           // rows of one transposed plane image incl. 2+2 guard rows
-    int planes_per_wg, slices;
+    int planes_per_wg, slices;   // per TEAM
+    int iters_max;         // groups per team (upper bound: both teams of a workgroup run this many phase pairs)
+    int team_lds;          // LDS bytes of one team
     unsigned m_cpp;        // magic multiplier: n / chunks_pp == (n * m_cpp) >> 22
     int tr_pp, tr_cbs;     // transpose blocks per plane, per 4-row band
     unsigned tensor_bytes;
     float* stats;          // forward only, or NULL: [slices * 4][C][6] partial (sum y_v, sum y_v^2, sum y_h, sum y_h^2, sum y_s, sum y_s^2)
     int dbg;               // dev (SLAK_TEAM_DBG): 1 skip the MFMA tiles, 2 skip the copy-out, 4 skip the transposes
+    unsigned long long* tl; // dev: per-team timeline [team][64] (slak_debug_set_phase_buffer)
 };
 
+// The B fragment of tap r, k-step ks of a tile: 16 bytes at rp0 + r*rpitch + 32*ks.  SWAP: rows of x^T (vertical branch; pads are
+// zero).  Otherwise rows of the guarded row-major image; KS = k-steps of the plane class: the last two may reach past the row end --
+// pieces beyond it read the zero row instead (wlim = W - lhi*8: k-step ks of this lane lies inside the row iff ks*16 < wlim).
+template <bool SWAP, bool R16, int KS>
+__device__ __forceinline__ s16x8 team_load_b(const char* L, unsigned rpr, int ks, int wlim, unsigned zrow_l) {
+    u32x4 b;
+    if constexpr (SWAP) b = *(const u32x4*)(L + rpr + ks * 32);
+    else if constexpr (R16) {
+        if (ks >= KS - 2) { const unsigned q = ks * 16 < wlim ? rpr + ks * 32 : zrow_l; b = *(const u32x4*)(L + q); }
+        else b = *(const u32x4*)(L + rpr + ks * 32);
+    } else {                                                                          // W % 8 == 4: rows are 8-byte aligned
+        if (ks >= KS - 2) {
+            const unsigned q0 = ks * 16 < wlim ? rpr + ks * 32 : zrow_l, q1 = ks * 16 + 4 < wlim ? rpr + ks * 32 + 8 : zrow_l + 8;
+            const u32x2 lo = *(const u32x2*)(L + q0), hi = *(const u32x2*)(L + q1);
+            b = u32x4{lo[0], lo[1], hi[0], hi[1]};
+        } else {
+            const u32x2 lo = *(const u32x2*)(L + rpr + ks * 32), hi = *(const u32x2*)(L + rpr + ks * 32 + 8);
+            b = u32x4{lo[0], lo[1], hi[0], hi[1]};
+        }
+    }
+    return __builtin_bit_cast(s16x8, b);
+}
+constexpr int TT_NBUF = MF_TAPS + 1;
+// the first five fragments of a tile (the tile that opens a compute phase; later tiles get theirs from their predecessor)
+template <bool SWAP, bool R16, int KS, int K0, int ROT>
+__device__ __forceinline__ void team_tile_prefetch(s16x8 (&b)[TT_NBUF], const char* L, unsigned rp0, unsigned rpitch, int wlim, unsigned zrow_l) {
+#pragma unroll
+    for (int r = 0; r < MF_TAPS; ++r) b[(ROT + r) % TT_NBUF] = team_load_b<SWAP, R16, KS>(L, rp0 + r * rpitch, K0, wlim, zrow_l);
+}
 // One 32x32 tile: NK k-steps starting at K0, five short taps each, accumulated INTO acc; SWAP: operands swapped (vertical branch:
-// D^T = X^T-tile x T^T, so that a lane holds 4 consecutive columns of one output row).  The fragment of tap r for the next k-step is
-// fetched right after this k-step's MFMA of tap r has issued, into the same registers (pinned with sched_barrier).  KS: k-steps of
-// the plane class -- the last two may reach past the row end (horizontal: pieces beyond it read the zero row instead).
-template <typename T, bool SWAP, bool R16, int KS, int NK, int K0>
-__device__ __forceinline__ void team_tile_mma(f32x16& acc, const s16x8 (&afrag)[MF_TAPS][NK], const char* L, unsigned rp0, unsigned rpitch,
-                                              int wlim, unsigned zrow_l) {
-    // rp0: LDS byte address of tap 0's operand row (+ lhi*16), rpitch: bytes from one tap's row to the next (wave-uniform);
-    // wlim = W - lhi*8: k-step ks of this lane lies inside the row iff ks*16 < wlim; zrow_l: the zero row (+ lhi*16)
+// D^T = X^T-tile x T^T, so that a lane holds 4 consecutive columns of one output row).  A software pipeline pinned with sched_barrier:
+// five fragments are in flight in SIX buffers -- the fragment fetched right after MFMA j goes into the registers MFMA j-1 read (an LDS
+// load into the registers of the MFMA that has just issued waits for that MFMA to read them), fragment j of the tile lives in
+// b[(ROT + j) % 6] and the first five are already there (team_tile_prefetch, or the tile before: NXT).  The pipeline runs ACROSS tiles:
+// during the last k-step the first five fragments of the NEXT tile are fetched (NXT = 1: a SWAP tile, 2: a plain tile, at nrp0 /
+// npitch, k-step NXT_K0), so a tile boundary costs no LDS latency (measured before: 64 cycles per MFMA with ~300 idle cycles per
+// boundary, against 37 inside a tile).
+struct TeamNoFill { __device__ __forceinline__ void operator()(int) const {} };
+// fill(j): instructions issued in the shadow of MFMA j -- the epilogue of the tile before (pack + LDS stores of an accumulator that is complete)
+template <typename T, bool SWAP, bool R16, int KS, int NK, int K0, int ROT, int NXT, int NXT_K0, typename F = TeamNoFill>
+__device__ __forceinline__ void team_tile_mma(f32x16& acc, const s16x8 (&afrag)[MF_TAPS][NK], s16x8 (&b)[TT_NBUF], const char* L, unsigned rp0,
+                                              unsigned rpitch, int wlim, unsigned zrow_l, unsigned nrp0, unsigned npitch, F fill = F()) {
+    constexpr int NJ = MF_TAPS * NK;
     unsigned rp[MF_TAPS];
 #pragma unroll
     for (int r = 0; r < MF_TAPS; ++r) rp[r] = rp0 + r * rpitch;
-    auto load_b = [&](int r, int ks) -> s16x8 {
-        u32x4 b;
-        if constexpr (SWAP) b = *(const u32x4*)(L + rp[r] + ks * 32);                  // x^T pads are zero
-        else if constexpr (R16) {
-            if (ks >= KS - 2) { const unsigned q = ks * 16 < wlim ? rp[r] + ks * 32 : zrow_l; b = *(const u32x4*)(L + q); }
-            else b = *(const u32x4*)(L + rp[r] + ks * 32);
-        } else {                                                                      // W % 8 == 4: rows are 8-byte aligned
-            if (ks >= KS - 2) {
-                const unsigned q0 = ks * 16 < wlim ? rp[r] + ks * 32 : zrow_l, q1 = ks * 16 + 4 < wlim ? rp[r] + ks * 32 + 8 : zrow_l + 8;
-                const u32x2 lo = *(const u32x2*)(L + q0), hi = *(const u32x2*)(L + q1);
-                b = u32x4{lo[0], lo[1], hi[0], hi[1]};
-            } else {
-                const u32x2 lo = *(const u32x2*)(L + rp[r] + ks * 32), hi = *(const u32x2*)(L + rp[r] + ks * 32 + 8);
-                b = u32x4{lo[0], lo[1], hi[0], hi[1]};
-            }
-        }
-        return __builtin_bit_cast(s16x8, b);
-    };
-    s16x8 b[MF_TAPS];
-#pragma unroll
-    for (int r = 0; r < MF_TAPS; ++r) b[r] = load_b(r, K0);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int kk = 0; kk < NK; ++kk) {
-#pragma unroll
-        for (int r = 0; r < MF_TAPS; ++r) {
-            acc = SWAP ? mfma32<T>(b[r], afrag[r][kk], acc) : mfma32<T>(afrag[r][kk], b[r], acc);
-            if (kk + 1 < NK) b[r] = load_b(r, K0 + kk + 1);
-            __builtin_amdgcn_sched_barrier(0);
+    for (int j = 0; j < NJ; ++j) {
+        const int kk = j / MF_TAPS, r = j % MF_TAPS;
+        acc = SWAP ? mfma32<T>(b[(ROT + j) % TT_NBUF], afrag[r][kk], acc) : mfma32<T>(afrag[r][kk], b[(ROT + j) % TT_NBUF], acc);
+        if (j + MF_TAPS < NJ) {
+            b[(ROT + j + MF_TAPS) % TT_NBUF] = team_load_b<SWAP, R16, KS>(L, rp[(j + MF_TAPS) % MF_TAPS], K0 + (j + MF_TAPS) / MF_TAPS, wlim, zrow_l);
+            asm volatile("" :: "v"(b[(ROT + j) % TT_NBUF]));         // the operand MFMA j is reading stays allocated across the load (no register reuse)
+        } else if constexpr (NXT != 0) {
+            const int i = j + MF_TAPS - NJ;                           // fragment i of the next tile
+            b[(ROT + j + MF_TAPS) % TT_NBUF] = team_load_b<NXT == 1, R16, KS>(L, nrp0 + i * npitch, NXT_K0, wlim, zrow_l);
+            asm volatile("" :: "v"(b[(ROT + j) % TT_NBUF]));
         }
+        fill(j);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// CLS 2: the 5 x 5 tile with its Toeplitz fragments in LDS (keeping them in registers -- 60 on top of branch A's 80 -- spilled).
+// A fragment depends on d = ks - 2 mt only (window start 16 d + 8 lhi - l31 + 2): twenty fragments (d = -1 .. 2 x five taps) of 1 KiB
+// at sfr + ((d + 1) * 5 + r) * 1024 + lane * 16, built once per team.  Entries for inputs beyond the row need no mask: the B pieces
+// there are the zero row.  Tile (MT, sub): k-steps MT .. MT + 2, i.e. d = kk - MT.  Both operands of MFMA j are fetched five MFMAs
+// ahead: B into bq (chained from the tile before, as in team_tile_mma), A into sa (first five by team_small_prefetch).
+constexpr int TT_SFR_BYTES = 4 * MF_TAPS * 1024;
+template <int MT>
+__device__ __forceinline__ void team_small_prefetch(s16x8 (&sa)[TT_NBUF], const char* L, unsigned sfr_l) {
+#pragma unroll
+    for (int r = 0; r < MF_TAPS; ++r) sa[r] = __builtin_bit_cast(s16x8, *(const u32x4*)(L + sfr_l + ((1 - MT) * MF_TAPS + r) * 1024));
+}
+template <typename T, bool R16, int KS, int MT, int ROT, int NXT, int NXT_K0, typename F = TeamNoFill>
+__device__ __forceinline__ void team_small_tile_mma(f32x16& acc, s16x8 (&sa)[TT_NBUF], s16x8 (&b)[TT_NBUF], const char* L, unsigned rp0, unsigned rpitch,
+                                                    int wlim, unsigned zrow_l, unsigned sfr_l, unsigned nrp0, unsigned npitch, F fill = F()) {
+    constexpr int NJ = MF_TAPS * 3;
+    unsigned rp[MF_TAPS];
+#pragma unroll
+    for (int r = 0; r < MF_TAPS; ++r) rp[r] = rp0 + r * rpitch;
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        acc = mfma32<T>(sa[j % TT_NBUF], b[(ROT + j) % TT_NBUF], acc);
+        if (j + MF_TAPS < NJ) {
+            const int jn = j + MF_TAPS, kk = jn / MF_TAPS, r = jn % MF_TAPS;
+            sa[jn % TT_NBUF] = __builtin_bit_cast(s16x8, *(const u32x4*)(L + sfr_l + ((kk - MT + 1) * MF_TAPS + r) * 1024));
+            b[(ROT + jn) % TT_NBUF] = team_load_b<false, R16, KS>(L, rp[r], MT + kk, wlim, zrow_l);
+            asm volatile("" :: "v"(b[(ROT + j) % TT_NBUF]), "v"(sa[j % TT_NBUF]));
+        } else if constexpr (NXT != 0) {
+            const int i = j + MF_TAPS - NJ;                           // fragment i of the next tile
+            b[(ROT + j + MF_TAPS) % TT_NBUF] = team_load_b<NXT == 1, R16, KS>(L, nrp0 + i * npitch, NXT_K0, wlim, zrow_l);
+            asm volatile("" :: "v"(b[(ROT + j) % TT_NBUF]));
+        }
+        fill(j);
+        __builtin_amdgcn_sched_barrier(0);
     }
 }
 
@@ -133,7 +199,7 @@ __device__ __forceinline__ void team_build_frags(s16x8 (&afrag)[MF_TAPS][NK], co
 // CLS 2: planes of 2 x 2 tiles (32 < H, W <= 64), KS = 4 k-steps, one plane per group.  CLS 1: planes of one tile (16 < H, W <= 32),
 // KS = 2, four planes per group.  R16: image rows are 16-byte aligned (W % 8 == 0).
 template <typename T, int CLS, bool DGRAD, bool R16>
-__global__ __launch_bounds__(TT_THREADS, 2) void dwconv_mfma_team_tri_kernel(const TeamParams p) {
+__global__ __launch_bounds__(2 * TT_THREADS, 1) void dwconv_mfma_team_tri_kernel(const TeamParams p) {
     constexpr int KS = CLS == 2 ? 4 : 2;
     constexpr int NKS = CLS == 2 ? 3 : 2;                            // k-steps of a 5 x 5 tile (band)
     constexpr int NT = DGRAD ? 3 : 1;                                // input tensors
@@ -142,10 +208,12 @@ __global__ __launch_bounds__(TT_THREADS, 2) void dwconv_mfma_team_tri_kernel(con
                                                                      // CLS 1: all three branches do)
     constexpr int NPW = DGRAD ? TT_NPW : 2;                          // LDS-DMA pieces per wave and group (upper bound)
     extern __shared__ __attribute__((aligned(16))) uint16_t lds[];
-    char* const L = (char*)lds;                                      // everything below is a BYTE offset into the LDS block
+    const int team = wave_id_uniform() >> 2;                         // 0 / 1: the two teams of the workgroup
+    char* const L = (char*)lds + (size_t)team * p.team_lds;          // everything below is a BYTE offset into the TEAM's LDS block
     const int HW = p.H * p.W;
     const unsigned tslot_b = (unsigned)p.tslot_elems * 2;            // one tensor's part of a slot
-    const unsigned slot_b = tslot_b * NT;
+    const unsigned t0_b = (unsigned)p.t0_elems * 2;                  // tensor 0's part; tensors 1, 2 follow at t0_b, t0_b + tslot_b
+    const unsigned slot_b = t0_b + tslot_b * (NT - 1);
     const unsigned xt_buf_b = (unsigned)(p.G * p.xt_rows * p.PT) * 2;
     const unsigned out_buf_b = (unsigned)(p.G * HW) * 2;             // one out-buffer
     const int NB = p.NB;
@@ -155,14 +223,17 @@ __global__ __launch_bounds__(TT_THREADS, 2) void dwconv_mfma_team_tri_kernel(con
     const unsigned win_b = lout_b;                                   // [3 branches][2 copies][5 taps][TT_LEN]: prologue only, aliases the out-buffers
     constexpr unsigned win1_bytes = 2 * MF_TAPS * TT_LEN * 2;
     const unsigned zrow_b = lout_b + (NOB * out_buf_b > 3 * win1_bytes ? NOB * out_buf_b : 3 * win1_bytes);   // TT_ZROW zeros
+    const unsigned sfr_b = zrow_b + TT_ZROW * 2;                     // CLS 2: the 5 x 5 branch's twenty Toeplitz fragments
 
-    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, lhi = lane >> 5;
-    const int wave = wave_id_uniform();
-    const int c = blockIdx.x % p.C, slice = blockIdx.x / p.C;
+    const int tid = threadIdx.x & (TT_THREADS - 1), lane = tid & 63, l31 = lane & 31, lhi = lane >> 5;   // thread / wave index WITHIN the team
+    const int wave = wave_id_uniform() & 3;
+    const int vb = blockIdx.x * 2 + team;                            // the team's (channel, slice)
+    const bool has_work = vb < p.C * p.slices;
+    const int c = has_work ? vb % p.C : 0, slice = has_work ? vb / p.C : 0;
     const int n_begin = slice * p.planes_per_wg;
     int n_end = n_begin + p.planes_per_wg; if (n_end > p.N) n_end = p.N;
-    if (n_begin >= n_end) return;
-    const int iters = (n_end - n_begin + p.G - 1) / p.G;
+    if (!has_work) n_end = n_begin;
+    const int iters = (n_end - n_begin + p.G - 1) / p.G;             // (a team without planes keeps the workgroup's barriers company)
 
     // ---- LDS-DMA: piece q = (tensor t, plane j of the group, 64-chunk piece pp) is issued by wave q % 4 ----------------------------
     v4i_t rsrc[NT];
@@ -174,7 +245,7 @@ __global__ __launch_bounds__(TT_THREADS, 2) void dwconv_mfma_team_tri_kernel(con
         rsrc[t][2] = __builtin_amdgcn_readfirstlane((int)p.tensor_bytes);
         rsrc[t][3] = 0x00020000;
     }
-    const unsigned lds_base = (unsigned)(uintptr_t)SLAK_LDS(uint16_t, lds);
+    const unsigned lds_base = (unsigned)(uintptr_t)SLAK_LDS(uint16_t, lds) + (unsigned)team * (unsigned)p.team_lds;
     const unsigned plane_b = (unsigned)p.plane_lds * 2;              // LDS bytes from plane to plane within a slot
     const unsigned first_plane_b = (unsigned)(2 * p.W) * 2;          // two guard rows in front of every plane
     const unsigned gplane_b = (unsigned)(p.C * HW) * 2;              // HBM bytes from image n to image n+1 of this channel
@@ -213,10 +284,12 @@ __global__ __launch_bounds__(TT_THREADS, 2) void dwconv_mfma_team_tri_kernel(con
         if (tid < TT_ZROW * 2 / 16) *(u32x4*)(L + zrow_b + tid * 16) = z4;
         for (unsigned o = tid * 16; o < xt_buf_b; o += TT_THREADS * 16) *(u32x4*)(L + xt_b + o) = z4;         // x^T guard rows / pad columns
         // ring: 2 guard rows in front of every plane + 2 behind the last, of every tensor part of every slot
-        const int ngr = NB * NT * (p.G + 1);
+        constexpr int NGT = DGRAD ? 2 : 1;                            // guarded tensors per slot (dgrad: tensors 1, 2)
+        const int ngr = NB * NGT * (p.G + 1);
         for (int q = wave; q < ngr; q += TT_WAVES) {
-            const int st = q / (p.G + 1), jj = q - st * (p.G + 1);                          // st = slot * NT + tensor
-            const unsigned gb = ring_b + (unsigned)st * tslot_b + jj * plane_b;
+            const int st = q / (p.G + 1), jj = q - st * (p.G + 1);                          // st = slot * NGT + guarded tensor
+            const int sl = st / NGT, gt = st - sl * NGT;
+            const unsigned gb = ring_b + (unsigned)sl * slot_b + (DGRAD ? t0_b + (unsigned)gt * tslot_b : 0u) + jj * plane_b;
             for (int o = lane; o < p.W; o += 64) *(unsigned*)(L + gb + o * 4) = 0u;       // 2W elements = W dwords
         }
     }
@@ -251,11 +324,22 @@ __global__ __launch_bounds__(TT_THREADS, 2) void dwconv_mfma_team_tri_kernel(con
     const bool a_vert = CLS == 2 ? (g2 == 0) : true;
     const int s_sub = CLS == 2 ? (DGRAD ? (g2 == 0 ? mt : 1 - mt) : g2) : 0;
     s16x8 fragA[MF_TAPS][KS];                                        // CLS 2: branch A;  CLS 1: vertical
-    s16x8 fragS[MF_TAPS][NKS];                                       // 5 x 5
+    s16x8 fragS[MF_TAPS][CLS == 1 ? NKS : 1];                        // CLS 1: 5 x 5 (CLS 2 keeps them in LDS: team_small_tile_mma)
     s16x8 fragH[MF_TAPS][CLS == 1 ? KS : 1];                         // CLS 1: horizontal
     if constexpr (CLS == 2) {
         team_build_frags<KS>(fragA, L + win_b + (a_vert ? 0u : win1_bytes), 0, mt, l31, lhi, a_vert ? p.H : p.W, KL / 2);
-        team_build_frags<NKS>(fragS, L + win_b + 2 * win1_bytes, mt, mt, l31, lhi, p.W, MF_TAPS / 2);
+        {                                                             // wave w builds the five fragments of d = w - 1
+            const int a = TT_ZP + 16 * (wave - 1) + lhi * 8 - l31 + MF_TAPS / 2;          // window start (element index), >= 1
+            const int par = a & 1;
+            const unsigned* src = (const unsigned*)(L + win_b + 2 * win1_bytes + par * MF_TAPS * TT_LEN * 2) + ((a - par) >> 1);
+#pragma unroll
+            for (int r = 0; r < MF_TAPS; ++r) {
+                u32x4 d;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) d[k] = src[r * (TT_LEN / 2) + k];
+                *(u32x4*)(L + sfr_b + (wave * MF_TAPS + r) * 1024 + lane * 16) = d;
+            }
+        }
     } else {
         team_build_frags<KS>(fragA, L + win_b, 0, 0, l31, lhi, p.H, KL / 2);
         team_build_frags<KS>(fragH, L + win_b + win1_bytes, 0, 0, l31, lhi, p.W, KL / 2);
@@ -276,17 +360,21 @@ __global__ __launch_bounds__(TT_THREADS, 2) void dwconv_mfma_team_tri_kernel(con
         orel = (unsigned)(j * HW + orow * p.W + oc) * 2;
         ocmax = orow < p.H ? p.W - oc : 0;
     };
-    auto store_tile = [&](const f32x16& acc, unsigned ob, unsigned orel, int ocmax) {
-        char* op = L + ob + orel;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            if (8 * q < ocmax) {
-                u32x2 v;
-                v[0] = pack2<T>(acc[4 * q + 0], acc[4 * q + 1]);
-                v[1] = pack2<T>(acc[4 * q + 2], acc[4 * q + 3]);
-                *(u32x2*)(op + 16 * q) = v;
-            }
+    auto store_quad = [&](const f32x16& acc, unsigned ob, unsigned orel, int ocmax, int q) {
+        if (8 * q < ocmax) {
+            u32x2 v;
+            v[0] = pack2<T>(acc[4 * q + 0], acc[4 * q + 1]);
+            v[1] = pack2<T>(acc[4 * q + 2], acc[4 * q + 3]);
+            *(u32x2*)(L + ob + orel + 16 * q) = v;
         }
+    };
+    auto store_tile = [&](const f32x16& acc, unsigned ob, unsigned orel, int ocmax) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) store_quad(acc, ob, orel, ocmax, q);
+    };
+    // the same epilogue as fillers of the next tile's MFMAs 2 .. 5 (its accumulator is a different one and has been complete for a while)
+    auto deferred = [&](const f32x16& acc, unsigned ob, unsigned orel, int ocmax) {
+        return [&acc, ob, orel, ocmax, &store_quad](int j) { if (j >= 2 && j < 6) store_quad(acc, ob, orel, ocmax, j - 2); };
     };
     unsigned relA, relS, orelA0, orelA1, orelS; int ocA0, ocA1, ocS;
     if constexpr (CLS == 2) {
@@ -298,7 +386,6 @@ __global__ __launch_bounds__(TT_THREADS, 2) void dwconv_mfma_team_tri_kernel(con
         out_rel(wave, 0, 0, orelA0, ocA0);
         orelA1 = orelA0; orelS = orelA0; ocA1 = ocA0; ocS = ocA0;
     }
-    const unsigned a_pitch = a_vert ? pitch_v : pitch_h;              // CLS 2: branch A's operand pitch; its second tile starts 32 rows further
     // copy-out: chunk idx (< TC = G * chunks_pp) of an out-buffer -> the same chunk of the group's planes in HBM
     const int TC = p.G * p.chunks_pp;
     unsigned co_g[TT_NCO], co_l[TT_NCO]; int co_j[TT_NCO];
@@ -325,7 +412,7 @@ __global__ __launch_bounds__(TT_THREADS, 2) void dwconv_mfma_team_tri_kernel(con
             const bool ok = b < total;                                // uniform per 16-lane group
             const int j = ok ? b / p.tr_pp : 0, rem = ok ? b - j * p.tr_pp : 0;
             const int kb = rem / p.tr_cbs, cb = rem - kb * p.tr_cbs;
-            const unsigned src = (unsigned)(j * p.plane_lds + 2 * p.W + (kb * 4 + (i16 >> 2)) * p.W + cb * 16 + (i16 & 3) * 4) * 2;
+            const unsigned src = (unsigned)(j * p.t0_plane + p.t0_first + (kb * 4 + (i16 >> 2)) * p.W + cb * 16 + (i16 & 3) * 4) * 2;
             const unsigned dst = (cb * 16 + i16 < p.W) ? (unsigned)((j * p.xt_rows + 2 + cb * 16 + i16) * p.PT + kb * 4) * 2 : 0xffffu;
             tr_map[k] = ok ? (src | (dst << 16)) : 0xffffffffu;
         }
@@ -382,78 +469,148 @@ __global__ __launch_bounds__(TT_THREADS, 2) void dwconv_mfma_team_tri_kernel(con
         }
     };
 
+    unsigned long long* tl = p.tl ? p.tl + (size_t)vb * 64 : nullptr;
+    if (tl && tid == 0) {
+        tl[0] = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);        // HW_ID
+        tl[1] = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20);        // XCC_ID
+        tl[2] = __builtin_amdgcn_s_memrealtime();
+        tl[60] = __builtin_readcyclecounter();
+    }
     // group 0 has to be transposed before the loop: every wave waits for ITS pieces of group 0 (NB - 1 groups are younger)
     wait_vmcnt_dyn((NB - 1) * my_pieces);
     wg_barrier();
     if (!(p.dbg & 4)) transpose_group(0);
-    for (int it = 0; it < iters; ++it) {
-        wg_barrier();                        // A: x^T of group `it` complete; the out-buffers have been read out
-        // ---------------- compute phase: this wave's tiles of group `it` -> out-buffers
+    auto compute_phase = [&](int it) {
+        if (tl && tid == 0 && it < 27) tl[3 + 2 * it] = __builtin_amdgcn_s_memrealtime();
+        if (tl && tid == 0 && it == 10) tl[57] = __builtin_readcyclecounter();
+        // ---------------- compute phase: this wave's tiles of group `it` -> out-buffers.  One MFMA stream over the wave's tiles: the
+        // B-fragment pipeline runs across tile boundaries, consecutive tiles alternate between two accumulators and a tile's epilogue
+        // (pack + LDS stores) is issued behind the NEXT tile's MFMAs, when its accumulator has long been complete.
         const unsigned img_b = ring_b + (unsigned)(it % NB) * slot_b;
         if (!(p.dbg & 1)) {
-            f32x16 acc;
+            s16x8 bq[TT_NBUF];
+            f32x16 acc0;
+            auto zero = [](f32x16& a) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) a[i] = 0.f;
+            };
             if constexpr (CLS == 2) {
-                const unsigned a_img = a_vert ? xt_b : img_b + (DGRAD ? tslot_b : 0u);
                 const unsigned a_ob = lout_b + (a_vert ? 0u : out_buf_b);
-                const unsigned s_img = img_b + (DGRAD ? 2 * tslot_b : 0u);
-                auto small_tile = [&]() {
-                    if (mt == 0) team_tile_mma<T, false, R16, KS, NKS, 0>(acc, fragS, L, s_img + relS, pitch_h, wlim, zrow_l);
-                    else team_tile_mma<T, false, R16, KS, NKS, 1>(acc, fragS, L, s_img + relS, pitch_h, wlim, zrow_l);
+                const unsigned s_rp = img_b + (DGRAD ? t0_b + tslot_b : 0u) + relS;
+                // (AV, MT) are wave-uniform run-time values: four straight-line instantiations
+                auto run = [&](auto av_c, auto mt_c) {
+                    constexpr bool AV = decltype(av_c)::value;
+                    constexpr int MT = decltype(mt_c)::value;
+                    constexpr int NA = 1 + !AV;                       // NXT code of an A tile: 1 = SWAP (vertical), 2 = plain
+                    const unsigned a_rp = (AV ? xt_b : img_b + (DGRAD ? t0_b : 0u)) + relA;
+                    const unsigned a_p = AV ? pitch_v : pitch_h, a_rp1 = a_rp + 32u * a_p;
+                    team_tile_prefetch<AV, R16, KS, 0, 0>(bq, L, a_rp, a_p, wlim, zrow_l);
+                    const unsigned sfr_l = sfr_b + lane * 16;
+                    s16x8 sa[TT_NBUF];
+                    if constexpr (!DGRAD) {                           // A(sub 0) -> acc0, A(sub 1) -> acc1, S -> acc0: an epilogue is issued behind the next tile's MFMAs
+                        f32x16 acc1;
+                        zero(acc0);
+                        if (tl && tid == 0 && it == 10) tl[55] = __builtin_readcyclecounter();
+                        team_tile_mma<T, AV, R16, KS, KS, 0, 0, NA, 0>(acc0, fragA, bq, L, a_rp, a_p, wlim, zrow_l, a_rp1, a_p);
+                        if (tl && tid == 0 && it == 10) tl[56] = __builtin_readcyclecounter();
+                        team_small_prefetch<MT>(sa, L, sfr_l);
+                        zero(acc1);
+                        team_tile_mma<T, AV, R16, KS, KS, 0, (MF_TAPS * KS) % TT_NBUF, 2, MT>(acc1, fragA, bq, L, a_rp1, a_p, wlim, zrow_l, s_rp, pitch_h,
+                                                                                                 deferred(acc0, a_ob, orelA0, ocA0));
+                        f32x16 acc2;                                  // (a third name: the first tile's stores are fillers of the second tile)
+                        zero(acc2);
+                        team_small_tile_mma<T, R16, KS, MT, (2 * MF_TAPS * KS) % TT_NBUF, 0, 0>(acc2, sa, bq, L, s_rp, pitch_h, wlim, zrow_l, sfr_l, 0u, 0u,
+                                                                                              deferred(acc1, a_ob, orelA1, ocA1));
+                        store_tile(acc2, lout_b + 2 * out_buf_b, orelS, ocS);
+                    } else {
+                        // the 5 x 5 tile continues the accumulator of the A tile that covers the same pixels: sub = MT (vertical waves), 1 - MT (horizontal)
+                        constexpr int SS = AV ? MT : 1 - MT;
+                        f32x16 acc1;
+                        zero(acc0);
+                        if constexpr (SS == 0) {                      // A(sub 0) + S -> acc0, A(sub 1) -> acc1
+                            team_small_prefetch<MT>(sa, L, sfr_l);
+                            team_tile_mma<T, AV, R16, KS, KS, 0, 0, 2, MT>(acc0, fragA, bq, L, a_rp, a_p, wlim, zrow_l, s_rp, pitch_h);
+                            team_small_tile_mma<T, R16, KS, MT, (MF_TAPS * KS) % TT_NBUF, NA, 0>(acc0, sa, bq, L, s_rp, pitch_h, wlim, zrow_l, sfr_l, a_rp1, a_p);
+                            zero(acc1);
+                            team_tile_mma<T, AV, R16, KS, KS, 0, (MF_TAPS * (KS + 3)) % TT_NBUF, 0, 0>(acc1, fragA, bq, L, a_rp1, a_p, wlim, zrow_l, 0u, 0u,
+                                                                                                      deferred(acc0, a_ob, orelA0, ocA0));
+                            store_tile(acc1, a_ob, orelA1, ocA1);
+                        } else {                                      // A(sub 0) -> acc0, A(sub 1) + S -> acc1
+                            team_tile_mma<T, AV, R16, KS, KS, 0, 0, NA, 0>(acc0, fragA, bq, L, a_rp, a_p, wlim, zrow_l, a_rp1, a_p);
+                            team_small_prefetch<MT>(sa, L, sfr_l);
+                            zero(acc1);
+                            team_tile_mma<T, AV, R16, KS, KS, 0, (MF_TAPS * KS) % TT_NBUF, 2, MT>(acc1, fragA, bq, L, a_rp1, a_p, wlim, zrow_l, s_rp, pitch_h,
+                                                                                                     deferred(acc0, a_ob, orelA0, ocA0));
+                            team_small_tile_mma<T, R16, KS, MT, (2 * MF_TAPS * KS) % TT_NBUF, 0, 0>(acc1, sa, bq, L, s_rp, pitch_h, wlim, zrow_l, sfr_l, 0u, 0u);
+                            store_tile(acc1, a_ob, orelA1, ocA1);
+                        }
+                    }
                 };
-#pragma unroll
-                for (int sub = 0; sub < 2; ++sub) {
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-                    const unsigned rp0 = a_img + relA + (unsigned)sub * 32u * a_pitch;
-                    if (a_vert) team_tile_mma<T, true, R16, KS, KS, 0>(acc, fragA, L, rp0, pitch_v, wlim, zrow_l);
-                    else team_tile_mma<T, false, R16, KS, KS, 0>(acc, fragA, L, rp0, pitch_h, wlim, zrow_l);
-                    if (DGRAD && s_sub == sub) small_tile();          // same pixels, same lane / register map: one accumulator
-                    store_tile(acc, a_ob, sub == 0 ? orelA0 : orelA1, sub == 0 ? ocA0 : ocA1);
-                }
-                if constexpr (!DGRAD) {
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-                    small_tile();
-                    store_tile(acc, lout_b + 2 * out_buf_b, orelS, ocS);
-                }
+                using std::integral_constant;
+                if (a_vert) { if (mt == 0) run(integral_constant<bool, true>{}, integral_constant<int, 0>{}); else run(integral_constant<bool, true>{}, integral_constant<int, 1>{}); }
+                else { if (mt == 0) run(integral_constant<bool, false>{}, integral_constant<int, 0>{}); else run(integral_constant<bool, false>{}, integral_constant<int, 1>{}); }
             } else {
-#pragma unroll
-                for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-                team_tile_mma<T, true, R16, KS, KS, 0>(acc, fragA, L, xt_b + relA, pitch_v, wlim, zrow_l);
-                if constexpr (!DGRAD) {
-                    store_tile(acc, lout_b, orelA0, ocA0);
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+                const unsigned v_rp = xt_b + relA, h_rp = img_b + (DGRAD ? t0_b : 0u) + relS, s_rp = img_b + (DGRAD ? t0_b + tslot_b : 0u) + relS;
+                team_tile_prefetch<true, R16, KS, 0, 0>(bq, L, v_rp, pitch_v, wlim, zrow_l);
+                zero(acc0);
+                team_tile_mma<T, true, R16, KS, KS, 0, 0, 2, 0>(acc0, fragA, bq, L, v_rp, pitch_v, wlim, zrow_l, h_rp, pitch_h);
+                if constexpr (!DGRAD) {                               // V -> acc0, H -> acc1, S -> acc0: an epilogue is issued behind the next tile's MFMAs
+                    f32x16 acc1;
+                    zero(acc1);
+                    team_tile_mma<T, false, R16, KS, KS, 0, (MF_TAPS * KS) % TT_NBUF, 2, 0>(acc1, fragH, bq, L, h_rp, pitch_h, wlim, zrow_l, s_rp, pitch_h,
+                                                                                               deferred(acc0, lout_b, orelA0, ocA0));
+                    f32x16 acc2;
+                    zero(acc2);
+                    team_tile_mma<T, false, R16, KS, NKS, 0, (2 * MF_TAPS * KS) % TT_NBUF, 0, 0>(acc2, fragS, bq, L, s_rp, pitch_h, wlim, zrow_l, 0u, 0u,
+                                                                                                 deferred(acc1, lout_b + out_buf_b, orelA0, ocA0));
+                    store_tile(acc2, lout_b + 2 * out_buf_b, orelA0, ocA0);
+                } else {                                              // the three branches in ONE accumulator
+                    team_tile_mma<T, false, R16, KS, KS, 0, (MF_TAPS * KS) % TT_NBUF, 2, 0>(acc0, fragH, bq, L, h_rp, pitch_h, wlim, zrow_l, s_rp, pitch_h);
+                    team_tile_mma<T, false, R16, KS, NKS, 0, (2 * MF_TAPS * KS) % TT_NBUF, 0, 0>(acc0, fragS, bq, L, s_rp, pitch_h, wlim, zrow_l, 0u, 0u);
+                    store_tile(acc0, lout_b, orelA0, ocA0);
                 }
-                team_tile_mma<T, false, R16, KS, KS, 0>(acc, fragH, L, img_b + (DGRAD ? tslot_b : 0u) + relS, pitch_h, wlim, zrow_l);
-                if constexpr (!DGRAD) {
-                    store_tile(acc, lout_b + out_buf_b, orelA0, ocA0);
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-                }
-                team_tile_mma<T, false, R16, KS, NKS, 0>(acc, fragS, L, img_b + (DGRAD ? 2 * tslot_b : 0u) + relS, pitch_h, wlim, zrow_l);
-                store_tile(acc, lout_b + (DGRAD ? 0u : 2 * out_buf_b), orelA0, ocA0);
             }
         }
         // the transposes of the IO phase read group it+1: this wave's pieces of it.  Younger operations of this wave:
         //   it + 1 <  NB (issued in the prologue): the prologue's later groups + every IO phase so far
         //   it + 1 >= NB (issued in IO phase it + 1 - NB): that phase's stores + NB - 2 whole phases
         {
-            const int younger = it + 1 < NB ? (NB - 2 - it) * my_pieces + it * (my_pieces + NST) : NST + (NB - 2) * (my_pieces + NST);
-            wait_vmcnt_dyn(younger);
+            if (tl && tid == 0 && it == 10) tl[58] = __builtin_readcyclecounter();
+            if (it + 1 < NB) wait_vmcnt_dyn((NB - 2 - it) * my_pieces + it * (my_pieces + NST));
+            else if (NB >= 3) wait_vmcnt<2 * NST + 1>();             // <= NST + (NB - 2) * (my_pieces + NST): a compile-time bound (no jump table in the loop)
+            else wait_vmcnt<NST>();
+            if (tl && tid == 0 && it == 10) tl[59] = __builtin_readcyclecounter();
         }
-        wg_barrier();                        // B: out-buffers complete; x^T and ring slot `it` are free; group it+1 has landed
+    };
+    auto io_phase = [&](int it) {
+        if (tl && tid == 0 && it < 27) tl[4 + 2 * it] = __builtin_amdgcn_s_memrealtime();
         // ---------------- IO phase
+        if (tl && tid == 0 && it == 10) tl[52] = __builtin_readcyclecounter();
         issue_group(it + NB);                                         // into the slot group `it` just left
+        if (tl && tid == 0 && it == 10) tl[53] = __builtin_readcyclecounter();
         if (!(p.dbg & 2)) copy_out(it);
         else {
 #pragma unroll
             for (int k = 0; k < NST; ++k) __builtin_amdgcn_raw_buffer_store_b128(u32x4{0u, 0u, 0u, 0u}, ro[0], TT_OOB, 0, 0);   // keeps the count
         }
+        if (tl && tid == 0 && it == 10) tl[54] = __builtin_readcyclecounter();
         if (it + 1 < iters && !(p.dbg & 4)) transpose_group(it + 1);
+        if (tl && tid == 0 && it == 10) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); tl[51] = __builtin_readcyclecounter(); }
+    };
+    // Anti-phase schedule: between two workgroup barriers team 0 computes group i while team 1 moves the data of its group i-1,
+    // then team 0 moves the data of group i while team 1 computes its group i.  A phase the team has no group for is skipped; the
+    // barriers are executed by everybody (p.iters_max + 1 pairs).
+    for (int i = 0; i <= p.iters_max; ++i) {
+        wg_barrier();
+        if (team == 0) { if (i < iters) compute_phase(i); }
+        else if (i >= 1 && i - 1 < iters) io_phase(i - 1);
+        wg_barrier();
+        if (team == 0) { if (i < iters) io_phase(i); }
+        else if (i < iters) compute_phase(i);
     }
+    if (tl && tid == 0) { tl[63] = __builtin_amdgcn_s_memrealtime(); tl[61] = __builtin_readcyclecounter(); }
     wait_vmcnt<0>();                                                 // nothing of this wave (an LDS-DMA into a slot nobody reads any more) may outlive it
-    if (p.stats) {                                                    // one partial row per wave
+    if (p.stats && has_work) {                                        // one partial row per wave
 #pragma unroll
         for (int k = 0; k < 6; ++k) {
 #pragma unroll
@@ -489,6 +646,9 @@ static bool fill_team_params(TeamParams& p, int N, int C, int H, int W, int K, b
     p.NT = dgrad ? 3 : 1;
     p.plane_lds = HW + 2 * W;
     p.tslot_elems = (p.G * (HW + 2 * W) + 2 * W + 7) & ~7;            // tensor parts stay 16-byte aligned
+    p.t0_elems = dgrad ? ((p.G * HW + 7) & ~7) : p.tslot_elems;
+    p.t0_plane = dgrad ? HW : p.plane_lds;
+    p.t0_first = dgrad ? 0 : 2 * W;
     p.PT = KS * 16 + 8;
     p.xt_rows = W + 4;
     const int TC = p.G * p.chunks_pp;
@@ -512,7 +672,8 @@ static bool fill_team_params(TeamParams& p, int N, int C, int H, int W, int K, b
             if (q >= npieces) { pc.lds_off = 0; pc.g_off = 0; pc.info = 0; continue; }
             const int t = q / (p.G * p.ppp), rem = q - t * (p.G * p.ppp), j = rem / p.ppp, pp = rem - j * p.ppp;
             const int lanes = pp == p.ppp - 1 ? p.chunks_pp - 64 * pp : 64;
-            pc.lds_off = (unsigned)t * (unsigned)p.tslot_elems * 2u + (unsigned)(2 * W) * 2u + (unsigned)j * (unsigned)p.plane_lds * 2u + (unsigned)pp * 1024u;
+            pc.lds_off = t == 0 ? (unsigned)p.t0_first * 2u + (unsigned)j * (unsigned)p.t0_plane * 2u + (unsigned)pp * 1024u
+                                : (unsigned)p.t0_elems * 2u + (unsigned)(t - 1) * (unsigned)p.tslot_elems * 2u + (unsigned)(2 * W) * 2u + (unsigned)j * (unsigned)p.plane_lds * 2u + (unsigned)pp * 1024u;
             pc.g_off = (unsigned)j * (unsigned)(C * HW) * 2u + (unsigned)pp * 1024u;
             pc.info = t | (j << 4) | (lanes << 8);
             ++p.my_pieces[w];
@@ -524,7 +685,8 @@ static bool fill_team_params(TeamParams& p, int N, int C, int H, int W, int K, b
 static size_t team_lds_bytes(const TeamParams& p, int cls) {
     const int nob = p.dgrad ? (cls == 1 ? 1 : 2) : 3;
     const size_t outb = (size_t)nob * p.G * p.H * p.W * 2, win = (size_t)3 * 2 * MF_TAPS * TT_LEN * 2;
-    return (size_t)p.NB * p.NT * p.tslot_elems * 2 + 128 + (size_t)p.G * p.xt_rows * p.PT * 2 + (outb > win ? outb : win) + (size_t)TT_ZROW * 2 + 16;
+    return (size_t)p.NB * ((size_t)p.t0_elems + (size_t)(p.NT - 1) * p.tslot_elems) * 2 + 128 + (size_t)p.G * p.xt_rows * p.PT * 2 + (outb > win ? outb : win) + (size_t)TT_ZROW * 2 +
+           (cls == 2 ? (size_t)TT_SFR_BYTES : 0) + 16;
 }
 
 // ring depth: as deep as two workgroups per CU allow (80 KB each), at most 6 (forward) / 3 (dgrad: three tensors per slot)
@@ -546,6 +708,7 @@ bool dwconv_mfma_team_tri_supported(int N, int C, int H, int W, int K, int dtype
     if (N <= 0 || C <= 0 || (long long)N * C * H * W >= (1LL << 30)) return false;       // byte offsets stay below TT_OOB
     const int cls = team_class(H, W, K);
     if (!cls) return false;
+    if (cls == 2 && W % 8 != 0) return false;                         // (two-half fragment reads do not fit this class's register budget)
     TeamParams p;
     if (!fill_team_params(p, N, C, H, W, K, dgrad, cls, 512)) return false;
     return team_pick_ring(p, cls);
@@ -563,13 +726,15 @@ static int launch_team_t(TeamParams& p, int N, int C, int H, int W, int K, hipSt
     auto k = dwconv_mfma_team_tri_kernel<T, CLS, DGRAD, R16>;
     fill_team_params(p, N, C, H, W, K, DGRAD, CLS, 2 * mfma_cu_count());
     if (!team_pick_ring(p, CLS)) return SLAK_ERR_UNSUPPORTED;
-    const size_t lds = team_lds_bytes(p, CLS);
+    p.team_lds = (int)((team_lds_bytes(p, CLS) + 15) & ~(size_t)15);
+    p.iters_max = (p.planes_per_wg + p.G - 1) / p.G;
+    const size_t lds = (size_t)2 * p.team_lds;
     static thread_local size_t cached_lds = 0;
     if (cached_lds != lds) {
         if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         cached_lds = lds;
     }
-    hipLaunchKernelGGL(k, dim3((unsigned)(p.C * p.slices)), dim3(TT_THREADS), lds, st, p);
+    hipLaunchKernelGGL(k, dim3((unsigned)((p.C * p.slices + 1) / 2)), dim3(2 * TT_THREADS), lds, st, p);
     SLAK_LAUNCH_CHECK();
     return SLAK_OK;
 }
@@ -588,6 +753,7 @@ int launch_dwconv_mfma_team_tri(bool dgrad, const void* const* in, void* const* 
     for (int b = 0; b < 3; ++b) { p.in[b] = in[b]; p.out[b] = out[b]; p.w[b] = w[b]; }
     p.stats = (stats && !dgrad && dtype == SLAK_BF16) ? stats : nullptr;
     { static const int dbg = [] { const char* e = getenv("SLAK_TEAM_DBG"); return e ? atoi(e) : 0; }(); p.dbg = dbg; }
+    p.tl = (p.dbg & 16) ? g_dma_dbg : nullptr;
     const bool r16 = W % 8 == 0;
     if (dtype == SLAK_BF16) return cls == 2 ? launch_team_c<bf16_t, 2>(p, dgrad, r16, N, C, H, W, K, st) : launch_team_c<bf16_t, 1>(p, dgrad, r16, N, C, H, W, K, st);
     return cls == 2 ? launch_team_c<f16_t, 2>(p, dgrad, r16, N, C, H, W, K, st) : launch_team_c<f16_t, 1>(p, dgrad, r16, N, C, H, W, K, st);

@@ -250,7 +250,7 @@ def test_branch_bn3_with_large_channel_offsets(N, C, H, W, ratio, gpu):
     for i in range(3):
         v_ref = yr[i].detach().var(dim=(0, 2, 3), unbiased=True)
         rv = (bns[i].running_var.double() - 0.9) / 0.1
-        assert ((rv - v_ref).abs() <= 2e-3 * v_ref + 1e-12).all(), (i, ((rv - v_ref).abs() / v_ref).max().item())
+        assert ((rv - v_ref).abs() <= 2e-3 * v_ref + 1e-5).all(), (i, ((rv - v_ref).abs() / (v_ref + 1e-3)).max().item())   # (a channel of identical values: 0)
         _close(bns[i].running_mean, refs[i].running_mean, 1e-6, "running_mean%d" % i)
         _close(bns[i].weight.grad, refs[i].weight.grad, 2e-3, "dgamma%d" % i)
         _close(bns[i].bias.grad, refs[i].bias.grad, 2e-4, "dbeta%d" % i)
@@ -282,7 +282,7 @@ def test_branch_bn3_remeasures_channels_the_conv_sums_cannot_carry(N, C, H, K, g
         m_ref = y.double().mean(dim=(0, 2, 3))
         assert (m_ref.abs() > 20 * v_ref.sqrt()).any()               # the case is what it claims to be
         rv = (bns[i].running_var.double() - 0.9) / 0.1
-        assert ((rv - v_ref).abs() <= 2e-3 * v_ref + 1e-12).all(), (i, ((rv - v_ref).abs() / v_ref).max().item())
+        assert ((rv - v_ref).abs() <= 2e-3 * v_ref + 1e-5).all(), (i, ((rv - v_ref).abs() / (v_ref + 1e-3)).max().item())   # (a channel of identical values: 0)
     _close(out, outr, 2.0 ** -8 * 1.05 + 2e-3, "out")
 
 
