@@ -101,6 +101,9 @@ def parse():
     ap.add_argument("--no-fused-tri", action="store_true", help="run the three branch convolutions as three autograd nodes (one launch each)")
     ap.add_argument("--no-fused-bn", action="store_true", help="run the three branch BatchNorms + adds as the reference's PyTorch modules")
     ap.add_argument("--no-fused-tail", action="store_true", help="run the block tail (permute/LayerNorm/gamma/residual) as the reference's PyTorch ops")
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl", help="torch.distributed backend at N>1: nccl (= RCCL over xGMI) or gloo (CPU-staged; lets the N>1 code path run with several ranks on ONE GPU)")
+    ap.add_argument("--device", type=int, default=None, help="GPU index of this rank (default LOCAL_RANK); --device 0 on every rank shares one GPU (gloo)")
+    ap.add_argument("--per-step-sync", action="store_true", help="torch.cuda.synchronize() after every step, as engine.py:90 does (default: the K steps are only bracketed)")
     return ap.parse_args()
 
 
@@ -124,9 +127,10 @@ def hot_path_kernels(device, batch, reps, dtype, stages):
     are called directly on preallocated buffers (the tensor-level wrappers of slak_amd.ops add ~10 us of host work per call,
     more than the smallest kernels take), HIP events on the launch stream around `reps` back-to-back launches.
     Per block and pass the model runs (slak_amd.block_ops._TriDwConv):
-      forward   : one launch per branch -- or ONE launch for the three (`tri`, where slak_dwconv2d_tri_supported == 1);
-      bwd_data  : branch 1 plain, branches 2 and 3 ACCUMULATING into the same dx (`+acc`: autograd's adds folded in; 3*S*b bytes:
-                  read dy, read dx, write dx) -- or ONE launch for the three;
+      forward   : one launch per branch -- or ONE launch for the three (`tri`, where slak_dwconv2d_tri_supported_op(.., 0) == 1);
+      bwd_data  : branch 1 plain, branches 2 and 3 ACCUMULATING into the same dx (`+acc`: autograd's adds folded in; they also read dx:
+                  `alg_bytes_incl_acc_read` = 3*S*b, but the HEADLINE price stays SURVEY 8(d)'s 2*S*b per op) -- or ONE launch for the
+                  three (slak_dwconv2d_tri_supported_op(.., 1) == 1);
       bwd_filter: one launch per branch -- or ONE launch for the three (where slak_dwconv2d_tri_filter_workspace_bytes > 0), or ONE for
                   the K x 5 and the 5 x 5 branch (`pair`, where slak_dwconv2d_pair_filter_workspace_bytes > 0) beside the 5 x K launch.
     Algorithmic bytes: SURVEY.md 8(d) per op -- 2*S*b (+ C*kh*kw*4); a three-branch (two-branch) launch is priced at the per-op figure
@@ -144,12 +148,15 @@ def hot_path_kernels(device, batch, reps, dtype, stages):
         S = x.numel()
         shapes = (("Kx5", (K, 5)), ("5xK", (5, K)), ("5x5", (5, 5)))
         wts = [torch.randn(C, 1, kh, kw, device=device) * 0.02 for _, (kh, kw) in shapes]
-        tri = dtype != torch.float32 and L.slak_dwconv2d_tri_supported(dt, batch, C, HW, HW, K) == 1
+        tri_f = dtype != torch.float32 and L.slak_dwconv2d_tri_supported_op(dt, batch, C, HW, HW, K, 0) == 1
+        tri_d = dtype != torch.float32 and L.slak_dwconv2d_tri_supported_op(dt, batch, C, HW, HW, K, 1) == 1
 
-        def add(kernel, branch, op, fn, alg_bytes, flop):
+        def add(kernel, branch, op, fn, alg_bytes, flop, extra_read=0):
             ms = event_time_ms(fn, reps, device)
+            name = L.slak_debug_last_kernel()
             out.append(dict(stage=si + 1, kernel=kernel, branch=branch, op=op, ms=ms, calls_per_step=blocks, alg_bytes=alg_bytes,
-                            gbs=alg_bytes / ms / 1e6, gflop_nominal=flop / 1e9))
+                            alg_bytes_incl_acc_read=alg_bytes + extra_read, gbs=alg_bytes / ms / 1e6, gflop_nominal=flop / 1e9,
+                            hip_kernel=name.decode() if name else ""))
         wbytes = sum(C * kh * kw * 4 for _, (kh, kw) in shapes)
         flops3 = sum(2.0 * S * kh * kw for _, (kh, kw) in shapes)
         tri_w_nb = int(L.slak_dwconv2d_tri_filter_workspace_bytes(dt, batch, C, HW, HW, K)) if dtype != torch.float32 else 0
@@ -159,11 +166,13 @@ def hot_path_kernels(device, batch, reps, dtype, stages):
             a_tw = (dys[0].data_ptr(), dys[1].data_ptr(), dys[2].data_ptr(), x.data_ptr(), dws3[0].data_ptr(), dws3[1].data_ptr(), dws3[2].data_ptr(),
                     dt, batch, C, HW, HW, K, ws3.data_ptr(), tri_w_nb, st)
             add("%dx5+5x%d+5x5" % (K, K), "tri", "bwd_filter", lambda: _lib.check(L.slak_dwconv2d_tri_backward_filter(*a_tw)), 3 * 2 * S * b + wbytes, flops3)
-        if tri:
+        if tri_f or tri_d:
             a_tf = (x.data_ptr(), wts[0].data_ptr(), wts[1].data_ptr(), wts[2].data_ptr(), ys[0].data_ptr(), ys[1].data_ptr(), ys[2].data_ptr(), dt, batch, C, HW, HW, K, st)
             a_td = (dys[0].data_ptr(), dys[1].data_ptr(), dys[2].data_ptr(), wts[0].data_ptr(), wts[1].data_ptr(), wts[2].data_ptr(), ys[0].data_ptr(), dt, batch, C, HW, HW, K, st)
-            add("%dx5+5x%d+5x5" % (K, K), "tri", "fwd", lambda: _lib.check(L.slak_dwconv2d_tri_forward(*a_tf)), 3 * 2 * S * b + wbytes, flops3)
-            add("%dx5+5x%d+5x5" % (K, K), "tri", "bwd_data", lambda: _lib.check(L.slak_dwconv2d_tri_backward_data(*a_td)), 3 * 2 * S * b + wbytes, flops3)
+            if tri_f:
+                add("%dx5+5x%d+5x5" % (K, K), "tri", "fwd", lambda: _lib.check(L.slak_dwconv2d_tri_forward(*a_tf)), 3 * 2 * S * b + wbytes, flops3)
+            if tri_d:
+                add("%dx5+5x%d+5x5" % (K, K), "tri", "bwd_data", lambda: _lib.check(L.slak_dwconv2d_tri_backward_data(*a_td)), 3 * 2 * S * b + wbytes, flops3)
         pair_nb = int(L.slak_dwconv2d_pair_filter_workspace_bytes(dt, batch, C, HW, HW, K)) if (dtype != torch.float32 and not tri_w_nb) else 0
         if pair_nb:
             dwp = [torch.empty_like(wts[0]), torch.empty_like(wts[2])]
@@ -184,11 +193,12 @@ def hot_path_kernels(device, batch, reps, dtype, stages):
             a_d = (dys[0].data_ptr(), dt, w.data_ptr(), _lib.SLAK_F32, ys[0].data_ptr(), dt) + dims + (ws.data_ptr(), ws.numel(), st)
             a_w = (dys[0].data_ptr(), dt, x.data_ptr(), dt, dw.data_ptr()) + dims + (ws.data_ptr(), ws.numel(), st)
             kn, flop, wb = "%dx%d" % (kh, kw), 2.0 * S * kh * kw, C * kh * kw * 4
-            if not tri:
+            if not tri_f:
                 add(kn, kname, "fwd", lambda: _lib.check(L.slak_dwconv2d_forward(*a_f)), 2 * S * b + wb, flop)
+            if not tri_d:
                 acc_ok = bi > 0 and dtype != torch.float32 and L.slak_dwconv2d_backward_data_accumulate(*a_d) == _lib.OK
                 if acc_ok:
-                    add(kn, kname, "bwd_data+acc", lambda: _lib.check(L.slak_dwconv2d_backward_data_accumulate(*a_d)), 3 * S * b + wb, flop)
+                    add(kn, kname, "bwd_data+acc", lambda: _lib.check(L.slak_dwconv2d_backward_data_accumulate(*a_d)), 2 * S * b + wb, flop, extra_read=S * b)
                 else:
                     add(kn, kname, "bwd_data", lambda: _lib.check(L.slak_dwconv2d_backward_data(*a_d)), 2 * S * b + wb, flop)
             if not tri_w_nb and not (pair_nb and bi != 1):
@@ -249,7 +259,44 @@ def cpu_baseline(threads, stages, label, batch=4, seconds_per_shape=1.5):
                            time.perf_counter() - t_start))
 
 
-def mask_step_bench(device, model_name, ks, only_L, reps=20, cpu_seconds=12.0):
+def mask_reference_cpu(ws, ms, gs, rate, elems, gpu_update_ms, budget_s=15.0):
+    """The reference's prune-and-grow step with the reference's own algorithm -- full torch.sort per tensor, twice -- on the host cores
+    (all of them: torch.set_num_threads(os.cpu_count())), over the FULL mask set of the bench model:
+      magnitude_prune (funcs.py:107-114): num_remove = ceil(rate * nnz), k = ceil(zeros + num_remove), idx = sort(|w|) -> mask[idx[:k]] = 0
+      gradient_growth (funcs.py:196-205): g = grad * (mask == 0), idx = sort(|g|, descending) -> mask[idx[:removed]] = 1
+      apply_mask      (sparse_core.py:316-333): w = w * mask
+    Loop structure of truncate_weights (sparse_core.py:335-357): prune every tensor, then grow every tensor, then apply."""
+    import math
+    threads = os.cpu_count() or 1
+    torch.set_num_threads(threads)
+    cw = [w.detach().cpu().clone() for w in ws]; cm = [m.detach().cpu().clone() for m in ms]; cg = [g.detach().cpu() for g in gs]
+    def update():
+        removed = []
+        for w, m in zip(cw, cm):
+            nnz = int(m.sum().item()); zeros = m.numel() - nnz
+            num_remove = math.ceil(rate * nnz)
+            k = math.ceil(zeros + num_remove)
+            _, idx = torch.sort(torch.abs(w.flatten()))
+            m.view(-1)[idx[:k]] = 0.0
+            removed.append(num_remove)
+        for g, m, r in zip(cg, cm, removed):
+            gg = g * (m == 0).float()
+            _, idx = torch.sort(torch.abs(gg).flatten(), descending=True)
+            m.view(-1)[idx[:r]] = 1.0
+        for w, m in zip(cw, cm):
+            w.mul_(m)
+    t0 = time.perf_counter(); n = 0
+    while n < 1 or (time.perf_counter() - t0 < budget_s and n < 10):
+        update(); n += 1
+    dt = (time.perf_counter() - t0) / n
+    return {"kind": "reference", "cores": threads, "ms_per_update": dt * 1e3, "elements": elems, "tensors": len(ws),
+            "melem_per_s": elems / dt / 1e6, "gpu_over_cpu": (dt * 1e3) / gpu_update_ms,
+            "sample": "the reference algorithm (funcs.py:107-114 magnitude_prune, :196-205 gradient_growth: a full torch.sort per tensor and "
+                      "direction; sparse_core.py:335-357 loop order) in torch %s on the host, torch.set_num_threads(%d), all %d tensors / %d elements, "
+                      "%d repetitions" % (torch.__version__, threads, len(ws), elems, n)}
+
+
+def mask_step_bench(device, model_name, ks, only_L, reps=20, cpu_seconds=6.0):
     """The Masking kernels alone: `slak_mask_apply` (ordinary steps when the optimizer does not fold
     the mask in; 12 B per masked element: w r/w + mask r) and `slak_mask_prune_and_grow` (update steps; fused ideal 20 B per element:
     w r/w 8 + grad r 4 + mask r/w 8) over the mask set of the bench model -- every 2-D / 4-D parameter (95 tensors / 30.7 M elements
@@ -298,6 +345,7 @@ def mask_step_bench(device, model_name, ks, only_L, reps=20, cpu_seconds=12.0):
     while reps_cpu < 1 or (time.perf_counter() - t1 < cpu_seconds and reps_cpu < 20):
         oracle.truncate_weights(cw, cm, cg, 0.3); reps_cpu += 1
     dt = (time.perf_counter() - t1) / reps_cpu
+    out["cpu_reference"] = mask_reference_cpu(ws, ms, gs, 0.3, elems, t_update)
     out["cpu_port"] = {"kind": "port", "cores": 1, "ms_per_update": dt * 1e3, "elements": done, "tensors": n_t,
                        "melem_per_s": done / dt / 1e6, "gpu_melem_per_s": elems / (t_update / 1e3) / 1e6,
                        "sample": "oracle/mask_oracle.py truncate_weights (numpy restatement of sparse_core.py:335-357, funcs.py:107-114,196-205) on the %d smallest tensors (%d elements), %d repetitions" % (n_t, done, reps_cpu)}
@@ -311,13 +359,17 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X (no CPU fallback for the hot path)")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    dev_index = local_rank if a.device is None else a.device
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     distributed = world > 1
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=device)        # "nccl" is RCCL on ROCm
+        if a.backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)    # "nccl" is RCCL on ROCm
+        else:
+            dist.init_process_group("gloo")
     n_gpus = world if distributed else 1
     ks = kernel_sizes(a.kernel)
     stages = stages_of(a.model, a.kernel, a.res)
@@ -343,7 +395,7 @@ def main():
     model = M.create_model("SLaK_" + a.model, kernel_size=ks, Decom=True, bn=True, drop_path_rate=drop_path,
                            lowp_dwconv=not a.fp32_dwconv).to(device)
     if distributed:
-        model = nn.parallel.DistributedDataParallel(model, device_ids=[local_rank], find_unused_parameters=False)   # main.py:374-376
+        model = nn.parallel.DistributedDataParallel(model, device_ids=[dev_index], find_unused_parameters=False)   # main.py:374-376
     decay, no_decay = [], []
     for n, p in model.named_parameters():
         (no_decay if (p.dim() == 1 or n.endswith(".bias")) else decay).append(p)                                     # optim_factory.py no-decay rule
@@ -384,6 +436,8 @@ def main():
         opt.zero_grad(set_to_none=True)
         if model_ema is not None:
             model_ema.update(model, mask)
+        if a.per_step_sync:
+            torch.cuda.synchronize()                              # engine.py:90
         return loss
 
     model.train()
@@ -449,7 +503,10 @@ def main():
                    "cudnn_benchmark": bool(a.cudnn_benchmark),
                    "prime_steps": a.prime,
                    "world_size": (dist.get_world_size() if distributed else 1),
-                   "rccl_version": (".".join(str(v) for v in torch.cuda.nccl.version()) if distributed else None),
+                   "backend": (a.backend if distributed else None),
+                   "rccl_version": (".".join(str(v) for v in torch.cuda.nccl.version()) if (distributed and a.backend == "nccl") else None),
+                   "per_step_sync": bool(a.per_step_sync),
+                   "timing": "K steps between barrier + torch.cuda.synchronize() on both sides; " + ("a synchronize after every step as engine.py:90" if a.per_step_sync else "no synchronize inside (GPU-busy time == step time: the host runs ahead)"),
                    "per_rank_ms_per_step": [round(v, 4) for v in per_rank_ms],
                    "mask_sync": mask_sync,
                    "final_loss": final_loss},
@@ -463,13 +520,20 @@ def main():
             k["step_ms"] = k["ms"] * k["calls_per_step"]
         dom = max(kl, key=lambda k: k["step_ms"])
         hot_ms = sum(k["step_ms"] for k in kl)
-        hot_bytes = sum(k["alg_bytes"] * k["calls_per_step"] for k in kl)
+        hot_bytes = sum(k["alg_bytes"] * k["calls_per_step"] for k in kl)               # 2*S*b per op and pass (9.88 GB for SLaK-T)
+        hot_bytes_acc = sum(k["alg_bytes_incl_acc_read"] * k["calls_per_step"] for k in kl)
+        pmc = [(measured_traffic(k), k["calls_per_step"]) for k in kl]
+        hot_bytes_pmc = sum(t * c for t, c in pmc) if all(t is not None for t, _ in pmc) else None
         out["roofline"] = {"bound": "hbm", "achieved": dom["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": dom["gbs"] / HBM_PEAK_GBS,
                            "traffic": measured_traffic(dom), "kernel": "dwconv %s %s stage %d (N=%d)" % (dom["kernel"], dom["op"], dom["stage"], a.batch),
                            "avg_launch_ms": dom["ms"], "alg_bytes_per_launch": dom["alg_bytes"],
                            "valu_tflops_nominal": dom["gflop_nominal"] / dom["ms"]}
         out["hot_path"] = {"dwconv_ms_per_step": hot_ms, "dwconv_alg_gb_per_step": hot_bytes / 1e9,
                            "dwconv_gbs": hot_bytes / hot_ms / 1e6, "dwconv_frac_of_hbm_peak": hot_bytes / hot_ms / 1e6 / HBM_PEAK_GBS,
+                           "pricing": "SURVEY 8(d): 2*S*b per op and pass; a launch that replaces several ops is priced at the ops it replaces",
+                           "dwconv_frac_incl_acc_reads": hot_bytes_acc / hot_ms / 1e6 / HBM_PEAK_GBS,
+                           "dwconv_frac_of_measured_hbm_traffic": (hot_bytes_pmc / hot_ms / 1e6 / HBM_PEAK_GBS) if hot_bytes_pmc else None,
+                           "lowest_kernel_frac": min(k["gbs"] for k in kl) / HBM_PEAK_GBS,
                            "share_of_step": hot_ms / ms_per_step,
                            "images_per_s_dwconv_only": a.batch / (hot_ms / 1e3),
                            "kernels": [{k2: (round(v, 4) if isinstance(v, float) else v) for k2, v in k.items()} for k in kl]}

@@ -132,11 +132,16 @@ int slak_mask_checksum(slak_mask_plan_t* plan, unsigned long long* out_host, voi
  * ReparamLargeKernelConv.forward runs LoRA1 (K x 5), LoRA2 (5 x K) and small_conv (5 x 5) on the same input (models/SLaK.py:82-100).
  * forward: x is read once for the three outputs; backward_data: the three partial input gradients are summed inside the kernel
  * (autograd would add them with two elementwise passes).  16-bit tensors (dtype = SLAK_BF16 / SLAK_F16), fp32 filters
- * (C,1,K,5), (C,1,5,K), (C,1,5,5).  slak_dwconv2d_tri_supported returns 1 for the 14x14 class (W even, 8 <= W <= 14, H <= 14: the
- * three contributions are summed in the fp32 accumulator and rounded once), 2 for the 56x56 / 28x28 class (16 < H, W <= 64, both in
- * (16,32] or both in (32,64], H % 4 == W % 4 == 0: every branch's partial gradient is rounded to the tensor dtype, the three are added
- * in fp32 and rounded again -- one rounding fewer than autograd's two adds), 0 otherwise: then the calls return SLAK_ERR_UNSUPPORTED
- * and the caller issues the three slak_dwconv2d_* calls instead. */
+ * (C,1,K,5), (C,1,5,K), (C,1,5,5).  slak_dwconv2d_tri_supported_op(.., op) -- op 0 forward, 1 backward_data -- returns 1 where a
+ * one-launch kernel exists AND measured faster than the per-branch entry points on MI355X: planes up to 16 x 16 (wave-independent
+ * kernels; the three gradient contributions are summed in the fp32 accumulator and rounded once) and planes of one MFMA tile (17..32:
+ * four-wave-team kernels, same rounding) for both ops; planes of 2 x 2 tiles (33..64, H % 4 == 0, W % 8 == 0) for the data gradient only
+ * (two rounded partial planes -- vertical [+ small], horizontal [+ small] -- added like a tensor add: one rounding fewer than autograd's
+ * two adds).  0: the caller issues the three slak_dwconv2d_* calls.  slak_dwconv2d_tri_supported = both ops.  The launches themselves
+ * run wherever a kernel exists (SLAK_ERR_UNSUPPORTED otherwise).
+ * slak_debug_last_kernel(): name of the kernel family the calling thread's last conv entry point launched (dispatch tests). */
+int slak_dwconv2d_tri_supported_op(int dtype, int N, int C, int H, int W, int K, int op);
+const char* slak_debug_last_kernel(void);
 int slak_dwconv2d_tri_supported(int dtype, int N, int C, int H, int W, int K);
 int slak_dwconv2d_tri_forward(const void* x, const float* w_v, const float* w_h, const float* w_s, void* y_v, void* y_h, void* y_s,
                               int dtype, int N, int C, int H, int W, int K, void* stream);

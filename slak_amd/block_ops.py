@@ -123,7 +123,6 @@ class _ScaleResidual(torch.autograd.Function):
 
 accumulate_dgrad = os.environ.get("SLAK_DGRAD_ACC", "1") != "0"     # A/B switch: 0 = three plain launches + two tensor adds
 fused_tri_wgrad = os.environ.get("SLAK_TRI_WGRAD", "1") != "0"      # A/B switch: 0 = three weight-gradient launches per block everywhere
-use_big_tri = os.environ.get("SLAK_BIG_TRI", "0") == "1"      # dev switch: take the one-launch kernels of the 56x56 / 28x28 class where they exist
 
 
 class _TriDwConv(torch.autograd.Function):
@@ -142,11 +141,11 @@ class _TriDwConv(torch.autograd.Function):
             raise RuntimeError("tri_dwconv expects filters (C,1,K,5), (C,1,5,K), (C,1,5,5)")
         L = _lib.lib()
         dt = ops._DT.get(x.dtype)
-        # 1: one-launch kernels that win (14x14 / 7x7 class; round 3: the four-wave-team kernels of the 56x56 / 28x28 class).
-        # 2: the round-2 twelve-wave kernels of the 56x56 / 28x28 class (lost to three launches: dev switch only).
-        kind = L.slak_dwconv2d_tri_supported(dt, N, C, H, W, K) if dt is not None else 0
-        tri = (all(w.dtype == torch.float32 and w.is_contiguous() for w in (wv, wh, ws))
-               and (kind == 1 or (use_big_tri and kind == 2)))
+        # one launch for the three branches where the library says it wins (slak_dwconv2d_tri_supported_op: per op -- on the 56x56
+        # class only the data gradient does)
+        f32w = all(w.dtype == torch.float32 and w.is_contiguous() for w in (wv, wh, ws))
+        tri = bool(dt is not None and f32w and L.slak_dwconv2d_tri_supported_op(dt, N, C, H, W, K, 0) == 1)
+        ctx.tri_dgrad = bool(dt is not None and f32w and L.slak_dwconv2d_tri_supported_op(dt, N, C, H, W, K, 1) == 1)
         stats = None
         if tri:
             yv, yh, ys = torch.empty_like(x), torch.empty_like(x), torch.empty_like(x)
@@ -168,7 +167,6 @@ class _TriDwConv(torch.autograd.Function):
         else:
             yv, yh, ys = ops.dwconv2d_forward(x, wv), ops.dwconv2d_forward(x, wh), ops.dwconv2d_forward(x, ws)
         ctx.save_for_backward(x, wv, wh, ws)
-        ctx.tri = tri
         if want_stats:
             # the sums travel as three non-differentiable outputs: one [rows][C][6] array (three-branch launch) seen through three offsets,
             # three [rows_b][C][2] arrays (per-branch launches), or three empty tensors
@@ -190,7 +188,7 @@ class _TriDwConv(torch.autograd.Function):
         dyv, dyh, dys = (g.contiguous() if g.dtype == x.dtype else g.to(x.dtype).contiguous() for g in (dyv, dyh, dys))
         dx = None
         if ctx.needs_input_grad[0]:
-            if ctx.tri:
+            if ctx.tri_dgrad:
                 dx = torch.empty_like(x)
                 L = _lib.lib()
                 with torch.cuda.device(x.device):
@@ -266,9 +264,8 @@ def tri_dwconv_sum(x, w_vertical, w_horizontal, w_small, bias=None):
         L = _lib.lib()
         dt = ops._DT.get(x.dtype)
         ws = [w.detach().float().contiguous() for w in (w_vertical, w_horizontal, w_small)]
-        kind = L.slak_dwconv2d_tri_supported(dt, N, C, H, W, K) if dt is not None else 0
-        if (ws[0].shape == (C, 1, K, 5) and ws[1].shape == (C, 1, 5, K) and ws[2].shape == (C, 1, 5, 5)
-                and (kind == 1 or (use_big_tri and kind == 2))):          # the same policy as the training node
+        if (dt is not None and ws[0].shape == (C, 1, K, 5) and ws[1].shape == (C, 1, 5, K) and ws[2].shape == (C, 1, 5, 5)
+                and L.slak_dwconv2d_tri_supported_op(dt, N, C, H, W, K, 1) == 1):      # (it IS the data-gradient kernel: same policy as the training node)
             fl = [w.flip(2, 3).contiguous() for w in ws]
             y = torch.empty_like(x)
             with torch.cuda.device(x.device):

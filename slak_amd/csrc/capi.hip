@@ -12,6 +12,8 @@ namespace slak {
 static std::mutex g_err_mu;
 static std::string g_last_hip_error = "";
 static std::atomic<int> g_conv_algo{SLAK_ALGO_AUTO};     // process-wide A/B switch (tests); read once per call
+thread_local const char* g_last_kernel = "";           // slak_debug_last_kernel()
+#define SLAK_RAN(name, call) (slak::g_last_kernel = (name), (call))
 static bool use_small_dma() {                // SLAK_MFMA_SMALL_DMA=0 keeps the channel-blocked small-plane kernel (A/B testing)
     static const bool v = [] { const char* e = getenv("SLAK_MFMA_SMALL_DMA"); return !(e && e[0] == '0'); }();
     return v;
@@ -23,13 +25,6 @@ static bool use_vrows_pair() {               // SLAK_VROWS_PAIR=0: the 56 x 56 c
 static bool use_vrows() {                    // SLAK_MFMA_VROWS=0 keeps the transposing vertical weight-gradient kernel (A/B testing)
     static const bool v = [] { const char* e = getenv("SLAK_MFMA_VROWS"); return !(e && e[0] == '0'); }();
     return v;
-}
-static std::atomic<int> g_dense_tri{-1};     // -1: SLAK_DENSE_TRI (default off: measured on par with the per-plane kernels), 0 / 1: slak_debug_set_dense_tri
-static bool use_dense_tri() {
-    const int v = g_dense_tri.load();
-    if (v >= 0) return v != 0;
-    static const bool e = [] { const char* s = getenv("SLAK_DENSE_TRI"); return s && s[0] == '1'; }();
-    return e;
 }
 static bool use_small() {                    // SLAK_MFMA_SMALL=0 keeps the generic register-staged kernel for H,W <= 16 (A/B testing)
     static int v = -1;
@@ -68,8 +63,9 @@ extern "C" {
 
 /* dev hook (not in the public header): device buffer of 4x8 u64 that workgroup 0 of the DMA conv kernel fills with per-phase cycle counts */
 void slak_debug_set_phase_buffer(void* p) { slak::g_dma_dbg = (unsigned long long*)p; }
-/* dev hook (not in the public header): route planes of <= 64 pixels through the dense-operator three-branch kernels (1), the per-plane ones (0), or follow SLAK_DENSE_TRI (-1) */
-void slak_debug_set_dense_tri(int v) { g_dense_tri = v; }
+/* dev hook (tests/test_dispatch_gpu.py): the name of the kernel family the calling thread's last conv / mask entry point launched -- a support
+ * predicate that regresses lands a shape on a slower kernel with parity intact; this is what the dispatch tests pin */
+const char* slak_debug_last_kernel(void) { return slak::g_last_kernel; }
 
 const char* slak_status_string(int status) {
     switch (status) {
@@ -129,17 +125,17 @@ int slak_dwconv2d_forward(const void* x, int x_dtype, const void* w, int w_dtype
     if (rc != SLAK_OK) return rc;
     ConvDims d{N, C, H, W, kh, kw};
     if (g_conv_algo != SLAK_ALGO_DIRECT && use_dma() && dwconv_mfma_dma_supported(d, x_dtype, w_dtype, y_dtype))
-        return launch_dwconv_mfma_dma(x, x_dtype, w, w_dtype, y, y_dtype, d, /*flip=*/false, workspace, workspace_bytes, (hipStream_t)stream);
+        return SLAK_RAN("dwconv_mfma_dma", launch_dwconv_mfma_dma(x, x_dtype, w, w_dtype, y, y_dtype, d, /*flip=*/false, workspace, workspace_bytes, (hipStream_t)stream));
     if (g_conv_algo != SLAK_ALGO_DIRECT && dwconv_mfma_wide_supported(d, x_dtype, w_dtype, y_dtype))
-        return launch_dwconv_mfma_wide(x, x_dtype, w, w_dtype, y, y_dtype, d, /*flip=*/false, (hipStream_t)stream);
+        return SLAK_RAN("dwconv_mfma_wide", launch_dwconv_mfma_wide(x, x_dtype, w, w_dtype, y, y_dtype, d, /*flip=*/false, (hipStream_t)stream));
     if (g_conv_algo != SLAK_ALGO_DIRECT && use_small_dma() && dwconv_mfma_small_dma_supported(d, x_dtype, w_dtype, y_dtype))
-        return launch_dwconv_mfma_small_dma(x, x_dtype, w, w_dtype, y, y_dtype, d, /*flip=*/false, (hipStream_t)stream);
+        return SLAK_RAN("dwconv_mfma_small_dma", launch_dwconv_mfma_small_dma(x, x_dtype, w, w_dtype, y, y_dtype, d, /*flip=*/false, (hipStream_t)stream));
     if (g_conv_algo != SLAK_ALGO_DIRECT && use_small() && dwconv_mfma_small_supported(d, x_dtype, w_dtype, y_dtype))
-        return launch_dwconv_mfma_small(x, x_dtype, w, w_dtype, y, y_dtype, d, /*flip=*/false, workspace, workspace_bytes, (hipStream_t)stream);
+        return SLAK_RAN("dwconv_mfma_small", launch_dwconv_mfma_small(x, x_dtype, w, w_dtype, y, y_dtype, d, /*flip=*/false, workspace, workspace_bytes, (hipStream_t)stream));
     if (g_conv_algo != SLAK_ALGO_DIRECT && dwconv_mfma_supported(d, x_dtype, w_dtype, y_dtype))
-        return launch_dwconv_mfma(x, x_dtype, w, w_dtype, y, y_dtype, d, /*flip=*/false, workspace, workspace_bytes, (hipStream_t)stream);
+        return SLAK_RAN("dwconv_mfma", launch_dwconv_mfma(x, x_dtype, w, w_dtype, y, y_dtype, d, /*flip=*/false, workspace, workspace_bytes, (hipStream_t)stream));
     if (g_conv_algo == SLAK_ALGO_MFMA) return SLAK_ERR_UNSUPPORTED;
-    return launch_dwconv_direct(x, x_dtype, w, w_dtype, y, y_dtype, d, /*flip=*/false, workspace, workspace_bytes, (hipStream_t)stream);
+    return SLAK_RAN("dwconv_direct", launch_dwconv_direct(x, x_dtype, w, w_dtype, y, y_dtype, d, /*flip=*/false, workspace, workspace_bytes, (hipStream_t)stream));
 }
 
 int slak_dwconv2d_backward_data(const void* dy, int dy_dtype, const void* w, int w_dtype, void* dx, int dx_dtype,
@@ -151,17 +147,17 @@ int slak_dwconv2d_backward_data(const void* dy, int dy_dtype, const void* w, int
     // data-grad of a stride-1 "same" cross-correlation with odd kernels == cross-correlation of dy with
     // the filter rotated by 180 degrees (h + kh/2 - r == h - kh/2 + (kh-1-r)).
     if (g_conv_algo != SLAK_ALGO_DIRECT && use_dma() && dwconv_mfma_dma_supported(d, dy_dtype, w_dtype, dx_dtype))
-        return launch_dwconv_mfma_dma(dy, dy_dtype, w, w_dtype, dx, dx_dtype, d, /*flip=*/true, workspace, workspace_bytes, (hipStream_t)stream);
+        return SLAK_RAN("dwconv_mfma_dma", launch_dwconv_mfma_dma(dy, dy_dtype, w, w_dtype, dx, dx_dtype, d, /*flip=*/true, workspace, workspace_bytes, (hipStream_t)stream));
     if (g_conv_algo != SLAK_ALGO_DIRECT && dwconv_mfma_wide_supported(d, dy_dtype, w_dtype, dx_dtype))
-        return launch_dwconv_mfma_wide(dy, dy_dtype, w, w_dtype, dx, dx_dtype, d, /*flip=*/true, (hipStream_t)stream);
+        return SLAK_RAN("dwconv_mfma_wide", launch_dwconv_mfma_wide(dy, dy_dtype, w, w_dtype, dx, dx_dtype, d, /*flip=*/true, (hipStream_t)stream));
     if (g_conv_algo != SLAK_ALGO_DIRECT && use_small_dma() && dwconv_mfma_small_dma_supported(d, dy_dtype, w_dtype, dx_dtype))
-        return launch_dwconv_mfma_small_dma(dy, dy_dtype, w, w_dtype, dx, dx_dtype, d, /*flip=*/true, (hipStream_t)stream);
+        return SLAK_RAN("dwconv_mfma_small_dma", launch_dwconv_mfma_small_dma(dy, dy_dtype, w, w_dtype, dx, dx_dtype, d, /*flip=*/true, (hipStream_t)stream));
     if (g_conv_algo != SLAK_ALGO_DIRECT && use_small() && dwconv_mfma_small_supported(d, dy_dtype, w_dtype, dx_dtype))
-        return launch_dwconv_mfma_small(dy, dy_dtype, w, w_dtype, dx, dx_dtype, d, /*flip=*/true, workspace, workspace_bytes, (hipStream_t)stream);
+        return SLAK_RAN("dwconv_mfma_small", launch_dwconv_mfma_small(dy, dy_dtype, w, w_dtype, dx, dx_dtype, d, /*flip=*/true, workspace, workspace_bytes, (hipStream_t)stream));
     if (g_conv_algo != SLAK_ALGO_DIRECT && dwconv_mfma_supported(d, dy_dtype, w_dtype, dx_dtype))
-        return launch_dwconv_mfma(dy, dy_dtype, w, w_dtype, dx, dx_dtype, d, /*flip=*/true, workspace, workspace_bytes, (hipStream_t)stream);
+        return SLAK_RAN("dwconv_mfma", launch_dwconv_mfma(dy, dy_dtype, w, w_dtype, dx, dx_dtype, d, /*flip=*/true, workspace, workspace_bytes, (hipStream_t)stream));
     if (g_conv_algo == SLAK_ALGO_MFMA) return SLAK_ERR_UNSUPPORTED;
-    return launch_dwconv_direct(dy, dy_dtype, w, w_dtype, dx, dx_dtype, d, /*flip=*/true, workspace, workspace_bytes, (hipStream_t)stream);
+    return SLAK_RAN("dwconv_direct", launch_dwconv_direct(dy, dy_dtype, w, w_dtype, dx, dx_dtype, d, /*flip=*/true, workspace, workspace_bytes, (hipStream_t)stream));
 }
 
 int slak_dwconv2d_backward_data_accumulate(const void* dy, int dy_dtype, const void* w, int w_dtype, void* dx, int dx_dtype,
@@ -171,7 +167,7 @@ int slak_dwconv2d_backward_data_accumulate(const void* dy, int dy_dtype, const v
     if (rc != SLAK_OK) return rc;
     ConvDims d{N, C, H, W, kh, kw};
     if (g_conv_algo != SLAK_ALGO_DIRECT && use_dma() && dwconv_mfma_dma_supported(d, dy_dtype, w_dtype, dx_dtype))
-        return launch_dwconv_mfma_dma(dy, dy_dtype, w, w_dtype, dx, dx_dtype, d, /*flip=*/true, workspace, workspace_bytes, (hipStream_t)stream, /*accumulate=*/true);
+        return SLAK_RAN("dwconv_mfma_dma", launch_dwconv_mfma_dma(dy, dy_dtype, w, w_dtype, dx, dx_dtype, d, /*flip=*/true, workspace, workspace_bytes, (hipStream_t)stream, /*accumulate=*/true));
     return SLAK_ERR_UNSUPPORTED;            // the caller computes into a temporary and adds
 }
 
@@ -182,55 +178,62 @@ int slak_dwconv2d_backward_filter(const void* dy, int dy_dtype, const void* x, i
     if (rc != SLAK_OK) return rc;
     ConvDims d{N, C, H, W, kh, kw};
     if (g_conv_algo != SLAK_ALGO_DIRECT && use_small_dma() && dwconv_mfma_small_wgrad_dma_supported(d, dy_dtype, x_dtype)) {
-        const int rc = launch_dwconv_mfma_small_wgrad_dma(dy, dy_dtype, x, x_dtype, dw, d, workspace, workspace_bytes, (hipStream_t)stream);
+        const int rc = SLAK_RAN("dwconv_mfma_small_wgrad_dma", launch_dwconv_mfma_small_wgrad_dma(dy, dy_dtype, x, x_dtype, dw, d, workspace, workspace_bytes, (hipStream_t)stream));
         if (rc != SLAK_ERR_UNSUPPORTED) return rc;
     }
     if (g_conv_algo != SLAK_ALGO_DIRECT && use_small() && dwconv_mfma_small_wgrad_supported(d, dy_dtype, x_dtype))
-        return launch_dwconv_mfma_small_wgrad(dy, dy_dtype, x, x_dtype, dw, d, workspace, workspace_bytes, (hipStream_t)stream);
+        return SLAK_RAN("dwconv_mfma_small_wgrad", launch_dwconv_mfma_small_wgrad(dy, dy_dtype, x, x_dtype, dw, d, workspace, workspace_bytes, (hipStream_t)stream));
     if (g_conv_algo != SLAK_ALGO_DIRECT && use_dma() && use_vrows() && dwconv_mfma_wgrad_vrows_supported(d, dy_dtype, x_dtype)) {
-        const int rc = launch_dwconv_mfma_wgrad_vrows(dy, dy_dtype, x, x_dtype, dw, d, workspace, workspace_bytes, (hipStream_t)stream);
+        const int rc = SLAK_RAN("dwconv_mfma_wgrad_vrows", launch_dwconv_mfma_wgrad_vrows(dy, dy_dtype, x, x_dtype, dw, d, workspace, workspace_bytes, (hipStream_t)stream));
         if (rc != SLAK_ERR_UNSUPPORTED) return rc;
     }
     if (g_conv_algo != SLAK_ALGO_DIRECT && use_dma() && dwconv_mfma_wgrad_vwave_supported(d, dy_dtype, x_dtype)) {     // vertical, planes of <= 32 rows
-        const int rc = launch_dwconv_mfma_wgrad_vwave(dy, dy_dtype, x, x_dtype, dw, d, workspace, workspace_bytes, (hipStream_t)stream);
+        const int rc = SLAK_RAN("dwconv_mfma_wgrad_vwave", launch_dwconv_mfma_wgrad_vwave(dy, dy_dtype, x, x_dtype, dw, d, workspace, workspace_bytes, (hipStream_t)stream));
         if (rc != SLAK_ERR_UNSUPPORTED) return rc;
     }
     if (g_conv_algo != SLAK_ALGO_DIRECT && use_dma() && dwconv_mfma_wgrad_dma_supported(d, dy_dtype, x_dtype))
-        return launch_dwconv_mfma_wgrad_dma(dy, dy_dtype, x, x_dtype, dw, d, workspace, workspace_bytes, (hipStream_t)stream);
+        return SLAK_RAN("dwconv_mfma_wgrad_dma", launch_dwconv_mfma_wgrad_dma(dy, dy_dtype, x, x_dtype, dw, d, workspace, workspace_bytes, (hipStream_t)stream));
     if (g_conv_algo != SLAK_ALGO_DIRECT && dwconv_mfma_wide_wgrad_supported(d, dy_dtype, x_dtype))
-        return launch_dwconv_mfma_wide_wgrad(dy, dy_dtype, x, x_dtype, dw, d, workspace, workspace_bytes, (hipStream_t)stream);
+        return SLAK_RAN("dwconv_mfma_wide_wgrad", launch_dwconv_mfma_wide_wgrad(dy, dy_dtype, x, x_dtype, dw, d, workspace, workspace_bytes, (hipStream_t)stream));
     if (g_conv_algo != SLAK_ALGO_DIRECT && dwconv_mfma_wgrad_supported(d, dy_dtype, x_dtype))
-        return launch_dwconv_mfma_wgrad(dy, dy_dtype, x, x_dtype, dw, d, workspace, workspace_bytes, (hipStream_t)stream);
+        return SLAK_RAN("dwconv_mfma_wgrad", launch_dwconv_mfma_wgrad(dy, dy_dtype, x, x_dtype, dw, d, workspace, workspace_bytes, (hipStream_t)stream));
     if (g_conv_algo == SLAK_ALGO_MFMA) return SLAK_ERR_UNSUPPORTED;
-    return launch_dwconv_wgrad(dy, dy_dtype, x, x_dtype, dw, d, workspace, workspace_bytes, (hipStream_t)stream);
+    return SLAK_RAN("dwconv_wgrad", launch_dwconv_wgrad(dy, dy_dtype, x, x_dtype, dw, d, workspace, workspace_bytes, (hipStream_t)stream));
 }
 
 
+/* One launch for the three branches of a block: is there a kernel for (op, shape) that the measurements say should be used?
+ * op 0 forward, 1 backward_data.  1: yes; 0: run the per-branch entry points.  Policy (MI355X, profiles/r03_*):
+ *   planes up to 16 x 16 (14 x 14, 7 x 7 stages): wave-independent three-branch kernels, both ops;
+ *   planes of one MFMA tile (17..32: 28 x 28, 24 x 24): four-wave-team kernels, both ops;
+ *   planes of 2 x 2 tiles (33..64: 56 x 56, 48 x 48): team kernel for the data gradient (117 vs 134 us for plain + 2 accumulating launches
+ *   at 128 x 96 x 56 x 56); forward stays three launches (108 vs 122 us). */
+int slak_dwconv2d_tri_supported_op(int dtype, int N, int C, int H, int W, int K, int op) {
+    if (op != 0 && op != 1) return 0;
+    if (dwconv_mfma_small_tri_supported(N, C, H, W, K, dtype)) return 1;
+    if (!dwconv_mfma_team_tri_supported(N, C, H, W, K, dtype, op == 1)) return 0;
+    const bool one_tile = H <= 32 && W <= 32;
+    static const bool all = [] { const char* e = getenv("SLAK_TEAM_ALL"); return e && e[0] == '1'; }();     // A/B: team kernels wherever they exist
+    return (one_tile || op == 1 || all) ? 1 : 0;
+}
+/* both ops (the merged inference block, callers that want all or nothing) */
 int slak_dwconv2d_tri_supported(int dtype, int N, int C, int H, int W, int K) {
-    if (use_dense_tri() && dwconv_mfma_dense_tri_supported(N, C, H, W, K, dtype)) return 1;                  // planes of <= 64 pixels: dense operator, batch as GEMM dimension
-    if (dwconv_mfma_small_tri_supported(N, C, H, W, K, dtype)) return 1;                                     // 14x14 class: sums in the accumulator
-    if (dwconv_mfma_team_tri_supported(N, C, H, W, K, dtype, false) && dwconv_mfma_team_tri_supported(N, C, H, W, K, dtype, true)) return 1;   // 56x56 / 28x28 class: four-wave teams
-    return (dwconv_mfma_tri_supported(N, C, H, W, K, dtype, false) && dwconv_mfma_tri_supported(N, C, H, W, K, dtype, true)) ? 2 : 0;   // 56x56 / 28x28 class
+    return (slak_dwconv2d_tri_supported_op(dtype, N, C, H, W, K, 0) && slak_dwconv2d_tri_supported_op(dtype, N, C, H, W, K, 1)) ? 1 : 0;
 }
 
 int slak_dwconv2d_tri_forward(const void* x, const float* w_v, const float* w_h, const float* w_s, void* y_v, void* y_h, void* y_s,
                               int dtype, int N, int C, int H, int W, int K, void* stream) {
     if (!x || !w_v || !w_h || !w_s || !y_v || !y_h || !y_s) return SLAK_ERR_INVALID_ARG;
     const void* in[3] = {x, x, x}; void* out[3] = {y_v, y_h, y_s}; const float* w[3] = {w_v, w_h, w_s};
-    if (use_dense_tri() && dwconv_mfma_dense_tri_supported(N, C, H, W, K, dtype))
-        return launch_dwconv_mfma_dense_tri(false, in, out, w, dtype, N, C, H, W, K, (hipStream_t)stream);
     if (dwconv_mfma_small_tri_supported(N, C, H, W, K, dtype))
-        return launch_dwconv_mfma_small_tri(false, in, out, w, dtype, N, C, H, W, K, (hipStream_t)stream);
-    if (dwconv_mfma_team_tri_supported(N, C, H, W, K, dtype, false))
-        return launch_dwconv_mfma_team_tri(false, in, out, w, dtype, N, C, H, W, K, (hipStream_t)stream);
-    return launch_dwconv_mfma_tri(false, in, out, w, dtype, N, C, H, W, K, (hipStream_t)stream);
+        return SLAK_RAN("dwconv_mfma_small_tri", launch_dwconv_mfma_small_tri(false, in, out, w, dtype, N, C, H, W, K, (hipStream_t)stream));
+    return SLAK_RAN("dwconv_mfma_team_tri", launch_dwconv_mfma_team_tri(false, in, out, w, dtype, N, C, H, W, K, (hipStream_t)stream));
 }
 
 /* The forward three-branch launch that also leaves the branch BatchNorms' batch statistics: stats[rows][C][6] = per (row, channel) partial
  * sums (sum y_v, sum y_v^2, sum y_h, sum y_h^2, sum y_s, sum y_s^2) of the stored (rounded) outputs; rows = slak_dwconv2d_tri_stats_rows(...)
  * (0: this shape has no such kernel -- use slak_dwconv2d_tri_forward).  bf16 only. */
 int slak_dwconv2d_tri_stats_rows(int dtype, int N, int C, int H, int W, int K) {
-    if (use_dense_tri()) return 0;
     if (dwconv_mfma_small_tri_supported(N, C, H, W, K, dtype)) return dwconv_mfma_small_tri_stats_rows(N, C, H, W, K, dtype);
     return dwconv_mfma_team_tri_stats_rows(N, C, H, W, K, dtype);
 }
@@ -240,8 +243,8 @@ int slak_dwconv2d_tri_forward_stats(const void* x, const float* w_v, const float
     if (slak_dwconv2d_tri_stats_rows(dtype, N, C, H, W, K) <= 0) return SLAK_ERR_UNSUPPORTED;
     const void* in[3] = {x, x, x}; void* out[3] = {y_v, y_h, y_s}; const float* w[3] = {w_v, w_h, w_s};
     if (dwconv_mfma_small_tri_supported(N, C, H, W, K, dtype))
-        return launch_dwconv_mfma_small_tri(false, in, out, w, dtype, N, C, H, W, K, (hipStream_t)stream, stats);
-    return launch_dwconv_mfma_team_tri(false, in, out, w, dtype, N, C, H, W, K, (hipStream_t)stream, stats);
+        return SLAK_RAN("dwconv_mfma_small_tri", launch_dwconv_mfma_small_tri(false, in, out, w, dtype, N, C, H, W, K, (hipStream_t)stream, stats));
+    return SLAK_RAN("dwconv_mfma_team_tri", launch_dwconv_mfma_team_tri(false, in, out, w, dtype, N, C, H, W, K, (hipStream_t)stream, stats));
 }
 
 /* slak_dwconv2d_forward that also leaves the batch statistics of the BatchNorm behind the conv (models/SLaK.py:38-47 conv -> bn):
@@ -254,21 +257,17 @@ int slak_dwconv2d_forward_stats(const void* x, int x_dtype, const void* w, int w
     if (!stats || !stats_rows) return SLAK_ERR_INVALID_ARG;
     ConvDims d{N, C, H, W, kh, kw};
     if (g_conv_algo == SLAK_ALGO_DIRECT || !use_dma() || x_dtype != SLAK_BF16 || !dwconv_mfma_dma_supported(d, x_dtype, w_dtype, y_dtype)) return SLAK_ERR_UNSUPPORTED;
-    return launch_dwconv_mfma_dma(x, x_dtype, w, w_dtype, y, y_dtype, d, /*flip=*/false, nullptr, 0, (hipStream_t)stream, /*accumulate=*/false,
-                                  stats, stats_capacity_rows, stats_rows);
+    return SLAK_RAN("dwconv_mfma_dma", launch_dwconv_mfma_dma(x, x_dtype, w, w_dtype, y, y_dtype, d, /*flip=*/false, nullptr, 0, (hipStream_t)stream, /*accumulate=*/false,
+                                                         stats, stats_capacity_rows, stats_rows));
 }
 
 int slak_dwconv2d_tri_backward_data(const void* dy_v, const void* dy_h, const void* dy_s, const float* w_v, const float* w_h,
                                     const float* w_s, void* dx, int dtype, int N, int C, int H, int W, int K, void* stream) {
     if (!dy_v || !dy_h || !dy_s || !w_v || !w_h || !w_s || !dx) return SLAK_ERR_INVALID_ARG;
     const void* in[3] = {dy_v, dy_h, dy_s}; void* out[3] = {dx, dx, dx}; const float* w[3] = {w_v, w_h, w_s};
-    if (use_dense_tri() && dwconv_mfma_dense_tri_supported(N, C, H, W, K, dtype))
-        return launch_dwconv_mfma_dense_tri(true, in, out, w, dtype, N, C, H, W, K, (hipStream_t)stream);
     if (dwconv_mfma_small_tri_supported(N, C, H, W, K, dtype))
-        return launch_dwconv_mfma_small_tri(true, in, out, w, dtype, N, C, H, W, K, (hipStream_t)stream);
-    if (dwconv_mfma_team_tri_supported(N, C, H, W, K, dtype, true))
-        return launch_dwconv_mfma_team_tri(true, in, out, w, dtype, N, C, H, W, K, (hipStream_t)stream);
-    return launch_dwconv_mfma_tri(true, in, out, w, dtype, N, C, H, W, K, (hipStream_t)stream);
+        return SLAK_RAN("dwconv_mfma_small_tri", launch_dwconv_mfma_small_tri(true, in, out, w, dtype, N, C, H, W, K, (hipStream_t)stream));
+    return SLAK_RAN("dwconv_mfma_team_tri", launch_dwconv_mfma_team_tri(true, in, out, w, dtype, N, C, H, W, K, (hipStream_t)stream));
 }
 
 size_t slak_dwconv2d_tri_filter_workspace_bytes(int dtype, int N, int C, int H, int W, int K) {
@@ -280,7 +279,7 @@ int slak_dwconv2d_tri_backward_filter(const void* dy_v, const void* dy_h, const 
                                       void* workspace, size_t workspace_bytes, void* stream) {
     if (!dy_v || !dy_h || !dy_s || !x || !dw_v || !dw_h || !dw_s) return SLAK_ERR_INVALID_ARG;
     const void* dy[3] = {dy_v, dy_h, dy_s}; float* dw[3] = {dw_v, dw_h, dw_s};
-    return launch_dwconv_mfma_small_tri_wgrad(dy, x, dw, dtype, N, C, H, W, K, workspace, workspace_bytes, (hipStream_t)stream);
+    return SLAK_RAN("dwconv_mfma_small_tri_wgrad", launch_dwconv_mfma_small_tri_wgrad(dy, x, dw, dtype, N, C, H, W, K, workspace, workspace_bytes, (hipStream_t)stream));
 }
 
 /* The K x 5 and the 5 x 5 weight gradient of a block in ONE launch where the three-branch launch above does not reach (x and its five
@@ -297,9 +296,9 @@ int slak_dwconv2d_pair_backward_filter(const void* dy_v, const void* dy_s, const
     if (N <= 0 || C <= 0 || H <= 0 || W <= 0 || K <= 5) return SLAK_ERR_INVALID_ARG;
     ConvDims d{N, C, H, W, K, MF_TAPS_HOST};
     if (g_conv_algo != SLAK_ALGO_DIRECT && use_dma() && dwconv_mfma_wgrad_vwave_supported(d, dtype, dtype))
-        return launch_dwconv_mfma_wgrad_vwave(dy_v, dtype, x, dtype, dw_v, d, workspace, workspace_bytes, (hipStream_t)stream, dy_s, dw_s);
+        return SLAK_RAN("dwconv_mfma_wgrad_vwave(pair)", launch_dwconv_mfma_wgrad_vwave(dy_v, dtype, x, dtype, dw_v, d, workspace, workspace_bytes, (hipStream_t)stream, dy_s, dw_s));
     if (g_conv_algo != SLAK_ALGO_DIRECT && use_dma() && use_vrows() && use_vrows_pair() && dwconv_mfma_wgrad_vrows_supported(d, dtype, dtype))
-        return launch_dwconv_mfma_wgrad_vrows(dy_v, dtype, x, dtype, dw_v, d, workspace, workspace_bytes, (hipStream_t)stream, dy_s, dw_s);
+        return SLAK_RAN("dwconv_mfma_wgrad_vrows(pair)", launch_dwconv_mfma_wgrad_vrows(dy_v, dtype, x, dtype, dw_v, d, workspace, workspace_bytes, (hipStream_t)stream, dy_s, dw_s));
     return SLAK_ERR_UNSUPPORTED;
 }
 

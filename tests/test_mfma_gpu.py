@@ -215,8 +215,8 @@ def test_tri_dwconv_matches_the_three_branch_convs(N, C, H, W, K, dtype, gpu):
         assert (w.grad - ref).abs().max().item() <= 1e-5 * max(1.0, ref.abs().max().item())
     # where the one-launch kernel ran: the summed gradient is rounded ONCE -> the oracle's half-ulp bound holds for the sum
     L = _lib()
-    kind = L.lib().slak_dwconv2d_tri_supported(L.SLAK_BF16 if dtype == torch.bfloat16 else L.SLAK_F16, N, C, H, W, K)
-    if kind == 2:                                                    # the node runs three launches there (accumulating data gradient)
+    kind = L.lib().slak_dwconv2d_tri_supported_op(L.SLAK_BF16 if dtype == torch.bfloat16 else L.SLAK_F16, N, C, H, W, K, 1)
+    if kind == 1 and (H > 32 or W > 32):                             # planes of 2 x 2 tiles: two rounded partial planes are added (tests/test_fused_launches_gpu.py)
         kind = 0
     xr = [_round(dy, dtype) for dy in dys]
     parts = [oracle.dwconv2d_bwd_data(d, _round(w.detach(), dtype)) for d, w in zip(xr, ws)]
@@ -242,26 +242,6 @@ def test_backward_data_accumulate_is_a_tensor_add_of_the_gradient(N, C, H, W, K,
         want = base + ops.dwconv2d_backward_data(dy, w)
         got = ops.dwconv2d_backward_data_accumulate(dy, w, base.clone())
         assert torch.equal(got, want), (kh, kw, (got.float() - want.float()).abs().max().item())
-
-
-def test_big_tri_kernels_behind_the_dev_switch(gpu):
-    """block_ops.use_big_tri routes the 56x56 / 28x28 class through the one-launch kernels (kept for A/B measurements)."""
-    from slak_amd import block_ops
-    ops = _ops()
-    torch.manual_seed(11)
-    x = torch.randn(5, 3, 56, 56, device=gpu).bfloat16().requires_grad_(True)
-    ws = [(torch.randn(3, 1, kh, kw, device=gpu) * 0.05).requires_grad_(True) for kh, kw in ((51, 5), (5, 51), (5, 5))]
-    dys = [torch.randn(5, 3, 56, 56, device=gpu).bfloat16() for _ in range(3)]
-    block_ops.use_big_tri = True
-    try:
-        ys = block_ops.tri_dwconv(x, *ws)
-        torch.autograd.backward(ys, dys)
-    finally:
-        block_ops.use_big_tri = False
-    for y, w in zip(ys, ws):
-        assert torch.equal(y, ops.dwconv2d_forward(x.detach(), w.detach()))
-    ref = sum(ops.dwconv2d_backward_data(dy, w.detach()).float() for dy, w in zip(dys, ws))
-    assert (x.grad.float() - ref).abs().max().item() <= 2e-2 * max(1.0, ref.abs().max().item())
 
 
 @pytest.mark.parametrize("N,C,H,W,kh,kw", [(32, 24, 56, 56, 51, 5), (32, 24, 28, 28, 5, 49), (48, 64, 14, 14, 47, 5), (16, 8, 96, 96, 5, 61)])
@@ -382,42 +362,6 @@ def test_four_planes_per_tile_three_branch_kernels_on_planes_up_to_7x7(N, C, H, 
     _check(dx, ref, ulp, "quad dgrad")
     for b in ybuf:
         assert (b[x.numel():] == 7.0).all()
-
-
-@pytest.mark.parametrize("N,C,H,W,K", [(6, 5, 7, 7, 13), (40, 5, 7, 7, 13), (1, 1, 7, 7, 13), (65, 3, 8, 8, 9), (33, 2, 3, 4, 7), (100, 9, 7, 7, 13), (4, 3, 6, 6, 9), (3, 2, 7, 5, 7)])
-@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-def test_dense_operator_three_branch_kernels_behind_the_dev_hook(N, C, H, W, K, dtype, gpu):
-    """dwconv_mfma_dense_tri.hip (planes of <= 64 pixels as a dense per-channel operator with the batch as GEMM dimension; off by
-    default: measured on par with the per-plane kernels at SLaK's sizes) against the oracle: every output rounded once."""
-    import ctypes
-    L = _lib()
-    lib = L.lib()
-    hook = lib.slak_debug_set_dense_tri
-    hook.argtypes = [ctypes.c_int]; hook.restype = None
-    dt = L.SLAK_BF16 if dtype == torch.bfloat16 else L.SLAK_F16
-    torch.manual_seed(N + K)
-    x = torch.randn(N, C, H, W, device=gpu).to(dtype)
-    dys = [torch.randn(N, C, H, W, device=gpu).to(dtype) for _ in range(3)]
-    ws = [torch.randn(C, 1, kh, kw, device=gpu) * 0.05 for kh, kw in ((K, 5), (5, K), (5, 5))]
-    ys = [torch.empty_like(x) for _ in range(3)]
-    dx = torch.empty_like(x)
-    st = torch.cuda.current_stream(gpu).cuda_stream
-    hook(1)
-    try:
-        assert lib.slak_dwconv2d_tri_supported(dt, N, C, H, W, K) == 1
-        L.check(lib.slak_dwconv2d_tri_forward(x.data_ptr(), ws[0].data_ptr(), ws[1].data_ptr(), ws[2].data_ptr(), ys[0].data_ptr(), ys[1].data_ptr(),
-                                              ys[2].data_ptr(), dt, N, C, H, W, K, st))
-        L.check(lib.slak_dwconv2d_tri_backward_data(dys[0].data_ptr(), dys[1].data_ptr(), dys[2].data_ptr(), ws[0].data_ptr(), ws[1].data_ptr(),
-                                                    ws[2].data_ptr(), dx.data_ptr(), dt, N, C, H, W, K, st))
-        torch.cuda.synchronize()
-    finally:
-        hook(-1)
-    ulp = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11
-    xr = _round(x, dtype)
-    for y, w in zip(ys, ws):
-        _check(y, oracle.dwconv2d_fwd(xr, _round(w, dtype)), ulp, "dense fwd")
-    ref = sum(oracle.dwconv2d_bwd_data(_round(dy, dtype), _round(w, dtype)) for dy, w in zip(dys, ws))
-    _check(dx, ref, ulp, "dense dgrad")
 
 
 @pytest.mark.parametrize("N,C,H,W,K", [(128, 32, 14, 14, 47), (6, 3, 14, 10, 13), (33, 8, 12, 14, 31),
