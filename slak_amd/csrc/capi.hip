@@ -211,6 +211,7 @@ int slak_dwconv2d_backward_filter(const void* dy, int dy_dtype, const void* x, i
 int slak_dwconv2d_tri_supported_op(int dtype, int N, int C, int H, int W, int K, int op) {
     if (op != 0 && op != 1) return 0;
     if (dwconv_mfma_small_tri_supported(N, C, H, W, K, dtype)) return 1;
+    if (op == 0 && dwconv_mfma_stream_tri_supported(N, C, H, W, K, dtype)) return 1;                        // planes of 2 x 2 tiles, forward: one MFMA stream per wave
     if (!dwconv_mfma_team_tri_supported(N, C, H, W, K, dtype, op == 1)) return 0;
     const bool one_tile = H <= 32 && W <= 32;
     static const bool all = [] { const char* e = getenv("SLAK_TEAM_ALL"); return e && e[0] == '1'; }();     // A/B: team kernels wherever they exist
@@ -227,6 +228,8 @@ int slak_dwconv2d_tri_forward(const void* x, const float* w_v, const float* w_h,
     const void* in[3] = {x, x, x}; void* out[3] = {y_v, y_h, y_s}; const float* w[3] = {w_v, w_h, w_s};
     if (dwconv_mfma_small_tri_supported(N, C, H, W, K, dtype))
         return SLAK_RAN("dwconv_mfma_small_tri", launch_dwconv_mfma_small_tri(false, in, out, w, dtype, N, C, H, W, K, (hipStream_t)stream));
+    if (dwconv_mfma_stream_tri_supported(N, C, H, W, K, dtype))
+        return SLAK_RAN("dwconv_mfma_stream_tri", launch_dwconv_mfma_stream_tri(x, out, w, dtype, N, C, H, W, K, (hipStream_t)stream));
     return SLAK_RAN("dwconv_mfma_team_tri", launch_dwconv_mfma_team_tri(false, in, out, w, dtype, N, C, H, W, K, (hipStream_t)stream));
 }
 
@@ -235,6 +238,7 @@ int slak_dwconv2d_tri_forward(const void* x, const float* w_v, const float* w_h,
  * (0: this shape has no such kernel -- use slak_dwconv2d_tri_forward).  bf16 only. */
 int slak_dwconv2d_tri_stats_rows(int dtype, int N, int C, int H, int W, int K) {
     if (dwconv_mfma_small_tri_supported(N, C, H, W, K, dtype)) return dwconv_mfma_small_tri_stats_rows(N, C, H, W, K, dtype);
+    if (dwconv_mfma_stream_tri_supported(N, C, H, W, K, dtype)) return dwconv_mfma_stream_tri_stats_rows(N, C, H, W, K, dtype);
     return dwconv_mfma_team_tri_stats_rows(N, C, H, W, K, dtype);
 }
 int slak_dwconv2d_tri_forward_stats(const void* x, const float* w_v, const float* w_h, const float* w_s, void* y_v, void* y_h, void* y_s,
@@ -244,6 +248,8 @@ int slak_dwconv2d_tri_forward_stats(const void* x, const float* w_v, const float
     const void* in[3] = {x, x, x}; void* out[3] = {y_v, y_h, y_s}; const float* w[3] = {w_v, w_h, w_s};
     if (dwconv_mfma_small_tri_supported(N, C, H, W, K, dtype))
         return SLAK_RAN("dwconv_mfma_small_tri", launch_dwconv_mfma_small_tri(false, in, out, w, dtype, N, C, H, W, K, (hipStream_t)stream, stats));
+    if (dwconv_mfma_stream_tri_supported(N, C, H, W, K, dtype))
+        return SLAK_RAN("dwconv_mfma_stream_tri", launch_dwconv_mfma_stream_tri(x, out, w, dtype, N, C, H, W, K, (hipStream_t)stream, stats));
     return SLAK_RAN("dwconv_mfma_team_tri", launch_dwconv_mfma_team_tri(false, in, out, w, dtype, N, C, H, W, K, (hipStream_t)stream, stats));
 }
 

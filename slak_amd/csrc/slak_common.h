@@ -95,6 +95,10 @@ bool dwconv_mfma_small_tri_wgrad_supported(int N, int C, int H, int W, int K, in
 size_t dwconv_mfma_small_tri_wgrad_workspace(int N, int C, int K);
 int launch_dwconv_mfma_small_tri_wgrad(const void* const* dy, const void* x, float* const* dw, int dtype,
                                        int N, int C, int H, int W, int K, void* ws, size_t ws_bytes, hipStream_t st);
+bool dwconv_mfma_stream_tri_supported(int N, int C, int H, int W, int K, int dtype);
+int dwconv_mfma_stream_tri_stats_rows(int N, int C, int H, int W, int K, int dtype);
+int launch_dwconv_mfma_stream_tri(const void* x, void* const* out, const float* const* w, int dtype,
+                                  int N, int C, int H, int W, int K, hipStream_t st, float* stats = nullptr);
 bool dwconv_mfma_team_tri_supported(int N, int C, int H, int W, int K, int dtype, bool dgrad);
 int dwconv_mfma_team_tri_stats_rows(int N, int C, int H, int W, int K, int dtype);
 int launch_dwconv_mfma_team_tri(bool dgrad, const void* const* in, void* const* out, const float* const* w, int dtype,

@@ -259,31 +259,49 @@ def test_branch_bn3_with_large_channel_offsets(N, C, H, W, ratio, gpu):
         _close(ys[i].grad, yr[i].grad, 2.0 ** -8 * 1.5 + 2e-3, "dy%d" % i)
 
 
-@pytest.mark.parametrize("N,C,H,K", [(6, 8, 14, 13), (5, 6, 28, 49), (4, 4, 56, 51), (9, 8, 7, 13)])
-def test_branch_bn3_remeasures_channels_the_conv_sums_cannot_carry(N, C, H, K, gpu):
-    """The forward conv launches gather sum y, sum y^2 of what they store as plain fp32 sums (fast path).  A branch output with a large
-    per-channel offset (a constant input and an all-positive filter) makes those sums useless for the variance: the statistics kernel
-    detects mean^2 > 1024 var and re-measures the channel with a two-pass read.  Result vs nn.BatchNorm2d (fp64) on the stored outputs."""
+@pytest.mark.parametrize("N,C,H,rows", [(6, 8, 14, 3), (5, 6, 28, 5), (4, 4, 56, 8), (9, 8, 7, 2)])
+@pytest.mark.parametrize("ratio", [300.0, 1e3])
+def test_branch_bn3_remeasures_channels_the_conv_sums_cannot_carry(N, C, H, rows, ratio, gpu):
+    """The forward conv launches gather sum y, sum y^2 of what they store as plain fp32 partial sums (`stats=` of branch_bn3: rows of
+    [sum, sum of squares] per channel).  With a large per-channel offset those sums cannot carry the variance -- fp32 accumulation has
+    already lost (mean/std)^2 * 1e-7 of it inside every row: the statistics kernel detects mean^2 > 1024 var and re-measures the channel
+    with a two-pass read of its planes.  Here the rows are made the way the kernels make them (fp32 sums over slices of the batch) from
+    tensors with |mean| / std of 300 and 1000; result vs nn.BatchNorm2d (fp64) on the same tensors."""
     import copy
     import torch.nn as nn
     from slak_amd import block_ops
-    torch.manual_seed(H + K)
-    x = (40.0 + torch.randn(N, C, H, H, device=gpu)).bfloat16()
-    ws = [(0.02 + 0.01 * torch.rand(C, 1, kh, kw, device=gpu)) for kh, kw in ((K, 5), (5, K), (5, 5))]
-    y1, y2, y3, st = block_ops.tri_dwconv(x, *ws, want_stats=2)
-    if st[0].numel() == 0:
-        pytest.skip("this shape's conv launches gather no statistics")
+    torch.manual_seed(H + int(ratio))
+    ys, stats = [], []
+    for i in range(3):
+        std = (0.5 + torch.rand(C, device=gpu)).view(1, C, 1, 1) * (1 + i)
+        mean = std * ratio * (0.5 + torch.rand(C, device=gpu)).view(1, C, 1, 1) * (1 if i != 1 else -1)
+        y = (torch.randn(N, C, H, H, device=gpu) * std + mean).bfloat16()
+        ys.append(y)
+        r = torch.zeros(rows, C, 2, dtype=torch.float32, device=gpu)
+        for k, part in enumerate(torch.tensor_split(y.float(), rows, dim=0)):             # fp32 partial sums, as the conv kernels leave them
+            r[k, :, 0] = part.sum(dim=(0, 2, 3)); r[k, :, 1] = (part * part).sum(dim=(0, 2, 3))
+        stats.append(r)
     bns = [nn.BatchNorm2d(C).to(gpu) for _ in range(3)]
     refs = [copy.deepcopy(bn).double() for bn in bns]
-    out = block_ops.branch_bn3(y1, y2, y3, *bns, stats=st)
-    outr = sum(r(y.double()) for r, y in zip(refs, (y1, y2, y3)))
-    for i, y in enumerate((y1, y2, y3)):
+    out = block_ops.branch_bn3(ys[0], ys[1], ys[2], *bns, stats=tuple(stats))
+    outr = sum(r(y.double()) for r, y in zip(refs, ys))
+    for i, y in enumerate(ys):
         v_ref = y.double().var(dim=(0, 2, 3), unbiased=True)
-        m_ref = y.double().mean(dim=(0, 2, 3))
-        assert (m_ref.abs() > 20 * v_ref.sqrt()).any()               # the case is what it claims to be
         rv = (bns[i].running_var.double() - 0.9) / 0.1
-        assert ((rv - v_ref).abs() <= 2e-3 * v_ref + 1e-5).all(), (i, ((rv - v_ref).abs() / (v_ref + 1e-3)).max().item())   # (a channel of identical values: 0)
+        assert ((rv - v_ref).abs() <= 2e-3 * v_ref + 1e-5).all(), (i, ((rv - v_ref).abs() / (v_ref + 1e-3)).max().item())
+        _close(bns[i].running_mean, refs[i].running_mean, 1e-6, "running_mean%d" % i)
     _close(out, outr, 2.0 ** -8 * 1.05 + 2e-3, "out")
+    # and with sums that CAN carry it (ordinary branch outputs) the fast path gives the same statistics as the read pass
+    y0 = [torch.randn(N, C, H, H, device=gpu).bfloat16() * (1 + i) for i in range(3)]
+    st0 = []
+    for y in y0:
+        r = torch.zeros(rows, C, 2, dtype=torch.float32, device=gpu)
+        for k, part in enumerate(torch.tensor_split(y.float(), rows, dim=0)):
+            r[k, :, 0] = part.sum(dim=(0, 2, 3)); r[k, :, 1] = (part * part).sum(dim=(0, 2, 3))
+        st0.append(r)
+    b1 = [nn.BatchNorm2d(C).to(gpu) for _ in range(3)]; b2 = [copy.deepcopy(b) for b in b1]
+    o1 = block_ops.branch_bn3(*y0, *b1, stats=tuple(st0)); o2 = block_ops.branch_bn3(*y0, *b2)
+    _close(o1, o2.double(), 2.0 ** -7, "fast path vs read pass")
 
 
 def test_bn_counter_pool_outside_a_managed_forward(gpu):

@@ -145,3 +145,27 @@ def test_two_ranks_match_single_process(gpu, tmp_path):
             continue
         ref = v.detach().float().cpu()
         assert (got["w"][k] - ref).abs().max() <= 2e-2 * max(1e-3, ref.abs().max().item()) + 1e-5, k
+
+
+def test_bench_n_gt_1_path_runs_with_two_ranks_on_one_gpu():
+    """bench.py's N > 1 branch -- DDP, SyncBatchNorm statistics exchange, Masking with the mask-agreement check, max-over-ranks timing,
+    per-rank times -- launched exactly as the driver launches it (torch.distributed.run, one process per rank), with `--backend gloo
+    --device 0` so that two ranks share the one GPU of this box.  The RCCL backend itself needs two GPUs; everything around it runs here."""
+    import json
+    import socket
+    import subprocess
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--device", "0", "--steps", "3", "--warmup", "1", "--prime", "1",
+           "--batch", "8", "--update-frequency", "2", "--no-roofline", "--no-mask-bench", "--no-cpu-baseline", "--debug-mask-sync"]
+    env = dict(os.environ, SLAK_TUNED_GEMMS="0", OMP_NUM_THREADS="4")
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["config"]["world_size"] == 2 and d["config"]["backend"] == "gloo" and d["scaling"] == "weak"
+    assert d["config"]["global_batch"] == 16 and d["config"]["parallelism"] == "dp2"
+    assert len(d["config"]["per_rank_ms_per_step"]) == 2 and all(t > 0 for t in d["config"]["per_rank_ms_per_step"])
+    assert d["config"]["mask_sync"]["ranks_agree"] is True and d["config"]["mask_sync"]["resyncs"] == 0
+    assert "configs[2]" in d["config"]["workload"] and d["value"] > 0
+    assert abs(d["value"] - 16 * d["steps"] / (d["ms_per_step"] * d["steps"] / 1e3)) <= 1e-6 * d["value"]      # whole-job images/s from the max-over-ranks time
