@@ -76,6 +76,17 @@ def stages_of(model, K, res):
     return [(dims[i], res // (4 << i), ks[i], depths[i]) for i in range(4)]
 
 
+def survey_8d_bytes(stages, batch, b=2):
+    """dw-conv algorithmic bytes of one train step = sum over blocks of 3 convs x 3 passes x 2*S*b (+ the filters: read forward
+    and backward-data, written by backward-filter), S = batch * C * H * W.  9.88 GB for SLaK-T at 128 images (Appendix A)."""
+    total = 0
+    for (C, HW, K, blocks) in stages:
+        S = batch * C * HW * HW
+        wb = C * (2 * K * 5 + 25) * 4
+        total += blocks * (9 * 2 * S * b + 3 * wb)
+    return total
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -528,6 +539,7 @@ def main():
                            "traffic": measured_traffic(dom), "kernel": "dwconv %s %s stage %d (N=%d)" % (dom["kernel"], dom["op"], dom["stage"], a.batch),
                            "avg_launch_ms": dom["ms"], "alg_bytes_per_launch": dom["alg_bytes"],
                            "valu_tflops_nominal": dom["gflop_nominal"] / dom["ms"]}
+        assert abs(hot_bytes - survey_8d_bytes(stages, a.batch, 4 if a.fp32_dwconv else 2)) <= 1e-6 * hot_bytes, "the launches timed do not add up to SURVEY 8(d)'s per-op bytes"
         out["hot_path"] = {"dwconv_ms_per_step": hot_ms, "dwconv_alg_gb_per_step": hot_bytes / 1e9,
                            "dwconv_gbs": hot_bytes / hot_ms / 1e6, "dwconv_frac_of_hbm_peak": hot_bytes / hot_ms / 1e6 / HBM_PEAK_GBS,
                            "pricing": "SURVEY 8(d): 2*S*b per op and pass; a launch that replaces several ops is priced at the ops it replaces",

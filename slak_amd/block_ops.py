@@ -167,6 +167,9 @@ class _TriDwConv(torch.autograd.Function):
         else:
             yv, yh, ys = ops.dwconv2d_forward(x, wv), ops.dwconv2d_forward(x, wh), ops.dwconv2d_forward(x, ws)
         ctx.save_for_backward(x, wv, wh, ws)
+        # (the three statistics outputs are non-differentiable; autograd would still hand backward() a ZERO tensor for each of them --
+        # three fill launches per block and step, 54 of the 56 FillFunctor launches of a SLaK-T step)
+        ctx.set_materialize_grads(False)
         if want_stats:
             # the sums travel as three non-differentiable outputs: one [rows][C][6] array (three-branch launch) seen through three offsets,
             # three [rows_b][C][2] arrays (per-branch launches), or three empty tensors
@@ -185,6 +188,7 @@ class _TriDwConv(torch.autograd.Function):
         x, wv, wh, ws = ctx.saved_tensors
         N, C, H, W = x.shape
         K = wv.shape[2]
+        dyv, dyh, dys = (torch.zeros_like(x) if g is None else g for g in (dyv, dyh, dys))       # (a branch output nobody used)
         dyv, dyh, dys = (g.contiguous() if g.dtype == x.dtype else g.to(x.dtype).contiguous() for g in (dyv, dyh, dys))
         dx = None
         if ctx.needs_input_grad[0]:

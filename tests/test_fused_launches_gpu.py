@@ -137,8 +137,7 @@ def test_pair_backward_filter_vs_oracle(N, C, H, W, K, dtype, gpu):
     x = torch.randn(N, C, H, W, device=gpu).to(dtype)
     dyv, dys = (torch.randn(N, C, H, W, device=gpu).to(dtype) for _ in range(2))
     r = _pair_wgrad(dyv, dys, x, K)
-    if r is None:
-        pytest.skip("no two-branch weight-gradient launch for this shape (two launches run)")
+    assert r is not None, "every shape of PAIR_SMALL has a two-branch weight-gradient launch"
     dwv, dws = r
     xr = _r(x, dtype)
     _check_dw(dwv, oracle.dwconv2d_bwd_filter(_r(dyv, dtype), xr, K, 5), N * H * W, "dw Kx5")
@@ -149,15 +148,30 @@ def test_pair_backward_filter_vs_oracle(N, C, H, W, K, dtype, gpu):
 
 TRI_SMALL = [(5, 7, 14, 14, 47), (4, 3, 12, 10, 9), (1, 1, 14, 14, 13), (6, 5, 7, 7, 13), (17, 6, 7, 7, 13), (3, 9, 14, 14, 47), (9, 4, 12, 12, 13),
              (5, 3, 56, 56, 51), (1, 1, 56, 56, 51), (7, 2, 56, 56, 51), (9, 2, 28, 28, 49), (1, 1, 28, 28, 49), (11, 3, 28, 28, 49),
-             (2, 2, 48, 40, 31), (2, 3, 64, 64, 61), (3, 2, 32, 32, 31), (6, 2, 24, 24, 13), (5, 2, 24, 24, 57), (7, 2, 28, 20, 13), (3, 2, 48, 48, 59)]
+             (2, 2, 48, 40, 31), (3, 2, 32, 32, 31), (6, 2, 24, 24, 13), (5, 2, 24, 24, 57), (7, 2, 28, 20, 13), (3, 2, 48, 48, 59)]
+
+
+def test_shapes_without_a_three_branch_launch_say_so(gpu):
+    """64 x 64 planes (their LDS budget does not fit two workgroups per CU), maps beyond 64, fp32: the support query is 0 and the entry
+    points refuse instead of running something else (block_ops.tri_dwconv then issues the three per-branch launches:
+    tests/test_mfma_gpu.py::test_tri_dwconv_matches_the_three_branch_convs covers those shapes)."""
+    L = _L(); lib = L.lib()
+    for (N, C, H, W, K) in [(2, 3, 64, 64, 61), (3, 2, 96, 96, 61), (2, 2, 36, 36, 31)]:
+        assert lib.slak_dwconv2d_tri_supported(L.SLAK_BF16, N, C, H, W, K) == 0
+        x = torch.randn(N, C, H, W, device=gpu).bfloat16()
+        ws = _filters(C, K, gpu, 1)
+        ys = [torch.empty_like(x) for _ in range(3)]
+        rc = lib.slak_dwconv2d_tri_forward(x.data_ptr(), ws[0].data_ptr(), ws[1].data_ptr(), ws[2].data_ptr(), ys[0].data_ptr(), ys[1].data_ptr(),
+                                           ys[2].data_ptr(), L.SLAK_BF16, N, C, H, W, K, _st(gpu))
+        assert rc == L.ERR_UNSUPPORTED, (N, C, H, W, K, rc)
+    assert lib.slak_dwconv2d_tri_supported_op(L.SLAK_F32, 4, 4, 14, 14, 47, 0) == 0
 
 
 @pytest.mark.parametrize("N,C,H,W,K", TRI_SMALL)
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 def test_tri_forward_and_backward_data_vs_oracle(N, C, H, W, K, dtype, gpu):
     L = _L()
-    if not L.lib().slak_dwconv2d_tri_supported(_dt(dtype), N, C, H, W, K):
-        pytest.skip("no three-branch launch for this shape")
+    assert L.lib().slak_dwconv2d_tri_supported(_dt(dtype), N, C, H, W, K) == 1
     torch.manual_seed(N * 100 + H + K)
     x = torch.randn(N, C, H, W, device=gpu).to(dtype)
     dys = [torch.randn(N, C, H, W, device=gpu).to(dtype) for _ in range(3)]
@@ -187,8 +201,7 @@ def test_tri_backward_filter_vs_oracle(N, C, H, W, K, dtype, gpu):
     x = torch.randn(N, C, H, W, device=gpu).to(dtype)
     dys = [torch.randn(N, C, H, W, device=gpu).to(dtype) for _ in range(3)]
     dws = _tri_wgrad(dys, x, K)
-    if dws is None:
-        pytest.skip("no three-branch weight-gradient launch for this shape")
+    assert dws is not None
     xr = _r(x, dtype)
     for dw, dy, (kh, kw) in zip(dws, dys, ((K, 5), (5, K), (5, 5))):
         _check_dw(dw, oracle.dwconv2d_bwd_filter(_r(dy, dtype), xr, kh, kw), N * H * W, "dw %dx%d" % (kh, kw))
@@ -210,8 +223,7 @@ def test_pair_backward_filter_at_bench_shapes(N, C, H, W, K, gpu):
     x = torch.randn(N, C, H, W, device=gpu).to(dtype)
     dyv, dys = (torch.randn(N, C, H, W, device=gpu).to(dtype) for _ in range(2))
     r = _pair_wgrad(dyv, dys, x, K)
-    if r is None:
-        pytest.skip("no two-branch weight-gradient launch for this shape")
+    assert r is not None
     dwv, dws = r
     ch = _sample_channels(C, 9, seed=K)
     xr = _r(x[:, ch], dtype)
@@ -228,8 +240,7 @@ def test_pair_backward_filter_at_bench_shapes(N, C, H, W, K, gpu):
 def test_tri_launches_at_bench_shapes(N, C, H, W, K, gpu):
     dtype = torch.bfloat16
     L = _L()
-    if not L.lib().slak_dwconv2d_tri_supported(_dt(dtype), N, C, H, W, K):
-        pytest.skip("no three-branch launch for this shape")
+    assert L.lib().slak_dwconv2d_tri_supported(_dt(dtype), N, C, H, W, K) == 1
     torch.manual_seed(K + 1)
     x = torch.randn(N, C, H, W, device=gpu).to(dtype)
     dys = [torch.randn(N, C, H, W, device=gpu).to(dtype) for _ in range(3)]
