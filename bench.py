@@ -102,6 +102,7 @@ def parse():
     ap.add_argument("--no-mask-bench", action="store_true", help="skip the mask_step measurement")
     ap.add_argument("--debug-mask-sync", action="store_true", help="N>1: all-reduce a mask checksum after the timed region and fail on disagreement")
     ap.add_argument("--update-frequency", type=int, default=2000)
+    ap.add_argument("--host-profile", action="store_true", help="cProfile of the step's enqueue path, printed to stderr after the timed region")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--kernel-reps", type=int, default=30)
@@ -312,8 +313,8 @@ def mask_step_bench(device, model_name, ks, only_L, reps=20, cpu_seconds=6.0):
     the mask in; 12 B per masked element: w r/w + mask r) and `slak_mask_prune_and_grow` (update steps; fused ideal 20 B per element:
     w r/w 8 + grad r 4 + mask r/w 8) over the mask set of the bench model -- every 2-D / 4-D parameter (95 tensors / 30.7 M elements
     for SLaK-T; --only-L: the 36 LoRA tensors) -- through the C ABI, HIP events on the launch stream.  `passes` = how many times the
-    implementation streams the key arrays (exact radix select: 4 histogram passes + tie count + select per k-th-element search,
-    twice, + count + apply).  CPU side: the numpy port of sparse_core.Masking.truncate_weights / funcs.magnitude_prune /
+    implementation streams the tensors (mask_kernels.hip: histogram + compaction + membership per k-th-element search, the prune
+    membership pass also being the regrow histogram pass and the regrow membership pass also being the apply: 5 passes, 56 B/elem).  CPU side: the numpy port of sparse_core.Masking.truncate_weights / funcs.magnitude_prune /
     gradient_growth (oracle/mask_oracle.py; the reference itself is not on this box) on a bounded prefix of the same tensors."""
     import ctypes
     from slak_amd import _lib
@@ -334,13 +335,26 @@ def mask_step_bench(device, model_name, ks, only_L, reps=20, cpu_seconds=6.0):
     _lib.check(L.slak_mask_plan_create(segs, len(shapes), ctypes.byref(plan)), "slak_mask_plan_create")
     elems = sum(w.numel() for w in ws)
     t_apply = event_time_ms(lambda: _lib.check(L.slak_mask_apply(plan, st)), reps, device)
-    t_update = event_time_ms(lambda: _lib.check(L.slak_mask_prune_and_grow(plan, 0.3, st)), reps, device)
+    # every timed prune-and-grow starts from the same state (masked trained weights, density 0.6): repeating it on its own output would
+    # prune weights that were regrown at exactly 0 a moment ago, which no training run does (2000 optimizer steps lie between updates)
+    ws0 = [w.clone() for w in ws]; ms0 = [m.clone() for m in ms]
+    times = []
+    for rep in range(reps + 3):
+        torch._foreach_copy_(ws, ws0); torch._foreach_copy_(ms, ms0)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        _lib.check(L.slak_mask_prune_and_grow(plan, 0.3, st))
+        e1.record(); e1.synchronize()
+        if rep >= 3:
+            times.append(e0.elapsed_time(e1))
+    t_update = float(np.median(times))
+    del ws0, ms0
     density = float(sum(m.sum().item() for m in ms)) / elems
     L.slak_mask_plan_destroy(plan)
     out = {"tensors": len(shapes), "elements": elems, "only_L": bool(only_L),
            "apply_ms": t_apply, "apply_alg_bytes": 12 * elems, "apply_gbs": 12 * elems / t_apply / 1e6, "apply_frac_of_hbm_peak": 12 * elems / t_apply / 1e6 / HBM_PEAK_GBS,
            "update_ms": t_update, "update_alg_bytes": 20 * elems, "update_gbs": 20 * elems / t_update / 1e6, "update_frac_of_hbm_peak": 20 * elems / t_update / 1e6 / HBM_PEAK_GBS,
-           "update_passes_over_keys": 14, "update_launches": 25, "density_after": density,
+           "update_passes_over_keys": 5, "update_launches": 12, "update_bytes_moved_per_elem": 56, "density_after": density,
            "note": "apply is folded into MaskedAdamW's update on ordinary steps (0 extra bytes); prune-and-grow runs every update_frequency steps"}
     # CPU port on a bounded prefix of the same mask set
     import oracle
@@ -459,13 +473,23 @@ def main():
     if distributed:
         dist.barrier()
     torch.cuda.synchronize()
+    host_s = 0.0                                                  # time the host spends ENQUEUEING the steps (no sync inside)
     t0 = time.perf_counter()
     for _ in range(a.steps):
+        h0 = time.perf_counter()
         loss = step()
+        host_s += time.perf_counter() - h0
     if distributed:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    if a.host_profile:                                            # after the timed region: where the enqueue time goes
+        import cProfile, pstats
+        pr = cProfile.Profile(); pr.enable()
+        for _ in range(a.steps):
+            step()
+        pr.disable(); torch.cuda.synchronize()
+        pstats.Stats(pr, stream=sys.stderr).sort_stats("cumulative").print_stats(60)
     per_rank_ms = [1e3 * elapsed / a.steps]
     mask_sync = None
     if distributed:
@@ -519,6 +543,7 @@ def main():
                    "per_step_sync": bool(a.per_step_sync),
                    "timing": "K steps between barrier + torch.cuda.synchronize() on both sides; " + ("a synchronize after every step as engine.py:90" if a.per_step_sync else "no synchronize inside (GPU-busy time == step time: the host runs ahead)"),
                    "per_rank_ms_per_step": [round(v, 4) for v in per_rank_ms],
+                   "host_enqueue_ms_per_step": round(1e3 * host_s / a.steps, 3),
                    "mask_sync": mask_sync,
                    "final_loss": final_loss},
     }

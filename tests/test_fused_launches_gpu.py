@@ -152,11 +152,12 @@ TRI_SMALL = [(5, 7, 14, 14, 47), (4, 3, 12, 10, 9), (1, 1, 14, 14, 13), (6, 5, 7
 
 
 def test_shapes_without_a_three_branch_launch_say_so(gpu):
-    """64 x 64 planes (their LDS budget does not fit two workgroups per CU), maps beyond 64, fp32: the support query is 0 and the entry
-    points refuse instead of running something else (block_ops.tri_dwconv then issues the three per-branch launches:
-    tests/test_mfma_gpu.py::test_tri_dwconv_matches_the_three_branch_convs covers those shapes)."""
+    """Maps beyond 64, planes whose width is not a multiple of 8 above 32, fp32: the support query is 0 and the entry points refuse
+    instead of running something else (block_ops.tri_dwconv then issues the three per-branch launches:
+    tests/test_mfma_gpu.py::test_tri_dwconv_matches_the_three_branch_convs covers those shapes).  64 x 64 planes have a forward
+    kernel (the stream kernel) and no data-gradient one: each op answers for itself."""
     L = _L(); lib = L.lib()
-    for (N, C, H, W, K) in [(2, 3, 64, 64, 61), (3, 2, 96, 96, 61), (2, 2, 36, 36, 31)]:
+    for (N, C, H, W, K) in [(3, 2, 96, 96, 61), (2, 2, 36, 36, 31)]:
         assert lib.slak_dwconv2d_tri_supported(L.SLAK_BF16, N, C, H, W, K) == 0
         x = torch.randn(N, C, H, W, device=gpu).bfloat16()
         ws = _filters(C, K, gpu, 1)
@@ -164,6 +165,21 @@ def test_shapes_without_a_three_branch_launch_say_so(gpu):
         rc = lib.slak_dwconv2d_tri_forward(x.data_ptr(), ws[0].data_ptr(), ws[1].data_ptr(), ws[2].data_ptr(), ys[0].data_ptr(), ys[1].data_ptr(),
                                            ys[2].data_ptr(), L.SLAK_BF16, N, C, H, W, K, _st(gpu))
         assert rc == L.ERR_UNSUPPORTED, (N, C, H, W, K, rc)
+    N, C, H, W, K = 2, 3, 64, 64, 61
+    assert lib.slak_dwconv2d_tri_supported(L.SLAK_BF16, N, C, H, W, K) == 0
+    assert lib.slak_dwconv2d_tri_supported_op(L.SLAK_BF16, N, C, H, W, K, 1) == 0
+    dys = [torch.randn(N, C, H, W, device=gpu).bfloat16() for _ in range(3)]
+    ws = _filters(C, K, gpu, 1)
+    dx = torch.empty_like(dys[0])
+    rc = lib.slak_dwconv2d_tri_backward_data(dys[0].data_ptr(), dys[1].data_ptr(), dys[2].data_ptr(), ws[0].data_ptr(), ws[1].data_ptr(),
+                                             ws[2].data_ptr(), dx.data_ptr(), L.SLAK_BF16, N, C, H, W, K, _st(gpu))
+    assert rc == L.ERR_UNSUPPORTED, rc
+    if lib.slak_dwconv2d_tri_supported_op(L.SLAK_BF16, N, C, H, W, K, 0) == 1:
+        x = torch.randn(N, C, H, W, device=gpu).bfloat16()
+        ys, _ = _tri_fwd(x, ws, K)
+        xr = _r(x, torch.bfloat16)
+        for y, w, name in zip(ys, ws, ("Kx5", "5xK", "5x5")):
+            _check_lowp(y, oracle.dwconv2d_fwd(xr, _r(w, torch.bfloat16)), torch.bfloat16, "tri fwd 64x64 " + name)
     assert lib.slak_dwconv2d_tri_supported_op(L.SLAK_F32, 4, 4, 14, 14, 47, 0) == 0
 
 

@@ -173,6 +173,43 @@ def test_prune_grow_edge_rates_and_masks(gpu):
     _run_case(SHAPES, 0.3, gpu, seed=7, zero_grads=True)      # all growth keys tie at 0 -> lowest indices
 
 
+def test_prune_grow_block_boundaries_unaligned_views_and_unreachable_taps(gpu):
+    """The five-pass select: tensors around the 2048 / 16384-element block sizes, bases that are not 16-byte aligned (views into a
+    flat bucket take the scalar path), and gradients that are exactly zero on most inactive weights -- the taps of a 51 x 5
+    kernel a 7 x 7 plane never reaches -- so that the regrow cut falls inside the ties at key 0."""
+    shapes = [(16383,), (16384,), (16385,), (32768 + 3,), (3 * 16384 + 2047,), (768, 1, 51, 5)]
+    rng = np.random.default_rng(21)
+    ws, ms, gs = [], [], []
+    for shp in shapes:
+        w = rng.standard_normal(shp).astype(np.float32) * 0.05
+        g = rng.standard_normal(shp).astype(np.float32)
+        if len(shp) == 4:
+            g[:, :, :19, :] = 0; g[:, :, 32:, :] = 0             # rows a 7-row plane cannot reach
+        m = (rng.random(shp) < 0.6).astype(np.float32)
+        ws.append((w * m).astype(np.float32)); ms.append(m); gs.append(g)
+    for shift in (0, 1, 3):                                     # element offset of every tensor inside its flat buffer
+        def put(arrs):
+            out = []
+            for a in arrs:
+                flat = torch.zeros(a.size + 8, device=gpu)
+                v = flat[shift:shift + a.size].view(a.shape)
+                v.copy_(torch.from_numpy(a))
+                out.append(v)
+            return out
+        tw, tm, tg = put(ws), put(ms), put(gs)
+        tmom = put([np.ones_like(a) for a in ws])
+        plan = Plan(tw, tm, tg, momenta=tmom)
+        stats = plan.prune_and_grow(0.3)
+        ow, om, ost = _oracle_step(ws, ms, gs, 0.3)
+        for i in range(len(shapes)):
+            np.testing.assert_array_equal(tm[i].cpu().numpy(), om[i], err_msg=f"mask {shapes[i]} shift {shift}")
+            np.testing.assert_array_equal(tw[i].cpu().numpy(), ow[i], err_msg=f"weight {shapes[i]} shift {shift}")
+            np.testing.assert_array_equal(tmom[i].cpu().numpy(), om[i], err_msg=f"momentum {shapes[i]} shift {shift}")
+            assert stats[i, 2] == ost[i]["removed"] and stats[i, 3] == om[i].sum()
+    # the regrow cut of the last tensor is inside the zero-gradient ties: fewer weights come back than were removed
+    assert stats[-1, 3] < stats[-1, 0]
+
+
 def test_apply_mask_and_momentum(gpu):
     torch.manual_seed(0)
     w = torch.randn(5000, device=gpu); m = (torch.rand(5000, device=gpu) < 0.5).float(); mom = torch.randn(5000, device=gpu)
