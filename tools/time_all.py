@@ -1,29 +1,29 @@
-"""Dev: time every SLaK-T dw-conv kernel shape (bf16, N=128) through the C ABI."""
-import sys, os
+"""tools/time_all.py -- every dw-conv launch of the hot path AS THE MODEL RUNS IT (bench.hot_path_kernels: three-branch forward and
+data-gradient launches, pair / three-branch weight-gradient launches), timed alone through the C ABI.  One line per launch.
+    python tools/time_all.py [--model tiny|base] [--kernel 51] [--res 224] [--batch 128]
+SLAK_TIME_ALL_REPS=n: n launches per kernel (PMC passes: tools/pmc_hot.sh)."""
+import argparse, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from slak_amd import ops
+import bench
+ap = argparse.ArgumentParser()
+ap.add_argument("--model", default="tiny"); ap.add_argument("--kernel", type=int, default=51); ap.add_argument("--res", type=int, default=224)
+ap.add_argument("--batch", type=int, default=None)
+a = ap.parse_args()
+batch = a.batch or (64 if (a.model == "base" or a.res != 224) else 128)
 dev = torch.device("cuda:0")
-_R = int(os.environ.get("SLAK_TIME_ALL_REPS", "0"))
-def ev(fn, reps=20, batches=5):
-    if _R:
-        reps, batches = _R, 1
-    for _ in range(2 if _R else 20): fn()
-    best = 1e30
-    for _ in range(batches):                      # min over batches: robust against clock ramp / stray activity
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        torch.cuda.synchronize(); e0.record()
-        for _ in range(reps): fn()
-        e1.record(); e1.synchronize()
-        best = min(best, e0.elapsed_time(e1) / reps * 1e3)
-    return best
-tot = 0
-for (C, H, K, blocks) in ((96, 56, 51, 3), (192, 28, 49, 3), (384, 14, 47, 9), (768, 7, 13, 3)):
-    x = torch.randn(128, C, H, H, device=dev).bfloat16(); dy = torch.randn_like(x)
-    for (kh, kw) in ((K, 5), (5, K), (5, 5)):
-        w = torch.randn(C, 1, kh, kw, device=dev) * 0.02
-        tf = ev(lambda: ops.dwconv2d_forward(x, w)); td = ev(lambda: ops.dwconv2d_backward_data(dy, w)); tw = ev(lambda: ops.dwconv2d_backward_filter(dy, x, w))
-        by = 2 * x.numel() * 2
-        tot += (tf + td + tw) * blocks
-        print("C%-3d %2dx%-2d k%2dx%-2d  fwd %6.1f us %5.0f GB/s | dgrad %6.1f us | wgrad %6.1f us %5.0f GB/s" % (C, H, H, kh, kw, tf, by / tf / 1e3, td, tw, by / tw / 1e3), flush=True)
-print("dwconv per step: %.2f ms" % (tot / 1e3))
+reps = int(os.environ.get("SLAK_TIME_ALL_REPS", "0")) or 30
+stages = bench.stages_of(a.model, a.kernel, a.res)
+kl = bench.hot_path_kernels(dev, batch, reps, torch.bfloat16, stages)
+tot = byt = 0.0
+print("%-5s %-22s %-5s %-10s %9s %6s %8s %6s  %s" % ("stage", "kernel", "kind", "op", "us", "calls", "GB/s", "frac", "hip kernel"))
+for k in kl:
+    ms = k["ms"] * k["calls_per_step"]; tot += ms; byt += k["alg_bytes"] * k["calls_per_step"]
+    gbs = k["alg_bytes"] / k["ms"] / 1e6
+    print("%-5d %-22s %-5s %-10s %9.1f %6d %8.0f %6.3f  %s" % (k["stage"], k["kernel"], k["branch"], k["op"], k["ms"] * 1e3, k["calls_per_step"], gbs,
+                                                       gbs / bench.HBM_PEAK_GBS, k.get("hip_kernel")))
+if os.environ.get("SLAK_TIME_ALL_JSON"):
+    import json
+    keep = ("stage", "kernel", "branch", "op", "alg_bytes", "alg_bytes_incl_acc_read", "hip_kernel", "calls_per_step", "ms")
+    json.dump([{k: e.get(k) for k in keep} for e in kl], open(os.environ["SLAK_TIME_ALL_JSON"], "w"), indent=1)
+print("dw-conv hot path per step: %.3f ms, %.3f GB (SURVEY 8d), %.3f of the %.0f GB/s HBM peak" % (tot, byt / 1e9, byt / tot / 1e6 / bench.HBM_PEAK_GBS, bench.HBM_PEAK_GBS))
