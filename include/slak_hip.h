@@ -238,17 +238,6 @@ int slak_linear_wgrad_supported(int M, int N1, int N2);
 size_t slak_linear_wgrad_workspace_bytes(int M, int N1, int N2);
 int slak_linear_wgrad(const void* x1_bf16, const void* x2_bf16, float* d, int M, int N1, int N2, void* workspace, size_t workspace_bytes, void* stream);
 
-/* The expanding pointwise GEMM of the MLP on stages 2-4 (N = 4C a multiple of 192, K = C a multiple of 64) with the GELU work in its epilogue
- * (models/SLaK.py:158-160): _gelu: y = bf16(x . wt^T + bias) and, if gelu_out is given, gelu_out = nn.GELU()(y) of the rounded y;
- * _dgelu: dy1 = bf16((dz . wt^T) * gelu'(y1)) -- autograd's data gradient of pwconv2 (wt = W2^T, [4C][C]) followed by the GELU backward, without
- * the 4C-wide intermediate -- and colsum[r][n] (r < slak_linear_gemm_colsum_rows(M, N)) = partial column sums of the rounded dy1 (their sum over r
- * is pwconv1's bias gradient).  x / dz [M][K], wt [N][K], y / y1 / dy1 [M][N]: bf16, row-major.  Other shapes: SLAK_ERR_UNSUPPORTED. */
-int slak_linear_gemm_supported(int M, int N, int K);
-int slak_linear_gemm_colsum_rows(int M, int N);
-int slak_linear_gemm_gelu(const void* x_bf16, const void* wt_bf16, const void* bias_bf16 /* or NULL */, void* y_bf16, void* gelu_out_bf16 /* or NULL */,
-                          int M, int N, int K, void* stream);
-int slak_linear_gemm_dgelu(const void* dz_bf16, const void* wt_bf16, const void* y1_bf16, void* dy1_bf16, float* colsum, int M, int N, int K, void* stream);
-
 /* GELU backward (exact erf form, nn.GELU()) fused with the bias gradient of the Linear in front of it (models/SLaK.py:158-160):
  * dy1 = dact * gelu'(y1); dbias[col] = sum_rows dy1.  [rows][cols] bf16 contiguous, cols % 8 == 0. */
 size_t slak_gelu_bwd_workspace_bytes(int rows, int cols);

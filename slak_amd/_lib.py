@@ -107,10 +107,6 @@ SIGNATURES = {
     "slak_ln_patch_supported": (_i, [_i, _i, _i, _i]),
     "slak_ln_patch_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, ctypes.c_float, _vp]),
     "slak_ln_patch_backward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _sz, _vp]),
-    "slak_linear_gemm_supported": (_i, [_i, _i, _i]),
-    "slak_linear_gemm_colsum_rows": (_i, [_i, _i]),
-    "slak_linear_gemm_gelu": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
-    "slak_linear_gemm_dgelu": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "slak_linear_nt_supported": (_i, [_i, _i, _i, _i]),
     "slak_linear_nt": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "slak_linear_wgrad_supported": (_i, [_i, _i, _i]),

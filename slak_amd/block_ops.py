@@ -789,47 +789,6 @@ def linear_nt(x, wt, bias=None, gelu=False):
     return (y, g) if gelu else y
 
 
-# csrc/linear_gemm.hip: pwconv1 + GELU and (dz W2) * gelu'(y1) as one kernel each on stages 2-4.  Parity green, but OFF: measured 146 / 139 us
-# (forward / backward, stage 3) against 82 / 102 us for the tuned library GEMM + the elementwise kernel -- one workgroup per CU runs its K loop
-# (75 us: 64-byte row segments make the LDS-DMA pieces expensive) and its store-bound epilogue (70 us) one after the other.  SLAK_LINEAR_GEMM=1 turns it on.
-use_linear_gemm = os.environ.get("SLAK_LINEAR_GEMM", "0") == "1"
-
-
-def linear_gemm_gelu(x, wt, bias=None, gelu=True):
-    """(y, gelu(y)) with y = x @ wt.T + bias for bf16 x (..., K), wt (N, K) through slak_linear_gemm_gelu; None when not covered."""
-    if not (use_linear_gemm and x.is_cuda and x.dtype == torch.bfloat16 and wt.dtype == torch.bfloat16 and x.is_contiguous() and wt.is_contiguous()):
-        return None
-    K = x.shape[-1]; N = wt.shape[0]; M = x.numel() // K
-    L = _lib.lib()
-    if wt.shape[1] != K or not L.slak_linear_gemm_supported(M, N, K):
-        return None
-    if bias is not None and (bias.dtype != torch.bfloat16 or not bias.is_contiguous()):
-        return None
-    y = torch.empty(x.shape[:-1] + (N,), dtype=torch.bfloat16, device=x.device)
-    g = torch.empty_like(y) if gelu else None
-    with torch.cuda.device(x.device):
-        _lib.check(L.slak_linear_gemm_gelu(x.data_ptr(), wt.data_ptr(), bias.data_ptr() if bias is not None else None, y.data_ptr(),
-                                           g.data_ptr() if gelu else None, M, N, K, _stream(x.device)), "slak_linear_gemm_gelu")
-    return (y, g) if gelu else y
-
-
-def linear_gemm_dgelu(dz, wt, y1):
-    """(dy1, db1) = ((dz @ wt.T) * gelu'(y1) rounded to bf16, its column sums in fp32) for bf16 dz (M, K), wt (N, K), y1 (M, N); None when not covered."""
-    if not (use_linear_gemm and dz.is_cuda and dz.dtype == torch.bfloat16 and wt.dtype == torch.bfloat16 and y1.dtype == torch.bfloat16
-            and dz.is_contiguous() and wt.is_contiguous() and y1.is_contiguous()):
-        return None
-    M, K = dz.shape; N = wt.shape[0]
-    L = _lib.lib()
-    if wt.shape[1] != K or tuple(y1.shape) != (M, N) or not L.slak_linear_gemm_supported(M, N, K):
-        return None
-    dy1 = torch.empty_like(y1)
-    part = torch.empty((int(L.slak_linear_gemm_colsum_rows(M, N)), N), dtype=torch.float32, device=dz.device)
-    with torch.cuda.device(dz.device):
-        _lib.check(L.slak_linear_gemm_dgelu(dz.data_ptr(), wt.data_ptr(), y1.data_ptr(), dy1.data_ptr(), part.data_ptr(), M, N, K, _stream(dz.device)),
-                   "slak_linear_gemm_dgelu")
-    return dy1, part.sum(0)
-
-
 def _mlp_fwd(t, w1, b1, w2, b2):
     F = torch.nn.functional
     w1b, w2b = lowp_param(w1), lowp_param(w2)

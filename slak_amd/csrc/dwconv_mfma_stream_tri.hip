@@ -227,7 +227,7 @@ __global__ __launch_bounds__(TT_THREADS, 2) void dwconv_mfma_stream_tri_kernel(c
         else if (j == 11 || j == 12) {
             const int k = j - 11;
             const u32x4 v = k ? r1 : r0;
-            const unsigned go = (!pend || goff[t][k] == TT_OOB || (p.dbg & 2)) ? TT_OOB : gb + goff[t][k];
+            const unsigned go = (!pend || goff[t][k] == TT_OOB || TT_DBG(p, 2)) ? TT_OOB : gb + goff[t][k];
             const int br = t == 2 ? 2 : (a_vert ? 0 : 1);            // output tensor of the tile
             if (p.stats && go != TT_OOB) { if (br == 0) stat8(v, bs[0], bs[1]); else if (br == 1) stat8(v, bs[2], bs[3]); else stat8(v, bs[4], bs[5]); }
             if (br == 0) __builtin_amdgcn_raw_buffer_store_b128(v, ro[0], go, 0, 0);
@@ -237,7 +237,7 @@ __global__ __launch_bounds__(TT_THREADS, 2) void dwconv_mfma_stream_tri_kernel(c
     };
     s16x4 tv0, tv1;
     auto transposes = [&](int k0, int pl, int j) __attribute__((always_inline)) {      // blocks k0, k0 + 1 of plane pl: reads at j = 14, 15, writes at j = 17, 18
-        if (pl >= iters || (p.dbg & 4)) return;
+        if (pl >= iters || TT_DBG(p, 4)) return;
         const unsigned sb = ring_b + (unsigned)(pl % NB) * slot_b, db = xt_b + (unsigned)(pl & 1) * xt_buf_b;
         if (j == 14 && tr_map[k0] != 0xffffffffu) tv0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(SLAK_LDS(s16x4, L + sb + (tr_map[k0] & 0xffffu)));
         if (j == 15 && tr_map[k0 + 1] != 0xffffffffu) tv1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(SLAK_LDS(s16x4, L + sb + (tr_map[k0 + 1] & 0xffffu)));
@@ -260,8 +260,8 @@ __global__ __launch_bounds__(TT_THREADS, 2) void dwconv_mfma_stream_tri_kernel(c
             // ---- tile 0: A(MT, sub 0).  Fillers: the LDS-DMA pieces of plane i + 2, the previous plane's 5 x 5 tile, two transpose blocks
             zero(accA);
             auto f0 = [&](int j) __attribute__((always_inline)) {
-                if (j == 0 && !(p.dbg & 64)) issue_piece(pc0, i + 2);
-                if (j == 1 && !(p.dbg & 64)) issue_piece(pc1, i + 2);
+                if (j == 0 && !TT_DBG(p, 64)) issue_piece(pc0, i + 2);
+                if (j == 1 && !TT_DBG(p, 64)) issue_piece(pc1, i + 2);
                 finish(accS, 2, 0, !first, gbp, j);
                 transposes(0, i + 1, j);
             };
@@ -276,8 +276,8 @@ __global__ __launch_bounds__(TT_THREADS, 2) void dwconv_mfma_stream_tri_kernel(c
             auto f2 = [&](int j) __attribute__((always_inline)) { finish(accB, 1, 1, true, gb, j); };
             team_small_tile_mma<T, R16, KS, MT, R2, 0, 0>(accS, sa, bq, L, s_rp, pitch_h, wlim, zrow_l, sfr_l, 0u, 0u, f2);
             // ---- end of plane i: this wave's pieces of plane i + 2 have landed (the 6 stores are younger); publish them and plane i + 1's transpose
-            if (!(p.dbg & 8)) wait_vmcnt<6>();
-            if (!(p.dbg & 32)) wg_barrier();
+            if (!TT_DBG(p, 8)) wait_vmcnt<6>();
+            if (!TT_DBG(p, 32)) wg_barrier();
         }
         {                                                             // the last plane's 5 x 5 tile
             const unsigned gb = (unsigned)(((size_t)(n_begin + iters - 1) * p.C + c) * HW * 2);
@@ -384,7 +384,7 @@ int launch_dwconv_mfma_stream_tri(const void* x, void* const* out, const float* 
     TeamParams p;
     for (int b = 0; b < 3; ++b) { p.in[b] = x; p.out[b] = out[b]; p.w[b] = w[b]; }
     p.stats = (stats && dtype == SLAK_BF16) ? stats : nullptr;
-    { static const int dbg = [] { const char* e = getenv("SLAK_TEAM_DBG"); return e ? atoi(e) : 0; }(); p.dbg = dbg; }
+    p.dbg = team_dev_flags();
     p.tl = nullptr;
     return dtype == SLAK_BF16 ? launch_stream_t<bf16_t>(p, N, C, H, W, K, st) : launch_stream_t<f16_t>(p, N, C, H, W, K, st);
 }

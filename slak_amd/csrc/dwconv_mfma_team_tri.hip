@@ -300,7 +300,7 @@ __global__ __launch_bounds__(2 * TT_THREADS, 1) void dwconv_mfma_team_tri_kernel
         }
     };
 
-    unsigned long long* tl = p.tl ? p.tl + (size_t)vb * 64 : nullptr;
+    unsigned long long* tl = TT_TIMELINE(p, vb);
     if (tl && tid == 0) {
         tl[0] = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);        // HW_ID
         tl[1] = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20);        // XCC_ID
@@ -310,7 +310,7 @@ __global__ __launch_bounds__(2 * TT_THREADS, 1) void dwconv_mfma_team_tri_kernel
     // group 0 has to be transposed before the loop: every wave waits for ITS pieces of group 0 (NB - 1 groups are younger)
     wait_vmcnt_dyn((NB - 1) * my_pieces);
     wg_barrier();
-    if (!(p.dbg & 4)) transpose_group(0);
+    if (!TT_DBG(p, 4)) transpose_group(0);
     auto compute_phase = [&](int it) {
         if (tl && tid == 0 && it < 27) tl[3 + 2 * it] = __builtin_amdgcn_s_memrealtime();
         if (tl && tid == 0 && it == 10) tl[57] = __builtin_readcyclecounter();
@@ -318,7 +318,7 @@ __global__ __launch_bounds__(2 * TT_THREADS, 1) void dwconv_mfma_team_tri_kernel
         // B-fragment pipeline runs across tile boundaries, consecutive tiles alternate between two accumulators and a tile's epilogue
         // (pack + LDS stores) is issued behind the NEXT tile's MFMAs, when its accumulator has long been complete.
         const unsigned img_b = ring_b + (unsigned)(it % NB) * slot_b;
-        if (!(p.dbg & 1)) {
+        if (!TT_DBG(p, 1)) {
             s16x8 bq[TT_NBUF];
             f32x16 acc0;
             auto zero = [](f32x16& a) {
@@ -419,13 +419,13 @@ __global__ __launch_bounds__(2 * TT_THREADS, 1) void dwconv_mfma_team_tri_kernel
         if (tl && tid == 0 && it == 10) tl[52] = __builtin_readcyclecounter();
         issue_group(it + NB);                                         // into the slot group `it` just left
         if (tl && tid == 0 && it == 10) tl[53] = __builtin_readcyclecounter();
-        if (!(p.dbg & 2)) copy_out(it);
+        if (!TT_DBG(p, 2)) copy_out(it);
         else {
 #pragma unroll
             for (int k = 0; k < NST; ++k) __builtin_amdgcn_raw_buffer_store_b128(u32x4{0u, 0u, 0u, 0u}, ro[0], TT_OOB, 0, 0);   // keeps the count
         }
         if (tl && tid == 0 && it == 10) tl[54] = __builtin_readcyclecounter();
-        if (it + 1 < iters && !(p.dbg & 4)) transpose_group(it + 1);
+        if (it + 1 < iters && !TT_DBG(p, 4)) transpose_group(it + 1);
         if (tl && tid == 0 && it == 10) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); tl[51] = __builtin_readcyclecounter(); }
     };
     // Anti-phase schedule: between two workgroup barriers team 0 computes group i while team 1 moves the data of its group i-1,
@@ -583,8 +583,8 @@ int launch_dwconv_mfma_team_tri(bool dgrad, const void* const* in, void* const* 
     TeamParams p;
     for (int b = 0; b < 3; ++b) { p.in[b] = in[b]; p.out[b] = out[b]; p.w[b] = w[b]; }
     p.stats = (stats && !dgrad && dtype == SLAK_BF16) ? stats : nullptr;
-    { static const int dbg = [] { const char* e = getenv("SLAK_TEAM_DBG"); return e ? atoi(e) : 0; }(); p.dbg = dbg; }
-    p.tl = (p.dbg & 16) ? g_dma_dbg : nullptr;
+    p.dbg = team_dev_flags();
+    p.tl = TT_DBG(p, 16) ? g_dma_dbg : nullptr;
     const bool r16 = W % 8 == 0;
     if (dtype == SLAK_BF16) return cls == 2 ? launch_team_c<bf16_t, 2>(p, dgrad, r16, N, C, H, W, K, st) : launch_team_c<bf16_t, 1>(p, dgrad, r16, N, C, H, W, K, st);
     return cls == 2 ? launch_team_c<f16_t, 2>(p, dgrad, r16, N, C, H, W, K, st) : launch_team_c<f16_t, 1>(p, dgrad, r16, N, C, H, W, K, st);

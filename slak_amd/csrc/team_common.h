@@ -21,6 +21,18 @@ constexpr int TT_WCH = 5;               // filter elements staged per lane of a 
 constexpr int TT_NCO = 2;               // 16-byte copy-out chunks per thread, tensor and group (upper bound)
 constexpr unsigned TT_OOB = 0x80000000u;   // a buffer offset beyond every tensor (< 2^31 bytes): loads return zeros, stores are dropped
 
+// Dev instrumentation (ablation bits and the s_memtime timeline of tools/time_team.py / tools/team_timeline.py) exists only in a build with
+// -DSLAK_TEAM_DEV; in the shipped library the conditions are constants and the compiler drops the code.
+#ifdef SLAK_TEAM_DEV
+#define TT_DBG(p, bit) ((p).dbg & (bit))
+#define TT_TIMELINE(p, vb) ((p).tl ? (p).tl + (size_t)(vb) * 64 : nullptr)
+static inline int team_dev_flags() { static const int dbg = [] { const char* e = getenv("SLAK_TEAM_DBG"); return e ? atoi(e) : 0; }(); return dbg; }
+#else
+#define TT_DBG(p, bit) 0
+#define TT_TIMELINE(p, vb) ((unsigned long long*)nullptr)
+static inline int team_dev_flags() { return 0; }
+#endif
+
 struct TeamPiece { unsigned lds_off, g_off; int info; };       // info = tensor | plane-of-group << 4 | lanes << 8 (0: no such piece)
 constexpr int TT_NPW = 6;               // LDS-DMA pieces per wave and group (upper bound: dgrad)
 
