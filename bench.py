@@ -107,6 +107,7 @@ def parse():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--kernel-reps", type=int, default=30)
     ap.add_argument("--fp32-dwconv", action="store_true", help="reference dtype flow: dw convs see fp32 even under autocast")
+    ap.add_argument("--fp32-matrix-cores", action="store_true", help="with --fp32-dwconv: fp32 tensors through the bf16 matrix cores (opt-in two-term split, slak_set_fp32_matrix_cores)")
     ap.add_argument("--cudnn-benchmark", type=int, default=1, help="torch.backends.cudnn.benchmark (main.py:235 sets it): MIOpen find mode for the stem/downsample convolutions")
     ap.add_argument("--torch-adamw", action="store_true", help="torch.optim.AdamW(fused=True) (+ a separate mask-apply launch) instead of slak_amd's one-launch MaskedAdamW")
     ap.add_argument("--model-ema", action="store_true", help="also keep the reference's sparsity-aware EMA (--model_ema true recipes): one HIP launch per step")
@@ -407,6 +408,9 @@ def main():
     n_gpus = world if distributed else 1
     ks = kernel_sizes(a.kernel)
     stages = stages_of(a.model, a.kernel, a.res)
+    if a.fp32_matrix_cores:
+        from slak_amd import ops as _ops
+        _ops.allow_fp32_matrix_cores(True)
     batch = a.batch if a.batch is not None else (64 if (a.model != "tiny" or a.res > 224) else 128)
     a.batch = batch
     sparsity = a.sparsity if a.sparsity is not None else (0.4 if (n_gpus > 1 or a.model == "base") and a.res == 224 else 0.0)
@@ -538,7 +542,7 @@ def main():
         "config": {"workload": workload,
                    "global_batch": n_gpus * a.batch, "per_gpu_batch": a.batch, "parallelism": "dp%d" % n_gpus,
                    "kernel_sizes": ks, "resolution": a.res, "variant": a.model,
-                   "dwconv_dtype": "fp32" if a.fp32_dwconv else "bf16 in/out, fp32 accumulate", "optimizer": "torch AdamW(fused)" if a.torch_adamw else "slak_amd MaskedAdamW (update + mask + bf16 copies, one launch)",
+                   "dwconv_dtype": ("fp32" + (" on the bf16 matrix cores (two-term split, three MFMAs per product)" if a.fp32_matrix_cores else " (exact VALU kernels)")) if a.fp32_dwconv else "bf16 in/out, fp32 accumulate", "optimizer": "torch AdamW(fused)" if a.torch_adamw else "slak_amd MaskedAdamW (update + mask + bf16 copies, one launch)",
                    "model_ema": bool(a.model_ema),
                    "sync_bn": True, "block_tail": "hip (ln_nchw_to_nhwc + scale_residual)" if M.Block.fused_tail else "pytorch ops",
                    "branch_bn": "hip (bn3: one stats pass + one apply pass)" if M.ReparamLargeKernelConv.fused_bn else "pytorch (Sync)BatchNorm x3 + adds",

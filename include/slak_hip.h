@@ -48,7 +48,7 @@ typedef enum {
 typedef enum { SLAK_F32 = 0, SLAK_F16 = 1, SLAK_BF16 = 2, SLAK_I64 = 3 /* slak_ema_update only */ } slak_dtype_t;
 
 /* conv algorithm selector: AUTO picks per dtype/shape; DIRECT = fp32-exact VALU kernels (any dtype);
- * MFMA = banded-Toeplitz matrix-core kernels (f16/bf16 inputs only). */
+ * MFMA = banded-Toeplitz matrix-core kernels (f16/bf16 inputs; fp32 inputs through the two-term split below). */
 typedef enum { SLAK_ALGO_AUTO = 0, SLAK_ALGO_DIRECT = 1, SLAK_ALGO_MFMA = 2 } slak_algo_t;
 
 const char* slak_status_string(int status);
@@ -56,6 +56,13 @@ const char* slak_last_hip_error(void);      /* text of the last HIP error seen b
 int slak_version(void);                     /* ABI version, currently 1 */
 int slak_device_info(int* cu_count, int* lds_bytes_per_cu, char* arch_name, size_t arch_name_len);
 int slak_set_conv_algo(int algo);           /* process-wide override of the AUTO choice */
+/* fp32 tensors on the bf16 matrix cores: x = bf16(x) + bf16(x - bf16(x)) (and the same for the filter / dy), three MFMAs per product,
+ * fp32 accumulation: 16 significand bits per operand, ~2e-5 of sum|x||w| per output -- 50x inside the 1e-3 the reference's own test allows
+ * (test_correctness.py), not bit-compatible with the exact path.  OFF by default (the fp32 entry points then run the exact VALU kernels), the
+ * way torch.backends.cudnn.allow_tf32 gates TF32; SLAK_FP32_MFMA=1 in the environment sets the initial value.  Covers kernels with a 5-tap
+ * side on maps up to 64 along the long axis (the SLaK stages at 224 px); everything else stays exact. */
+int slak_set_fp32_matrix_cores(int allow);
+int slak_get_fp32_matrix_cores(void);
 
 /* ---------------------------------------------------------------- boundary 1: depthwise conv */
 

@@ -103,6 +103,13 @@ int slak_device_info(int* cu_count, int* lds_bytes_per_cu, char* arch_name, size
     return SLAK_OK;
 }
 
+// fp32 tensors on the bf16 matrix cores (two-term split, ~2^-16 relative per product) are OPT-IN, like torch.backends.cudnn.allow_tf32:
+// the default fp32 path stays the exact VALU one.  SLAK_FP32_MFMA=1 sets the initial value.
+static std::atomic<int> g_fp32_mfma{[] { const char* e = getenv("SLAK_FP32_MFMA"); return (e && e[0] == '1') ? 1 : 0; }()};
+static bool f32_ok(int dt) { return dt != SLAK_F32 || g_fp32_mfma.load() != 0 || g_conv_algo == SLAK_ALGO_MFMA; }
+int slak_set_fp32_matrix_cores(int allow) { g_fp32_mfma = allow ? 1 : 0; return SLAK_OK; }
+int slak_get_fp32_matrix_cores(void) { return g_fp32_mfma.load(); }
+
 int slak_set_conv_algo(int algo) {
     if (algo != SLAK_ALGO_AUTO && algo != SLAK_ALGO_DIRECT && algo != SLAK_ALGO_MFMA) return SLAK_ERR_INVALID_ARG;
     g_conv_algo = algo;
@@ -132,8 +139,9 @@ int slak_dwconv2d_forward(const void* x, int x_dtype, const void* w, int w_dtype
         return SLAK_RAN("dwconv_mfma_small_dma", launch_dwconv_mfma_small_dma(x, x_dtype, w, w_dtype, y, y_dtype, d, /*flip=*/false, (hipStream_t)stream));
     if (g_conv_algo != SLAK_ALGO_DIRECT && use_small() && dwconv_mfma_small_supported(d, x_dtype, w_dtype, y_dtype))
         return SLAK_RAN("dwconv_mfma_small", launch_dwconv_mfma_small(x, x_dtype, w, w_dtype, y, y_dtype, d, /*flip=*/false, workspace, workspace_bytes, (hipStream_t)stream));
-    if (g_conv_algo != SLAK_ALGO_DIRECT && dwconv_mfma_supported(d, x_dtype, w_dtype, y_dtype))
-        return SLAK_RAN("dwconv_mfma", launch_dwconv_mfma(x, x_dtype, w, w_dtype, y, y_dtype, d, /*flip=*/false, workspace, workspace_bytes, (hipStream_t)stream));
+    if (g_conv_algo != SLAK_ALGO_DIRECT && f32_ok(x_dtype) && dwconv_mfma_supported(d, x_dtype, w_dtype, y_dtype))
+        return SLAK_RAN(x_dtype == SLAK_F32 ? "dwconv_mfma(f32 split)" : "dwconv_mfma",
+                        launch_dwconv_mfma(x, x_dtype, w, w_dtype, y, y_dtype, d, /*flip=*/false, workspace, workspace_bytes, (hipStream_t)stream));
     if (g_conv_algo == SLAK_ALGO_MFMA) return SLAK_ERR_UNSUPPORTED;
     return SLAK_RAN("dwconv_direct", launch_dwconv_direct(x, x_dtype, w, w_dtype, y, y_dtype, d, /*flip=*/false, workspace, workspace_bytes, (hipStream_t)stream));
 }
@@ -154,8 +162,9 @@ int slak_dwconv2d_backward_data(const void* dy, int dy_dtype, const void* w, int
         return SLAK_RAN("dwconv_mfma_small_dma", launch_dwconv_mfma_small_dma(dy, dy_dtype, w, w_dtype, dx, dx_dtype, d, /*flip=*/true, (hipStream_t)stream));
     if (g_conv_algo != SLAK_ALGO_DIRECT && use_small() && dwconv_mfma_small_supported(d, dy_dtype, w_dtype, dx_dtype))
         return SLAK_RAN("dwconv_mfma_small", launch_dwconv_mfma_small(dy, dy_dtype, w, w_dtype, dx, dx_dtype, d, /*flip=*/true, workspace, workspace_bytes, (hipStream_t)stream));
-    if (g_conv_algo != SLAK_ALGO_DIRECT && dwconv_mfma_supported(d, dy_dtype, w_dtype, dx_dtype))
-        return SLAK_RAN("dwconv_mfma", launch_dwconv_mfma(dy, dy_dtype, w, w_dtype, dx, dx_dtype, d, /*flip=*/true, workspace, workspace_bytes, (hipStream_t)stream));
+    if (g_conv_algo != SLAK_ALGO_DIRECT && f32_ok(dy_dtype) && dwconv_mfma_supported(d, dy_dtype, w_dtype, dx_dtype))
+        return SLAK_RAN(dy_dtype == SLAK_F32 ? "dwconv_mfma(f32 split)" : "dwconv_mfma",
+                        launch_dwconv_mfma(dy, dy_dtype, w, w_dtype, dx, dx_dtype, d, /*flip=*/true, workspace, workspace_bytes, (hipStream_t)stream));
     if (g_conv_algo == SLAK_ALGO_MFMA) return SLAK_ERR_UNSUPPORTED;
     return SLAK_RAN("dwconv_direct", launch_dwconv_direct(dy, dy_dtype, w, w_dtype, dx, dx_dtype, d, /*flip=*/true, workspace, workspace_bytes, (hipStream_t)stream));
 }
@@ -195,8 +204,9 @@ int slak_dwconv2d_backward_filter(const void* dy, int dy_dtype, const void* x, i
         return SLAK_RAN("dwconv_mfma_wgrad_dma", launch_dwconv_mfma_wgrad_dma(dy, dy_dtype, x, x_dtype, dw, d, workspace, workspace_bytes, (hipStream_t)stream));
     if (g_conv_algo != SLAK_ALGO_DIRECT && dwconv_mfma_wide_wgrad_supported(d, dy_dtype, x_dtype))
         return SLAK_RAN("dwconv_mfma_wide_wgrad", launch_dwconv_mfma_wide_wgrad(dy, dy_dtype, x, x_dtype, dw, d, workspace, workspace_bytes, (hipStream_t)stream));
-    if (g_conv_algo != SLAK_ALGO_DIRECT && dwconv_mfma_wgrad_supported(d, dy_dtype, x_dtype))
-        return SLAK_RAN("dwconv_mfma_wgrad", launch_dwconv_mfma_wgrad(dy, dy_dtype, x, x_dtype, dw, d, workspace, workspace_bytes, (hipStream_t)stream));
+    if (g_conv_algo != SLAK_ALGO_DIRECT && f32_ok(x_dtype) && dwconv_mfma_wgrad_supported(d, dy_dtype, x_dtype))
+        return SLAK_RAN(x_dtype == SLAK_F32 ? "dwconv_mfma_wgrad(f32 split)" : "dwconv_mfma_wgrad",
+                        launch_dwconv_mfma_wgrad(dy, dy_dtype, x, x_dtype, dw, d, workspace, workspace_bytes, (hipStream_t)stream));
     if (g_conv_algo == SLAK_ALGO_MFMA) return SLAK_ERR_UNSUPPORTED;
     return SLAK_RAN("dwconv_wgrad", launch_dwconv_wgrad(dy, dy_dtype, x, x_dtype, dw, d, workspace, workspace_bytes, (hipStream_t)stream));
 }

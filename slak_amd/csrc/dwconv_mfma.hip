@@ -29,6 +29,7 @@ namespace slak {
 
 struct MfmaFwdParams {
     const void* x; const uint16_t* frags; void* y;
+    const uint16_t* frags_lo;   // F32 kernels: the filters' second bf16 term
     int N, C, H, W, kh, kw, flip;
     int Wt, Wl, KL, padL;
     int G;                 // planes staged per iteration
@@ -72,6 +73,16 @@ __global__ void toeplitz_pack_kernel(const ToeplitzPackParams p) {
     for (int e = 0; e < 8; e += 2)
         out[e >> 1] = p.is_bf16 ? pack2<bf16_t>(v[e], v[e + 1]) : pack2<f16_t>(v[e], v[e + 1]);
     ((u32x4*)p.frags)[idx] = out;
+    if (p.frags_lo) {                                       // w = bf16(w) + bf16(w - bf16(w)) + O(2^-17 |w|)
+        u32x4 lo;
+#pragma unroll
+        for (int e = 0; e < 8; e += 2) {
+            uint16_t h0, l0, h1, l1;
+            split_bf16(v[e], h0, l0); split_bf16(v[e + 1], h1, l1);
+            lo[e >> 1] = (unsigned)l0 | ((unsigned)l1 << 16);
+        }
+        ((u32x4*)p.frags_lo)[idx] = lo;
+    }
 }
 
 void launch_toeplitz_pack(const ToeplitzPackParams& p, hipStream_t st) {
@@ -81,15 +92,22 @@ void launch_toeplitz_pack(const ToeplitzPackParams& p, hipStream_t st) {
 
 // MT: 32-row tiles along the Toeplitz axis (wave w owns tile w % MT); KS: 16-deep k-steps (Wt <= 16*KS);
 // RPM: short taps packed per MFMA (32/RPM rows each); V: staging vector width (elements); VERT: long axis = H.
-template <typename T, int MT, int KS, int RPM, int V, bool VERT>
+// F32: fp32 activations and results on the bf16 matrix cores.  x = x_hi + x_lo is split ONCE per element while it is staged (two LDS stacks),
+// w = w_hi + w_lo by the pack kernel; every (tap group, k-step) is three MFMAs into the same fp32 accumulator: w_hi x_hi + w_hi x_lo + w_lo x_hi
+// (the dropped w_lo x_lo term and the two representation errors are each <= 2^-16 of |w||x|: ~2e-5 relative, measured in tests/test_fp32_mfma_gpu.py).
+// w_hi fragments live in registers, w_lo fragments in LDS.
+template <typename T, int MT, int KS, int RPM, int V, bool VERT, bool F32 = false>
 __global__ __launch_bounds__(MF_THREADS, 2) void dwconv_mfma_fwd_kernel(const MfmaFwdParams p) {
     constexpr int NG = (MF_TAPS + RPM - 1) / RPM;          // accumulators (MFMA groups) per unit
     constexpr int MPAD = 32 / RPM;                          // rows per tap inside an MFMA
     constexpr int NR = 16 / RPM;                            // output registers per lane
     constexpr int WL = MF_WAVES / MT;                       // lane-tile workers per Toeplitz tile
     extern __shared__ __attribute__((aligned(16))) uint16_t lds[];
-    uint16_t* lin = lds;                                    // staged stack
-    uint16_t* lout = lds + p.in_elems;                      // [G][HWp] results
+    uint16_t* lin = lds;                                    // staged stack (F32: the x_hi stack, the x_lo stack follows)
+    uint16_t* lin_lo = lds + p.in_elems;
+    uint16_t* lout = lds + (F32 ? 2 : 1) * p.in_elems;      // [G][HWp] results (F32: fp32)
+    float* loutf = (float*)lout;
+    const s16x8* alo = (const s16x8*)(loutf + (F32 ? p.G * p.HWp : 0));   // F32: [MT][NG][KS][64] w_lo fragments
 
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, lhi = lane >> 5;
     const int wave = wave_id_uniform();
@@ -98,6 +116,8 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dwconv_mfma_fwd_kernel(const Mf
     const int HW = p.H * p.W;
     const uint16_t* __restrict__ x = (const uint16_t*)p.x;
     uint16_t* __restrict__ y = (uint16_t*)p.y;
+    const float* __restrict__ xf = (const float*)p.x;
+    float* __restrict__ yf = (float*)p.y;
 
     const int n_begin = slice * p.planes_per_wg;
     int n_end = n_begin + p.planes_per_wg; if (n_end > p.N) n_end = p.N;
@@ -118,22 +138,31 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dwconv_mfma_fwd_kernel(const Mf
         ooff[k] = j * p.HWp + rem * V;
         loff[k] = VERT ? (h * p.P + u0 + w0) : ((u0 + h) * p.P + w0);
     }
-    chunk_t<V> st[MF_NCH];
+    chunk_t<V> st[F32 ? 1 : MF_NCH];
+    fchunk_t<V> stf[F32 ? MF_NCH : 1];
     auto prefetch = [&](int it) {
         const int n0 = n_begin + it * p.G;
-        const uint16_t* base = x + ((size_t)n0 * p.C + c) * HW;
+        const size_t plane0 = ((size_t)n0 * p.C + c) * HW;
 #pragma unroll
         for (int k = 0; k < MF_NCH; ++k) {
-            if (jpl[k] >= 0 && n0 + jpl[k] < n_end) st[k] = chunk_load<V>(base + goff[k]);
-            else st[k] = chunk_zero<V>();
+            const bool on = jpl[k] >= 0 && n0 + jpl[k] < n_end;
+            if constexpr (F32) stf[k] = on ? fchunk_load<V>(xf + plane0 + goff[k]) : fchunk_zero<V>();
+            else st[k] = on ? chunk_load<V>(x + plane0 + goff[k]) : chunk_zero<V>();
         }
     };
     auto stage_write = [&]() {
 #pragma unroll
         for (int k = 0; k < MF_NCH; ++k) {
             if (jpl[k] >= 0) {
-                if constexpr (VERT) chunk_store_lds_a4<V>(lin + loff[k], st[k]);
-                else chunk_store<V>(lin + loff[k], st[k]);
+                if constexpr (F32) {
+                    chunk_t<V> hi, lo;
+                    fchunk_split<V>(stf[k], hi, lo);
+                    if constexpr (VERT) { chunk_store_lds_a4<V>(lin + loff[k], hi); chunk_store_lds_a4<V>(lin_lo + loff[k], lo); }
+                    else { chunk_store<V>(lin + loff[k], hi); chunk_store<V>(lin_lo + loff[k], lo); }
+                } else {
+                    if constexpr (VERT) chunk_store_lds_a4<V>(lin + loff[k], st[k]);
+                    else chunk_store<V>(lin + loff[k], st[k]);
+                }
             }
         }
     };
@@ -142,7 +171,12 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dwconv_mfma_fwd_kernel(const Mf
     // ---- zero the stack (pads stay zero for the whole kernel), fetch this channel's filter --------
     {
         u32x4* z = (u32x4*)lin;
-        for (int i = tid; i < p.in_elems / 8; i += MF_THREADS) z[i] = u32x4{0u, 0u, 0u, 0u};
+        for (int i = tid; i < (F32 ? 2 : 1) * p.in_elems / 8; i += MF_THREADS) z[i] = u32x4{0u, 0u, 0u, 0u};
+        if constexpr (F32) {                                // this channel's w_lo fragments: global -> LDS, register layout kept
+            const s16x8* src = (const s16x8*)p.frags_lo + (size_t)c * MT * NG * KS * 64;
+            s16x8* dst = const_cast<s16x8*>(alo);
+            for (int i = tid; i < MT * NG * KS * 64; i += MF_THREADS) dst[i] = src[i];
+        }
     }
     __syncthreads();
     stage_write();
@@ -168,19 +202,32 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dwconv_mfma_fwd_kernel(const Mf
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 if (!ks_active[ks]) continue;
-                s16x8 b;
-                if constexpr (!VERT) {
-                    b = *(const s16x8*)(lin + (ustart + l31) * p.P + ks * 16 + lhi * 8);
-                } else {
-                    // ds_read_b64_tr_b16: the 16 lanes of group g = lane>>4 read a 4(k) x 16(u) block; lane gets column lane&15
-                    const int grp = lane >> 4, i16 = lane & 15;
-                    const uint16_t* a0 = lin + (ks * 16 + (grp >> 1) * 8 + (i16 >> 2)) * p.P + ustart + (grp & 1) * 16 + (i16 & 3) * 4;
-                    s16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(SLAK_LDS(s16x4, a0));
-                    s16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(SLAK_LDS(s16x4, a0 + 4 * p.P));
-                    b = s16x8{b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
-                }
+                auto read_b = [&](const uint16_t* stack) -> s16x8 {
+                    if constexpr (!VERT) {
+                        return *(const s16x8*)(stack + (ustart + l31) * p.P + ks * 16 + lhi * 8);
+                    } else {
+                        // ds_read_b64_tr_b16: the 16 lanes of group g = lane>>4 read a 4(k) x 16(u) block; lane gets column lane&15
+                        const int grp = lane >> 4, i16 = lane & 15;
+                        const uint16_t* a0 = stack + (ks * 16 + (grp >> 1) * 8 + (i16 >> 2)) * p.P + ustart + (grp & 1) * 16 + (i16 & 3) * 4;
+                        s16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(SLAK_LDS(s16x4, a0));
+                        s16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(SLAK_LDS(s16x4, a0 + 4 * p.P));
+                        return s16x8{b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+                    }
+                };
+                const s16x8 b = read_b(lin);
+                if constexpr (F32) {
+                    const s16x8 bl = read_b(lin_lo);
 #pragma unroll
-                for (int g = 0; g < NG; ++g) acc[g] = mfma32<T>(afrag[g][ks], b, acc[g]);
+                    for (int g = 0; g < NG; ++g) {
+                        const s16x8 al = alo[((mt * NG + g) * KS + ks) * 64 + lane];
+                        acc[g] = mfma32<T>(al, b, acc[g]);               // small terms first
+                        acc[g] = mfma32<T>(afrag[g][ks], bl, acc[g]);
+                        acc[g] = mfma32<T>(afrag[g][ks], b, acc[g]);
+                    }
+                } else {
+#pragma unroll
+                    for (int g = 0; g < NG; ++g) acc[g] = mfma32<T>(afrag[g][ks], b, acc[g]);
+                }
             }
             // ---- epilogue: Y = Z2 + shr(Z1 + shr(Z0)) + shl(Z3 + shl(Z4)) along the lane axis -----------
             float yv[NR];
@@ -203,14 +250,15 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dwconv_mfma_fwd_kernel(const Mf
             valid = valid && pos < p.Wl && (n0 + j) < n_end;
             if (valid) {
                 uint16_t* op = lout + j * p.HWp;
+                float* opf = loutf + j * p.HWp;
 #pragma unroll
                 for (int i = 0; i < NR; ++i) {
                     const int o = (RPM == 4) ? ((i & 3) + 4 * lhi) : ((i & 3) + 8 * (i >> 2) + 4 * lhi);
                     const int o_abs = mt * 32 + o;
                     if (o_abs < p.Wt) {
-                        const uint16_t bits = cvt_to_bits(yv[i], (T*)nullptr);
-                        if constexpr (VERT) op[o_abs * p.W + pos] = bits;        // (oh = o, ow = lane position)
-                        else op[pos * p.W + o_abs] = bits;                         // (oh = lane position, ow = o)
+                        const int at = VERT ? o_abs * p.W + pos : pos * p.W + o_abs;   // (oh, ow) = (o, lane position) / (lane position, o)
+                        if constexpr (F32) opf[at] = yv[i];
+                        else op[at] = cvt_to_bits(yv[i], (T*)nullptr);
                     }
                 }
             }
@@ -218,10 +266,13 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dwconv_mfma_fwd_kernel(const Mf
         __syncthreads();
         // ---- results of this iteration -> global (coalesced), next iteration's planes -> stack --------
         {
-            uint16_t* base = y + ((size_t)n0 * p.C + c) * HW;
+            const size_t plane0 = ((size_t)n0 * p.C + c) * HW;
 #pragma unroll
             for (int k = 0; k < MF_NCH; ++k) {
-                if (jpl[k] >= 0 && n0 + jpl[k] < n_end) chunk_store<V>(base + goff[k], chunk_load<V>(lout + ooff[k]));
+                if (jpl[k] >= 0 && n0 + jpl[k] < n_end) {
+                    if constexpr (F32) fchunk_store<V>(yf + plane0 + goff[k], fchunk_load<V>(loutf + ooff[k]));
+                    else chunk_store<V>(y + plane0 + goff[k], chunk_load<V>(lout + ooff[k]));
+                }
             }
         }
         if (it + 1 < iters) stage_write();
@@ -285,20 +336,22 @@ static bool fill_mfma_params(MfmaFwdParams& p, const ConvDims& d, bool vert, con
     return true;
 }
 
-static size_t mfma_fwd_lds_bytes(const MfmaFwdParams& p) {
-    return (size_t)p.in_elems * 2 + (size_t)p.G * p.HWp * 2 + 16;
+static size_t mfma_fwd_lds_bytes(const MfmaFwdParams& p, const MfmaShape& s, bool f32) {
+    if (!f32) return (size_t)p.in_elems * 2 + (size_t)p.G * p.HWp * 2 + 16;
+    const size_t ng = (MF_TAPS + s.RPM - 1) / s.RPM;
+    return (size_t)p.in_elems * 4 + (size_t)p.G * p.HWp * 4 + (size_t)s.MT * ng * s.KS * 64 * 16 + 16;     // two stacks, fp32 results, w_lo fragments
 }
 
-template <typename T, int MT, int KS, int RPM, int V>
+template <typename T, int MT, int KS, int RPM, int V, bool F32>
 static int launch_mfma_fwd_t(const MfmaFwdParams& p, bool vert, hipStream_t st) {
-    const size_t lds = mfma_fwd_lds_bytes(p);
+    const size_t lds = mfma_fwd_lds_bytes(p, MfmaShape{MT, KS, RPM, V}, F32);
     dim3 grid((unsigned)(p.C * p.slices));
     if (vert) {
-        auto k = dwconv_mfma_fwd_kernel<T, MT, KS, RPM, V, true>;
+        auto k = dwconv_mfma_fwd_kernel<T, MT, KS, RPM, V, true, F32>;
         if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(k, grid, dim3(MF_THREADS), lds, st, p);
     } else {
-        auto k = dwconv_mfma_fwd_kernel<T, MT, KS, RPM, V, false>;
+        auto k = dwconv_mfma_fwd_kernel<T, MT, KS, RPM, V, false, F32>;
         if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(k, grid, dim3(MF_THREADS), lds, st, p);
     }
@@ -306,12 +359,12 @@ static int launch_mfma_fwd_t(const MfmaFwdParams& p, bool vert, hipStream_t st) 
     return SLAK_OK;
 }
 
-template <typename T>
+template <typename T, bool F32>
 static int launch_mfma_fwd_shape(const MfmaFwdParams& p, const MfmaShape& s, bool vert, hipStream_t st) {
-    if (s.MT == 2) return launch_mfma_fwd_t<T, 2, 4, 1, 8>(p, vert, st);
-    if (s.KS == 2) return launch_mfma_fwd_t<T, 1, 2, 1, 4>(p, vert, st);
-    if (s.RPM == 2) return launch_mfma_fwd_t<T, 1, 1, 2, 2>(p, vert, st);
-    return launch_mfma_fwd_t<T, 1, 1, 4, 1>(p, vert, st);
+    if (s.MT == 2) return launch_mfma_fwd_t<T, 2, 4, 1, 8, F32>(p, vert, st);
+    if (s.KS == 2) return launch_mfma_fwd_t<T, 1, 2, 1, 4, F32>(p, vert, st);
+    if (s.RPM == 2) return launch_mfma_fwd_t<T, 1, 1, 2, 2, F32>(p, vert, st);
+    return launch_mfma_fwd_t<T, 1, 1, 4, 1, F32>(p, vert, st);
 }
 
 static int g_cu_count = 0;
@@ -324,21 +377,23 @@ int mfma_cu_count() {
     return g_cu_count;
 }
 
-// true when the MFMA path covers (dims, dtypes); fp32 filter only (the caller converts otherwise)
+// true when the MFMA path covers (dims, dtypes); fp32 filter only (the caller converts otherwise).  fp32 activations: the two-term
+// bf16 split (three MFMAs per product term group), two workgroups per CU as long as the doubled stacks and the w_lo fragments fit 80 KB.
 bool dwconv_mfma_supported(const ConvDims& d, int x_dt, int w_dt, int y_dt) {
-    if (x_dt != y_dt || (x_dt != SLAK_BF16 && x_dt != SLAK_F16) || w_dt != SLAK_F32) return false;
+    if (x_dt != y_dt || (x_dt != SLAK_BF16 && x_dt != SLAK_F16 && x_dt != SLAK_F32) || w_dt != SLAK_F32) return false;
     const bool vert = d.kh > d.kw;
     MfmaShape s; MfmaFwdParams p;
     if (!mfma_fwd_shape(d, vert, s)) return false;
     if (!fill_mfma_params(p, d, vert, s, 256)) return false;
-    return mfma_fwd_lds_bytes(p) <= 64 * 1024;
+    if (x_dt == SLAK_F32) return mfma_fwd_lds_bytes(p, s, true) <= 80 * 1024;
+    return mfma_fwd_lds_bytes(p, s, false) <= 64 * 1024;
 }
 
 size_t dwconv_mfma_workspace(const ConvDims& d) {
     const bool vert = d.kh > d.kw;
     MfmaShape s;
     if (!mfma_fwd_shape(d, vert, s)) return 0;
-    return align_up(toeplitz_pack_bytes(d.C, s.MT, (MF_TAPS + s.RPM - 1) / s.RPM, s.KS), 256);
+    return 2 * align_up(toeplitz_pack_bytes(d.C, s.MT, (MF_TAPS + s.RPM - 1) / s.RPM, s.KS), 256);     // w_hi (all dtypes) + w_lo (fp32 activations)
 }
 
 int launch_dwconv_mfma(const void* x, int x_dt, const void* w, int w_dt, void* y, int y_dt,
@@ -349,13 +404,16 @@ int launch_dwconv_mfma(const void* x, int x_dt, const void* w, int w_dt, void* y
     MfmaShape s; MfmaFwdParams p;
     mfma_fwd_shape(d, vert, s);
     fill_mfma_params(p, d, vert, s, mfma_cu_count());
+    const bool f32 = x_dt == SLAK_F32;
+    uint16_t* lo = f32 ? (uint16_t*)((char*)ws + dwconv_mfma_workspace(d) / 2) : nullptr;
     ToeplitzPackParams tp{(const float*)w, (uint16_t*)ws, d.C, d.kh, d.kw, s.MT, (MF_TAPS + s.RPM - 1) / s.RPM, s.KS, s.RPM,
-                          vert ? 1 : 0, flip_filter ? 1 : 0, p.Wt, p.KL, p.padL, x_dt == SLAK_BF16 ? 1 : 0};
+                          vert ? 1 : 0, flip_filter ? 1 : 0, p.Wt, p.KL, p.padL, x_dt != SLAK_F16 ? 1 : 0, lo};
     launch_toeplitz_pack(tp, st);
     SLAK_LAUNCH_CHECK();
-    p.x = x; p.frags = (const uint16_t*)ws; p.y = y; p.flip = flip_filter ? 1 : 0;
-    if (x_dt == SLAK_BF16) return launch_mfma_fwd_shape<bf16_t>(p, s, vert, st);
-    return launch_mfma_fwd_shape<f16_t>(p, s, vert, st);
+    p.x = x; p.frags = (const uint16_t*)ws; p.frags_lo = lo; p.y = y; p.flip = flip_filter ? 1 : 0;
+    if (f32) return launch_mfma_fwd_shape<bf16_t, true>(p, s, vert, st);
+    if (x_dt == SLAK_BF16) return launch_mfma_fwd_shape<bf16_t, false>(p, s, vert, st);
+    return launch_mfma_fwd_shape<f16_t, false>(p, s, vert, st);
 }
 
 }  // namespace slak

@@ -43,16 +43,22 @@ struct MfmaWgradParams {
 
 // MT: 32-wide tiles along the long axis for both o and i (wave w owns (w & 1, w >> 1) when MT == 2; when MT == 1 the
 // four waves split the k-steps); RPN: short taps packed per 32 MFMA columns; V: staging vector width; VERT: long axis = H.
-template <typename T, int MT, int RPN, int V, bool VERT>
+// F32: fp32 operands on the bf16 matrix cores.  Both tensors are split x = x_hi + x_lo while they are staged (a second pair of stacks, and of
+// staging images on the vertical path, `lo_off` elements behind the first); every k-step is dy_lo x_hi + dy_hi x_lo + dy_hi x_hi into the
+// same fp32 accumulator (dropped: dy_lo x_lo and the representation errors, each <= 2^-16 of |dy||x|).
+template <typename T, int MT, int RPN, int V, bool VERT, bool F32 = false>
 __global__ __launch_bounds__(MF_THREADS, 2) void dwconv_mfma_wgrad_kernel(const MfmaWgradParams p) {
     constexpr int NG = (MF_TAPS + RPN - 1) / RPN;
     constexpr int NPAD = 32 / RPN;
+    constexpr int NSET = F32 ? 2 : 1;
     extern __shared__ __attribute__((aligned(16))) uint16_t lds[];
     uint16_t* dys = lds;
     uint16_t* xs = lds + p.dy_elems;
-    const int stack_elems = (p.dy_elems + p.x_elems) > MF_WAVES * 32 * 33 * 2 ? (p.dy_elems + p.x_elems) : MF_WAVES * 32 * 33 * 2;
+    const int lo_off = p.dy_elems + p.x_elems;              // F32: [dy_hi | x_hi | dy_lo | x_lo]
+    const int stack_elems = NSET * (p.dy_elems + p.x_elems) > MF_WAVES * 32 * 33 * 2 ? NSET * (p.dy_elems + p.x_elems) : MF_WAVES * 32 * 33 * 2;
     float* dwl = (float*)(lds + stack_elems);               // [MF_WAVES][kh*kw]
-    uint16_t* img = (uint16_t*)(dwl + MF_WAVES * p.kh * p.kw);   // vertical only: row-major staging images [dy|x][G][Hi][Pi]
+    uint16_t* img = (uint16_t*)(dwl + MF_WAVES * p.kh * p.kw);   // vertical only: row-major staging images [dy|x][G][Hi][Pi] (F32: a second set behind)
+    const int img_lo = 2 * p.G * p.Hi * p.Pi;
 
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, lhi = lane >> 5;
     const int wave = wave_id_uniform();
@@ -61,6 +67,8 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dwconv_mfma_wgrad_kernel(const 
     const int HW = p.H * p.W, ntap = p.kh * p.kw;
     const uint16_t* __restrict__ gx = (const uint16_t*)p.x;
     const uint16_t* __restrict__ gdy = (const uint16_t*)p.dy;
+    const float* __restrict__ fx = (const float*)p.x;
+    const float* __restrict__ fdy = (const float*)p.dy;
 
     const int n_begin = slice * p.planes_per_wg;
     int n_end = n_begin + p.planes_per_wg; if (n_end > p.N) n_end = p.N;
@@ -107,46 +115,65 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dwconv_mfma_wgrad_kernel(const 
             tr_w[k] = (ok && col < p.W) ? dst_plane + (2 + col) * p.P + kb * 4 : -1;
         }
     }
-    chunk_t<V> sx[MF_NCH], sd[MF_NCH];
+    chunk_t<V> sx[F32 ? 1 : MF_NCH], sd[F32 ? 1 : MF_NCH];
+    fchunk_t<V> sxf[F32 ? MF_NCH : 1], sdf[F32 ? MF_NCH : 1];
     auto prefetch = [&](int it) {
         const int n0 = n_begin + it * p.G;
         const size_t base = ((size_t)n0 * p.C + c) * HW;
 #pragma unroll
         for (int k = 0; k < MF_NCH; ++k) {
-            if (jpl[k] >= 0 && n0 + jpl[k] < n_end) { sx[k] = chunk_load<V>(gx + base + goff[k]); sd[k] = chunk_load<V>(gdy + base + goff[k]); }
-            else { sx[k] = chunk_zero<V>(); sd[k] = chunk_zero<V>(); }
+            const bool on = jpl[k] >= 0 && n0 + jpl[k] < n_end;
+            if constexpr (F32) {
+                sxf[k] = on ? fchunk_load<V>(fx + base + goff[k]) : fchunk_zero<V>();
+                sdf[k] = on ? fchunk_load<V>(fdy + base + goff[k]) : fchunk_zero<V>();
+            } else {
+                sx[k] = on ? chunk_load<V>(gx + base + goff[k]) : chunk_zero<V>();
+                sd[k] = on ? chunk_load<V>(gdy + base + goff[k]) : chunk_zero<V>();
+            }
         }
     };
     // the x stack carries 2 extra k-rows in front, so that row "k + rho" (rho = 0..4) holds x[k + rho - 2]
+    auto put = [&](int k, const chunk_t<V>& d_, const chunk_t<V>& x_, int set) {
+        if constexpr (VERT) { chunk_store<V>(img + set * img_lo + loff[k], d_); chunk_store<V>(img + set * img_lo + p.G * p.Hi * p.Pi + loff[k], x_); }
+        else { chunk_store<V>(dys + set * lo_off + loff[k], d_); chunk_store<V>(xs + set * lo_off + loff[k] + 2 * p.P, x_); }
+    };
     auto stage_write = [&]() {
 #pragma unroll
         for (int k = 0; k < MF_NCH; ++k) {
             if (jpl[k] >= 0) {
-                if constexpr (VERT) { chunk_store<V>(img + loff[k], sd[k]); chunk_store<V>(img + p.G * p.Hi * p.Pi + loff[k], sx[k]); }
-                else { chunk_store<V>(dys + loff[k], sd[k]); chunk_store<V>(xs + loff[k] + 2 * p.P, sx[k]); }
+                if constexpr (F32) {
+                    chunk_t<V> dh, dl, xh, xl;
+                    fchunk_split<V>(sdf[k], dh, dl); fchunk_split<V>(sxf[k], xh, xl);
+                    put(k, dh, xh, 0); put(k, dl, xl, 1);
+                } else put(k, sd[k], sx[k], 0);
             }
         }
     };
     auto transpose_images = [&]() {                          // vertical: images -> stacks (all threads; caller syncs around it)
         if constexpr (VERT) {
-            if (tr_flat) {
 #pragma unroll
-                for (int k = 0; k < WG_NTR; ++k) {
-                    if (tr_r[k] >= 0) {
-                        const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16(SLAK_LDS(s16x4, img + tr_r[k]));
-                        if (tr_w[k] >= 0) *(s16x4*)(lds + tr_w[k]) = v;
+            for (int set = 0; set < NSET; ++set) {
+                const uint16_t* imgs = img + set * img_lo;
+                uint16_t* base = lds + set * lo_off;
+                if (tr_flat) {
+#pragma unroll
+                    for (int k = 0; k < WG_NTR; ++k) {
+                        if (tr_r[k] >= 0) {
+                            const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16(SLAK_LDS(s16x4, imgs + tr_r[k]));
+                            if (tr_w[k] >= 0) *(s16x4*)(base + tr_w[k]) = v;
+                        }
                     }
-                }
-            } else {
-                for (int t = 0; t < 2; ++t) {
-                    for (int j = 0; j < p.G; ++j) {
-                        const uint16_t* src = img + (t * p.G + j) * p.Hi * p.Pi;
-                        uint16_t* dst = (t ? xs + 2 * p.P : dys) + j * (p.Wl + 2) * p.P;
+                } else {
+                    for (int t = 0; t < 2; ++t) {
+                        for (int j = 0; j < p.G; ++j) {
+                            const uint16_t* src = imgs + (t * p.G + j) * p.Hi * p.Pi;
+                            uint16_t* dst = base + (t ? p.dy_elems + 2 * p.P : 0) + j * (p.Wl + 2) * p.P;
 #pragma unroll
-                        for (int k = 0; k < WG_NTR; ++k) {
-                            if (tr_r[k] >= 0) {
-                                const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16(SLAK_LDS(s16x4, src + tr_r[k]));
-                                if (tr_w[k] >= 0) *(s16x4*)(dst + tr_w[k]) = v;
+                            for (int k = 0; k < WG_NTR; ++k) {
+                                if (tr_r[k] >= 0) {
+                                    const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16(SLAK_LDS(s16x4, src + tr_r[k]));
+                                    if (tr_w[k] >= 0) *(s16x4*)(dst + tr_w[k]) = v;
+                                }
                             }
                         }
                     }
@@ -160,11 +187,11 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dwconv_mfma_wgrad_kernel(const 
     if (iters > 0) prefetch(0);
     {
         u32x4* z = (u32x4*)lds;
-        const int n8 = (p.dy_elems + p.x_elems) / 8;
+        const int n8 = NSET * (p.dy_elems + p.x_elems) / 8;
         for (int i = tid; i < n8; i += MF_THREADS) z[i] = u32x4{0u, 0u, 0u, 0u};
         for (int i = tid; i < MF_WAVES * ntap; i += MF_THREADS) dwl[i] = 0.f;
     }
-    if constexpr (VERT) { for (int i = tid; i < p.G * p.Hi * p.Pi; i += MF_THREADS) ((unsigned*)img)[i] = 0u; }   // 2 images x G planes, 2 elements per dword
+    if constexpr (VERT) { for (int i = tid; i < NSET * p.G * p.Hi * p.Pi; i += MF_THREADS) ((unsigned*)img)[i] = 0u; }   // NSET x 2 images x G planes, 2 elements per dword
     __syncthreads();
     if (iters > 0) stage_write();
     __syncthreads();
@@ -197,16 +224,26 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dwconv_mfma_wgrad_kernel(const 
     for (int it = 0; it < iters; ++it) {
         if (it + 1 < iters) prefetch(it + 1);
         for (int ks = ks_first; ks < p.NKS; ks += ks_stride) {
+            auto frag = [&](const uint16_t* q) -> s16x8 {
+                const s16x4 f0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(SLAK_LDS(s16x4, q));
+                const s16x4 f1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(SLAK_LDS(s16x4, q + 4 * p.P));
+                return s16x8{f0[0], f0[1], f0[2], f0[3], f1[0], f1[1], f1[2], f1[3]};
+            };
             const uint16_t* ap = dys + a_off + ks * kstep_elems;
-            const s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(SLAK_LDS(s16x4, ap));
-            const s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(SLAK_LDS(s16x4, ap + 4 * p.P));
-            const s16x8 a = s16x8{a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+            const s16x8 a = frag(ap);
+            if constexpr (F32) {
+                const s16x8 al = frag(ap + lo_off);
 #pragma unroll
-            for (int g = 0; g < NG; ++g) {
-                const uint16_t* bp = xs + b_off[g] + ks * kstep_elems;
-                const s16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(SLAK_LDS(s16x4, bp));
-                const s16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(SLAK_LDS(s16x4, bp + 4 * p.P));
-                acc[g] = mfma32<T>(a, s16x8{b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]}, acc[g]);
+                for (int g = 0; g < NG; ++g) {
+                    const uint16_t* bp = xs + b_off[g] + ks * kstep_elems;
+                    const s16x8 b = frag(bp), bl = frag(bp + lo_off);
+                    acc[g] = mfma32<T>(al, b, acc[g]);                 // small terms first
+                    acc[g] = mfma32<T>(a, bl, acc[g]);
+                    acc[g] = mfma32<T>(a, b, acc[g]);
+                }
+            } else {
+#pragma unroll
+                for (int g = 0; g < NG; ++g) acc[g] = mfma32<T>(a, frag(xs + b_off[g] + ks * kstep_elems), acc[g]);
             }
         }
         __syncthreads();
@@ -312,18 +349,21 @@ static bool fill_wgrad_params(MfmaWgradParams& p, const ConvDims& d, bool vert, 
     return true;
 }
 
-static size_t mfma_wgrad_lds_bytes(const MfmaWgradParams& p, bool vert) {
-    size_t stacks = (size_t)(p.dy_elems + p.x_elems) * 2, scratch = (size_t)MF_WAVES * 32 * 33 * 4;
-    return (stacks > scratch ? stacks : scratch) + (size_t)MF_WAVES * p.kh * p.kw * 4 + (vert ? (size_t)2 * p.G * p.Hi * p.Pi * 2 : 0) + 32;
+static size_t mfma_wgrad_lds_bytes(const MfmaWgradParams& p, bool vert, bool f32) {
+    const size_t sets = f32 ? 2 : 1;
+    size_t stacks = sets * (size_t)(p.dy_elems + p.x_elems) * 2, scratch = (size_t)MF_WAVES * 32 * 33 * 4;
+    return (stacks > scratch ? stacks : scratch) + (size_t)MF_WAVES * p.kh * p.kw * 4 + (vert ? sets * (size_t)2 * p.G * p.Hi * p.Pi * 2 : 0) + 32;
 }
 
+// fp32 operands: the two-term bf16 split, doubled stacks (one workgroup per CU where they pass 80 KB)
 bool dwconv_mfma_wgrad_supported(const ConvDims& d, int dy_dt, int x_dt) {
-    if (dy_dt != x_dt || (x_dt != SLAK_BF16 && x_dt != SLAK_F16)) return false;
+    if (dy_dt != x_dt || (x_dt != SLAK_BF16 && x_dt != SLAK_F16 && x_dt != SLAK_F32)) return false;
     const bool vert = d.kh > d.kw;
     WShape s; MfmaWgradParams p;
     if (!mfma_wgrad_shape(d, vert, s)) return false;
     if (!fill_wgrad_params(p, d, vert, s, 256)) return false;
-    return mfma_wgrad_lds_bytes(p, vert) <= 72 * 1024;
+    if (x_dt == SLAK_F32) return mfma_wgrad_lds_bytes(p, vert, true) <= 160 * 1024;
+    return mfma_wgrad_lds_bytes(p, vert, false) <= 72 * 1024;
 }
 
 size_t dwconv_mfma_wgrad_workspace(const ConvDims& d) {
@@ -334,16 +374,16 @@ size_t dwconv_mfma_wgrad_workspace(const ConvDims& d) {
     return align_up((size_t)p.slices * d.C * d.kh * d.kw * sizeof(float), 256);
 }
 
-template <typename T, int MT, int RPN, int V>
+template <typename T, int MT, int RPN, int V, bool F32>
 static int launch_wgrad_t(const MfmaWgradParams& p, bool vert, hipStream_t st) {
-    const size_t lds = mfma_wgrad_lds_bytes(p, vert);
+    const size_t lds = mfma_wgrad_lds_bytes(p, vert, F32);
     dim3 grid((unsigned)(p.C * p.slices));
     if (vert) {
-        auto k = dwconv_mfma_wgrad_kernel<T, MT, RPN, V, true>;
+        auto k = dwconv_mfma_wgrad_kernel<T, MT, RPN, V, true, F32>;
         if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(k, grid, dim3(MF_THREADS), lds, st, p);
     } else {
-        auto k = dwconv_mfma_wgrad_kernel<T, MT, RPN, V, false>;
+        auto k = dwconv_mfma_wgrad_kernel<T, MT, RPN, V, false, F32>;
         if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(k, grid, dim3(MF_THREADS), lds, st, p);
     }
@@ -351,12 +391,12 @@ static int launch_wgrad_t(const MfmaWgradParams& p, bool vert, hipStream_t st) {
     return SLAK_OK;
 }
 
-template <typename T>
+template <typename T, bool F32>
 static int launch_wgrad_shape(const MfmaWgradParams& p, const WShape& s, bool vert, hipStream_t st) {
-    if (s.MT == 2) return launch_wgrad_t<T, 2, 1, 8>(p, vert, st);
-    if (s.RPN == 1) return launch_wgrad_t<T, 1, 1, 4>(p, vert, st);
-    if (s.RPN == 2) return launch_wgrad_t<T, 1, 2, 2>(p, vert, st);
-    return launch_wgrad_t<T, 1, 4, 1>(p, vert, st);
+    if (s.MT == 2) return launch_wgrad_t<T, 2, 1, 8, F32>(p, vert, st);
+    if (s.RPN == 1) return launch_wgrad_t<T, 1, 1, 4, F32>(p, vert, st);
+    if (s.RPN == 2) return launch_wgrad_t<T, 1, 2, 2, F32>(p, vert, st);
+    return launch_wgrad_t<T, 1, 4, 1, F32>(p, vert, st);
 }
 
 int launch_dwconv_mfma_wgrad(const void* dy, int dy_dt, const void* x, int x_dt, float* dw,
@@ -369,7 +409,8 @@ int launch_dwconv_mfma_wgrad(const void* dy, int dy_dt, const void* x, int x_dt,
     if (ws == nullptr || ws_bytes < dwconv_mfma_wgrad_workspace(d)) return SLAK_ERR_WORKSPACE;
     p.dy = dy; p.x = x; p.partial = (float*)ws; p.dbg = g_dma_dbg;
     p.dw = dw; p.counters = wgrad_arrival_counters(d.C);
-    int rc = (x_dt == SLAK_BF16) ? launch_wgrad_shape<bf16_t>(p, s, vert, st) : launch_wgrad_shape<f16_t>(p, s, vert, st);
+    int rc = (x_dt == SLAK_F32) ? launch_wgrad_shape<bf16_t, true>(p, s, vert, st)
+           : (x_dt == SLAK_BF16) ? launch_wgrad_shape<bf16_t, false>(p, s, vert, st) : launch_wgrad_shape<f16_t, false>(p, s, vert, st);
     if (rc != SLAK_OK || p.counters) return rc;
     return launch_wgrad_reduce((const float*)ws, dw, d.C * d.kh * d.kw, p.slices, st);
 }

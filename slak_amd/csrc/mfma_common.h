@@ -12,6 +12,8 @@ typedef s16x8 __attribute__((aligned(2))) s16x8_u;       // LDS vector at a 2-by
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
 
@@ -104,6 +106,34 @@ template <int V> __device__ __forceinline__ void chunk_set(chunk_t<V>& c, int i,
     } else if constexpr (V == 2) c.v = (c.v & ~m) | ((unsigned)val << sh);
     else c.v = val;
 }
+// fp32 operands on the matrix cores (two-term bf16 split): a chunk of V fp32 values and its split x = x_hi + x_lo + O(2^-17 |x|),
+// x_hi = bf16(x) (round to nearest even), x_lo = bf16(x - x_hi) (the subtraction is exact).
+template <int V> struct fchunk_t { float v[V]; };
+template <int V> __device__ __forceinline__ fchunk_t<V> fchunk_zero() { fchunk_t<V> c; for (int i = 0; i < V; ++i) c.v[i] = 0.f; return c; }
+template <int V> __device__ __forceinline__ fchunk_t<V> fchunk_load(const float* p) {
+    fchunk_t<V> c;
+    if constexpr (V == 8) { const f32x4 a = *(const f32x4*)p, b = *(const f32x4*)(p + 4); for (int i = 0; i < 4; ++i) { c.v[i] = a[i]; c.v[4 + i] = b[i]; } }
+    else if constexpr (V == 4) { const f32x4 a = *(const f32x4*)p; for (int i = 0; i < 4; ++i) c.v[i] = a[i]; }
+    else if constexpr (V == 2) { const f32x2 a = *(const f32x2*)p; c.v[0] = a[0]; c.v[1] = a[1]; }
+    else c.v[0] = *p;
+    return c;
+}
+template <int V> __device__ __forceinline__ void fchunk_store(float* p, const fchunk_t<V>& c) {
+    if constexpr (V == 8) { *(f32x4*)p = f32x4{c.v[0], c.v[1], c.v[2], c.v[3]}; *(f32x4*)(p + 4) = f32x4{c.v[4], c.v[5], c.v[6], c.v[7]}; }
+    else if constexpr (V == 4) *(f32x4*)p = f32x4{c.v[0], c.v[1], c.v[2], c.v[3]};
+    else if constexpr (V == 2) *(f32x2*)p = f32x2{c.v[0], c.v[1]};
+    else *p = c.v[0];
+}
+__device__ __forceinline__ void split_bf16(float x, uint16_t& hi, uint16_t& lo) {
+    hi = f32_to_bf16_bits(x);
+    lo = ((hi & 0x7f80u) == 0x7f80u) ? (uint16_t)0 : f32_to_bf16_bits(x - __uint_as_float((unsigned)hi << 16));   // inf / NaN: carried by the first term alone
+}
+template <int V> __device__ __forceinline__ void fchunk_split(const fchunk_t<V>& f, chunk_t<V>& hi, chunk_t<V>& lo) {
+    hi = chunk_zero<V>(); lo = chunk_zero<V>();
+#pragma unroll
+    for (int i = 0; i < V; ++i) { uint16_t h, l; split_bf16(f.v[i], h, l); chunk_set<V>(hi, i, h); chunk_set<V>(lo, i, l); }
+}
+
 // LDS store of a chunk whose address is only 4-byte aligned (vertical kernels place planes at lane offset 2)
 template <int V> __device__ __forceinline__ void chunk_store_lds_a4(uint16_t* p, const chunk_t<V>& c) {
     if constexpr (V == 8) { unsigned* q = (unsigned*)p; q[0] = c.v[0]; q[1] = c.v[1]; q[2] = c.v[2]; q[3] = c.v[3]; }
@@ -121,6 +151,7 @@ template <int V> __device__ __forceinline__ void chunk_store_lds_a4(uint16_t* p,
 struct ToeplitzPackParams {
     const float* w; uint16_t* frags;
     int C, kh, kw, MT, NG, KS, RPM, vert, flip, Wt, KL, padL, is_bf16;
+    uint16_t* frags_lo;    // fp32 operands on the matrix cores: second bf16 term of every filter value (w - bf16(w)), same layout; or NULL
 };
 void launch_toeplitz_pack(const ToeplitzPackParams& p, hipStream_t st);
 static inline size_t toeplitz_pack_bytes(int C, int MT, int NG, int KS) { return (size_t)C * MT * NG * KS * 64 * 8 * 2; }

@@ -54,6 +54,15 @@ def _stream(device):
     return torch.cuda.current_stream(device).cuda_stream
 
 
+def allow_fp32_matrix_cores(allow=True):
+    """fp32 tensors through the bf16 matrix cores (two-term split, slak_set_fp32_matrix_cores): off by default like
+    torch.backends.cudnn.allow_tf32 gates TF32 -- the fp32 path is then the exact VALU kernels.  Returns the previous setting."""
+    L = _lib.lib()
+    prev = bool(L.slak_get_fp32_matrix_cores())
+    _lib.check(L.slak_set_fp32_matrix_cores(1 if allow else 0), "slak_set_fp32_matrix_cores")
+    return prev
+
+
 def dwconv2d_forward(x, w, out_dtype=None):
     _check_tensor(x, "input"); _check_tensor(w, "weight")
     N, C, H, W, kh, kw = _dims(x, w)

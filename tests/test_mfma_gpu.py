@@ -128,8 +128,10 @@ def test_mfma_is_what_auto_runs_for_lowp(gpu):
     L.lib().slak_set_conv_algo(L.ALGO_MFMA)
     try:
         y_mfma = ops.dwconv2d_forward(x, w)
+        y32 = ops.dwconv2d_forward(x.float(), w)                    # fp32 activations, MFMA forced: the two-term split (tests/test_fp32_mfma_gpu.py)
+        assert L.lib().slak_debug_last_kernel() == b"dwconv_mfma(f32 split)" and y32.dtype == torch.float32
         with pytest.raises(L.SlakHipError):
-            ops.dwconv2d_forward(x.float(), w)                     # fp32 activations: no MFMA kernel
+            ops.dwconv2d_forward(torch.randn(2, 3, 96, 96, device=gpu), w)   # fp32 on a map beyond 64: no matrix-core kernel
         with pytest.raises(L.SlakHipError):
             ops.dwconv2d_forward(x, torch.randn(3, 1, 7, 7, device=gpu))   # no 5-tap side
         L.lib().slak_set_conv_algo(L.ALGO_DIRECT)
