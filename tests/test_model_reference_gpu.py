@@ -68,6 +68,25 @@ def test_fp32_mirror_reproduces_the_reference_model(gpu):
     assert worst[0] <= 2e-3, worst
 
 
+def test_fp32_mirror_on_the_matrix_cores_stays_within_the_reference_tolerance(gpu):
+    """The same fp32 run with the opt-in two-term split (slak_set_fp32_matrix_cores): every dw conv of the narrow model's maps runs three bf16
+    MFMAs per product.  End to end the logits stay within 1e-3 of the reference model's fp64 run (north star; measured ~1e-4), gradients 5e-3."""
+    from slak_amd import _lib, ops
+    g = load_golden("model_reference")
+    _set_fused(False)
+    m = _build(g, gpu, lowp=False)
+    prev = ops.allow_fp32_matrix_cores(True)
+    try:
+        logits, grads, running, ev = _run(m, g, gpu, autocast=False)
+        assert b"f32 split" in _lib.lib().slak_debug_last_kernel()
+    finally:
+        ops.allow_fp32_matrix_cores(prev)
+    print("fp32 split: logits rel err %.2e (train) %.2e (eval)" % (_rel(logits, g["logits_train"]), _rel(ev, g["logits_eval"])))
+    assert _rel(logits, g["logits_train"]) <= 1e-3 and _rel(ev, g["logits_eval"]) <= 1e-3
+    worst = max((_rel(v, g["grad/" + n]), n) for n, v in grads.items())
+    assert worst[0] <= 5e-3, worst
+
+
 @pytest.mark.parametrize("fused", [False, True])
 def test_bf16_mirror_stays_within_the_bf16_tolerance_of_the_reference_model(fused, gpu):
     g = load_golden("model_reference")
