@@ -11,7 +11,7 @@ import os
 import torch
 
 from . import _lib
-from .ops import _workspace, _stream
+from .ops import _workspace, _stream, _on
 
 
 def _chk(t, name, dtype=None):
@@ -30,7 +30,7 @@ class _LnNchwToNhwc(torch.autograd.Function):
         mean = torch.empty((N, H * W), dtype=torch.float32, device=x.device)
         rstd = torch.empty_like(mean)
         L = _lib.lib()
-        with torch.cuda.device(x.device):
+        with _on(x.device):
             _lib.check(L.slak_ln_nchw_to_nhwc_forward(x.data_ptr(), weight.data_ptr(), bias.data_ptr(), y.data_ptr(), mean.data_ptr(),
                                                       rstd.data_ptr(), N, C, H * W, float(eps), _stream(x.device)), "slak_ln_nchw_to_nhwc_forward")
         ctx.save_for_backward(x, weight, mean, rstd)
@@ -47,7 +47,7 @@ class _LnNchwToNhwc(torch.autograd.Function):
         dw = torch.empty_like(weight); db = torch.empty_like(weight)
         L = _lib.lib()
         ws, nb = _workspace(L.slak_block_tail_workspace_bytes(N, C, H * W), x.device)
-        with torch.cuda.device(x.device):
+        with _on(x.device):
             _lib.check(L.slak_ln_nchw_to_nhwc_backward(g.data_ptr(), x.data_ptr(), weight.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
                                                        dx.data_ptr(), dw.data_ptr(), db.data_ptr(), N, C, H * W,
                                                        ws.data_ptr() if ws is not None else None, nb, _stream(x.device)), "slak_ln_nchw_to_nhwc_backward")
@@ -65,7 +65,7 @@ def _scale_residual_fwd(shortcut, z, gamma, sample_scale, emit_lowp):
     out = torch.empty((N, C, H, W), dtype=torch.float32, device=z.device)
     out16 = torch.empty((N, C, H, W), dtype=torch.bfloat16, device=z.device) if emit_lowp else None
     L = _lib.lib()
-    with torch.cuda.device(z.device):
+    with _on(z.device):
         _lib.check(L.slak_scale_residual_forward(shortcut.data_ptr(), sdt, z.data_ptr(), gamma.data_ptr(),
                                                  sample_scale.data_ptr() if sample_scale is not None else None,
                                                  out.data_ptr(), out16.data_ptr() if emit_lowp else None,
@@ -91,7 +91,7 @@ def _scale_residual_bwd(z, gamma, sample_scale, shortcut_dtype, dout, dout16):
     dzc = torch.empty_like(gamma)
     L = _lib.lib()
     ws, nb = _workspace(L.slak_block_tail_workspace_bytes(N, C, H * W), z.device)
-    with torch.cuda.device(z.device):
+    with _on(z.device):
         _lib.check(L.slak_scale_residual_backward(dout.data_ptr(), dout16.data_ptr() if dout16 is not None else None,
                                                   dsum.data_ptr() if dsum is not None else None, z.data_ptr(), gamma.data_ptr(),
                                                   sample_scale.data_ptr() if sample_scale is not None else None,
@@ -150,7 +150,7 @@ class _TriDwConv(torch.autograd.Function):
         if tri:
             yv, yh, ys = torch.empty_like(x), torch.empty_like(x), torch.empty_like(x)
             rows = int(L.slak_dwconv2d_tri_stats_rows(dt, N, C, H, W, K)) if (want_stats == 2 and bn_stats_in_conv) else 0
-            with torch.cuda.device(x.device):
+            with _on(x.device):
                 if rows > 0:                                     # the launch also leaves the branch BatchNorms' batch statistics
                     stats = torch.empty((rows, C, 6), dtype=torch.float32, device=x.device)
                     _lib.check(L.slak_dwconv2d_tri_forward_stats(x.data_ptr(), wv.data_ptr(), wh.data_ptr(), ws.data_ptr(), yv.data_ptr(),
@@ -195,7 +195,7 @@ class _TriDwConv(torch.autograd.Function):
             if ctx.tri_dgrad:
                 dx = torch.empty_like(x)
                 L = _lib.lib()
-                with torch.cuda.device(x.device):
+                with _on(x.device):
                     _lib.check(L.slak_dwconv2d_tri_backward_data(dyv.data_ptr(), dyh.data_ptr(), dys.data_ptr(), wv.data_ptr(),
                                                                  wh.data_ptr(), ws.data_ptr(), dx.data_ptr(), ops._DT[x.dtype],
                                                                  N, C, H, W, K, _stream(x.device)), "slak_dwconv2d_tri_backward_data")
@@ -215,7 +215,7 @@ class _TriDwConv(torch.autograd.Function):
             if nb:                                               # one launch for the three weight gradients (x fetched once)
                 dwv, dwh, dws = (torch.empty_like(w, dtype=torch.float32) for w in (wv, wh, ws))
                 wsb, nbb = _workspace(nb, x.device)
-                with torch.cuda.device(x.device):
+                with _on(x.device):
                     rc = L.slak_dwconv2d_tri_backward_filter(dyv.data_ptr(), dyh.data_ptr(), dys.data_ptr(), x.data_ptr(), dwv.data_ptr(),
                                                              dwh.data_ptr(), dws.data_ptr(), dt, N, C, H, W, K, wsb.data_ptr(), nbb, _stream(x.device))
                 if rc == _lib.ERR_UNSUPPORTED:
@@ -229,7 +229,7 @@ class _TriDwConv(torch.autograd.Function):
             if nb:                                               # K x 5 and 5 x 5 in one launch (x fetched and shifted once)
                 dwv, dws = (torch.empty_like(w, dtype=torch.float32) for w in (wv, ws))
                 wsb, nbb = _workspace(nb, x.device)
-                with torch.cuda.device(x.device):
+                with _on(x.device):
                     rc = L.slak_dwconv2d_pair_backward_filter(dyv.data_ptr(), dys.data_ptr(), x.data_ptr(), dwv.data_ptr(), dws.data_ptr(),
                                                               dt, N, C, H, W, K, wsb.data_ptr(), nbb, _stream(x.device))
                 if rc == _lib.ERR_UNSUPPORTED:
@@ -272,7 +272,7 @@ def tri_dwconv_sum(x, w_vertical, w_horizontal, w_small, bias=None):
                 and L.slak_dwconv2d_tri_supported_op(dt, N, C, H, W, K, 1) == 1):      # (it IS the data-gradient kernel: same policy as the training node)
             fl = [w.flip(2, 3).contiguous() for w in ws]
             y = torch.empty_like(x)
-            with torch.cuda.device(x.device):
+            with _on(x.device):
                 _lib.check(L.slak_dwconv2d_tri_backward_data(x.data_ptr(), x.data_ptr(), x.data_ptr(), fl[0].data_ptr(), fl[1].data_ptr(),
                                                              fl[2].data_ptr(), y.data_ptr(), dt, N, C, H, W, K, _stream(x.device)),
                            "slak_dwconv2d_tri_backward_data")
@@ -423,7 +423,7 @@ class _BranchBN3(torch.autograd.Function):
             coef = torch.empty(C * 4, dtype=torch.float32, device=dev)
             stats = torch.empty(C * 6, dtype=torch.float32, device=dev)
             out = torch.empty_like(y1)
-            with torch.cuda.device(dev):
+            with _on(dev):
                 _lib.check(L.slak_bn3_forward_local(y1.data_ptr(), y2.data_ptr(), y3.data_ptr(), _ptr3(gam), _ptr3(bet), _ptr3(rmean), _ptr3(rvar),
                                                     eps, float(momentum), 1 if bns[0].track_running_stats else 0, coef.data_ptr(), stats.data_ptr(),
                                                     out.data_ptr(), N, C, P, ws.data_ptr() if ws is not None else None, nb, _stream(dev),
@@ -439,7 +439,7 @@ class _BranchBN3(torch.autograd.Function):
         sums = torch.empty(C * 6 + 1, dtype=torch.float64, device=dev)      # sum y_b, sum y_b^2 per channel as doubles + the element count
         pre_args = ((_ptr3(list(pre)), (ctypes.c_int * 3)(*[int(t.shape[0]) for t in pre]), int(pre[0].stride(1))) if pre is not None
                     else (None, None, 0))                                 # the conv launches' rows feed the exchange buffer: no read pass
-        with torch.cuda.device(dev):
+        with _on(dev):
             _lib.check(L.slak_bn3_forward_sums(y1.data_ptr(), y2.data_ptr(), y3.data_ptr(), sums.data_ptr(), N, C, P,
                                                ws.data_ptr() if ws is not None else None, nb, _stream(dev), *pre_args), "slak_bn3_forward_sums")
         count = float(N * P)
@@ -451,7 +451,7 @@ class _BranchBN3(torch.autograd.Function):
         coef = torch.empty(C * 4, dtype=torch.float32, device=dev)
         stats = torch.empty(C * 6, dtype=torch.float32, device=dev)
         out = torch.empty_like(y1)
-        with torch.cuda.device(dev):
+        with _on(dev):
             _lib.check(L.slak_bn3_forward_apply(y1.data_ptr(), y2.data_ptr(), y3.data_ptr(), sums.data_ptr(), count,
                                                 count_dev.data_ptr() if count_dev is not None else None, _ptr3(gam), _ptr3(bet), _ptr3(rmean), _ptr3(rvar), eps, float(momentum), 1,
                                                 1 if bns[0].track_running_stats else 0,
@@ -479,13 +479,13 @@ class _BranchBN3(torch.autograd.Function):
             dgamma = torch.empty(3, C, dtype=torch.float32, device=dev)
             dbeta = torch.empty(3, C, dtype=torch.float32, device=dev)
             d1, d2, d3 = torch.empty_like(y1), torch.empty_like(y2), torch.empty_like(y3)
-            with torch.cuda.device(dev):
+            with _on(dev):
                 _lib.check(L.slak_bn3_backward_local(dout.data_ptr(), y1.data_ptr(), y2.data_ptr(), y3.data_ptr(), stats.data_ptr(), _ptr3([g1, g2, g3]),
                                                      bcoef.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), d1.data_ptr(), d2.data_ptr(), d3.data_ptr(),
                                                      N, C, P, ws.data_ptr() if ws is not None else None, nb, _stream(dev)), "slak_bn3_backward_local")
             return d1, d2, d3, dgamma[0], dbeta[0], dgamma[1], dbeta[1], dgamma[2], dbeta[2], None, None, None
         lsums = torch.empty(C * 4, dtype=torch.float32, device=dev)
-        with torch.cuda.device(dev):
+        with _on(dev):
             _lib.check(L.slak_bn3_backward_sums(dout.data_ptr(), y1.data_ptr(), y2.data_ptr(), y3.data_ptr(), stats.data_ptr(), lsums.data_ptr(), N, C, P,
                                                 ws.data_ptr() if ws is not None else None, nb, _stream(dev)), "slak_bn3_backward_sums")
         gsums = lsums
@@ -496,7 +496,7 @@ class _BranchBN3(torch.autograd.Function):
         dgamma = torch.empty(3, C, dtype=torch.float32, device=dev)
         dbeta = torch.empty(3, C, dtype=torch.float32, device=dev)
         d1, d2, d3 = torch.empty_like(y1), torch.empty_like(y2), torch.empty_like(y3)
-        with torch.cuda.device(dev):
+        with _on(dev):
             _lib.check(L.slak_bn3_backward_apply(dout.data_ptr(), y1.data_ptr(), y2.data_ptr(), y3.data_ptr(), gsums.data_ptr(),
                                                  lsums.data_ptr(), ctx.count, ctx.count_dev.data_ptr() if ctx.count_dev is not None else None,
                                                  stats.data_ptr(), _ptr3([g1, g2, g3]),
@@ -528,7 +528,7 @@ def branch_bn3(y1, y2, y3, bn1, bn2, bn3, stats=None):
     L = _lib.lib()
     coef = torch.empty(C * 4, dtype=torch.float32, device=y1.device)
     out = torch.empty_like(y1)
-    with torch.cuda.device(y1.device):
+    with _on(y1.device):
         _lib.check(L.slak_bn3_forward_apply(y1.data_ptr(), y2.data_ptr(), y3.data_ptr(), None, 0.0, None,
                                             _ptr3([b.weight for b in bns]), _ptr3([b.bias for b in bns]),
                                             _ptr3([b.running_mean for b in bns]), _ptr3([b.running_var for b in bns]),
@@ -553,7 +553,7 @@ class _LnChannelsFirst(torch.autograd.Function):
         mean = torch.empty((N, H * W), dtype=torch.float32, device=x.device)
         rstd = torch.empty_like(mean)
         L = _lib.lib()
-        with torch.cuda.device(x.device):
+        with _on(x.device):
             _lib.check(L.slak_ln_channels_first_forward(x.data_ptr(), _SDT[x.dtype], weight.data_ptr(), bias.data_ptr(), y.data_ptr(), _SDT[out_dtype],
                                                         mean.data_ptr(), rstd.data_ptr(), N, C, H * W, float(eps), _stream(x.device)),
                        "slak_ln_channels_first_forward")
@@ -571,7 +571,7 @@ class _LnChannelsFirst(torch.autograd.Function):
         dw = torch.empty_like(weight); db = torch.empty_like(weight)
         L = _lib.lib()
         ws, nb = _workspace(L.slak_ln_cf_workspace_bytes(N, C, H * W), x.device)
-        with torch.cuda.device(x.device):
+        with _on(x.device):
             _lib.check(L.slak_ln_channels_first_backward(g.data_ptr(), _SDT[g.dtype], x.data_ptr(), _SDT[x.dtype], weight.data_ptr(), mean.data_ptr(),
                                                          rstd.data_ptr(), dx.data_ptr(), dw.data_ptr(), db.data_ptr(), N, C, H * W,
                                                          ws.data_ptr() if ws is not None else None, nb, _stream(x.device)), "slak_ln_channels_first_backward")
@@ -604,7 +604,7 @@ class _DownsampleLnConv(torch.autograd.Function):
         mean = torch.empty((N, H * W), dtype=torch.float32, device=x.device)
         rstd = torch.empty_like(mean)
         L = _lib.lib()
-        with torch.cuda.device(x.device):
+        with _on(x.device):
             _lib.check(L.slak_ln_patch_forward(x.data_ptr(), ln_w.data_ptr(), ln_b.data_ptr(), a.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
                                                N, C, H, W, float(eps), _stream(x.device)), "slak_ln_patch_forward")
         wp = conv_w.detach().permute(0, 2, 3, 1).reshape(Co, 4 * C).to(torch.bfloat16)       # Wp[co][(kh*2+kw)*C + c]
@@ -639,7 +639,7 @@ class _DownsampleLnConv(torch.autograd.Function):
         L = _lib.lib()
         ws, nb = _workspace(L.slak_block_tail_workspace_bytes(N, C, H * W), x.device)
         da = da.contiguous()
-        with torch.cuda.device(x.device):
+        with _on(x.device):
             _lib.check(L.slak_ln_patch_backward(da.data_ptr(), x.data_ptr(), ln_w.data_ptr(), mean.data_ptr(), rstd.data_ptr(), dx.data_ptr(),
                                                 dlw.data_ptr(), dlb.data_ptr(), N, C, H, W, ws.data_ptr() if ws is not None else None, nb,
                                                 _stream(x.device)), "slak_ln_patch_backward")
@@ -657,7 +657,7 @@ class _StemConv(torch.autograd.Function):
         P16 = (H // 4) * (W // 4)
         a = torch.empty((N, P16, Ci * 16), dtype=torch.bfloat16, device=x.device)
         L = _lib.lib()
-        with torch.cuda.device(x.device):
+        with _on(x.device):
             _lib.check(L.slak_stem_patchify(x.data_ptr(), a.data_ptr(), N, Ci, H, W, _stream(x.device)), "slak_stem_patchify")
         wp = conv_w.detach().reshape(Co, Ci * 16).to(torch.bfloat16)
         if conv_b is not None:
@@ -754,7 +754,7 @@ def linear_wgrad(dy, x):
         return None
     d = torch.empty((N1, N2), dtype=torch.float32, device=dy.device)
     ws, nb = _workspace(L.slak_linear_wgrad_workspace_bytes(M, N1, N2), dy.device)
-    with torch.cuda.device(dy.device):
+    with _on(dy.device):
         _lib.check(L.slak_linear_wgrad(dy.data_ptr(), x.data_ptr(), d.data_ptr(), M, N1, N2, ws.data_ptr() if ws is not None else None, nb,
                                        _stream(dy.device)), "slak_linear_wgrad")
     return d
@@ -783,7 +783,7 @@ def linear_nt(x, wt, bias=None, gelu=False):
         return None
     y = torch.empty(x.shape[:-1] + (N,), dtype=torch.bfloat16, device=x.device)
     g = torch.empty_like(y) if gelu else None
-    with torch.cuda.device(x.device):
+    with _on(x.device):
         _lib.check(L.slak_linear_nt(x.data_ptr(), wt.data_ptr(), bias.data_ptr() if bias is not None else None, y.data_ptr(),
                                     g.data_ptr() if gelu else None, M, N, K, _stream(x.device)), "slak_linear_nt")
     return (y, g) if gelu else y
@@ -834,7 +834,7 @@ def _mlp_bwd(saved, dz, db2=None):
     db1 = torch.empty(dact.shape[1], dtype=torch.float32, device=dact.device)
     L = _lib.lib()
     ws, nb = _workspace(L.slak_gelu_bwd_workspace_bytes(M, dact.shape[1]), dact.device)
-    with torch.cuda.device(dact.device):
+    with _on(dact.device):
         _lib.check(L.slak_gelu_backward_bias(dact.data_ptr(), y12.data_ptr(), dy1.data_ptr(), db1.data_ptr(), M, dact.shape[1],
                                              ws.data_ptr() if ws is not None else None, nb, _stream(dact.device)), "slak_gelu_backward_bias")
     dw1 = wgrad(dy1, t2)

@@ -21,6 +21,7 @@ from copy import deepcopy
 import torch
 
 from . import _lib
+from .ops import _on, _stream
 
 _logger = logging.getLogger(__name__)
 _SLAK_I64 = 3
@@ -109,7 +110,7 @@ class ModelEma:
             segs[i].numel, segs[i].dtype = e.numel(), dt
         if live:
             h = ctypes.c_void_p()
-            with torch.cuda.device(live[0][1].device):
+            with _on(live[0][1].device):
                 _lib.check(_lib.lib().slak_ema_plan_create(segs, len(live), ctypes.byref(h)), "slak_ema_plan_create")
             self._plan = (h, live[0][1].device)
         self._plan_key = key
@@ -132,5 +133,5 @@ class ModelEma:
             if self._plan is None:
                 return
             h, dev = self._plan
-            with torch.cuda.device(dev):
-                _lib.check(_lib.lib().slak_ema_update(h, float(self.decay), torch.cuda.current_stream(dev).cuda_stream), "slak_ema_update")
+            with _on(dev):
+                _lib.check(_lib.lib().slak_ema_update(h, float(self.decay), _stream(dev)), "slak_ema_update")

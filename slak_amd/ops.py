@@ -42,7 +42,7 @@ def _workspace(nbytes, device):
     that touches it is enqueued on that same stream."""
     if nbytes == 0:
         return None, 0
-    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    key = (device.index, _stream(device))
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
@@ -50,8 +50,35 @@ def _workspace(nbytes, device):
     return buf, buf.numel()
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_cur_device = getattr(torch._C, "_cuda_getDevice", None)
+
+
 def _stream(device):
+    """The raw handle of torch's current stream on `device` (what every C-ABI entry point takes).  The two private torch._C calls
+    skip building a torch.cuda.Stream object per launch (~5 us each, ~100 launches per step); without them: the public API."""
+    if _raw_stream is not None and device.index is not None:
+        return _raw_stream(device.index)
     return torch.cuda.current_stream(device).cuda_stream
+
+
+class _NullCtx:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *exc):
+        return False
+
+
+_NULL = _NullCtx()
+
+
+def _on(device):
+    """`with _on(device):` == `with _on(device):`, without the device switch (and its two runtime calls) when `device`
+    is already current -- the one-process-per-GPU case."""
+    if _cur_device is not None and device.index is not None and _cur_device() == device.index:
+        return _NULL
+    return torch.cuda.device(device)
 
 
 def allow_fp32_matrix_cores(allow=True):
@@ -69,7 +96,7 @@ def dwconv2d_forward(x, w, out_dtype=None):
     y = torch.empty_like(x, dtype=out_dtype or x.dtype)
     L = _lib.lib()
     ws, nb = _workspace(L.slak_dwconv2d_workspace_bytes(_lib.OP_FWD, N, C, H, W, kh, kw, _dt(x, "input")), x.device)
-    with torch.cuda.device(x.device):
+    with _on(x.device):
         _lib.check(L.slak_dwconv2d_forward(x.data_ptr(), _dt(x, "input"), w.data_ptr(), _dt(w, "weight"), y.data_ptr(), _dt(y, "output"),
                                            N, C, H, W, kh, kw, ws.data_ptr() if ws is not None else None, nb, _stream(x.device)),
                    "slak_dwconv2d_forward")
@@ -87,7 +114,7 @@ def dwconv2d_forward_stats(x, w):
         y = torch.empty_like(x)
         stats = torch.empty((4 * N, C, 2), dtype=torch.float32, device=x.device)
         rows = ctypes.c_int(0)
-        with torch.cuda.device(x.device):
+        with _on(x.device):
             rc = L.slak_dwconv2d_forward_stats(x.data_ptr(), _dt(x, "input"), w.data_ptr(), _dt(w, "weight"), y.data_ptr(), _dt(y, "output"),
                                                stats.data_ptr(), 4 * N, ctypes.byref(rows), N, C, H, W, kh, kw, _stream(x.device))
         if rc == _lib.OK:
@@ -103,7 +130,7 @@ def dwconv2d_backward_data(dy, w, out_dtype=None):
     dx = torch.empty_like(dy, dtype=out_dtype or dy.dtype)
     L = _lib.lib()
     ws, nb = _workspace(L.slak_dwconv2d_workspace_bytes(_lib.OP_BWD_DATA, N, C, H, W, kh, kw, _dt(dy, "grad")), dy.device)
-    with torch.cuda.device(dy.device):
+    with _on(dy.device):
         _lib.check(L.slak_dwconv2d_backward_data(dy.data_ptr(), _dt(dy, "grad"), w.data_ptr(), _dt(w, "weight"), dx.data_ptr(), _dt(dx, "dx"),
                                                  N, C, H, W, kh, kw, ws.data_ptr() if ws is not None else None, nb, _stream(dy.device)),
                    "slak_dwconv2d_backward_data")
@@ -119,7 +146,7 @@ def dwconv2d_backward_data_accumulate(dy, w, dx):
         raise RuntimeError("dx and grad must have the same shape and dtype")
     L = _lib.lib()
     ws, nb = _workspace(L.slak_dwconv2d_workspace_bytes(_lib.OP_BWD_DATA, N, C, H, W, kh, kw, _dt(dy, "grad")), dy.device)
-    with torch.cuda.device(dy.device):
+    with _on(dy.device):
         rc = L.slak_dwconv2d_backward_data_accumulate(dy.data_ptr(), _dt(dy, "grad"), w.data_ptr(), _dt(w, "weight"), dx.data_ptr(), _dt(dx, "dx"),
                                                       N, C, H, W, kh, kw, ws.data_ptr() if ws is not None else None, nb, _stream(dy.device))
     if rc == _lib.ERR_UNSUPPORTED:
@@ -138,7 +165,7 @@ def dwconv2d_backward_filter(dy, x, w):
     dw = torch.empty((C, 1, kh, kw), dtype=torch.float32, device=x.device)
     L = _lib.lib()
     ws, nb = _workspace(L.slak_dwconv2d_workspace_bytes(_lib.OP_BWD_FILTER, N, C, H, W, kh, kw, _dt(x, "input")), x.device)
-    with torch.cuda.device(x.device):
+    with _on(x.device):
         _lib.check(L.slak_dwconv2d_backward_filter(dy.data_ptr(), _dt(dy, "grad"), x.data_ptr(), _dt(x, "input"), dw.data_ptr(),
                                                    N, C, H, W, kh, kw, ws.data_ptr() if ws is not None else None, nb, _stream(x.device)),
                    "slak_dwconv2d_backward_filter")

@@ -15,6 +15,7 @@ import torch
 from torch import optim
 
 from . import _lib
+from .ops import _on, _stream
 
 
 # ------------------------------------------------------------------------------------------------------------------ layer decay
@@ -187,7 +188,7 @@ class MaskedAdamW(optim.Optimizer):
                 if e is not None:
                     cached.append((p, e))
             h = ctypes.c_void_p()
-            with torch.cuda.device(params[0][1].device):
+            with _on(params[0][1].device):
                 _lib.check(L.slak_adamw_plan_create(segs, len(sel), ctypes.byref(h)), "slak_adamw_plan_create")
             plans.append((h, [p for _, _, p in sel], g0, min(G, len(self.param_groups) - g0), cached))
         self._plans, self._key = plans, key
@@ -240,8 +241,8 @@ class MaskedAdamW(optim.Optimizer):
         else:
             self._steps.add_(self._active)
         L = _lib.lib()
-        stream = torch.cuda.current_stream(dev).cuda_stream
-        with torch.cuda.device(dev):
+        stream = _stream(dev)
+        with _on(dev):
             for (h, ps, g0, ng, cached), tab in zip(self._plans, self._grad_tabs):
                 hyp = (_lib.AdamwGroup * ng)()
                 for k in range(ng):

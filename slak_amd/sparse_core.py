@@ -36,6 +36,7 @@ import torch.nn.functional as F
 import torch.optim as optim
 
 from . import _lib
+from .ops import _on, _stream
 
 __all__ = ["CosineDecay", "Masking", "SNIP"]
 
@@ -292,7 +293,7 @@ class Masking(object):
                 segs[i].momentum = None
                 segs[i].numel = t.numel()
             plan = ctypes.c_void_p()
-            with torch.cuda.device(self.device):
+            with _on(self.device):
                 _lib.check(L.slak_mask_plan_create(segs, len(params), ctypes.byref(plan)), "slak_mask_plan_create")
             self._plan, self._plan_key = plan, key
             self._plan_names = [n for n, _ in params]
@@ -300,7 +301,7 @@ class Masking(object):
         return params
 
     def _stream(self):
-        return torch.cuda.current_stream(self.device).cuda_stream
+        return _stream(self.device)
 
     def _bind_momentum(self, params):
         ptrs = []
@@ -350,7 +351,7 @@ class Masking(object):
         params = self._ensure_plan()
         if params is None:
             return
-        with torch.cuda.device(self.device):
+        with _on(self.device):
             self._bind_momentum(params)
             _lib.check(_lib.lib().slak_mask_apply(self._plan, self._stream()), "slak_mask_apply")
         self._bump_versions([t for _, t in params])
@@ -376,7 +377,7 @@ class Masking(object):
         (main.py:232 seeds with seed + rank), which is what the reference's per-step mask broadcast papers over: the masks are
         re-synchronised from rank 0 right after this growth."""
         L = _lib.lib()
-        with torch.cuda.device(self.device):
+        with _on(self.device):
             self._bind_momentum(params)
             _lib.check(L.slak_mask_prune(self._plan, float(self.prune_rate), self._stream()), "slak_mask_prune")
             stats = (ctypes.c_double * (4 * len(params)))()
@@ -413,7 +414,7 @@ class Masking(object):
             if g.dtype != torch.float32 or not g.is_contiguous():
                 raise _lib.SlakHipError("gradient of %s must be contiguous float32" % name)
             grads.append(g)
-        with torch.cuda.device(self.device):
+        with _on(self.device):
             self._bind_momentum(params)
             arr = (ctypes.c_void_p * len(grads))(*[g.data_ptr() for g in grads])
             _lib.check(L.slak_mask_plan_set_grads(self._plan, arr, self._stream()), "slak_mask_plan_set_grads")
@@ -561,7 +562,7 @@ class Masking(object):
         """64-bit order-independent checksum of all masks (device kernel); equal on every rank iff masks agree."""
         self._ensure_plan()
         out = ctypes.c_ulonglong(0)
-        with torch.cuda.device(self.device):
+        with _on(self.device):
             _lib.check(_lib.lib().slak_mask_checksum(self._plan, ctypes.byref(out), self._stream()), "slak_mask_checksum")
         return out.value
 
