@@ -321,7 +321,8 @@ def mask_step_bench(device, model_name, ks, only_L, reps=20, cpu_seconds=6.0):
     w r/w 8 + grad r 4 + mask r/w 8) over the mask set of the bench model -- every 2-D / 4-D parameter (95 tensors / 30.7 M elements
     for SLaK-T; --only-L: the 36 LoRA tensors) -- through the C ABI, HIP events on the launch stream.  `passes` = how many times the
     implementation streams the tensors (mask_kernels.hip: histogram + compaction + membership per k-th-element search, the prune
-    membership pass also being the regrow histogram pass and the regrow membership pass also being the apply: 5 passes, 56 B/elem).  CPU side: the numpy port of sparse_core.Masking.truncate_weights / funcs.magnitude_prune /
+    membership pass also being the regrow histogram pass and the regrow membership pass also being the apply, the pruned mask travelling
+    between them as a byte per four elements: 5 passes, 41 B/elem).  CPU side: the numpy port of sparse_core.Masking.truncate_weights / funcs.magnitude_prune /
     gradient_growth (oracle/mask_oracle.py; the reference itself is not on this box) on a bounded prefix of the same tensors."""
     import ctypes
     from slak_amd import _lib
@@ -364,7 +365,7 @@ def mask_step_bench(device, model_name, ks, only_L, reps=20, cpu_seconds=6.0):
     out = {"tensors": len(shapes), "elements": elems, "only_L": bool(only_L),
            "apply_ms": t_apply, "apply_alg_bytes": 12 * elems, "apply_gbs": 12 * elems / t_apply / 1e6, "apply_frac_of_hbm_peak": 12 * elems / t_apply / 1e6 / HBM_PEAK_GBS,
            "update_ms": t_update, "update_alg_bytes": 20 * elems, "update_gbs": 20 * elems / t_update / 1e6, "update_frac_of_hbm_peak": 20 * elems / t_update / 1e6 / HBM_PEAK_GBS,
-           "update_passes_over_keys": 5, "update_launches": 12, "update_bytes_moved_per_elem": 56, "density_after": density,
+           "update_passes_over_keys": 5, "update_launches": 13, "update_bytes_moved_per_elem": 41, "density_after": density,
            "note": "apply is folded into MaskedAdamW's update on ordinary steps (0 extra bytes); prune-and-grow runs every update_frequency steps"}
     # CPU port on a bounded prefix of the same mask set
     import oracle

@@ -11,8 +11,8 @@
 //   regrow : key = |grad * (mask == 0)|; mask[ floor(removed) largest key ] = 1   funcs.py:196-205
 //   then apply again                                                      sparse_core.py:357
 //
-// One truncate_weights() is FIVE passes over the tensors (round 2: 14 passes, 25 launches), 1 memset + 11 launches of which 4 are
-// one-block-per-tensor bookkeeping:
+// One truncate_weights() is FIVE passes over the tensors (round 2: 14 passes, 25 launches), 1 memset + 12 launches of which 5 are
+// bookkeeping on a block per tensor / on the candidate lists:
 //
 //   P1  read w, mask        histogram of the top 11 bits of |w| (LDS, one global histogram per tensor) + sum(mask)
 //   pick                    per tensor: k in fp64 exactly as CPython evaluates it, and the bin d1 that holds the k-th key
@@ -22,18 +22,21 @@
 //                           only some of the keys EQUAL to the k-th one are taken, the index of the last one taken
 //                           (ties go lowest flat index first -- the behaviour of torch.sort(stable=True); the
 //                           reference's plain torch.sort is arbitrary on ties)
-//   P3  read w, g; r/w mask membership is  key < thr || (key == thr && index <= idx_thr); the new mask is written and, in the
-//                           same pass, the regrow key |g * (new mask == 0)| is histogrammed (its select is "k largest",
-//                           done as "k smallest" of 0x7fffffff - key)
+//   P3  read w, mask, g     membership is  key < thr || (key == thr && index <= idx_thr); the pruned mask leaves as ONE BYTE PER FOUR
+//                           ELEMENTS (`act`) and, in the same pass, the regrow key |g * (new mask == 0)| is histogrammed (its select
+//                           is "k largest", done as "k smallest" of 0x7fffffff - key)
 //   pick                    per tensor: removed, the regrow k and its bin
-//   P4  read g, mask        regrow candidates compacted
+//   P4  read g, act         regrow candidates compacted; elements below the cut bin are marked in `grown` (same byte layout)
 //   R   (candidates only)
-//   P5  read g; r/w mask, w regrow membership, final mask, w *= mask (+ momentum): the apply of sparse_core.py:357
+//   mark (candidates only)  the listed candidates that made the cut are or-ed into `grown`
+//   P5  read act, grown, w  final mask = act | grown written as exact 0.0 / 1.0, w *= mask (+ momentum): the apply of sparse_core.py:357
+//       write mask, w       (g is read again only for a tensor whose cut fell among the zero keys: those are taken by index)
 //   finish                  nonzeros after
 //
-// = 56 B/element against SURVEY 8d's fused ideal of 20 (a k-th element cannot be known before every key was seen once,
-// so prune needs >= 2 reads of w and regrow >= 2 of g: 36 B is the floor of this family).  The prune rate arrives as the
-// host scheduler's fp64 value; masks never leave the device.
+// = 41 B/element against SURVEY 8d's fused ideal of 20 (a k-th element cannot be known before every key was seen once,
+// so prune needs >= 2 reads of w and regrow >= 2 of g: 36 B is the floor of this family).  Masks are 0/1 tensors
+// (sparse_core.py only ever writes 0.0 and 1.0 into them); prune-and-grow writes exactly those two values.  The prune rate arrives
+// as the host scheduler's fp64 value; masks never leave the device.
 #include <cstdint>
 #include <cstring>
 #include <vector>
@@ -100,6 +103,10 @@ struct slak_mask_plan {
     slak::SegState* state = nullptr;
     unsigned* blk_special = nullptr;      // device [nsblk]: keys == special key per 16384-element block (written when the cut bin holds it)
     uint2* cand = nullptr;                // device [total] (key, flat index); allocated by the first prune
+    unsigned char* act = nullptr;         // device: one byte per four elements, bit e = (mask after the prune != 0); prune-and-grow only
+    unsigned char* grown = nullptr;       // device: same layout, bit e = element is regrown
+    long long* seg_nib = nullptr;         // device [nseg]: first byte of each tensor in act / grown (multiple of 4)
+    size_t nib_bytes = 0;
     double* stats = nullptr;              // device [nseg][4]
     unsigned long long* checksum = nullptr;
 };
@@ -296,7 +303,9 @@ template <int PHASE>
 __global__ __launch_bounds__(MK_THREADS) void mask_compact_kernel(const slak_mask_segment_t* __restrict__ segs,
                                                                   const int* __restrict__ sblk_seg, const int* __restrict__ seg_sblk0,
                                                                   SegState* __restrict__ state, const long long* __restrict__ seg_off,
-                                                                  uint2* __restrict__ cand, unsigned* __restrict__ sblk_special) {
+                                                                  uint2* __restrict__ cand, unsigned* __restrict__ sblk_special,
+                                                                  const unsigned char* __restrict__ act, unsigned char* __restrict__ grown,
+                                                                  const long long* __restrict__ seg_nib) {
     // Candidates are staged in LDS (wave-aggregated appends) and leave with ONE global atomic per block and coalesced stores; a
     // wave whose candidates no longer fit appends straight to the global list (only tie-heavy data gets there).
     __shared__ uint2 stage[CP_STAGE];
@@ -315,25 +324,31 @@ __global__ __launch_bounds__(MK_THREADS) void mask_compact_kernel(const slak_mas
     if (threadIdx.x == 0) { lcount = 0; lfail = 0xffffffffu; }
     __syncthreads();
     unsigned nsp = 0;
+    const long long nib0 = (PHASE == PH_GROW) ? seg_nib[s] : 0;
+    // (issuing the block's 16 loads per thread before the first use -- fully unrolled -- measured 3.5x SLOWER: 161 vs 46 us)
 #pragma unroll 2
     for (int it = 0; it < SB_ITERS; ++it) {
         const long long i = base + ((long long)it * MK_THREADS + threadIdx.x) * 4;
-        float4 a = make_float4(0.f, 0.f, 0.f, 0.f), m = a;
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+        unsigned abits = 0;
         if (i < sg.numel) {
             if (PHASE == PH_PRUNE) a = load4(sg.weight, i, sg.numel);
-            else { a = load4(sg.grad, i, sg.numel); m = load4(sg.mask, i, sg.numel); }
+            else { a = load4(sg.grad, i, sg.numel); abits = act[nib0 + (i >> 2)]; }
         }
-        const float av[4] = {a.x, a.y, a.z, a.w}, mv[4] = {m.x, m.y, m.z, m.w};
-        unsigned key[4]; bool f[4]; unsigned long long bal[4]; unsigned n = 0;
+        const float av[4] = {a.x, a.y, a.z, a.w};
+        unsigned key[4]; bool f[4]; unsigned long long bal[4]; unsigned n = 0, sure = 0;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            key[e] = (PHASE == PH_PRUNE) ? key_w(av[e]) : key_g(av[e], mv[e]);
-            const bool in_bin = i + e < sg.numel && (key[e] >> D1_SHIFT) == d1;
+            key[e] = (PHASE == PH_PRUNE) ? key_w(av[e]) : key_g(av[e], (abits >> e) & 1u ? 1.0f : 0.0f);
+            const bool in = i + e < sg.numel;
+            const bool in_bin = in && (key[e] >> D1_SHIFT) == d1;
+            if (in && (key[e] >> D1_SHIFT) < d1) sure |= 1u << e;       // below the cut bin: taken whatever the refine finds
             f[e] = in_bin && key[e] != SPECIAL;
             nsp += (in_bin && key[e] == SPECIAL) ? 1u : 0u;
             bal[e] = __ballot(f[e]);
             n += (unsigned)__popcll(bal[e]);
         }
+        if (PHASE == PH_GROW && i < sg.numel) grown[nib0 + (i >> 2)] = (unsigned char)sure;
         if (n == 0) continue;                                           // wave-uniform
         unsigned pos = 0;
         if (lane == 0) pos = atomicAdd(&lcount, n);
@@ -367,7 +382,8 @@ __global__ __launch_bounds__(MK_THREADS) void mask_compact_kernel(const slak_mas
 template <int PHASE>
 __global__ __launch_bounds__(RF_THREADS) void mask_refine_kernel(const slak_mask_segment_t* __restrict__ segs, SegState* __restrict__ state,
                                                                  const long long* __restrict__ seg_off, const uint2* __restrict__ cand,
-                                                                 const int* __restrict__ seg_sblk0, const unsigned* __restrict__ sblk_special) {
+                                                                 const int* __restrict__ seg_sblk0, const unsigned* __restrict__ sblk_special,
+                                                                 const unsigned char* __restrict__ act, const long long* __restrict__ seg_nib) {
     __shared__ unsigned lh[2048];
     __shared__ unsigned sh[RF_THREADS / 64];
     __shared__ unsigned res[4];
@@ -439,7 +455,10 @@ __global__ __launch_bounds__(RF_THREADS) void mask_refine_kernel(const slak_mask
             for (int e = 0; e < 2; ++e) {
                 const long long i = i0 + e;
                 unsigned key = ~SPECIAL;
-                if (i < sg.numel) key = (PHASE == PH_PRUNE) ? key_w(sg.weight[i]) : key_g(sg.grad[i], sg.mask[i]);
+                if (i < sg.numel) {                                     // regrow: the pruned mask lives in the byte-per-four-elements copy (P3)
+                    if (PHASE == PH_PRUNE) key = key_w(sg.weight[i]);
+                    else key = key_g(sg.grad[i], (act[seg_nib[s] + (i >> 2)] >> (i & 3)) & 1u ? 1.0f : 0.0f);
+                }
                 f[e] = key == SPECIAL;
             }
             unsigned total;
@@ -491,7 +510,8 @@ __global__ __launch_bounds__(RF_THREADS) void mask_refine_kernel(const slak_mask
 template <bool GROW>
 __global__ __launch_bounds__(MK_THREADS) void mask_prune_final_kernel(const slak_mask_segment_t* __restrict__ segs,
                                                                       const int* __restrict__ sblk_seg, const int* __restrict__ seg_sblk0,
-                                                                      SegState* __restrict__ state, unsigned* __restrict__ hist, int nseg) {
+                                                                      SegState* __restrict__ state, unsigned* __restrict__ hist, int nseg,
+                                                                      unsigned char* __restrict__ act, const long long* __restrict__ seg_nib) {
     __shared__ unsigned lh[GROW ? D1_BINS : 1];
     __shared__ unsigned sh[MK_THREADS / 64];
     const int s = sblk_seg[blockIdx.x];
@@ -533,7 +553,10 @@ __global__ __launch_bounds__(MK_THREADS) void mask_prune_final_kernel(const slak
                 }
             }
         }
-        if (mode != MODE_NONE) store4(sg.mask, i, sg.numel, make_float4(nm[0], nm[1], nm[2], nm[3]));
+        if (GROW) {
+            // prune-and-grow: the pruned mask travels to P4 / P5 as one byte per four elements; the fp32 mask is written once, by P5
+            act[seg_nib[s] + (i >> 2)] = (unsigned char)((nm[0] != 0.0f ? 1u : 0u) | (nm[1] != 0.0f ? 2u : 0u) | (nm[2] != 0.0f ? 4u : 0u) | (nm[3] != 0.0f ? 8u : 0u));
+        } else if (mode != MODE_NONE) store4(sg.mask, i, sg.numel, make_float4(nm[0], nm[1], nm[2], nm[3]));
     }
     const unsigned ct = block_sum<MK_THREADS>(changed, sh);
     if (threadIdx.x == 0 && ct) atomicAdd(&sp.cnt_changed, (unsigned long long)(long long)(int)ct);
@@ -571,36 +594,70 @@ __global__ void mask_finish_kernel(const SegState* __restrict__ state, double* _
     stats[4 * s + 3] = stats[4 * s + 0] - (double)(long long)state[s].removed + (double)state[s].sel[PH_GROW].cnt_changed;
 }
 
-// P5: regrow membership -> final mask; w *= mask (+ momentum)
+// after the regrow refine: the listed candidates that made the cut
+__global__ __launch_bounds__(MK_THREADS) void mask_mark_kernel(const int* __restrict__ blk_seg, const int* __restrict__ seg_blk0,
+                                                               const SegState* __restrict__ state, const long long* __restrict__ seg_off,
+                                                               const uint2* __restrict__ cand, unsigned* __restrict__ grown32,
+                                                               const long long* __restrict__ seg_nib) {
+    // 2048 list entries per block (the list is never longer than the tensor); 16 K-entry blocks measured 34 us against 17: a tensor's
+    // list sits in few blocks and the kernel is latency-bound
+    const int s = blk_seg[blockIdx.x];
+    const SelState& sel = state[s].sel[PH_GROW];
+    if (sel.mode != MODE_SELECT) return;
+    const unsigned c = sel.cand, thr = sel.thr, idx_thr = sel.idx_thr;
+    const unsigned j0 = (unsigned)(blockIdx.x - seg_blk0[s]) * MK_BLOCK_ELEMS;
+    if (j0 >= c) return;
+    const uint2* list = cand + seg_off[s];
+    const long long nib0 = seg_nib[s];
+#pragma unroll
+    for (int q = 0; q < MK_PER_THREAD; ++q) {
+        const unsigned j = j0 + q * MK_THREADS + threadIdx.x;
+        if (j < c) {
+            const uint2 kv = list[j];
+            if (kv.x < thr || (kv.x == thr && kv.y <= idx_thr)) {
+                const long long nib = nib0 + (kv.y >> 2);
+                atomicOr(&grown32[nib >> 2], 1u << ((unsigned)(nib & 3) * 8u + (kv.y & 3u)));
+            }
+        }
+    }
+}
+
+// P5: final mask = pruned mask | regrown, written as exact 0.0 / 1.0; w *= mask (+ momentum): the apply of sparse_core.py:357.
+// The gradient is only read where the cut fell among the keys that are exactly 0 (counted, not listed): those are taken by index.
 __global__ __launch_bounds__(MK_THREADS) void mask_grow_final_kernel(const slak_mask_segment_t* __restrict__ segs,
                                                                      const int* __restrict__ blk_seg, const int* __restrict__ seg_blk0,
-                                                                     SegState* __restrict__ state) {
+                                                                     SegState* __restrict__ state, const unsigned char* __restrict__ act,
+                                                                     const unsigned char* __restrict__ grown, const long long* __restrict__ seg_nib) {
     __shared__ unsigned sh[MK_THREADS / 64];
     const int s = blk_seg[blockIdx.x];
     const slak_mask_segment_t sg = segs[s];
     SelState& sel = state[s].sel[PH_GROW];
     const int mode = sel.mode;
-    const unsigned thr = sel.thr, idx_thr = sel.idx_thr;
+    const unsigned idx_thr = sel.idx_thr;
+    const bool ties_at_zero = mode == MODE_SELECT && sel.thr == KEY_MAX;
     const long long base = (long long)(blockIdx.x - seg_blk0[s]) * MK_BLOCK_ELEMS;
+    const long long nib0 = seg_nib[s];
     unsigned changed = 0;
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         const long long i = base + ((long long)h * MK_THREADS + threadIdx.x) * 4;
         if (i >= sg.numel) break;
-        const float4 m = load4(sg.mask, i, sg.numel), w = load4(sg.weight, i, sg.numel);
-        float4 g = make_float4(0.f, 0.f, 0.f, 0.f), mo = g;
-        if (mode == MODE_SELECT) g = load4(sg.grad, i, sg.numel);
+        const unsigned a = act[nib0 + (i >> 2)];
+        unsigned gr = (mode == MODE_SELECT) ? grown[nib0 + (i >> 2)] : 0u;
+        const float4 w = load4(sg.weight, i, sg.numel);
+        float4 mo = make_float4(0.f, 0.f, 0.f, 0.f);
         if (sg.momentum) mo = load4(sg.momentum, i, sg.numel);
-        float mv[4] = {m.x, m.y, m.z, m.w};
-        const float gv[4] = {g.x, g.y, g.z, g.w};
-        if (mode == MODE_SELECT) {
+        if (ties_at_zero) {
+            const float4 g = load4(sg.grad, i, sg.numel);
+            const float gv[4] = {g.x, g.y, g.z, g.w};
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const unsigned key = key_g(gv[e], mv[e]);
-                if (i + e < sg.numel && (key < thr || (key == thr && (unsigned)(i + e) <= idx_thr))) { if (mv[e] == 0.0f) ++changed; mv[e] = 1.0f; }
-            }
-            store4(sg.mask, i, sg.numel, make_float4(mv[0], mv[1], mv[2], mv[3]));
+            for (int e = 0; e < 4; ++e)
+                if (i + e < sg.numel && key_g(gv[e], (a >> e) & 1u ? 1.0f : 0.0f) == KEY_MAX && (unsigned)(i + e) <= idx_thr) gr |= 1u << e;
         }
+        changed += (unsigned)__popc(gr & ~a & 15u);
+        const unsigned on = (a | gr) & 15u;
+        const float mv[4] = {on & 1u ? 1.0f : 0.0f, on & 2u ? 1.0f : 0.0f, on & 4u ? 1.0f : 0.0f, on & 8u ? 1.0f : 0.0f};
+        store4(sg.mask, i, sg.numel, make_float4(mv[0], mv[1], mv[2], mv[3]));
         store4(sg.weight, i, sg.numel, make_float4(w.x * mv[0], w.y * mv[1], w.z * mv[2], w.w * mv[3]));
         if (sg.momentum) store4(sg.momentum, i, sg.numel, make_float4(mo.x * mv[0], mo.y * mv[1], mo.z * mv[2], mo.w * mv[3]));
     }
@@ -636,15 +693,16 @@ __global__ __launch_bounds__(MK_THREADS) void mask_checksum_kernel(const slak_ma
 template <bool GROW>
 static int run_prune(slak_mask_plan* p, double prune_rate, hipStream_t st) {
     if (!p->cand) HIPCHK(hipMalloc((void**)&p->cand, sizeof(uint2) * (size_t)p->total));
+    if (GROW && !p->act) { HIPCHK(hipMalloc((void**)&p->act, p->nib_bytes)); HIPCHK(hipMalloc((void**)&p->grown, p->nib_bytes)); }
     HIPCHK(hipMemsetAsync(p->zeroed, 0, p->zeroed_bytes, st));
     hipLaunchKernelGGL(mask_prune_hist_kernel, dim3(p->nsblk), dim3(MK_THREADS), 0, st, p->segs, p->sblk_seg, p->seg_sblk0, p->state, p->hist);
     hipLaunchKernelGGL(mask_pick_prune_kernel, dim3(p->nseg), dim3(MK_THREADS), 0, st, p->segs, p->state, p->hist, p->stats, prune_rate);
     hipLaunchKernelGGL(mask_compact_kernel<PH_PRUNE>, dim3(p->nsblk), dim3(MK_THREADS), 0, st, p->segs, p->sblk_seg, p->seg_sblk0, p->state,
-                       p->seg_off, p->cand, p->blk_special);
+                       p->seg_off, p->cand, p->blk_special, (const unsigned char*)nullptr, (unsigned char*)nullptr, (const long long*)nullptr);
     hipLaunchKernelGGL(mask_refine_kernel<PH_PRUNE>, dim3(p->nseg), dim3(RF_THREADS), 0, st, p->segs, p->state, p->seg_off, p->cand, p->seg_sblk0,
-                       p->blk_special);
+                       p->blk_special, (const unsigned char*)nullptr, (const long long*)nullptr);
     hipLaunchKernelGGL(mask_prune_final_kernel<GROW>, dim3(p->nsblk), dim3(MK_THREADS), 0, st, p->segs, p->sblk_seg, p->seg_sblk0, p->state,
-                       p->hist, p->nseg);
+                       p->hist, p->nseg, p->act, p->seg_nib);
     hipLaunchKernelGGL(mask_pick_grow_kernel, dim3(p->nseg), dim3(MK_THREADS), 0, st, p->state, p->hist, p->stats, p->nseg, GROW ? 1 : 0);
     SLAK_LAUNCH_CHECK();
     return SLAK_OK;
@@ -662,7 +720,8 @@ int slak_mask_plan_create(const slak_mask_segment_t* segs_host, int nseg, slak_m
     p->nseg = nseg;
     p->segs_host.assign(segs_host, segs_host + nseg);
     std::vector<int> blk_seg, sblk_seg, seg_sblk0(nseg + 1);
-    std::vector<long long> seg_off(nseg);
+    std::vector<long long> seg_off(nseg), seg_nib(nseg);
+    long long nib = 0;
     p->seg_first_blk.resize(nseg + 1);
     for (int s = 0; s < nseg; ++s) {
         if (!segs_host[s].weight || !segs_host[s].mask || segs_host[s].numel <= 0 || segs_host[s].numel >= (1ll << 31)) {
@@ -671,6 +730,7 @@ int slak_mask_plan_create(const slak_mask_segment_t* segs_host, int nseg, slak_m
         p->seg_first_blk[s] = (int)blk_seg.size();
         seg_sblk0[s] = (int)sblk_seg.size();
         seg_off[s] = p->total;
+        seg_nib[s] = nib; nib += ((segs_host[s].numel + 3) / 4 + 3) / 4 * 4;   // a byte per four elements, tensors start at a dword
         const long long nb = (segs_host[s].numel + MK_BLOCK_ELEMS - 1) / MK_BLOCK_ELEMS;
         for (long long b = 0; b < nb; ++b) blk_seg.push_back(s);
         const long long nsb = (segs_host[s].numel + SB_ELEMS - 1) / SB_ELEMS;
@@ -690,6 +750,7 @@ int slak_mask_plan_create(const slak_mask_segment_t* segs_host, int nseg, slak_m
     ALLOC(p->sblk_seg, sizeof(int) * p->nsblk);
     ALLOC(p->seg_sblk0, sizeof(int) * (nseg + 1));
     ALLOC(p->seg_off, sizeof(long long) * nseg);
+    ALLOC(p->seg_nib, sizeof(long long) * nseg);
     ALLOC(p->blk_special, sizeof(unsigned) * p->nsblk);
     ALLOC(p->zeroed, p->zeroed_bytes);
     ALLOC(p->stats, sizeof(double) * 4 * nseg);
@@ -705,6 +766,8 @@ int slak_mask_plan_create(const slak_mask_segment_t* segs_host, int nseg, slak_m
     HIPCHK(hipMemcpy(p->sblk_seg, sblk_seg.data(), sizeof(int) * p->nsblk, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(p->seg_sblk0, seg_sblk0.data(), sizeof(int) * (nseg + 1), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(p->seg_off, seg_off.data(), sizeof(long long) * nseg, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(p->seg_nib, seg_nib.data(), sizeof(long long) * nseg, hipMemcpyHostToDevice));
+    p->nib_bytes = (size_t)nib + 16;
     HIPCHK(hipMemset(p->stats, 0, sizeof(double) * 4 * nseg));
     HIPCHK(hipMemset(p->zeroed, 0, p->zeroed_bytes));
     *plan_out = p;
@@ -737,7 +800,7 @@ int slak_mask_plan_set_momentum(slak_mask_plan_t* p, void* const* momentum_host,
 
 int slak_mask_plan_destroy(slak_mask_plan_t* p) {
     if (!p) return SLAK_ERR_INVALID_ARG;
-    void* dev[] = {p->segs, p->blk_seg, p->seg_blk0, p->sblk_seg, p->seg_sblk0, p->seg_off, p->blk_special, p->zeroed, p->cand,
+    void* dev[] = {p->segs, p->blk_seg, p->seg_blk0, p->sblk_seg, p->seg_sblk0, p->seg_off, p->seg_nib, p->act, p->grown, p->blk_special, p->zeroed, p->cand,
                    p->stats, p->checksum};
     for (void* d : dev) if (d) (void)hipFree(d);
     if (p->segs_pinned) (void)hipHostFree(p->segs_pinned);
@@ -760,10 +823,13 @@ int slak_mask_prune_and_grow(slak_mask_plan_t* p, double prune_rate, void* strea
     int rc = run_prune<true>(p, prune_rate, st);           // prune loop, sparse_core.py:337-347 (+ first regrow pass)
     if (rc != SLAK_OK) return rc;
     hipLaunchKernelGGL(mask_compact_kernel<PH_GROW>, dim3(p->nsblk), dim3(MK_THREADS), 0, st, p->segs, p->sblk_seg, p->seg_sblk0, p->state,
-                       p->seg_off, p->cand, p->blk_special);   // growth loop, sparse_core.py:349-355
+                       p->seg_off, p->cand, p->blk_special, p->act, p->grown, p->seg_nib);   // growth loop, sparse_core.py:349-355
     hipLaunchKernelGGL(mask_refine_kernel<PH_GROW>, dim3(p->nseg), dim3(RF_THREADS), 0, st, p->segs, p->state, p->seg_off, p->cand, p->seg_sblk0,
-                       p->blk_special);
-    hipLaunchKernelGGL(mask_grow_final_kernel, dim3(p->nblk), dim3(MK_THREADS), 0, st, p->segs, p->blk_seg, p->seg_blk0, p->state);  // ... and the apply of sparse_core.py:357
+                       p->blk_special, p->act, p->seg_nib);
+    hipLaunchKernelGGL(mask_mark_kernel, dim3(p->nblk), dim3(MK_THREADS), 0, st, p->blk_seg, p->seg_blk0, p->state, p->seg_off, p->cand,
+                       (unsigned*)p->grown, p->seg_nib);
+    hipLaunchKernelGGL(mask_grow_final_kernel, dim3(p->nblk), dim3(MK_THREADS), 0, st, p->segs, p->blk_seg, p->seg_blk0, p->state, p->act, p->grown,
+                       p->seg_nib);                         // ... and the apply of sparse_core.py:357
     hipLaunchKernelGGL(mask_finish_kernel, dim3(ceil_div(p->nseg, 64)), dim3(64), 0, st, p->state, p->stats, p->nseg);
     SLAK_LAUNCH_CHECK();
     return SLAK_OK;
