@@ -86,9 +86,9 @@ def test_fp32_stays_exact_unless_allowed(gpu):
 
 
 def test_fp32_split_at_the_stage_1_shape_is_faster_than_the_exact_kernels(gpu, split_on):
-    """Not a benchmark -- a guard that the switch does what it is for: the 51 x 5 stage-1 forward (N = 32)."""
+    """Not a benchmark -- a guard that the switch does what it is for: the 5 x 51 stage-1 forward (N = 64; measured 2.4x apart at N = 128)."""
     from slak_amd import ops
-    x = torch.randn(32, 96, 56, 56, device=gpu); w = torch.randn(96, 1, 51, 5, device=gpu) * 0.02
+    x = torch.randn(64, 96, 56, 56, device=gpu); w = torch.randn(96, 1, 5, 51, device=gpu) * 0.02
 
     def timed():
         for _ in range(3):
@@ -103,5 +103,5 @@ def test_fp32_split_at_the_stage_1_shape_is_faster_than_the_exact_kernels(gpu, s
     ops.allow_fp32_matrix_cores(False)
     t_exact = timed()
     ops.allow_fp32_matrix_cores(True)
-    print("51x5 fwd fp32, N=32: split %.3f ms, exact %.3f ms" % (t_split, t_exact))
+    print("5x51 fwd fp32, N=64: split %.3f ms, exact %.3f ms" % (t_split, t_exact))
     assert t_split < t_exact
