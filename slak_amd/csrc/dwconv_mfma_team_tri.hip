@@ -29,8 +29,10 @@ namespace slak {
 
 // CLS 2: planes of 2 x 2 tiles (32 < H, W <= 64), KS = 4 k-steps, one plane per group.  CLS 1: planes of one tile (16 < H, W <= 32),
 // KS = 2, four planes per group.  R16: image rows are 16-byte aligned (W % 8 == 0).
-template <typename T, int CLS, bool DGRAD, bool R16>
-__global__ __launch_bounds__(2 * TT_THREADS, 1) void dwconv_mfma_team_tri_kernel(const TeamParams p) {
+// SOLO: the workgroup IS one team (four waves, two workgroups per CU): it runs its own compute and I/O phases one after the other, and the
+// two workgroups of a CU drift against each other freely instead of alternating at workgroup barriers.
+template <typename T, int CLS, bool DGRAD, bool R16, bool SOLO>
+__global__ __launch_bounds__(SOLO ? TT_THREADS : 2 * TT_THREADS, SOLO ? 2 : 1) void dwconv_mfma_team_tri_kernel(const TeamParams p) {
     constexpr int KS = CLS == 2 ? 4 : 2;
     constexpr int NKS = CLS == 2 ? 3 : 2;                            // k-steps of a 5 x 5 tile (band)
     constexpr int NT = DGRAD ? 3 : 1;                                // input tensors
@@ -39,7 +41,7 @@ __global__ __launch_bounds__(2 * TT_THREADS, 1) void dwconv_mfma_team_tri_kernel
                                                                      // CLS 1: all three branches do)
     constexpr int NPW = DGRAD ? TT_NPW : 2;                          // LDS-DMA pieces per wave and group (upper bound)
     extern __shared__ __attribute__((aligned(16))) uint16_t lds[];
-    const int team = wave_id_uniform() >> 2;                         // 0 / 1: the two teams of the workgroup
+    const int team = SOLO ? 0 : (wave_id_uniform() >> 2);            // 0 / 1: the two teams of the workgroup
     char* const L = (char*)lds + (size_t)team * p.team_lds;          // everything below is a BYTE offset into the TEAM's LDS block
     const int HW = p.H * p.W;
     const unsigned tslot_b = (unsigned)p.tslot_elems * 2;            // one tensor's part of a slot
@@ -58,7 +60,7 @@ __global__ __launch_bounds__(2 * TT_THREADS, 1) void dwconv_mfma_team_tri_kernel
 
     const int tid = threadIdx.x & (TT_THREADS - 1), lane = tid & 63, l31 = lane & 31, lhi = lane >> 5;   // thread / wave index WITHIN the team
     const int wave = wave_id_uniform() & 3;
-    const int vb = blockIdx.x * 2 + team;                            // the team's (channel, slice)
+    const int vb = SOLO ? (int)blockIdx.x : (int)blockIdx.x * 2 + team;   // the team's (channel, slice)
     const bool has_work = vb < p.C * p.slices;
     const int c = has_work ? vb % p.C : 0, slice = has_work ? vb / p.C : 0;
     const int n_begin = slice * p.planes_per_wg;
@@ -274,30 +276,50 @@ __global__ __launch_bounds__(2 * TT_THREADS, 1) void dwconv_mfma_team_tri_kernel
             s1 += (a0 + a1) + (a2 + a3); s2 += (q0 + q1) + (q2 + q3);
         }
     };
-    auto copy_out = [&](int it_done) {                               // results of group it_done: LDS -> HBM, 16 bytes per lane; NST stores, always
+    // results of group it_done: LDS -> HBM, 16 bytes per lane; NST stores, always.  Two halves, so that the I/O phase can put every LDS read it
+    // needs (these and the transposing reads of the next group) in flight before it consumes the first: the phase is a chain of LDS
+    // round trips under the other workgroup's fragment traffic, not work.
+    u32x4 cbuf[TT_NCO][NOB];
+    auto copy_out_read = [&]() {
+#pragma unroll
+        for (int k = 0; k < TT_NCO; ++k) {
+            const unsigned lo = co_j[k] == 0x3fffffff ? 0u : co_l[k];                       // lanes beyond the buffer read its first chunk (dropped)
+#pragma unroll
+            for (int t = 0; t < NOB; ++t) cbuf[k][t] = *(const u32x4*)(L + lout_b + t * out_buf_b + lo);
+        }
+    };
+    auto copy_out_store = [&](int it_done) {
         const int n0 = n_begin + it_done * p.G;
         const unsigned gb = (unsigned)(((size_t)n0 * p.C + c) * HW * 2);
 #pragma unroll
         for (int k = 0; k < TT_NCO; ++k) {
             const bool live = n0 + co_j[k] < n_end;
             const unsigned go = live ? gb + co_g[k] : TT_OOB;
-            const unsigned lo = co_j[k] == 0x3fffffff ? 0u : co_l[k];                       // lanes beyond the buffer read its first chunk (dropped)
             if constexpr (!DGRAD) {
 #pragma unroll
                 for (int t = 0; t < 3; ++t) {
-                    const u32x4 v = *(const u32x4*)(L + lout_b + t * out_buf_b + lo);
-                    if (p.stats && live) stat8(v, bs[2 * t], bs[2 * t + 1]);
-                    __builtin_amdgcn_raw_buffer_store_b128(v, ro[t], go, 0, 0);
+                    if (p.stats && live) stat8(cbuf[k][t], bs[2 * t], bs[2 * t + 1]);
+                    __builtin_amdgcn_raw_buffer_store_b128(cbuf[k][t], ro[t], go, 0, 0);
                 }
             } else if constexpr (NOB == 1) {
-                const u32x4 v = *(const u32x4*)(L + lout_b + lo);
-                __builtin_amdgcn_raw_buffer_store_b128(v, ro[0], go, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(cbuf[k][0], ro[0], go, 0, 0);
             } else {
                 // dx = (vertical partial) + (horizontal + small partial): a tensor add of two rounded planes (what autograd's adds do)
-                const u32x4 a = *(const u32x4*)(L + lout_b + lo), b = *(const u32x4*)(L + lout_b + out_buf_b + lo);
-                __builtin_amdgcn_raw_buffer_store_b128(add_packed<T>(a, b), ro[0], go, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(add_packed<T>(cbuf[k][0], cbuf[k][1]), ro[0], go, 0, 0);
             }
         }
+    };
+    s16x4 tbuf[TT_NTR];
+    auto transpose_read = [&](int g) {                               // tensor 0 of ring slot g
+        const unsigned sb = ring_b + (unsigned)(g % NB) * slot_b;
+#pragma unroll
+        for (int k = 0; k < TT_NTR; ++k)
+            if (tr_map[k] != 0xffffffffu) tbuf[k] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(SLAK_LDS(s16x4, L + sb + (tr_map[k] & 0xffffu)));
+    };
+    auto transpose_write = [&]() {                                   // -> x^T
+#pragma unroll
+        for (int k = 0; k < TT_NTR; ++k)
+            if (tr_map[k] != 0xffffffffu && (tr_map[k] >> 16) != 0xffffu) *(s16x4*)(L + xt_b + (tr_map[k] >> 16)) = tbuf[k];
     };
 
     unsigned long long* tl = TT_TIMELINE(p, vb);
@@ -417,27 +439,39 @@ __global__ __launch_bounds__(2 * TT_THREADS, 1) void dwconv_mfma_team_tri_kernel
         if (tl && tid == 0 && it < 27) tl[4 + 2 * it] = __builtin_amdgcn_s_memrealtime();
         // ---------------- IO phase
         if (tl && tid == 0 && it == 10) tl[52] = __builtin_readcyclecounter();
+        const bool tr = it + 1 < iters && !TT_DBG(p, 4);
+        if (!TT_DBG(p, 2)) copy_out_read();
+        if (tr) transpose_read(it + 1);
         issue_group(it + NB);                                         // into the slot group `it` just left
         if (tl && tid == 0 && it == 10) tl[53] = __builtin_readcyclecounter();
-        if (!TT_DBG(p, 2)) copy_out(it);
+        if (!TT_DBG(p, 2)) copy_out_store(it);
         else {
 #pragma unroll
             for (int k = 0; k < NST; ++k) __builtin_amdgcn_raw_buffer_store_b128(u32x4{0u, 0u, 0u, 0u}, ro[0], TT_OOB, 0, 0);   // keeps the count
         }
         if (tl && tid == 0 && it == 10) tl[54] = __builtin_readcyclecounter();
-        if (it + 1 < iters && !TT_DBG(p, 4)) transpose_group(it + 1);
+        if (tr) transpose_write();
         if (tl && tid == 0 && it == 10) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); tl[51] = __builtin_readcyclecounter(); }
     };
     // Anti-phase schedule: between two workgroup barriers team 0 computes group i while team 1 moves the data of its group i-1,
     // then team 0 moves the data of group i while team 1 computes its group i.  A phase the team has no group for is skipped; the
     // barriers are executed by everybody (p.iters_max + 1 pairs).
-    for (int i = 0; i <= p.iters_max; ++i) {
-        wg_barrier();
-        if (team == 0) { if (i < iters) compute_phase(i); }
-        else if (i >= 1 && i - 1 < iters) io_phase(i - 1);
-        wg_barrier();
-        if (team == 0) { if (i < iters) io_phase(i); }
-        else if (i < iters) compute_phase(i);
+    if constexpr (SOLO) {
+        for (int i = 0; i < iters; ++i) {
+            wg_barrier();
+            compute_phase(i);
+            wg_barrier();
+            io_phase(i);
+        }
+    } else {
+        for (int i = 0; i <= p.iters_max; ++i) {
+            wg_barrier();
+            if (team == 0) { if (i < iters) compute_phase(i); }
+            else if (i >= 1 && i - 1 < iters) io_phase(i - 1);
+            wg_barrier();
+            if (team == 0) { if (i < iters) io_phase(i); }
+            else if (i < iters) compute_phase(i);
+        }
     }
     if (tl && tid == 0) { tl[63] = __builtin_amdgcn_s_memrealtime(); tl[61] = __builtin_readcyclecounter(); }
     wait_vmcnt<0>();                                                 // nothing of this wave (an LDS-DMA into a slot nobody reads any more) may outlive it
@@ -552,22 +586,36 @@ int dwconv_mfma_team_tri_stats_rows(int N, int C, int H, int W, int K, int dtype
     return p.slices * TT_WAVES;
 }
 
-template <typename T, int CLS, bool DGRAD, bool R16>
-static int launch_team_t(TeamParams& p, int N, int C, int H, int W, int K, hipStream_t st) {
-    auto k = dwconv_mfma_team_tri_kernel<T, CLS, DGRAD, R16>;
+// which (op, class) runs one team per workgroup: bit 0 forward one-tile planes, 1 forward 2 x 2 tiles, 2 dgrad one-tile, 3 dgrad 2 x 2
+static int team_solo_mask() {
+    static const int m = [] { const char* e = getenv("SLAK_TEAM_SOLO"); return e ? atoi(e) : TT_SOLO_DEFAULT; }();
+    return m;
+}
+
+template <typename T, int CLS, bool DGRAD, bool R16, bool SOLO>
+static int launch_team_s(TeamParams& p, int N, int C, int H, int W, int K, hipStream_t st) {
+    auto k = dwconv_mfma_team_tri_kernel<T, CLS, DGRAD, R16, SOLO>;
     fill_team_params(p, N, C, H, W, K, DGRAD, CLS, 2 * mfma_cu_count());
     if (!team_pick_ring(p, CLS)) return SLAK_ERR_UNSUPPORTED;
     p.team_lds = (int)((team_lds_bytes(p, CLS) + 15) & ~(size_t)15);
     p.iters_max = (p.planes_per_wg + p.G - 1) / p.G;
-    const size_t lds = (size_t)2 * p.team_lds;
+    const size_t lds = (size_t)(SOLO ? 1 : 2) * p.team_lds;
     static thread_local size_t cached_lds = 0;
     if (cached_lds != lds) {
         if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         cached_lds = lds;
     }
-    hipLaunchKernelGGL(k, dim3((unsigned)((p.C * p.slices + 1) / 2)), dim3(2 * TT_THREADS), lds, st, p);
+    if (SOLO) hipLaunchKernelGGL(k, dim3((unsigned)(p.C * p.slices)), dim3(TT_THREADS), lds, st, p);
+    else hipLaunchKernelGGL(k, dim3((unsigned)((p.C * p.slices + 1) / 2)), dim3(2 * TT_THREADS), lds, st, p);
     SLAK_LAUNCH_CHECK();
     return SLAK_OK;
+}
+
+template <typename T, int CLS, bool DGRAD, bool R16>
+static int launch_team_t(TeamParams& p, int N, int C, int H, int W, int K, hipStream_t st) {
+    const int bit = (DGRAD ? 2 : 0) + (CLS == 2 ? 1 : 0);
+    if ((team_solo_mask() >> bit) & 1) return launch_team_s<T, CLS, DGRAD, R16, true>(p, N, C, H, W, K, st);
+    return launch_team_s<T, CLS, DGRAD, R16, false>(p, N, C, H, W, K, st);
 }
 
 template <typename T, int CLS>

@@ -1,4 +1,5 @@
-"""Dev: per-workgroup timeline of the team kernel (SLAK_TEAM_DBG=16): which workgroups share a CU, and how their phases line up."""
+"""Dev: per-workgroup timeline of the team kernel (SLAK_TEAM_DBG=16 in a library built with SLAK_BUILD_DEFS=-DSLAK_TEAM_DEV): which workgroups
+share a CU, and how their phases line up.  --dgrad: the data-gradient launch instead of the forward one (SLAK_STREAM_TRI=0 keeps the forward on the team kernel)."""
 import sys, os, ctypes
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -10,7 +11,10 @@ N, C, H, W, K = 128, 96, 56, 56, 51
 x = torch.randn(N, C, H, W, device=dev).bfloat16()
 ws = [torch.randn(C, 1, kh, kw, device=dev) * 0.05 for kh, kw in ((K, 5), (5, K), (5, 5))]
 ys = [torch.empty_like(x) for _ in range(3)]
-def tf(): _lib.check(L.slak_dwconv2d_tri_forward(x.data_ptr(), ws[0].data_ptr(), ws[1].data_ptr(), ws[2].data_ptr(), ys[0].data_ptr(), ys[1].data_ptr(), ys[2].data_ptr(), _lib.SLAK_BF16, N, C, H, W, K, st))
+dys = [torch.randn_like(x) for _ in range(3)]
+def td(): _lib.check(L.slak_dwconv2d_tri_backward_data(dys[0].data_ptr(), dys[1].data_ptr(), dys[2].data_ptr(), ws[0].data_ptr(), ws[1].data_ptr(), ws[2].data_ptr(), ys[0].data_ptr(), _lib.SLAK_BF16, N, C, H, W, K, st))
+def tf0(): _lib.check(L.slak_dwconv2d_tri_forward(x.data_ptr(), ws[0].data_ptr(), ws[1].data_ptr(), ws[2].data_ptr(), ys[0].data_ptr(), ys[1].data_ptr(), ys[2].data_ptr(), _lib.SLAK_BF16, N, C, H, W, K, st))
+tf = td if "--dgrad" in sys.argv else tf0
 for _ in range(3): tf()
 buf = torch.zeros(1024 * 64, dtype=torch.int64, device=dev)
 L.slak_debug_set_phase_buffer(buf.data_ptr())
@@ -47,3 +51,4 @@ t0c = [int(r[56]) - int(r[55]) for _, r in rows if int(r[56])]
 if t0c: print("first tile (20 MFMAs) of compute phase 10, wave 0: %d cycles (median), prologue-to-first-tile %d" % (statistics.median(t0c), statistics.median([int(r[55]) - int(r[57]) for _, r in rows if int(r[56])])))
 io = [(int(r[53]) - int(r[52]), int(r[54]) - int(r[53]), int(r[51]) - int(r[54])) for _, r in rows if int(r[51])]
 if io: print("IO phase 10, wave 0: DMA issue %d, copy-out %d, transposes %d cycles (medians)" % tuple(statistics.median(x[k] for x in io) for k in range(3)))
+
