@@ -9,6 +9,8 @@ st = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
 check = "--check" in sys.argv
 shapes = [(128, 96, 56, 56, 51), (128, 192, 28, 28, 49), (64, 192, 48, 48, 59), (64, 384, 24, 24, 57), (64, 128, 56, 56, 51)]
 shapes = shapes[:int(os.environ.get("TEAM_SHAPES", "5"))]
+if os.environ.get("TEAM_SHAPE"):
+    shapes = [tuple(int(v) for v in os.environ["TEAM_SHAPE"].split(","))]
 if "--small" in sys.argv:
     shapes = [(5, 3, 56, 56, 51), (9, 2, 28, 28, 49), (2, 2, 48, 40, 31), (3, 2, 32, 32, 31), (6, 2, 24, 24, 13), (7, 2, 28, 20, 13), (1, 1, 56, 56, 51), (130, 2, 28, 28, 49)]
 tag = "team=%s nb=%s dbg=%s dual=%s stag=%s" % (os.environ.get("SLAK_TEAM_TRI", "1"), os.environ.get("SLAK_TEAM_NB", "-"), os.environ.get("SLAK_TEAM_DBG", "0"), os.environ.get("SLAK_TEAM_DUAL", "1"), os.environ.get("SLAK_TEAM_STAGGER", "0"))
@@ -35,6 +37,10 @@ for (N, C, H, W, K) in shapes:
         continue
     by = 3 * 2 * x.numel() * 2
     for what, fn in (("tri fwd", tf), ("tri dgrad", td)):
+        try:
+            fn()
+        except Exception as e:
+            print(tag, (N, C, H, W, K), what, "not available:", str(e)[-60:]); continue
         for _ in range(5): fn()
         torch.cuda.synchronize()
         best = 1e9
