@@ -439,6 +439,10 @@ __global__ __launch_bounds__(SOLO ? TT_THREADS : 2 * TT_THREADS, SOLO ? 2 : 1) v
         if (tl && tid == 0 && it < 27) tl[4 + 2 * it] = __builtin_amdgcn_s_memrealtime();
         // ---------------- IO phase
         if (tl && tid == 0 && it == 10) tl[52] = __builtin_readcyclecounter();
+        // The I/O phase is ~500 cycles of instructions whose LDS round trips chain; a SIMD issues strictly oldest-wave-first
+        // (tools/mfma_share_probe.hip: of two MFMA-streaming waves the younger one does not move until the older one stalls), so beside
+        // a computing wave of the CU's other workgroup this wave would only get the slots that one leaves: raise its priority for the phase.
+        if (TT_IO_PRIO) __builtin_amdgcn_s_setprio(3);
         const bool tr = it + 1 < iters && !TT_DBG(p, 4);
         if (!TT_DBG(p, 2)) copy_out_read();
         if (tr) transpose_read(it + 1);
@@ -451,6 +455,7 @@ __global__ __launch_bounds__(SOLO ? TT_THREADS : 2 * TT_THREADS, SOLO ? 2 : 1) v
         }
         if (tl && tid == 0 && it == 10) tl[54] = __builtin_readcyclecounter();
         if (tr) transpose_write();
+        if (TT_IO_PRIO) __builtin_amdgcn_s_setprio(0);
         if (tl && tid == 0 && it == 10) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); tl[51] = __builtin_readcyclecounter(); }
     };
     // Anti-phase schedule: between two workgroup barriers team 0 computes group i while team 1 moves the data of its group i-1,

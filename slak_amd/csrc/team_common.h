@@ -35,6 +35,10 @@ static inline int team_dev_flags() { return 0; }
 
 constexpr int TT_SOLO_DEFAULT = 15;  // SLAK_TEAM_SOLO bit mask (dwconv_mfma_team_tri.hip): one team per workgroup measured 5-12 % faster for every (op, class)
 
+#ifndef TT_IO_PRIO
+#define TT_IO_PRIO 1
+#endif
+
 struct TeamPiece { unsigned lds_off, g_off; int info; };       // info = tensor | plane-of-group << 4 | lanes << 8 (0: no such piece)
 constexpr int TT_NPW = 6;               // LDS-DMA pieces per wave and group (upper bound: dgrad)
 
