@@ -106,9 +106,17 @@ int slak_device_info(int* cu_count, int* lds_bytes_per_cu, char* arch_name, size
 // fp32 tensors on the bf16 matrix cores (two-term split, ~2^-16 relative per product) are OPT-IN, like torch.backends.cudnn.allow_tf32:
 // the default fp32 path stays the exact VALU one.  SLAK_FP32_MFMA=1 sets the initial value.
 static std::atomic<int> g_fp32_mfma{[] { const char* e = getenv("SLAK_FP32_MFMA"); return (e && e[0] == '1') ? 1 : 0; }()};
-static bool f32_ok(int dt) { return dt != SLAK_F32 || g_fp32_mfma.load() != 0 || g_conv_algo == SLAK_ALGO_MFMA; }
+static thread_local int t_fp32_mfma = -1;                    // per-thread override: -1 follow the process-wide setting, 0 exact, 1 matrix cores
+static bool f32_ok(int dt) {
+    if (dt != SLAK_F32 || g_conv_algo == SLAK_ALGO_MFMA) return true;
+    return t_fp32_mfma >= 0 ? t_fp32_mfma != 0 : g_fp32_mfma.load() != 0;
+}
 int slak_set_fp32_matrix_cores(int allow) { g_fp32_mfma = allow ? 1 : 0; return SLAK_OK; }
-int slak_get_fp32_matrix_cores(void) { return g_fp32_mfma.load(); }
+int slak_get_fp32_matrix_cores(void) { return t_fp32_mfma >= 0 ? t_fp32_mfma : g_fp32_mfma.load(); }
+int slak_set_fp32_matrix_cores_thread(int mode) {
+    if (mode < -1 || mode > 1) return SLAK_ERR_INVALID_ARG;
+    const int prev = t_fp32_mfma; t_fp32_mfma = mode; return prev + 1 + 16;      // 16 + (previous mode + 1): never a status code
+}
 
 int slak_set_conv_algo(int algo) {
     if (algo != SLAK_ALGO_AUTO && algo != SLAK_ALGO_DIRECT && algo != SLAK_ALGO_MFMA) return SLAK_ERR_INVALID_ARG;

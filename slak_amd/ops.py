@@ -90,6 +90,22 @@ def allow_fp32_matrix_cores(allow=True):
     return prev
 
 
+class fp32_matrix_cores:
+    """``with fp32_matrix_cores(True):`` -- the calls of THIS thread inside the block run fp32 tensors on the matrix cores (two-term split)
+    whatever the process-wide switch says; ``False`` forces the exact kernels; nests."""
+
+    def __init__(self, enabled=True):
+        self.mode = 1 if enabled else 0
+
+    def __enter__(self):
+        self.prev = _lib.lib().slak_set_fp32_matrix_cores_thread(self.mode) - 17
+        return self
+
+    def __exit__(self, *exc):
+        _lib.lib().slak_set_fp32_matrix_cores_thread(self.prev)
+        return False
+
+
 def dwconv2d_forward(x, w, out_dtype=None):
     _check_tensor(x, "input"); _check_tensor(w, "weight")
     N, C, H, W, kh, kw = _dims(x, w)

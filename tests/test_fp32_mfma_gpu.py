@@ -105,3 +105,35 @@ def test_fp32_split_at_the_stage_1_shape_is_faster_than_the_exact_kernels(gpu, s
     ops.allow_fp32_matrix_cores(True)
     print("5x51 fwd fp32, N=64: split %.3f ms, exact %.3f ms" % (t_split, t_exact))
     assert t_split < t_exact
+
+
+def test_fp32_under_autocast_runs_on_the_matrix_cores_and_plain_fp32_stays_exact(gpu):
+    """The op module's policy (slak_amd/depthwise_conv2d_implicit_gemm.py): entered under torch.autocast with an fp32 activation -- the
+    reference's default AMP flow, depthwise_conv2d_implicit_gemm.py:16 -- forward, data gradient and weight gradient take the two-term split;
+    without autocast, or with the class switch off, the exact kernels; results stay fp32 either way."""
+    from slak_amd import _lib
+    from slak_amd.depthwise_conv2d_implicit_gemm import DepthWiseConv2dImplicitGEMM
+    L = _lib.lib()
+    torch.manual_seed(3)
+    m = DepthWiseConv2dImplicitGEMM(6, (31, 5)).to(gpu)
+    x = torch.randn(3, 6, 28, 28, device=gpu, requires_grad=True)
+    y0 = m(x)
+    assert L.slak_debug_last_kernel() == b"dwconv_direct" and y0.dtype == torch.float32
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        y1 = m(x)
+    assert L.slak_debug_last_kernel() == b"dwconv_mfma(f32 split)" and y1.dtype == torch.float32
+    assert (y1 - y0).abs().max().item() <= 1e-4 * y0.abs().max().item()
+    dy = torch.randn_like(y0)
+    gx0, gw0 = torch.autograd.grad(y0, (x, m.weight), dy)                        # exact
+    gx1, gw1 = torch.autograd.grad(y1, (x, m.weight), dy)                        # the backward runs on autograd's thread: the override travels in ctx
+    assert gx1.dtype == torch.float32 and gw1.dtype == torch.float32
+    for a, b in ((gx1, gx0), (gw1, gw0)):
+        assert not torch.equal(a, b) and (a - b).abs().max().item() <= 1e-4 * b.abs().max().item()
+    assert L.slak_get_fp32_matrix_cores() == 0                                    # the per-thread override did not leak
+    DepthWiseConv2dImplicitGEMM.fp32_matrix_cores_under_autocast = False
+    try:
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            y2 = m(x)
+        assert L.slak_debug_last_kernel() == b"dwconv_direct" and torch.equal(y2, y0)
+    finally:
+        DepthWiseConv2dImplicitGEMM.fp32_matrix_cores_under_autocast = True
