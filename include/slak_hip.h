@@ -63,10 +63,10 @@ int slak_set_conv_algo(int algo);           /* process-wide override of the AUTO
  * side on maps up to 64 along the long axis (the SLaK stages at 224 px); everything else stays exact. */
 int slak_set_fp32_matrix_cores(int allow);
 int slak_get_fp32_matrix_cores(void);
-/* Per-thread override for the calls that follow on this thread: -1 follow the process-wide setting, 0 exact, 1 matrix cores.  Returns
- * 16 + (previous mode + 1), i.e. 16 / 17 / 18, or SLAK_ERR_INVALID_ARG.  The op module uses it to run fp32 tensors on the matrix cores when
- * it was entered under torch.autocast (the reference's default AMP flow hands the op fp32, depthwise_conv2d_implicit_gemm.py:16). */
-int slak_set_fp32_matrix_cores_thread(int mode);
+/* Per-thread override for the calls that follow on this thread: -1 follow the process-wide setting, 0 exact, 1 matrix cores; the mode it
+ * replaces is stored to *previous (may be NULL).  The op module uses it to run fp32 tensors on the matrix cores when it was entered under
+ * torch.autocast (the reference's default AMP flow hands the op fp32, depthwise_conv2d_implicit_gemm.py:16). */
+int slak_set_fp32_matrix_cores_thread(int mode, int* previous);
 
 /* ---------------------------------------------------------------- boundary 1: depthwise conv */
 

@@ -113,9 +113,11 @@ static bool f32_ok(int dt) {
 }
 int slak_set_fp32_matrix_cores(int allow) { g_fp32_mfma = allow ? 1 : 0; return SLAK_OK; }
 int slak_get_fp32_matrix_cores(void) { return t_fp32_mfma >= 0 ? t_fp32_mfma : g_fp32_mfma.load(); }
-int slak_set_fp32_matrix_cores_thread(int mode) {
+int slak_set_fp32_matrix_cores_thread(int mode, int* previous) {
     if (mode < -1 || mode > 1) return SLAK_ERR_INVALID_ARG;
-    const int prev = t_fp32_mfma; t_fp32_mfma = mode; return prev + 1 + 16;      // 16 + (previous mode + 1): never a status code
+    if (previous) *previous = t_fp32_mfma;
+    t_fp32_mfma = mode;
+    return SLAK_OK;
 }
 
 int slak_set_conv_algo(int algo) {

@@ -98,11 +98,14 @@ class fp32_matrix_cores:
         self.mode = 1 if enabled else 0
 
     def __enter__(self):
-        self.prev = _lib.lib().slak_set_fp32_matrix_cores_thread(self.mode) - 17
+        import ctypes
+        prev = ctypes.c_int(-1)
+        _lib.check(_lib.lib().slak_set_fp32_matrix_cores_thread(self.mode, ctypes.byref(prev)), "slak_set_fp32_matrix_cores_thread")
+        self.prev = prev.value
         return self
 
     def __exit__(self, *exc):
-        _lib.lib().slak_set_fp32_matrix_cores_thread(self.prev)
+        _lib.check(_lib.lib().slak_set_fp32_matrix_cores_thread(self.prev, None), "slak_set_fp32_matrix_cores_thread")
         return False
 
 
