@@ -30,6 +30,7 @@ namespace slak {
 struct MfmaFwdParams {
     const void* x; const uint16_t* frags; void* y;
     const uint16_t* frags_lo;   // F32 kernels: the filters' second bf16 term
+    int nch, guard;             // tap chunks along the short axis (1 unless the kernel has more than five rows), zero rows in front of a plane
     int N, C, H, W, kh, kw, flip;
     int Wt, Wl, KL, padL;
     int G;                 // planes staged per iteration
@@ -44,16 +45,19 @@ struct MfmaFwdParams {
 };
 
 __global__ void toeplitz_pack_kernel(const ToeplitzPackParams p) {
-    const int total = p.C * p.MT * p.NG * p.KS * 64;
+    const int total = p.C * p.MT * p.NCH * p.NG * p.KS * 64;
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= total) return;
     const int lane = idx & 63;
     int f = idx >> 6;
     const int ks = f % p.KS; f /= p.KS;
     const int g = f % p.NG; f /= p.NG;
+    const int q = f % p.NCH; f /= p.NCH;
     const int mt = f % p.MT; const int c = f / p.MT;
     const int MPAD = 32 / p.RPM, l31 = lane & 31, lhi = lane >> 5;
-    const int r = g * p.RPM + l31 / MPAD, o_abs = mt * 32 + (l31 % MPAD);
+    const int short_taps = p.vert ? p.kw : p.kh;                 // MF_TAPS unless NCH > 1
+    const int rj = g * p.RPM + l31 / MPAD;                       // tap inside the chunk
+    const int r = q * MF_TAPS + rj, o_abs = mt * 32 + (l31 % MPAD);
     const float* wc = p.w + (size_t)c * p.kh * p.kw;
     // all 8 loads are issued unconditionally (clamped index) and masked afterwards, so they overlap
     float v[8];
@@ -61,10 +65,10 @@ __global__ void toeplitz_pack_kernel(const ToeplitzPackParams p) {
     for (int e = 0; e < 8; ++e) {
         const int i_abs = ks * 16 + lhi * 8 + e;
         int t = i_abs - o_abs + p.padL;
-        const bool ok = r < MF_TAPS && o_abs < p.Wt && i_abs < p.Wt && t >= 0 && t < p.KL;
-        int rr = r < MF_TAPS ? r : 0;
+        const bool ok = rj < MF_TAPS && r < short_taps && o_abs < p.Wt && i_abs < p.Wt && t >= 0 && t < p.KL;
+        int rr = ok ? r : 0;
         t = ok ? t : 0;
-        if (p.flip) { t = p.KL - 1 - t; rr = MF_TAPS - 1 - rr; }
+        if (p.flip) { t = p.KL - 1 - t; rr = short_taps - 1 - rr; }
         const float wv = p.vert ? wc[t * p.kw + rr] : wc[rr * p.kw + t];
         v[e] = ok ? wv : 0.f;
     }
@@ -86,7 +90,7 @@ __global__ void toeplitz_pack_kernel(const ToeplitzPackParams p) {
 }
 
 void launch_toeplitz_pack(const ToeplitzPackParams& p, hipStream_t st) {
-    const int total = p.C * p.MT * p.NG * p.KS * 64;
+    const int total = p.C * p.MT * p.NCH * p.NG * p.KS * 64;
     hipLaunchKernelGGL(toeplitz_pack_kernel, dim3((total + 255) / 256), dim3(256), 0, st, p);
 }
 
@@ -96,7 +100,7 @@ void launch_toeplitz_pack(const ToeplitzPackParams& p, hipStream_t st) {
 // w = w_hi + w_lo by the pack kernel; every (tap group, k-step) is three MFMAs into the same fp32 accumulator: w_hi x_hi + w_hi x_lo + w_lo x_hi
 // (the dropped w_lo x_lo term and the two representation errors are each <= 2^-16 of |w||x|: ~2e-5 relative, measured in tests/test_fp32_mfma_gpu.py).
 // w_hi fragments live in registers, w_lo fragments in LDS.
-template <typename T, int MT, int KS, int RPM, int V, bool VERT, bool F32 = false>
+template <typename T, int MT, int KS, int RPM, int V, bool VERT, bool F32 = false, bool TALL = false>
 __global__ __launch_bounds__(MF_THREADS, 2) void dwconv_mfma_fwd_kernel(const MfmaFwdParams p) {
     constexpr int NG = (MF_TAPS + RPM - 1) / RPM;          // accumulators (MFMA groups) per unit
     constexpr int MPAD = 32 / RPM;                          // rows per tap inside an MFMA
@@ -132,7 +136,7 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dwconv_mfma_fwd_kernel(const Mf
         const bool ok = idx < p.nchunks;
         const int j = ok ? idx / p.cpp : 0, rem = ok ? idx - j * p.cpp : 0;
         const int h = rem / p.cpr, w0 = (rem - h * p.cpr) * V;
-        const int u0 = (p.ppt ? (j / p.ppt) * p.TS + (j % p.ppt) * (p.Wl + 2) : 0) + 2;
+        const int u0 = (p.ppt ? (j / p.ppt) * p.TS + (j % p.ppt) * (p.Wl + 2) : 0) + p.guard;
         jpl[k] = ok ? j : -1;
         goff[k] = j * p.C * HW + rem * V;
         ooff[k] = j * p.HWp + rem * V;
@@ -185,7 +189,7 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dwconv_mfma_fwd_kernel(const Mf
     //      k = ks*16 + lhi*8 + e -> i, the weight w[r][i - o + padL] (0 outside the filter or the plane) ----
     s16x8 afrag[NG][KS];
     bool ks_active[KS];
-    load_toeplitz_frags<NG, KS>(afrag, ks_active, p.frags, c, MT, mt, lane, MPAD, p.Wt, p.KL, p.padL);
+    load_toeplitz_frags_at<NG, KS>(afrag, ks_active, p.frags, (size_t)(c * MT + mt) * p.nch, mt, lane, MPAD, p.Wt, p.KL, p.padL);   // chunk 0
     __syncthreads();
 
     for (int it = 0; it < iters; ++it) {
@@ -199,12 +203,21 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dwconv_mfma_fwd_kernel(const Mf
             for (int g = 0; g < NG; ++g)
 #pragma unroll
                 for (int i = 0; i < 16; ++i) acc[g][i] = 0.f;
+            // Kernels with more than five rows (square kernels, the reference's own test grid): the rows are taken five at a time.  Chunk q's
+            // five-tap sum has to land 5q + 2 - kh/2 rows further along the short axis; with kh/2 zero rows in front of the plane that is the
+            // stack 5q rows further down, so every chunk adds into the SAME five accumulators and the lane-shift epilogue runs once.  The
+            // chunk's fragments come from the workspace (L2) each time: 5 KS loads per 5 KS MFMAs -- a path for completeness, not a hot one.
+            for (int q = 0; q < (TALL ? p.nch : 1); ++q) {
+            if constexpr (TALL) {
+                if (q > 0) load_toeplitz_frags_at<NG, KS>(afrag, ks_active, p.frags, (size_t)(c * MT + mt) * p.nch + q, mt, lane, MPAD, p.Wt, p.KL, p.padL);
+            }
+            const int qrow = TALL ? q * MF_TAPS : 0;
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 if (!ks_active[ks]) continue;
                 auto read_b = [&](const uint16_t* stack) -> s16x8 {
                     if constexpr (!VERT) {
-                        return *(const s16x8*)(stack + (ustart + l31) * p.P + ks * 16 + lhi * 8);
+                        return *(const s16x8*)(stack + (ustart + l31 + qrow) * p.P + ks * 16 + lhi * 8);
                     } else {
                         // ds_read_b64_tr_b16: the 16 lanes of group g = lane>>4 read a 4(k) x 16(u) block; lane gets column lane&15
                         const int grp = lane >> 4, i16 = lane & 15;
@@ -228,6 +241,10 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dwconv_mfma_fwd_kernel(const Mf
 #pragma unroll
                     for (int g = 0; g < NG; ++g) acc[g] = mfma32<T>(afrag[g][ks], b, acc[g]);
                 }
+            }
+            }
+            if constexpr (TALL) {                                   // the next tile starts with chunk 0 again
+                if (p.nch > 1) load_toeplitz_frags_at<NG, KS>(afrag, ks_active, p.frags, (size_t)(c * MT + mt) * p.nch, mt, lane, MPAD, p.Wt, p.KL, p.padL);
             }
             // ---- epilogue: Y = Z2 + shr(Z1 + shr(Z0)) + shl(Z3 + shl(Z4)) along the lane axis -----------
             float yv[NR];
@@ -283,10 +300,15 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dwconv_mfma_fwd_kernel(const Mf
 // ------------------------------------------------------------------------------------------------------------
 struct MfmaShape { int MT, KS, RPM, V; };
 
+// kernels with more than five rows and at least as many columns (the square kernels of the reference's test grid, --Decom False): the
+// long axis is W, the kh rows are taken in chunks of five (forward and data gradient; 16-bit tensors)
+static bool mfma_tall(const ConvDims& d) { return d.kh != MF_TAPS && d.kw != MF_TAPS && d.kh <= d.kw && (d.kh & 1) && (d.kw & 1) && d.kw <= 63; }
+static int mfma_nch(const ConvDims& d) { return mfma_tall(d) ? (d.kh + MF_TAPS - 1) / MF_TAPS : 1; }
+
 static bool mfma_fwd_shape(const ConvDims& d, bool vert, MfmaShape& s) {
     const int Wt = vert ? d.H : d.W;
     const int KS_short = vert ? d.kw : d.kh;
-    if (KS_short != MF_TAPS) return false;
+    if (KS_short != MF_TAPS && !(mfma_tall(d) && !vert)) return false;
     if (Wt > 64) return false;
     if (Wt > 32) s = MfmaShape{2, 4, 1, 8};
     else if (Wt > 16) s = MfmaShape{1, 2, 1, 4};
@@ -303,7 +325,10 @@ static bool fill_mfma_params(MfmaFwdParams& p, const ConvDims& d, bool vert, con
     const int HW = d.H * d.W;
     p.HWp = (HW + 7) & ~7;
     const int WLW = MF_WAVES / s.MT;
-    if (p.Wl + 2 * 2 <= 32 && s.MT == 1) {
+    const bool tall = mfma_tall(d) && !vert;
+    p.nch = tall ? mfma_nch(d) : 1;
+    p.guard = tall ? d.kh / 2 : 2;
+    if (p.Wl + 2 * 2 <= 32 && s.MT == 1 && !tall) {
         // small lane axis: ppt planes per tile, 2 zero lanes in front of each
         p.ppt = 32 / (p.Wl + 2);
         if (p.ppt * (p.Wl + 2) + 0 > 32) return false;
@@ -318,7 +343,7 @@ static bool fill_mfma_params(MfmaFwdParams& p, const ConvDims& d, bool vert, con
     if (p.G > d.N) {                                      // tiny batches: do not stage planes that do not exist
         if (p.ppt) { p.ntiles = (d.N + p.ppt - 1) / p.ppt; p.G = p.ntiles * p.ppt; }
     }
-    const int U = p.ntiles * p.TS + 32 + 4;               // lane-axis extent incl. slack read by the last tile
+    const int U = p.ntiles * p.TS + 32 + 4 + (tall ? MF_TAPS * p.nch + p.guard : 0);   // lane-axis extent incl. slack read by the last tile (tall: + the chunks' reach)
     if (vert) {
         p.P = (U + 3) & ~3;
         p.in_elems = s.KS * 16 * p.P;
@@ -346,6 +371,15 @@ template <typename T, int MT, int KS, int RPM, int V, bool F32>
 static int launch_mfma_fwd_t(const MfmaFwdParams& p, bool vert, hipStream_t st) {
     const size_t lds = mfma_fwd_lds_bytes(p, MfmaShape{MT, KS, RPM, V}, F32);
     dim3 grid((unsigned)(p.C * p.slices));
+    if constexpr (!F32) {
+        if (p.nch > 1 || p.guard != 2) {                             // more than five rows (or fewer: 3 x 3): the chunked horizontal kernel
+            auto k = dwconv_mfma_fwd_kernel<T, MT, KS, RPM, V, false, false, true>;
+            if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL(k, grid, dim3(MF_THREADS), lds, st, p);
+            SLAK_LAUNCH_CHECK();
+            return SLAK_OK;
+        }
+    }
     if (vert) {
         auto k = dwconv_mfma_fwd_kernel<T, MT, KS, RPM, V, true, F32>;
         if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -385,7 +419,7 @@ bool dwconv_mfma_supported(const ConvDims& d, int x_dt, int w_dt, int y_dt) {
     MfmaShape s; MfmaFwdParams p;
     if (!mfma_fwd_shape(d, vert, s)) return false;
     if (!fill_mfma_params(p, d, vert, s, 256)) return false;
-    if (x_dt == SLAK_F32) return mfma_fwd_lds_bytes(p, s, true) <= 80 * 1024;
+    if (x_dt == SLAK_F32) return !mfma_tall(d) && mfma_fwd_lds_bytes(p, s, true) <= 80 * 1024;
     return mfma_fwd_lds_bytes(p, s, false) <= 64 * 1024;
 }
 
@@ -393,7 +427,7 @@ size_t dwconv_mfma_workspace(const ConvDims& d) {
     const bool vert = d.kh > d.kw;
     MfmaShape s;
     if (!mfma_fwd_shape(d, vert, s)) return 0;
-    return 2 * align_up(toeplitz_pack_bytes(d.C, s.MT, (MF_TAPS + s.RPM - 1) / s.RPM, s.KS), 256);     // w_hi (all dtypes) + w_lo (fp32 activations)
+    return 2 * align_up((size_t)mfma_nch(d) * toeplitz_pack_bytes(d.C, s.MT, (MF_TAPS + s.RPM - 1) / s.RPM, s.KS), 256);     // w_hi (all dtypes) + w_lo (fp32 activations)
 }
 
 int launch_dwconv_mfma(const void* x, int x_dt, const void* w, int w_dt, void* y, int y_dt,
@@ -407,7 +441,7 @@ int launch_dwconv_mfma(const void* x, int x_dt, const void* w, int w_dt, void* y
     const bool f32 = x_dt == SLAK_F32;
     uint16_t* lo = f32 ? (uint16_t*)((char*)ws + dwconv_mfma_workspace(d) / 2) : nullptr;
     ToeplitzPackParams tp{(const float*)w, (uint16_t*)ws, d.C, d.kh, d.kw, s.MT, (MF_TAPS + s.RPM - 1) / s.RPM, s.KS, s.RPM,
-                          vert ? 1 : 0, flip_filter ? 1 : 0, p.Wt, p.KL, p.padL, x_dt != SLAK_F16 ? 1 : 0, lo};
+                          vert ? 1 : 0, flip_filter ? 1 : 0, p.Wt, p.KL, p.padL, x_dt != SLAK_F16 ? 1 : 0, lo, p.nch};
     launch_toeplitz_pack(tp, st);
     SLAK_LAUNCH_CHECK();
     p.x = x; p.frags = (const uint16_t*)ws; p.frags_lo = lo; p.y = y; p.flip = flip_filter ? 1 : 0;

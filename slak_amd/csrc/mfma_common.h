@@ -152,6 +152,8 @@ struct ToeplitzPackParams {
     const float* w; uint16_t* frags;
     int C, kh, kw, MT, NG, KS, RPM, vert, flip, Wt, KL, padL, is_bf16;
     uint16_t* frags_lo;    // fp32 operands on the matrix cores: second bf16 term of every filter value (w - bf16(w)), same layout; or NULL
+    int NCH;               // short-axis tap chunks of MF_TAPS (1: the K x 5 / 5 x K kernels; > 1: kernels with more than five rows, layout
+                           // frag[(((c*MT + mt)*NCH + q)*NG + g)*KS + ks])
 };
 void launch_toeplitz_pack(const ToeplitzPackParams& p, hipStream_t st);
 static inline size_t toeplitz_pack_bytes(int C, int MT, int NG, int KS) { return (size_t)C * MT * NG * KS * 64 * 8 * 2; }
@@ -190,9 +192,9 @@ __device__ __forceinline__ void build_toeplitz_frags_lds(s16x8 (&afrag)[NG][KS],
 }
 
 template <int NG, int KS>
-__device__ __forceinline__ void load_toeplitz_frags(s16x8 (&afrag)[NG][KS], bool (&ks_active)[KS], const uint16_t* frags,
-                                                    int c, int MT, int mt, int lane, int MPAD, int Wt, int KL, int padL) {
-    const s16x8* base = (const s16x8*)frags + ((size_t)(c * MT + mt) * NG * KS) * 64 + lane;
+__device__ __forceinline__ void load_toeplitz_frags_at(s16x8 (&afrag)[NG][KS], bool (&ks_active)[KS], const uint16_t* frags,
+                                                       size_t block, int mt, int lane, int MPAD, int Wt, int KL, int padL) {
+    const s16x8* base = (const s16x8*)frags + (block * NG * KS) * 64 + lane;       // block = (c*MT + mt) [* NCH + q]
 #pragma unroll
     for (int g = 0; g < NG; ++g)
 #pragma unroll
@@ -202,6 +204,12 @@ __device__ __forceinline__ void load_toeplitz_frags(s16x8 (&afrag)[NG][KS], bool
         const int i_lo = ks * 16, i_hi = ks * 16 + 15, o_lo = mt * 32, o_hi = mt * 32 + MPAD - 1;
         ks_active[ks] = (i_lo < Wt) && (o_lo < Wt) && (i_lo - o_hi <= KL - 1 - padL) && (o_lo - i_hi <= padL);
     }
+}
+
+template <int NG, int KS>
+__device__ __forceinline__ void load_toeplitz_frags(s16x8 (&afrag)[NG][KS], bool (&ks_active)[KS], const uint16_t* frags,
+                                                    int c, int MT, int mt, int lane, int MPAD, int Wt, int KL, int padL) {
+    load_toeplitz_frags_at<NG, KS>(afrag, ks_active, frags, (size_t)(c * MT + mt), mt, lane, MPAD, Wt, KL, padL);
 }
 
 // ---- LDS-DMA (buffer_load_dwordx4 ... lds) and explicit synchronisation (see dwconv_mfma_dma.hip for the protocol) ----

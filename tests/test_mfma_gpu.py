@@ -133,7 +133,7 @@ def test_mfma_is_what_auto_runs_for_lowp(gpu):
         with pytest.raises(L.SlakHipError):
             ops.dwconv2d_forward(torch.randn(2, 3, 96, 96, device=gpu), w)   # fp32 on a map beyond 64: no matrix-core kernel
         with pytest.raises(L.SlakHipError):
-            ops.dwconv2d_forward(x, torch.randn(3, 1, 7, 7, device=gpu))   # no 5-tap side
+            ops.dwconv2d_forward(x, torch.randn(3, 1, 7, 3, device=gpu))   # more rows than columns and no 5-tap side
         L.lib().slak_set_conv_algo(L.ALGO_DIRECT)
         y_direct = ops.dwconv2d_forward(x, w)
     finally:
@@ -141,6 +141,33 @@ def test_mfma_is_what_auto_runs_for_lowp(gpu):
     assert torch.equal(y_auto, y_mfma)
     assert not torch.equal(y_auto, y_direct)                       # direct keeps the fp32 filter: different rounding
     assert (y_auto.float() - y_direct.float()).abs().max().item() <= 1e-2 * max(1.0, y_direct.float().abs().max().item())
+
+
+@pytest.mark.parametrize("N,C,H,W,kh,kw", [(2, 3, 32, 32, 3, 3), (2, 3, 32, 32, 7, 7), (3, 2, 24, 40, 13, 13), (2, 4, 56, 56, 31, 31), (2, 2, 64, 64, 27, 27),
+                                           (3, 3, 14, 14, 9, 9), (4, 2, 7, 7, 3, 3), (2, 3, 28, 28, 7, 11), (2, 2, 20, 40, 9, 21), (1, 2, 64, 48, 31, 31)])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_kernels_with_more_than_five_rows_run_on_the_matrix_cores(N, C, H, W, kh, kw, dtype, gpu):
+    """Square kernels (the reference's own test grid: test_correctness.py:16-20, 3 .. 31) and other kernels without a 5-tap side whose rows do
+    not outnumber their columns: forward and data gradient take the rows five at a time through the generic MFMA kernel (dwconv_mfma.hip,
+    TALL); the weight gradient of these shapes stays on the exact kernels.  Against the C oracle on the rounded operands."""
+    ops, L = _ops(), _lib()
+    torch.manual_seed(kh * 10 + H)
+    x = torch.randn(N, C, H, W, device=gpu).to(dtype)
+    dy = torch.randn(N, C, H, W, device=gpu).to(dtype)
+    w = torch.randn(C, 1, kh, kw, device=gpu) * (0.5 / (kh * kw) ** 0.5)
+    wr = _round(w, dtype)
+    y = ops.dwconv2d_forward(x, w)
+    assert L.lib().slak_debug_last_kernel() == b"dwconv_mfma"
+    ref = oracle.dwconv2d_fwd(_round(x, dtype), wr)
+    tol = (2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11)
+    assert np.abs(y.double().cpu().numpy() - ref).max() <= tol * max(1.0, np.abs(ref).max()) + 1e-6
+    dx = ops.dwconv2d_backward_data(dy, w)
+    assert L.lib().slak_debug_last_kernel() == b"dwconv_mfma"
+    ref = oracle.dwconv2d_bwd_data(_round(dy, dtype), wr)
+    assert np.abs(dx.double().cpu().numpy() - ref).max() <= tol * max(1.0, np.abs(ref).max()) + 1e-6
+    dw = ops.dwconv2d_backward_filter(dy, x, w)                                   # exact kernels
+    ref = oracle.dwconv2d_bwd_filter(_round(dy, dtype), _round(x, dtype), kh, kw)
+    assert np.abs(dw.double().cpu().numpy() - ref).max() <= 1e-5 * max(1.0, np.abs(ref).max()) * max(1.0, (N * H * W) ** 0.5 / 30)
 
 
 @pytest.mark.parametrize("H,W,kh,kw", [(56, 56, 5, 51), (56, 56, 51, 5), (28, 28, 49, 5), (14, 14, 5, 47), (7, 7, 13, 5), (96, 96, 5, 61), (96, 96, 61, 5)])
