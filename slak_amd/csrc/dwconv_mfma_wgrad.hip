@@ -39,6 +39,11 @@ struct MfmaWgradParams {
     int planes_per_wg, slices;
     int nchunks, cpp, cpr; // staging chunks per iteration / per plane / per row
     unsigned long long* dbg;
+    // filters with more than five rows (horizontal kernels only): one launch per chunk of five rows.  The kernel itself sees a 5 x kw filter
+    // (kh == 5); gap = zero k-rows between stacked planes (2; kh_total / 2 here: the row shift of x is still a plain address offset), row0 =
+    // rows of x the chunk's first tap lies below the top one (5 q), rows = rows of this chunk that exist (<= 5), rec = floats per channel in
+    // `partial` / `dw` (kh_total * kw; both pointers arrive offset to the chunk's first row)
+    int gap, row0, rows, rec;
 };
 
 // MT: 32-wide tiles along the long axis for both o and i (wave w owns (w & 1, w >> 1) when MT == 2; when MT == 1 the
@@ -86,7 +91,7 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dwconv_mfma_wgrad_kernel(const 
         goff[k] = j * p.C * HW + rem * V;
         // horizontal: straight into the stacks, k-position of (plane j, row h) = 2 + j*(Wl+2) + h;
         // vertical: into the row-major staging image of plane j (transposed into the stacks afterwards)
-        loff[k] = VERT ? ((j * p.Hi + h) * p.Pi + w0) : ((2 + j * (p.Wl + 2) + h) * p.P + w0);
+        loff[k] = VERT ? ((j * p.Hi + h) * p.Pi + w0) : ((p.gap + j * (p.Wl + p.gap) + h) * p.P + w0);
     }
     // vertical: transpose map.  Block b = (tensor t, plane j, 4 image rows kb, 16 image columns cb): one ds_read_b64_tr_b16 per
     // 16-lane group (lane i16 supplies row kb*4 + i16/4, columns cb*16 + 4*(i16%4); receives column cb*16 + i16, rows kb*4..+3),
@@ -135,7 +140,7 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dwconv_mfma_wgrad_kernel(const 
     // the x stack carries 2 extra k-rows in front, so that row "k + rho" (rho = 0..4) holds x[k + rho - 2]
     auto put = [&](int k, const chunk_t<V>& d_, const chunk_t<V>& x_, int set) {
         if constexpr (VERT) { chunk_store<V>(img + set * img_lo + loff[k], d_); chunk_store<V>(img + set * img_lo + p.G * p.Hi * p.Pi + loff[k], x_); }
-        else { chunk_store<V>(dys + set * lo_off + loff[k], d_); chunk_store<V>(xs + set * lo_off + loff[k] + 2 * p.P, x_); }
+        else { chunk_store<V>(dys + set * lo_off + loff[k], d_); chunk_store<V>(xs + set * lo_off + loff[k] + p.gap * p.P, x_); }
     };
     auto stage_write = [&]() {
 #pragma unroll
@@ -215,7 +220,7 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dwconv_mfma_wgrad_kernel(const 
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
             int rho = g * RPN + ncol / NPAD; if (rho > MF_TAPS - 1) rho = MF_TAPS - 1;
-            b_off[g] = (krow + rho) * p.P + nt * 32 + (ncol % NPAD);
+            b_off[g] = (krow + rho + (VERT ? 0 : p.row0)) * p.P + nt * 32 + (ncol % NPAD);
         }
     }
     const int kstep_elems = 16 * p.P;
@@ -284,30 +289,34 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dwconv_mfma_wgrad_kernel(const 
             ssum = (part[0] + part[1]) + (part[2] + part[3]);
             const int rho = g * RPN + rsel;
             const int tau = dd - (NPAD - 1) + (nt - mt) * 32 + p.padL;
-            if (rho < MF_TAPS && tau >= 0 && tau < p.KL) mine[VERT ? (tau * p.kw + rho) : (rho * p.kw + tau)] = ssum;
+            if (rho < (VERT ? MF_TAPS : p.rows) && tau >= 0 && tau < p.KL) mine[VERT ? (tau * p.kw + rho) : (rho * p.kw + tau)] = ssum;
         }
         __builtin_amdgcn_wave_barrier();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
     t3 = __builtin_readcyclecounter();
     __syncthreads();
-    for (int t = tid; t < ntap; t += MF_THREADS) {
+    const int nvalid = VERT ? ntap : p.rows * p.kw, rec = p.rec ? p.rec : ntap;
+    for (int t = tid; t < nvalid; t += MF_THREADS) {
         float s = dwl[t];
 #pragma unroll
         for (int w = 1; w < MF_WAVES; ++w) s += dwl[w * ntap + t];
-        wgrad_store_partial(&p.partial[((size_t)slice * p.C + c) * ntap + t], s);
+        wgrad_store_partial(&p.partial[((size_t)slice * p.C + c) * rec + t], s);
     }
     t4 = __builtin_readcyclecounter();
     if (prof) { p.dbg[0] = t1 - t0; p.dbg[1] = t2 - t1; p.dbg[2] = t3 - t2; p.dbg[3] = t4 - t3; p.dbg[4] = iters; }
-    if (p.counters) wgrad_finish(p.partial, p.dw, p.counters + c, (int*)lds, p.slices, p.C, c, 1, ntap, tid, MF_THREADS);
+    if (p.counters) wgrad_finish(p.partial, p.dw, p.counters + c, (int*)lds, p.slices, p.C, c, 1, nvalid, tid, MF_THREADS, nullptr, 0, rec);
 }
 
 // ------------------------------------------------------------------------------------------------------------
 struct WShape { int MT, RPN, V; };
 
+static bool mfma_wgrad_shape(const ConvDims& d, bool vert, WShape& s);
+static bool wgrad_tall(const ConvDims& d);
+
 static bool mfma_wgrad_shape(const ConvDims& d, bool vert, WShape& s) {
     const int Wt = vert ? d.H : d.W;
-    if ((vert ? d.kw : d.kh) != MF_TAPS) return false;
+    if ((vert ? d.kw : d.kh) != MF_TAPS && !(wgrad_tall(d) && !vert)) return false;
     if (Wt > 64) return false;
     if (Wt > 32) s = WShape{2, 1, 8};
     else if (Wt > 16) s = WShape{1, 1, 4};
@@ -316,7 +325,15 @@ static bool mfma_wgrad_shape(const ConvDims& d, bool vert, WShape& s) {
     return d.W % s.V == 0;
 }
 
-static bool fill_wgrad_params(MfmaWgradParams& p, const ConvDims& d, bool vert, const WShape& s, int cu_count) {
+// filters with more than five rows and at least as many columns (square kernels: the reference's test grid, --Decom False), 16-bit tensors:
+// one launch per chunk of five rows of the horizontal kernel (see MfmaWgradParams)
+static bool wgrad_tall(const ConvDims& d) { return d.kh != MF_TAPS && d.kw != MF_TAPS && d.kh <= d.kw && (d.kh & 1) && (d.kw & 1) && d.kw <= 63; }
+
+static bool fill_wgrad_params(MfmaWgradParams& p, const ConvDims& d_in, bool vert, const WShape& s, int cu_count) {
+    const bool tall = wgrad_tall(d_in) && !vert;
+    ConvDims d = d_in;
+    if (tall) d.kh = MF_TAPS;                              // what one launch computes
+    p.gap = tall ? d_in.kh / 2 : 2; p.row0 = 0; p.rows = tall ? (d_in.kh < MF_TAPS ? d_in.kh : MF_TAPS) : MF_TAPS; p.rec = tall ? d_in.kh * d_in.kw : 0;
     p.N = d.N; p.C = d.C; p.H = d.H; p.W = d.W; p.kh = d.kh; p.kw = d.kw;
     p.Wt = vert ? d.H : d.W; p.Wl = vert ? d.W : d.H;
     p.KL = vert ? d.kh : d.kw; p.padL = p.KL / 2;
@@ -334,12 +351,12 @@ static bool fill_wgrad_params(MfmaWgradParams& p, const ConvDims& d, bool vert, 
     per = (per + G - 1) / G * G;
     p.planes_per_wg = per; p.slices = (d.N + per - 1) / per;
     p.nchunks = G * p.cpp;
-    const int K = 2 + G * (p.Wl + 2);
+    const int K = p.gap + G * (p.Wl + p.gap);
     p.NKS = (K + 15) / 16;
     const int Kp = p.NKS * 16;
     p.P = s.MT * 32;                                       // k along rows, long-axis positions along columns
     p.dy_elems = Kp * p.P;
-    p.x_elems = (Kp + 8) * p.P;                            // 2 rows in front + rho <= 4 behind
+    p.x_elems = (Kp + (tall ? 2 * p.gap + 8 : 8)) * p.P;   // gap rows in front + the taps' reach behind
     p.Hi = (d.H + 3) & ~3; p.Pi = (d.W + 3) & ~3;
     {
         const int per_plane = (p.Hi / 4) * ((d.W + 15) / 16);
@@ -362,7 +379,7 @@ bool dwconv_mfma_wgrad_supported(const ConvDims& d, int dy_dt, int x_dt) {
     WShape s; MfmaWgradParams p;
     if (!mfma_wgrad_shape(d, vert, s)) return false;
     if (!fill_wgrad_params(p, d, vert, s, 256)) return false;
-    if (x_dt == SLAK_F32) return mfma_wgrad_lds_bytes(p, vert, true) <= 160 * 1024;
+    if (x_dt == SLAK_F32) return !wgrad_tall(d) && mfma_wgrad_lds_bytes(p, vert, true) <= 160 * 1024;
     return mfma_wgrad_lds_bytes(p, vert, false) <= 72 * 1024;
 }
 
@@ -409,8 +426,18 @@ int launch_dwconv_mfma_wgrad(const void* dy, int dy_dt, const void* x, int x_dt,
     if (ws == nullptr || ws_bytes < dwconv_mfma_wgrad_workspace(d)) return SLAK_ERR_WORKSPACE;
     p.dy = dy; p.x = x; p.partial = (float*)ws; p.dbg = g_dma_dbg;
     p.dw = dw; p.counters = wgrad_arrival_counters(d.C);
-    int rc = (x_dt == SLAK_F32) ? launch_wgrad_shape<bf16_t, true>(p, s, vert, st)
+    int rc = SLAK_OK;
+    const int nq = p.rec ? (d.kh + MF_TAPS - 1) / MF_TAPS : 1;       // chunks of five rows (one launch each; 1: the 5-tap kernels)
+    for (int q = 0; q < nq && rc == SLAK_OK; ++q) {
+        if (p.rec) {
+            p.row0 = q * MF_TAPS;
+            p.rows = d.kh - p.row0 < MF_TAPS ? d.kh - p.row0 : MF_TAPS;
+            p.partial = (float*)ws + (size_t)p.row0 * d.kw;
+            p.dw = dw + (size_t)p.row0 * d.kw;
+        }
+        rc = (x_dt == SLAK_F32) ? launch_wgrad_shape<bf16_t, true>(p, s, vert, st)
            : (x_dt == SLAK_BF16) ? launch_wgrad_shape<bf16_t, false>(p, s, vert, st) : launch_wgrad_shape<f16_t, false>(p, s, vert, st);
+    }
     if (rc != SLAK_OK || p.counters) return rc;
     return launch_wgrad_reduce((const float*)ws, dw, d.C * d.kh * d.kw, p.slices, st);
 }

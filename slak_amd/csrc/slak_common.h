@@ -142,10 +142,13 @@ unsigned* wgrad_arrival_counters(int ngroups);      // host; nullptr -> use laun
 // so "arriving" needs no L2 write-back -- an agent-scope release fence costs a whole-L2 flush per workgroup on gfx942/gfx950
 // (measured: 18 -> 107 us for the 14x14 weight gradient).
 __device__ __forceinline__ void wgrad_store_partial(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-// dw2 != nullptr: a channel's record of ntap floats holds TWO filters back to back (ntap1 taps of dw, then ntap - ntap1 of dw2)
+// dw2 != nullptr: a channel's record of ntap floats holds TWO filters back to back (ntap1 taps of dw, then ntap - ntap1 of dw2).
+// rec != 0: a channel's record is `rec` floats long in both `partial` and `dw` and this call sums its first ntap (a launch that produces
+// some rows of a filter: the pointers arrive offset to the first of them).
 __device__ __forceinline__ void wgrad_finish(const float* partial, float* dw, unsigned* counter, int* lds_flag,
                                              int nslices, int C, int c0, int nch, int ntap, int tid, int nthreads,
-                                             float* dw2 = nullptr, int ntap1 = 0) {
+                                             float* dw2 = nullptr, int ntap1 = 0, int rec = 0) {
+    const int R = rec ? rec : ntap;
     // Hand-off form "sc1 payload -> vmcnt(0) -> agent atomic flag; consumer: sc1 (agent-scope) loads" of MI355X_MICROARCH.md
     // (inter-workgroup visibility, valid forms): the partials were written through to the device coherence point (agent-scope atomic
     // stores), the explicit s_waitcnt below makes this wave's stores acknowledged before it can reach the barrier (inline asm: the
@@ -168,8 +171,8 @@ __device__ __forceinline__ void wgrad_finish(const float* partial, float* dw, un
     if (!*lds_flag) return;
     for (int t = tid; t < nch * ntap; t += nthreads) {
         float s = 0.f;
-        const float* src = partial + (size_t)c0 * ntap + t;
-        const size_t stride = (size_t)C * ntap;
+        const float* src = partial + (size_t)c0 * R + t;
+        const size_t stride = (size_t)C * R;
         for (int k0 = 0; k0 < nslices; k0 += 8) {      // 8 loads in flight, added in slice order; agent-scope loads read at the coherence point
             float v[8];
 #pragma unroll
@@ -178,7 +181,7 @@ __device__ __forceinline__ void wgrad_finish(const float* partial, float* dw, un
 #pragma unroll
             for (int j = 0; j < 8; ++j) s += v[j];
         }
-        if (dw2 == nullptr) dw[(size_t)c0 * ntap + t] = s;
+        if (dw2 == nullptr) dw[(size_t)c0 * R + t] = s;
         else {
             const int ch = t / ntap, e = t - ch * ntap;
             if (e < ntap1) dw[(size_t)(c0 + ch) * ntap1 + e] = s; else dw2[(size_t)(c0 + ch) * (ntap - ntap1) + (e - ntap1)] = s;

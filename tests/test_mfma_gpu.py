@@ -149,7 +149,7 @@ def test_mfma_is_what_auto_runs_for_lowp(gpu):
 def test_kernels_with_more_than_five_rows_run_on_the_matrix_cores(N, C, H, W, kh, kw, dtype, gpu):
     """Square kernels (the reference's own test grid: test_correctness.py:16-20, 3 .. 31) and other kernels without a 5-tap side whose rows do
     not outnumber their columns: forward and data gradient take the rows five at a time through the generic MFMA kernel (dwconv_mfma.hip,
-    TALL); the weight gradient of these shapes stays on the exact kernels.  Against the C oracle on the rounded operands."""
+    TALL); the weight gradient is one launch of the generic MFMA weight-gradient kernel per five filter rows.  Against the C oracle on the rounded operands."""
     ops, L = _ops(), _lib()
     torch.manual_seed(kh * 10 + H)
     x = torch.randn(N, C, H, W, device=gpu).to(dtype)
@@ -165,9 +165,11 @@ def test_kernels_with_more_than_five_rows_run_on_the_matrix_cores(N, C, H, W, kh
     assert L.lib().slak_debug_last_kernel() == b"dwconv_mfma"
     ref = oracle.dwconv2d_bwd_data(_round(dy, dtype), wr)
     assert np.abs(dx.double().cpu().numpy() - ref).max() <= tol * max(1.0, np.abs(ref).max()) + 1e-6
-    dw = ops.dwconv2d_backward_filter(dy, x, w)                                   # exact kernels
+    dw = ops.dwconv2d_backward_filter(dy, x, w)                                   # one launch per five rows of the filter
+    assert L.lib().slak_debug_last_kernel() == b"dwconv_mfma_wgrad" and dw.dtype == torch.float32
     ref = oracle.dwconv2d_bwd_filter(_round(dy, dtype), _round(x, dtype), kh, kw)
     assert np.abs(dw.double().cpu().numpy() - ref).max() <= 1e-5 * max(1.0, np.abs(ref).max()) * max(1.0, (N * H * W) ** 0.5 / 30)
+    assert torch.equal(dw, ops.dwconv2d_backward_filter(dy, x, w))                # fixed-order reduction
 
 
 @pytest.mark.parametrize("H,W,kh,kw", [(56, 56, 5, 51), (56, 56, 51, 5), (28, 28, 49, 5), (14, 14, 5, 47), (7, 7, 13, 5), (96, 96, 5, 61), (96, 96, 61, 5)])
