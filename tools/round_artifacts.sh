@@ -13,6 +13,8 @@ timeout 300 python tools/time_all.py > $O/kernel_times.txt 2>&1
 timeout 300 python tools/time_all.py --model base >> $O/kernel_times.txt 2>&1
 timeout 300 python tools/time_all.py --kernel 61 --res 384 >> $O/kernel_times.txt 2>&1
 timeout 200 python tools/time_mask.py > $O/mask_step_times.txt 2>&1
+timeout 300 python tools/time_square.py > $O/square_kernels.txt 2>&1
+timeout 300 python tools/time_fp32.py > $O/time_fp32.txt 2>&1
 timeout 900 bash tools/pmc_run.sh > /dev/null 2>&1
 cp gpurun_out/sum/pmc_traffic.txt $O/pmc_traffic.txt; cp gpurun_out/sum/pmc_traffic.json $O/pmc_traffic.json
 timeout 600 bash tools/pmc_hot.sh > /dev/null 2>&1
