@@ -48,7 +48,10 @@ typedef enum {
 typedef enum { SLAK_F32 = 0, SLAK_F16 = 1, SLAK_BF16 = 2, SLAK_I64 = 3 /* slak_ema_update only */ } slak_dtype_t;
 
 /* conv algorithm selector: AUTO picks per dtype/shape; DIRECT = fp32-exact VALU kernels (any dtype);
- * MFMA = banded-Toeplitz matrix-core kernels (f16/bf16 inputs; fp32 inputs through the two-term split below). */
+ * MFMA = banded-Toeplitz matrix-core kernels (f16/bf16 inputs; fp32 inputs through the two-term split below).  AUTO runs 16-bit tensors on
+ * the matrix cores for every kernel with a 5-tap side and, with the rows taken five at a time, for every odd kh <= kw <= 63 kernel on maps
+ * up to 64 wide (the square 3 .. 31 kernels of test_correctness.py:16-20, the 51 x 51 of --Decom False); everything else (maps beyond 128,
+ * kernels with more rows than columns and no 5-tap side, fp32 unless allowed below) runs the exact VALU kernels. */
 typedef enum { SLAK_ALGO_AUTO = 0, SLAK_ALGO_DIRECT = 1, SLAK_ALGO_MFMA = 2 } slak_algo_t;
 
 const char* slak_status_string(int status);
