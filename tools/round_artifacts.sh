@@ -7,6 +7,7 @@ timeout 600 python bench.py --sparsity 0.4 --no-cpu-baseline --no-mask-bench    
 timeout 600 python bench.py --sparsity 0.4 --update-frequency 1 --steps 10 --warmup 3 --no-cpu-baseline --no-mask-bench 2>/dev/null | tail -1 > $O/bench_cfg2_update_every_step.json
 timeout 600 python bench.py --model base --steps 20 --warmup 5 --no-cpu-baseline --no-mask-bench 2>/dev/null | tail -1 > $O/bench_cfg3_slak_b.json
 timeout 600 python bench.py --kernel 61 --res 384 --steps 20 --warmup 5 --no-cpu-baseline --no-mask-bench 2>/dev/null | tail -1 > $O/bench_cfg4_61x61_384px.json
+SLAK_TUNED_GEMMS=0 OMP_NUM_THREADS=4 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --backend gloo --device 0 --steps 5 --warmup 2 --prime 2 --batch 32 --no-roofline --no-mask-bench --no-cpu-baseline 2>/dev/null | grep '^{' | tail -1 > $O/bench_n2_two_ranks_one_gpu_gloo.json
 BENCH_ARGS="" timeout 600 bash tools/profile_bench.sh > /dev/null 2>&1
 cp gpurun_out/sum/bench_kernel_stats.txt $O/bench_kernel_stats.txt; cp gpurun_out/sum/step_breakdown.txt $O/step_breakdown.txt; cp gpurun_out/sum/bench_under_rocprof.json $O/bench_under_rocprof.json
 timeout 300 python tools/time_all.py > $O/kernel_times.txt 2>&1
