@@ -153,6 +153,15 @@ def hot_path_kernels(device, batch, reps, dtype, stages):
     st = torch.cuda.current_stream(device).cuda_stream
     out = []
     b = 2 if dtype != torch.float32 else 4
+    # the GPU has idled through the CPU baselines by now: ~0.3 s of work first, as the --prime steps do for the training loop (clocks ramp up
+    # slowly: the first launches after an idle period measured 10-15 % slower than the same launches in tools/time_all.py)
+    wa = torch.randn(4096, 4096, device=device, dtype=torch.bfloat16)
+    t_warm = time.perf_counter()
+    while time.perf_counter() - t_warm < 0.3:
+        for _ in range(20):
+            wa @ wa
+        torch.cuda.synchronize(device)
+    del wa
     for si, (C, HW, K, blocks) in enumerate(stages):
         x = torch.randn(batch, C, HW, HW, device=device).to(dtype)
         dys = [torch.randn_like(x) for _ in range(3)]
