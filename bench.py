@@ -102,6 +102,8 @@ def parse():
     ap.add_argument("--no-mask-bench", action="store_true", help="skip the mask_step measurement")
     ap.add_argument("--debug-mask-sync", action="store_true", help="N>1: all-reduce a mask checksum after the timed region and fail on disagreement")
     ap.add_argument("--update-frequency", type=int, default=2000)
+    ap.add_argument("--graph", action="store_true", help="N = 1: forward and backward of the model replayed as two HIP graphs (torch.cuda.make_graphed_callables); "
+                                                          "the loss, the optimizer / Masking step stay eager.  Takes the ~12 ms (SLaK-T) / ~25 ms (SLaK-B) of host enqueue work per step out")
     ap.add_argument("--host-profile", action="store_true", help="cProfile of the step's enqueue path, printed to stderr after the timed region")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -473,9 +475,16 @@ def main():
     samples = torch.randn(a.batch, 3, a.res, a.res, device=device, generator=g)
     targets = torch.randint(0, 1000, (a.batch,), device=device, generator=g)
 
+    fwd = model
+    if a.graph:
+        if distributed:
+            sys.exit("--graph is wired for N = 1 (under DDP the graphed callable has to be made before the wrap)")
+        with torch.autocast("cuda", dtype=torch.bfloat16, cache_enabled=False):
+            fwd = torch.cuda.make_graphed_callables(model, (samples,), num_warmup_iters=3)
+
     def step():
-        with torch.autocast("cuda", dtype=torch.bfloat16):
-            loss = criterion(model(samples), targets)
+        with torch.autocast("cuda", dtype=torch.bfloat16, cache_enabled=not a.graph):
+            loss = criterion(fwd(samples), targets)
         loss.backward()
         if mask is not None:
             mask.step()                                           # engine.py:82-83
@@ -565,6 +574,7 @@ def main():
                    "backend": (a.backend if distributed else None),
                    "rccl_version": (".".join(str(v) for v in torch.cuda.nccl.version()) if (distributed and a.backend == "nccl") else None),
                    "per_step_sync": bool(a.per_step_sync),
+                   "hip_graph": ("forward and backward of the model replayed as two captured HIP graphs (torch.cuda.make_graphed_callables)" if a.graph else None),
                    "timing": "K steps between barrier + torch.cuda.synchronize() on both sides; " + ("a synchronize after every step as engine.py:90" if a.per_step_sync else "no synchronize inside (GPU-busy time == step time: the host runs ahead)"),
                    "per_rank_ms_per_step": [round(v, 4) for v in per_rank_ms],
                    "host_enqueue_ms_per_step": round(1e3 * host_s / a.steps, 3),
