@@ -43,6 +43,35 @@ def test_library_exports_every_declared_symbol(built_lib):
     assert lib.slak_dwconv2d_workspace_bytes(0, 128, 96, 56, 56, 51, 5, 2) > 0
 
 
+def test_fp32_matrix_core_switches_are_host_state(built_lib):
+    """slak_set_fp32_matrix_cores (process-wide, off by default) and the per-thread override the op module uses under autocast: pure host
+    state, nests through the Python context manager, does not leak into other threads."""
+    import threading
+    from slak_amd import _lib, ops
+    L = _lib.lib()
+    assert L.slak_get_fp32_matrix_cores() == 0
+    with ops.fp32_matrix_cores(True):
+        assert L.slak_get_fp32_matrix_cores() == 1
+        with ops.fp32_matrix_cores(False):
+            assert L.slak_get_fp32_matrix_cores() == 0
+        assert L.slak_get_fp32_matrix_cores() == 1
+        seen = []
+        t = threading.Thread(target=lambda: seen.append(L.slak_get_fp32_matrix_cores()))
+        t.start(); t.join()
+        assert seen == [0]                                         # another thread follows the process-wide setting
+    assert L.slak_get_fp32_matrix_cores() == 0
+    prev = ops.allow_fp32_matrix_cores(True)
+    try:
+        assert prev is False and L.slak_get_fp32_matrix_cores() == 1
+        with ops.fp32_matrix_cores(False):
+            assert L.slak_get_fp32_matrix_cores() == 0
+    finally:
+        ops.allow_fp32_matrix_cores(prev)
+    assert L.slak_set_fp32_matrix_cores_thread(7, None) == 1       # SLAK_ERR_INVALID_ARG
+    # shapes AUTO takes to the matrix cores need scratch for the packed filter fragments, per chunk of five rows
+    assert L.slak_dwconv2d_workspace_bytes(0, 8, 16, 32, 32, 31, 31, 2) >= 7 * L.slak_dwconv2d_workspace_bytes(0, 8, 16, 32, 32, 5, 31, 2) // 2
+
+
 def test_library_contains_gfx950_code(built_lib):
     out = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-objdump", "--offloading", built_lib], capture_output=True, text=True).stdout
     if not out:
