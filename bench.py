@@ -562,7 +562,7 @@ def main():
                    "global_batch": n_gpus * a.batch, "per_gpu_batch": a.batch, "parallelism": "dp%d" % n_gpus,
                    "kernel_sizes": ks, "resolution": a.res, "variant": a.model,
                    "dwconv_dtype": ("fp32" + (" on the bf16 matrix cores (two-term split, three MFMAs per product)"
-                                              if (a.fp32_matrix_cores or os.environ.get("SLAK_FP32_AUTOCAST_SPLIT", "1") != "0") else " (exact VALU kernels)")) if a.fp32_dwconv else "bf16 in/out, fp32 accumulate", "optimizer": "torch AdamW(fused)" if a.torch_adamw else "slak_amd MaskedAdamW (update + mask + bf16 copies, one launch)",
+                                              if (a.fp32_matrix_cores or os.environ.get("SLAK_FP32_AUTOCAST_SPLIT", "0") == "1") else " (exact VALU kernels)")) if a.fp32_dwconv else "bf16 in/out, fp32 accumulate", "optimizer": "torch AdamW(fused)" if a.torch_adamw else "slak_amd MaskedAdamW (update + mask + bf16 copies, one launch)",
                    "model_ema": bool(a.model_ema),
                    "sync_bn": True, "block_tail": "hip (ln_nchw_to_nhwc + scale_residual)" if M.Block.fused_tail else "pytorch ops",
                    "branch_bn": "hip (bn3: one stats pass + one apply pass)" if M.ReparamLargeKernelConv.fused_bn else "pytorch (Sync)BatchNorm x3 + adds",

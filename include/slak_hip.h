@@ -65,10 +65,12 @@ int slak_set_conv_algo(int algo);           /* process-wide override of the AUTO
  * way torch.backends.cudnn.allow_tf32 gates TF32; SLAK_FP32_MFMA=1 in the environment sets the initial value.  Covers kernels with a 5-tap
  * side on maps up to 64 along the long axis (the SLaK stages at 224 px); everything else stays exact. */
 int slak_set_fp32_matrix_cores(int allow);
-int slak_get_fp32_matrix_cores(void);
+int slak_get_fp32_matrix_cores(void);            /* the process-wide switch (never the per-thread override: safe for save / restore) */
+int slak_get_fp32_matrix_cores_effective(void);  /* what a call on THIS thread would do: the per-thread override if one is set, else the switch */
 /* Per-thread override for the calls that follow on this thread: -1 follow the process-wide setting, 0 exact, 1 matrix cores; the mode it
- * replaces is stored to *previous (may be NULL).  The op module uses it to run fp32 tensors on the matrix cores when it was entered under
- * torch.autocast (the reference's default AMP flow hands the op fp32, depthwise_conv2d_implicit_gemm.py:16). */
+ * replaces is stored to *previous (may be NULL).  Nothing in the library or the Python op module sets it by default: the op module does so
+ * only where the user opted in (DepthWiseConv2dImplicitGEMM.fp32_matrix_cores_under_autocast = True / SLAK_FP32_AUTOCAST_SPLIT=1: fp32
+ * activations that reach the op under torch.autocast -- the reference's default AMP flow, depthwise_conv2d_implicit_gemm.py:16). */
 int slak_set_fp32_matrix_cores_thread(int mode, int* previous);
 
 /* ---------------------------------------------------------------- boundary 1: depthwise conv */

@@ -56,6 +56,7 @@ SIGNATURES = {
     "slak_set_conv_algo": (_i, [_i]),
     "slak_set_fp32_matrix_cores": (_i, [_i]),
     "slak_get_fp32_matrix_cores": (_i, []),
+    "slak_get_fp32_matrix_cores_effective": (_i, []),
     "slak_set_fp32_matrix_cores_thread": (_i, [_i, ctypes.POINTER(ctypes.c_int)]),
     "slak_dwconv2d_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i, _i, _i]),
     "slak_dwconv2d_forward": (_i, _CONV),

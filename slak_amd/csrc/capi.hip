@@ -112,7 +112,8 @@ static bool f32_ok(int dt) {
     return t_fp32_mfma >= 0 ? t_fp32_mfma != 0 : g_fp32_mfma.load() != 0;
 }
 int slak_set_fp32_matrix_cores(int allow) { g_fp32_mfma = allow ? 1 : 0; return SLAK_OK; }
-int slak_get_fp32_matrix_cores(void) { return t_fp32_mfma >= 0 ? t_fp32_mfma : g_fp32_mfma.load(); }
+int slak_get_fp32_matrix_cores(void) { return g_fp32_mfma.load(); }                            // the PROCESS-WIDE switch (what a save / restore pair wants)
+int slak_get_fp32_matrix_cores_effective(void) { return t_fp32_mfma >= 0 ? t_fp32_mfma : g_fp32_mfma.load(); }   // what a call on THIS thread would do
 int slak_set_fp32_matrix_cores_thread(int mode, int* previous) {
     if (mode < -1 || mode > 1) return SLAK_ERR_INVALID_ARG;
     if (previous) *previous = t_fp32_mfma;

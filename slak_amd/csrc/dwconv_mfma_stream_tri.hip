@@ -368,10 +368,11 @@ static int launch_stream_t(TeamParams& p, int N, int C, int H, int W, int K, hip
     auto k = dwconv_mfma_stream_tri_kernel<T>;
     fill_stream_params(p, N, C, H, W, K, 2 * mfma_cu_count());
     const size_t lds = stream_lds_bytes(p);
-    static thread_local size_t cached_lds = 0;
-    if (cached_lds != lds) {
+    static thread_local size_t cached_key = 0;                    // (device + 1, LDS size): the attribute is per device
+    const size_t key = ((size_t)(slak_current_device() + 1) << 32) | lds;
+    if (cached_key != key) {
         if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        cached_lds = lds;
+        cached_key = key;
     }
     hipLaunchKernelGGL(k, dim3((unsigned)(p.C * p.slices)), dim3(TT_THREADS), lds, st, p);
     SLAK_LAUNCH_CHECK();

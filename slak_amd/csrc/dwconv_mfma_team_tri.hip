@@ -605,10 +605,11 @@ static int launch_team_s(TeamParams& p, int N, int C, int H, int W, int K, hipSt
     p.team_lds = (int)((team_lds_bytes(p, CLS) + 15) & ~(size_t)15);
     p.iters_max = (p.planes_per_wg + p.G - 1) / p.G;
     const size_t lds = (size_t)(SOLO ? 1 : 2) * p.team_lds;
-    static thread_local size_t cached_lds = 0;
-    if (cached_lds != lds) {
+    static thread_local size_t cached_key = 0;                    // (device + 1, LDS size): the attribute is per device
+    const size_t key = ((size_t)(slak_current_device() + 1) << 32) | lds;
+    if (cached_key != key) {
         if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        cached_lds = lds;
+        cached_key = key;
     }
     if (SOLO) hipLaunchKernelGGL(k, dim3((unsigned)(p.C * p.slices)), dim3(TT_THREADS), lds, st, p);
     else hipLaunchKernelGGL(k, dim3((unsigned)((p.C * p.slices + 1) / 2)), dim3(2 * TT_THREADS), lds, st, p);

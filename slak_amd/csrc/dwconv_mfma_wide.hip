@@ -345,12 +345,13 @@ template <typename T, bool VERT>
 static int launch_wide_tv(WideParams& p, const ConvDims& d, hipStream_t st) {
     auto k = dwconv_mfma_wide_kernel<T, VERT>;
     const size_t lds = wide_lds_bytes(p);
-    static thread_local size_t cached_lds = 0; static thread_local int cached_per_cu = 0;     // per instantiation; queried once per LDS size
-    if (cached_lds != lds) {
+    static thread_local size_t cached_lds = 0; static thread_local int cached_per_cu = 0;     // per instantiation; queried once per (device, LDS size)
+    const size_t lds_key = ((size_t)(slak_current_device() + 1) << 32) | lds;
+    if (cached_lds != lds_key) {
         if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         int per_cu = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k, MF_THREADS, lds) != hipSuccess || per_cu < 1) per_cu = 1;
-        cached_per_cu = per_cu > 8 ? 8 : per_cu; cached_lds = lds;
+        cached_per_cu = per_cu > 8 ? 8 : per_cu; cached_lds = lds_key;
     }
     fill_wide_params(p, d, VERT, cached_per_cu * mfma_cu_count());
     hipLaunchKernelGGL(k, dim3((unsigned)(p.C * p.slices)), dim3(MF_THREADS), lds, st, p);

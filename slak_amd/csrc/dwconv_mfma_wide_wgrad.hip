@@ -277,7 +277,7 @@ static int launch_wide_wgrad_tv(WideWgradParams& p, const ConvDims& d, size_t ws
     auto k = dwconv_mfma_wide_wgrad_kernel<T, VERT>;
     const size_t lds = wide_wgrad_lds_bytes(p);
     static thread_local size_t cached_key = 0; static thread_local int cached_per_cu = 0;     // per instantiation; queried once per (LDS size, block size)
-    const size_t key = lds * 16 + (size_t)p.ntiles;
+    const size_t key = ((size_t)(slak_current_device() + 1) << 40) | (lds * 16 + (size_t)p.ntiles);      // (the attribute is per device)
     if (cached_key != key) {
         if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         int per_cu = 0;

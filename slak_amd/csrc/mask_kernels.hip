@@ -692,8 +692,7 @@ __global__ __launch_bounds__(MK_THREADS) void mask_checksum_kernel(const slak_ma
 // memset + P1 + P2 + R + P3: the prune half (sparse_core.py:337-347) and, with GROW, the first regrow pass
 template <bool GROW>
 static int run_prune(slak_mask_plan* p, double prune_rate, hipStream_t st) {
-    if (!p->cand) HIPCHK(hipMalloc((void**)&p->cand, sizeof(uint2) * (size_t)p->total));
-    if (GROW && !p->act) { HIPCHK(hipMalloc((void**)&p->act, p->nib_bytes)); HIPCHK(hipMalloc((void**)&p->grown, p->nib_bytes)); }
+    if (!p->cand || (GROW && !p->act)) return SLAK_ERR_WORKSPACE;       // (allocated by slak_mask_plan_create: nothing is hipMalloc'ed mid-training)
     HIPCHK(hipMemsetAsync(p->zeroed, 0, p->zeroed_bytes, st));
     hipLaunchKernelGGL(mask_prune_hist_kernel, dim3(p->nsblk), dim3(MK_THREADS), 0, st, p->segs, p->sblk_seg, p->seg_sblk0, p->state, p->hist);
     hipLaunchKernelGGL(mask_pick_prune_kernel, dim3(p->nseg), dim3(MK_THREADS), 0, st, p->segs, p->state, p->hist, p->stats, prune_rate);
@@ -768,6 +767,13 @@ int slak_mask_plan_create(const slak_mask_segment_t* segs_host, int nseg, slak_m
     HIPCHK(hipMemcpy(p->seg_off, seg_off.data(), sizeof(long long) * nseg, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(p->seg_nib, seg_nib.data(), sizeof(long long) * nseg, hipMemcpyHostToDevice));
     p->nib_bytes = (size_t)nib + 16;
+    // The select's scratch is taken HERE, when the plan is made (Masking.add_module: before the first training step), not lazily at the first
+    // prune-and-grow: a raw hipMalloc in the middle of training synchronises the device and can fail once the framework's caching allocator
+    // has reserved the memory.  cand: worst case one (key, index) record per element (8 B/element: 245 MB for SLaK-T; the
+    // lists normally hold a few per cent of a tensor); the two byte-per-four-elements arrays of the regrow half.
+    HIPCHK(hipMalloc((void**)&p->cand, sizeof(uint2) * (size_t)p->total));
+    HIPCHK(hipMalloc((void**)&p->act, p->nib_bytes));
+    HIPCHK(hipMalloc((void**)&p->grown, p->nib_bytes));
     HIPCHK(hipMemset(p->stats, 0, sizeof(double) * 4 * nseg));
     HIPCHK(hipMemset(p->zeroed, 0, p->zeroed_bytes));
     *plan_out = p;

@@ -8,6 +8,11 @@
 
 namespace slak {
 
+// The device the calling thread launches on.  Function attributes (hipFuncSetAttribute) are PER DEVICE: launchers that cache "already set"
+// key the cache on (device, value), so a thread that moves to a second GPU sets the attribute there too.
+static inline int slak_current_device() { int dev = 0; return hipGetDevice(&dev) == hipSuccess ? dev : 0; }
+
+
 // ---- element types -------------------------------------------------------------------------
 struct bf16_t { uint16_t v; };          // storage-only bfloat16
 typedef _Float16 f16_t;

@@ -6,10 +6,12 @@ Differences, all additive:
   * bf16 is supported (the reference raises TypeError for it: depthwise_conv2d_implicit_gemm.py:63);
   * kernels run on PyTorch's current stream (the reference uses the null stream: convolution.h:243);
   * failures raise instead of exit()ing the process (forward_fp32.cu:173-192);
-  * an fp32 activation that reaches the op UNDER torch.autocast (the reference's default AMP flow: the residual stream is fp32 and
+  * OPT-IN (off by default, ``DepthWiseConv2dImplicitGEMM.fp32_matrix_cores_under_autocast = True`` or SLAK_FP32_AUTOCAST_SPLIT=1): an
+    fp32 activation that reaches the op UNDER torch.autocast (the reference's default AMP flow: the residual stream is fp32 and
     depthwise_conv2d_implicit_gemm.py:16 keeps it so) runs on the bf16 matrix cores as a two-term split -- 16 significand bits per
-    operand, fp32 accumulation and result: more precise than anything autocast does around it, 2.2x faster than the exact kernels.
-    Outside autocast fp32 stays exact.  ``DepthWiseConv2dImplicitGEMM.fp32_matrix_cores_under_autocast = False`` switches it off.
+    operand, fp32 accumulation and result: more precise than anything autocast does around it, 2.2x faster than the exact kernels, but
+    not the reference's exact fp32 arithmetic.  By default fp32 follows the process-wide switch (ops.allow_fp32_matrix_cores /
+    slak_set_fp32_matrix_cores, itself off by default): exact VALU kernels, in and out of autocast.
 """
 import os
 
@@ -75,7 +77,7 @@ class DepthWiseConv2dImplicitGEMM(nn.Conv2d):
     """``nn.Conv2d`` subclass with weight ``(C,1,kh,kw)``; computes a stride-1 "same" depthwise conv
     regardless of ``self.padding`` (which stays (0,0), as in the reference)."""
 
-    fp32_matrix_cores_under_autocast = os.environ.get("SLAK_FP32_AUTOCAST_SPLIT", "1") != "0"
+    fp32_matrix_cores_under_autocast = os.environ.get("SLAK_FP32_AUTOCAST_SPLIT", "0") == "1"      # opt-in, like allow_tf32
 
     def __init__(self, channels, kernel, bias=False):
         super().__init__(channels, channels, kernel, groups=channels, bias=bias)

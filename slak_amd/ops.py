@@ -74,7 +74,7 @@ _NULL = _NullCtx()
 
 
 def _on(device):
-    """`with _on(device):` == `with _on(device):`, without the device switch (and its two runtime calls) when `device`
+    """`with _on(device):` == `with torch.cuda.device(device):`, without the device switch (and its two runtime calls) when `device`
     is already current -- the one-process-per-GPU case."""
     if _cur_device is not None and device.index is not None and _cur_device() == device.index:
         return _NULL
@@ -83,7 +83,8 @@ def _on(device):
 
 def allow_fp32_matrix_cores(allow=True):
     """fp32 tensors through the bf16 matrix cores (two-term split, slak_set_fp32_matrix_cores): off by default like
-    torch.backends.cudnn.allow_tf32 gates TF32 -- the fp32 path is then the exact VALU kernels.  Returns the previous setting."""
+    torch.backends.cudnn.allow_tf32 gates TF32 -- the fp32 path is then the exact VALU kernels.  Returns the previous PROCESS-WIDE setting (never a per-thread
+    override that happens to be active: `prev = allow_fp32_matrix_cores(x); ...; allow_fp32_matrix_cores(prev)` is safe anywhere)."""
     L = _lib.lib()
     prev = bool(L.slak_get_fp32_matrix_cores())
     _lib.check(L.slak_set_fp32_matrix_cores(1 if allow else 0), "slak_set_fp32_matrix_cores")

@@ -240,14 +240,19 @@ class Block(nn.Module):
 class _Stage(nn.Sequential):
     """A stage of blocks (models/SLaK.py:201-206 builds an nn.Sequential; this IS one: same state-dict keys, indexing, iteration).  Its
     forward hands each block's low-precision output copy to the next block explicitly, so every module boundary carries a Tensor.  A block
-    with forward (pre-)hooks is called through ``__call__`` like any module -- the hooks see tensors -- and simply gets no hand-off."""
+    with forward (pre-)hooks or backward (pre-)hooks is called through ``__call__`` like any module -- the hooks see tensors -- and simply gets
+    no hand-off."""
 
     def forward(self, x):
         import torch.nn.modules.module as _m
-        global_hooks = bool(_m._global_forward_hooks or _m._global_forward_pre_hooks or getattr(_m, "_global_forward_hooks_always_called", None))
+        # the fast-path test of nn.Module._call_impl: ANY hook -- forward, forward-pre, full backward, backward-pre, per module or global --
+        # sends the block through __call__ (register_full_backward_hook on a Block fires as on any module)
+        global_hooks = bool(_m._global_forward_hooks or _m._global_forward_pre_hooks or _m._global_backward_hooks or _m._global_backward_pre_hooks
+                            or getattr(_m, "_global_forward_hooks_always_called", None))
         lowp = None
         for blk in self:
-            if isinstance(blk, Block) and not (global_hooks or blk._forward_hooks or blk._forward_pre_hooks):
+            if isinstance(blk, Block) and not (global_hooks or blk._forward_hooks or blk._forward_pre_hooks or blk._backward_hooks
+                                               or blk._backward_pre_hooks):
                 x, lowp = blk.forward_pair(x, lowp)
             else:
                 x, lowp = blk(x), None

@@ -49,24 +49,32 @@ def test_fp32_matrix_core_switches_are_host_state(built_lib):
     import threading
     from slak_amd import _lib, ops
     L = _lib.lib()
-    assert L.slak_get_fp32_matrix_cores() == 0
+    eff, glob = L.slak_get_fp32_matrix_cores_effective, L.slak_get_fp32_matrix_cores
+    assert glob() == 0 and eff() == 0
     with ops.fp32_matrix_cores(True):
-        assert L.slak_get_fp32_matrix_cores() == 1
+        assert eff() == 1 and glob() == 0                          # the override is this thread's; the process-wide switch is untouched
         with ops.fp32_matrix_cores(False):
-            assert L.slak_get_fp32_matrix_cores() == 0
-        assert L.slak_get_fp32_matrix_cores() == 1
+            assert eff() == 0
+        assert eff() == 1
         seen = []
-        t = threading.Thread(target=lambda: seen.append(L.slak_get_fp32_matrix_cores()))
+        t = threading.Thread(target=lambda: seen.append(eff()))
         t.start(); t.join()
         assert seen == [0]                                         # another thread follows the process-wide setting
-    assert L.slak_get_fp32_matrix_cores() == 0
+        # a save / restore pair INSIDE an override must not write the override into the process-wide switch
+        prev = ops.allow_fp32_matrix_cores(False)
+        assert prev is False
+        ops.allow_fp32_matrix_cores(prev)
+        assert glob() == 0
+    assert eff() == 0 and glob() == 0
     prev = ops.allow_fp32_matrix_cores(True)
     try:
-        assert prev is False and L.slak_get_fp32_matrix_cores() == 1
+        assert prev is False and glob() == 1 and eff() == 1
         with ops.fp32_matrix_cores(False):
-            assert L.slak_get_fp32_matrix_cores() == 0
+            assert eff() == 0 and glob() == 1
+            assert ops.allow_fp32_matrix_cores(True) is True       # reports the switch, not the override
     finally:
         ops.allow_fp32_matrix_cores(prev)
+    assert glob() == 0
     assert L.slak_set_fp32_matrix_cores_thread(7, None) == 1       # SLAK_ERR_INVALID_ARG
     # shapes AUTO takes to the matrix cores need scratch for the packed filter fragments, per chunk of five rows
     assert L.slak_dwconv2d_workspace_bytes(0, 8, 16, 32, 32, 31, 31, 2) >= 7 * L.slak_dwconv2d_workspace_bytes(0, 8, 16, 32, 32, 5, 31, 2) // 2

@@ -85,32 +85,11 @@ def test_fp32_stays_exact_unless_allowed(gpu):
         ops.allow_fp32_matrix_cores(prev)
 
 
-def test_fp32_split_at_the_stage_1_shape_is_faster_than_the_exact_kernels(gpu, split_on):
-    """Not a benchmark -- a guard that the switch does what it is for: the 5 x 51 stage-1 forward (N = 64; measured 2.4x apart at N = 128)."""
-    from slak_amd import ops
-    x = torch.randn(64, 96, 56, 56, device=gpu); w = torch.randn(96, 1, 5, 51, device=gpu) * 0.02
-
-    def timed():
-        for _ in range(3):
-            ops.dwconv2d_forward(x, w)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(10):
-            ops.dwconv2d_forward(x, w)
-        e1.record(); e1.synchronize()
-        return e0.elapsed_time(e1) / 10
-    t_split = timed()
-    ops.allow_fp32_matrix_cores(False)
-    t_exact = timed()
-    ops.allow_fp32_matrix_cores(True)
-    print("5x51 fwd fp32, N=64: split %.3f ms, exact %.3f ms" % (t_split, t_exact))
-    assert t_split < t_exact
-
-
-def test_fp32_under_autocast_runs_on_the_matrix_cores_and_plain_fp32_stays_exact(gpu):
-    """The op module's policy (slak_amd/depthwise_conv2d_implicit_gemm.py): entered under torch.autocast with an fp32 activation -- the
-    reference's default AMP flow, depthwise_conv2d_implicit_gemm.py:16 -- forward, data gradient and weight gradient take the two-term split;
-    without autocast, or with the class switch off, the exact kernels; results stay fp32 either way."""
+def test_fp32_under_autocast_is_exact_by_default_and_takes_the_matrix_cores_when_opted_in(gpu):
+    """The op module's policy (slak_amd/depthwise_conv2d_implicit_gemm.py): by default an fp32 activation runs the exact kernels, in and out of
+    torch.autocast, and follows the process-wide switch.  With the class switch ON (opt-in), an fp32 activation entered under
+    torch.autocast -- the reference's default AMP flow, depthwise_conv2d_implicit_gemm.py:16 -- takes the two-term split in forward, data
+    gradient and weight gradient; results stay fp32 either way."""
     from slak_amd import _lib
     from slak_amd.depthwise_conv2d_implicit_gemm import DepthWiseConv2dImplicitGEMM
     L = _lib.lib()
@@ -119,8 +98,26 @@ def test_fp32_under_autocast_runs_on_the_matrix_cores_and_plain_fp32_stays_exact
     x = torch.randn(3, 6, 28, 28, device=gpu, requires_grad=True)
     y0 = m(x)
     assert L.slak_debug_last_kernel() == b"dwconv_direct" and y0.dtype == torch.float32
+    assert DepthWiseConv2dImplicitGEMM.fp32_matrix_cores_under_autocast is False            # the default: opt-in
     with torch.autocast("cuda", dtype=torch.bfloat16):
-        y1 = m(x)
+        yd = m(x)
+    assert L.slak_debug_last_kernel() == b"dwconv_direct" and torch.equal(yd, y0)
+    from slak_amd import ops
+    prev = ops.allow_fp32_matrix_cores(True)                                               # the process-wide switch is followed ...
+    try:
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            m(x)
+        assert L.slak_debug_last_kernel() == b"dwconv_mfma(f32 split)"
+    finally:
+        ops.allow_fp32_matrix_cores(prev)
+    with torch.autocast("cuda", dtype=torch.bfloat16):                                     # ... and restoring it restores exact fp32
+        assert torch.equal(m(x), y0)
+    DepthWiseConv2dImplicitGEMM.fp32_matrix_cores_under_autocast = True
+    try:
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            y1 = m(x)
+    finally:
+        DepthWiseConv2dImplicitGEMM.fp32_matrix_cores_under_autocast = False
     assert L.slak_debug_last_kernel() == b"dwconv_mfma(f32 split)" and y1.dtype == torch.float32
     assert (y1 - y0).abs().max().item() <= 1e-4 * y0.abs().max().item()
     dy = torch.randn_like(y0)
@@ -129,11 +126,4 @@ def test_fp32_under_autocast_runs_on_the_matrix_cores_and_plain_fp32_stays_exact
     assert gx1.dtype == torch.float32 and gw1.dtype == torch.float32
     for a, b in ((gx1, gx0), (gw1, gw0)):
         assert not torch.equal(a, b) and (a - b).abs().max().item() <= 1e-4 * b.abs().max().item()
-    assert L.slak_get_fp32_matrix_cores() == 0                                    # the per-thread override did not leak
-    DepthWiseConv2dImplicitGEMM.fp32_matrix_cores_under_autocast = False
-    try:
-        with torch.autocast("cuda", dtype=torch.bfloat16):
-            y2 = m(x)
-        assert L.slak_debug_last_kernel() == b"dwconv_direct" and torch.equal(y2, y0)
-    finally:
-        DepthWiseConv2dImplicitGEMM.fp32_matrix_cores_under_autocast = True
+    assert L.slak_get_fp32_matrix_cores_effective() == 0                          # the per-thread override did not leak
