@@ -118,6 +118,8 @@ def parse():
     ap.add_argument("--no-fused-tail", action="store_true", help="run the block tail (permute/LayerNorm/gamma/residual) as the reference's PyTorch ops")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl", help="torch.distributed backend at N>1: nccl (= RCCL over xGMI) or gloo (CPU-staged; lets the N>1 code path run with several ranks on ONE GPU)")
     ap.add_argument("--device", type=int, default=None, help="GPU index of this rank (default LOCAL_RANK); --device 0 on every rank shares one GPU (gloo)")
+    ap.add_argument("--markers", action="store_true", help="bracket the K timed steps with two empty marker launches (slak_debug_marker ids 1 and 2): "
+                                                            "tools/step_breakdown.py cuts a rocprofv3 kernel trace exactly there")
     ap.add_argument("--per-step-sync", action="store_true", help="torch.cuda.synchronize() after every step, as engine.py:90 does (default: the K steps are only bracketed)")
     return ap.parse_args()
 
@@ -137,7 +139,7 @@ def event_time_ms(fn, reps, stream_device):
     return e0.elapsed_time(e1) / reps
 
 
-def hot_path_kernels(device, batch, reps, dtype, stages):
+def hot_path_kernels(device, batch, reps, dtype, stages, plain_too=True):
     """Every distinct launch of the dw-conv hot path at the bench shapes AS THE MODEL RUNS IT, timed alone: the C-ABI entry points
     are called directly on preallocated buffers (the tensor-level wrappers of slak_amd.ops add ~10 us of host work per call,
     more than the smallest kernels take), HIP events on the launch stream around `reps` back-to-back launches.
@@ -150,11 +152,13 @@ def hot_path_kernels(device, batch, reps, dtype, stages):
                   the K x 5 and the 5 x 5 branch (`pair`, where slak_dwconv2d_pair_filter_workspace_bytes > 0) beside the 5 x K launch.
     Algorithmic bytes: SURVEY.md 8(d) per op -- 2*S*b (+ C*kh*kw*4); a three-branch (two-branch) launch is priced at the per-op figure
     of the three (two) ops it replaces (3 x 2*S*b, 2 x 2*S*b), as 8(d) prescribes."""
-    from slak_amd import _lib, ops
+    import ctypes
+    from slak_amd import _lib, ops, block_ops
     L = _lib.lib()
     st = torch.cuda.current_stream(device).cuda_stream
     out = []
     b = 2 if dtype != torch.float32 else 4
+    stats_in_conv = bool(block_ops.bn_stats_in_conv)
     # the GPU has idled through the CPU baselines by now: ~0.3 s of work first, as the --prime steps do for the training loop (clocks ramp up
     # slowly: the first launches after an idle period measured 10-15 % slower than the same launches in tools/time_all.py)
     wa = torch.randn(4096, 4096, device=device, dtype=torch.bfloat16)
@@ -194,7 +198,18 @@ def hot_path_kernels(device, batch, reps, dtype, stages):
             a_tf = (x.data_ptr(), wts[0].data_ptr(), wts[1].data_ptr(), wts[2].data_ptr(), ys[0].data_ptr(), ys[1].data_ptr(), ys[2].data_ptr(), dt, batch, C, HW, HW, K, st)
             a_td = (dys[0].data_ptr(), dys[1].data_ptr(), dys[2].data_ptr(), wts[0].data_ptr(), wts[1].data_ptr(), wts[2].data_ptr(), ys[0].data_ptr(), dt, batch, C, HW, HW, K, st)
             if tri_f:
-                add("%dx5+5x%d+5x5" % (K, K), "tri", "fwd", lambda: _lib.check(L.slak_dwconv2d_tri_forward(*a_tf)), 3 * 2 * S * b + wbytes, flops3)
+                # the model (block_ops._TriDwConv, training) launches the variant that also gathers the branch BatchNorms' batch sums
+                # wherever it exists (SLAK_BN_STATS_IN_CONV, default on): THAT launch is timed; the plain one is kept beside it
+                rows = int(L.slak_dwconv2d_tri_stats_rows(dt, batch, C, HW, HW, K)) if stats_in_conv else 0
+                if rows > 0:
+                    stt = torch.empty((rows, C, 6), dtype=torch.float32, device=device)
+                    a_ts = a_tf[:7] + (stt.data_ptr(),) + a_tf[7:]
+                    add("%dx5+5x%d+5x5" % (K, K), "tri", "fwd", lambda: _lib.check(L.slak_dwconv2d_tri_forward_stats(*a_ts)), 3 * 2 * S * b + wbytes, flops3)
+                    out[-1]["variant"] = "forward + BatchNorm batch sums (slak_dwconv2d_tri_forward_stats: what the training step launches)"
+                    if plain_too:                                  # (tools/time_all.py under a profiler: one dispatch group per entry)
+                        out[-1]["plain_forward_ms"] = event_time_ms(lambda: _lib.check(L.slak_dwconv2d_tri_forward(*a_tf)), reps, device)
+                else:
+                    add("%dx5+5x%d+5x5" % (K, K), "tri", "fwd", lambda: _lib.check(L.slak_dwconv2d_tri_forward(*a_tf)), 3 * 2 * S * b + wbytes, flops3)
             if tri_d:
                 add("%dx5+5x%d+5x5" % (K, K), "tri", "bwd_data", lambda: _lib.check(L.slak_dwconv2d_tri_backward_data(*a_td)), 3 * 2 * S * b + wbytes, flops3)
         pair_nb = int(L.slak_dwconv2d_pair_filter_workspace_bytes(dt, batch, C, HW, HW, K)) if (dtype != torch.float32 and not tri_w_nb) else 0
@@ -218,7 +233,17 @@ def hot_path_kernels(device, batch, reps, dtype, stages):
             a_w = (dys[0].data_ptr(), dt, x.data_ptr(), dt, dw.data_ptr()) + dims + (ws.data_ptr(), ws.numel(), st)
             kn, flop, wb = "%dx%d" % (kh, kw), 2.0 * S * kh * kw, C * kh * kw * 4
             if not tri_f:
-                add(kn, kname, "fwd", lambda: _lib.check(L.slak_dwconv2d_forward(*a_f)), 2 * S * b + wb, flop)
+                st_ok = False
+                if stats_in_conv and dtype == torch.bfloat16:      # per-branch launches that gather their BatchNorm's sums (ops.dwconv2d_forward_stats)
+                    stb = torch.empty((4 * batch, C, 2), dtype=torch.float32, device=device)
+                    rws = ctypes.c_int(0)
+                    a_fs = (x.data_ptr(), dt, w.data_ptr(), _lib.SLAK_F32, ys[0].data_ptr(), dt, stb.data_ptr(), 4 * batch, ctypes.byref(rws)) + dims + (st,)
+                    st_ok = L.slak_dwconv2d_forward_stats(*a_fs) == _lib.OK
+                if st_ok:
+                    add(kn, kname, "fwd", lambda: _lib.check(L.slak_dwconv2d_forward_stats(*a_fs)), 2 * S * b + wb, flop)
+                    out[-1]["variant"] = "forward + BatchNorm batch sums (slak_dwconv2d_forward_stats: what the training step launches)"
+                else:
+                    add(kn, kname, "fwd", lambda: _lib.check(L.slak_dwconv2d_forward(*a_f)), 2 * S * b + wb, flop)
             if not tri_d:
                 acc_ok = bi > 0 and dtype != torch.float32 and L.slak_dwconv2d_backward_data_accumulate(*a_d) == _lib.OK
                 if acc_ok:
@@ -505,12 +530,17 @@ def main():
     if distributed:
         dist.barrier()
     torch.cuda.synchronize()
+    if a.markers:
+        from slak_amd import _lib as _mk
+        _mk.check(_mk.lib().slak_debug_marker(1, torch.cuda.current_stream(device).cuda_stream), "slak_debug_marker")
     host_s = 0.0                                                  # time the host spends ENQUEUEING the steps (no sync inside)
     t0 = time.perf_counter()
     for _ in range(a.steps):
         h0 = time.perf_counter()
         loss = step()
         host_s += time.perf_counter() - h0
+    if a.markers:
+        _mk.check(_mk.lib().slak_debug_marker(2, torch.cuda.current_stream(device).cuda_stream), "slak_debug_marker")
     if distributed:
         dist.barrier()
     torch.cuda.synchronize()
@@ -599,6 +629,12 @@ def main():
                            "avg_launch_ms": dom["ms"], "alg_bytes_per_launch": dom["alg_bytes"],
                            "valu_tflops_nominal": dom["gflop_nominal"] / dom["ms"]}
         assert abs(hot_bytes - survey_8d_bytes(stages, a.batch, 4 if a.fp32_dwconv else 2)) <= 1e-6 * hot_bytes, "the launches timed do not add up to SURVEY 8(d)'s per-op bytes"
+        # the PATH-level figures inside `roofline` as well (the north star's target is on the path): every dw-conv launch of a step, as the
+        # step launches it (statistics-gathering forward variants included), algorithmic bytes / summed launch time
+        out["roofline"].update({"path_frac": hot_bytes / hot_ms / 1e6 / HBM_PEAK_GBS, "path_achieved": hot_bytes / hot_ms / 1e6,
+                                "path_ms_per_step": hot_ms, "path_alg_gb_per_step": hot_bytes / 1e9,
+                                "path_lowest_launch_frac": min(k["gbs"] for k in kl) / HBM_PEAK_GBS,
+                                "path_traffic_gb_per_step": (hot_bytes_pmc / 1e9) if hot_bytes_pmc else None})
         out["hot_path"] = {"dwconv_ms_per_step": hot_ms, "dwconv_alg_gb_per_step": hot_bytes / 1e9,
                            "dwconv_gbs": hot_bytes / hot_ms / 1e6, "dwconv_frac_of_hbm_peak": hot_bytes / hot_ms / 1e6 / HBM_PEAK_GBS,
                            "pricing": "SURVEY 8(d): 2*S*b per op and pass; a launch that replaces several ops is priced at the ops it replaces",
@@ -610,6 +646,9 @@ def main():
                            "kernels": [{k2: (round(v, 4) if isinstance(v, float) else v) for k2, v in k.items()} for k in kl]}
     if rank == 0 and not a.no_mask_bench:
         out["mask_step"] = mask_step_bench(device, a.model, ks, a.only_L)
+        if "roofline" in out:
+            out["roofline"]["mask_apply_frac"] = out["mask_step"]["apply_frac_of_hbm_peak"]
+            out["roofline"]["mask_update_frac"] = out["mask_step"]["update_frac_of_hbm_peak"]
     if rank == 0 and n_gpus == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(min(os.cpu_count() or 1, 32), stages, label)   # >32 threads only oversubscribes a 96-channel depthwise conv
     if rank == 0:

@@ -158,6 +158,9 @@ int slak_mask_checksum(slak_mask_plan_t* plan, unsigned long long* out_host, voi
  * slak_debug_last_kernel(): name of the kernel family the calling thread's last conv entry point launched (dispatch tests). */
 int slak_dwconv2d_tri_supported_op(int dtype, int N, int C, int H, int W, int K, int op);
 const char* slak_debug_last_kernel(void);
+/* An empty kernel `slak::marker_kernel` with grid = id + 1 workgroups on `stream` (0 <= id <= 65535): a cut mark in a kernel trace
+ * (bench.py --markers brackets its K timed steps with ids 1 and 2; tools/step_breakdown.py reads them). */
+int slak_debug_marker(int id, void* stream);
 int slak_dwconv2d_tri_supported(int dtype, int N, int C, int H, int W, int K);
 int slak_dwconv2d_tri_forward(const void* x, const float* w_v, const float* w_h, const float* w_s, void* y_v, void* y_h, void* y_s,
                               int dtype, int N, int C, int H, int W, int K, void* stream);

@@ -101,6 +101,7 @@ SIGNATURES = {
     "slak_dwconv2d_tri_supported": (_i, [_i, _i, _i, _i, _i, _i]),
     "slak_dwconv2d_tri_supported_op": (_i, [_i, _i, _i, _i, _i, _i, _i]),
     "slak_debug_last_kernel": (ctypes.c_char_p, []),
+    "slak_debug_marker": (_i, [_i, _vp]),
     "slak_dwconv2d_tri_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "slak_dwconv2d_tri_backward_data": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "slak_dwconv2d_tri_filter_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i]),

@@ -67,6 +67,16 @@ void slak_debug_set_phase_buffer(void* p) { slak::g_dma_dbg = (unsigned long lon
  * predicate that regresses lands a shape on a slower kernel with parity intact; this is what the dispatch tests pin */
 const char* slak_debug_last_kernel(void) { return slak::g_last_kernel; }
 
+// An empty launch whose GRID SIZE carries an id: profiling tools cut a kernel trace at these (tools/step_breakdown.py takes exactly the
+// dispatches between marker 1 and marker 2 of bench.py --markers: the K timed steps, nothing else)
+namespace slak { __global__ void marker_kernel(int id) { (void)id; } }
+int slak_debug_marker(int id, void* stream) {
+    if (id < 0 || id > 65535) return SLAK_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(slak::marker_kernel, dim3((unsigned)(id + 1)), dim3(64), 0, (hipStream_t)stream, id);
+    SLAK_LAUNCH_CHECK();
+    return SLAK_OK;
+}
+
 const char* slak_status_string(int status) {
     switch (status) {
         case SLAK_OK: return "ok";

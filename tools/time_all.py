@@ -14,7 +14,7 @@ batch = a.batch or (64 if (a.model == "base" or a.res != 224) else 128)
 dev = torch.device("cuda:0")
 reps = int(os.environ.get("SLAK_TIME_ALL_REPS", "0")) or 30
 stages = bench.stages_of(a.model, a.kernel, a.res)
-kl = bench.hot_path_kernels(dev, batch, reps, torch.bfloat16, stages)
+kl = bench.hot_path_kernels(dev, batch, reps, torch.bfloat16, stages, plain_too=False)
 tot = byt = 0.0
 print("%-5s %-22s %-5s %-10s %9s %6s %8s %6s  %s" % ("stage", "kernel", "kind", "op", "us", "calls", "GB/s", "frac", "hip kernel"))
 for k in kl:
@@ -24,6 +24,6 @@ for k in kl:
                                                        gbs / bench.HBM_PEAK_GBS, k.get("hip_kernel")))
 if os.environ.get("SLAK_TIME_ALL_JSON"):
     import json
-    keep = ("stage", "kernel", "branch", "op", "alg_bytes", "alg_bytes_incl_acc_read", "hip_kernel", "calls_per_step", "ms")
+    keep = ("stage", "kernel", "branch", "op", "alg_bytes", "alg_bytes_incl_acc_read", "hip_kernel", "calls_per_step", "ms", "variant")
     json.dump([{k: e.get(k) for k in keep} for e in kl], open(os.environ["SLAK_TIME_ALL_JSON"], "w"), indent=1)
 print("dw-conv hot path per step: %.3f ms, %.3f GB (SURVEY 8d), %.3f of the %.0f GB/s HBM peak" % (tot, byt / 1e9, byt / tot / 1e6 / bench.HBM_PEAK_GBS, bench.HBM_PEAK_GBS))
