@@ -1,0 +1,496 @@
+// slak_amd/csrc/dwconv_mfma_tri_wgrad_rows.hip -- the THREE weight gradients of a decomposed block (K x 5, 5 x K, 5 x 5: models/SLaK.py:82-100;
+// the reference runs backward_filter_fp16.cu:181-243 once per branch) in ONE launch on planes of 2 x 2 MFMA tiles (32 < H, W <= 64, W % 8 == 0:
+// the 56 x 56 stage, 48 x 48, 64 x 64).  x is fetched from HBM once for the three correlations (4 plane reads per block instead of 6).
+//
+//   vertical   (K x 5)  G^v_r[o, i] = sum_{n,u} dYv[o, u] X[i, u + r - 2]   o, i = image ROWS,    contraction along a row     dw_v[tau, r] = sum_o G^v_r[o, o+tau-padL]
+//   small      (5 x 5)  G^s_r[o, i] = sum_{n,u} dYs[o, u] X[i, u + r - 2]   (the vertical correlation with its own dY: same B operands) dw_s[tau, r], |tau-2| <= 2
+//   horizontal (5 x K)  G^h_r[o, i] = sum_{n,y} dYh[y, o] X[y + r - 2, i]   o, i = image COLUMNS, contraction along a column  dw_h[r, tau] = sum_o G^h_r[o, o+tau-padL]
+//
+// One LDS image per tensor and plane, rows of CPR 16-byte chunks (CPR odd, >= W/8 + 1: the pad chunks are never written and read as the
+// zero padding), landed by LDS-DMA.  The vertical / small operands are 16-byte row reads, the five column shifts of X formed in registers
+// from a six-dword window (dwconv_mfma_wgrad_vrows.hip); the horizontal operands are transposing reads (ds_read_b64_tr_b16) of the SAME
+// images, and its five ROW shifts are the same six-dword window arithmetic on a twelve-row column segment (three transposing reads)
+// -- so every k-step of either kind costs five LDS reads, eight v_alignbit and a few moves beside its ten / five MFMAs.
+//
+// A workgroup is four waves, ONE PER SIMD (15 accumulators of 16 registers: the kernel is compiled for one wave per SIMD and 512
+// registers); wave (mt, nt) owns tile (mt, nt) of all three correlations over the workgroup's batch slice.  With nobody to share a SIMD with,
+// the MFMA pipe only stays busy if the wave's own stream does: every k-step is software-pipelined by hand -- the LDS reads and the
+// shift arithmetic of step j + 1 and one LDS-DMA piece of plane i + 2 are placed behind the MFMAs of step j and pinned with
+// sched_barrier (hipcc otherwise gathers them in front of the MFMAs: measured 73 cycles per MFMA for the compiler-ordered loop of the
+// two-branch kernel when it runs alone on a SIMD, against the pipe's 32).  Three ring slots; one workgroup barrier per plane.
+// Epilogue (skewed per-wave tile for the diagonal sums, write-through partials, last-arriver reduction in slice order): as in the
+// other MFMA weight-gradient kernels -- deterministic, no atomics on data.
+#include "mfma_common.h"
+#include <stdlib.h>
+
+namespace slak {
+
+constexpr int TW_NB = 3;                // ring slots: plane i is consumed while i + 1 has landed / is landing and i + 2 is requested
+constexpr int TW_J = 3;                 // DMA instructions per wave and plane copy (upper bound: ceil(ipc / 4), ipc <= 12)
+constexpr unsigned TW_OOB = 0x80000000u;   // source offset of a lane with nothing to fetch: out of range -> the DMA writes zeros (into padding)
+
+struct TriRowsParams {
+    const void* dy[3];                  // dY of the K x 5, 5 x K, 5 x 5 branch
+    const void* x; float* partial; float* dw[3]; unsigned* counters;
+    int N, C, H, W, K, padL;
+    int CPR;               // 16-byte chunks per LDS row (odd, >= 2 * KS + 1)
+    int ipc;               // DMA instructions per plane copy: ceil(H * CPR / 64)
+    int RS;                // rows per plane copy in LDS (>= 16 * KS + 4: the rows behind the image stay zero)
+    int per, grid;         // planes per workgroup, workgroups: workgroup b owns planes [b * per, b * per + per) of the C * N planes in (channel, image) order
+    int maxspan;           // channels such a range can touch (partial records per workgroup)
+    unsigned tensor_bytes;
+    int dbg;               // SLAK_TRIROWS_DBG (timing experiments): 1 = no k-loops, 2 = no DMA, 4 = no epilogue, 8 = no wait / barrier
+};
+
+// buffer_load_dwordx4 ... lds without saving M0 around it (lds_dma16 of mfma_common.h does)
+__device__ __forceinline__ void tw_dma16(unsigned voff, v4i_t rsrc, unsigned lds_dst) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds" :: "v"(voff), "s"(rsrc), "s"(lds_dst) : "memory");
+}
+
+// the five shifted operands from a six-dword window: tap r = the eight 16-bit elements that start r elements behind the window's first
+__device__ __forceinline__ void tw_taps(s16x8 (&b)[MF_TAPS], unsigned d0, unsigned d1, unsigned d2, unsigned d3, unsigned d4, unsigned d5) {
+    auto sh = [](unsigned hi, unsigned lo) -> unsigned { return __builtin_amdgcn_alignbit(hi, lo, 16); };
+    b[0] = __builtin_bit_cast(s16x8, u32x4{d0, d1, d2, d3});
+    b[1] = __builtin_bit_cast(s16x8, u32x4{sh(d1, d0), sh(d2, d1), sh(d3, d2), sh(d4, d3)});
+    b[2] = __builtin_bit_cast(s16x8, u32x4{d1, d2, d3, d4});
+    b[3] = __builtin_bit_cast(s16x8, u32x4{sh(d2, d1), sh(d3, d2), sh(d4, d3), sh(d5, d4)});
+    b[4] = __builtin_bit_cast(s16x8, u32x4{d2, d3, d4, d5});
+}
+
+// The fifteen accumulators are the accumulator registers a[0:239], NAMED in the instruction text: a[0:79] the vertical branch's five taps,
+// a[80:159] the small branch's, a[160:239] the horizontal one's.  (As C++ values -- builtin MFMAs, or inline asm with "+a" operands -- hipcc
+// carries them over the loop's back edge in VGPRs and copies sixteen registers in and out around every MFMA: 480 v_accvgpr moves per
+// plane.)  Registers written literally belong to the kernel only because tw_acc_claim() lists them as clobbers (that also makes the kernel
+// descriptor allocate them); the compiler's own code stays below 256 VGPRs and never touches the accumulator file -- audited in the ISA
+// after every edit: no v_accvgpr_* outside ASMSTART / ASMEND, no scratch.  Each string carries its own wait states (hipcc pads nothing
+// inside an asm statement): a VALU-written A / B operand -> MFMA needs two; an MFMA's D is only read by the next MFMA that takes it whole as
+// C (none) and, after the loop and a barrier, by tw_acc_read (16 states in front of the first read).
+constexpr int TW_ACC_V = 0, TW_ACC_S = 80, TW_ACC_H = 160;
+__device__ __forceinline__ void tw_acc_claim() {
+    asm volatile("" ::: "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15", "a16", "a17", "a18", "a19", "a20", "a21", "a22", "a23", "a24", "a25", "a26", "a27", "a28", "a29", "a30", "a31", "a32", "a33", "a34", "a35", "a36", "a37", "a38", "a39", "a40", "a41", "a42", "a43", "a44", "a45", "a46", "a47", "a48", "a49", "a50", "a51", "a52", "a53", "a54", "a55", "a56", "a57", "a58", "a59", "a60", "a61", "a62", "a63", "a64", "a65", "a66", "a67", "a68", "a69", "a70", "a71", "a72", "a73", "a74", "a75", "a76", "a77", "a78", "a79", "a80", "a81", "a82", "a83", "a84", "a85", "a86", "a87", "a88", "a89", "a90", "a91", "a92", "a93", "a94", "a95", "a96", "a97", "a98", "a99", "a100", "a101", "a102", "a103", "a104", "a105", "a106", "a107", "a108", "a109", "a110", "a111", "a112", "a113", "a114", "a115", "a116", "a117", "a118", "a119", "a120", "a121", "a122", "a123", "a124", "a125", "a126", "a127", "a128", "a129", "a130", "a131", "a132", "a133", "a134", "a135", "a136", "a137", "a138", "a139", "a140", "a141", "a142", "a143", "a144", "a145", "a146", "a147", "a148", "a149", "a150", "a151", "a152", "a153", "a154", "a155", "a156", "a157", "a158", "a159", "a160", "a161", "a162", "a163", "a164", "a165", "a166", "a167", "a168", "a169", "a170", "a171", "a172", "a173", "a174", "a175", "a176", "a177", "a178", "a179", "a180", "a181", "a182", "a183", "a184", "a185", "a186", "a187", "a188", "a189", "a190", "a191", "a192", "a193", "a194", "a195", "a196", "a197", "a198", "a199", "a200", "a201", "a202", "a203", "a204", "a205", "a206", "a207", "a208", "a209", "a210", "a211", "a212", "a213", "a214", "a215", "a216", "a217", "a218", "a219", "a220", "a221", "a222", "a223", "a224", "a225", "a226", "a227", "a228", "a229", "a230", "a231", "a232", "a233", "a234", "a235", "a236", "a237", "a238", "a239");
+}
+template <int LO, int HI> __device__ __forceinline__ void tw_acc_zero() {
+    if constexpr (LO < HI) {
+        asm volatile("v_accvgpr_write_b32 a[%c0], 0\n\tv_accvgpr_write_b32 a[%c1], 0\n\tv_accvgpr_write_b32 a[%c2], 0\n\tv_accvgpr_write_b32 a[%c3], 0"
+                     :: "i"(LO), "i"(LO + 1), "i"(LO + 2), "i"(LO + 3));
+        tw_acc_zero<LO + 4, HI>();
+    }
+}
+// (s_nop 1 in EVERY string: hipcc is free to sink a v_perm / v_mov that forms a B operand down to right in front of the MFMA that reads it --
+// it did, and without the two wait states that MFMA read the register's previous content: wrong sums that changed from run to run)
+template <typename T, int BASE> __device__ __forceinline__ void tw_mfma(s16x8 a, s16x8 b) {
+    if constexpr (dtype_of<T>::value == SLAK_BF16)
+        asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 a[%c2:%c3], %0, %1, a[%c2:%c3]" :: "v"(a), "v"(b), "i"(BASE), "i"(BASE + 15));
+    else
+        asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_f16 a[%c2:%c3], %0, %1, a[%c2:%c3]" :: "v"(a), "v"(b), "i"(BASE), "i"(BASE + 15));
+}
+template <int BASE> __device__ __forceinline__ void tw_acc_read(float (&v)[16]) {
+    asm volatile("s_nop 15\n\t"
+                 "v_accvgpr_read_b32 %0, a[%c16]\n\tv_accvgpr_read_b32 %1, a[%c17]\n\tv_accvgpr_read_b32 %2, a[%c18]\n\tv_accvgpr_read_b32 %3, a[%c19]\n\t"
+                 "v_accvgpr_read_b32 %4, a[%c20]\n\tv_accvgpr_read_b32 %5, a[%c21]\n\tv_accvgpr_read_b32 %6, a[%c22]\n\tv_accvgpr_read_b32 %7, a[%c23]\n\t"
+                 "v_accvgpr_read_b32 %8, a[%c24]\n\tv_accvgpr_read_b32 %9, a[%c25]\n\tv_accvgpr_read_b32 %10, a[%c26]\n\tv_accvgpr_read_b32 %11, a[%c27]\n\t"
+                 "v_accvgpr_read_b32 %12, a[%c28]\n\tv_accvgpr_read_b32 %13, a[%c29]\n\tv_accvgpr_read_b32 %14, a[%c30]\n\tv_accvgpr_read_b32 %15, a[%c31]"
+                 : "=v"(v[0]), "=v"(v[1]), "=v"(v[2]), "=v"(v[3]), "=v"(v[4]), "=v"(v[5]), "=v"(v[6]), "=v"(v[7]),
+                   "=v"(v[8]), "=v"(v[9]), "=v"(v[10]), "=v"(v[11]), "=v"(v[12]), "=v"(v[13]), "=v"(v[14]), "=v"(v[15])
+                 : "i"(BASE), "i"(BASE + 1), "i"(BASE + 2), "i"(BASE + 3), "i"(BASE + 4), "i"(BASE + 5), "i"(BASE + 6), "i"(BASE + 7),
+                   "i"(BASE + 8), "i"(BASE + 9), "i"(BASE + 10), "i"(BASE + 11), "i"(BASE + 12), "i"(BASE + 13), "i"(BASE + 14), "i"(BASE + 15));
+}
+
+// diagonal sums of the five taps of one branch through the wave's skewed tile (G[o][i] -> row o, column i - o + 31: a diagonal is a column)
+template <int BASE, int G>
+__device__ __forceinline__ void tw_diag(float* tile, float* wr, bool col_ok, int o_max, int lane, int lhi, int dtau, int KL, float* out, int s_tau, int s_g) {
+    if constexpr (G < MF_TAPS) {
+        float v[16];
+        tw_acc_read<BASE + 16 * G>(v);
+        if (col_ok) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if ((r & 3) + 8 * (r >> 2) + 4 * lhi < o_max) wr[((r & 3) + 8 * (r >> 2)) * 63] = v[r];
+        }
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (lane < 63) {
+            float part[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int o = 0; o < 32; ++o) part[o & 3] += tile[o * 64 + lane];
+            const int tau = lane + dtau;
+            if (tau >= 0 && tau < KL) out[tau * s_tau + G * s_g] = (part[0] + part[1]) + (part[2] + part[3]);
+        }
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        tw_diag<BASE, G + 1>(tile, wr, col_ok, o_max, lane, lhi, dtau, KL, out, s_tau, s_g);
+    }
+}
+
+// KS: 16-deep k-steps of both contractions (ceil(max(H, W) / 16): 3 or 4); CPRC: chunks per LDS row as a compile-time constant (every
+// fragment offset of a plane is then an instruction immediate)
+template <typename T, int KS, int CPRC>
+__global__ __launch_bounds__(MF_THREADS, 1) void dwconv_mfma_tri_wgrad_rows_kernel(const TriRowsParams p) {
+    constexpr int NG = MF_TAPS;
+    constexpr unsigned PB = (unsigned)CPRC * 16;                  // row pitch (bytes)
+    constexpr unsigned RSC = KS == 3 ? 56 : 68;                   // rows per copy: >= 16 KS + 4, and a copy's DMA instructions (whole KiB) end inside it
+    constexpr unsigned copy_b = RSC * PB;                         // [dYv][X][dYs][dYh]: X's rows -2, -1 are the (zero) tail of dYv's copy
+    constexpr unsigned slot_b = 4 * copy_b;
+    constexpr unsigned ring_b = 64;                               // zero bytes in front ("chunk -1" of the first row)
+    extern __shared__ __attribute__((aligned(16))) uint16_t lds[];
+    char* const LB = (char*)lds;
+    const int HW = p.H * p.W, ntl = p.K * MF_TAPS, ntot = 2 * ntl + MF_TAPS * MF_TAPS;
+    float* scratch = (float*)(LB + ring_b + TW_NB * slot_b);      // [MF_WAVES][32][64] skewed tiles of the diagonal sums (NOT in the ring: a workgroup whose
+                                                                  // range crosses a channel boundary sums up in mid-stream, with planes in flight)
+    float* dwl = scratch + MF_WAVES * 32 * 64;                    // [MF_WAVES][ntot]
+    int* flags = (int*)(dwl + MF_WAVES * ntot);                   // [8]
+    float* segres = (float*)(flags + 8);                          // [ntot]: the first channel's sums of a workgroup whose range crosses ONE boundary
+
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, lhi = lane >> 5;
+    const int wave = wave_id_uniform();
+    const int mt = wave & 1, nt = wave >> 1;
+    // Work decomposition: the C * N planes in (channel, image) order are cut into `grid` equal ranges, one per workgroup = one per CU (a
+    // whole number of slices per channel would leave a quarter of the CUs idle at C = 96: 192 workgroups of 64 planes instead of 256 of 48).
+    // A range may cross channel boundaries: the accumulators are summed up, stored as the workgroup's partial record number `kseg` and cleared
+    // at each boundary; channel c is reduced by the last of the workgroups b_lo(c) .. b_hi(c) to arrive, in workgroup order.
+    const int bwg = blockIdx.x;
+    const int P = p.C * p.N;
+    const int q0 = bwg * p.per;
+    int q1 = q0 + p.per; if (q1 > P) q1 = P;
+    const int iters = q1 > q0 ? q1 - q0 : 0;
+    const int c_first = q0 / p.N;
+
+    for (unsigned o = tid * 16; o < ring_b + TW_NB * slot_b + (unsigned)(MF_WAVES * 32 * 64 + MF_WAVES * ntot) * 4 + 32; o += MF_THREADS * 16) *(u32x4*)(LB + o) = u32x4{0u, 0u, 0u, 0u};
+    __syncthreads();
+
+    // ---- DMA plan: instruction ii of a copy fetches chunks g = 64 ii + lane -> (row g / CPR, piece g % CPR); wave w issues ii = w + 4 j ---------
+    v4i_t rs[4];
+    {
+        const void* src[4] = {p.dy[0], p.x, p.dy[2], p.dy[1]};
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const uint64_t a = (uint64_t)src[t];
+            rs[t][0] = __builtin_amdgcn_readfirstlane((int)(a & 0xffffffffu)); rs[t][1] = __builtin_amdgcn_readfirstlane((int)((a >> 32) & 0xffffu));
+            rs[t][2] = __builtin_amdgcn_readfirstlane((int)p.tensor_bytes); rs[t][3] = 0x00020000;
+        }
+    }
+    unsigned src_off[TW_J]; bool j_live[TW_J];
+    int my_instr = 0;
+#pragma unroll
+    for (int j = 0; j < TW_J; ++j) {
+        const int ii = wave + MF_WAVES * j;
+        j_live[j] = ii < p.ipc;                                   // wave-uniform
+        const int g = ii * 64 + lane, row = g / CPRC, piece = g - row * CPRC;
+        src_off[j] = (j_live[j] && row < p.H && piece < p.W / 8) ? (unsigned)(row * p.W * 2 + piece * 16) : TW_OOB;
+        my_instr += j_live[j] ? 4 : 0;
+    }
+    const unsigned lds_base = (unsigned)(uintptr_t)SLAK_LDS(uint16_t, lds) + ring_b;
+    const unsigned plane_b = (unsigned)HW * 2, img_b = (unsigned)p.C * plane_b;
+    // gb: byte offset of a plane (n, c) in the NCHW tensors (the same in all four); the issue pointer runs two planes ahead of the compute pointer.
+    // A piece in the MFMA stream is five instructions (M0, the wait state, the load, one scalar test): the lane offsets of the plane being
+    // requested (voff) and whether it exists (iss_on) are formed once per plane, M0 is not saved (the compiler's own code never reads it here:
+    // checked in the ISA).
+    unsigned voff[TW_J]; bool iss_on = false;
+    auto aim = [&](int g, unsigned gb) {
+        iss_on = g < iters && !(p.dbg & 2);
+#pragma unroll
+        for (int j = 0; j < TW_J; ++j) voff[j] = src_off[j] == TW_OOB ? TW_OOB : gb + src_off[j];
+    };
+    auto issue_piece = [&](int g, int k) __attribute__((always_inline)) {      // k = t * TW_J + j, compile-time at every call site
+        const int t = k / TW_J, j = k % TW_J;
+        if (iss_on && j_live[j] && (p.dbg & 16)) {               // (timing experiment: a plain load to registers instead of the LDS-DMA piece)
+            u32x4 dummy;
+            asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(dummy) : "v"(voff[j]), "s"(rs[t]) : "memory");
+        } else if (iss_on && j_live[j])
+            tw_dma16(voff[j], rs[t], __builtin_amdgcn_readfirstlane(lds_base + (unsigned)(g % TW_NB) * slot_b + (unsigned)t * copy_b + (unsigned)(wave + MF_WAVES * j) * 1024));
+    };
+    int c_iss = c_first, n_iss = q0 - c_first * p.N;               // plane the issue pointer is at
+    unsigned gb_iss = (unsigned)n_iss * img_b + (unsigned)c_iss * plane_b;
+    auto advance_issue = [&]() {
+        ++n_iss; gb_iss += img_b;
+        if (n_iss == p.N) { n_iss = 0; ++c_iss; gb_iss = (unsigned)c_iss * plane_b; }
+    };
+    aim(0, gb_iss);
+#pragma unroll
+    for (int k = 0; k < 4 * TW_J; ++k) issue_piece(0, k);
+    advance_issue();
+    aim(1, gb_iss);
+#pragma unroll
+    for (int k = 0; k < 4 * TW_J; ++k) issue_piece(1, k);
+    advance_issue();                                              // -> plane 2
+
+    tw_acc_claim();
+    tw_acc_zero<0, 240>();
+
+    // ---- fragment addresses (relative to a slot) ---------------------------------------------------------------------------
+    // vertical / small: lane -> image row (o = mt * 32 + l31 resp. i = nt * 32 + l31), 8 consecutive k = columns 16 ks + 8 lhi .. +7
+    const unsigned av_off = ring_b + (unsigned)(mt * 32 + l31) * PB + lhi * 16;                     // dYv (copy 0)
+    const unsigned xv_off = ring_b + copy_b + (unsigned)(nt * 32 + l31) * PB + lhi * 16;           // X   (copy 1)
+    // horizontal: lane -> image column (o = mt * 32 + l31 resp. i = nt * 32 + l31), 8 consecutive k = rows 16 ks + 8 lhi .. +7: a 16-lane
+    // group of a transposing read covers 4 rows x 16 columns (lane i16 supplies row i16 / 4, columns 4 (i16 % 4) .. +3, receives column i16)
+    const int i16 = lane & 15, gq = lane >> 4;
+    const unsigned trl = (unsigned)(8 * lhi + (i16 >> 2)) * PB + (unsigned)(16 * (gq & 1) + 4 * (i16 & 3)) * 2;
+    const unsigned ah_off = ring_b + 3 * copy_b + trl + (unsigned)mt * 64;                          // dYh (copy 3), columns of tile mt
+    const unsigned xh_off = ring_b + copy_b + trl + (unsigned)nt * 64 - 2 * PB;                     // X, columns of tile nt, the window starts two rows up
+    auto rdq = [&](unsigned addr) -> u32x4 { return *(const u32x4*)(LB + addr); };
+    auto rdd = [&](unsigned addr) -> unsigned { return *(const unsigned*)(LB + addr); };
+    auto rdt = [&](unsigned addr) -> u32x2 { return __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16(SLAK_LDS(s16x4, LB + addr))); };
+
+    float* mine = dwl + wave * ntot;
+    float* tile = scratch + wave * (32 * 64);
+    float* wr = tile + (4 * lhi) * 64 + (l31 - 4 * lhi + 31);
+    const int dtau = (nt - mt) * 32 - 31;
+    int it = 0, kseg = 0;
+    int n_cur = q0 - c_first * p.N;                               // image index of plane `it` inside its channel
+    while (it < iters) {
+    int seg_end = it + (p.N - n_cur); if (seg_end > iters) seg_end = iters;      // planes [it, seg_end) belong to channel c_first + kseg
+    for (; it < seg_end; ++it) {
+        if (!(p.dbg & 8)) {
+        wait_vmcnt_dyn((it + 1 < iters ? 1 : 0) * my_instr);      // my pieces of plane `it` have landed (loads retire in order); plane it + 1's may be in flight
+        wg_barrier();                                             // everyone's have; everyone is done with plane it - 1, whose slot plane it + 2 takes
+        }
+        const unsigned sb = (unsigned)(it % TW_NB) * slot_b;
+        aim(it + 2, gb_iss);
+        if (p.dbg & 1) {
+#pragma unroll
+            for (int k = 0; k < 4 * TW_J; ++k) issue_piece(it + 2, k);
+            advance_issue();
+            continue;
+        }
+        const unsigned av = sb + av_off, as = av + 2 * copy_b, xv = sb + xv_off, ah = sb + ah_off, xh = sb + xh_off;
+        s16x8 a[2], a2[2], b[2][NG];
+        // operands of the first vertical k-step (nothing to hide them behind: the plane has only just been released)
+        {
+            a[0] = __builtin_bit_cast(s16x8, rdq(av)); a2[0] = __builtin_bit_cast(s16x8, rdq(as));
+            const u32x4 C = rdq(xv); const unsigned P3 = rdd(xv - 4), N0 = rdd(xv + 16);
+            tw_taps(b[0], P3, C[0], C[1], C[2], C[3], N0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- vertical + small: KS k-steps of ten MFMAs; behind them the operands of the next step (the last one: of the first horizontal step)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int cu = ks & 1, nx = cu ^ 1;
+            const bool last = ks + 1 == KS;
+            u32x4 Cn; unsigned Pn = 0, Nn = 0; u32x2 w0, w1, w2, h0, h1;
+            tw_mfma<T, TW_ACC_V + 16 * 0>(a[cu], b[cu][0]);
+            if (!last) a[nx] = __builtin_bit_cast(s16x8, rdq(av + (ks + 1) * 32)); else h0 = rdt(ah);
+            __builtin_amdgcn_sched_barrier(0);
+            tw_mfma<T, TW_ACC_S + 16 * 0>(a2[cu], b[cu][0]);
+            if (!last) a2[nx] = __builtin_bit_cast(s16x8, rdq(as + (ks + 1) * 32)); else h1 = rdt(ah + 4 * PB);
+            __builtin_amdgcn_sched_barrier(0);
+            tw_mfma<T, TW_ACC_V + 16 * 1>(a[cu], b[cu][1]);
+            if (!last) Cn = rdq(xv + (ks + 1) * 32); else w0 = rdt(xh);
+            __builtin_amdgcn_sched_barrier(0);
+            tw_mfma<T, TW_ACC_S + 16 * 1>(a2[cu], b[cu][1]);
+            if (!last) Pn = rdd(xv + (ks + 1) * 32 - 4); else w1 = rdt(xh + 4 * PB);
+            __builtin_amdgcn_sched_barrier(0);
+            tw_mfma<T, TW_ACC_V + 16 * 2>(a[cu], b[cu][2]);
+            if (!last) Nn = rdd(xv + (ks + 1) * 32 + 16); else w2 = rdt(xh + 8 * PB);
+            __builtin_amdgcn_sched_barrier(0);
+            tw_mfma<T, TW_ACC_S + 16 * 2>(a2[cu], b[cu][2]);
+            issue_piece(it + 2, 2 * ks);
+            __builtin_amdgcn_sched_barrier(0);
+            tw_mfma<T, TW_ACC_V + 16 * 3>(a[cu], b[cu][3]);
+            issue_piece(it + 2, 2 * ks + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            tw_mfma<T, TW_ACC_S + 16 * 3>(a2[cu], b[cu][3]);
+            __builtin_amdgcn_sched_barrier(0);
+            tw_mfma<T, TW_ACC_V + 16 * 4>(a[cu], b[cu][4]);
+            if (!last) tw_taps(b[nx], Pn, Cn[0], Cn[1], Cn[2], Cn[3], Nn);
+            else { a[nx] = __builtin_bit_cast(s16x8, u32x4{h0[0], h0[1], h1[0], h1[1]}); tw_taps(b[nx], w0[0], w0[1], w1[0], w1[1], w2[0], w2[1]); }
+            __builtin_amdgcn_sched_barrier(0);
+            tw_mfma<T, TW_ACC_S + 16 * 4>(a2[cu], b[cu][4]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // ---- horizontal: KS k-steps of five MFMAs (a / b buffers continue to alternate: step ks uses buffer (KS + ks) & 1) ------------------------
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int cu = (KS + ks) & 1, nx = cu ^ 1;
+            const bool last = ks + 1 == KS;
+            const unsigned ro = (unsigned)(ks + 1) * 16 * PB;
+            u32x2 w0, w1, w2, h0, h1;
+            tw_mfma<T, TW_ACC_H + 16 * 0>(a[cu], b[cu][0]);
+            if (!last) { h0 = rdt(ah + ro); h1 = rdt(ah + ro + 4 * PB); }
+            __builtin_amdgcn_sched_barrier(0);
+            tw_mfma<T, TW_ACC_H + 16 * 1>(a[cu], b[cu][1]);
+            if (!last) { w0 = rdt(xh + ro); w1 = rdt(xh + ro + 4 * PB); w2 = rdt(xh + ro + 8 * PB); }
+            __builtin_amdgcn_sched_barrier(0);
+            tw_mfma<T, TW_ACC_H + 16 * 2>(a[cu], b[cu][2]);
+            issue_piece(it + 2, 2 * KS + ks);
+            __builtin_amdgcn_sched_barrier(0);
+            tw_mfma<T, TW_ACC_H + 16 * 3>(a[cu], b[cu][3]);
+            if (!last) { a[nx] = __builtin_bit_cast(s16x8, u32x4{h0[0], h0[1], h1[0], h1[1]}); tw_taps(b[nx], w0[0], w0[1], w1[0], w1[1], w2[0], w2[1]); }
+            __builtin_amdgcn_sched_barrier(0);
+            tw_mfma<T, TW_ACC_H + 16 * 4>(a[cu], b[cu][4]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // (KS = 3: the 4 * TW_J = 12 piece slots of a plane are 2 * KS + KS = 9 above; the rest go out here)
+#pragma unroll
+        for (int k = 3 * KS; k < 4 * TW_J; ++k) issue_piece(it + 2, k);
+        advance_issue();
+    }
+    // ---- end of a channel segment: diagonal sums of the fifteen accumulators through the wave's skewed tile (G[o][i] -> row o, column i - o + 31), the
+    //      workgroup's partial record `kseg`, accumulators cleared.  In mid-stream (planes of the next channel in flight) the stores below and the
+    //      DMA pieces share the wave's vmcnt: everything is drained once here (one boundary per workgroup at most when per <= N).
+    if (!(p.dbg & 4)) {
+        for (int i = lane; i < 32 * 64 / 4; i += 64) ((u32x4*)tile)[i] = u32x4{0u, 0u, 0u, 0u};
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        {   // (every tile entry a tap writes is rewritten by the next tap of the same extent; H and W may differ: clear between the passes)
+            const bool col_ok = nt * 32 + l31 < p.H;
+            int o_max = p.H - mt * 32; if (o_max > 32) o_max = 32;
+            tw_diag<TW_ACC_V, 0>(tile, wr, col_ok, o_max, lane, lhi, dtau + p.padL, p.K, mine, MF_TAPS, 1);                          // dw_v[tau][r = g]
+            tw_diag<TW_ACC_S, 0>(tile, wr, col_ok, o_max, lane, lhi, dtau + MF_TAPS / 2, MF_TAPS, mine + 2 * ntl, MF_TAPS, 1);       // dw_s[tau][r = g]
+        }
+        if (p.H != p.W) {
+            for (int i = lane; i < 32 * 64 / 4; i += 64) ((u32x4*)tile)[i] = u32x4{0u, 0u, 0u, 0u};
+            __builtin_amdgcn_wave_barrier();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+        {
+            const bool col_ok = nt * 32 + l31 < p.W;
+            int o_max = p.W - mt * 32; if (o_max > 32) o_max = 32;
+            tw_diag<TW_ACC_H, 0>(tile, wr, col_ok, o_max, lane, lhi, dtau + p.padL, p.K, mine + ntl, 1, p.K);                          // dw_h[r = g][tau]
+        }
+        __syncthreads();
+        // In mid-stream nothing goes to memory if it can wait: stores would share the wave's vmcnt with the DMA pieces in flight (counted waits) and
+        // draining it costs a plane's time.  With at most one boundary per workgroup (maxspan == 2) the first channel's sums stay in LDS and leave
+        // with the last record; more boundaries than that (per > N: tiny batches) store and drain.
+        const bool more = it < iters, defer = more && p.maxspan == 2;
+        float* out = p.partial + ((size_t)bwg * p.maxspan + kseg) * ntot;
+        for (int t = tid; t < ntot; t += MF_THREADS) {
+            float s = dwl[t];
+#pragma unroll
+            for (int w = 1; w < MF_WAVES; ++w) s += dwl[w * ntot + t];
+            if (defer) segres[t] = s;
+            else {
+                wgrad_store_partial(&out[t], s);
+                if (p.maxspan == 2 && kseg == 1) wgrad_store_partial(&out[t - ntot], segres[t]);      // record 0: the deferred first channel
+            }
+#pragma unroll
+            for (int w = 0; w < MF_WAVES; ++w) dwl[w * ntot + t] = 0.f;      // (taps no diagonal reaches are never written: they must read 0 next time too)
+        }
+        if (more && !defer) { wait_vmcnt<0>(); __syncthreads(); }
+    }
+    ++kseg; n_cur = 0;
+    if (it < iters) tw_acc_zero<0, 240>();                        // more planes (of the next channel) follow
+    }   // while (it < iters)
+    wait_vmcnt<0>();
+    __syncthreads();
+    if (p.dbg & 4) return;
+    // ---- arrive at every channel this workgroup holds a record of; the last arriver of a channel adds the records of workgroups b_lo .. b_hi in
+    //      workgroup order (bitwise reproducible) and scatters into the three dw tensors (hand-off form: see wgrad_finish in slak_common.h) --------
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const int nseg = kseg;
+    if (tid < nseg) {
+        const int ch = c_first + tid;
+        const int b_lo = (ch * p.N) / p.per, b_hi = (ch * p.N + p.N - 1) / p.per;
+        int last = 1;
+        if (b_hi > b_lo) {
+            const unsigned old = __hip_atomic_fetch_add(p.counters + ch, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            last = old == (unsigned)(b_hi - b_lo);
+            if (last) __hip_atomic_store(p.counters + ch, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        flags[tid] = last;
+    }
+    __syncthreads();
+    for (int sg = 0; sg < nseg; ++sg) {
+        if (!flags[sg]) continue;
+        const int ch = c_first + sg;
+        const int b_lo = (ch * p.N) / p.per, b_hi = (ch * p.N + p.N - 1) / p.per;
+        for (int t = tid; t < ntot; t += MF_THREADS) {
+            float s = 0.f;
+            for (int b0 = b_lo; b0 <= b_hi; b0 += 8) {            // 8 loads in flight, added in workgroup order; agent-scope loads read at the coherence point
+                float v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int bb = b0 + j;
+                    const int kk = ch - (bb * p.per) / p.N;        // the record of workgroup bb that belongs to channel ch
+                    v[j] = bb <= b_hi ? __hip_atomic_load(p.partial + ((size_t)bb * p.maxspan + kk) * ntot + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.f;
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) s += v[j];
+            }
+            if (t < ntl) p.dw[0][(size_t)ch * ntl + t] = s;
+            else if (t < 2 * ntl) p.dw[1][(size_t)ch * ntl + (t - ntl)] = s;
+            else p.dw[2][(size_t)ch * (MF_TAPS * MF_TAPS) + (t - 2 * ntl)] = s;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+static bool tri_rows_enabled() {               // SLAK_TRI_ROWS=0: the 2 x 2-tile planes keep the two-launch weight gradient (A/B testing)
+    static const bool v = [] { const char* e = getenv("SLAK_TRI_ROWS"); return !(e && e[0] == '0'); }();
+    return v;
+}
+
+static bool fill_tri_rows_params(TriRowsParams& p, int N, int C, int H, int W, int K, int wgs) {
+    p.N = N; p.C = C; p.H = H; p.W = W; p.K = K; p.padL = K / 2;
+    if (N <= 0 || C <= 0 || K <= MF_TAPS || !(K & 1) || K > 63) return false;
+    if (H <= 32 || H > 64 || W <= 32 || W > 64 || (W % 8)) return false;
+    const int ks = (H > W ? H : W) > 48 ? 4 : 3;
+    p.CPR = 2 * ks + 1;                                               // 9 (maps up to 64) or 7 (up to 48): odd, >= W / 8 + 1, and chunk 2 ks (the "next" of the last k-step) is padding
+    if (p.CPR < W / 8 + 1) return false;
+    p.ipc = (H * p.CPR + 63) / 64;
+    p.RS = ks == 3 ? 56 : 68;
+    if ((p.ipc + MF_WAVES - 1) / MF_WAVES > TW_J) return false;
+    if ((size_t)p.ipc * 1024 > (size_t)p.RS * p.CPR * 16) return false;      // a copy's DMA instructions stay inside the copy
+    if ((size_t)N * C >= 0x40000000ull) return false;
+    const int P = N * C;
+    if (wgs < 1) wgs = 1;
+    p.per = (P + wgs - 1) / wgs;
+    p.grid = (P + p.per - 1) / p.per;
+    p.maxspan = (p.per - 1 + N - 1) / N + 1;                          // a range of `per` planes touches at most this many channels
+    if (p.maxspan > 8) return false;
+    p.tensor_bytes = (unsigned)((size_t)N * C * H * W * 2);
+    { static const int dbg = [] { const char* e = getenv("SLAK_TRIROWS_DBG"); return e ? atoi(e) : 0; }(); p.dbg = dbg; }
+    return (size_t)N * C * H * W * 2 < 0x7fffffffull;
+}
+
+static size_t tri_rows_lds_bytes(const TriRowsParams& p) {
+    const size_t ntot = 2 * p.K * MF_TAPS + MF_TAPS * MF_TAPS;
+    return 64 + (size_t)TW_NB * 4 * p.RS * p.CPR * 16 + (size_t)MF_WAVES * 32 * 64 * 4 + (size_t)(MF_WAVES + 1) * ntot * 4 + 32 + 64;
+}
+
+bool dwconv_mfma_tri_wgrad_rows_supported(int N, int C, int H, int W, int K, int dtype) {
+    if (!tri_rows_enabled() || (dtype != SLAK_BF16 && dtype != SLAK_F16)) return false;
+    TriRowsParams p;
+    return fill_tri_rows_params(p, N, C, H, W, K, 256) && tri_rows_lds_bytes(p) <= 160 * 1024 - 256;
+}
+
+// records: grid * maxspan <= C + 2 * grid + 2 whatever the CU count turns out to be (grid <= min(C * N, CUs)); sized for up to 1024 CUs
+size_t dwconv_mfma_tri_wgrad_rows_workspace(int N, int C, int K) {
+    const size_t P = (size_t)N * C, g = P < 1024 ? P : 1024;
+    return align_up(((size_t)C + 2 * g + 2 + (P / g + N - 1) / N) * (2 * K * MF_TAPS + MF_TAPS * MF_TAPS) * sizeof(float), 256);
+}
+
+template <typename T, int KS, int CPRC>
+static int launch_tri_rows_t(TriRowsParams& p, size_t ws_bytes, hipStream_t st) {
+    auto k = dwconv_mfma_tri_wgrad_rows_kernel<T, KS, CPRC>;
+    const size_t lds = tri_rows_lds_bytes(p);
+    static thread_local size_t cached_key = 0;                    // (device + 1, LDS size): the attribute is per device
+    const size_t key = ((size_t)(slak_current_device() + 1) << 32) | lds;
+    if (cached_key != key) {
+        if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) { (void)hipGetLastError(); return SLAK_ERR_UNSUPPORTED; }
+        cached_key = key;
+    }
+    if ((size_t)p.grid * p.maxspan * (2 * p.K * MF_TAPS + MF_TAPS * MF_TAPS) * sizeof(float) > ws_bytes) return SLAK_ERR_WORKSPACE;
+    hipLaunchKernelGGL(k, dim3((unsigned)p.grid), dim3(MF_THREADS), lds, st, p);
+    SLAK_LAUNCH_CHECK();
+    return SLAK_OK;
+}
+
+int launch_dwconv_mfma_tri_wgrad_rows(const void* const* dy, const void* x, float* const* dw, int dtype,
+                                      int N, int C, int H, int W, int K, void* ws, size_t ws_bytes, hipStream_t st) {
+    if (!dwconv_mfma_tri_wgrad_rows_supported(N, C, H, W, K, dtype)) return SLAK_ERR_UNSUPPORTED;
+    if (ws == nullptr) return SLAK_ERR_WORKSPACE;
+    TriRowsParams p;
+    static const int wgs = [] { const char* e = getenv("SLAK_TRIROWS_WGS"); return e ? atoi(e) : 0; }();      // (dev: a grid other than one workgroup per CU)
+    fill_tri_rows_params(p, N, C, H, W, K, wgs > 0 ? wgs : mfma_cu_count());          // one wave per SIMD: one four-wave workgroup per CU
+    for (int b = 0; b < 3; ++b) { p.dy[b] = dy[b]; p.dw[b] = dw[b]; }
+    p.x = x; p.partial = (float*)ws;
+    p.counters = wgrad_arrival_counters(C);
+    if (!p.counters) return SLAK_ERR_UNSUPPORTED;
+    const bool bf = dtype == SLAK_BF16;
+    if (p.CPR == 9) return bf ? launch_tri_rows_t<bf16_t, 4, 9>(p, ws_bytes, st) : launch_tri_rows_t<f16_t, 4, 9>(p, ws_bytes, st);
+    return bf ? launch_tri_rows_t<bf16_t, 3, 7>(p, ws_bytes, st) : launch_tri_rows_t<f16_t, 3, 7>(p, ws_bytes, st);
+}
+
+}  // namespace slak

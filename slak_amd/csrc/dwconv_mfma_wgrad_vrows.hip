@@ -134,8 +134,10 @@ __global__ __launch_bounds__(MF_THREADS, PAIR ? 2 : 3) void dwconv_mfma_wgrad_vr
 
     for (int it = 0; it < iters; ++it) {
         int later = iters - 1 - it; if (later > p.nb - 2) later = p.nb - 2;       // planes issued after `it` that may still be in flight
+        if (!(p.dbg & 8)) {
         wait_vmcnt_dyn(later * my_instr);                         // my DMAs of plane `it` have landed (loads retire in order)
         wg_barrier();                                             // everyone's have; everyone is done with the slot refilled next
+        }
         issue_plane(it + p.nb - 1);                               // streams in while this and the following planes are consumed
         const unsigned slot = ring_b + (unsigned)(it % p.nb) * slot_b;
         if (p.dbg & 1) continue;
@@ -278,6 +280,7 @@ static int launch_vrows_t(WgradRowsParams& p, const ConvDims& d, size_t ws_bytes
         int per_cu = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k, MF_THREADS, lds) != hipSuccess || per_cu < 1) per_cu = 1;
         if (per_cu > 8) per_cu = 8;
+        { const char* e = getenv("SLAK_VROWS_WGS"); if (e && atoi(e) > 0 && atoi(e) < per_cu) per_cu = atoi(e); }      // (dev: fewer workgroups per CU)
         if ((size_t)per_cu * (lds + 512) > 160 * 1024) --per_cu;       // (the query ignores the LDS allocation granule)
         if (per_cu < 1) per_cu = 1;
         resident = per_cu * mfma_cu_count();
