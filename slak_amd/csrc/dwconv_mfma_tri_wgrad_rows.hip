@@ -96,17 +96,21 @@ template <int BASE> __device__ __forceinline__ void tw_acc_read(float (&v)[16]) 
                    "i"(BASE + 8), "i"(BASE + 9), "i"(BASE + 10), "i"(BASE + 11), "i"(BASE + 12), "i"(BASE + 13), "i"(BASE + 14), "i"(BASE + 15));
 }
 
-// diagonal sums of the five taps of one branch through the wave's skewed tile (G[o][i] -> row o, column i - o + 31: a diagonal is a column)
-template <int BASE, int G>
-__device__ __forceinline__ void tw_diag(float* tile, float* wr, bool col_ok, int o_max, int lane, int lhi, int dtau, int KL, float* out, int s_tau, int s_g) {
-    if constexpr (G < MF_TAPS) {
+// diagonal sums of the five taps of one branch through the wave's skewed tile (G[o][i] -> row o, column i - o + 31: a diagonal is a column).
+// ONE copy of the scatter / column-sum code in a run-time loop over the taps (the register NAMES are compile-time: a switch picks the read).
+// lim: per lane, how many of its rows are inside the image (0 for a lane whose column is outside): entries beyond are written as zeros, so
+// nothing of a padded row / column -- finite or not -- reaches a sum and the stores need no exec masking.
+template <int BASE>
+__device__ __forceinline__ void tw_diag5(float* tile, float* wr, int lim, int lane, int dtau, int KL, float* out, int s_tau, int s_g) {
+#pragma unroll 1
+    for (int g = 0; g < MF_TAPS; ++g) {
         float v[16];
-        tw_acc_read<BASE + 16 * G>(v);
-        if (col_ok) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                if ((r & 3) + 8 * (r >> 2) + 4 * lhi < o_max) wr[((r & 3) + 8 * (r >> 2)) * 63] = v[r];
+        switch (g) {
+            case 0: tw_acc_read<BASE + 0>(v); break;  case 1: tw_acc_read<BASE + 16>(v); break; case 2: tw_acc_read<BASE + 32>(v); break;
+            case 3: tw_acc_read<BASE + 48>(v); break; default: tw_acc_read<BASE + 64>(v); break;
         }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) wr[((r & 3) + 8 * (r >> 2)) * 63] = (r & 3) + 8 * (r >> 2) < lim ? v[r] : 0.f;
         __builtin_amdgcn_wave_barrier();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (lane < 63) {
@@ -114,11 +118,10 @@ __device__ __forceinline__ void tw_diag(float* tile, float* wr, bool col_ok, int
 #pragma unroll
             for (int o = 0; o < 32; ++o) part[o & 3] += tile[o * 64 + lane];
             const int tau = lane + dtau;
-            if (tau >= 0 && tau < KL) out[tau * s_tau + G * s_g] = (part[0] + part[1]) + (part[2] + part[3]);
+            if (tau >= 0 && tau < KL) out[tau * s_tau + g * s_g] = (part[0] + part[1]) + (part[2] + part[3]);
         }
         __builtin_amdgcn_wave_barrier();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        tw_diag<BASE, G + 1>(tile, wr, col_ok, o_max, lane, lhi, dtau, KL, out, s_tau, s_g);
     }
 }
 
@@ -193,10 +196,7 @@ __global__ __launch_bounds__(MF_THREADS, 1) void dwconv_mfma_tri_wgrad_rows_kern
     };
     auto issue_piece = [&](int g, int k) __attribute__((always_inline)) {      // k = t * TW_J + j, compile-time at every call site
         const int t = k / TW_J, j = k % TW_J;
-        if (iss_on && j_live[j] && (p.dbg & 16)) {               // (timing experiment: a plain load to registers instead of the LDS-DMA piece)
-            u32x4 dummy;
-            asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(dummy) : "v"(voff[j]), "s"(rs[t]) : "memory");
-        } else if (iss_on && j_live[j])
+        if (iss_on && j_live[j])
             tw_dma16(voff[j], rs[t], __builtin_amdgcn_readfirstlane(lds_base + (unsigned)(g % TW_NB) * slot_b + (unsigned)t * copy_b + (unsigned)(wave + MF_WAVES * j) * 1024));
     };
     int c_iss = c_first, n_iss = q0 - c_first * p.N;               // plane the issue pointer is at
@@ -328,24 +328,16 @@ __global__ __launch_bounds__(MF_THREADS, 1) void dwconv_mfma_tri_wgrad_rows_kern
     //      workgroup's partial record `kseg`, accumulators cleared.  In mid-stream (planes of the next channel in flight) the stores below and the
     //      DMA pieces share the wave's vmcnt: everything is drained once here (one boundary per workgroup at most when per <= N).
     if (!(p.dbg & 4)) {
-        for (int i = lane; i < 32 * 64 / 4; i += 64) ((u32x4*)tile)[i] = u32x4{0u, 0u, 0u, 0u};
-        __builtin_amdgcn_wave_barrier();
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        {   // (every tile entry a tap writes is rewritten by the next tap of the same extent; H and W may differ: clear between the passes)
-            const bool col_ok = nt * 32 + l31 < p.H;
+        {   // (every tap writes all of the wave's 32 x 32 entries of the skewed tile: nothing to clear between taps or extents)
             int o_max = p.H - mt * 32; if (o_max > 32) o_max = 32;
-            tw_diag<TW_ACC_V, 0>(tile, wr, col_ok, o_max, lane, lhi, dtau + p.padL, p.K, mine, MF_TAPS, 1);                          // dw_v[tau][r = g]
-            tw_diag<TW_ACC_S, 0>(tile, wr, col_ok, o_max, lane, lhi, dtau + MF_TAPS / 2, MF_TAPS, mine + 2 * ntl, MF_TAPS, 1);       // dw_s[tau][r = g]
-        }
-        if (p.H != p.W) {
-            for (int i = lane; i < 32 * 64 / 4; i += 64) ((u32x4*)tile)[i] = u32x4{0u, 0u, 0u, 0u};
-            __builtin_amdgcn_wave_barrier();
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            const int lim = nt * 32 + l31 < p.H ? o_max - 4 * lhi : 0;
+            tw_diag5<TW_ACC_V>(tile, wr, lim, lane, dtau + p.padL, p.K, mine, MF_TAPS, 1);                          // dw_v[tau][r = g]
+            tw_diag5<TW_ACC_S>(tile, wr, lim, lane, dtau + MF_TAPS / 2, MF_TAPS, mine + 2 * ntl, MF_TAPS, 1);       // dw_s[tau][r = g]
         }
         {
-            const bool col_ok = nt * 32 + l31 < p.W;
             int o_max = p.W - mt * 32; if (o_max > 32) o_max = 32;
-            tw_diag<TW_ACC_H, 0>(tile, wr, col_ok, o_max, lane, lhi, dtau + p.padL, p.K, mine + ntl, 1, p.K);                          // dw_h[r = g][tau]
+            const int lim = nt * 32 + l31 < p.W ? o_max - 4 * lhi : 0;
+            tw_diag5<TW_ACC_H>(tile, wr, lim, lane, dtau + p.padL, p.K, mine + ntl, 1, p.K);                          // dw_h[r = g][tau]
         }
         __syncthreads();
         // In mid-stream nothing goes to memory if it can wait: stores would share the wave's vmcnt with the DMA pieces in flight (counted waits) and
@@ -483,7 +475,8 @@ int launch_dwconv_mfma_tri_wgrad_rows(const void* const* dy, const void* x, floa
     if (ws == nullptr) return SLAK_ERR_WORKSPACE;
     TriRowsParams p;
     static const int wgs = [] { const char* e = getenv("SLAK_TRIROWS_WGS"); return e ? atoi(e) : 0; }();      // (dev: a grid other than one workgroup per CU)
-    fill_tri_rows_params(p, N, C, H, W, K, wgs > 0 ? wgs : mfma_cu_count());          // one wave per SIMD: one four-wave workgroup per CU
+    if (!fill_tri_rows_params(p, N, C, H, W, K, wgs > 0 ? wgs : mfma_cu_count())) return SLAK_ERR_UNSUPPORTED;   // one wave per SIMD: one four-wave workgroup per CU
+                                                                                       // (the CU count decides `per`, and with it how many channels a range can span)
     for (int b = 0; b < 3; ++b) { p.dy[b] = dy[b]; p.dw[b] = dw[b]; }
     p.x = x; p.partial = (float*)ws;
     p.counters = wgrad_arrival_counters(C);

@@ -4,7 +4,7 @@ called THROUGH THE C ABI and compared with the C ORACLE directly (not with their
     slak_dwconv2d_pair_backward_filter   K x 5 and 5 x 5 weight gradient in one launch (56 x 56 / 28 x 28 class)
     slak_dwconv2d_tri_forward[_stats]    the three branch outputs in one launch
     slak_dwconv2d_tri_backward_data      the summed input gradient in one launch
-    slak_dwconv2d_tri_backward_filter    the three weight gradients in one launch (14 x 14 / 7 x 7 class)
+    slak_dwconv2d_tri_backward_filter    the three weight gradients in one launch (14 x 14 / 7 x 7 class; round 4: planes of 2 x 2 MFMA tiles, 56 x 56 class)
 
 Small shapes are checked exhaustively; the shapes bench.py times (BASELINE configs[1], [3], [4] at their per-GPU batch) are run at full
 size and checked on a sample of >= 9 channels (first, last and seeded picks): the oracle works channel by channel, so a channel subset
@@ -221,6 +221,47 @@ def test_tri_backward_filter_vs_oracle(N, C, H, W, K, dtype, gpu):
     xr = _r(x, dtype)
     for dw, dy, (kh, kw) in zip(dws, dys, ((K, 5), (5, K), (5, 5))):
         _check_dw(dw, oracle.dwconv2d_bwd_filter(_r(dy, dtype), xr, kh, kw), N * H * W, "dw %dx%d" % (kh, kw))
+
+
+# planes of 2 x 2 MFMA tiles (33 .. 64, W % 8 == 0): dwconv_mfma_tri_wgrad_rows.hip.  One workgroup per CU owns a RANGE of the C * N planes in
+# (channel, image) order; (129, 3), (67, 5) and (9, 37) make ranges that cross channel boundaries with 256 workgroups (the accumulators are summed
+# up and cleared in mid-stream, the first channel's sums leave with the last record), (300, 1) gives workgroups of several planes of one channel
+TRI_ROWS = [(5, 3, 56, 56, 51), (1, 1, 56, 56, 51), (7, 2, 56, 56, 51), (2, 2, 64, 64, 61), (3, 2, 48, 48, 59), (2, 3, 40, 48, 31), (2, 2, 56, 40, 13),
+            (7, 2, 64, 56, 51), (129, 3, 56, 56, 51), (67, 5, 56, 56, 51), (9, 37, 48, 48, 59), (300, 1, 56, 56, 51)]
+
+
+@pytest.mark.parametrize("N,C,H,W,K", TRI_ROWS)
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_tri_backward_filter_on_planes_of_2x2_tiles_vs_oracle(N, C, H, W, K, dtype, gpu):
+    torch.manual_seed(N + K + W)
+    x = torch.randn(N, C, H, W, device=gpu).to(dtype)
+    dys = [torch.randn(N, C, H, W, device=gpu).to(dtype) for _ in range(3)]
+    dws = _tri_wgrad(dys, x, K)
+    assert dws is not None, "every shape of TRI_ROWS has a one-launch weight gradient"
+    assert _L().lib().slak_debug_last_kernel() == b"dwconv_mfma_tri_wgrad_rows"
+    xr = _r(x, dtype)
+    for dw, dy, (kh, kw) in zip(dws, dys, ((K, 5), (5, K), (5, 5))):
+        _check_dw(dw, oracle.dwconv2d_bwd_filter(_r(dy, dtype), xr, kh, kw), N * H * W, "dw %dx%d" % (kh, kw))
+    again = _tri_wgrad(dys, x, K)
+    assert all(torch.equal(a, b) for a, b in zip(dws, again))              # fixed-order reduction over the workgroups of a channel
+    # the one-launch gradients against the per-branch launches (other kernels, other summation order): fp32 accumulation noise only
+    from slak_amd import ops
+    for dw, dy, (kh, kw) in zip(dws, dys, ((K, 5), (5, K), (5, 5))):
+        ref = ops.dwconv2d_backward_filter(dy, x, torch.empty(C, 1, kh, kw, device=gpu))
+        assert (dw - ref).abs().max().item() <= 2e-5 * max(1.0, ref.abs().max().item()) * max(1.0, (N * H * W) ** 0.5 / 30)
+
+
+def test_tri_backward_filter_keeps_padding_out_of_the_sums(gpu):
+    """Rows / columns behind the image are zero PADDING of the LDS images: a non-finite value in the LAST row and column of a plane must only
+    reach the taps that touch it -- the gradient of every other plane and channel, and the taps of this one that never see the corner, stay finite."""
+    N, C, H, W, K = 3, 2, 56, 56, 51
+    torch.manual_seed(0)
+    x = torch.randn(N, C, H, W, device=gpu).bfloat16()
+    dys = [torch.randn(N, C, H, W, device=gpu).bfloat16() for _ in range(3)]
+    x[1, 0, H - 1, W - 1] = float("inf")
+    dws = _tri_wgrad(dys, x, K)
+    assert all(torch.isfinite(dw[1]).all() for dw in dws)                  # the other channel
+    assert not all(torch.isfinite(dw[0]).all() for dw in dws)              # the channel that holds it
 
 
 # ------------------------------------------------------------------------------------------------ the shapes bench.py times, sampled channels
