@@ -310,6 +310,7 @@ int slak_dwconv2d_tri_backward_data(const void* dy_v, const void* dy_h, const vo
 size_t slak_dwconv2d_tri_filter_workspace_bytes(int dtype, int N, int C, int H, int W, int K) {
     if (dwconv_mfma_small_tri_wgrad_supported(N, C, H, W, K, dtype)) return dwconv_mfma_small_tri_wgrad_workspace(N, C, K);
     if (dwconv_mfma_tri_wgrad_rows_supported(N, C, H, W, K, dtype)) return dwconv_mfma_tri_wgrad_rows_workspace(N, C, K);     // planes of 2 x 2 tiles (56 x 56 class)
+    if (dwconv_mfma_tri_wgrad_wave_supported(N, C, H, W, K, dtype)) return dwconv_mfma_tri_wgrad_wave_workspace(N, C, K);     // planes of one tile (28 x 28 class)
     return 0;
 }
 
@@ -320,6 +321,8 @@ int slak_dwconv2d_tri_backward_filter(const void* dy_v, const void* dy_h, const 
     const void* dy[3] = {dy_v, dy_h, dy_s}; float* dw[3] = {dw_v, dw_h, dw_s};
     if (!dwconv_mfma_small_tri_wgrad_supported(N, C, H, W, K, dtype) && dwconv_mfma_tri_wgrad_rows_supported(N, C, H, W, K, dtype))
         return SLAK_RAN("dwconv_mfma_tri_wgrad_rows", launch_dwconv_mfma_tri_wgrad_rows(dy, x, dw, dtype, N, C, H, W, K, workspace, workspace_bytes, (hipStream_t)stream));
+    if (!dwconv_mfma_small_tri_wgrad_supported(N, C, H, W, K, dtype) && dwconv_mfma_tri_wgrad_wave_supported(N, C, H, W, K, dtype))
+        return SLAK_RAN("dwconv_mfma_tri_wgrad_wave", launch_dwconv_mfma_tri_wgrad_wave(dy, x, dw, dtype, N, C, H, W, K, workspace, workspace_bytes, (hipStream_t)stream));
     return SLAK_RAN("dwconv_mfma_small_tri_wgrad", launch_dwconv_mfma_small_tri_wgrad(dy, x, dw, dtype, N, C, H, W, K, workspace, workspace_bytes, (hipStream_t)stream));
 }
 

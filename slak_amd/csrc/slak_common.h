@@ -104,6 +104,10 @@ bool dwconv_mfma_tri_wgrad_rows_supported(int N, int C, int H, int W, int K, int
 size_t dwconv_mfma_tri_wgrad_rows_workspace(int N, int C, int K);
 int launch_dwconv_mfma_tri_wgrad_rows(const void* const* dy, const void* x, float* const* dw, int dtype,
                                       int N, int C, int H, int W, int K, void* ws, size_t ws_bytes, hipStream_t st);
+bool dwconv_mfma_tri_wgrad_wave_supported(int N, int C, int H, int W, int K, int dtype);
+size_t dwconv_mfma_tri_wgrad_wave_workspace(int N, int C, int K);
+int launch_dwconv_mfma_tri_wgrad_wave(const void* const* dy, const void* x, float* const* dw, int dtype,
+                                      int N, int C, int H, int W, int K, void* ws, size_t ws_bytes, hipStream_t st);
 bool dwconv_mfma_stream_tri_supported(int N, int C, int H, int W, int K, int dtype);
 int dwconv_mfma_stream_tri_stats_rows(int N, int C, int H, int W, int K, int dtype);
 int launch_dwconv_mfma_stream_tri(const void* x, void* const* out, const float* const* w, int dtype,

@@ -251,6 +251,31 @@ def test_tri_backward_filter_on_planes_of_2x2_tiles_vs_oracle(N, C, H, W, K, dty
         assert (dw - ref).abs().max().item() <= 2e-5 * max(1.0, ref.abs().max().item()) * max(1.0, (N * H * W) ** 0.5 / 30)
 
 
+# planes of one MFMA tile (15 .. 32 rows, W even 16 .. 32): dwconv_mfma_tri_wgrad_wave.hip.  Wave-granular, channel-aligned work split: (130, 7) and
+# (2, 300) give channels an uneven number of waves resp. more channels than ... waves per channel = 1
+TRI_WAVE = [(9, 2, 28, 28, 49), (1, 1, 28, 28, 49), (11, 3, 28, 28, 49), (5, 2, 24, 24, 57), (7, 2, 28, 20, 13), (3, 2, 32, 32, 31), (4, 3, 16, 32, 31),
+            (6, 2, 20, 24, 21), (130, 7, 28, 28, 49), (2, 300, 24, 24, 13), (1, 1030, 28, 28, 13)]
+
+
+@pytest.mark.parametrize("N,C,H,W,K", TRI_WAVE)
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_tri_backward_filter_on_one_tile_planes_vs_oracle(N, C, H, W, K, dtype, gpu):
+    torch.manual_seed(N + K + W)
+    x = torch.randn(N, C, H, W, device=gpu).to(dtype)
+    dys = [torch.randn(N, C, H, W, device=gpu).to(dtype) for _ in range(3)]
+    dws = _tri_wgrad(dys, x, K)
+    if C > 1024:                                                     # more channels than waves (4 x 256 CUs): no one-launch kernel, the support query says so
+        assert dws is None
+        return
+    assert dws is not None, "every shape of TRI_WAVE has a one-launch weight gradient"
+    assert _L().lib().slak_debug_last_kernel() == b"dwconv_mfma_tri_wgrad_wave"
+    xr = _r(x, dtype)
+    for dw, dy, (kh, kw) in zip(dws, dys, ((K, 5), (5, K), (5, 5))):
+        _check_dw(dw, oracle.dwconv2d_bwd_filter(_r(dy, dtype), xr, kh, kw), N * H * W, "dw %dx%d" % (kh, kw))
+    again = _tri_wgrad(dys, x, K)
+    assert all(torch.equal(a, b) for a, b in zip(dws, again))              # fixed-order reduction over the waves of a channel
+
+
 def test_tri_backward_filter_keeps_padding_out_of_the_sums(gpu):
     """Rows / columns behind the image are zero PADDING of the LDS images: a non-finite value in the LAST row and column of a plane must only
     reach the taps that touch it -- the gradient of every other plane and channel, and the taps of this one that never see the corner, stay finite."""

@@ -15,7 +15,8 @@ def tri(dys, x, K):
     _lib.check(L.slak_dwconv2d_tri_backward_filter(dys[0].data_ptr(), dys[1].data_ptr(), dys[2].data_ptr(), x.data_ptr(), dws[0].data_ptr(), dws[1].data_ptr(), dws[2].data_ptr(),
                                                    dt, N, C, H, W, K, ws.data_ptr(), nb, st()))
     return dws, L.slak_debug_last_kernel()
-for (N, C, H, W, K) in [(1, 1, 56, 56, 51), (3, 2, 56, 56, 51), (5, 3, 56, 56, 51), (2, 2, 64, 64, 61), (3, 2, 48, 48, 59), (2, 3, 40, 48, 31), (2, 2, 56, 40, 13), (7, 2, 64, 56, 51), (129, 3, 56, 56, 51), (7, 5, 56, 56, 51), (3, 11, 48, 48, 59)]:
+for (N, C, H, W, K) in [(1, 1, 56, 56, 51), (3, 2, 56, 56, 51), (5, 3, 56, 56, 51), (2, 2, 64, 64, 61), (3, 2, 48, 48, 59), (2, 3, 40, 48, 31), (2, 2, 56, 40, 13), (7, 2, 64, 56, 51), (129, 3, 56, 56, 51), (7, 5, 56, 56, 51), (3, 11, 48, 48, 59),
+                        (9, 2, 28, 28, 49), (1, 1, 28, 28, 49), (11, 3, 28, 28, 49), (5, 2, 24, 24, 57), (7, 2, 28, 20, 13), (3, 2, 32, 32, 31), (130, 7, 28, 28, 49), (2, 300, 24, 24, 13)]:
     torch.manual_seed(N + K)
     x = torch.randn(N, C, H, W, device=dev).bfloat16(); dys = [torch.randn(N, C, H, W, device=dev).bfloat16() for _ in range(3)]
     dws, name = tri(dys, x, K)
@@ -32,7 +33,7 @@ def t(fn, reps=50):
     b.record(); b.synchronize(); return a.elapsed_time(b) / reps * 1e3
 wa = torch.randn(4096, 4096, device=dev, dtype=torch.bfloat16)
 for _ in range(200): wa @ wa
-for (N, C, H, K) in [(128, 96, 56, 51), (64, 128, 56, 51), (64, 192, 48, 59)]:
+for (N, C, H, K) in [(128, 96, 56, 51), (64, 128, 56, 51), (64, 192, 48, 59), (128, 192, 28, 49), (64, 256, 28, 49), (64, 384, 24, 57)]:
     x = torch.randn(N, C, H, H, device=dev).bfloat16(); dys = [torch.randn_like(x) for _ in range(3)]
     nb = int(L.slak_dwconv2d_tri_filter_workspace_bytes(dt, N, C, H, H, K)); ws = torch.empty(max(nb, 16), dtype=torch.uint8, device=dev)
     dws = [torch.empty(C, 1, kh, kw, device=dev) for kh, kw in ((K, 5), (5, K), (5, 5))]

@@ -1,0 +1,6 @@
+#!/bin/bash
+# The shader clock inside the one-launch weight gradient (128 x 96 x 56 x 56, bf16) as a function of how many CUs work and whether they stream from
+# HBM: s_memtime cycles / s_memrealtime (100 MHz) of workgroup 0.  36 = the kernel without its epilogue; 38 = without DMA as well; 100 = DMA from
+# one cached MiB.  -> profiles/rNN_power_clock_probe.txt
+cd $GRAFT_REPO_ROOT
+for w in 256 128 64 32; do for d in 36 100 38; do printf "workgroups %3d  SLAK_TRIROWS_DBG=%-3d  " $w $d; SLAK_TRIROWS_WGS=$w SLAK_TRIROWS_DBG=$d python tools/clk_tri_rows.py 2>&1 | grep "wg 0"; done; done
