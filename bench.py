@@ -114,6 +114,7 @@ def parse():
     ap.add_argument("--torch-adamw", action="store_true", help="torch.optim.AdamW(fused=True) (+ a separate mask-apply launch) instead of slak_amd's one-launch MaskedAdamW")
     ap.add_argument("--model-ema", action="store_true", help="also keep the reference's sparsity-aware EMA (--model_ema true recipes): one HIP launch per step")
     ap.add_argument("--no-fused-tri", action="store_true", help="run the three branch convolutions as three autograd nodes (one launch each)")
+    ap.add_argument("--no-fused-block", action="store_true", help="keep the block's four fused ops as four autograd nodes (default: one node per block)")
     ap.add_argument("--no-fused-bn", action="store_true", help="run the three branch BatchNorms + adds as the reference's PyTorch modules")
     ap.add_argument("--no-fused-tail", action="store_true", help="run the block tail (permute/LayerNorm/gamma/residual) as the reference's PyTorch ops")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl", help="torch.distributed backend at N>1: nccl (= RCCL over xGMI) or gloo (CPU-staged; lets the N>1 code path run with several ranks on ONE GPU)")
@@ -462,6 +463,8 @@ def main():
     M.SLaK.fused_stem = os.environ.get("SLAK_FUSED_STEM", "1") != "0"
     M.SLaK.fused_downsample = not a.no_fused_tail and os.environ.get("SLAK_FUSED_DOWNSAMPLE", "1") != "0"   # LN -> 2x2/s2 conv as LN-to-patch kernel + library GEMMs
     M.ReparamLargeKernelConv.fused_tri = M.ReparamLargeKernelConv.fused_bn and not a.no_fused_tri   # three branch convs as one autograd node
+    M.Block.fused_block = (M.Block.fused_tail and M.ReparamLargeKernelConv.fused_tri and not a.no_fused_block
+                           and os.environ.get("SLAK_FUSED_BLOCK", "1") != "0")          # the whole block as ONE autograd node (same launches)
     from slak_amd import block_ops
     block_ops.cache_lowp_weights = True                            # bf16 weight copies refreshed by one multi-tensor launch per step
     M.use_sync_bn = True                                          # reference default (models/SLaK.py:19); falls back to BN math at world 1
@@ -593,7 +596,7 @@ def main():
                    "kernel_sizes": ks, "resolution": a.res, "variant": a.model,
                    "dwconv_dtype": ("fp32" + (" on the bf16 matrix cores (two-term split, three MFMAs per product)"
                                               if (a.fp32_matrix_cores or os.environ.get("SLAK_FP32_AUTOCAST_SPLIT", "0") == "1") else " (exact VALU kernels)")) if a.fp32_dwconv else "bf16 in/out, fp32 accumulate", "optimizer": "torch AdamW(fused)" if a.torch_adamw else "slak_amd MaskedAdamW (update + mask + bf16 copies, one launch)",
-                   "model_ema": bool(a.model_ema),
+                   "model_ema": bool(a.model_ema), "one_autograd_node_per_block": bool(M.Block.fused_block),
                    "sync_bn": True, "block_tail": "hip (ln_nchw_to_nhwc + scale_residual)" if M.Block.fused_tail else "pytorch ops",
                    "branch_bn": "hip (bn3: one stats pass + one apply pass)" if M.ReparamLargeKernelConv.fused_bn else "pytorch (Sync)BatchNorm x3 + adds",
                    "pointwise_gemm": "hipBLASLt via torch" + (", TunableOp solutions from slak_amd/tuning/tunableop_gfx950.csv" if TUNED_GEMMS else ""),

@@ -21,36 +21,57 @@ def _chk(t, name, dtype=None):
         raise TypeError("%s must be %s, got %s" % (name, dtype, t.dtype))
 
 
+def _ln_fwd_impl(x, weight, bias, eps):
+    _chk(x, "x", torch.bfloat16); _chk(weight, "weight", torch.float32); _chk(bias, "bias", torch.float32)
+    N, C, H, W = x.shape
+    y = torch.empty((N, H, W, C), dtype=torch.bfloat16, device=x.device)
+    mean = torch.empty((N, H * W), dtype=torch.float32, device=x.device)
+    rstd = torch.empty_like(mean)
+    L = _lib.lib()
+    with _on(x.device):
+        _lib.check(L.slak_ln_nchw_to_nhwc_forward(x.data_ptr(), weight.data_ptr(), bias.data_ptr(), y.data_ptr(), mean.data_ptr(),
+                                                  rstd.data_ptr(), N, C, H * W, float(eps), _stream(x.device)), "slak_ln_nchw_to_nhwc_forward")
+    return y, mean, rstd
+
+
+_tail_ws_cache = {}
+
+
+def _tail_ws_bytes(N, C, P):
+    key = (N, C, P)
+    v = _tail_ws_cache.get(key)
+    if v is None:
+        v = _tail_ws_cache[key] = int(_lib.lib().slak_block_tail_workspace_bytes(N, C, P))
+    return v
+
+
+def _ln_bwd_impl(g, x, weight, mean, rstd):
+    N, C, H, W = x.shape
+    g = g.contiguous()
+    if g.dtype != torch.bfloat16:
+        g = g.to(torch.bfloat16)
+    dx = torch.empty_like(x)
+    dw = torch.empty_like(weight); db = torch.empty_like(weight)
+    L = _lib.lib()
+    ws, nb = _workspace(_tail_ws_bytes(N, C, H * W), x.device)
+    with _on(x.device):
+        _lib.check(L.slak_ln_nchw_to_nhwc_backward(g.data_ptr(), x.data_ptr(), weight.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                                                   dx.data_ptr(), dw.data_ptr(), db.data_ptr(), N, C, H * W,
+                                                   ws.data_ptr() if ws is not None else None, nb, _stream(x.device)), "slak_ln_nchw_to_nhwc_backward")
+    return dx, dw, db
+
+
 class _LnNchwToNhwc(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, eps):
-        _chk(x, "x", torch.bfloat16); _chk(weight, "weight", torch.float32); _chk(bias, "bias", torch.float32)
-        N, C, H, W = x.shape
-        y = torch.empty((N, H, W, C), dtype=torch.bfloat16, device=x.device)
-        mean = torch.empty((N, H * W), dtype=torch.float32, device=x.device)
-        rstd = torch.empty_like(mean)
-        L = _lib.lib()
-        with _on(x.device):
-            _lib.check(L.slak_ln_nchw_to_nhwc_forward(x.data_ptr(), weight.data_ptr(), bias.data_ptr(), y.data_ptr(), mean.data_ptr(),
-                                                      rstd.data_ptr(), N, C, H * W, float(eps), _stream(x.device)), "slak_ln_nchw_to_nhwc_forward")
+        y, mean, rstd = _ln_fwd_impl(x, weight, bias, eps)
         ctx.save_for_backward(x, weight, mean, rstd)
         return y
 
     @staticmethod
     def backward(ctx, g):
         x, weight, mean, rstd = ctx.saved_tensors
-        N, C, H, W = x.shape
-        g = g.contiguous()
-        if g.dtype != torch.bfloat16:
-            g = g.to(torch.bfloat16)
-        dx = torch.empty_like(x)
-        dw = torch.empty_like(weight); db = torch.empty_like(weight)
-        L = _lib.lib()
-        ws, nb = _workspace(L.slak_block_tail_workspace_bytes(N, C, H * W), x.device)
-        with _on(x.device):
-            _lib.check(L.slak_ln_nchw_to_nhwc_backward(g.data_ptr(), x.data_ptr(), weight.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
-                                                       dx.data_ptr(), dw.data_ptr(), db.data_ptr(), N, C, H * W,
-                                                       ws.data_ptr() if ws is not None else None, nb, _stream(x.device)), "slak_ln_nchw_to_nhwc_backward")
+        dx, dw, db = _ln_bwd_impl(g, x, weight, mean, rstd)
         return dx, dw, db, None
 
 
@@ -125,47 +146,129 @@ accumulate_dgrad = os.environ.get("SLAK_DGRAD_ACC", "1") != "0"     # A/B switch
 fused_tri_wgrad = os.environ.get("SLAK_TRI_WGRAD", "1") != "0"      # A/B switch: 0 = three weight-gradient launches per block everywhere
 
 
+_tri_plan_cache = {}
+
+
+def _tri_plan(dt, N, C, H, W, K):
+    """What the library answers for a block shape -- (one-launch forward?, one-launch data gradient?, rows of the forward launch's BatchNorm
+    statistics, workspace bytes of the three-branch weight gradient, of the two-branch one) -- asked once per (dtype, shape): five ctypes
+    calls per block and direction otherwise."""
+    key = (dt, N, C, H, W, K)
+    plan = _tri_plan_cache.get(key)
+    if plan is None:
+        L = _lib.lib()
+        plan = (L.slak_dwconv2d_tri_supported_op(dt, N, C, H, W, K, 0) == 1, L.slak_dwconv2d_tri_supported_op(dt, N, C, H, W, K, 1) == 1,
+                int(L.slak_dwconv2d_tri_stats_rows(dt, N, C, H, W, K)), int(L.slak_dwconv2d_tri_filter_workspace_bytes(dt, N, C, H, W, K)),
+                int(L.slak_dwconv2d_pair_filter_workspace_bytes(dt, N, C, H, W, K)))
+        _tri_plan_cache[key] = plan
+    return plan
+
+
+def _tri_forward_impl(x, wv, wh, ws, want_stats):
+    """-> (yv, yh, ys, stats, tri_dgrad): the three branch outputs, the BatchNorm sums the launch(es) gathered (one [rows][C][6] array, a triple
+    of [rows_b][C][2] arrays, or None) and whether the one-launch data gradient exists for this shape."""
+    from . import ops
+    _chk(x, "input")
+    N, C, H, W = x.shape
+    K = wv.shape[2]
+    if wv.shape != (C, 1, K, 5) or wh.shape != (C, 1, 5, K) or ws.shape != (C, 1, 5, 5):
+        raise RuntimeError("tri_dwconv expects filters (C,1,K,5), (C,1,5,K), (C,1,5,5)")
+    L = _lib.lib()
+    dt = ops._DT.get(x.dtype)
+    # one launch for the three branches where the library says it wins (slak_dwconv2d_tri_supported_op: per op)
+    f32w = all(w.dtype == torch.float32 and w.is_contiguous() for w in (wv, wh, ws))
+    plan = _tri_plan(dt, N, C, H, W, K) if (dt is not None and f32w) else (False, False, 0, 0, 0)
+    tri, tri_dgrad = plan[0], plan[1]
+    stats = None
+    if tri:
+        yv, yh, ys = torch.empty_like(x), torch.empty_like(x), torch.empty_like(x)
+        rows = plan[2] if (want_stats == 2 and bn_stats_in_conv) else 0
+        with _on(x.device):
+            if rows > 0:                                     # the launch also leaves the branch BatchNorms' batch statistics
+                stats = torch.empty((rows, C, 6), dtype=torch.float32, device=x.device)
+                _lib.check(L.slak_dwconv2d_tri_forward_stats(x.data_ptr(), wv.data_ptr(), wh.data_ptr(), ws.data_ptr(), yv.data_ptr(),
+                                                             yh.data_ptr(), ys.data_ptr(), stats.data_ptr(), dt, N, C, H, W, K, _stream(x.device)),
+                           "slak_dwconv2d_tri_forward_stats")
+            else:
+                _lib.check(L.slak_dwconv2d_tri_forward(x.data_ptr(), wv.data_ptr(), wh.data_ptr(), ws.data_ptr(), yv.data_ptr(),
+                                                       yh.data_ptr(), ys.data_ptr(), dt, N, C, H, W, K, _stream(x.device)),
+                           "slak_dwconv2d_tri_forward")
+    elif want_stats == 2 and bn_stats_in_conv:               # per-branch launches that gather their BatchNorm's sums in the copy-out
+        (yv, sv), (yh, sh), (ys, ss) = ops.dwconv2d_forward_stats(x, wv), ops.dwconv2d_forward_stats(x, wh), ops.dwconv2d_forward_stats(x, ws)
+        if sv is not None and sh is not None and ss is not None:
+            stats = (sv, sh, ss)
+    else:
+        yv, yh, ys = ops.dwconv2d_forward(x, wv), ops.dwconv2d_forward(x, wh), ops.dwconv2d_forward(x, ws)
+    return yv, yh, ys, stats, tri_dgrad
+
+
+def _tri_backward_impl(x, wv, wh, ws, dyv, dyh, dys, tri_dgrad, need_dx, need_w):
+    """-> (dx, dwv, dwh, dws); need_w: three booleans."""
+    from . import ops
+    N, C, H, W = x.shape
+    K = wv.shape[2]
+    dyv, dyh, dys = (torch.zeros_like(x) if g is None else g for g in (dyv, dyh, dys))       # (a branch output nobody used)
+    dyv, dyh, dys = (g.contiguous() if g.dtype == x.dtype else g.to(x.dtype).contiguous() for g in (dyv, dyh, dys))
+    dx = None
+    if need_dx:
+        if tri_dgrad:
+            dx = torch.empty_like(x)
+            L = _lib.lib()
+            with _on(x.device):
+                _lib.check(L.slak_dwconv2d_tri_backward_data(dyv.data_ptr(), dyh.data_ptr(), dys.data_ptr(), wv.data_ptr(),
+                                                             wh.data_ptr(), ws.data_ptr(), dx.data_ptr(), ops._DT[x.dtype],
+                                                             N, C, H, W, K, _stream(x.device)), "slak_dwconv2d_tri_backward_data")
+        else:
+            dx = ops.dwconv2d_backward_data(dyv, wv)
+            if accumulate_dgrad:
+                ops.dwconv2d_backward_data_accumulate(dyh, wh, dx)   # autograd's two adds folded into the kernels' copy-out
+                ops.dwconv2d_backward_data_accumulate(dys, ws, dx)
+            else:
+                dx += ops.dwconv2d_backward_data(dyh, wh)
+                dx += ops.dwconv2d_backward_data(dys, ws)
+    dwv = dwh = dws = None
+    plan = _tri_plan(ops._DT[x.dtype], N, C, H, W, K) if x.dtype in ops._DT else (False, False, 0, 0, 0)
+    if all(need_w) and fused_tri_wgrad and plan[3]:          # one launch for the three weight gradients (x fetched once)
+        L = _lib.lib()
+        dt = ops._DT[x.dtype]
+        dwv, dwh, dws = (torch.empty_like(w, dtype=torch.float32) for w in (wv, wh, ws))
+        wsb, nbb = _workspace(plan[3], x.device)
+        with _on(x.device):
+            rc = L.slak_dwconv2d_tri_backward_filter(dyv.data_ptr(), dyh.data_ptr(), dys.data_ptr(), x.data_ptr(), dwv.data_ptr(),
+                                                     dwh.data_ptr(), dws.data_ptr(), dt, N, C, H, W, K, wsb.data_ptr(), nbb, _stream(x.device))
+        if rc == _lib.ERR_UNSUPPORTED:
+            dwv = dwh = dws = None
+        else:
+            _lib.check(rc, "slak_dwconv2d_tri_backward_filter")
+    if dwv is None and need_w[0] and need_w[2] and fused_tri_wgrad and plan[4]:      # K x 5 and 5 x 5 in one launch (x fetched and shifted once)
+        L = _lib.lib()
+        dt = ops._DT[x.dtype]
+        dwv, dws = (torch.empty_like(w, dtype=torch.float32) for w in (wv, ws))
+        wsb, nbb = _workspace(plan[4], x.device)
+        with _on(x.device):
+            rc = L.slak_dwconv2d_pair_backward_filter(dyv.data_ptr(), dys.data_ptr(), x.data_ptr(), dwv.data_ptr(), dws.data_ptr(),
+                                                      dt, N, C, H, W, K, wsb.data_ptr(), nbb, _stream(x.device))
+        if rc == _lib.ERR_UNSUPPORTED:
+            dwv = dws = None
+        else:
+            _lib.check(rc, "slak_dwconv2d_pair_backward_filter")
+            dwh = ops.dwconv2d_backward_filter(dyh, x, wh) if need_w[1] else None
+    if dwv is None:
+        dwv = ops.dwconv2d_backward_filter(dyv, x, wv) if need_w[0] else None
+        dwh = ops.dwconv2d_backward_filter(dyh, x, wh) if need_w[1] else None
+        dws = ops.dwconv2d_backward_filter(dys, x, ws) if need_w[2] else None
+    return dx, dwv, dwh, dws
+
+
 class _TriDwConv(torch.autograd.Function):
     """The three branch convolutions of a decomposed large-kernel block -- LoRA1 (K x 5), LoRA2 (5 x K), small_conv (5 x 5) on the
-    same input (models/SLaK.py:82-100) -- as one autograd node.  Where the one-launch kernels exist (slak_dwconv2d_tri_*: the 14x14
-    class) the input is read once forward and the three input gradients are summed in the accumulator; elsewhere the three
-    per-branch kernels run and the gradients are added here.  Weight gradients always come from the per-branch kernels."""
+    same input (models/SLaK.py:82-100) -- as one autograd node.  Where the one-launch kernels exist (slak_dwconv2d_tri_*) the input is
+    read once forward and the three input gradients are summed in the accumulator; elsewhere the per-branch kernels run and the
+    gradients are added here."""
 
     @staticmethod
     def forward(ctx, x, wv, wh, ws, want_stats=False):
-        from . import ops
-        _chk(x, "input")
-        N, C, H, W = x.shape
-        K = wv.shape[2]
-        if wv.shape != (C, 1, K, 5) or wh.shape != (C, 1, 5, K) or ws.shape != (C, 1, 5, 5):
-            raise RuntimeError("tri_dwconv expects filters (C,1,K,5), (C,1,5,K), (C,1,5,5)")
-        L = _lib.lib()
-        dt = ops._DT.get(x.dtype)
-        # one launch for the three branches where the library says it wins (slak_dwconv2d_tri_supported_op: per op -- on the 56x56
-        # class only the data gradient does)
-        f32w = all(w.dtype == torch.float32 and w.is_contiguous() for w in (wv, wh, ws))
-        tri = bool(dt is not None and f32w and L.slak_dwconv2d_tri_supported_op(dt, N, C, H, W, K, 0) == 1)
-        ctx.tri_dgrad = bool(dt is not None and f32w and L.slak_dwconv2d_tri_supported_op(dt, N, C, H, W, K, 1) == 1)
-        stats = None
-        if tri:
-            yv, yh, ys = torch.empty_like(x), torch.empty_like(x), torch.empty_like(x)
-            rows = int(L.slak_dwconv2d_tri_stats_rows(dt, N, C, H, W, K)) if (want_stats == 2 and bn_stats_in_conv) else 0
-            with _on(x.device):
-                if rows > 0:                                     # the launch also leaves the branch BatchNorms' batch statistics
-                    stats = torch.empty((rows, C, 6), dtype=torch.float32, device=x.device)
-                    _lib.check(L.slak_dwconv2d_tri_forward_stats(x.data_ptr(), wv.data_ptr(), wh.data_ptr(), ws.data_ptr(), yv.data_ptr(),
-                                                                 yh.data_ptr(), ys.data_ptr(), stats.data_ptr(), dt, N, C, H, W, K, _stream(x.device)),
-                               "slak_dwconv2d_tri_forward_stats")
-                else:
-                    _lib.check(L.slak_dwconv2d_tri_forward(x.data_ptr(), wv.data_ptr(), wh.data_ptr(), ws.data_ptr(), yv.data_ptr(),
-                                                           yh.data_ptr(), ys.data_ptr(), dt, N, C, H, W, K, _stream(x.device)),
-                               "slak_dwconv2d_tri_forward")
-        elif want_stats == 2 and bn_stats_in_conv:               # per-branch launches that gather their BatchNorm's sums in the copy-out
-            (yv, sv), (yh, sh), (ys, ss) = ops.dwconv2d_forward_stats(x, wv), ops.dwconv2d_forward_stats(x, wh), ops.dwconv2d_forward_stats(x, ws)
-            if sv is not None and sh is not None and ss is not None:
-                stats = (sv, sh, ss)
-        else:
-            yv, yh, ys = ops.dwconv2d_forward(x, wv), ops.dwconv2d_forward(x, wh), ops.dwconv2d_forward(x, ws)
+        yv, yh, ys, stats, ctx.tri_dgrad = _tri_forward_impl(x, wv, wh, ws, want_stats)
         ctx.save_for_backward(x, wv, wh, ws)
         # (the three statistics outputs are non-differentiable; autograd would still hand backward() a ZERO tensor for each of them --
         # three fill launches per block and step, 54 of the 56 FillFunctor launches of a SLaK-T step)
@@ -173,75 +276,25 @@ class _TriDwConv(torch.autograd.Function):
         if want_stats:
             # the sums travel as three non-differentiable outputs: one [rows][C][6] array (three-branch launch) seen through three offsets,
             # three [rows_b][C][2] arrays (per-branch launches), or three empty tensors
-            if stats is None:
-                e = torch.empty(0, device=x.device)
-                stats = (e, e.clone(), e.clone())
-            elif not isinstance(stats, tuple):
-                stats = (stats, stats[:, :, 2:], stats[:, :, 4:])
+            stats = _stats_triple(stats, x.device)
             ctx.mark_non_differentiable(*stats)
             return (yv, yh, ys) + tuple(stats)
         return yv, yh, ys
 
     @staticmethod
     def backward(ctx, dyv, dyh, dys, *_dstats):
-        from . import ops
         x, wv, wh, ws = ctx.saved_tensors
-        N, C, H, W = x.shape
-        K = wv.shape[2]
-        dyv, dyh, dys = (torch.zeros_like(x) if g is None else g for g in (dyv, dyh, dys))       # (a branch output nobody used)
-        dyv, dyh, dys = (g.contiguous() if g.dtype == x.dtype else g.to(x.dtype).contiguous() for g in (dyv, dyh, dys))
-        dx = None
-        if ctx.needs_input_grad[0]:
-            if ctx.tri_dgrad:
-                dx = torch.empty_like(x)
-                L = _lib.lib()
-                with _on(x.device):
-                    _lib.check(L.slak_dwconv2d_tri_backward_data(dyv.data_ptr(), dyh.data_ptr(), dys.data_ptr(), wv.data_ptr(),
-                                                                 wh.data_ptr(), ws.data_ptr(), dx.data_ptr(), ops._DT[x.dtype],
-                                                                 N, C, H, W, K, _stream(x.device)), "slak_dwconv2d_tri_backward_data")
-            else:
-                dx = ops.dwconv2d_backward_data(dyv, wv)
-                if accumulate_dgrad:
-                    ops.dwconv2d_backward_data_accumulate(dyh, wh, dx)   # autograd's two adds folded into the kernels' copy-out
-                    ops.dwconv2d_backward_data_accumulate(dys, ws, dx)
-                else:
-                    dx += ops.dwconv2d_backward_data(dyh, wh)
-                    dx += ops.dwconv2d_backward_data(dys, ws)
-        dwv = dwh = dws = None
-        if all(ctx.needs_input_grad[1:4]) and fused_tri_wgrad and x.dtype in ops._DT:
-            L = _lib.lib()
-            dt = ops._DT[x.dtype]
-            nb = int(L.slak_dwconv2d_tri_filter_workspace_bytes(dt, N, C, H, W, K))
-            if nb:                                               # one launch for the three weight gradients (x fetched once)
-                dwv, dwh, dws = (torch.empty_like(w, dtype=torch.float32) for w in (wv, wh, ws))
-                wsb, nbb = _workspace(nb, x.device)
-                with _on(x.device):
-                    rc = L.slak_dwconv2d_tri_backward_filter(dyv.data_ptr(), dyh.data_ptr(), dys.data_ptr(), x.data_ptr(), dwv.data_ptr(),
-                                                             dwh.data_ptr(), dws.data_ptr(), dt, N, C, H, W, K, wsb.data_ptr(), nbb, _stream(x.device))
-                if rc == _lib.ERR_UNSUPPORTED:
-                    dwv = dwh = dws = None
-                else:
-                    _lib.check(rc, "slak_dwconv2d_tri_backward_filter")
-        if dwv is None and ctx.needs_input_grad[1] and ctx.needs_input_grad[3] and fused_tri_wgrad and x.dtype in ops._DT:
-            L = _lib.lib()
-            dt = ops._DT[x.dtype]
-            nb = int(L.slak_dwconv2d_pair_filter_workspace_bytes(dt, N, C, H, W, K))
-            if nb:                                               # K x 5 and 5 x 5 in one launch (x fetched and shifted once)
-                dwv, dws = (torch.empty_like(w, dtype=torch.float32) for w in (wv, ws))
-                wsb, nbb = _workspace(nb, x.device)
-                with _on(x.device):
-                    rc = L.slak_dwconv2d_pair_backward_filter(dyv.data_ptr(), dys.data_ptr(), x.data_ptr(), dwv.data_ptr(), dws.data_ptr(),
-                                                              dt, N, C, H, W, K, wsb.data_ptr(), nbb, _stream(x.device))
-                if rc == _lib.ERR_UNSUPPORTED:
-                    dwv = dws = None
-                else:
-                    _lib.check(rc, "slak_dwconv2d_pair_backward_filter")
-                    dwh = ops.dwconv2d_backward_filter(dyh, x, wh) if ctx.needs_input_grad[2] else None
-        if dwv is None:
-            dwv = ops.dwconv2d_backward_filter(dyv, x, wv) if ctx.needs_input_grad[1] else None
-            dwh = ops.dwconv2d_backward_filter(dyh, x, wh) if ctx.needs_input_grad[2] else None
-            dws = ops.dwconv2d_backward_filter(dys, x, ws) if ctx.needs_input_grad[3] else None
+        dx, dwv, dwh, dws = _tri_backward_impl(x, wv, wh, ws, dyv, dyh, dys, ctx.tri_dgrad, ctx.needs_input_grad[0], ctx.needs_input_grad[1:4])
         return dx, dwv, dwh, dws, None
+
+
+def _stats_triple(stats, device):
+    if stats is None:
+        e = torch.empty(0, device=device)
+        return (e, e.clone(), e.clone())
+    if not isinstance(stats, tuple):
+        return (stats, stats[:, :, 2:], stats[:, :, 4:])
+    return stats
 
 
 bn_stats_in_conv = os.environ.get("SLAK_BN_STATS_IN_CONV", "1") != "0"   # three-branch forward launches also leave the branch BatchNorms' batch sums
@@ -387,10 +440,117 @@ class BnCounterPool:
         return True
 
 
-def _sync_bn_all_reduce(buf, group):
-    """The SyncBatchNorm statistics exchange of one block and direction (6C + 1 doubles forward, 4C floats backward)."""
+def _sync_bn_all_reduce(buf, group, async_op=False):
+    """The SyncBatchNorm statistics exchange of one block and direction (6C + 1 doubles forward, 4C floats backward).  async_op: returns the
+    work handle right after the issue (the caller launches independent kernels, then waits)."""
     import torch.distributed as dist
-    dist.all_reduce(buf, group=group)
+    return dist.all_reduce(buf, group=group, async_op=async_op)
+
+
+def _bn3_forward_impl(y1, y2, y3, gam, bet, bns, group, pre):
+    """Training-mode statistics of the three branch BatchNorms (cross-rank when ``group`` is given: one all-reduce of 6C+1 doubles), running-stat
+    update, fused scale / shift / add.  -> (out, stats [6C] for the backward, count, count_dev)"""
+    for t, n in ((y1, "y1"), (y2, "y2"), (y3, "y3")):
+        _chk(t, n, torch.bfloat16)
+    N, C, H, W = y1.shape
+    P = H * W
+    dev = y1.device
+    L = _lib.lib()
+    rmean = [bn.running_mean for bn in bns]; rvar = [bn.running_var for bn in bns]
+    eps = float(bns[0].eps)
+    momentum = bns[0].momentum
+    ctrs = [bn.num_batches_tracked for bn in bns if bn.track_running_stats and bn.num_batches_tracked is not None]
+    pool = getattr(bns[0], "_slak_ctr_pool", None)
+    if pool is not None and len(ctrs) == len(bns) and pool.covers(bns) and pool.bump_once():
+        pass                                                  # every pooled counter of the model in one launch per managed forward pass
+    elif ctrs:
+        torch._foreach_add_(ctrs, 1)
+    if momentum is None:                                     # cumulative moving average, as nn.BatchNorm
+        momentum = 1.0 / float(bns[0].num_batches_tracked.item())
+    ws, nb = _workspace(_bn3_ws_bytes(N, C), dev)
+    coef = torch.empty(C * 4, dtype=torch.float32, device=dev)
+    stats = torch.empty(C * 6, dtype=torch.float32, device=dev)
+    out = torch.empty_like(y1)
+    if group is None:                                        # single process: sums, finalise and apply without the exchange step (3 launches)
+        with _on(dev):
+            _lib.check(L.slak_bn3_forward_local(y1.data_ptr(), y2.data_ptr(), y3.data_ptr(), _ptr3(gam), _ptr3(bet), _ptr3(rmean), _ptr3(rvar),
+                                                eps, float(momentum), 1 if bns[0].track_running_stats else 0, coef.data_ptr(), stats.data_ptr(),
+                                                out.data_ptr(), N, C, P, ws.data_ptr() if ws is not None else None, nb, _stream(dev),
+                                                _ptr3(list(pre)) if pre is not None else None,
+                                                (ctypes.c_int * 3)(*[int(t.shape[0]) for t in pre]) if pre is not None else None,
+                                                int(pre[0].stride(1)) if pre is not None else 0),
+                       "slak_bn3_forward_local")
+        return out, stats, float(N * P), None
+    sums = torch.empty(C * 6 + 1, dtype=torch.float64, device=dev)      # sum y_b, sum y_b^2 per channel as doubles + the element count
+    pre_args = ((_ptr3(list(pre)), (ctypes.c_int * 3)(*[int(t.shape[0]) for t in pre]), int(pre[0].stride(1))) if pre is not None
+                else (None, None, 0))                                 # the conv launches' rows feed the exchange buffer: no read pass
+    with _on(dev):
+        _lib.check(L.slak_bn3_forward_sums(y1.data_ptr(), y2.data_ptr(), y3.data_ptr(), sums.data_ptr(), N, C, P,
+                                           ws.data_ptr() if ws is not None else None, nb, _stream(dev), *pre_args), "slak_bn3_forward_sums")
+    count = float(N * P)
+    sums[C * 6:].fill_(count)
+    _sync_bn_all_reduce(sums, group)
+    count_dev = sums[C * 6:]                                 # global element count, stays on the device (no host sync)
+    with _on(dev):
+        _lib.check(L.slak_bn3_forward_apply(y1.data_ptr(), y2.data_ptr(), y3.data_ptr(), sums.data_ptr(), count,
+                                            count_dev.data_ptr(), _ptr3(gam), _ptr3(bet), _ptr3(rmean), _ptr3(rvar), eps, float(momentum), 1,
+                                            1 if bns[0].track_running_stats else 0,
+                                            coef.data_ptr(), stats.data_ptr(), out.data_ptr(), N, C, P, _stream(dev)), "slak_bn3_forward_apply")
+    return out, stats, count, count_dev
+
+
+_bn3_ws_cache = {}
+
+
+def _bn3_ws_bytes(N, C):
+    key = (N, C)
+    v = _bn3_ws_cache.get(key)
+    if v is None:
+        v = _bn3_ws_cache[key] = int(_lib.lib().slak_bn3_workspace_bytes(N, C))
+    return v
+
+
+def _bn3_backward_impl(dout, y1, y2, y3, gs, stats, group, count, count_dev, between=None):
+    """-> (d1, d2, d3, dgamma [3][C], dbeta [3][C]).  ``between``: work that does not depend on the statistics exchange (the block's pointwise
+    weight gradients); with a process group it is launched AFTER the all-reduce of the backward sums has been issued (asynchronously) and
+    BEFORE the apply pass waits for it -- the collective's latency hides behind those launches; single process: simply runs first."""
+    N, C, H, W = y1.shape
+    P = H * W
+    dev = y1.device
+    dout = dout.contiguous()
+    if dout.dtype != torch.bfloat16:
+        dout = dout.to(torch.bfloat16)
+    L = _lib.lib()
+    ws, nb = _workspace(_bn3_ws_bytes(N, C), dev)
+    bcoef = torch.empty(C * 9, dtype=torch.float32, device=dev)
+    dgamma = torch.empty(3, C, dtype=torch.float32, device=dev)
+    dbeta = torch.empty(3, C, dtype=torch.float32, device=dev)
+    d1, d2, d3 = torch.empty_like(y1), torch.empty_like(y2), torch.empty_like(y3)
+    if group is None:
+        if between is not None:
+            between()
+        with _on(dev):
+            _lib.check(L.slak_bn3_backward_local(dout.data_ptr(), y1.data_ptr(), y2.data_ptr(), y3.data_ptr(), stats.data_ptr(), _ptr3(gs),
+                                                 bcoef.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), d1.data_ptr(), d2.data_ptr(), d3.data_ptr(),
+                                                 N, C, P, ws.data_ptr() if ws is not None else None, nb, _stream(dev)), "slak_bn3_backward_local")
+        return d1, d2, d3, dgamma, dbeta
+    lsums = torch.empty(C * 4, dtype=torch.float32, device=dev)
+    with _on(dev):
+        _lib.check(L.slak_bn3_backward_sums(dout.data_ptr(), y1.data_ptr(), y2.data_ptr(), y3.data_ptr(), stats.data_ptr(), lsums.data_ptr(), N, C, P,
+                                            ws.data_ptr() if ws is not None else None, nb, _stream(dev)), "slak_bn3_backward_sums")
+    gsums = lsums.clone()
+    work = _sync_bn_all_reduce(gsums, group, async_op=between is not None)
+    if between is not None:
+        between()                                            # launched behind the collective's issue, in front of its wait
+        if work is not None:
+            work.wait()
+    with _on(dev):
+        _lib.check(L.slak_bn3_backward_apply(dout.data_ptr(), y1.data_ptr(), y2.data_ptr(), y3.data_ptr(), gsums.data_ptr(),
+                                             lsums.data_ptr(), count, count_dev.data_ptr() if count_dev is not None else None,
+                                             stats.data_ptr(), _ptr3(gs),
+                                             bcoef.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(),
+                                             d1.data_ptr(), d2.data_ptr(), d3.data_ptr(), N, C, P, _stream(dev)), "slak_bn3_backward_apply")
+    return d1, d2, d3, dgamma, dbeta
 
 
 class _BranchBN3(torch.autograd.Function):
@@ -399,110 +559,34 @@ class _BranchBN3(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, y1, y2, y3, g1, b1, g2, b2, g3, b3, bns, group, pre=None):
-        import torch.distributed as dist
-        for t, n in ((y1, "y1"), (y2, "y2"), (y3, "y3")):
-            _chk(t, n, torch.bfloat16)
-        N, C, H, W = y1.shape
-        P = H * W
-        dev = y1.device
-        L = _lib.lib()
-        gam, bet = [g1, g2, g3], [b1, b2, b3]
-        rmean = [bn.running_mean for bn in bns]; rvar = [bn.running_var for bn in bns]
-        eps = float(bns[0].eps)
-        momentum = bns[0].momentum
-        ctrs = [bn.num_batches_tracked for bn in bns if bn.track_running_stats and bn.num_batches_tracked is not None]
-        pool = getattr(bns[0], "_slak_ctr_pool", None)
-        if pool is not None and len(ctrs) == len(bns) and pool.covers(bns) and pool.bump_once():
-            pass                                                  # every pooled counter of the model in one launch per managed forward pass
-        elif ctrs:
-            torch._foreach_add_(ctrs, 1)
-        if momentum is None:                                     # cumulative moving average, as nn.BatchNorm
-            momentum = 1.0 / float(bns[0].num_batches_tracked.item())
-        ws, nb = _workspace(L.slak_bn3_workspace_bytes(N, C), dev)
-        if group is None:                                        # single process: sums, finalise and apply without the exchange step (3 launches)
-            coef = torch.empty(C * 4, dtype=torch.float32, device=dev)
-            stats = torch.empty(C * 6, dtype=torch.float32, device=dev)
-            out = torch.empty_like(y1)
-            with _on(dev):
-                _lib.check(L.slak_bn3_forward_local(y1.data_ptr(), y2.data_ptr(), y3.data_ptr(), _ptr3(gam), _ptr3(bet), _ptr3(rmean), _ptr3(rvar),
-                                                    eps, float(momentum), 1 if bns[0].track_running_stats else 0, coef.data_ptr(), stats.data_ptr(),
-                                                    out.data_ptr(), N, C, P, ws.data_ptr() if ws is not None else None, nb, _stream(dev),
-                                                    _ptr3(list(pre)) if pre is not None else None,
-                                                    (ctypes.c_int * 3)(*[int(t.shape[0]) for t in pre]) if pre is not None else None,
-                                                    int(pre[0].stride(1)) if pre is not None else 0),
-                           "slak_bn3_forward_local")
-            ctx.save_for_backward(y1, y2, y3, g1, g2, g3, stats)
-            ctx.group = None
-            ctx.count = float(N * P)
-            ctx.count_dev = None
-            return out
-        sums = torch.empty(C * 6 + 1, dtype=torch.float64, device=dev)      # sum y_b, sum y_b^2 per channel as doubles + the element count
-        pre_args = ((_ptr3(list(pre)), (ctypes.c_int * 3)(*[int(t.shape[0]) for t in pre]), int(pre[0].stride(1))) if pre is not None
-                    else (None, None, 0))                                 # the conv launches' rows feed the exchange buffer: no read pass
-        with _on(dev):
-            _lib.check(L.slak_bn3_forward_sums(y1.data_ptr(), y2.data_ptr(), y3.data_ptr(), sums.data_ptr(), N, C, P,
-                                               ws.data_ptr() if ws is not None else None, nb, _stream(dev), *pre_args), "slak_bn3_forward_sums")
-        count = float(N * P)
-        count_dev = None
-        if group is not None:
-            sums[C * 6:].fill_(count)
-            _sync_bn_all_reduce(sums, group)
-            count_dev = sums[C * 6:]                                 # global element count, stays on the device (no host sync)
-        coef = torch.empty(C * 4, dtype=torch.float32, device=dev)
-        stats = torch.empty(C * 6, dtype=torch.float32, device=dev)
-        out = torch.empty_like(y1)
-        with _on(dev):
-            _lib.check(L.slak_bn3_forward_apply(y1.data_ptr(), y2.data_ptr(), y3.data_ptr(), sums.data_ptr(), count,
-                                                count_dev.data_ptr() if count_dev is not None else None, _ptr3(gam), _ptr3(bet), _ptr3(rmean), _ptr3(rvar), eps, float(momentum), 1,
-                                                1 if bns[0].track_running_stats else 0,
-                                                coef.data_ptr(), stats.data_ptr(), out.data_ptr(), N, C, P, _stream(dev)), "slak_bn3_forward_apply")
+        out, stats, ctx.count, ctx.count_dev = _bn3_forward_impl(y1, y2, y3, [g1, g2, g3], [b1, b2, b3], bns, group, pre)
         ctx.save_for_backward(y1, y2, y3, g1, g2, g3, stats)
         ctx.group = group
-        ctx.count = count
-        ctx.count_dev = count_dev
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        import torch.distributed as dist
         y1, y2, y3, g1, g2, g3, stats = ctx.saved_tensors
-        N, C, H, W = y1.shape
-        P = H * W
-        dev = y1.device
-        dout = dout.contiguous()
-        if dout.dtype != torch.bfloat16:
-            dout = dout.to(torch.bfloat16)
-        L = _lib.lib()
-        ws, nb = _workspace(L.slak_bn3_workspace_bytes(N, C), dev)
-        if ctx.group is None:
-            bcoef = torch.empty(C * 9, dtype=torch.float32, device=dev)
-            dgamma = torch.empty(3, C, dtype=torch.float32, device=dev)
-            dbeta = torch.empty(3, C, dtype=torch.float32, device=dev)
-            d1, d2, d3 = torch.empty_like(y1), torch.empty_like(y2), torch.empty_like(y3)
-            with _on(dev):
-                _lib.check(L.slak_bn3_backward_local(dout.data_ptr(), y1.data_ptr(), y2.data_ptr(), y3.data_ptr(), stats.data_ptr(), _ptr3([g1, g2, g3]),
-                                                     bcoef.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), d1.data_ptr(), d2.data_ptr(), d3.data_ptr(),
-                                                     N, C, P, ws.data_ptr() if ws is not None else None, nb, _stream(dev)), "slak_bn3_backward_local")
-            return d1, d2, d3, dgamma[0], dbeta[0], dgamma[1], dbeta[1], dgamma[2], dbeta[2], None, None, None
-        lsums = torch.empty(C * 4, dtype=torch.float32, device=dev)
-        with _on(dev):
-            _lib.check(L.slak_bn3_backward_sums(dout.data_ptr(), y1.data_ptr(), y2.data_ptr(), y3.data_ptr(), stats.data_ptr(), lsums.data_ptr(), N, C, P,
-                                                ws.data_ptr() if ws is not None else None, nb, _stream(dev)), "slak_bn3_backward_sums")
-        gsums = lsums
-        if ctx.group is not None:
-            gsums = lsums.clone()
-            _sync_bn_all_reduce(gsums, ctx.group)
-        bcoef = torch.empty(C * 9, dtype=torch.float32, device=dev)
-        dgamma = torch.empty(3, C, dtype=torch.float32, device=dev)
-        dbeta = torch.empty(3, C, dtype=torch.float32, device=dev)
-        d1, d2, d3 = torch.empty_like(y1), torch.empty_like(y2), torch.empty_like(y3)
-        with _on(dev):
-            _lib.check(L.slak_bn3_backward_apply(dout.data_ptr(), y1.data_ptr(), y2.data_ptr(), y3.data_ptr(), gsums.data_ptr(),
-                                                 lsums.data_ptr(), ctx.count, ctx.count_dev.data_ptr() if ctx.count_dev is not None else None,
-                                                 stats.data_ptr(), _ptr3([g1, g2, g3]),
-                                                 bcoef.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(),
-                                                 d1.data_ptr(), d2.data_ptr(), d3.data_ptr(), N, C, P, _stream(dev)), "slak_bn3_backward_apply")
+        d1, d2, d3, dgamma, dbeta = _bn3_backward_impl(dout, y1, y2, y3, [g1, g2, g3], stats, ctx.group, ctx.count, ctx.count_dev)
         return d1, d2, d3, dgamma[0], dbeta[0], dgamma[1], dbeta[1], dgamma[2], dbeta[2], None, None, None
+
+
+def _bn3_pre_rows(stats, C):
+    """The conv launches' statistics rows in the form slak_bn3_forward_* take them, or None (SyncBatchNorm too: the rows feed the all-reduce buffer)."""
+    if (stats is not None and len(stats) == 3
+            and all(t.dim() == 3 and t.shape[0] > 0 and t.shape[1] == C and t.dtype == torch.float32 and t.stride(2) == 1
+                    and t.stride(0) == t.shape[1] * t.stride(1) for t in stats) and len({t.stride(1) for t in stats}) == 1):
+        return tuple(stats)
+    return None
+
+
+def _bn3_group(bn1):
+    import torch.distributed as dist
+    if isinstance(bn1, torch.nn.SyncBatchNorm) and dist.is_available() and dist.is_initialized():
+        pg = bn1.process_group if bn1.process_group is not None else dist.group.WORLD
+        if dist.get_world_size(pg) > 1:
+            return pg
+    return None
 
 
 def branch_bn3(y1, y2, y3, bn1, bn2, bn3, stats=None):
@@ -512,16 +596,8 @@ def branch_bn3(y1, y2, y3, bn1, bn2, bn3, stats=None):
     import torch.distributed as dist
     bns = (bn1, bn2, bn3)
     if bn1.training or not bn1.track_running_stats:
-        group = None
-        if isinstance(bn1, torch.nn.SyncBatchNorm) and dist.is_available() and dist.is_initialized():
-            pg = bn1.process_group if bn1.process_group is not None else dist.group.WORLD
-            if dist.get_world_size(pg) > 1:
-                group = pg
-        pre = None
-        if (stats is not None and len(stats) == 3          # (SyncBatchNorm too: the rows feed the all-reduce buffer)
-                and all(t.dim() == 3 and t.shape[0] > 0 and t.shape[1] == y1.shape[1] and t.dtype == torch.float32 and t.stride(2) == 1
-                        and t.stride(0) == t.shape[1] * t.stride(1) for t in stats) and len({t.stride(1) for t in stats}) == 1):
-            pre = tuple(stats)
+        group = _bn3_group(bn1)
+        pre = _bn3_pre_rows(stats, y1.shape[1])
         return _BranchBN3.apply(y1, y2, y3, bn1.weight, bn1.bias, bn2.weight, bn2.bias, bn3.weight, bn3.bias, bns, group, pre)
     # eval: one apply pass with coefficients from the running statistics (no autograd needed for the statistics)
     N, C, H, W = y1.shape
@@ -804,27 +880,29 @@ def _mlp_fwd(t, w1, b1, w2, b2):
     return z, (t, w1b, y1, a, w2b)
 
 
-def _mlp_bwd(saved, dz, db2=None):
-    """db2: the column sums of dz when the caller already has them (scale_residual's backward produces them for free)."""
-    t, w1b, y1, a, w2b = saved
-    dz2 = dz.reshape(-1, dz.shape[-1])
-    a2 = a.reshape(-1, a.shape[-1]); t2 = t.reshape(-1, t.shape[-1]); y12 = y1.reshape(-1, y1.shape[-1])
-    M = dz2.shape[0]
+def _mlp_wgrad(dy, x):
+    """dW = dy^T x (fp32) for the pointwise Linear layers: slak_linear_wgrad where it covers the shape, else the library's split-K batched GEMM."""
+    d = linear_wgrad(dy, x)
+    if d is not None:
+        return d
+    M = dy.shape[0]
     S = max(1, M // _SPLITK_ROWS) if _SPLITK_ROWS > 0 else 1
     while S > 1 and M % S:
         S -= 1
+    if S > 1:
+        return torch.bmm(dy.view(S, M // S, -1).transpose(1, 2), x.view(S, M // S, -1)).sum(0, dtype=torch.float32)
+    return torch.mm(dy.t(), x).float()
 
-    def wgrad(dy, x):
-        d = linear_wgrad(dy, x)
-        if d is not None:
-            return d
-        if S > 1:
-            return torch.bmm(dy.view(S, M // S, -1).transpose(1, 2), x.view(S, M // S, -1)).sum(0, dtype=torch.float32)
-        return torch.mm(dy.t(), x).float()
 
-    dw2 = wgrad(dz2, a2)
-    if db2 is None:
-        db2 = dz2.sum(0, dtype=torch.float32)
+_gelu_ws_cache = {}
+
+
+def _mlp_bwd_data(saved, dz):
+    """The data path of the MLP's backward: dz -> dact -> (GELU') dy1 (+ pwconv1's bias gradient) -> dt.  -> (dt, dy1 [M][4C], db1)"""
+    t, w1b, y1, a, w2b = saved
+    dz2 = dz.reshape(-1, dz.shape[-1])
+    y12 = y1.reshape(-1, y1.shape[-1])
+    M = dz2.shape[0]
     dact = None
     if linear_nt_covers(dz2, w2b.shape[1]):
         dact = linear_nt(dz2, w2b.t().contiguous())              # dz @ W2: NT against the (small) transposed weight
@@ -833,13 +911,34 @@ def _mlp_bwd(saved, dz, db2=None):
     dy1 = torch.empty_like(dact)
     db1 = torch.empty(dact.shape[1], dtype=torch.float32, device=dact.device)
     L = _lib.lib()
-    ws, nb = _workspace(L.slak_gelu_bwd_workspace_bytes(M, dact.shape[1]), dact.device)
+    key = (M, dact.shape[1])
+    nbw = _gelu_ws_cache.get(key)
+    if nbw is None:
+        nbw = _gelu_ws_cache[key] = int(L.slak_gelu_bwd_workspace_bytes(M, dact.shape[1]))
+    ws, nb = _workspace(nbw, dact.device)
     with _on(dact.device):
         _lib.check(L.slak_gelu_backward_bias(dact.data_ptr(), y12.data_ptr(), dy1.data_ptr(), db1.data_ptr(), M, dact.shape[1],
                                              ws.data_ptr() if ws is not None else None, nb, _stream(dact.device)), "slak_gelu_backward_bias")
-    dw1 = wgrad(dy1, t2)
     dt = linear_nt(dy1, w1b.t().contiguous()) if linear_nt_covers(dy1, w1b.shape[1]) else None
     dt = (dt if dt is not None else torch.mm(dy1, w1b)).view_as(t)
+    return dt, dy1, db1
+
+
+def _mlp_bwd_weights(saved, dz, dy1):
+    """The two pointwise weight gradients (they feed nothing else of the block's backward) -> (dw1, dw2)"""
+    t, w1b, y1, a, w2b = saved
+    dz2 = dz.reshape(-1, dz.shape[-1])
+    dw2 = _mlp_wgrad(dz2, a.reshape(-1, a.shape[-1]))
+    dw1 = _mlp_wgrad(dy1, t.reshape(-1, t.shape[-1]))
+    return dw1, dw2
+
+
+def _mlp_bwd(saved, dz, db2=None):
+    """db2: the column sums of dz when the caller already has them (scale_residual's backward produces them for free)."""
+    dt, dy1, db1 = _mlp_bwd_data(saved, dz)
+    dw1, dw2 = _mlp_bwd_weights(saved, dz, dy1)
+    if db2 is None:
+        db2 = dz.reshape(-1, dz.shape[-1]).sum(0, dtype=torch.float32)
     return dt, dw1, db1, dw2, db2
 
 
@@ -892,3 +991,64 @@ def mlp_scale_residual(shortcut, t, w1, b1, w2, b2, gamma, sample_scale=None, em
 
 def mlp_splitk(t, w1, b1, w2, b2):
     return _MlpSplitK.apply(t, w1, b1, w2, b2)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# One autograd node per block (models/SLaK.py:153-166): dw convs x 3 -> BN x 3 + add -> permute + LayerNorm -> pwconv1 -> GELU ->
+# pwconv2 -> gamma * + permute + residual.  The same launches as the four nodes above in the same order forward; backward the node owns the ORDER:
+# the chain that the SyncBatchNorm statistics exchange waits for (residual kernel -> dz W2 -> GELU' -> dy1 W1 -> LayerNorm backward -> BatchNorm
+# sums) is issued first, the all-reduce goes out asynchronously, the two pointwise weight-gradient launches (which nothing in the block waits for)
+# run behind it, then the apply pass waits -- the collective's latency hides behind ~80 us of launches instead of stalling the stream.
+class _BlockFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, x_lowp, wv, wh, ws, g1, b1, g2, b2, g3, b3, lnw, lnb, w1, bb1, w2, bb2, gamma, sample_scale, cfg):
+        bns, eps, emit = cfg["bns"], cfg["eps"], cfg["emit_lowp"]
+        x16 = x_lowp if x_lowp is not None else x.to(torch.bfloat16)
+        x16 = x16.contiguous()
+        yv, yh, ys, st, tri_dgrad = _tri_forward_impl(x16, wv, wh, ws, 2)
+        group = _bn3_group(bns[0])
+        pre = _bn3_pre_rows(_stats_triple(st, x.device), x16.shape[1]) if st is not None else None
+        s, bnstats, count, count_dev = _bn3_forward_impl(yv, yh, ys, [g1, g2, g3], [b1, b2, b3], bns, group, pre)
+        t, mean, rstd = _ln_fwd_impl(s, lnw, lnb, eps)
+        z, saved = _mlp_fwd(t, w1, bb1, w2, bb2)
+        if z.dtype != torch.bfloat16:
+            z = z.to(torch.bfloat16)
+        z = z.contiguous()
+        out, out16 = _scale_residual_fwd(x, z, gamma, sample_scale, emit)
+        ctx.save_for_backward(x16, wv, wh, ws, yv, yh, ys, g1, g2, g3, bnstats, s, lnw, mean, rstd, *saved, z, gamma, sample_scale)
+        ctx.misc = (tri_dgrad, group, count, count_dev, x.dtype, x_lowp is not None)
+        ctx.set_materialize_grads(False)
+        return (out, out16) if emit else out
+
+    @staticmethod
+    def backward(ctx, dout, dout16=None):
+        (x16, wv, wh, ws, yv, yh, ys, g1, g2, g3, bnstats, s, lnw, mean, rstd, t, w1b, y1m, a, w2b, z, gamma, sample_scale) = ctx.saved_tensors
+        tri_dgrad, group, count, count_dev, xdtype, had_lowp = ctx.misc
+        saved = (t, w1b, y1m, a, w2b)
+        dshortcut, dz, dgamma, dzc = _scale_residual_bwd(z, gamma, sample_scale, xdtype, dout, dout16)
+        dt, dy1, db1 = _mlp_bwd_data(saved, dz)
+        ds, dlnw, dlnb = _ln_bwd_impl(dt, s, lnw, mean, rstd)
+        wg = {}
+
+        def weights():
+            wg["dw1"], wg["dw2"] = _mlp_bwd_weights(saved, dz, dy1)
+        d1, d2, d3, dgam, dbet = _bn3_backward_impl(ds, yv, yh, ys, [g1, g2, g3], bnstats, group, count, count_dev, between=weights)
+        need = ctx.needs_input_grad
+        dx16, dwv, dwh, dws = _tri_backward_impl(x16, wv, wh, ws, d1, d2, d3, tri_dgrad, need[0] or need[1], need[2:5])
+        dx = dxl = None
+        if had_lowp:
+            dx, dxl = dshortcut, dx16
+        elif dx16 is not None:
+            dx = dshortcut + dx16                                     # (not in place: dshortcut may be autograd's own incoming tensor)
+        else:
+            dx = dshortcut
+        return (dx, dxl, dwv, dwh, dws, dgam[0], dbet[0], dgam[1], dbet[1], dgam[2], dbet[2], dlnw, dlnb, wg["dw1"], db1, wg["dw2"], dzc, dgamma,
+                None, None)
+
+
+def fused_block(x, x_lowp, wv, wh, ws, bns, lnw, lnb, eps, w1, bb1, w2, bb2, gamma, sample_scale=None, emit_lowp=False):
+    """One block of the decomposed SLaK trunk in training mode as ONE autograd node -- see _BlockFn.  ``bns``: the three branch BatchNorm
+    modules (their parameters are the differentiable inputs, their buffers are updated in place).  Returns out, or (out, out_bf16)."""
+    cfg = {"bns": bns, "eps": eps, "emit_lowp": emit_lowp}
+    return _BlockFn.apply(x, x_lowp, wv, wh, ws, bns[0].weight, bns[0].bias, bns[1].weight, bns[1].bias, bns[2].weight, bns[2].bias,
+                          lnw, lnb, w1, bb1, w2, bb2, gamma, sample_scale, cfg)

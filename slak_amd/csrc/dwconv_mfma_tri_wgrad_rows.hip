@@ -27,6 +27,7 @@ namespace slak {
 
 constexpr int TW_NB = 3;                // ring slots: plane i is consumed while i + 1 has landed / is landing and i + 2 is requested
 constexpr int TW_J = 3;                 // DMA instructions per wave and plane copy (upper bound: ceil(ipc / 4), ipc <= 12)
+constexpr int TW_MAXWG = 320;           // workgroups at most (one per CU: 256 on MI355X; the range table travels in the kernel argument)
 constexpr unsigned TW_OOB = 0x80000000u;   // source offset of a lane with nothing to fetch: out of range -> the DMA writes zeros (into padding)
 
 struct TriRowsParams {
@@ -36,8 +37,9 @@ struct TriRowsParams {
     int CPR;               // 16-byte chunks per LDS row (odd, >= 2 * KS + 1)
     int ipc;               // DMA instructions per plane copy: ceil(H * CPR / 64)
     int RS;                // rows per plane copy in LDS (>= 16 * KS + 4: the rows behind the image stay zero)
-    int per, grid;         // planes per workgroup, workgroups: workgroup b owns planes [b * per, b * per + per) of the C * N planes in (channel, image) order
-    int maxspan;           // channels such a range can touch (partial records per workgroup)
+    int grid;              // workgroups; workgroup b owns planes [qs[b], qs[b + 1]) of the C * N planes in (channel, image) order
+    int maxspan;           // channels a range touches at most (partial records per workgroup)
+    int qs[TW_MAXWG + 1];  // the ranges, balanced by COST on the host: a range that crosses a channel boundary pays for summing up in mid-stream with fewer planes
     unsigned tensor_bytes;
     int dbg;               // SLAK_TRIROWS_DBG (timing experiments): 1 = no k-loops, 2 = no DMA, 4 = no epilogue, 8 = no wait / barrier, 32 = clock probe (with 4), 64 = every plane from the first MiB
 };
@@ -74,9 +76,7 @@ __global__ __launch_bounds__(MF_THREADS, 1) void dwconv_mfma_tri_wgrad_rows_kern
     // A range may cross channel boundaries: the accumulators are summed up, stored as the workgroup's partial record number `kseg` and cleared
     // at each boundary; channel c is reduced by the last of the workgroups b_lo(c) .. b_hi(c) to arrive, in workgroup order.
     const int bwg = blockIdx.x;
-    const int P = p.C * p.N;
-    const int q0 = bwg * p.per;
-    int q1 = q0 + p.per; if (q1 > P) q1 = P;
+    const int q0 = p.qs[bwg], q1 = p.qs[bwg + 1];
     const int iters = q1 > q0 ? q1 - q0 : 0;
     const int c_first = q0 / p.N;
 
@@ -297,9 +297,14 @@ __global__ __launch_bounds__(MF_THREADS, 1) void dwconv_mfma_tri_wgrad_rows_kern
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     const int nseg = kseg;
+    auto owner = [&](int q) -> int {                              // the workgroup whose range holds plane q: the last b with qs[b] <= q
+        int lo = 0, hi = p.grid - 1;
+        while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (p.qs[mid] <= q) lo = mid; else hi = mid - 1; }
+        return lo;
+    };
     if (tid < nseg) {
         const int ch = c_first + tid;
-        const int b_lo = (ch * p.N) / p.per, b_hi = (ch * p.N + p.N - 1) / p.per;
+        const int b_lo = owner(ch * p.N), b_hi = owner(ch * p.N + p.N - 1);
         int last = 1;
         if (b_hi > b_lo) {
             const unsigned old = __hip_atomic_fetch_add(p.counters + ch, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -312,7 +317,7 @@ __global__ __launch_bounds__(MF_THREADS, 1) void dwconv_mfma_tri_wgrad_rows_kern
     for (int sg = 0; sg < nseg; ++sg) {
         if (!flags[sg]) continue;
         const int ch = c_first + sg;
-        const int b_lo = (ch * p.N) / p.per, b_hi = (ch * p.N + p.N - 1) / p.per;
+        const int b_lo = owner(ch * p.N), b_hi = owner(ch * p.N + p.N - 1);
         for (int t = tid; t < ntot; t += MF_THREADS) {
             float s = 0.f;
             for (int b0 = b_lo; b0 <= b_hi; b0 += 8) {            // 8 loads in flight, added in workgroup order; agent-scope loads read at the coherence point
@@ -320,7 +325,7 @@ __global__ __launch_bounds__(MF_THREADS, 1) void dwconv_mfma_tri_wgrad_rows_kern
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const int bb = b0 + j;
-                    const int kk = ch - (bb * p.per) / p.N;        // the record of workgroup bb that belongs to channel ch
+                    const int kk = bb <= b_hi ? ch - p.qs[bb] / p.N : 0;      // the record of workgroup bb that belongs to channel ch
                     v[j] = bb <= b_hi ? __hip_atomic_load(p.partial + ((size_t)bb * p.maxspan + kk) * ntot + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.f;
                 }
 #pragma unroll
@@ -353,9 +358,39 @@ static bool fill_tri_rows_params(TriRowsParams& p, int N, int C, int H, int W, i
     if ((size_t)N * C >= 0x40000000ull) return false;
     const int P = N * C;
     if (wgs < 1) wgs = 1;
-    p.per = (P + wgs - 1) / wgs;
-    p.grid = (P + p.per - 1) / p.per;
-    p.maxspan = (p.per - 1 + N - 1) / N + 1;                          // a range of `per` planes touches at most this many channels
+    if (wgs > TW_MAXWG) wgs = TW_MAXWG;
+    // Ranges of equal COST: a plane costs 4 units, summing up at a channel boundary inside a range 29 (measured: 1.5 us per plane, ~11 us per sum),
+    // so a workgroup that crosses a boundary gets ~7 planes fewer.  The smallest budget T for which a greedy cut needs <= wgs ranges.
+    struct RangeCache { int N, C, wgs, grid, maxspan; int qs[TW_MAXWG + 1]; };
+    static thread_local RangeCache rc = {0, 0, 0, 0, 0, {0}};        // (the cut costs ~0.2 ms of host time: once per shape, not per launch)
+    if (rc.N == N && rc.C == C && rc.wgs == wgs) {
+        p.grid = rc.grid; p.maxspan = rc.maxspan;
+        for (int b = 0; b <= rc.grid; ++b) p.qs[b] = rc.qs[b];
+    } else {
+    auto cut = [&](long long T, int* qs) -> int {                     // -> ranges used (qs filled if not NULL), or wgs + 1 if T is too small
+        int b = 0, q = 0;
+        while (q < P) {
+            if (b >= wgs) return wgs + 1;
+            if (qs) qs[b] = q;
+            long long cost = 0; int q2 = q;
+            while (q2 < P) {
+                const long long add = 4 + ((q2 > q && q2 % N == 0) ? 29 : 0);
+                if (cost + add > T && q2 > q) break;
+                cost += add; ++q2;
+            }
+            q = q2; ++b;
+        }
+        if (qs) qs[b] = P;
+        return b;
+    };
+    long long lo = 4, hi = 4ll * P + 29ll * C;
+    while (lo < hi) { const long long mid = (lo + hi) / 2; if (cut(mid, nullptr) <= wgs) hi = mid; else lo = mid + 1; }
+    p.grid = cut(lo, p.qs);
+    p.maxspan = 1;
+    for (int b = 0; b < p.grid; ++b) { const int span = (p.qs[b + 1] - 1) / N - p.qs[b] / N + 1; if (span > p.maxspan) p.maxspan = span; }
+    rc.N = N; rc.C = C; rc.wgs = wgs; rc.grid = p.grid; rc.maxspan = p.maxspan;
+    for (int b = 0; b <= p.grid; ++b) rc.qs[b] = p.qs[b];
+    }
     if (p.maxspan > 8) return false;
     p.tensor_bytes = (unsigned)((size_t)N * C * H * W * 2);
     { static const int dbg = [] { const char* e = getenv("SLAK_TRIROWS_DBG"); return e ? atoi(e) : 0; }(); p.dbg = dbg; }

@@ -221,6 +221,10 @@ class Block(nn.Module):
         """(out, out_lowp): ``out_lowp`` is the copy of ``out`` in the autocast dtype that the fused tail writes alongside its fp32 output
         when ``emit_lowp`` is set (None otherwise), ``x_lowp`` the previous block's.  Only ``_Stage.forward`` threads the pair from block
         to block; it never leaves a stage."""
+        if self.fused_block and self.training and x.is_cuda and torch.is_grad_enabled():
+            r = self._forward_fused_block(x, x_lowp)
+            if r is not None:
+                return r
         shortcut = x
         x = self.large_kernel(x, lowp=x_lowp)
         # the fused tail kernels take even C <= 1024 (tail_args_ok in csrc/block_tail.hip); anything else runs the PyTorch ops below
@@ -280,7 +284,44 @@ def _block_forward_fused_tail(self, shortcut, x):
                                         self.pwconv2.bias, self.gamma.float(), scale, emit_lowp=emit)
 
 
+def _block_forward_fused_block(self, x, x_lowp):
+    """The whole block as ONE autograd node (block_ops.fused_block: the same launches as the fused ops above, one Python call forward and one
+    backward; under SyncBatchNorm the backward hides the statistics all-reduce behind the pointwise weight gradients).  None: a precondition of
+    one of the fused ops does not hold -- the caller takes the ordinary path."""
+    lk = self.large_kernel
+    if not (self.fused_tail and lk.fused_bn and lk.fused_tri and lk.Decom and lk.lowp_dwconv and self.gamma is not None
+            and hasattr(lk, "small_conv") and hasattr(lk, "LoRA1") and hasattr(lk.LoRA1, "bn")
+            and torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == torch.bfloat16
+            and x.dim() == 4 and x.dtype in (torch.float32, torch.bfloat16) and x.shape[1] % 2 == 0 and x.shape[1] <= 1024):
+        return None
+    c1, c2, c3 = lk.LoRA1.conv, lk.LoRA2.conv, lk.small_conv.conv
+    bns = (lk.LoRA1.bn, lk.LoRA2.bn, lk.small_conv.bn)
+    if not (c1.bias is None and c2.bias is None and c3.bias is None and tuple(c3.kernel_size) == (5, 5) and c1.kernel_size[1] == 5
+            and c2.kernel_size[0] == 5 and c1.kernel_size[0] == c2.kernel_size[1] and c1.kernel_size[0] > 5
+            and all(b.training and b.track_running_stats and b.running_mean is not None and b.affine for b in bns)
+            and all(w.dtype == torch.float32 for w in (c1.weight, c2.weight, c3.weight, self.norm.weight, self.gamma))):
+        return None
+    from . import block_ops
+    if x_lowp is not None and not (x_lowp.dtype == torch.bfloat16 and x_lowp.shape == x.shape):
+        x_lowp = None
+    scale = None
+    dp = self.drop_path
+    if isinstance(dp, DropPath) and dp.drop_prob > 0.0:
+        scale = self.__dict__.pop("_pending_scale", None)        # drawn for all blocks at once by SLaK.forward_features
+        if scale is None or scale.shape[0] != x.shape[0] or scale.device != x.device:
+            keep = 1.0 - dp.drop_prob
+            scale = torch.empty(x.shape[0], device=x.device, dtype=torch.float32).bernoulli_(keep)
+            if keep > 0.0:
+                scale.div_(keep)
+    r = block_ops.fused_block(x.contiguous(), x_lowp, c1.weight, c2.weight, c3.weight, bns, self.norm.weight, self.norm.bias, self.norm.eps,
+                              self.pwconv1.weight, self.pwconv1.bias, self.pwconv2.weight, self.pwconv2.bias, self.gamma, scale,
+                              emit_lowp=bool(self.emit_lowp))
+    return r if isinstance(r, tuple) else (r, None)
+
+
 Block._forward_fused_tail = _block_forward_fused_tail
+Block._forward_fused_block = _block_forward_fused_block
+Block.fused_block = False    # the whole block as one autograd node (needs fused_tail + the large kernel's fused_bn / fused_tri); bench.py turns it on
 Block.fused_tail = False
 Block.emit_lowp = False      # per instance: the next module is another Block with lowp_dwconv (set by SLaK.__init__ / bench.py)
 ReparamLargeKernelConv.fused_bn = False

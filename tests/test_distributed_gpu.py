@@ -49,6 +49,38 @@ def _worker(rank, world, port, out):
     loss.backward()
     opt.step()
     res["w"] = {k: v.detach().float().cpu() for k, v in blk.state_dict().items()}
+    # the same block step with the block as ONE autograd node (block_ops.fused_block): its backward issues the SyncBatchNorm all-reduce of the
+    # backward sums ASYNCHRONOUSLY, launches the two pointwise weight gradients behind it and only then waits -- the ordering is recorded here
+    events = []
+    orig_ar, orig_wg = block_ops._sync_bn_all_reduce, block_ops._mlp_bwd_weights
+    def ar(buf, group, async_op=False):
+        events.append("all_reduce(async=%d, %d)" % (int(async_op), buf.numel()))
+        w = orig_ar(buf, group, async_op=async_op)
+        if w is None:
+            return None
+        class _W:                                                     # (the Work object itself takes no attributes)
+            def wait(self_, *a, **k):
+                events.append("wait")
+                return w.wait(*a, **k)
+        return _W()
+    def wg(*a, **k):
+        events.append("pointwise_wgrads")
+        return orig_wg(*a, **k)
+    block_ops._sync_bn_all_reduce, block_ops._mlp_bwd_weights = ar, wg
+    torch.manual_seed(1)
+    M.ReparamLargeKernelConv.fused_tri = True; M.Block.fused_block = True
+    blk1 = M.Block(16, drop_path=0.0, layer_scale_init_value=0.5, kernel_size=(13, 5), Decom=True, bn=True, lowp_dwconv=True).to(dev)
+    ddp1 = nn.parallel.DistributedDataParallel(blk1, device_ids=[0])
+    opt1 = torch.optim.SGD(ddp1.parameters(), lr=0.1)
+    xfull1 = torch.randn(8, 16, 14, 14, device=dev)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        loss1 = ddp1(xfull1[rank * 4:(rank + 1) * 4]).float().pow(2).mean()
+    events.append("backward")
+    loss1.backward()
+    opt1.step()
+    block_ops._sync_bn_all_reduce, block_ops._mlp_bwd_weights = orig_ar, orig_wg
+    res["w_one_node"] = {k: v.detach().float().cpu() for k, v in blk1.state_dict().items()}
+    res["events_one_node"] = events
     # the bench's N > 1 configuration in miniature: whole (narrow) SLaK under DDP with every fused op, the bf16 hand-off between
     # blocks, cached bf16 weights and Masking prune-and-grow: ranks must stay bit-identical (weights and masks)
     import types, contextlib, io
@@ -91,6 +123,7 @@ def _worker(rank, world, port, out):
     res["ranks_identical"] = bool(torch.equal(other[0], other[1]))
     res["mask_density"] = float(torch.cat([m.flatten() for m in mask.masks.values()]).mean().item())
     M.LayerNorm.fused_cf = False; B.cache_lowp_weights = False
+    M.ReparamLargeKernelConv.fused_tri = False; M.Block.fused_block = False
     if rank == 0:
         torch.save(res, out)
     dist.barrier()
@@ -145,6 +178,12 @@ def test_two_ranks_match_single_process(gpu, tmp_path):
             continue
         ref = v.detach().float().cpu()
         assert (got["w"][k] - ref).abs().max() <= 2e-2 * max(1e-3, ref.abs().max().item()) + 1e-5, k
+        assert (got["w_one_node"][k] - ref).abs().max() <= 2e-2 * max(1e-3, ref.abs().max().item()) + 1e-5, k      # the one-node block, same step
+    # the one-node block's backward: all-reduce of the 4C backward sums issued asynchronously, THEN the pointwise weight gradients, THEN the wait
+    ev = got["events_one_node"]
+    bw = ev[ev.index("backward") + 1:]
+    assert bw[:3] == ["all_reduce(async=1, 64)", "pointwise_wgrads", "wait"], ev
+    assert ev[0].startswith("all_reduce(async=0, ")                          # forward: the statistics exchange the apply pass needs at once
 
 
 def test_bench_n_gt_1_path_runs_with_two_ranks_on_one_gpu():
