@@ -179,10 +179,13 @@ int slak_dwconv2d_tri_forward_stats(const void* x, const float* w_v, const float
 int slak_dwconv2d_tri_backward_data(const void* dy_v, const void* dy_h, const void* dy_s, const float* w_v, const float* w_h,
                                     const float* w_s, void* dx, int dtype, int N, int C, int H, int W, int K, void* stream);
 
-/* The three weight gradients of a block in one launch (x fetched once; the 5 x K and 5 x 5 branches share their x fragments): dw_v
- * (C,1,K,5), dw_h (C,1,5,K), dw_s (C,1,5,5), fp32 (backward_filter_fp16.cu:187), bitwise reproducible.  Covered: H <= 14 and W even
- * 8..14 or 4..7 (the 14x14 and 7x7 stages); slak_dwconv2d_tri_filter_workspace_bytes returns 0 for anything else and the call
- * SLAK_ERR_UNSUPPORTED (three slak_dwconv2d_backward_filter calls instead). */
+/* The three weight gradients of a block in one launch (x fetched from HBM once for the three correlations): dw_v (C,1,K,5), dw_h (C,1,5,K),
+ * dw_s (C,1,5,5), fp32 (backward_filter_fp16.cu:187), bitwise reproducible (fixed-order reductions, no atomics on data).  Covered: H <= 14
+ * and W even 8..14 or 4..7 (the 14x14 and 7x7 stages); round 4: planes of one MFMA tile (15 <= H <= 32, W even 16..32: the 28x28 stage,
+ * C <= 4 x CUs) and planes of 2 x 2 tiles (32 < H, W <= 64, W % 8 == 0: the 56x56 stage).  slak_dwconv2d_tri_filter_workspace_bytes
+ * returns 0 for anything else and the call SLAK_ERR_UNSUPPORTED (slak_dwconv2d_pair_backward_filter + one, or three,
+ * slak_dwconv2d_backward_filter calls instead; a caller must be ready for SLAK_ERR_UNSUPPORTED from the call even after a non-zero
+ * workspace answer: the device's CU count, unknown to the query, decides the work split). */
 size_t slak_dwconv2d_tri_filter_workspace_bytes(int dtype, int N, int C, int H, int W, int K);
 int slak_dwconv2d_tri_backward_filter(const void* dy_v, const void* dy_h, const void* dy_s, const void* x, float* dw_v, float* dw_h,
                                       float* dw_s, int dtype, int N, int C, int H, int W, int K,

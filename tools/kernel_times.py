@@ -25,6 +25,19 @@ def main():
         else:
             groups.append([(n, g), [e - s]])
     want = list(entries)
+    # consecutive entries that dispatch the same (kernel, grid) -- the per-branch launches of the wide-map kernels -- arrive as one run: every entry
+    # has the same number of dispatches (warm-up + reps), so runs that are a multiple of it are cut
+    total = sum(len(g[1]) for g in groups)
+    if len(groups) != len(want) and total % len(want) == 0:
+        per = total // len(want)
+        cut = []
+        for key, d in groups:
+            if len(d) % per:
+                cut = None
+                break
+            cut += [[key, d[i:i + per]] for i in range(0, len(d), per)]
+        if cut is not None:
+            groups = cut
     if len(groups) != len(want):
         print("run-length groups %d != expected %d" % (len(groups), len(want)))
         for g in groups:
