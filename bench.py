@@ -121,6 +121,8 @@ def parse():
     ap.add_argument("--device", type=int, default=None, help="GPU index of this rank (default LOCAL_RANK); --device 0 on every rank shares one GPU (gloo)")
     ap.add_argument("--markers", action="store_true", help="bracket the K timed steps with two empty marker launches (slak_debug_marker ids 1 and 2): "
                                                             "tools/step_breakdown.py cuts a rocprofv3 kernel trace exactly there")
+    ap.add_argument("--dry-nccl-env", action="store_true", help="print the environment the collective library would see (NCCL_* / RCCL_* / HSA_* / rendezvous variables, as "
+                                                                 "config.comm_env records them) as one JSON line and exit: no GPU work")
     ap.add_argument("--per-step-sync", action="store_true", help="torch.cuda.synchronize() after every step, as engine.py:90 does (default: the K steps are only bracketed)")
     return ap.parse_args()
 
@@ -430,6 +432,13 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.dry_nccl_env:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        print(json.dumps({"comm_env": {k: v for k, v in sorted(os.environ.items()) if k.startswith(("NCCL_", "RCCL_", "HSA_", "HIP_VISIBLE", "ROCR_VISIBLE", "CUDA_VISIBLE", "TORCH_NCCL", "MASTER_", "GLOO_"))
+                                       or k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "OMP_NUM_THREADS")},
+                          "world_size": world, "rank": rank, "backend": a.backend, "torch": torch.__version__,
+                          "rccl_available": bool(dist.is_available() and dist.is_nccl_available())}))
+        return
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X (no CPU fallback for the hot path)")
     dev_index = local_rank if a.device is None else a.device
@@ -606,6 +615,9 @@ def main():
                    "world_size": (dist.get_world_size() if distributed else 1),
                    "backend": (a.backend if distributed else None),
                    "rccl_version": (".".join(str(v) for v in torch.cuda.nccl.version()) if (distributed and a.backend == "nccl") else None),
+                   # what the collective library will see (the first real 8-GPU run must be diagnosable from its JSON line alone)
+                   "comm_env": {k: v for k, v in sorted(os.environ.items()) if k.startswith(("NCCL_", "RCCL_", "HSA_", "HIP_VISIBLE", "ROCR_VISIBLE", "CUDA_VISIBLE", "TORCH_NCCL", "MASTER_", "GLOO_"))
+                                or k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "OMP_NUM_THREADS")},
                    "per_step_sync": bool(a.per_step_sync),
                    "hip_graph": ("forward and backward of the model replayed as two captured HIP graphs (torch.cuda.make_graphed_callables)" if a.graph else None),
                    "timing": "K steps between barrier + torch.cuda.synchronize() on both sides; " + ("a synchronize after every step as engine.py:90" if a.per_step_sync else "no synchronize inside (GPU-busy time == step time: the host runs ahead)"),

@@ -52,3 +52,16 @@ def test_defaults_are_the_driver_contract(bench, monkeypatch):
     a = bench.parse()
     assert (a.gpus, a.steps, a.warmup) == (8, 7, 2)
     assert bench.HBM_PEAK_GBS == 8000.0
+
+
+def test_dry_nccl_env_prints_the_collective_environment_without_a_gpu():
+    """bench.py --dry-nccl-env: the NCCL_* / RCCL_* / HSA_* / rendezvous variables a real multi-GPU run would start with, as one JSON
+    line, on a box without a GPU (the same dictionary the bench line records as config.comm_env)."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, NCCL_DEBUG="WARN", WORLD_SIZE="8", RANK="3", LOCAL_RANK="3", MASTER_ADDR="127.0.0.1")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--dry-nccl-env", "--gpus", "8"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["world_size"] == 8 and d["rank"] == 3 and d["backend"] == "nccl"
+    assert d["comm_env"]["NCCL_DEBUG"] == "WARN" and d["comm_env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0" and d["comm_env"]["MASTER_ADDR"] == "127.0.0.1"
