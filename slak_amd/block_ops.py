@@ -999,10 +999,54 @@ def mlp_splitk(t, w1, b1, w2, b2):
 # the chain that the SyncBatchNorm statistics exchange waits for (residual kernel -> dz W2 -> GELU' -> dy1 W1 -> LayerNorm backward -> BatchNorm
 # sums) is issued first, the all-reduce goes out asynchronously, the two pointwise weight-gradient launches (which nothing in the block waits for)
 # run behind it, then the apply pass waits -- the collective's latency hides behind ~80 us of launches instead of stalling the stream.
+_runner_mod = False
+
+
+def _runner():
+    """slak_amd/pybind/block_runner.cpp, when `__graft_entry__.build()` / `python -m slak_amd.build --pybind` has built it (never built here: an
+    import must not start a compiler): the block's call sequence issued from C++ -- two host calls per block and step.  SLAK_BLOCK_RUNNER=0 keeps
+    the Python sequence (same launches, same results)."""
+    global _runner_mod
+    if _runner_mod is False:
+        _runner_mod = None
+        if os.environ.get("SLAK_BLOCK_RUNNER", "1") != "0" and use_skinny_linear and use_linear_wgrad and _SPLITK_ROWS == 6272:
+            try:                                                      # (the development switches above select paths only the Python sequence knows)
+                import importlib
+                import sys
+                from . import build
+                path = build.runner_path()
+                if os.path.exists(path):
+                    d = os.path.dirname(path)
+                    if d not in sys.path:
+                        sys.path.insert(0, d)
+                    _runner_mod = importlib.import_module(build.RUNNER_NAME)
+            except Exception:                                         # (no compiled module for this interpreter / torch: the Python sequence runs)
+                _runner_mod = None
+    return _runner_mod
+
+
 class _BlockFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, x_lowp, wv, wh, ws, g1, b1, g2, b2, g3, b3, lnw, lnb, w1, bb1, w2, bb2, gamma, sample_scale, cfg):
         bns, eps, emit = cfg["bns"], cfg["eps"], cfg["emit_lowp"]
+        ctx.runner = False
+        R = _runner()
+        if (R is not None and bns[0].momentum is not None and _bn3_group(bns[0]) is None and x.is_contiguous()
+                and all(bn.track_running_stats and bn.num_batches_tracked is not None for bn in bns)):
+            w1b, w2b = lowp_param(w1), lowp_param(w2)
+            res = R.block_forward(x, x_lowp, wv, wh, ws, [g1, g2, g3], [b1, b2, b3], [bn.running_mean for bn in bns], [bn.running_var for bn in bns],
+                                  float(bns[0].eps), float(bns[0].momentum), True, lnw, lnb, float(eps), w1b, lowp_param(bb1), w2b, lowp_param(bb2),
+                                  gamma, sample_scale, bool(emit))
+            if res:                                                   # (empty: the shape has no one-launch path -- the Python sequence knows the fallbacks)
+                out, out16, x16, yv, yh, ys, bnstats, s, t, mean, rstd, y1m, a, z = res
+                pool = getattr(bns[0], "_slak_ctr_pool", None)
+                if not (pool is not None and pool.covers(bns) and pool.bump_once()):
+                    torch._foreach_add_([bn.num_batches_tracked for bn in bns], 1)
+                ctx.save_for_backward(x16, wv, wh, ws, yv, yh, ys, g1, g2, g3, bnstats, s, lnw, mean, rstd, t, w1b, y1m, a, w2b, z, gamma, sample_scale)
+                ctx.misc = (True, None, float(x.shape[0] * x.shape[2] * x.shape[3]), None, x.dtype, x_lowp is not None)
+                ctx.runner = True
+                ctx.set_materialize_grads(False)
+                return (out, out16) if emit else out
         x16 = x_lowp if x_lowp is not None else x.to(torch.bfloat16)
         x16 = x16.contiguous()
         yv, yh, ys, st, tri_dgrad = _tri_forward_impl(x16, wv, wh, ws, 2)
@@ -1024,6 +1068,11 @@ class _BlockFn(torch.autograd.Function):
     def backward(ctx, dout, dout16=None):
         (x16, wv, wh, ws, yv, yh, ys, g1, g2, g3, bnstats, s, lnw, mean, rstd, t, w1b, y1m, a, w2b, z, gamma, sample_scale) = ctx.saved_tensors
         tri_dgrad, group, count, count_dev, xdtype, had_lowp = ctx.misc
+        if ctx.runner:
+            (dx, dxl, dwv, dwh, dws, dgam, dbet, dlnw, dlnb, dw1, db1, dw2, dzc, dgamma) = _runner().block_backward(
+                x16, wv, wh, ws, yv, yh, ys, [g1, g2, g3], bnstats, s, lnw, mean, rstd, t, w1b, y1m, a, w2b, z, gamma, sample_scale, dout, dout16,
+                xdtype == torch.bfloat16, had_lowp)
+            return (dx, dxl, dwv, dwh, dws, dgam[0], dbet[0], dgam[1], dbet[1], dgam[2], dbet[2], dlnw, dlnb, dw1, db1, dw2, dzc, dgamma, None, None)
         saved = (t, w1b, y1m, a, w2b)
         dshortcut, dz, dgamma, dzc = _scale_residual_bwd(z, gamma, sample_scale, xdtype, dout, dout16)
         dt, dy1, db1 = _mlp_bwd_data(saved, dz)

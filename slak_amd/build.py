@@ -61,21 +61,35 @@ def pybind_path() -> str:
     return os.path.join(LIBDIR, PYBIND_NAME + sysconfig.get_config_var("EXT_SUFFIX"))
 
 
-def build_pybind(force: bool = False, verbose: bool = False) -> str:
+RUNNER_NAME = "_slak_block_runner_C"                        # slak_amd/pybind/block_runner.cpp: a block's call sequence issued from C++
+
+
+def runner_path() -> str:
+    import sysconfig
+    return os.path.join(LIBDIR, RUNNER_NAME + sysconfig.get_config_var("EXT_SUFFIX"))
+
+
+def build_runner(force: bool = False, verbose: bool = False) -> str:
+    """slak_amd/pybind/block_runner.cpp (block_ops._BlockFn's call sequence in C++): built like the pybind boundary module."""
+    return build_pybind(force=force, verbose=verbose, name=RUNNER_NAME, source="block_runner.cpp")
+
+
+def build_pybind(force: bool = False, verbose: bool = False, name: str = None, source: str = "frontend_hip.cpp") -> str:
     """The reference's pybind module (frontend.cpp:3-16) on top of libslak_hip.so: slak_amd/pybind/frontend_hip.cpp, host-only C++
     compiled with g++ against the torch headers (what torch.utils.cpp_extension.CppExtension would run), in-tree next to
-    libslak_hip.so so that it travels with the repository snapshot."""
+    libslak_hip.so so that it travels with the repository snapshot.  (`name` / `source`: the other host-only module, build_runner.)"""
     import sysconfig
     import torch
     from torch.utils import cpp_extension as ce
     lib = build(force=False, verbose=verbose)
-    src = os.path.join(HERE, "pybind", "frontend_hip.cpp")
-    out = pybind_path()
+    name = name or PYBIND_NAME
+    src = os.path.join(HERE, "pybind", source)
+    out = os.path.join(LIBDIR, name + sysconfig.get_config_var("EXT_SUFFIX"))
     if not (force or _stale(out, [src, lib, os.path.join(HERE, "..", "include", "slak_hip.h")])):
         return out
     tlib = os.path.join(os.path.dirname(torch.__file__), "lib")
     cmd = [os.environ.get("CXX", "g++"), "-O2", "-std=c++17", "-fPIC", "-shared", "-w", src, "-o", out,
-           "-DTORCH_EXTENSION_NAME=" + PYBIND_NAME, "-DTORCH_API_INCLUDE_EXTENSION_H", "-D__HIP_PLATFORM_AMD__=1", "-DUSE_ROCM=1",
+           "-DTORCH_EXTENSION_NAME=" + name, "-DTORCH_API_INCLUDE_EXTENSION_H", "-D__HIP_PLATFORM_AMD__=1", "-DUSE_ROCM=1",
            "-D_GLIBCXX_USE_CXX11_ABI=%d" % int(torch._C._GLIBCXX_USE_CXX11_ABI)]
     for inc in ce.include_paths("cuda") + [sysconfig.get_paths()["include"]]:
         cmd += ["-isystem", inc]
@@ -91,3 +105,4 @@ if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
     if "--pybind" in sys.argv:
         print(build_pybind(force="--force" in sys.argv, verbose=True))
+        print(build_runner(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,237 @@
+// slak_amd/pybind/block_runner.cpp -- one block of the decomposed SLaK trunk (models/SLaK.py:153-166) issued from C++: the call sequence of
+// slak_amd/block_ops._BlockFn (three branch convs + BatchNorm sums -> branch BatchNorms + add -> permute + LayerNorm -> pwconv1 -> GELU ->
+// pwconv2 -> gamma * + permute + residual, and its backward) as TWO host calls per block and step instead of ~70 ctypes calls, ~25 torch.empty
+// and 4-6 GEMM dispatches made from Python.  Same launches on the same operands in the same order as the Python node: results are bit-identical
+// (tests/test_block_runner_gpu.py).  Host-only C++ on the C ABI of include/slak_hip.h; tensors are allocated through the torch allocator, kernels
+// go to torch's CURRENT stream, the GEMMs the library does not cover are at::linear / at::mm (hipBLASLt).
+//
+// block_forward returns an EMPTY list when a precondition of the one-launch path does not hold for the shape (no three-branch forward with
+// statistics / data gradient / weight gradient launch): the caller (block_ops._BlockFn) then runs the Python sequence, which knows every fallback.
+#include <torch/extension.h>
+#include <c10/hip/HIPGuard.h>
+#include <c10/hip/HIPStream.h>
+
+#include <algorithm>
+#include <map>
+#include <vector>
+
+#include "../../include/slak_hip.h"
+
+namespace {
+
+using at::Tensor;
+
+void* stream_of(const Tensor& t) { return (void*)c10::hip::getCurrentHIPStream(t.get_device()).stream(); }
+
+void check_rc(int rc, const char* fn) {
+    TORCH_CHECK(rc == SLAK_OK, fn, ": ", slak_status_string(rc), " (", slak_last_hip_error(), ")");
+}
+
+// per-(device, stream) scratch, grown on demand; stream-ordered reuse is safe because every kernel that touches it is enqueued on that stream
+struct Scratch { void* p; size_t n; };
+Scratch scratch(const Tensor& like, size_t bytes) {
+    static std::map<std::pair<int, void*>, Tensor> cache;
+    const auto key = std::make_pair((int)like.get_device(), stream_of(like));
+    auto it = cache.find(key);
+    if (it == cache.end() || (size_t)it->second.numel() < bytes) {
+        Tensor t = at::empty({(int64_t)std::max<size_t>(bytes, (size_t)1 << 22)}, like.options().dtype(at::kByte));
+        cache[key] = t;
+        return {t.data_ptr(), (size_t)t.numel()};
+    }
+    return {it->second.data_ptr(), (size_t)it->second.numel()};
+}
+
+struct Shape { int N, C, H, W, K, P, M, C4; };
+
+// what the library answers for a block shape, asked once
+struct Plan { bool ok; int rows; size_t ws; bool nt1, nt2, ntd1, ntd2, wg1, wg2; };
+const Plan& plan_of(const Shape& s) {
+    static std::map<std::vector<int>, Plan> cache;
+    const std::vector<int> key = {s.N, s.C, s.H, s.W, s.K, s.C4};
+    auto it = cache.find(key);
+    if (it != cache.end()) return it->second;
+    Plan p{};
+    const int dt = SLAK_BF16;
+    p.rows = slak_dwconv2d_tri_stats_rows(dt, s.N, s.C, s.H, s.W, s.K);
+    const size_t wtri = slak_dwconv2d_tri_filter_workspace_bytes(dt, s.N, s.C, s.H, s.W, s.K);
+    p.ok = slak_dwconv2d_tri_supported_op(dt, s.N, s.C, s.H, s.W, s.K, 0) == 1 && slak_dwconv2d_tri_supported_op(dt, s.N, s.C, s.H, s.W, s.K, 1) == 1 &&
+           p.rows > 0 && wtri > 0 && (s.C % 2) == 0 && s.C <= 1024;
+    p.nt1 = slak_linear_nt_supported(s.M, s.C4, s.C, 1) != 0;      // pwconv1 + GELU in one streaming pass
+    p.nt2 = slak_linear_nt_supported(s.M, s.C, s.C4, 0) != 0;      // pwconv2
+    p.ntd1 = slak_linear_nt_supported(s.M, s.C4, s.C, 0) != 0;     // dz W2
+    p.ntd2 = slak_linear_nt_supported(s.M, s.C, s.C4, 0) != 0;     // dy1 W1
+    p.wg1 = slak_linear_wgrad_supported(s.M, s.C4, s.C) != 0;      // dW1 = dy1^T t
+    p.wg2 = slak_linear_wgrad_supported(s.M, s.C, s.C4) != 0;      // dW2 = dz^T a
+    size_t ws = std::max(wtri, slak_bn3_workspace_bytes(s.N, s.C));
+    ws = std::max(ws, slak_block_tail_workspace_bytes(s.N, s.C, s.P));
+    ws = std::max(ws, slak_gelu_bwd_workspace_bytes(s.M, s.C4));
+    if (p.wg1) ws = std::max(ws, slak_linear_wgrad_workspace_bytes(s.M, s.C4, s.C));
+    if (p.wg2) ws = std::max(ws, slak_linear_wgrad_workspace_bytes(s.M, s.C, s.C4));
+    p.ws = ws;
+    return cache.emplace(key, p).first->second;
+}
+
+Shape shape_of(const Tensor& x, const Tensor& wv, const Tensor& w1b) {
+    Shape s;
+    s.N = (int)x.size(0); s.C = (int)x.size(1); s.H = (int)x.size(2); s.W = (int)x.size(3); s.K = (int)wv.size(2);
+    s.P = s.H * s.W; s.M = s.N * s.P; s.C4 = (int)w1b.size(0);
+    return s;
+}
+
+const float* fp(const Tensor& t) { return (const float*)t.data_ptr(); }
+float* fpm(const Tensor& t) { return (float*)t.data_ptr(); }
+
+// -> [out, out16 | undefined, x16, yv, yh, ys, bnstats, s, t, mean, rstd, y1m, a, z], or an empty list (see the header)
+std::vector<Tensor> block_forward(const Tensor& x, const c10::optional<Tensor>& x_lowp, const Tensor& wv, const Tensor& wh, const Tensor& wsm,
+                                  const std::vector<Tensor>& bn_gamma, const std::vector<Tensor>& bn_beta, const std::vector<Tensor>& bn_mean,
+                                  const std::vector<Tensor>& bn_var, double bn_eps, double bn_momentum, bool update_running,
+                                  const Tensor& lnw, const Tensor& lnb, double ln_eps, const Tensor& w1b, const Tensor& bb1b, const Tensor& w2b,
+                                  const Tensor& bb2b, const Tensor& gamma, const c10::optional<Tensor>& sample_scale, bool emit_lowp) {
+    TORCH_CHECK(x.is_cuda() && x.is_contiguous() && x.dim() == 4, "x must be a contiguous (N,C,H,W) HIP tensor");
+    TORCH_CHECK(bn_gamma.size() == 3 && bn_beta.size() == 3 && bn_mean.size() == 3 && bn_var.size() == 3, "three branch BatchNorms");
+    const Shape s = shape_of(x, wv, w1b);
+    const Plan& pl = plan_of(s);
+    const bool f32w = wv.scalar_type() == at::kFloat && wh.scalar_type() == at::kFloat && wsm.scalar_type() == at::kFloat && wv.is_contiguous() &&
+                      wh.is_contiguous() && wsm.is_contiguous() && wv.size(3) == 5 && wh.size(2) == 5 && wh.size(3) == s.K && wsm.size(2) == 5 && wsm.size(3) == 5;
+    if (!pl.ok || !f32w || (x.scalar_type() != at::kFloat && x.scalar_type() != at::kBFloat16) || w1b.scalar_type() != at::kBFloat16) return {};
+    c10::hip::HIPGuard guard(x.get_device());
+    void* st = stream_of(x);
+    const int dt = SLAK_BF16;
+    Tensor x16 = (x_lowp.has_value() && x_lowp->defined()) ? x_lowp->contiguous() : x.to(at::kBFloat16).contiguous();
+    const Scratch ws = scratch(x, pl.ws);
+    // three branch convs + the BatchNorms' batch sums
+    Tensor yv = at::empty_like(x16), yh = at::empty_like(x16), ys = at::empty_like(x16);
+    Tensor stats = at::empty({pl.rows, s.C, 6}, x.options().dtype(at::kFloat));
+    check_rc(slak_dwconv2d_tri_forward_stats(x16.data_ptr(), fp(wv), fp(wh), fp(wsm), yv.data_ptr(), yh.data_ptr(), ys.data_ptr(), fpm(stats), dt,
+                                             s.N, s.C, s.H, s.W, s.K, st), "slak_dwconv2d_tri_forward_stats");
+    // branch BatchNorms + add
+    const float* gam[3] = {fp(bn_gamma[0]), fp(bn_gamma[1]), fp(bn_gamma[2])};
+    const float* bet[3] = {fp(bn_beta[0]), fp(bn_beta[1]), fp(bn_beta[2])};
+    float* rm[3] = {fpm(bn_mean[0]), fpm(bn_mean[1]), fpm(bn_mean[2])};
+    float* rv[3] = {fpm(bn_var[0]), fpm(bn_var[1]), fpm(bn_var[2])};
+    const float* pre[3] = {fp(stats), fp(stats) + 2, fp(stats) + 4};
+    const int pre_rows[3] = {pl.rows, pl.rows, pl.rows};
+    Tensor coef = at::empty({s.C * 4}, stats.options()), bnstats = at::empty({s.C * 6}, stats.options());
+    Tensor sum = at::empty_like(yv);
+    check_rc(slak_bn3_forward_local(yv.data_ptr(), yh.data_ptr(), ys.data_ptr(), gam, bet, rm, rv, (float)bn_eps, (float)bn_momentum, update_running ? 1 : 0,
+                                    fpm(coef), fpm(bnstats), sum.data_ptr(), s.N, s.C, s.P, ws.p, ws.n, st, pre, pre_rows, 6), "slak_bn3_forward_local");
+    // permute + LayerNorm
+    Tensor t = at::empty({s.N, s.H, s.W, s.C}, x16.options());
+    Tensor mean = at::empty({s.N, s.P}, stats.options()), rstd = at::empty({s.N, s.P}, stats.options());
+    check_rc(slak_ln_nchw_to_nhwc_forward(sum.data_ptr(), fp(lnw), fp(lnb), t.data_ptr(), fpm(mean), fpm(rstd), s.N, s.C, s.P, (float)ln_eps, st),
+             "slak_ln_nchw_to_nhwc_forward");
+    // pwconv1 -> GELU -> pwconv2
+    Tensor y1m, a, z;
+    if (pl.nt1) {
+        y1m = at::empty({s.N, s.H, s.W, s.C4}, x16.options()); a = at::empty_like(y1m);
+        check_rc(slak_linear_nt(t.data_ptr(), w1b.data_ptr(), bb1b.data_ptr(), y1m.data_ptr(), a.data_ptr(), s.M, s.C4, s.C, st), "slak_linear_nt");
+    } else {
+        y1m = at::linear(t, w1b, bb1b);
+        a = at::gelu(y1m);
+    }
+    if (pl.nt2) {
+        z = at::empty({s.N, s.H, s.W, s.C}, x16.options());
+        check_rc(slak_linear_nt(a.data_ptr(), w2b.data_ptr(), bb2b.data_ptr(), z.data_ptr(), nullptr, s.M, s.C, s.C4, st), "slak_linear_nt");
+    } else {
+        z = at::linear(a, w2b, bb2b);
+        if (z.scalar_type() != at::kBFloat16) z = z.to(at::kBFloat16);
+        z = z.contiguous();
+    }
+    // gamma * + permute + residual (+ the bf16 copy for the next block's convs)
+    Tensor out = at::empty({s.N, s.C, s.H, s.W}, stats.options());
+    Tensor out16 = emit_lowp ? at::empty({s.N, s.C, s.H, s.W}, x16.options()) : Tensor();
+    const bool has_scale = sample_scale.has_value() && sample_scale->defined();
+    check_rc(slak_scale_residual_forward(x.data_ptr(), x.scalar_type() == at::kFloat ? SLAK_F32 : SLAK_BF16, z.data_ptr(), fp(gamma),
+                                         has_scale ? fp(*sample_scale) : nullptr, fpm(out), emit_lowp ? out16.data_ptr() : nullptr, s.N, s.C, s.P, st),
+             "slak_scale_residual_forward");
+    return {out, out16, x16, yv, yh, ys, bnstats, sum, t, mean, rstd, y1m, a, z};
+}
+
+Tensor wgrad(const Tensor& dy, const Tensor& x, int M, int N1, int N2, bool covered, const Scratch& ws, void* st) {
+    if (covered) {
+        Tensor d = at::empty({N1, N2}, dy.options().dtype(at::kFloat));
+        check_rc(slak_linear_wgrad(dy.data_ptr(), x.data_ptr(), fpm(d), M, N1, N2, ws.p, ws.n, st), "slak_linear_wgrad");
+        return d;
+    }
+    // widths the row-reduction kernel does not cover (e.g. SLaK-B's 128 * 2^k): the reduction index M = N*H*W is split into S batches of a
+    // library batched GEMM, the S partial products are added in fp32 -- what block_ops._mlp_wgrad does (a single GEMM with K = M runs on four
+    // workgroups: measured 0.86 ms per call on stage 1)
+    int S = std::max(1, M / 6272);
+    while (S > 1 && M % S) --S;
+    if (S > 1) return at::bmm(dy.view({S, M / S, N1}).transpose(1, 2), x.view({S, M / S, N2})).sum(at::IntArrayRef{0}, false, at::kFloat);
+    return at::mm(dy.t(), x).to(at::kFloat);
+}
+
+// -> [dx, dx_lowp | undefined, dwv, dwh, dws, dgamma_bn [3][C], dbeta_bn [3][C], dlnw, dlnb, dw1, db1, dw2, db2, dgamma]
+std::vector<Tensor> block_backward(const Tensor& x16, const Tensor& wv, const Tensor& wh, const Tensor& wsm, const Tensor& yv, const Tensor& yh,
+                                   const Tensor& ys, const std::vector<Tensor>& bn_gamma, const Tensor& bnstats, const Tensor& sum, const Tensor& lnw,
+                                   const Tensor& mean, const Tensor& rstd, const Tensor& t, const Tensor& w1b, const Tensor& y1m, const Tensor& a,
+                                   const Tensor& w2b, const Tensor& z, const Tensor& gamma, const c10::optional<Tensor>& sample_scale,
+                                   const c10::optional<Tensor>& dout_opt, const c10::optional<Tensor>& dout16_opt, bool shortcut_bf16, bool had_lowp) {
+    const Shape s = shape_of(x16, wv, w1b);
+    const Plan& pl = plan_of(s);
+    TORCH_CHECK(pl.ok, "block_backward: the shape has no one-launch path (block_forward would have declined it)");
+    c10::hip::HIPGuard guard(x16.get_device());
+    void* st = stream_of(x16);
+    const int dt = SLAK_BF16;
+    const Scratch ws = scratch(x16, pl.ws);
+    const auto f32 = x16.options().dtype(at::kFloat);
+    // gamma * + permute + residual
+    Tensor dout = (dout_opt.has_value() && dout_opt->defined()) ? dout_opt->contiguous() : at::zeros({s.N, s.C, s.H, s.W}, f32);
+    if (dout.scalar_type() != at::kFloat) dout = dout.to(at::kFloat);
+    Tensor dout16 = (dout16_opt.has_value() && dout16_opt->defined()) ? dout16_opt->contiguous() : Tensor();
+    if (dout16.defined() && dout16.scalar_type() != at::kBFloat16) dout16 = dout16.to(at::kBFloat16);
+    Tensor dsum = dout16.defined() ? at::empty_like(dout) : Tensor();
+    Tensor dz = at::empty_like(z), dgamma = at::empty_like(gamma), dzc = at::empty_like(gamma);
+    const bool has_scale = sample_scale.has_value() && sample_scale->defined();
+    check_rc(slak_scale_residual_backward(fp(dout), dout16.defined() ? dout16.data_ptr() : nullptr, dsum.defined() ? fpm(dsum) : nullptr, z.data_ptr(),
+                                          fp(gamma), has_scale ? fp(*sample_scale) : nullptr, dz.data_ptr(), fpm(dgamma), fpm(dzc), s.N, s.C, s.P,
+                                          ws.p, ws.n, st), "slak_scale_residual_backward");
+    Tensor dshortcut = dsum.defined() ? dsum : dout;
+    if (shortcut_bf16) dshortcut = dshortcut.to(at::kBFloat16);
+    // the MLP's data path: dz -> dact -> (GELU') dy1 (+ pwconv1's bias gradient) -> dt
+    Tensor dz2 = dz.view({s.M, s.C});
+    Tensor dact;
+    if (pl.ntd1) {
+        Tensor w2t = w2b.t().contiguous();
+        dact = at::empty({s.M, s.C4}, x16.options());
+        check_rc(slak_linear_nt(dz2.data_ptr(), w2t.data_ptr(), nullptr, dact.data_ptr(), nullptr, s.M, s.C4, s.C, st), "slak_linear_nt");
+    } else dact = at::mm(dz2, w2b);
+    Tensor dy1 = at::empty_like(dact), db1 = at::empty({s.C4}, f32);
+    check_rc(slak_gelu_backward_bias(dact.data_ptr(), y1m.data_ptr(), dy1.data_ptr(), fpm(db1), s.M, s.C4, ws.p, ws.n, st), "slak_gelu_backward_bias");
+    Tensor dt_;
+    if (pl.ntd2) {
+        Tensor w1t = w1b.t().contiguous();
+        dt_ = at::empty({s.M, s.C}, x16.options());
+        check_rc(slak_linear_nt(dy1.data_ptr(), w1t.data_ptr(), nullptr, dt_.data_ptr(), nullptr, s.M, s.C, s.C4, st), "slak_linear_nt");
+    } else dt_ = at::mm(dy1, w1b);
+    // permute + LayerNorm
+    Tensor ds = at::empty_like(sum), dlnw = at::empty_like(lnw), dlnb = at::empty_like(lnw);
+    check_rc(slak_ln_nchw_to_nhwc_backward(dt_.data_ptr(), sum.data_ptr(), fp(lnw), fp(mean), fp(rstd), ds.data_ptr(), fpm(dlnw), fpm(dlnb), s.N, s.C, s.P,
+                                           ws.p, ws.n, st), "slak_ln_nchw_to_nhwc_backward");
+    // the two pointwise weight gradients (single process: in front of the BatchNorm pass, as the Python node launches them)
+    Tensor dw1 = wgrad(dy1, t.view({s.M, s.C}), s.M, s.C4, s.C, pl.wg1, ws, st);
+    Tensor dw2 = wgrad(dz2, a.view({s.M, s.C4}), s.M, s.C, s.C4, pl.wg2, ws, st);
+    // branch BatchNorms
+    const float* gam[3] = {fp(bn_gamma[0]), fp(bn_gamma[1]), fp(bn_gamma[2])};
+    Tensor bcoef = at::empty({s.C * 9}, f32), dgam = at::empty({3, s.C}, f32), dbet = at::empty({3, s.C}, f32);
+    Tensor d1 = at::empty_like(yv), d2 = at::empty_like(yv), d3 = at::empty_like(yv);
+    check_rc(slak_bn3_backward_local(ds.data_ptr(), yv.data_ptr(), yh.data_ptr(), ys.data_ptr(), fp(bnstats), gam, fpm(bcoef), fpm(dgam), fpm(dbet),
+                                     d1.data_ptr(), d2.data_ptr(), d3.data_ptr(), s.N, s.C, s.P, ws.p, ws.n, st), "slak_bn3_backward_local");
+    // three branch convs: the summed data gradient, the three weight gradients
+    Tensor dx16 = at::empty_like(x16);
+    check_rc(slak_dwconv2d_tri_backward_data(d1.data_ptr(), d2.data_ptr(), d3.data_ptr(), fp(wv), fp(wh), fp(wsm), dx16.data_ptr(), dt,
+                                             s.N, s.C, s.H, s.W, s.K, st), "slak_dwconv2d_tri_backward_data");
+    Tensor dwv = at::empty_like(wv), dwh = at::empty_like(wh), dws = at::empty_like(wsm);
+    check_rc(slak_dwconv2d_tri_backward_filter(d1.data_ptr(), d2.data_ptr(), d3.data_ptr(), x16.data_ptr(), fpm(dwv), fpm(dwh), fpm(dws), dt,
+                                               s.N, s.C, s.H, s.W, s.K, ws.p, ws.n, st), "slak_dwconv2d_tri_backward_filter");
+    Tensor dx = had_lowp ? dshortcut : (dshortcut + dx16);
+    return {dx, had_lowp ? dx16 : Tensor(), dwv, dwh, dws, dgam, dbet, dlnw, dlnb, dw1, db1, dw2, dzc, dgamma};
+}
+
+}  // namespace
+
+PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
+    m.def("block_forward", &block_forward, "one SLaK block, training forward (see slak_amd/block_ops._BlockFn)");
+    m.def("block_backward", &block_backward, "its backward");
+}

@@ -129,3 +129,44 @@ def test_one_autograd_node_per_block_reproduces_the_four_node_block_bit_for_bit(
     bad = [n for n in g0 if not np.array_equal(g0[n], g1[n])]
     assert not bad, bad[:5]
     assert all(np.array_equal(r0[k], r1[k]) for k in r0)
+
+
+def test_block_runner_issues_the_same_launches_as_the_python_node(gpu):
+    """slak_amd/pybind/block_runner.cpp (the block's call sequence in C++, built by __graft_entry__.build()): bit-identical logits, gradients and
+    running statistics with and without it, on the narrow reference model AND on a stage-1-sized block (where the streaming pointwise kernels and
+    the one-launch weight gradient of the 56 x 56 class run)."""
+    from slak_amd import block_ops
+    import slak_amd.slak_model as M
+    if block_ops._runner() is None:
+        pytest.skip("block runner module not built")
+    g = load_golden("model_reference")
+    res = []
+    for use in (False, True):
+        _set_fused(True, True)
+        saved = block_ops._runner_mod
+        if not use:
+            block_ops._runner_mod = None
+        try:
+            torch.manual_seed(5)
+            m = _build(g, gpu, lowp=True)
+            for st in m.stages:
+                for blk in list(st)[:-1]:
+                    blk.emit_lowp = True
+            res.append(_run(m, g, gpu, autocast=True))
+            torch.manual_seed(6)
+            blk = M.Block(96, drop_path=0.0, layer_scale_init_value=0.5, kernel_size=(51, 5), Decom=True, bn=True, lowp_dwconv=True).to(gpu)
+            blk.train()
+            x = torch.randn(4, 96, 56, 56, device=gpu, requires_grad=True)
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                y = blk(x)
+            y.float().pow(2).mean().backward()
+            res[-1] = res[-1] + (y.detach().double().cpu().numpy(), x.grad.double().cpu().numpy(),
+                                 {n: p.grad.double().cpu().numpy() for n, p in blk.named_parameters()})
+        finally:
+            block_ops._runner_mod = saved
+            _set_fused(False)
+    (l0, g0, r0, e0, y0, dx0, bg0), (l1, g1, r1, e1, y1, dx1, bg1) = res
+    assert np.array_equal(l0, l1) and np.array_equal(e0, e1) and np.array_equal(y0, y1) and np.array_equal(dx0, dx1)
+    bad = [n for n in g0 if not np.array_equal(g0[n], g1[n])] + [n for n in bg0 if not np.array_equal(bg0[n], bg1[n])]
+    assert not bad, bad[:5]
+    assert all(np.array_equal(r0[k], r1[k]) for k in r0)
