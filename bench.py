@@ -152,7 +152,8 @@ def hot_path_kernels(device, batch, reps, dtype, stages, plain_too=True):
                   `alg_bytes_incl_acc_read` = 3*S*b, but the HEADLINE price stays SURVEY 8(d)'s 2*S*b per op) -- or ONE launch for the
                   three (slak_dwconv2d_tri_supported_op(.., 1) == 1);
       bwd_filter: one launch per branch -- or ONE launch for the three (where slak_dwconv2d_tri_filter_workspace_bytes > 0), or ONE for
-                  the K x 5 and the 5 x 5 branch (`pair`, where slak_dwconv2d_pair_filter_workspace_bytes > 0) beside the 5 x K launch.
+                  the K x 5 and the 5 x 5 branch (`pair`, where slak_dwconv2d_pair_filter_workspace_bytes > 0) beside the 5 x K launch;
+      bwd_data+filter: ONE launch for the data gradient and the three weight gradients (where slak_dwconv2d_tri_backward_supported == 1).
     Algorithmic bytes: SURVEY.md 8(d) per op -- 2*S*b (+ C*kh*kw*4); a three-branch (two-branch) launch is priced at the per-op figure
     of the three (two) ops it replaces (3 x 2*S*b, 2 x 2*S*b), as 8(d) prescribes."""
     import ctypes
@@ -191,7 +192,17 @@ def hot_path_kernels(device, batch, reps, dtype, stages, plain_too=True):
         wbytes = sum(C * kh * kw * 4 for _, (kh, kw) in shapes)
         flops3 = sum(2.0 * S * kh * kw for _, (kh, kw) in shapes)
         tri_w_nb = int(L.slak_dwconv2d_tri_filter_workspace_bytes(dt, batch, C, HW, HW, K)) if dtype != torch.float32 else 0
-        if tri_w_nb:
+        # the data gradient and the three weight gradients in ONE launch (the 14 x 14 class; block_ops._tri_backward_impl takes it where it exists):
+        # priced at the per-op figures of the six ops it replaces
+        tri_b = bool(tri_w_nb) and block_ops.fused_tri_backward and block_ops.fused_tri_wgrad and L.slak_dwconv2d_tri_backward_supported(dt, batch, C, HW, HW, K) == 1
+        if tri_b:
+            dws3 = [torch.empty_like(w) for w in wts]
+            ws3 = torch.empty(tri_w_nb, dtype=torch.uint8, device=device)
+            a_tb = (dys[0].data_ptr(), dys[1].data_ptr(), dys[2].data_ptr(), x.data_ptr(), wts[0].data_ptr(), wts[1].data_ptr(), wts[2].data_ptr(), ys[0].data_ptr(),
+                    dws3[0].data_ptr(), dws3[1].data_ptr(), dws3[2].data_ptr(), dt, batch, C, HW, HW, K, ws3.data_ptr(), tri_w_nb, st)
+            add("%dx5+5x%d+5x5" % (K, K), "tri", "bwd_data+filter", lambda: _lib.check(L.slak_dwconv2d_tri_backward(*a_tb)), 2 * (3 * 2 * S * b + wbytes), 2 * flops3)
+            out[-1]["variant"] = "data gradient + three weight gradients in one launch (slak_dwconv2d_tri_backward: what the training step launches)"
+        elif tri_w_nb:
             dws3 = [torch.empty_like(w) for w in wts]
             ws3 = torch.empty(tri_w_nb, dtype=torch.uint8, device=device)
             a_tw = (dys[0].data_ptr(), dys[1].data_ptr(), dys[2].data_ptr(), x.data_ptr(), dws3[0].data_ptr(), dws3[1].data_ptr(), dws3[2].data_ptr(),
@@ -213,7 +224,7 @@ def hot_path_kernels(device, batch, reps, dtype, stages, plain_too=True):
                         out[-1]["plain_forward_ms"] = event_time_ms(lambda: _lib.check(L.slak_dwconv2d_tri_forward(*a_tf)), reps, device)
                 else:
                     add("%dx5+5x%d+5x5" % (K, K), "tri", "fwd", lambda: _lib.check(L.slak_dwconv2d_tri_forward(*a_tf)), 3 * 2 * S * b + wbytes, flops3)
-            if tri_d:
+            if tri_d and not tri_b:
                 add("%dx5+5x%d+5x5" % (K, K), "tri", "bwd_data", lambda: _lib.check(L.slak_dwconv2d_tri_backward_data(*a_td)), 3 * 2 * S * b + wbytes, flops3)
         pair_nb = int(L.slak_dwconv2d_pair_filter_workspace_bytes(dt, batch, C, HW, HW, K)) if (dtype != torch.float32 and not tri_w_nb) else 0
         if pair_nb:

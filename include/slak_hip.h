@@ -191,6 +191,16 @@ int slak_dwconv2d_tri_backward_filter(const void* dy_v, const void* dy_h, const 
                                       float* dw_s, int dtype, int N, int C, int H, int W, int K,
                                       void* workspace, size_t workspace_bytes, void* stream);
 
+/* The whole backward of a block's three branch convs in ONE launch -- dx (what slak_dwconv2d_tri_backward_data writes) and dw_v, dw_h, dw_s
+ * (what slak_dwconv2d_tri_backward_filter writes), bit for bit -- where the planes are small enough that a launch's fixed cost and the second
+ * staging of the three dY tensors dominate (round 4: H <= 14, W even 8..14 -- the 14 x 14 stage: backward_data_fp16.cu:181-243 and
+ * backward_filter_fp16.cu:181-243 per branch in the reference, six launches).  slak_dwconv2d_tri_backward_supported returns 1 where the
+ * launch exists; workspace: slak_dwconv2d_tri_filter_workspace_bytes.  Anything else: SLAK_ERR_UNSUPPORTED (the two calls above). */
+int slak_dwconv2d_tri_backward_supported(int dtype, int N, int C, int H, int W, int K);
+int slak_dwconv2d_tri_backward(const void* dy_v, const void* dy_h, const void* dy_s, const void* x, const float* w_v, const float* w_h,
+                               const float* w_s, void* dx, float* dw_v, float* dw_h, float* dw_s, int dtype, int N, int C, int H, int W, int K,
+                               void* workspace, size_t workspace_bytes, void* stream);
+
 /* The K x 5 and the 5 x 5 weight gradient of a block in one launch, for the planes the three-branch launch does not cover (round 2:
  * 15 <= H <= 32, W even 16..32 -- the 28 x 28 stage): the 5 x 5 correlation is the K x 5 one with its own dY, so x is fetched and
  * column-shifted once for both.  dw_v (C,1,K,5), dw_s (C,1,5,5), fp32, bitwise reproducible.  slak_dwconv2d_pair_filter_workspace_bytes

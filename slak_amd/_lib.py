@@ -105,6 +105,8 @@ SIGNATURES = {
     "slak_dwconv2d_tri_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "slak_dwconv2d_tri_backward_data": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "slak_dwconv2d_tri_filter_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i]),
+    "slak_dwconv2d_tri_backward_supported": (_i, [_i, _i, _i, _i, _i, _i]),
+    "slak_dwconv2d_tri_backward": (_i, [_vp] * 11 + [_i] * 6 + [_vp, _sz, _vp]),
     "slak_dwconv2d_pair_filter_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i]),
     "slak_dwconv2d_pair_backward_filter": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     "slak_dwconv2d_tri_backward_filter": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),

@@ -144,6 +144,7 @@ class _ScaleResidual(torch.autograd.Function):
 
 accumulate_dgrad = os.environ.get("SLAK_DGRAD_ACC", "1") != "0"     # A/B switch: 0 = three plain launches + two tensor adds
 fused_tri_wgrad = os.environ.get("SLAK_TRI_WGRAD", "1") != "0"      # A/B switch: 0 = three weight-gradient launches per block everywhere
+fused_tri_backward = os.environ.get("SLAK_TRI_BACKWARD", "1") != "0"   # A/B switch: 0 = the data-gradient launch and the weight-gradient launch apart on the 14 x 14 class as well
 
 
 _tri_plan_cache = {}
@@ -151,15 +152,16 @@ _tri_plan_cache = {}
 
 def _tri_plan(dt, N, C, H, W, K):
     """What the library answers for a block shape -- (one-launch forward?, one-launch data gradient?, rows of the forward launch's BatchNorm
-    statistics, workspace bytes of the three-branch weight gradient, of the two-branch one) -- asked once per (dtype, shape): five ctypes
-    calls per block and direction otherwise."""
+    statistics, workspace bytes of the three-branch weight gradient, of the two-branch one, one-launch backward?) -- asked once per (dtype,
+    shape): six ctypes calls per block and direction otherwise."""
     key = (dt, N, C, H, W, K)
     plan = _tri_plan_cache.get(key)
     if plan is None:
         L = _lib.lib()
         plan = (L.slak_dwconv2d_tri_supported_op(dt, N, C, H, W, K, 0) == 1, L.slak_dwconv2d_tri_supported_op(dt, N, C, H, W, K, 1) == 1,
                 int(L.slak_dwconv2d_tri_stats_rows(dt, N, C, H, W, K)), int(L.slak_dwconv2d_tri_filter_workspace_bytes(dt, N, C, H, W, K)),
-                int(L.slak_dwconv2d_pair_filter_workspace_bytes(dt, N, C, H, W, K)))
+                int(L.slak_dwconv2d_pair_filter_workspace_bytes(dt, N, C, H, W, K)),
+                L.slak_dwconv2d_tri_backward_supported(dt, N, C, H, W, K) == 1)      # [5]: data gradient + the three weight gradients in one launch
         _tri_plan_cache[key] = plan
     return plan
 
@@ -177,7 +179,7 @@ def _tri_forward_impl(x, wv, wh, ws, want_stats):
     dt = ops._DT.get(x.dtype)
     # one launch for the three branches where the library says it wins (slak_dwconv2d_tri_supported_op: per op)
     f32w = all(w.dtype == torch.float32 and w.is_contiguous() for w in (wv, wh, ws))
-    plan = _tri_plan(dt, N, C, H, W, K) if (dt is not None and f32w) else (False, False, 0, 0, 0)
+    plan = _tri_plan(dt, N, C, H, W, K) if (dt is not None and f32w) else (False, False, 0, 0, 0, False)
     tri, tri_dgrad = plan[0], plan[1]
     stats = None
     if tri:
@@ -210,6 +212,22 @@ def _tri_backward_impl(x, wv, wh, ws, dyv, dyh, dys, tri_dgrad, need_dx, need_w)
     dyv, dyh, dys = (torch.zeros_like(x) if g is None else g for g in (dyv, dyh, dys))       # (a branch output nobody used)
     dyv, dyh, dys = (g.contiguous() if g.dtype == x.dtype else g.to(x.dtype).contiguous() for g in (dyv, dyh, dys))
     dx = None
+    plan = _tri_plan(ops._DT[x.dtype], N, C, H, W, K) if x.dtype in ops._DT else (False, False, 0, 0, 0, False)
+    if need_dx and all(need_w) and fused_tri_wgrad and fused_tri_backward and plan[5] and plan[3] and \
+            all(w.dtype == torch.float32 and w.is_contiguous() for w in (wv, wh, ws)):
+        # the whole backward in ONE launch (14 x 14 class): the dY planes are staged once for dx and for the three weight gradients
+        L = _lib.lib()
+        dx = torch.empty_like(x)
+        dwv, dwh, dws = (torch.empty_like(w, dtype=torch.float32) for w in (wv, wh, ws))
+        wsb, nbb = _workspace(plan[3], x.device)
+        with _on(x.device):
+            rc = L.slak_dwconv2d_tri_backward(dyv.data_ptr(), dyh.data_ptr(), dys.data_ptr(), x.data_ptr(), wv.data_ptr(), wh.data_ptr(), ws.data_ptr(),
+                                              dx.data_ptr(), dwv.data_ptr(), dwh.data_ptr(), dws.data_ptr(), ops._DT[x.dtype], N, C, H, W, K,
+                                              wsb.data_ptr(), nbb, _stream(x.device))
+        if rc != _lib.ERR_UNSUPPORTED:
+            _lib.check(rc, "slak_dwconv2d_tri_backward")
+            return dx, dwv, dwh, dws
+        dx = None
     if need_dx:
         if tri_dgrad:
             dx = torch.empty_like(x)
@@ -227,7 +245,6 @@ def _tri_backward_impl(x, wv, wh, ws, dyv, dyh, dys, tri_dgrad, need_dx, need_w)
                 dx += ops.dwconv2d_backward_data(dyh, wh)
                 dx += ops.dwconv2d_backward_data(dys, ws)
     dwv = dwh = dws = None
-    plan = _tri_plan(ops._DT[x.dtype], N, C, H, W, K) if x.dtype in ops._DT else (False, False, 0, 0, 0)
     if all(need_w) and fused_tri_wgrad and plan[3]:          # one launch for the three weight gradients (x fetched once)
         L = _lib.lib()
         dt = ops._DT[x.dtype]
@@ -1009,7 +1026,7 @@ def _runner():
     global _runner_mod
     if _runner_mod is False:
         _runner_mod = None
-        if os.environ.get("SLAK_BLOCK_RUNNER", "1") != "0" and use_skinny_linear and use_linear_wgrad and _SPLITK_ROWS == 6272:
+        if os.environ.get("SLAK_BLOCK_RUNNER", "1") != "0" and use_skinny_linear and use_linear_wgrad and _SPLITK_ROWS == 6272 and fused_tri_backward:
             try:                                                      # (the development switches above select paths only the Python sequence knows)
                 import importlib
                 import sys

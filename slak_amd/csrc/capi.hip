@@ -326,6 +326,20 @@ int slak_dwconv2d_tri_backward_filter(const void* dy_v, const void* dy_h, const 
     return SLAK_RAN("dwconv_mfma_small_tri_wgrad", launch_dwconv_mfma_small_tri_wgrad(dy, x, dw, dtype, N, C, H, W, K, workspace, workspace_bytes, (hipStream_t)stream));
 }
 
+/* Data gradient AND the three weight gradients of a block's branches in ONE launch (the 14 x 14 class: the dY planes are staged once for
+ * both).  Same bits as slak_dwconv2d_tri_backward_data + slak_dwconv2d_tri_backward_filter; workspace: slak_dwconv2d_tri_filter_workspace_bytes. */
+int slak_dwconv2d_tri_backward_supported(int dtype, int N, int C, int H, int W, int K) {
+    return dwconv_mfma_small_tri_bwd_supported(N, C, H, W, K, dtype) ? 1 : 0;
+}
+
+int slak_dwconv2d_tri_backward(const void* dy_v, const void* dy_h, const void* dy_s, const void* x, const float* w_v, const float* w_h,
+                               const float* w_s, void* dx, float* dw_v, float* dw_h, float* dw_s, int dtype, int N, int C, int H, int W, int K,
+                               void* workspace, size_t workspace_bytes, void* stream) {
+    if (!dy_v || !dy_h || !dy_s || !x || !w_v || !w_h || !w_s || !dx || !dw_v || !dw_h || !dw_s) return SLAK_ERR_INVALID_ARG;
+    const void* dy[3] = {dy_v, dy_h, dy_s}; float* dw[3] = {dw_v, dw_h, dw_s}; const float* w[3] = {w_v, w_h, w_s};
+    return SLAK_RAN("dwconv_mfma_small_tri_bwd", launch_dwconv_mfma_small_tri_bwd(dy, x, w, dx, dw, dtype, N, C, H, W, K, workspace, workspace_bytes, (hipStream_t)stream));
+}
+
 /* The K x 5 and the 5 x 5 weight gradient of a block in ONE launch where the three-branch launch above does not reach (x and its five
  * column-shifted operands are shared: the 5 x 5 correlation is the K x 5 one with its own dY).  0 / SLAK_ERR_UNSUPPORTED: two calls. */
 size_t slak_dwconv2d_pair_filter_workspace_bytes(int dtype, int N, int C, int H, int W, int K) {

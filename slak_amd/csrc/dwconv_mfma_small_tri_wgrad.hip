@@ -13,6 +13,12 @@
 //     meets correlation entries of non-existent positions, which the diagonal sums skip; the tensor's last row is fetched early
 //     and shifted into place (see dwconv_mfma_small_tri.hip).
 // At this size a launch is ~10 us of fixed cost: one launch for three removes two of them per block.
+//
+// DG (the 14 x 14 class only: W even 8..14): the block's DATA gradient dx = sum over the three branches of dy_b correlated with the 180-degree
+// rotated filter (what dwconv_mfma_small_tri_kernel<T, true, false> computes: same Toeplitz fragments, same operand orders, same fp32 adds, so
+// the same bits) in the SAME launch: the plane pairs of dy_v, dy_h, dy_s are in LDS for the weight gradients anyway, dy_v^T is transposed for both,
+// so the whole backward of a block's depthwise convs reads 4 planes and writes 1 where the two launches read 7 and write 1 -- and a launch's
+// ~10 us of fixed cost is paid once.  The filter windows of the Toeplitz fragments (set-up only) alias the transposed images / result area.
 #include "mfma_common.h"
 #include <type_traits>
 #include <stdlib.h>
@@ -28,6 +34,10 @@ constexpr int TW_T = TW_RING + TW_NS * TW_SLOT + 64;      // [dy_v^T pair 1024][
 constexpr int TW_RES = TW_T + 2048 + 64;                  // res: up to 10 * 63 + 25 floats
 constexpr int TW_RESN = 672;
 constexpr int TW_WAVE_BYTES = TW_RES + TW_RESN * 4;
+// DG: filter windows as in dwconv_mfma_small_tri.hip (16 zeros, up to 63 taps, 17 zeros per short-axis tap; two copies one element apart)
+constexpr int TW_WZP = 16, TW_WLEN = 96, TW_WCH = 5;
+constexpr int TW_WINB = 2 * MF_TAPS * TW_WLEN * 2;       // bytes of one branch's windows
+constexpr int TW_WAVE_BYTES_DG = TW_T + 3 * TW_WINB > TW_WAVE_BYTES ? TW_T + 3 * TW_WINB : TW_WAVE_BYTES;
 static_assert(TW_NS * TW_SLOT >= 5 * 16 * 32 * 4, "the diagonal-sum tiles alias the ring");
 
 struct SmallTriWgradParams {
@@ -36,6 +46,7 @@ struct SmallTriWgradParams {
     int images_per_slice, slices;
     unsigned tensor_bytes;
     int dbg;                             // dev switches of the quad kernel (SLAK_QW_DBG): 1 no compute, 2 no DMA, 4 no diagonal sums, 8 no octets
+    const float* w[3]; void* dx;         // DG only: the three filters, the data gradient
 };
 
 template <typename T> __device__ __forceinline__ f32x4_t tw_mfma16(s16x8 a, s16x8 b, f32x4_t c);
@@ -84,8 +95,10 @@ __device__ __forceinline__ void tw_diag5(float* tile, int lane, const f32x4_t (&
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 }
 
-template <typename T, bool NARROW>
+template <typename T, bool NARROW, bool DG>
 __global__ __launch_bounds__(MF_THREADS) void dwconv_mfma_small_tri_wgrad_kernel(const SmallTriWgradParams p) {
+    static_assert(!(DG && NARROW), "the data gradient rides along on the 14 x 14 class only");
+    constexpr int TW_WAVE_BYTES = DG ? slak::TW_WAVE_BYTES_DG : slak::TW_WAVE_BYTES;
     extern __shared__ __attribute__((aligned(16))) uint16_t lds[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = wave_id_uniform();
@@ -101,8 +114,44 @@ __global__ __launch_bounds__(MF_THREADS) void dwconv_mfma_small_tri_wgrad_kernel
     const int HW = p.H * p.W;
     const int nt_long = p.K * MF_TAPS, ntot = 2 * nt_long + 25;  // [K x 5][5 x K][5 x 5] back to back
 
+    // DG: this channel's filters leave first (their latency runs under the zero fill)
+    const int ntap = p.K * MF_TAPS;
+    float fv[TW_WCH], fh[TW_WCH], fs = 0.f;
+    if constexpr (DG) {
+        const int cw = live ? c : 0;
+#pragma unroll
+        for (int k = 0; k < TW_WCH; ++k) {
+            const int e = lane + 64 * k;
+            fv[k] = e < ntap ? p.w[0][(size_t)cw * ntap + e] : 0.f;
+            fh[k] = e < ntap ? p.w[1][(size_t)cw * ntap + e] : 0.f;
+        }
+        if (lane < 25) fs = p.w[2][(size_t)cw * 25 + lane];
+    }
     for (int o = lane * 16; o < TW_WAVE_BYTES; o += 64 * 16) *(u32x4*)(L + o) = u32x4{0u, 0u, 0u, 0u};
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");            // zeros are in place before any DMA can land on them
+    if constexpr (DG) {
+        // filter windows, rotated by 180 degrees: branch b at TW_T + b * TW_WINB (the transposed images and the result area: unused until
+        // the first pair has landed; cleared again below).  Written BEFORE the first DMA leaves: the filter loads are vector-memory
+        // operations as well, and the wait the compiler puts in front of their first use then has nothing else to wait for.
+        auto put = [&](int b, int r, int t, int KL, float v) {        // short tap r, long tap t of branch b
+            r = MF_TAPS - 1 - r; t = KL - 1 - t;
+            const uint16_t h = cvt_to_bits(v, (T*)nullptr);
+            uint16_t* win = (uint16_t*)(L + TW_T + b * TW_WINB);
+            win[r * TW_WLEN + TW_WZP + t] = h;
+            win[MF_TAPS * TW_WLEN + r * TW_WLEN + TW_WZP + t - 1] = h;
+        };
+#pragma unroll
+        for (int k = 0; k < TW_WCH; ++k) {
+            const int e = lane + 64 * k;
+            if (e < ntap) {
+                put(0, e % MF_TAPS, e / MF_TAPS, p.K, fv[k]);        // (K,5): element [t][r]
+                put(1, e / p.K, e - (e / p.K) * p.K, p.K, fh[k]);    // (5,K): element [r][t]
+            }
+        }
+        if (lane < 25) put(2, lane / 5, lane % 5, 5, fs);
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+    }
 
     // ---- DMA: lane -> (plane of the pair, image row, half of the row: columns 0..7 / W-8..W-1) ------------------------
     v4i_t rs[4];
@@ -134,6 +183,47 @@ __global__ __launch_bounds__(MF_THREADS) void dwconv_mfma_small_tri_wgrad_kernel
 
     // ---- lane constants (see dwconv_mfma_small_wgrad_dma.hip) ----------------------------------------------------------
     const int g4 = lane >> 4, i16 = lane & 15;
+    // DG: Toeplitz fragments (dwconv_mfma_small_tri.hip): lane -> (o = long-axis output position, k-group g4 -> tap-in-pair rsel, half of the
+    // 16 k-slots); then the window area becomes zeros again (guard rows of the transposed images)
+    const int rsel = g4 >> 1, half = g4 & 1;
+    s16x8 tf[DG ? 3 : 1][3];
+    if constexpr (DG) {
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+            const bool vert = b == 0;
+            const int padL = (b == 2 ? 5 : p.K) / 2;
+            const int i0 = half ? (vert ? 8 : p.W - 8) : 0;
+            const int a = TW_WZP + i0 - i16 + padL;
+            const int par = a & 1;
+            const unsigned* src = (const unsigned*)(L + TW_T + b * TW_WINB + par * MF_TAPS * TW_WLEN * 2) + ((a - par) >> 1);
+#pragma unroll
+            for (int m = 0; m < 3; ++m) {
+                const int r = 2 * m + rsel;
+                u32x4 d;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    d[k] = r < MF_TAPS ? src[(r < MF_TAPS ? r : 0) * (TW_WLEN / 2) + k] : 0u;
+                    if (!vert && half && 2 * k < 16 - p.W) d[k] = 0u;     // columns already covered by the first half
+                }
+                tf[b][m] = __builtin_bit_cast(s16x8, d);
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        for (int o = lane * 16; o < TW_WAVE_BYTES - TW_T; o += 64 * 16) *(u32x4*)(L + TW_T + o) = u32x4{0u, 0u, 0u, 0u};
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+    }
+    // DG: fragment addresses and stores of the data gradient (output row i16, columns 4 g4 .. 4 g4 + 3)
+    const unsigned xlane = (unsigned)(i16 * 32 + rsel * 32 + half * 16);
+    const unsigned zlane = (unsigned)(half * 16);                    // the 64 zero bytes in front of the ring
+    const unsigned ooff = (unsigned)(i16 * p.W + 4 * g4) * 2;
+    const bool st0 = i16 < p.H && 4 * g4 < p.W, st1 = i16 < p.H && 4 * g4 + 2 < p.W;
+    __amdgpu_buffer_rsrc_t rdx = __builtin_amdgcn_make_buffer_rsrc(DG ? p.dx : nullptr, 0, (int)p.tensor_bytes, 0x00020000);
+    auto dfrag = [&](unsigned base, int m) -> s16x8 {              // MFMA m of a plane whose guarded image starts 64 bytes after `base`
+        const unsigned a = (m == 2 && rsel) ? zlane : base + xlane + m * 64;
+        return __builtin_bit_cast(s16x8, *(const u32x4*)(L + a));
+    };
     const unsigned rd = (unsigned)((g4 >> 1) * 512 + ((g4 & 1) * 8 + (i16 >> 2)) * 32 + (i16 & 3) * 8);
     const unsigned trd = (unsigned)((4 * g4 + (i16 >> 2)) * 32 + (i16 & 3) * 8);
     const int t_row = i16 < 8 ? i16 : i16 - (16 - p.W);
@@ -152,7 +242,8 @@ __global__ __launch_bounds__(MF_THREADS) void dwconv_mfma_small_tri_wgrad_kernel
     for (int q = 0; q < npairs; ++q) {
         {
             int dm = npairs - 1 - q; if (dm > TW_NS - 2) dm = TW_NS - 2;
-            wait_vmcnt_dyn(4 * dm);                               // only the DMAs of the pairs behind this one may be outstanding
+            // only the DMAs of the pairs behind this one may be outstanding (DG: and the four stores of the pair in front of it, issued after its DMAs)
+            wait_vmcnt_dyn(4 * dm + ((DG && q > 0) ? 4 : 0));
         }
         __builtin_amdgcn_wave_barrier();
         const int n0 = n_begin + 2 * q;
@@ -204,6 +295,26 @@ __global__ __launch_bounds__(MF_THREADS) void dwconv_mfma_small_tri_wgrad_kernel
         const unsigned xtb = (unsigned)TW_T + 1024 - 64 + rd;
 #pragma unroll
         for (int r = 0; r < MF_TAPS; ++r) av[r] = tw_mfma16<T>(a_v, frag(xtb + r * 32), av[r]);
+        if constexpr (DG) {
+            const unsigned bv = (unsigned)TW_T - 64;                // dy_v^T images
+            const unsigned bh = slot + 1024u - 64, bs = slot + 2048u - 64;      // row-major images of dy_h, dy_s
+            const unsigned gb = (unsigned)n0 * gplane_b + chan_b;
+#pragma unroll
+            for (int pp = 0; pp < 2; ++pp) {
+                if (pp == 1 && n0 + 1 >= n_end) break;              // (wave-uniform) odd slice: the second plane does not exist
+                f32x4_t dv = {0.f, 0.f, 0.f, 0.f}, dh = dv, ds = dv;
+#pragma unroll
+                for (int m = 0; m < 3; ++m) {
+                    dv = tw_mfma16<T>(dfrag(bv + pp * 512, m), tf[0][m], dv);       // operands swapped: D^T = dy_v^T-tile x T^T
+                    dh = tw_mfma16<T>(tf[1][m], dfrag(bh + pp * 512, m), dh);
+                    ds = tw_mfma16<T>(tf[2][m], dfrag(bs + pp * 512, m), ds);
+                }
+                const f32x4_t sum = (dv + dh) + ds;                 // the three partial gradients, added in fp32
+                const unsigned go = gb + pp * gplane_b;
+                if (st0) __builtin_amdgcn_raw_buffer_store_b32(pack2<T>(sum[0], sum[1]), rdx, ooff, go, 0);
+                if (st1) __builtin_amdgcn_raw_buffer_store_b32(pack2<T>(sum[2], sum[3]), rdx, ooff + 4, go, 0);
+            }
+        }
         if (q + TW_NS - 1 < npairs) issue_pair(q + TW_NS - 1);      // into the slot pair q-1 used
     }
 
@@ -608,12 +719,12 @@ static int launch_qw_t(SmallTriWgradParams& p, size_t ws_bytes, hipStream_t st) 
     return SLAK_OK;
 }
 
-template <typename T, bool NARROW>
+template <typename T, bool NARROW, bool DG = false>
 static int launch_stw_t(SmallTriWgradParams& p, size_t ws_bytes, hipStream_t st) {
-    auto k = dwconv_mfma_small_tri_wgrad_kernel<T, NARROW>;
+    auto k = dwconv_mfma_small_tri_wgrad_kernel<T, NARROW, DG>;
     fill_stw_params(p, p.N, p.C, p.H, p.W, p.K, 2 * mfma_cu_count());
     if ((size_t)p.slices * p.C * (2 * p.K * MF_TAPS + 25) * sizeof(float) > ws_bytes) return SLAK_ERR_WORKSPACE;
-    const size_t lds = (size_t)MF_WAVES * TW_WAVE_BYTES;
+    const size_t lds = (size_t)MF_WAVES * (DG ? TW_WAVE_BYTES_DG : TW_WAVE_BYTES);
     if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(k, dim3((unsigned)(((p.C + 3) / 4) * p.slices)), dim3(MF_THREADS), lds, st, p);
     SLAK_LAUNCH_CHECK();
@@ -627,7 +738,7 @@ int launch_dwconv_mfma_small_tri_wgrad(const void* const* dy, const void* x, flo
     SmallTriWgradParams p;
     fill_stw_params(p, N, C, H, W, K, 512);
     for (int b = 0; b < 3; ++b) { p.dy[b] = dy[b]; p.dw[b] = dw[b]; }
-    p.x = x; p.partial = (float*)ws;
+    p.x = x; p.partial = (float*)ws; p.dx = nullptr; p.w[0] = p.w[1] = p.w[2] = nullptr;
     { static const int dbg = [] { const char* e = getenv("SLAK_QW_DBG"); return e ? atoi(e) : 0; }(); p.dbg = dbg; }
     p.counters = wgrad_arrival_counters((C + 3) / 4);
     if (!p.counters) return SLAK_ERR_UNSUPPORTED;                 // (the caller runs the three per-branch launches)
@@ -635,6 +746,25 @@ int launch_dwconv_mfma_small_tri_wgrad(const void* const* dy, const void* x, flo
         return dtype == SLAK_BF16 ? launch_qw_t<bf16_t>(p, ws_bytes, st) : launch_qw_t<f16_t>(p, ws_bytes, st);
     if (dtype == SLAK_BF16) return W < 8 ? launch_stw_t<bf16_t, true>(p, ws_bytes, st) : launch_stw_t<bf16_t, false>(p, ws_bytes, st);
     return W < 8 ? launch_stw_t<f16_t, true>(p, ws_bytes, st) : launch_stw_t<f16_t, false>(p, ws_bytes, st);
+}
+
+// The whole backward of a block's three depthwise convs in one launch (14 x 14 class): dx and the three weight gradients.
+bool dwconv_mfma_small_tri_bwd_supported(int N, int C, int H, int W, int K, int dtype) {
+    static const bool on = [] { const char* e = getenv("SLAK_SMALL_TRI_BWD"); return !(e && e[0] == '0'); }();
+    return on && dwconv_mfma_small_tri_wgrad_supported(N, C, H, W, K, dtype) && W >= 8 && !(H <= 7 && W <= 7);
+}
+
+int launch_dwconv_mfma_small_tri_bwd(const void* const* dy, const void* x, const float* const* w, void* dx, float* const* dw, int dtype,
+                                     int N, int C, int H, int W, int K, void* ws, size_t ws_bytes, hipStream_t st) {
+    if (!dwconv_mfma_small_tri_bwd_supported(N, C, H, W, K, dtype)) return SLAK_ERR_UNSUPPORTED;
+    if (ws == nullptr) return SLAK_ERR_WORKSPACE;
+    SmallTriWgradParams p;
+    fill_stw_params(p, N, C, H, W, K, 512);
+    for (int b = 0; b < 3; ++b) { p.dy[b] = dy[b]; p.dw[b] = dw[b]; p.w[b] = w[b]; }
+    p.x = x; p.dx = dx; p.partial = (float*)ws; p.dbg = 0;
+    p.counters = wgrad_arrival_counters((C + 3) / 4);
+    if (!p.counters) return SLAK_ERR_UNSUPPORTED;
+    return dtype == SLAK_BF16 ? launch_stw_t<bf16_t, false, true>(p, ws_bytes, st) : launch_stw_t<f16_t, false, true>(p, ws_bytes, st);
 }
 
 }  // namespace slak

@@ -100,6 +100,9 @@ bool dwconv_mfma_small_tri_wgrad_supported(int N, int C, int H, int W, int K, in
 size_t dwconv_mfma_small_tri_wgrad_workspace(int N, int C, int K);
 int launch_dwconv_mfma_small_tri_wgrad(const void* const* dy, const void* x, float* const* dw, int dtype,
                                        int N, int C, int H, int W, int K, void* ws, size_t ws_bytes, hipStream_t st);
+bool dwconv_mfma_small_tri_bwd_supported(int N, int C, int H, int W, int K, int dtype);
+int launch_dwconv_mfma_small_tri_bwd(const void* const* dy, const void* x, const float* const* w, void* dx, float* const* dw, int dtype,
+                                     int N, int C, int H, int W, int K, void* ws, size_t ws_bytes, hipStream_t st);
 bool dwconv_mfma_tri_wgrad_rows_supported(int N, int C, int H, int W, int K, int dtype);
 size_t dwconv_mfma_tri_wgrad_rows_workspace(int N, int C, int K);
 int launch_dwconv_mfma_tri_wgrad_rows(const void* const* dy, const void* x, float* const* dw, int dtype,

@@ -44,7 +44,7 @@ Scratch scratch(const Tensor& like, size_t bytes) {
 struct Shape { int N, C, H, W, K, P, M, C4; };
 
 // what the library answers for a block shape, asked once
-struct Plan { bool ok; int rows; size_t ws; bool nt1, nt2, ntd1, ntd2, wg1, wg2; };
+struct Plan { bool ok; int rows; size_t ws; bool nt1, nt2, ntd1, ntd2, wg1, wg2, bwd1; };
 const Plan& plan_of(const Shape& s) {
     static std::map<std::vector<int>, Plan> cache;
     const std::vector<int> key = {s.N, s.C, s.H, s.W, s.K, s.C4};
@@ -62,6 +62,7 @@ const Plan& plan_of(const Shape& s) {
     p.ntd2 = slak_linear_nt_supported(s.M, s.C, s.C4, 0) != 0;     // dy1 W1
     p.wg1 = slak_linear_wgrad_supported(s.M, s.C4, s.C) != 0;      // dW1 = dy1^T t
     p.wg2 = slak_linear_wgrad_supported(s.M, s.C, s.C4) != 0;      // dW2 = dz^T a
+    p.bwd1 = slak_dwconv2d_tri_backward_supported(dt, s.N, s.C, s.H, s.W, s.K) == 1;
     size_t ws = std::max(wtri, slak_bn3_workspace_bytes(s.N, s.C));
     ws = std::max(ws, slak_block_tail_workspace_bytes(s.N, s.C, s.P));
     ws = std::max(ws, slak_gelu_bwd_workspace_bytes(s.M, s.C4));
@@ -220,11 +221,16 @@ std::vector<Tensor> block_backward(const Tensor& x16, const Tensor& wv, const Te
                                      d1.data_ptr(), d2.data_ptr(), d3.data_ptr(), s.N, s.C, s.P, ws.p, ws.n, st), "slak_bn3_backward_local");
     // three branch convs: the summed data gradient, the three weight gradients
     Tensor dx16 = at::empty_like(x16);
+    Tensor dwv = at::empty_like(wv), dwh = at::empty_like(wh), dws = at::empty_like(wsm);
+    if (pl.bwd1) {                                                 // 14 x 14 class: data gradient and the three weight gradients in one launch
+        check_rc(slak_dwconv2d_tri_backward(d1.data_ptr(), d2.data_ptr(), d3.data_ptr(), x16.data_ptr(), fp(wv), fp(wh), fp(wsm), dx16.data_ptr(),
+                                            fpm(dwv), fpm(dwh), fpm(dws), dt, s.N, s.C, s.H, s.W, s.K, ws.p, ws.n, st), "slak_dwconv2d_tri_backward");
+    } else {
     check_rc(slak_dwconv2d_tri_backward_data(d1.data_ptr(), d2.data_ptr(), d3.data_ptr(), fp(wv), fp(wh), fp(wsm), dx16.data_ptr(), dt,
                                              s.N, s.C, s.H, s.W, s.K, st), "slak_dwconv2d_tri_backward_data");
-    Tensor dwv = at::empty_like(wv), dwh = at::empty_like(wh), dws = at::empty_like(wsm);
     check_rc(slak_dwconv2d_tri_backward_filter(d1.data_ptr(), d2.data_ptr(), d3.data_ptr(), x16.data_ptr(), fpm(dwv), fpm(dwh), fpm(dws), dt,
                                                s.N, s.C, s.H, s.W, s.K, ws.p, ws.n, st), "slak_dwconv2d_tri_backward_filter");
+    }
     Tensor dx = had_lowp ? dshortcut : (dshortcut + dx16);
     return {dx, had_lowp ? dx16 : Tensor(), dwv, dwh, dws, dgam, dbet, dlnw, dlnb, dw1, db1, dw2, dzc, dgamma};
 }

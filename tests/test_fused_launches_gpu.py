@@ -124,6 +124,24 @@ def _tri_wgrad(dys, x, K):
     return dws
 
 
+def _tri_bwd(dys, x, ws, K):
+    """dx and the three weight gradients in ONE launch (slak_dwconv2d_tri_backward); None where there is no such launch"""
+    L = _L(); lib = L.lib()
+    N, C, H, W = x.shape
+    dt = _dt(x.dtype)
+    if not lib.slak_dwconv2d_tri_backward_supported(dt, N, C, H, W, K):
+        return None
+    nb = int(lib.slak_dwconv2d_tri_filter_workspace_bytes(dt, N, C, H, W, K))
+    assert nb > 0
+    wsb = torch.empty(nb, dtype=torch.uint8, device=x.device)
+    dx = torch.full_like(x, float("nan"))
+    dws = [torch.full((C, 1, kh, kw), float("nan"), dtype=torch.float32, device=x.device) for kh, kw in ((K, 5), (5, K), (5, 5))]
+    L.check(lib.slak_dwconv2d_tri_backward(dys[0].data_ptr(), dys[1].data_ptr(), dys[2].data_ptr(), x.data_ptr(), ws[0].data_ptr(), ws[1].data_ptr(),
+                                           ws[2].data_ptr(), dx.data_ptr(), dws[0].data_ptr(), dws[1].data_ptr(), dws[2].data_ptr(), dt, N, C, H, W, K,
+                                           wsb.data_ptr(), nb, _st(x.device)), "tri_backward")
+    return dx, dws
+
+
 # ------------------------------------------------------------------------------------------------ small shapes, every channel
 PAIR_SMALL = [(5, 3, 56, 56, 51), (3, 2, 56, 56, 51), (1, 1, 56, 56, 51), (9, 3, 28, 28, 49), (1, 1, 28, 28, 49), (11, 2, 28, 28, 49),
               (2, 2, 64, 16, 51), (2, 3, 36, 24, 35), (1, 1, 40, 48, 31), (6, 2, 32, 32, 31), (5, 3, 20, 24, 21), (13, 2, 15, 16, 13),
@@ -221,6 +239,53 @@ def test_tri_backward_filter_vs_oracle(N, C, H, W, K, dtype, gpu):
     xr = _r(x, dtype)
     for dw, dy, (kh, kw) in zip(dws, dys, ((K, 5), (5, K), (5, 5))):
         _check_dw(dw, oracle.dwconv2d_bwd_filter(_r(dy, dtype), xr, kh, kw), N * H * W, "dw %dx%d" % (kh, kw))
+
+
+# the block's whole conv backward in one launch (14 x 14 class): the SAME bits as the data-gradient launch and the weight-gradient launch (which
+# the tests above hold against the oracle), on odd and even slices, one image, one channel, every supported width, more channels than a workgroup's four
+TRI_BWD = [(5, 7, 14, 14, 47), (9, 4, 12, 12, 13), (4, 3, 12, 10, 9), (1, 1, 14, 14, 13), (2, 5, 14, 8, 27), (33, 6, 9, 14, 31), (128, 9, 14, 14, 47),
+           (7, 2, 8, 8, 7), (16, 4, 14, 12, 63)]
+
+
+@pytest.mark.parametrize("N,C,H,W,K", TRI_BWD)
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_tri_backward_in_one_launch_is_the_two_launches(N, C, H, W, K, dtype, gpu):
+    torch.manual_seed(3 * N + K)
+    x = torch.randn(N, C, H, W, device=gpu).to(dtype)
+    dys = [torch.randn(N, C, H, W, device=gpu).to(dtype) for _ in range(3)]
+    ws = _filters(C, K, gpu, K + N)
+    got = _tri_bwd(dys, x, ws, K)
+    assert got is not None, "no one-launch backward for a 14 x 14 class shape"
+    dx, dws = got
+    assert torch.equal(dx, _tri_dgrad(dys, ws, K))
+    for a, b in zip(dws, _tri_wgrad(dys, x, K)):
+        assert torch.equal(a, b)
+    # and against the oracle directly (the data gradient with the two-rounding bound of the tests above)
+    wr = [_r(w, dtype) for w in ws]
+    parts = [oracle.dwconv2d_bwd_data(_r(d, dtype), w) for d, w in zip(dys, wr)]
+    ref = sum(parts)
+    ulp = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11
+    bound = ulp * (np.abs(ref) + sum(np.abs(p) for p in parts)) + 5e-6 * max(1.0, float(np.abs(ref).max()))
+    assert (np.abs(dx.double().cpu().numpy() - ref) <= bound).all()
+    xr = _r(x, dtype)
+    for dw, dy, (kh, kw) in zip(dws, dys, ((K, 5), (5, K), (5, 5))):
+        _check_dw(dw, oracle.dwconv2d_bwd_filter(_r(dy, dtype), xr, kh, kw), N * H * W, "one-launch dw %dx%d" % (kh, kw))
+
+
+def test_tri_backward_in_one_launch_says_where_it_does_not_exist(gpu):
+    L = _L(); lib = L.lib()
+    for (N, C, H, W, K) in [(4, 4, 7, 7, 13), (4, 4, 28, 28, 49), (4, 4, 56, 56, 51), (4, 4, 14, 7, 13), (4, 4, 14, 13, 13)]:
+        assert lib.slak_dwconv2d_tri_backward_supported(L.SLAK_BF16, N, C, H, W, K) == 0, (N, C, H, W, K)
+        x = torch.randn(N, C, H, W, device=gpu).bfloat16()
+        ws = _filters(C, K, gpu, 1)
+        dws = [torch.empty(C, 1, kh, kw, dtype=torch.float32, device=gpu) for kh, kw in ((K, 5), (5, K), (5, 5))]
+        wsb = torch.empty(1 << 20, dtype=torch.uint8, device=gpu)
+        dx = torch.empty_like(x)
+        rc = lib.slak_dwconv2d_tri_backward(x.data_ptr(), x.data_ptr(), x.data_ptr(), x.data_ptr(), ws[0].data_ptr(), ws[1].data_ptr(), ws[2].data_ptr(),
+                                            dx.data_ptr(), dws[0].data_ptr(), dws[1].data_ptr(), dws[2].data_ptr(), L.SLAK_BF16, N, C, H, W, K,
+                                            wsb.data_ptr(), wsb.numel(), _st(gpu))
+        assert rc == L.ERR_UNSUPPORTED, (N, C, H, W, K, rc)
+    assert lib.slak_dwconv2d_tri_backward_supported(L.SLAK_F32, 4, 4, 14, 14, 47) == 0
 
 
 # planes of 2 x 2 MFMA tiles (33 .. 64, W % 8 == 0): dwconv_mfma_tri_wgrad_rows.hip.  One workgroup per CU owns a RANGE of the C * N planes in

@@ -33,6 +33,9 @@ for cfg, (N, stages) in CONFIGS.items():
         if nb:
             ws = torch.empty(nb, dtype=torch.uint8, device=dev); dws = [torch.empty_like(w) for w in wts]
             _lib.check(L.slak_dwconv2d_tri_backward_filter(x.data_ptr(), x.data_ptr(), x.data_ptr(), x.data_ptr(), dws[0].data_ptr(), dws[1].data_ptr(), dws[2].data_ptr(), dt, N, C, HW, HW, K, ws.data_ptr(), nb, st)); out[key + "/bwd_filter"] = last()
+        out[key + "/use_bwd"] = int(L.slak_dwconv2d_tri_backward_supported(dt, N, C, HW, HW, K))     # data gradient + the three weight gradients in one launch
+        if out[key + "/use_bwd"]:
+            _lib.check(L.slak_dwconv2d_tri_backward(x.data_ptr(), x.data_ptr(), x.data_ptr(), x.data_ptr(), wts[0].data_ptr(), wts[1].data_ptr(), wts[2].data_ptr(), ys[2].data_ptr(), dws[0].data_ptr(), dws[1].data_ptr(), dws[2].data_ptr(), dt, N, C, HW, HW, K, ws.data_ptr(), nb, st)); out[key + "/bwd"] = last()
         nb = int(L.slak_dwconv2d_pair_filter_workspace_bytes(dt, N, C, HW, HW, K))
         if nb:
             ws = torch.empty(nb, dtype=torch.uint8, device=dev); dws = [torch.empty_like(wts[0]), torch.empty_like(wts[2])]
