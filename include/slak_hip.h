@@ -262,6 +262,15 @@ int slak_linear_nt_supported(int M, int N, int K, int gelu);
 int slak_linear_nt(const void* x_bf16, const void* wt_bf16, const void* bias_bf16 /* or NULL */, void* y_bf16, void* gelu_out_bf16 /* or NULL */,
                    int M, int N, int K, void* stream);
 
+/* pwconv2's data gradient WITH nn.GELU()'s backward and pwconv1's bias gradient in the same pass (models/SLaK.py:159-160 backwards):
+ * dy1[M,N] = round(dz[M,K] . W2[K,N]) * gelu'(y1[M,N]) (bf16, the same bits as slak_linear_nt followed by slak_gelu_backward_bias),
+ * dbias[N] = column sums of the rounded dy1 (fp32, fixed order).  wt = W2^T stored [N][K].  The intermediate dact never reaches HBM.
+ * Round 4: K = 96, N = 384, M % 32 == 0 (stage 1 of SLaK-T / SLaK-S); anything else: SLAK_ERR_UNSUPPORTED (the two calls). */
+int slak_linear_nt_gelu_bwd_supported(int M, int N, int K);
+size_t slak_linear_nt_gelu_bwd_workspace_bytes(int M, int N, int K);
+int slak_linear_nt_gelu_bwd(const void* dz_bf16, const void* wt_bf16, const void* y1_bf16, void* dy1_bf16, float* dbias, int M, int N, int K,
+                            void* workspace, size_t workspace_bytes, void* stream);
+
 /* Weight gradient of the pointwise Linear layers (models/SLaK.py:117-118 pwconv1 / pwconv2; autograd's dW = dY^T X):
  * d[N1][N2] (fp32) = x1^T x2 over the M rows of x1 [M][N1] and x2 [M][N2] (bf16, row-major), fp32 accumulate, summed in a fixed
  * order (deterministic).  Covered: N1 and N2 multiples of 192, or one of them 96 and the other a multiple of 384 (the ConvNeXt widths

@@ -921,13 +921,27 @@ def _mlp_bwd_data(saved, dz):
     y12 = y1.reshape(-1, y1.shape[-1])
     M = dz2.shape[0]
     dact = None
+    L = _lib.lib()
+    N4 = w2b.shape[1]
+    if use_skinny_linear and dz2.is_contiguous() and y12.is_contiguous() and dz2.dtype == torch.bfloat16 and w2b.dtype == torch.bfloat16 and \
+            L.slak_linear_nt_gelu_bwd_supported(M, N4, dz2.shape[1]):
+        # stage 1: dz @ W2, GELU' and pwconv1's bias gradient in ONE pass (dact never reaches HBM)
+        dy1 = torch.empty((M, N4), dtype=torch.bfloat16, device=dz2.device)
+        db1 = torch.empty(N4, dtype=torch.float32, device=dz2.device)
+        w2t = w2b.t().contiguous()
+        ws, nb = _workspace(int(L.slak_linear_nt_gelu_bwd_workspace_bytes(M, N4, dz2.shape[1])), dz2.device)
+        with _on(dz2.device):
+            _lib.check(L.slak_linear_nt_gelu_bwd(dz2.data_ptr(), w2t.data_ptr(), y12.data_ptr(), dy1.data_ptr(), db1.data_ptr(), M, N4, dz2.shape[1],
+                                                 ws.data_ptr(), nb, _stream(dz2.device)), "slak_linear_nt_gelu_bwd")
+        dt = linear_nt(dy1, w1b.t().contiguous()) if linear_nt_covers(dy1, w1b.shape[1]) else None
+        dt = (dt if dt is not None else torch.mm(dy1, w1b)).view_as(t)
+        return dt, dy1, db1
     if linear_nt_covers(dz2, w2b.shape[1]):
         dact = linear_nt(dz2, w2b.t().contiguous())              # dz @ W2: NT against the (small) transposed weight
     if dact is None:
         dact = torch.mm(dz2, w2b)
     dy1 = torch.empty_like(dact)
     db1 = torch.empty(dact.shape[1], dtype=torch.float32, device=dact.device)
-    L = _lib.lib()
     key = (M, dact.shape[1])
     nbw = _gelu_ws_cache.get(key)
     if nbw is None:

@@ -21,6 +21,7 @@
 //   linear_nt_k96:  K = 96,  N = 32 NT <= 384  (pwconv1 forward [+ GELU], dz . W2):   walks the N/32 column tiles per row block
 //   linear_nt_n96:  N = 96,  K = 96 NKC <= 384 (pwconv2 forward, dy1 . W1):           three accumulators, walks K in 96-column blocks
 #include "mfma_common.h"
+#include "gelu_grad.h"
 #include <cmath>
 #include <cstring>
 #include <mutex>
@@ -241,6 +242,132 @@ __global__ __launch_bounds__(LK_THREADS, 1) void linear_nt_k96_kernel(const uint
     }
 }
 
+// dz . W2 WITH nn.GELU()'s backward in the epilogue (models/SLaK.py:159-160 backwards): dy1 = round(dz . W2) * gelu'(y1), rounded, and the column
+// sums of dy1 (pwconv1's bias gradient) -- the k96 kernel above, whose output tile (dact, rounded to bf16 as the stand-alone GEMM stores it)
+// meets the stored pre-activation y1 in the flush layout (lane = row lane/8, 16-byte chunk lane%8: full 128-byte lines in both directions)
+// instead of making a round trip through HBM: dact is never written, the stand-alone gelu_bwd_bias pass (3 x M x N x 2 bytes) disappears.
+// Same evaluation as gelu_bwd_bias_kernel (gelu_grad.h): the same dy1 bits.  FOUR waves, one per SIMD with the whole register file: the 24
+// y1 loads (96 registers) of the NEXT row block leave together with its X DMA, a block ahead of their use, into a second register set; the wait at the top of a block -- only the previous block's 24 stores may be outstanding --
+// covers both.  Column sums: eight per lane and column pair, reduced over the eight row lanes at the end, one partial row per wave;
+// tail_reduce_columns adds the rows in a fixed order.
+constexpr int LG_WAVES = 4, LG_THREADS = LG_WAVES * 64, LG_NP = 6;   // N = 64 LG_NP = 384
+
+__global__ __launch_bounds__(LG_THREADS, 1) void linear_nt_k96_gbwd_kernel(const uint16_t* __restrict__ X, const uint16_t* __restrict__ Wt,
+                                                                         const uint16_t* __restrict__ Y1, uint16_t* __restrict__ DY,
+                                                                         float* __restrict__ part, int M, unsigned x_bytes, unsigned y_bytes,
+                                                                         const float* __restrict__ table) {
+    constexpr int K = 96, KS = 6, N = 64 * LG_NP;
+    extern __shared__ __attribute__((aligned(16))) uint16_t lds[];
+    char* const L = (char*)lds;
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, lhi = lane >> 5;
+    const int wave = wave_id_uniform();
+    char* const Lw = L;                                               // [N][LS_XP]
+    const unsigned xbuf = (unsigned)N * LS_XP + (unsigned)wave * LS_XBUF;
+    char* const ot = L + (unsigned)N * LS_XP + LG_WAVES * LS_XBUF + wave * LK_OBUF;
+    const float* const T = (const float*)(L + (unsigned)N * LS_XP + LG_WAVES * (LS_XBUF + LK_OBUF));
+    const unsigned lds_base = (unsigned)(uintptr_t)SLAK_LDS(uint16_t, lds);
+    v4i_t rsrc;
+    {
+        const uint64_t a = (uint64_t)X;
+        rsrc[0] = __builtin_amdgcn_readfirstlane((int)(a & 0xffffffffu)); rsrc[1] = __builtin_amdgcn_readfirstlane((int)((a >> 32) & 0xffffu));
+        rsrc[2] = __builtin_amdgcn_readfirstlane((int)x_bytes); rsrc[3] = 0x00020000;
+    }
+    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(Y1), 0, (int)y_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(DY, 0, (int)y_bytes, 0x00020000);
+    XDma plan; xdma_plan(plan, lane, K * 2);
+    const int ntiles_m = M >> 5, stride = gridDim.x * LG_WAVES;       // (M % 32 == 0: every row of every block exists)
+    const int fr = lane >> 3, fc = lane & 7;                          // flush layout: row fr + 8 it, 16-byte chunk fc of the 64-column pair
+    const unsigned flane = (unsigned)fr * (unsigned)(N * 2) + (unsigned)fc * 16u;
+    // the 24 y1 loads of row block t, always issued (a block behind the matrix: out of range, zeros).  (A macro, not a lambda: register arrays
+    // taken by reference end up in scratch memory.)
+#define SLAK_LG_LOAD_Y(t_, yv_) { \
+        const unsigned g0_ = (t_) < ntiles_m ? (unsigned)(t_) * 32u * (unsigned)(N * 2) + flane : 0x80000000u; \
+        _Pragma("unroll") for (int pr = 0; pr < LG_NP; ++pr) \
+            _Pragma("unroll") for (int it = 0; it < 4; ++it) yv_[pr][it] = __builtin_amdgcn_raw_buffer_load_b128(ry, g0_ + (unsigned)(it * 8 * N * 2), pr * 128, 0); }
+    int tm = blockIdx.x * LG_WAVES + wave;
+    u32x4 cur[LG_NP][4], nxt[LG_NP][4];
+    if (tm < ntiles_m) xdma_issue(plan, (unsigned)tm * 32u * K * 2u, 32, rsrc, lds_base + xbuf);
+    SLAK_LG_LOAD_Y(tm, cur)
+    stage_weight(Lw, Wt, N, K, LS_XP, tid, LG_THREADS);
+    for (int i = tid; i < GD_BYTES / 16; i += LG_THREADS) ((u32x4*)T)[i] = ((const u32x4*)table)[i];
+    __syncthreads();                                                  // the only workgroup barrier
+    constexpr int nst = LG_NP * 4;                                    // store instructions of one row block
+    int pending = 0;
+    const unsigned wlane = (unsigned)l31 * LS_XP + (unsigned)lhi * 16u;
+    float acc[LG_NP][8];
+#pragma unroll
+    for (int pr = 0; pr < LG_NP; ++pr)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc[pr][k] = 0.f;
+    auto lsync = [] { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); };
+    for (; tm < ntiles_m; tm += stride) {
+        // my X block and my y1 registers have landed: their DMA / loads left a block ago, only the previous block's stores came after them
+        wait_vmcnt_dyn(pending);
+        __builtin_amdgcn_wave_barrier();
+        s16x8 xf[KS];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) xf[ks] = __builtin_bit_cast(s16x8, *(const u32x4*)(L + xbuf + wlane + ks * 32));
+        lsync();                                                      // every lane has its fragments: the buffer is free
+        pending = nst;
+        const int tn = tm + stride;
+        if (tn < ntiles_m) xdma_issue(plan, (unsigned)tn * 32u * K * 2u, 32, rsrc, lds_base + xbuf);
+        SLAK_LG_LOAD_Y(tn, nxt)
+        const unsigned g0 = (unsigned)tm * 32u * (unsigned)(N * 2) + flane;
+#pragma unroll
+        for (int pr = 0; pr < LG_NP; ++pr) {
+            unsigned py[2][8];
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const int nt = 2 * pr + half;
+                f32x16 a;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) a[i] = 0.f;
+                const char* wt = Lw + (size_t)nt * 32 * LS_XP + wlane;
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) a = mfma32<bf16_t>(__builtin_bit_cast(s16x8, *(const u32x4*)(wt + ks * 32)), xf[ks], a);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { py[half][2 * q] = pack2<bf16_t>(a[4 * q + 0], a[4 * q + 1]); py[half][2 * q + 1] = pack2<bf16_t>(a[4 * q + 2], a[4 * q + 3]); }
+            }
+            put_tile(ot, py[0], l31, lhi, 0); put_tile(ot, py[1], l31, lhi, 1);
+            lsync();
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const u32x4 g4 = *(const u32x4*)(ot + (it * 8 + fr) * LK_OP + fc * 16);
+                const uint4 g = uint4{g4[0], g4[1], g4[2], g4[3]}, y = uint4{cur[pr][it][0], cur[pr][it][1], cur[pr][it][2], cur[pr][it][3]};
+                float a2[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) a2[k] = acc[pr][k];
+                uint4 v;
+                const bool ok = gelu_bwd8_fast(T, g, y, v, a2);
+                if (__builtin_amdgcn_ballot_w64(!ok) != 0ull) {       // (wave-uniform, rare) an element outside the table: the general evaluation
+                    gelu_bwd8(T, g, y, v, acc[pr]);
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) acc[pr][k] = a2[k];
+                }
+                __builtin_amdgcn_raw_buffer_store_b128(u32x4{v.x, v.y, v.z, v.w}, rd, g0 + (unsigned)(it * 8 * N * 2), pr * 128, 0);
+            }
+            lsync();
+        }
+        // the next block's y1 becomes the current one (96 register moves: ~4 % of a block; the compiler's wait in front of them counts the
+        // 24 stores above, and those loads left before this block's first MFMA)
+#pragma unroll
+        for (int pr = 0; pr < LG_NP; ++pr)
+#pragma unroll
+            for (int it = 0; it < 4; ++it) cur[pr][it] = nxt[pr][it];
+    }
+#undef SLAK_LG_LOAD_Y
+    // column sums: over the eight row lanes, then one partial row per wave
+#pragma unroll
+    for (int pr = 0; pr < LG_NP; ++pr)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            float v = acc[pr][k];
+            v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);
+            if (lane < 8) part[((size_t)blockIdx.x * LG_WAVES + wave) * N + pr * 64 + lane * 8 + k] = v;
+        }
+}
+
 template <int NKC>                 // K = 96 NKC
 __global__ __launch_bounds__(LS_THREADS, 1) void linear_nt_n96_kernel(const uint16_t* __restrict__ X, const uint16_t* __restrict__ Wt,
                                                                     const uint16_t* __restrict__ bias, uint16_t* __restrict__ Y,
@@ -377,6 +504,35 @@ int slak_linear_nt(const void* x, const void* wt, const void* bias, void* y, voi
     }
     SLAK_LAUNCH_CHECK();
     return SLAK_OK;
+}
+
+/* dy1 = round(dz . W2) * gelu'(y1) and dbias = column sums of dy1 in ONE pass (see linear_nt_k96_gbwd_kernel): x = dz [M][K], wt = W2^T [N][K],
+ * y1, dy1 [M][N] bf16, dbias [N] fp32.  Round 4: K = 96, N = 384 (stage 1 of SLaK-T/S).  The same dy1 bits as slak_linear_nt followed by
+ * slak_gelu_backward_bias; dbias is the same sum of the rounded dy1 in another (fixed) order. */
+int slak_linear_nt_gelu_bwd_supported(int M, int N, int K) {
+    static const bool on = [] { const char* e = getenv("SLAK_LINEAR_GELU_BWD"); return !(e && e[0] == '0'); }();
+    return (on && M >= 32 && M % 32 == 0 && K == 96 && N == 64 * LG_NP && (long long)M * N * 2 < (1LL << 31)) ? 1 : 0;
+}
+size_t slak_linear_nt_gelu_bwd_workspace_bytes(int M, int N, int K) {
+    if (!slak_linear_nt_gelu_bwd_supported(M, N, K)) return 0;
+    return align_up((size_t)1024 * LG_WAVES * N * sizeof(float), 256);            // one partial row per wave, at most 1024 workgroups
+}
+int slak_linear_nt_gelu_bwd(const void* x, const void* wt, const void* y1, void* dy1, float* dbias, int M, int N, int K,
+                            void* workspace, size_t workspace_bytes, void* stream) {
+    if (!x || !wt || !y1 || !dy1 || !dbias) return SLAK_ERR_INVALID_ARG;
+    if (!slak_linear_nt_gelu_bwd_supported(M, N, K)) return SLAK_ERR_UNSUPPORTED;
+    if (!workspace || workspace_bytes < slak_linear_nt_gelu_bwd_workspace_bytes(M, N, K)) return SLAK_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    const int tiles = M / 32;
+    int wk = mfma_cu_count(); if (wk > 1024) wk = 1024; if (wk * LG_WAVES > tiles) wk = (tiles + LG_WAVES - 1) / LG_WAVES;
+    const float* table = gelu_grad_table_device();
+    if (!table) return SLAK_ERR_LAUNCH;
+    const size_t lds = (size_t)N * LS_XP + (size_t)LG_WAVES * (LS_XBUF + LK_OBUF) + GD_BYTES;
+    if (hipFuncSetAttribute((const void*)linear_nt_k96_gbwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return SLAK_ERR_LAUNCH;
+    hipLaunchKernelGGL(linear_nt_k96_gbwd_kernel, dim3(wk), dim3(LG_THREADS), lds, st, (const uint16_t*)x, (const uint16_t*)wt, (const uint16_t*)y1,
+                       (uint16_t*)dy1, (float*)workspace, M, (unsigned)((size_t)M * K * 2), (unsigned)((size_t)M * N * 2), table);
+    SLAK_LAUNCH_CHECK();
+    return tail_reduce_columns((const float*)workspace, dbias, wk * LG_WAVES, N, st);
 }
 
 }  // extern "C"

@@ -44,7 +44,7 @@ Scratch scratch(const Tensor& like, size_t bytes) {
 struct Shape { int N, C, H, W, K, P, M, C4; };
 
 // what the library answers for a block shape, asked once
-struct Plan { bool ok; int rows; size_t ws; bool nt1, nt2, ntd1, ntd2, wg1, wg2, bwd1; };
+struct Plan { bool ok; int rows; size_t ws; bool nt1, nt2, ntd1, ntd2, wg1, wg2, bwd1, gbwd; };
 const Plan& plan_of(const Shape& s) {
     static std::map<std::vector<int>, Plan> cache;
     const std::vector<int> key = {s.N, s.C, s.H, s.W, s.K, s.C4};
@@ -63,11 +63,13 @@ const Plan& plan_of(const Shape& s) {
     p.wg1 = slak_linear_wgrad_supported(s.M, s.C4, s.C) != 0;      // dW1 = dy1^T t
     p.wg2 = slak_linear_wgrad_supported(s.M, s.C, s.C4) != 0;      // dW2 = dz^T a
     p.bwd1 = slak_dwconv2d_tri_backward_supported(dt, s.N, s.C, s.H, s.W, s.K) == 1;
+    p.gbwd = slak_linear_nt_gelu_bwd_supported(s.M, s.C4, s.C) == 1;
     size_t ws = std::max(wtri, slak_bn3_workspace_bytes(s.N, s.C));
     ws = std::max(ws, slak_block_tail_workspace_bytes(s.N, s.C, s.P));
     ws = std::max(ws, slak_gelu_bwd_workspace_bytes(s.M, s.C4));
     if (p.wg1) ws = std::max(ws, slak_linear_wgrad_workspace_bytes(s.M, s.C4, s.C));
     if (p.wg2) ws = std::max(ws, slak_linear_wgrad_workspace_bytes(s.M, s.C, s.C4));
+    if (p.gbwd) ws = std::max(ws, slak_linear_nt_gelu_bwd_workspace_bytes(s.M, s.C4, s.C));
     p.ws = ws;
     return cache.emplace(key, p).first->second;
 }
@@ -192,14 +194,21 @@ std::vector<Tensor> block_backward(const Tensor& x16, const Tensor& wv, const Te
     if (shortcut_bf16) dshortcut = dshortcut.to(at::kBFloat16);
     // the MLP's data path: dz -> dact -> (GELU') dy1 (+ pwconv1's bias gradient) -> dt
     Tensor dz2 = dz.view({s.M, s.C});
-    Tensor dact;
+    Tensor dact, dy1, db1 = at::empty({s.C4}, f32);
+    if (pl.gbwd) {                                                 // stage 1: dz W2, GELU' and pwconv1's bias gradient in one pass
+        Tensor w2t = w2b.t().contiguous();
+        dy1 = at::empty({s.M, s.C4}, x16.options());
+        check_rc(slak_linear_nt_gelu_bwd(dz2.data_ptr(), w2t.data_ptr(), y1m.data_ptr(), dy1.data_ptr(), fpm(db1), s.M, s.C4, s.C, ws.p, ws.n, st),
+                 "slak_linear_nt_gelu_bwd");
+    } else {
     if (pl.ntd1) {
         Tensor w2t = w2b.t().contiguous();
         dact = at::empty({s.M, s.C4}, x16.options());
         check_rc(slak_linear_nt(dz2.data_ptr(), w2t.data_ptr(), nullptr, dact.data_ptr(), nullptr, s.M, s.C4, s.C, st), "slak_linear_nt");
     } else dact = at::mm(dz2, w2b);
-    Tensor dy1 = at::empty_like(dact), db1 = at::empty({s.C4}, f32);
+    dy1 = at::empty_like(dact);
     check_rc(slak_gelu_backward_bias(dact.data_ptr(), y1m.data_ptr(), dy1.data_ptr(), fpm(db1), s.M, s.C4, ws.p, ws.n, st), "slak_gelu_backward_bias");
+    }
     Tensor dt_;
     if (pl.ntd2) {
         Tensor w1t = w1b.t().contiguous();

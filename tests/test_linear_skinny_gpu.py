@@ -98,3 +98,51 @@ def test_linear_wgrad_unsupported_shapes_fall_back(gpu):
     assert block_ops.linear_wgrad(torch.zeros(4096, 128, device=gpu).bfloat16(), torch.zeros(4096, 512, device=gpu).bfloat16()) is None
 
 
+
+
+@pytest.mark.parametrize("M", [32, 96, 6272, 40032, 401408])
+def test_linear_nt_gelu_bwd_is_the_gemm_followed_by_the_gelu_backward(M, gpu):
+    """slak_linear_nt_gelu_bwd (stage 1: K = 96, N = 384): dy1 bit for bit what slak_linear_nt + slak_gelu_backward_bias store -- zeros, tiny,
+    huge, infinite and NaN pre-activations included (the general evaluation) -- and the bias gradient = column sums of the stored dy1."""
+    from slak_amd import block_ops, _lib
+    L = _lib.lib()
+    N, K = 384, 96
+    assert L.slak_linear_nt_gelu_bwd_supported(M, N, K) == 1
+    torch.manual_seed(M)
+    dz = (torch.randn(M, K, device=gpu) * 0.5).bfloat16()
+    wt = (torch.randn(N, K, device=gpu) * 0.1).bfloat16()
+    y1 = torch.randn(M, N, device=gpu)
+    flat = y1.view(-1)
+    sp = torch.tensor([0.0, -0.0, 1e-7, -1e-7, 3e-6, -3.9e-6, 15.9, -15.9, 16.0, -16.0, 40.0, -1e30, float("inf"), float("-inf"), float("nan")], device=gpu)
+    idx = torch.randperm(flat.numel(), device=gpu)[:sp.numel() * 3]
+    flat[idx] = sp.repeat(3)
+    y1 = y1.bfloat16()
+    st = torch.cuda.current_stream(gpu).cuda_stream
+    # the two calls
+    dact = torch.empty(M, N, device=gpu, dtype=torch.bfloat16)
+    _lib.check(L.slak_linear_nt(dz.data_ptr(), wt.data_ptr(), None, dact.data_ptr(), None, M, N, K, st), "linear_nt")
+    ref = torch.empty_like(dact); dbr = torch.empty(N, device=gpu)
+    ws, nb = block_ops._workspace(L.slak_gelu_bwd_workspace_bytes(M, N), gpu)
+    _lib.check(L.slak_gelu_backward_bias(dact.data_ptr(), y1.data_ptr(), ref.data_ptr(), dbr.data_ptr(), M, N, ws.data_ptr(), nb, st), "gelu")
+    # the one call
+    dy1 = torch.full((M, N), float("nan"), device=gpu, dtype=torch.bfloat16); db = torch.full((N,), float("nan"), device=gpu)
+    nb2 = int(L.slak_linear_nt_gelu_bwd_workspace_bytes(M, N, K))
+    ws2 = torch.empty(nb2, dtype=torch.uint8, device=gpu)
+    _lib.check(L.slak_linear_nt_gelu_bwd(dz.data_ptr(), wt.data_ptr(), y1.data_ptr(), dy1.data_ptr(), db.data_ptr(), M, N, K, ws2.data_ptr(), nb2, st), "fused")
+    torch.cuda.synchronize()
+    assert torch.equal(dy1.view(torch.int16), ref.view(torch.int16))
+    colfin = torch.isfinite(dy1.double().sum(0))
+    got, want = db.double()[colfin], dy1.double().sum(0)[colfin]
+    assert (got - want).abs().max().item() <= 1e-5 * max(1.0, want.abs().max().item()) * max(1.0, M ** 0.5 / 30)
+    assert (db.double()[colfin] - dbr.double()[colfin]).abs().max().item() <= 2e-5 * max(1.0, want.abs().max().item()) * max(1.0, M ** 0.5 / 30)
+
+
+def test_linear_nt_gelu_bwd_declines_what_it_does_not_cover(gpu):
+    from slak_amd import _lib
+    L = _lib.lib()
+    for (M, N, K) in [(6272, 768, 192), (6272, 384, 192), (100, 384, 96), (6272, 512, 128), (0, 384, 96)]:
+        assert L.slak_linear_nt_gelu_bwd_supported(M, N, K) == 0
+        assert L.slak_linear_nt_gelu_bwd_workspace_bytes(M, N, K) == 0
+    x = torch.zeros(100, 384, device=gpu, dtype=torch.bfloat16); db = torch.zeros(384, device=gpu)
+    rc = L.slak_linear_nt_gelu_bwd(x.data_ptr(), x.data_ptr(), x.data_ptr(), x.data_ptr(), db.data_ptr(), 100, 384, 96, x.data_ptr(), 1 << 20, None)
+    assert rc == _lib.ERR_UNSUPPORTED
