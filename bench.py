@@ -578,10 +578,12 @@ def main():
     torch.cuda.synchronize()
     if a.host_profile:                                            # after the timed region: where the enqueue time goes
         import cProfile, pstats
-        pr = cProfile.Profile(); pr.enable()
-        for _ in range(a.steps):
-            step()
-        pr.disable(); torch.cuda.synchronize()
+        pr = cProfile.Profile()
+        for i in range(a.steps):                                  # (three steps at a time on a drained queue: the host's own cost, see above)
+            pr.enable(); step(); pr.disable()
+            if i % 3 == 2:
+                torch.cuda.synchronize()
+        torch.cuda.synchronize()
         pstats.Stats(pr, stream=sys.stderr).sort_stats("cumulative").print_stats(60)
     per_rank_ms = [1e3 * elapsed / a.steps]
     mask_sync = None

@@ -262,6 +262,15 @@ int slak_linear_nt_supported(int M, int N, int K, int gelu);
 int slak_linear_nt(const void* x_bf16, const void* wt_bf16, const void* bias_bf16 /* or NULL */, void* y_bf16, void* gelu_out_bf16 /* or NULL */,
                    int M, int N, int K, void* stream);
 
+/* The fixed-order column sums that end slak_scale_residual_backward, slak_ln_nchw_to_nhwc_backward, slak_gelu_backward_bias,
+ * slak_linear_nt_gelu_bwd and slak_linear_wgrad (the parameter gradients of a block's tail: results nothing else of the block's backward
+ * reads) in ONE launch instead of one each: between _begin and _end ON THE CALLING THREAD those calls record their reduction instead of
+ * launching it -- the partial rows stay in the workspace each call was given, so the caller must hand every call in between its OWN
+ * workspace -- and _end launches one kernel that performs all of them, on the stream the calls were given, with the same additions in
+ * the same order (the same bits).  Not nestable; more than eight pending reductions, or a change of stream, launch what is pending. */
+int slak_defer_reductions_begin(void);
+int slak_defer_reductions_end(void);
+
 /* pwconv2's data gradient WITH nn.GELU()'s backward and pwconv1's bias gradient in the same pass (models/SLaK.py:159-160 backwards):
  * dy1[M,N] = round(dz[M,K] . W2[K,N]) * gelu'(y1[M,N]) (bf16, the same bits as slak_linear_nt followed by slak_gelu_backward_bias),
  * dbias[N] = column sums of the rounded dy1 (fp32, fixed order).  wt = W2^T stored [N][K].  The intermediate dact never reaches HBM.

@@ -797,6 +797,7 @@ __global__ __launch_bounds__(1024) void block_tail_reduce1(const float* __restri
 }
 static int reduce_partials(const float* part, float* tmp, float* out0, float* out1, int split, int ntiles, int width, hipStream_t st) {
     (void)tmp;
+    if (reduce_defer_push(0, part, out0, out1, split, ntiles, width, st)) return SLAK_OK;      // (slak_defer_reductions_begin: added later, with others, in one launch)
     hipLaunchKernelGGL(block_tail_reduce1, dim3((unsigned)((width + 31) / 32)), dim3(1024), 0, st, part, out0, out1, split, ntiles, width);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { set_last_hip_error(e); return SLAK_ERR_LAUNCH; }

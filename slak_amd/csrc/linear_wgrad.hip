@@ -269,6 +269,7 @@ int launch_linear_wgrad(const void* x1, const void* x2, float* d, int M, int N1,
     SLAK_LAUNCH_CHECK();
     if (pl.S > 1) {
         const int n4 = N1 * N2 / 4;
+        if (reduce_defer_push(pl.S <= 8 ? 2 : 1, (const float*)ws, d, d, 0, pl.S, n4, st)) return SLAK_OK;      // (slak_defer_reductions_begin)
         if (pl.S <= 8) hipLaunchKernelGGL(linear_wgrad_reduce_few_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, (const float*)ws, d, n4, pl.S, (size_t)n4);
         else hipLaunchKernelGGL(linear_wgrad_reduce_kernel, dim3((unsigned)((n4 + 15) / 16)), dim3(256), 0, st, (const float*)ws, d, n4, pl.S, (size_t)n4);
         SLAK_LAUNCH_CHECK();

@@ -53,6 +53,9 @@ static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; 
     } while (0)
 
 void set_last_hip_error(hipError_t e);
+// reduce_jobs.hip: inside slak_defer_reductions_begin / _end on this thread the fixed-order column sums are recorded (true) instead of launched
+// type 0: block_tail_reduce1(part, out0, out1, split, ntiles, width); 1 / 2: linear_wgrad_reduce(_few)_kernel (width = float4 elements, ntiles = slabs)
+bool reduce_defer_push(int type, const float* part, float* out0, float* out1, int split, int ntiles, int width, hipStream_t st);
 
 // ---- launchers implemented in the .hip files (host side, C++ linkage) -----------------------
 struct ConvDims { int N, C, H, W, kh, kw; };

@@ -44,7 +44,7 @@ Scratch scratch(const Tensor& like, size_t bytes) {
 struct Shape { int N, C, H, W, K, P, M, C4; };
 
 // what the library answers for a block shape, asked once
-struct Plan { bool ok; int rows; size_t ws; bool nt1, nt2, ntd1, ntd2, wg1, wg2, bwd1, gbwd; };
+struct Plan { bool ok; int rows; size_t ws; bool nt1, nt2, ntd1, ntd2, wg1, wg2, bwd1, gbwd; size_t off[5], len[5]; };   // off/len: the backward's deferred-reduction regions behind the common scratch
 const Plan& plan_of(const Shape& s) {
     static std::map<std::vector<int>, Plan> cache;
     const std::vector<int> key = {s.N, s.C, s.H, s.W, s.K, s.C4};
@@ -70,7 +70,17 @@ const Plan& plan_of(const Shape& s) {
     if (p.wg1) ws = std::max(ws, slak_linear_wgrad_workspace_bytes(s.M, s.C4, s.C));
     if (p.wg2) ws = std::max(ws, slak_linear_wgrad_workspace_bytes(s.M, s.C, s.C4));
     if (p.gbwd) ws = std::max(ws, slak_linear_nt_gelu_bwd_workspace_bytes(s.M, s.C4, s.C));
-    p.ws = ws;
+    // backward: the five calls whose final column sums are deferred into one launch keep their partial rows until then: a region each,
+    // behind the scratch the other calls share -- [scale_residual][gelu'][LayerNorm][dW1][dW2]
+    const auto up = [](size_t v) { return (v + 255) / 256 * 256; };
+    const size_t tail = slak_block_tail_workspace_bytes(s.N, s.C, s.P);
+    p.len[0] = tail; p.len[2] = tail;
+    p.len[1] = std::max(slak_gelu_bwd_workspace_bytes(s.M, s.C4), p.gbwd ? slak_linear_nt_gelu_bwd_workspace_bytes(s.M, s.C4, s.C) : (size_t)0);
+    p.len[3] = p.wg1 ? slak_linear_wgrad_workspace_bytes(s.M, s.C4, s.C) : 0;
+    p.len[4] = p.wg2 ? slak_linear_wgrad_workspace_bytes(s.M, s.C, s.C4) : 0;
+    size_t o = up(ws);
+    for (int k = 0; k < 5; ++k) { p.off[k] = o; p.len[k] = up(std::max<size_t>(p.len[k], 256)); o += p.len[k]; }
+    p.ws = o;
     return cache.emplace(key, p).first->second;
 }
 
@@ -178,7 +188,11 @@ std::vector<Tensor> block_backward(const Tensor& x16, const Tensor& wv, const Te
     void* st = stream_of(x16);
     const int dt = SLAK_BF16;
     const Scratch ws = scratch(x16, pl.ws);
+    const auto region = [&](int k) { return Scratch{(char*)ws.p + pl.off[k], pl.len[k]}; };
     const auto f32 = x16.options().dtype(at::kFloat);
+    // the parameter gradients' final column sums (five small launches, each alone on the GPU) are recorded and run as ONE launch at the end
+    struct Deferred { bool on; Deferred() : on(slak_defer_reductions_begin() == SLAK_OK) {} int end() { const bool o = on; on = false; return o ? slak_defer_reductions_end() : SLAK_OK; }
+                      ~Deferred() { if (on) (void)slak_defer_reductions_end(); } } deferred;
     // gamma * + permute + residual
     Tensor dout = (dout_opt.has_value() && dout_opt->defined()) ? dout_opt->contiguous() : at::zeros({s.N, s.C, s.H, s.W}, f32);
     if (dout.scalar_type() != at::kFloat) dout = dout.to(at::kFloat);
@@ -189,7 +203,7 @@ std::vector<Tensor> block_backward(const Tensor& x16, const Tensor& wv, const Te
     const bool has_scale = sample_scale.has_value() && sample_scale->defined();
     check_rc(slak_scale_residual_backward(fp(dout), dout16.defined() ? dout16.data_ptr() : nullptr, dsum.defined() ? fpm(dsum) : nullptr, z.data_ptr(),
                                           fp(gamma), has_scale ? fp(*sample_scale) : nullptr, dz.data_ptr(), fpm(dgamma), fpm(dzc), s.N, s.C, s.P,
-                                          ws.p, ws.n, st), "slak_scale_residual_backward");
+                                          region(0).p, region(0).n, st), "slak_scale_residual_backward");
     Tensor dshortcut = dsum.defined() ? dsum : dout;
     if (shortcut_bf16) dshortcut = dshortcut.to(at::kBFloat16);
     // the MLP's data path: dz -> dact -> (GELU') dy1 (+ pwconv1's bias gradient) -> dt
@@ -198,7 +212,7 @@ std::vector<Tensor> block_backward(const Tensor& x16, const Tensor& wv, const Te
     if (pl.gbwd) {                                                 // stage 1: dz W2, GELU' and pwconv1's bias gradient in one pass
         Tensor w2t = w2b.t().contiguous();
         dy1 = at::empty({s.M, s.C4}, x16.options());
-        check_rc(slak_linear_nt_gelu_bwd(dz2.data_ptr(), w2t.data_ptr(), y1m.data_ptr(), dy1.data_ptr(), fpm(db1), s.M, s.C4, s.C, ws.p, ws.n, st),
+        check_rc(slak_linear_nt_gelu_bwd(dz2.data_ptr(), w2t.data_ptr(), y1m.data_ptr(), dy1.data_ptr(), fpm(db1), s.M, s.C4, s.C, region(1).p, region(1).n, st),
                  "slak_linear_nt_gelu_bwd");
     } else {
     if (pl.ntd1) {
@@ -207,7 +221,7 @@ std::vector<Tensor> block_backward(const Tensor& x16, const Tensor& wv, const Te
         check_rc(slak_linear_nt(dz2.data_ptr(), w2t.data_ptr(), nullptr, dact.data_ptr(), nullptr, s.M, s.C4, s.C, st), "slak_linear_nt");
     } else dact = at::mm(dz2, w2b);
     dy1 = at::empty_like(dact);
-    check_rc(slak_gelu_backward_bias(dact.data_ptr(), y1m.data_ptr(), dy1.data_ptr(), fpm(db1), s.M, s.C4, ws.p, ws.n, st), "slak_gelu_backward_bias");
+    check_rc(slak_gelu_backward_bias(dact.data_ptr(), y1m.data_ptr(), dy1.data_ptr(), fpm(db1), s.M, s.C4, region(1).p, region(1).n, st), "slak_gelu_backward_bias");
     }
     Tensor dt_;
     if (pl.ntd2) {
@@ -218,10 +232,11 @@ std::vector<Tensor> block_backward(const Tensor& x16, const Tensor& wv, const Te
     // permute + LayerNorm
     Tensor ds = at::empty_like(sum), dlnw = at::empty_like(lnw), dlnb = at::empty_like(lnw);
     check_rc(slak_ln_nchw_to_nhwc_backward(dt_.data_ptr(), sum.data_ptr(), fp(lnw), fp(mean), fp(rstd), ds.data_ptr(), fpm(dlnw), fpm(dlnb), s.N, s.C, s.P,
-                                           ws.p, ws.n, st), "slak_ln_nchw_to_nhwc_backward");
+                                           region(2).p, region(2).n, st), "slak_ln_nchw_to_nhwc_backward");
     // the two pointwise weight gradients (single process: in front of the BatchNorm pass, as the Python node launches them)
-    Tensor dw1 = wgrad(dy1, t.view({s.M, s.C}), s.M, s.C4, s.C, pl.wg1, ws, st);
-    Tensor dw2 = wgrad(dz2, a.view({s.M, s.C4}), s.M, s.C, s.C4, pl.wg2, ws, st);
+    Tensor dw1 = wgrad(dy1, t.view({s.M, s.C}), s.M, s.C4, s.C, pl.wg1, region(3), st);
+    Tensor dw2 = wgrad(dz2, a.view({s.M, s.C4}), s.M, s.C, s.C4, pl.wg2, region(4), st);
+    check_rc(deferred.end(), "slak_defer_reductions_end");         // one launch: dgamma, db2 | db1 | dlnw, dlnb | dW1 | dW2
     // branch BatchNorms
     const float* gam[3] = {fp(bn_gamma[0]), fp(bn_gamma[1]), fp(bn_gamma[2])};
     Tensor bcoef = at::empty({s.C * 9}, f32), dgam = at::empty({3, s.C}, f32), dbet = at::empty({3, s.C}, f32);

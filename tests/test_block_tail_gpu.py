@@ -510,3 +510,55 @@ def test_stem_conv_matches_conv2d(N, Ci, Co, H, W, gpu):
     _close(y, yr, 2.0 ** -8 * 1.05, "y")
     _close(cw.grad, cwr.grad, 2.0 ** -7, "dconv_w")
     _close(cb.grad, cbr.grad, 1e-3, "dconv_b")
+
+
+def test_deferred_reductions_run_in_one_launch_with_the_same_bits(gpu):
+    """slak_defer_reductions_begin / _end: the column sums that end slak_gelu_backward_bias, slak_ln_nchw_to_nhwc_backward, slak_scale_residual_backward
+    and slak_linear_wgrad are recorded (each call with its OWN workspace) and performed by ONE launch at _end -- bit for bit what the stand-alone
+    launches give; nothing is written before _end; the switch is per thread, not nestable, and _end without _begin is an error."""
+    from slak_amd import _lib
+    L = _lib.lib()
+    st = torch.cuda.current_stream(gpu).cuda_stream
+    torch.manual_seed(11)
+    N, C, H, W = 8, 96, 28, 28
+    M, C4 = N * H * W, 4 * C
+    dact = torch.randn(M, C4, device=gpu).bfloat16(); y1 = torch.randn(M, C4, device=gpu).bfloat16()
+    g = torch.randn(N, H, W, C, device=gpu).bfloat16(); x = torch.randn(N, C, H, W, device=gpu).bfloat16()
+    lnw = torch.randn(C, device=gpu); mean = torch.randn(N, H * W, device=gpu); rstd = torch.rand(N, H * W, device=gpu) + 0.5
+    dout = torch.randn(N, C, H, W, device=gpu); z = torch.randn(N, H, W, C, device=gpu).bfloat16(); gamma = torch.randn(C, device=gpu)
+    t = torch.randn(M, C, device=gpu).bfloat16()
+    nbs = [int(L.slak_gelu_bwd_workspace_bytes(M, C4)), int(L.slak_block_tail_workspace_bytes(N, C, H * W)), int(L.slak_block_tail_workspace_bytes(N, C, H * W)),
+           int(L.slak_linear_wgrad_workspace_bytes(M, C4, C)), int(L.slak_linear_wgrad_workspace_bytes(M, C, C4))]
+    assert L.slak_linear_wgrad_supported(M, C4, C) and L.slak_linear_wgrad_supported(M, C, C4) and min(nbs[3:]) > 0
+
+    def run(deferred):
+        wss = [torch.empty(max(nb, 256), dtype=torch.uint8, device=gpu) for nb in nbs]
+        out = dict(dy1=torch.empty_like(dact), db1=torch.full((C4,), 7.0, device=gpu), ds=torch.empty_like(x), dlnw=torch.full((C,), 7.0, device=gpu),
+                   dlnb=torch.full((C,), 7.0, device=gpu), dz=torch.empty_like(z), dgamma=torch.full((C,), 7.0, device=gpu), dzc=torch.full((C,), 7.0, device=gpu),
+                   dw1=torch.full((C4, C), 7.0, device=gpu), dw2=torch.full((C, C4), 7.0, device=gpu))
+        if deferred:
+            assert L.slak_defer_reductions_begin() == _lib.OK
+            assert L.slak_defer_reductions_begin() == _lib.ERR_INVALID_ARG             # not nestable
+        _lib.check(L.slak_gelu_backward_bias(dact.data_ptr(), y1.data_ptr(), out["dy1"].data_ptr(), out["db1"].data_ptr(), M, C4, wss[0].data_ptr(), wss[0].numel(), st), "gelu")
+        _lib.check(L.slak_ln_nchw_to_nhwc_backward(g.data_ptr(), x.data_ptr(), lnw.data_ptr(), mean.data_ptr(), rstd.data_ptr(), out["ds"].data_ptr(),
+                                                   out["dlnw"].data_ptr(), out["dlnb"].data_ptr(), N, C, H * W, wss[1].data_ptr(), wss[1].numel(), st), "ln")
+        _lib.check(L.slak_scale_residual_backward(dout.data_ptr(), None, None, z.data_ptr(), gamma.data_ptr(), None, out["dz"].data_ptr(), out["dgamma"].data_ptr(),
+                                                  out["dzc"].data_ptr(), N, C, H * W, wss[2].data_ptr(), wss[2].numel(), st), "sr")
+        _lib.check(L.slak_linear_wgrad(out["dy1"].data_ptr(), t.data_ptr(), out["dw1"].data_ptr(), M, C4, C, wss[3].data_ptr(), wss[3].numel(), st), "dw1")
+        _lib.check(L.slak_linear_wgrad(out["dz"].view(M, C).data_ptr(), dact.data_ptr(), out["dw2"].data_ptr(), M, C, C4, wss[4].data_ptr(), wss[4].numel(), st), "dw2")
+        if deferred:
+            torch.cuda.synchronize()
+            for k in ("db1", "dlnw", "dlnb", "dgamma", "dzc"):                          # nothing has been reduced yet
+                assert bool((out[k] == 7.0).all()), k
+            assert L.slak_defer_reductions_end() == _lib.OK
+        torch.cuda.synchronize()
+        return out
+
+    a, b = run(False), run(True)
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
+        assert not bool((b[k].float() == 7.0).all()), k
+    assert L.slak_defer_reductions_end() == _lib.ERR_INVALID_ARG                       # no _begin on this thread
+    c = run(False)                                                                      # and the switch is off again
+    for k in a:
+        assert torch.equal(a[k], c[k]), k
