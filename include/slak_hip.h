@@ -262,6 +262,14 @@ int slak_linear_nt_supported(int M, int N, int K, int gelu);
 int slak_linear_nt(const void* x_bf16, const void* wt_bf16, const void* bias_bf16 /* or NULL */, void* y_bf16, void* gelu_out_bf16 /* or NULL */,
                    int M, int N, int K, void* stream);
 
+/* pwconv1 -> GELU -> pwconv2 in ONE pass (models/SLaK.py:158-160) where the whole second weight fits a wave's registers: x [M][C], w1 [C4][C],
+ * b1 [C4], w2 [C][C4], b2 [C] (the nn.Linear parameters as stored; biases may be NULL), y1 = x w1^T + b1 and a = GELU(y1) [M][C4] (the backward
+ * needs both: same bits as slak_linear_nt with gelu_out), z = a w2^T + b2 [M][C], all bf16, fp32 accumulate.  a is not read back from HBM and
+ * pwconv2 is not a launch.  Round 4: C = 96, C4 = 384 (stage 1 of SLaK-T / SLaK-S); anything else: SLAK_ERR_UNSUPPORTED (two slak_linear_nt). */
+int slak_linear_mlp_fwd_supported(int M, int C, int C4);
+int slak_linear_mlp_fwd(const void* x_bf16, const void* w1_bf16, const void* b1_bf16, const void* w2_bf16, const void* b2_bf16,
+                        void* y1_bf16, void* a_bf16, void* z_bf16, int M, int C, int C4, void* stream);
+
 /* The fixed-order column sums that end slak_scale_residual_backward, slak_ln_nchw_to_nhwc_backward, slak_gelu_backward_bias,
  * slak_linear_nt_gelu_bwd and slak_linear_wgrad (the parameter gradients of a block's tail: results nothing else of the block's backward
  * reads) in ONE launch instead of one each: between _begin and _end ON THE CALLING THREAD those calls record their reduction instead of

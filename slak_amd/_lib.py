@@ -116,6 +116,8 @@ SIGNATURES = {
     "slak_ln_patch_backward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _sz, _vp]),
     "slak_linear_nt_supported": (_i, [_i, _i, _i, _i]),
     "slak_linear_nt": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    "slak_linear_mlp_fwd_supported": (_i, [_i, _i, _i]),
+    "slak_linear_mlp_fwd": (_i, [_vp] * 8 + [_i, _i, _i, _vp]),
     "slak_defer_reductions_begin": (_i, []),
     "slak_defer_reductions_end": (_i, []),
     "slak_linear_nt_gelu_bwd_supported": (_i, [_i, _i, _i]),

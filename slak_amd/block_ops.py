@@ -885,6 +885,20 @@ def linear_nt(x, wt, bias=None, gelu=False):
 def _mlp_fwd(t, w1, b1, w2, b2):
     F = torch.nn.functional
     w1b, w2b = lowp_param(w1), lowp_param(w2)
+    L = _lib.lib()
+    C, C4 = w1b.shape[1], w1b.shape[0]
+    M = t.numel() // C
+    if use_skinny_linear and t.is_cuda and t.dtype == torch.bfloat16 and t.is_contiguous() and w1b.dtype == torch.bfloat16 and w1b.is_contiguous() and \
+            w2b.is_contiguous() and b1 is not None and b2 is not None and L.slak_linear_mlp_fwd_supported(M, C, C4):
+        # stage 1: pwconv1, GELU and pwconv2 in ONE pass (W2 lives in the waves' registers; a is not read back)
+        y1 = torch.empty(t.shape[:-1] + (C4,), dtype=torch.bfloat16, device=t.device)
+        a = torch.empty_like(y1)
+        z = torch.empty(t.shape[:-1] + (C,), dtype=torch.bfloat16, device=t.device)
+        bb1, bb2 = lowp_param(b1), lowp_param(b2)
+        with _on(t.device):
+            _lib.check(L.slak_linear_mlp_fwd(t.data_ptr(), w1b.data_ptr(), bb1.data_ptr(), w2b.data_ptr(), bb2.data_ptr(), y1.data_ptr(), a.data_ptr(),
+                                             z.data_ptr(), M, C, C4, _stream(t.device)), "slak_linear_mlp_fwd")
+        return z, (t, w1b, y1, a, w2b)
     r = linear_nt(t, w1b, lowp_param(b1), gelu=True)            # pwconv1 + GELU in one streaming pass on the large maps
     if r is not None:
         y1, a = r

@@ -242,6 +242,121 @@ __global__ __launch_bounds__(LK_THREADS, 1) void linear_nt_k96_kernel(const uint
     }
 }
 
+// pwconv1 -> GELU -> pwconv2 of stage 1 in ONE pass (models/SLaK.py:158-160: x = pwconv2(act(pwconv1(x))), C = 96): the k96 kernel above with the
+// second product in its epilogue.  A 32 x 32 tile of a = gelu(y1) leaves the first product as packed bf16 pairs with lane = row, eight
+// k-values per lane and half-wave -- exactly an MFMA B operand of the second product z^T = W2 . a^T if the matching W2 fragment takes its k in
+// the same (permuted) order: lane (row n2, half h) of k-step u of column tile nt holds W2[n2][32 nt + 16 u + 4 h + {0..3, 8..11}].  Those 72
+// fragments are loop invariants: each wave keeps ALL of W2 (96 x 384) in 288 registers -- four waves per workgroup, one per SIMD, 512
+// registers each; LDS holds W1, the biases, the GELU table and the waves' X blocks / out tiles as before.  y1 and a are still written (the
+// backward reads them), but a is not read again and pwconv2 is not a launch: 385 MB and ~110 us less per block.  z differs from the
+// two-launch result by the order in which an MFMA adds its 16 products (the k-permutation): fp32 rounding noise, far below z's bf16 rounding.
+constexpr int LM_WAVES = 4, LM_THREADS = LM_WAVES * 64, LM_NP = 6;   // N1 = 64 LM_NP = 384, N2 = K = 96
+
+__global__ __launch_bounds__(LM_THREADS, 1) void linear_mlp_fwd_k96_kernel(const uint16_t* __restrict__ X, const uint16_t* __restrict__ W1,
+                                                                         const uint16_t* __restrict__ B1, const uint16_t* __restrict__ W2,
+                                                                         const uint16_t* __restrict__ B2, uint16_t* __restrict__ Y1,
+                                                                         uint16_t* __restrict__ A, uint16_t* __restrict__ Z, int M, unsigned x_bytes,
+                                                                         const uint16_t* __restrict__ gelu_table) {
+    constexpr int K = 96, KS = 6, N = 64 * LM_NP, N2 = 96;
+    extern __shared__ __attribute__((aligned(16))) uint16_t lds[];
+    char* const L = (char*)lds;
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, lhi = lane >> 5;
+    const int wave = wave_id_uniform();
+    char* const Lw = L;                                               // [N][LS_XP]
+    const unsigned bias_b = (unsigned)N * LS_XP;                      // [N] bf16 bias of pwconv1, [96] of pwconv2 behind it (1 KB together)
+    const unsigned xbuf = bias_b + 1024u + (unsigned)wave * LS_XBUF;
+    char* const ot = L + bias_b + 1024u + LM_WAVES * LS_XBUF + wave * LK_OBUF;
+    const unsigned lds_base = (unsigned)(uintptr_t)SLAK_LDS(uint16_t, lds);
+    // W2 -> registers (loop invariant), k in the order the a tiles arrive in
+    s16x8 w2f[3][2 * LM_NP][2];
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int nt = 0; nt < 2 * LM_NP; ++nt)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const uint16_t* src = W2 + (size_t)(j * 32 + l31) * N + nt * 32 + 16 * u + 4 * lhi;
+                const u32x2 lo = *(const u32x2*)src, hi = *(const u32x2*)(src + 8);
+                w2f[j][nt][u] = __builtin_bit_cast(s16x8, u32x4{lo[0], lo[1], hi[0], hi[1]});
+            }
+    v4i_t rsrc;
+    {
+        const uint64_t a = (uint64_t)X;
+        rsrc[0] = __builtin_amdgcn_readfirstlane((int)(a & 0xffffffffu)); rsrc[1] = __builtin_amdgcn_readfirstlane((int)((a >> 32) & 0xffffu));
+        rsrc[2] = __builtin_amdgcn_readfirstlane((int)x_bytes); rsrc[3] = 0x00020000;
+    }
+    XDma plan; xdma_plan(plan, lane, K * 2);
+    const int ntiles_m = (M + 31) >> 5, stride = gridDim.x * LM_WAVES;
+    int tm = blockIdx.x * LM_WAVES + wave;
+    if (tm < ntiles_m) xdma_issue(plan, (unsigned)tm * 32u * K * 2u, M - tm * 32, rsrc, lds_base + xbuf);
+    stage_weight(Lw, W1, N, K, LS_XP, tid, LM_THREADS);
+    for (int i = tid; i < N + N2; i += LM_THREADS) ((uint16_t*)(L + bias_b))[i] = i < N ? (B1 ? B1[i] : (uint16_t)0) : (B2 ? B2[i - N] : (uint16_t)0);
+    const uint16_t* const glut = (const uint16_t*)(L + bias_b + 1024u + LM_WAVES * (LS_XBUF + LK_OBUF));
+    for (int i = tid; i < GL_BYTES / 16; i += LM_THREADS) ((u32x4*)glut)[i] = ((const u32x4*)gelu_table)[i];
+    __syncthreads();                                                  // the only workgroup barrier
+    const uint16_t* const lbias = (const uint16_t*)(L + bias_b);
+    constexpr int nst = LM_NP * 8 + 6;                                // store instructions of one row block: y1 and a (4 per pair each), z (2 per 32 columns)
+    int pending = 0;
+    const unsigned wlane = (unsigned)l31 * LS_XP + (unsigned)lhi * 16u;
+    auto lsync = [] { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); };
+    for (; tm < ntiles_m; tm += stride) {
+        wait_vmcnt_dyn(pending);                                      // my block has landed: only the stores issued after its DMA may be outstanding
+        __builtin_amdgcn_wave_barrier();
+        s16x8 xf[KS];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) xf[ks] = __builtin_bit_cast(s16x8, *(const u32x4*)(L + xbuf + wlane + ks * 32));
+        lsync();                                                      // every lane has its fragments: the buffer is free
+        pending = nst;
+        const int tn = tm + stride;
+        if (tn < ntiles_m) xdma_issue(plan, (unsigned)tn * 32u * K * 2u, M - tn * 32, rsrc, lds_base + xbuf);
+        f32x16 zacc[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) zacc[j][i] = 0.f;
+#pragma unroll
+        for (int pr = 0; pr < LM_NP; ++pr) {
+            unsigned py[2][8], pg[2][8];
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const int nt = 2 * pr + half;
+                f32x16 acc;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+                const char* wt = Lw + (size_t)nt * 32 * LS_XP + wlane;
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) acc = mfma32<bf16_t>(__builtin_bit_cast(s16x8, *(const u32x4*)(wt + ks * 32)), xf[ks], acc);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const u32x2 bb = *(const u32x2*)(lbias + nt * 32 + 8 * q + 4 * lhi);
+                    const unsigned y01 = pack2<bf16_t>(acc[4 * q + 0] + bf16_lo(bb[0]), acc[4 * q + 1] + bf16_hi(bb[0]));
+                    const unsigned y23 = pack2<bf16_t>(acc[4 * q + 2] + bf16_lo(bb[1]), acc[4 * q + 3] + bf16_hi(bb[1]));
+                    py[half][2 * q] = y01; py[half][2 * q + 1] = y23;
+                    pg[half][2 * q] = gelu_lut2(glut, y01); pg[half][2 * q + 1] = gelu_lut2(glut, y23);
+                }
+                // second product: this tile's 32 columns of a are 32 of its k
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const s16x8 bf = __builtin_bit_cast(s16x8, u32x4{pg[half][4 * u], pg[half][4 * u + 1], pg[half][4 * u + 2], pg[half][4 * u + 3]});
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) zacc[j] = mfma32<bf16_t>(w2f[j][nt][u], bf, zacc[j]);
+                }
+            }
+            put_tile(ot, py[0], l31, lhi, 0); put_tile(ot, py[1], l31, lhi, 1);
+            lsync();
+            flush_tile(ot, Y1, tm, M, N, pr * 64, lane);
+            lsync();                                                  // the tile has been read
+            put_tile(ot, pg[0], l31, lhi, 0); put_tile(ot, pg[1], l31, lhi, 1);
+            lsync();
+            flush_tile(ot, A, tm, M, N, pr * 64, lane);
+            lsync();
+        }
+        const int row = tm * 32 + l31;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) store_tile<false>(zacc[j], lbias + N, Z, nullptr, (size_t)row * N2, j * 32, lhi, row < M);
+    }
+}
+
 // dz . W2 WITH nn.GELU()'s backward in the epilogue (models/SLaK.py:159-160 backwards): dy1 = round(dz . W2) * gelu'(y1), rounded, and the column
 // sums of dy1 (pwconv1's bias gradient) -- the k96 kernel above, whose output tile (dact, rounded to bf16 as the stand-alone GEMM stores it)
 // meets the stored pre-activation y1 in the flush layout (lane = row lane/8, 16-byte chunk lane%8: full 128-byte lines in both directions)
@@ -502,6 +617,29 @@ int slak_linear_nt(const void* x, const void* wt, const void* bias, void* y, voi
         if (K == 96) SLAK_LS_N96(1) else if (K == 192) SLAK_LS_N96(2) else if (K == 288) SLAK_LS_N96(3) else SLAK_LS_N96(4)
 #undef SLAK_LS_N96
     }
+    SLAK_LAUNCH_CHECK();
+    return SLAK_OK;
+}
+
+/* pwconv1 -> GELU -> pwconv2 in ONE pass (see linear_mlp_fwd_k96_kernel): x [M][96], w1 [384][96], b1 [384], w2 [96][384], b2 [96] -> y1, a [M][384],
+ * z [M][96], all bf16.  y1 and a: the bits of slak_linear_nt(.., gelu_out); z: those of slak_linear_nt(a, w2, b2) up to fp32 summation order. */
+int slak_linear_mlp_fwd_supported(int M, int C, int C4) {
+    static const bool on = [] { const char* e = getenv("SLAK_LINEAR_MLP_FWD"); return !(e && e[0] == '0'); }();
+    return (on && M > 0 && C == 96 && C4 == 64 * LM_NP && (long long)M * C4 * 2 < (1LL << 32)) ? 1 : 0;
+}
+int slak_linear_mlp_fwd(const void* x, const void* w1, const void* b1, const void* w2, const void* b2, void* y1, void* a, void* z, int M, int C, int C4,
+                        void* stream) {
+    if (!x || !w1 || !w2 || !y1 || !a || !z) return SLAK_ERR_INVALID_ARG;
+    if (!slak_linear_mlp_fwd_supported(M, C, C4)) return SLAK_ERR_UNSUPPORTED;
+    const int tiles = (M + 31) / 32;
+    int wk = mfma_cu_count(); if (wk * LM_WAVES > tiles) wk = (tiles + LM_WAVES - 1) / LM_WAVES;
+    const uint16_t* lut = gelu_table_device();
+    if (!lut) return SLAK_ERR_LAUNCH;
+    const size_t lds = (size_t)C4 * LS_XP + 1024 + (size_t)LM_WAVES * (LS_XBUF + LK_OBUF) + GL_BYTES;
+    if (hipFuncSetAttribute((const void*)linear_mlp_fwd_k96_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return SLAK_ERR_LAUNCH;
+    hipLaunchKernelGGL(linear_mlp_fwd_k96_kernel, dim3(wk), dim3(LM_THREADS), lds, (hipStream_t)stream, (const uint16_t*)x, (const uint16_t*)w1,
+                       (const uint16_t*)b1, (const uint16_t*)w2, (const uint16_t*)b2, (uint16_t*)y1, (uint16_t*)a, (uint16_t*)z, M,
+                       (unsigned)((size_t)M * C * 2), lut);
     SLAK_LAUNCH_CHECK();
     return SLAK_OK;
 }

@@ -44,7 +44,7 @@ Scratch scratch(const Tensor& like, size_t bytes) {
 struct Shape { int N, C, H, W, K, P, M, C4; };
 
 // what the library answers for a block shape, asked once
-struct Plan { bool ok; int rows; size_t ws; bool nt1, nt2, ntd1, ntd2, wg1, wg2, bwd1, gbwd; size_t off[5], len[5]; };   // off/len: the backward's deferred-reduction regions behind the common scratch
+struct Plan { bool ok; int rows; size_t ws; bool nt1, nt2, ntd1, ntd2, wg1, wg2, bwd1, gbwd, mlp1; size_t off[5], len[5]; };   // off/len: the backward's deferred-reduction regions behind the common scratch
 const Plan& plan_of(const Shape& s) {
     static std::map<std::vector<int>, Plan> cache;
     const std::vector<int> key = {s.N, s.C, s.H, s.W, s.K, s.C4};
@@ -64,6 +64,7 @@ const Plan& plan_of(const Shape& s) {
     p.wg2 = slak_linear_wgrad_supported(s.M, s.C, s.C4) != 0;      // dW2 = dz^T a
     p.bwd1 = slak_dwconv2d_tri_backward_supported(dt, s.N, s.C, s.H, s.W, s.K) == 1;
     p.gbwd = slak_linear_nt_gelu_bwd_supported(s.M, s.C4, s.C) == 1;
+    p.mlp1 = slak_linear_mlp_fwd_supported(s.M, s.C, s.C4) == 1;
     size_t ws = std::max(wtri, slak_bn3_workspace_bytes(s.N, s.C));
     ws = std::max(ws, slak_block_tail_workspace_bytes(s.N, s.C, s.P));
     ws = std::max(ws, slak_gelu_bwd_workspace_bytes(s.M, s.C4));
@@ -135,6 +136,11 @@ std::vector<Tensor> block_forward(const Tensor& x, const c10::optional<Tensor>& 
              "slak_ln_nchw_to_nhwc_forward");
     // pwconv1 -> GELU -> pwconv2
     Tensor y1m, a, z;
+    if (pl.mlp1) {                                                 // stage 1: pwconv1, GELU and pwconv2 in one pass
+        y1m = at::empty({s.N, s.H, s.W, s.C4}, x16.options()); a = at::empty_like(y1m); z = at::empty({s.N, s.H, s.W, s.C}, x16.options());
+        check_rc(slak_linear_mlp_fwd(t.data_ptr(), w1b.data_ptr(), bb1b.data_ptr(), w2b.data_ptr(), bb2b.data_ptr(), y1m.data_ptr(), a.data_ptr(), z.data_ptr(),
+                                     s.M, s.C, s.C4, st), "slak_linear_mlp_fwd");
+    } else {
     if (pl.nt1) {
         y1m = at::empty({s.N, s.H, s.W, s.C4}, x16.options()); a = at::empty_like(y1m);
         check_rc(slak_linear_nt(t.data_ptr(), w1b.data_ptr(), bb1b.data_ptr(), y1m.data_ptr(), a.data_ptr(), s.M, s.C4, s.C, st), "slak_linear_nt");
@@ -149,6 +155,7 @@ std::vector<Tensor> block_forward(const Tensor& x, const c10::optional<Tensor>& 
         z = at::linear(a, w2b, bb2b);
         if (z.scalar_type() != at::kBFloat16) z = z.to(at::kBFloat16);
         z = z.contiguous();
+    }
     }
     // gamma * + permute + residual (+ the bf16 copy for the next block's convs)
     Tensor out = at::empty({s.N, s.C, s.H, s.W}, stats.options());

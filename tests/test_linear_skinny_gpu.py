@@ -146,3 +146,44 @@ def test_linear_nt_gelu_bwd_declines_what_it_does_not_cover(gpu):
     x = torch.zeros(100, 384, device=gpu, dtype=torch.bfloat16); db = torch.zeros(384, device=gpu)
     rc = L.slak_linear_nt_gelu_bwd(x.data_ptr(), x.data_ptr(), x.data_ptr(), x.data_ptr(), db.data_ptr(), 100, 384, 96, x.data_ptr(), 1 << 20, None)
     assert rc == _lib.ERR_UNSUPPORTED
+
+
+@pytest.mark.parametrize("M", [32, 50, 6272, 40033, 401408])
+def test_linear_mlp_fwd_is_pwconv1_gelu_pwconv2(M, gpu):
+    """slak_linear_mlp_fwd (stage 1: C = 96): y1 and a bit for bit what slak_linear_nt(.., gelu_out) stores (row tails included); z against the
+    fp64 product of the STORED a with w2 (+ b2) within half a bf16 ulp + fp32 accumulation noise, and equal to the two-launch z except where the
+    fp32 sums differ in their last bits (a rare one-ulp flip of the bf16 rounding)."""
+    from slak_amd import _lib
+    L = _lib.lib()
+    C, C4 = 96, 384
+    assert L.slak_linear_mlp_fwd_supported(M, C, C4) == 1
+    torch.manual_seed(M)
+    x = torch.randn(M, C, device=gpu).bfloat16()
+    w1 = (torch.randn(C4, C, device=gpu) * 0.1).bfloat16(); b1 = (torch.randn(C4, device=gpu) * 0.1).bfloat16()
+    w2 = (torch.randn(C, C4, device=gpu) * 0.05).bfloat16(); b2 = (torch.randn(C, device=gpu) * 0.1).bfloat16()
+    st = torch.cuda.current_stream(gpu).cuda_stream
+    y1r = torch.empty(M, C4, device=gpu, dtype=torch.bfloat16); ar = torch.empty_like(y1r); zr = torch.empty(M, C, device=gpu, dtype=torch.bfloat16)
+    _lib.check(L.slak_linear_nt(x.data_ptr(), w1.data_ptr(), b1.data_ptr(), y1r.data_ptr(), ar.data_ptr(), M, C4, C, st), "nt1")
+    _lib.check(L.slak_linear_nt(ar.data_ptr(), w2.data_ptr(), b2.data_ptr(), zr.data_ptr(), None, M, C, C4, st), "nt2")
+    nan = float("nan")
+    y1 = torch.full_like(y1r, nan); a = torch.full_like(ar, nan); z = torch.full_like(zr, nan)
+    _lib.check(L.slak_linear_mlp_fwd(x.data_ptr(), w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr(), y1.data_ptr(), a.data_ptr(), z.data_ptr(),
+                                     M, C, C4, st), "mlp")
+    torch.cuda.synchronize()
+    assert torch.equal(y1, y1r) and torch.equal(a, ar)
+    ref = a.double() @ w2.double().t() + b2.double()
+    err = (z.double() - ref).abs()
+    tol = ref.abs() * 2.0 ** -8 * 1.01 + 1e-4
+    assert bool((err <= tol).all()), float((err / tol).max())
+    differ = (z != zr)
+    assert differ.float().mean().item() < 2e-3
+    assert ((z.double() - zr.double()).abs() <= zr.double().abs() * 2.0 ** -7 + 1e-4).all()      # (one bf16 ulp; fp32 noise where z is ~0)
+
+
+def test_linear_mlp_fwd_declines_what_it_does_not_cover(gpu):
+    from slak_amd import _lib
+    L = _lib.lib()
+    for (M, C, C4) in [(6272, 192, 768), (6272, 128, 512), (6272, 96, 192), (0, 96, 384)]:
+        assert L.slak_linear_mlp_fwd_supported(M, C, C4) == 0
+    x = torch.zeros(64, 768, device=gpu, dtype=torch.bfloat16)
+    assert L.slak_linear_mlp_fwd(x.data_ptr(), x.data_ptr(), None, x.data_ptr(), None, x.data_ptr(), x.data_ptr(), x.data_ptr(), 64, 192, 768, None) == _lib.ERR_UNSUPPORTED
