@@ -70,6 +70,33 @@ __device__ __forceinline__ bool gelu_bwd8_fast(const float* __restrict__ T, cons
     return ok;
 }
 
+// gelu_bwd8_fast in two halves, so that a caller can put the gathers of several chunks in flight before it tests and uses any of them:
+// the eight table values of yv (false: an element outside the table; the values are then meaningless) ...
+__device__ __forceinline__ bool gelu_grad_gather8(const float* __restrict__ T, const uint4& yv, float (&t)[8]) {
+    const unsigned yw[4] = {yv.x, yv.y, yv.z, yv.w};
+    bool ok = true;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const unsigned i0 = (yw[k] & 0x7fffu) - GD_LO, i1 = ((yw[k] >> 16) & 0x7fffu) - GD_LO;
+        ok = ok && i0 < GD_N && i1 < GD_N;
+        const unsigned a0 = (i0 < GD_N ? i0 : 0u) + ((yw[k] >> 15) & 1u) * GD_N, a1 = (i1 < GD_N ? i1 : 0u) + (yw[k] >> 31) * GD_N;
+        t[2 * k] = T[a0]; t[2 * k + 1] = T[a1];
+    }
+    return ok;
+}
+// ... and the products, their rounding and the column sums of the ROUNDED values (the same operations in the same order as gelu_bwd8_fast)
+__device__ __forceinline__ void gelu_bwd8_apply(const uint4& gv, const float (&t)[8], uint4& ov, float (&acc)[8]) {
+    const unsigned gw[4] = {gv.x, gv.y, gv.z, gv.w};
+    unsigned ow[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float o0 = __uint_as_float(gw[k] << 16) * t[2 * k], o1 = __uint_as_float(gw[k] & 0xffff0000u) * t[2 * k + 1];
+        ow[k] = gg_pack2(o0, o1);
+        acc[2 * k] += __uint_as_float(ow[k] << 16); acc[2 * k + 1] += __uint_as_float(ow[k] & 0xffff0000u);
+    }
+    ov = uint4{ow[0], ow[1], ow[2], ow[3]};
+}
+
 // the table of gelu_grad_lut in device memory (one copy per device, built on first use; block_tail.hip)
 const float* gelu_grad_table_device();
 // column sums of part[ntiles][width] -> out[width] in one launch, fixed order (block_tail.hip: block_tail_reduce1)

@@ -67,6 +67,27 @@ __device__ __forceinline__ unsigned gelu_lut2(const uint16_t* __restrict__ T, un
         return (unsigned)T[il + (lo >> 15) * GL_N] | ((unsigned)T[ih + (hi >> 15) * GL_N] << 16);
     return gelu_lut(T, lo) | (gelu_lut(T, hi) << 16);
 }
+// eight pairs at once: ONE wave-uniform range test and sixteen gathers in flight together (pair by pair, every pair's two gathers sit behind their
+// own branch and expose a full LDS latency: 96 of them per 32 x 384 block were a third of the fused kernels' time)
+__device__ __forceinline__ void gelu_lut2x8(const uint16_t* __restrict__ T, const unsigned (&y)[8], unsigned (&g)[8]) {
+    unsigned il[8], ih[8];
+    bool out = false;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        il[k] = (y[k] & 0x7fffu) - GL_LO; ih[k] = ((y[k] >> 16) & 0x7fffu) - GL_LO;
+        out = out || il[k] >= GL_N || ih[k] >= GL_N;
+    }
+    if (__builtin_amdgcn_ballot_w64(out) == 0) {                     // (wave-uniform) everything inside the table
+        unsigned lo[8], hi[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { lo[k] = T[il[k] + ((y[k] >> 15) & 1u) * GL_N]; hi[k] = T[ih[k] + (y[k] >> 31) * GL_N]; }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) g[k] = lo[k] | (hi[k] << 16);
+    } else {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) g[k] = gelu_lut(T, y[k] & 0xffffu) | (gelu_lut(T, y[k] >> 16) << 16);
+    }
+}
 __device__ __forceinline__ float bf16_lo(unsigned v) { return __uint_as_float(v << 16); }
 __device__ __forceinline__ float bf16_hi(unsigned v) { return __uint_as_float(v & 0xffff0000u); }
 
@@ -225,8 +246,8 @@ __global__ __launch_bounds__(LK_THREADS, 1) void linear_nt_k96_kernel(const uint
                     const unsigned y01 = pack2<bf16_t>(acc[4 * q + 0] + bf16_lo(bb[0]), acc[4 * q + 1] + bf16_hi(bb[0]));
                     const unsigned y23 = pack2<bf16_t>(acc[4 * q + 2] + bf16_lo(bb[1]), acc[4 * q + 3] + bf16_hi(bb[1]));
                     py[half][2 * q] = y01; py[half][2 * q + 1] = y23;
-                    if constexpr (GELU) { pg[half][2 * q] = gelu_lut2(glut, y01); pg[half][2 * q + 1] = gelu_lut2(glut, y23); }
                 }
+                if constexpr (GELU) gelu_lut2x8(glut, py[half], pg[half]);
             }
             put_tile(ot, py[0], l31, lhi, 0); put_tile(ot, py[1], l31, lhi, 1);
             lsync();
@@ -265,7 +286,8 @@ __global__ __launch_bounds__(LM_THREADS, 1) void linear_mlp_fwd_k96_kernel(const
     char* const Lw = L;                                               // [N][LS_XP]
     const unsigned bias_b = (unsigned)N * LS_XP;                      // [N] bf16 bias of pwconv1, [96] of pwconv2 behind it (1 KB together)
     const unsigned xbuf = bias_b + 1024u + (unsigned)wave * LS_XBUF;
-    char* const ot = L + bias_b + 1024u + LM_WAVES * LS_XBUF + wave * LK_OBUF;
+    char* const ot = L + bias_b + 1024u + LM_WAVES * LS_XBUF + wave * 2 * LK_OBUF;      // two out tiles: y1's and a's 32 x 64 block
+    char* const og = ot + LK_OBUF;
     const unsigned lds_base = (unsigned)(uintptr_t)SLAK_LDS(uint16_t, lds);
     // W2 -> registers (loop invariant), k in the order the a tiles arrive in
     s16x8 w2f[3][2 * LM_NP][2];
@@ -291,7 +313,7 @@ __global__ __launch_bounds__(LM_THREADS, 1) void linear_mlp_fwd_k96_kernel(const
     if (tm < ntiles_m) xdma_issue(plan, (unsigned)tm * 32u * K * 2u, M - tm * 32, rsrc, lds_base + xbuf);
     stage_weight(Lw, W1, N, K, LS_XP, tid, LM_THREADS);
     for (int i = tid; i < N + N2; i += LM_THREADS) ((uint16_t*)(L + bias_b))[i] = i < N ? (B1 ? B1[i] : (uint16_t)0) : (B2 ? B2[i - N] : (uint16_t)0);
-    const uint16_t* const glut = (const uint16_t*)(L + bias_b + 1024u + LM_WAVES * (LS_XBUF + LK_OBUF));
+    const uint16_t* const glut = (const uint16_t*)(L + bias_b + 1024u + LM_WAVES * (LS_XBUF + 2 * LK_OBUF));
     for (int i = tid; i < GL_BYTES / 16; i += LM_THREADS) ((u32x4*)glut)[i] = ((const u32x4*)gelu_table)[i];
     __syncthreads();                                                  // the only workgroup barrier
     const uint16_t* const lbias = (const uint16_t*)(L + bias_b);
@@ -332,8 +354,8 @@ __global__ __launch_bounds__(LM_THREADS, 1) void linear_mlp_fwd_k96_kernel(const
                     const unsigned y01 = pack2<bf16_t>(acc[4 * q + 0] + bf16_lo(bb[0]), acc[4 * q + 1] + bf16_hi(bb[0]));
                     const unsigned y23 = pack2<bf16_t>(acc[4 * q + 2] + bf16_lo(bb[1]), acc[4 * q + 3] + bf16_hi(bb[1]));
                     py[half][2 * q] = y01; py[half][2 * q + 1] = y23;
-                    pg[half][2 * q] = gelu_lut2(glut, y01); pg[half][2 * q + 1] = gelu_lut2(glut, y23);
                 }
+                gelu_lut2x8(glut, py[half], pg[half]);
                 // second product: this tile's 32 columns of a are 32 of its k
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
@@ -342,14 +364,12 @@ __global__ __launch_bounds__(LM_THREADS, 1) void linear_mlp_fwd_k96_kernel(const
                     for (int j = 0; j < 3; ++j) zacc[j] = mfma32<bf16_t>(w2f[j][nt][u], bf, zacc[j]);
                 }
             }
+            lsync();                                                  // the previous pair's tiles have been read (a wait hidden behind the MFMAs above)
             put_tile(ot, py[0], l31, lhi, 0); put_tile(ot, py[1], l31, lhi, 1);
+            put_tile(og, pg[0], l31, lhi, 0); put_tile(og, pg[1], l31, lhi, 1);
             lsync();
             flush_tile(ot, Y1, tm, M, N, pr * 64, lane);
-            lsync();                                                  // the tile has been read
-            put_tile(ot, pg[0], l31, lhi, 0); put_tile(ot, pg[1], l31, lhi, 1);
-            lsync();
-            flush_tile(ot, A, tm, M, N, pr * 64, lane);
-            lsync();
+            flush_tile(og, A, tm, M, N, pr * 64, lane);
         }
         const int row = tm * 32 + l31;
 #pragma unroll
@@ -445,23 +465,32 @@ __global__ __launch_bounds__(LG_THREADS, 1) void linear_nt_k96_gbwd_kernel(const
             }
             put_tile(ot, py[0], l31, lhi, 0); put_tile(ot, py[1], l31, lhi, 1);
             lsync();
+            // the pair's four 8-element chunks with ONE wave-uniform range test: 32 table gathers in flight together
+            uint4 gq[4], vq[4];
+            bool ok = true;
+            float a2[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) a2[k] = acc[pr][k];
 #pragma unroll
             for (int it = 0; it < 4; ++it) {
                 const u32x4 g4 = *(const u32x4*)(ot + (it * 8 + fr) * LK_OP + fc * 16);
-                const uint4 g = uint4{g4[0], g4[1], g4[2], g4[3]}, y = uint4{cur[pr][it][0], cur[pr][it][1], cur[pr][it][2], cur[pr][it][3]};
-                float a2[8];
-#pragma unroll
-                for (int k = 0; k < 8; ++k) a2[k] = acc[pr][k];
-                uint4 v;
-                const bool ok = gelu_bwd8_fast(T, g, y, v, a2);
-                if (__builtin_amdgcn_ballot_w64(!ok) != 0ull) {       // (wave-uniform, rare) an element outside the table: the general evaluation
-                    gelu_bwd8(T, g, y, v, acc[pr]);
-                } else {
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) acc[pr][k] = a2[k];
-                }
-                __builtin_amdgcn_raw_buffer_store_b128(u32x4{v.x, v.y, v.z, v.w}, rd, g0 + (unsigned)(it * 8 * N * 2), pr * 128, 0);
+                gq[it] = uint4{g4[0], g4[1], g4[2], g4[3]};
             }
+            float tq[4][8];
+#pragma unroll
+            for (int it = 0; it < 4; ++it) ok = gelu_grad_gather8(T, uint4{cur[pr][it][0], cur[pr][it][1], cur[pr][it][2], cur[pr][it][3]}, tq[it]) && ok;
+            if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) {
+#pragma unroll
+                for (int it = 0; it < 4; ++it) gelu_bwd8_apply(gq[it], tq[it], vq[it], a2);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) acc[pr][k] = a2[k];
+            } else {                                                  // (wave-uniform, rare) an element outside the table: the general evaluation
+#pragma unroll
+                for (int it = 0; it < 4; ++it) gelu_bwd8(T, gq[it], uint4{cur[pr][it][0], cur[pr][it][1], cur[pr][it][2], cur[pr][it][3]}, vq[it], acc[pr]);
+            }
+#pragma unroll
+            for (int it = 0; it < 4; ++it)
+                __builtin_amdgcn_raw_buffer_store_b128(u32x4{vq[it].x, vq[it].y, vq[it].z, vq[it].w}, rd, g0 + (unsigned)(it * 8 * N * 2), pr * 128, 0);
             lsync();
         }
         // the next block's y1 becomes the current one (96 register moves: ~4 % of a block; the compiler's wait in front of them counts the
@@ -635,7 +664,7 @@ int slak_linear_mlp_fwd(const void* x, const void* w1, const void* b1, const voi
     int wk = mfma_cu_count(); if (wk * LM_WAVES > tiles) wk = (tiles + LM_WAVES - 1) / LM_WAVES;
     const uint16_t* lut = gelu_table_device();
     if (!lut) return SLAK_ERR_LAUNCH;
-    const size_t lds = (size_t)C4 * LS_XP + 1024 + (size_t)LM_WAVES * (LS_XBUF + LK_OBUF) + GL_BYTES;
+    const size_t lds = (size_t)C4 * LS_XP + 1024 + (size_t)LM_WAVES * (LS_XBUF + 2 * LK_OBUF) + GL_BYTES;
     if (hipFuncSetAttribute((const void*)linear_mlp_fwd_k96_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return SLAK_ERR_LAUNCH;
     hipLaunchKernelGGL(linear_mlp_fwd_k96_kernel, dim3(wk), dim3(LM_THREADS), lds, (hipStream_t)stream, (const uint16_t*)x, (const uint16_t*)w1,
                        (const uint16_t*)b1, (const uint16_t*)w2, (const uint16_t*)b2, (uint16_t*)y1, (uint16_t*)a, (uint16_t*)z, M,
