@@ -627,6 +627,7 @@ def main():
                    "dwconv_dtype": ("fp32" + (" on the bf16 matrix cores (two-term split, three MFMAs per product)"
                                               if (a.fp32_matrix_cores or os.environ.get("SLAK_FP32_AUTOCAST_SPLIT", "0") == "1") else " (exact VALU kernels)")) if a.fp32_dwconv else "bf16 in/out, fp32 accumulate", "optimizer": "torch AdamW(fused)" if a.torch_adamw else "slak_amd MaskedAdamW (update + mask + bf16 copies, one launch)",
                    "model_ema": bool(a.model_ema), "one_autograd_node_per_block": bool(M.Block.fused_block),
+                   "block_runner": bool(M.Block.fused_block and block_ops._runner() is not None and not distributed),   # the blocks' call sequences issued from C++ (single process; SyncBN runs the Python sequence)
                    "sync_bn": True, "block_tail": "hip (ln_nchw_to_nhwc + scale_residual)" if M.Block.fused_tail else "pytorch ops",
                    "branch_bn": "hip (bn3: one stats pass + one apply pass)" if M.ReparamLargeKernelConv.fused_bn else "pytorch (Sync)BatchNorm x3 + adds",
                    "pointwise_gemm": "hipBLASLt via torch" + (", TunableOp solutions from slak_amd/tuning/tunableop_gfx950.csv" if TUNED_GEMMS else ""),
