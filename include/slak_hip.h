@@ -275,7 +275,8 @@ int slak_linear_mlp_fwd(const void* x_bf16, const void* w1_bf16, const void* b1_
  * reads) in ONE launch instead of one each: between _begin and _end ON THE CALLING THREAD those calls record their reduction instead of
  * launching it -- the partial rows stay in the workspace each call was given, so the caller must hand every call in between its OWN
  * workspace -- and _end launches one kernel that performs all of them, on the stream the calls were given, with the same additions in
- * the same order (the same bits).  Not nestable; more than eight pending reductions, or a change of stream, launch what is pending. */
+ * the same order (the same bits).  Not nestable; a ninth pending reduction launches the eight before it; a call on ANOTHER stream than the
+ * first recorded one is not deferred (its reduction launches at once on its own stream). */
 int slak_defer_reductions_begin(void);
 int slak_defer_reductions_end(void);
 

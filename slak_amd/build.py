@@ -93,7 +93,7 @@ def build_pybind(force: bool = False, verbose: bool = False, name: str = None, s
            "-D_GLIBCXX_USE_CXX11_ABI=%d" % int(torch._C._GLIBCXX_USE_CXX11_ABI)]
     for inc in ce.include_paths("cuda") + [sysconfig.get_paths()["include"]]:
         cmd += ["-isystem", inc]
-    cmd += ["-L" + tlib, "-L" + LIBDIR, "-lslak_hip", "-lc10", "-lc10_hip", "-ltorch_cpu", "-ltorch", "-ltorch_hip", "-ltorch_python",
+    cmd += ["-L" + tlib, "-L" + LIBDIR, "-L/opt/rocm/lib", "-lslak_hip", "-lamdhip64", "-lc10", "-lc10_hip", "-ltorch_cpu", "-ltorch", "-ltorch_hip", "-ltorch_python",
             "-Wl,-rpath,$ORIGIN", "-Wl,-rpath," + tlib]
     if verbose:
         print(" ".join(cmd))

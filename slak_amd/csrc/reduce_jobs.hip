@@ -100,9 +100,7 @@ static int defer_flush() {
 bool reduce_defer_push(int type, const float* part, float* out0, float* out1, int split, int ntiles, int width, hipStream_t st) {
     DeferState& d = g_defer;
     if (!d.on) return false;
-    if (d.have_stream && st != d.st) {                           // one launch = one stream: what was recorded goes first
-        const int rc = defer_flush(); if (rc != SLAK_OK) d.rc = rc;
-    }
+    if (d.have_stream && st != d.st) return false;               // one launch = one stream (the first recorded call's): work on another stream reduces at once
     d.st = st; d.have_stream = true;
     if (d.jobs.n == RJ_MAX) { const int rc = defer_flush(); if (rc != SLAK_OK) d.rc = rc; }
     ReduceJob& J = d.jobs.j[d.jobs.n++];

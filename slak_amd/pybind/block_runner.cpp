@@ -10,6 +10,7 @@
 #include <torch/extension.h>
 #include <c10/hip/HIPGuard.h>
 #include <c10/hip/HIPStream.h>
+#include <hip/hip_runtime_api.h>
 
 #include <algorithm>
 #include <map>
@@ -39,6 +40,22 @@ Scratch scratch(const Tensor& like, size_t bytes) {
         return {t.data_ptr(), (size_t)t.numel()};
     }
     return {it->second.data_ptr(), (size_t)it->second.numel()};
+}
+
+// A second stream per device for work of a block's backward that nothing else in the block waits for (the two pointwise weight gradients:
+// matrix-core bound at ~0.3 of their peak, little HBM traffic) beside the HBM-bound passes of the main stream.  OFF by default
+// (SLAK_WGRAD_SIDE_STREAM=1 turns it on): measured 16.45-16.57 ms per SLaK-T step with it against 16.59-16.63 without in two interleaved pairs on
+// one box -- inside the noise -- for 0.6-1 ms more host time per step (two event records and two stream waits per block).
+struct Side { hipStream_t st = nullptr; hipEvent_t fork = nullptr, join = nullptr; bool ok = false; };
+Side& side_of(int dev) {
+    static std::map<int, Side> m;
+    auto it = m.find(dev);
+    if (it != m.end()) return it->second;
+    Side s;
+    static const bool on = [] { const char* e = getenv("SLAK_WGRAD_SIDE_STREAM"); return e && e[0] == '1'; }();
+    if (on && hipStreamCreateWithFlags(&s.st, hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&s.fork, hipEventDisableTiming) == hipSuccess &&
+        hipEventCreateWithFlags(&s.join, hipEventDisableTiming) == hipSuccess) s.ok = true;
+    return m.emplace(dev, s).first->second;
 }
 
 struct Shape { int N, C, H, W, K, P, M, C4; };
@@ -241,8 +258,14 @@ std::vector<Tensor> block_backward(const Tensor& x16, const Tensor& wv, const Te
     check_rc(slak_ln_nchw_to_nhwc_backward(dt_.data_ptr(), sum.data_ptr(), fp(lnw), fp(mean), fp(rstd), ds.data_ptr(), fpm(dlnw), fpm(dlnb), s.N, s.C, s.P,
                                            region(2).p, region(2).n, st), "slak_ln_nchw_to_nhwc_backward");
     // the two pointwise weight gradients (single process: in front of the BatchNorm pass, as the Python node launches them)
-    Tensor dw1 = wgrad(dy1, t.view({s.M, s.C}), s.M, s.C4, s.C, pl.wg1, region(3), st);
-    Tensor dw2 = wgrad(dz2, a.view({s.M, s.C4}), s.M, s.C, s.C4, pl.wg2, region(4), st);
+    // (with both on the library's kernel: on the side stream, joined at the end of this function -- their operands are complete on the main
+    // stream at the fork, their outputs, operands and workspace regions are not touched by the main stream before the join)
+    Side& sd = side_of(x16.get_device());
+    const bool forked = sd.ok && pl.wg1 && pl.wg2 && hipEventRecord(sd.fork, (hipStream_t)st) == hipSuccess && hipStreamWaitEvent(sd.st, sd.fork, 0) == hipSuccess;
+    void* wst = forked ? (void*)sd.st : st;
+    Tensor dw1 = wgrad(dy1, t.view({s.M, s.C}), s.M, s.C4, s.C, pl.wg1, region(3), wst);
+    Tensor dw2 = wgrad(dz2, a.view({s.M, s.C4}), s.M, s.C, s.C4, pl.wg2, region(4), wst);
+    struct Join { Side* sd; void* st; bool on; ~Join() { if (on && hipEventRecord(sd->join, sd->st) == hipSuccess) (void)hipStreamWaitEvent((hipStream_t)st, sd->join, 0); } } join{&sd, st, forked};
     check_rc(deferred.end(), "slak_defer_reductions_end");         // one launch: dgamma, db2 | db1 | dlnw, dlnb | dW1 | dW2
     // branch BatchNorms
     const float* gam[3] = {fp(bn_gamma[0]), fp(bn_gamma[1]), fp(bn_gamma[2])};
