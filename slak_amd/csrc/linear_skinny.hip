@@ -364,10 +364,11 @@ __global__ __launch_bounds__(LM_THREADS, 1) void linear_mlp_fwd_k96_kernel(const
                     for (int j = 0; j < 3; ++j) zacc[j] = mfma32<bf16_t>(w2f[j][nt][u], bf, zacc[j]);
                 }
             }
-            lsync();                                                  // the previous pair's tiles have been read (a wait hidden behind the MFMAs above)
+            // (no waits around the tiles: a wave's LDS operations execute in program order, so the flush reads below see these writes and the
+            // next pair's writes come after them; the compiler keeps that order -- same base pointer -- and is otherwise free to run the next
+            // pair's MFMAs under this pair's epilogue.  With a wait on either side the wave, alone on its SIMD, idled through every LDS round trip.)
             put_tile(ot, py[0], l31, lhi, 0); put_tile(ot, py[1], l31, lhi, 1);
             put_tile(og, pg[0], l31, lhi, 0); put_tile(og, pg[1], l31, lhi, 1);
-            lsync();
             flush_tile(ot, Y1, tm, M, N, pr * 64, lane);
             flush_tile(og, A, tm, M, N, pr * 64, lane);
         }
