@@ -97,14 +97,16 @@ def test_bf16_mirror_stays_within_the_bf16_tolerance_of_the_reference_model(fuse
         logits, grads, running, ev = _run(m, g, gpu, autocast=True)
     finally:
         _set_fused(False)
-    # north star: 1e-2 per bf16 op; this is a chain of 5 blocks (15 dw convs, 10 GEMMs, 17 normalisations) compared end to end
-    assert _rel(logits, g["logits_train"]) <= 3e-2
-    assert _rel(ev, g["logits_eval"]) <= 3e-2
+    # north star: 1e-2 per bf16 op.  This is a chain of 5 blocks (15 dw convs, 10 GEMMs, 17 normalisations) compared END TO END with the reference
+    # model's fp64 run, and it still meets the per-op figure on the logits (measured on MI355X: 0.0037-0.0043 train, 0.0040-0.0061 eval; running
+    # statistics 0.009; worst parameter gradient 0.022, median 0.006) -- the bounds below are those with a factor ~2 for other seeds of the silicon
+    assert _rel(logits, g["logits_train"]) <= 1e-2
+    assert _rel(ev, g["logits_eval"]) <= 1e-2
     for k, v in running.items():
-        assert _rel(v, g["state1/" + k]) <= 2e-2, k
+        assert _rel(v, g["state1/" + k]) <= 1.5e-2, k
     errs = sorted(((_rel(v, g["grad/" + n]), n) for n, v in grads.items()), reverse=True)
-    assert errs[0][0] <= 8e-2, errs[:5]
-    assert np.median([e for e, _ in errs]) <= 2e-2
+    assert errs[0][0] <= 4e-2, errs[:5]
+    assert np.median([e for e, _ in errs]) <= 1e-2
 
 
 def test_one_autograd_node_per_block_reproduces_the_four_node_block_bit_for_bit(gpu):
