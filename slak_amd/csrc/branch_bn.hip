@@ -37,6 +37,7 @@ __device__ __forceinline__ float bn_seg_sum(float v, int lpr) {
 static inline int bn_lpr(int P) { int n = (P + 7) / 8, l = 1; while (l < n && l < 64) l <<= 1; return l; }
 
 // 8 consecutive bf16 of a row; zeros beyond P.  mode 2: rows 16-byte aligned (P % 8 == 0), 1: 8-byte aligned (P % 4 == 0), 0: scalar
+struct __attribute__((packed, aligned(2))) bn_u4_a2 { unsigned x, y, z, w; };      // sixteen bytes at a 2-byte aligned address: one (split) access
 __device__ __forceinline__ void unpack2(unsigned u, float& a, float& b) { a = bnf((uint16_t)(u & 0xffff)); b = bnf((uint16_t)(u >> 16)); }
 __device__ __forceinline__ void load8(const uint16_t* __restrict__ row, int p, int P, int mode, float (&v)[8]) {
     if (mode == 2 && p + 8 <= P) {
@@ -50,8 +51,7 @@ __device__ __forceinline__ void load8(const uint16_t* __restrict__ row, int p, i
     } else if (p + 8 <= P) {
         // rows at 2-byte alignment (P odd: the 7 x 7 stage): ONE 16-byte access at a 2-byte aligned address (the hardware splits it: ~3x the cost of
         // an aligned one) instead of eight 2-byte ones (1.75 TB/s; the whole bn3 backward of a 7 x 7 block took 60 us for 106 MB)
-        typedef uint4 __attribute__((aligned(2))) uint4_a2;
-        const uint4 u = *(const uint4_a2*)(row + p);
+        const bn_u4_a2 u = *(const bn_u4_a2*)(row + p);
         unpack2(u.x, v[0], v[1]); unpack2(u.y, v[2], v[3]); unpack2(u.z, v[4], v[5]); unpack2(u.w, v[6], v[7]);
     } else {
 #pragma unroll
@@ -66,9 +66,8 @@ __device__ __forceinline__ void store8(uint16_t* __restrict__ row, int p, int P,
         if (p + 4 <= P) *(uint2*)(row + p) = uint2{bn_pack2(v[0], v[1]), bn_pack2(v[2], v[3])};
         if (p + 8 <= P) *(uint2*)(row + p + 4) = uint2{bn_pack2(v[4], v[5]), bn_pack2(v[6], v[7])};
     } else if (p + 8 <= P) {
-        typedef uint4 __attribute__((aligned(2))) uint4_a2;
-        uint4 u; u.x = bn_pack2(v[0], v[1]); u.y = bn_pack2(v[2], v[3]); u.z = bn_pack2(v[4], v[5]); u.w = bn_pack2(v[6], v[7]);
-        *(uint4_a2*)(row + p) = u;
+        bn_u4_a2 u; u.x = bn_pack2(v[0], v[1]); u.y = bn_pack2(v[2], v[3]); u.z = bn_pack2(v[4], v[5]); u.w = bn_pack2(v[6], v[7]);
+        *(bn_u4_a2*)(row + p) = u;
     } else {
 #pragma unroll
         for (int e = 0; e < 8; ++e) if (p + e < P) row[p + e] = (uint16_t)(bn_pack2(v[e], 0.f) & 0xffffu);
