@@ -430,3 +430,22 @@ def test_tri_launches_at_bench_shapes(N, C, H, W, K, gpu):
     if dws is not None:
         for dw, dy, (kh, kw) in zip(dws, dys, ((K, 5), (5, K), (5, 5))):
             _check_dw(dw[ch], oracle.dwconv2d_bwd_filter(_r(dy[:, ch], dtype), xr, kh, kw), N * H * W, "dw %dx%d" % (kh, kw))
+
+
+def test_tri_backward_in_one_launch_on_random_shapes(gpu):
+    """Forty seeded random shapes of the 14 x 14 class (1..40 images, 1..13 channels, 4..14 rows, even widths 8..14, odd K 7..63): the one-launch backward
+    reproduces the data-gradient launch and the weight-gradient launch bit for bit."""
+    import random
+    rnd = random.Random(20260927)
+    for _ in range(40):
+        N, C, H, W, K = rnd.randint(1, 40), rnd.randint(1, 13), rnd.randint(4, 14), 2 * rnd.randint(4, 7), 2 * rnd.randint(3, 31) + 1
+        torch.manual_seed(N * 1000 + C * 100 + H + W + K)
+        x = torch.randn(N, C, H, W, device=gpu).bfloat16()
+        dys = [torch.randn(N, C, H, W, device=gpu).bfloat16() for _ in range(3)]
+        ws = _filters(C, K, gpu, K + N)
+        got = _tri_bwd(dys, x, ws, K)
+        assert got is not None, (N, C, H, W, K)
+        dx, dws = got
+        assert torch.equal(dx, _tri_dgrad(dys, ws, K)), (N, C, H, W, K)
+        for a, b in zip(dws, _tri_wgrad(dys, x, K)):
+            assert torch.equal(a, b), (N, C, H, W, K)
