@@ -1,4 +1,4 @@
-"""Event-timed slak_linear_nt with N = 96 (pwconv2 forward / dy1 . W1 at stage 1 of SLaK-T: M = 128*56*56, K = 384).  SLAK_LINEAR_N96_DB=0: one X buffer per wave."""
+"""Event-timed slak_linear_nt with N = 96 (pwconv2 forward / dy1 . W1 at stage 1 of SLaK-T: M = 128*56*56, K = 384)."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
