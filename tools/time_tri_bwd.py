@@ -8,7 +8,7 @@ def main():
     dev = torch.device("cuda:0")
     L = _lib.lib()
     st = torch.cuda.current_stream().cuda_stream
-    for (N, C, H, W, K) in [(128, 384, 14, 14, 47), (128, 512, 14, 14, 47), (64, 384, 24 // 2, 12, 61)]:
+    for (N, C, H, W, K) in [(128, 384, 14, 14, 47), (128, 512, 14, 14, 47), (64, 384, 24 // 2, 12, 61), (128, 768, 7, 7, 13), (64, 1024, 7, 7, 13)]:
         x = torch.randn(N, C, H, W, device=dev).bfloat16()
         dys = [torch.randn(N, C, H, W, device=dev).bfloat16() for _ in range(3)]
         ws = [torch.randn(C, 1, kh, kw, device=dev) * 0.05 for kh, kw in ((K, 5), (5, K), (5, 5))]
