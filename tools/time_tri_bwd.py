@@ -26,7 +26,10 @@ def main():
             rc = L.slak_dwconv2d_tri_backward(dys[0].data_ptr(), dys[1].data_ptr(), dys[2].data_ptr(), x.data_ptr(), ws[0].data_ptr(), ws[1].data_ptr(), ws[2].data_ptr(),
                                               dx.data_ptr(), dws[0].data_ptr(), dws[1].data_ptr(), dws[2].data_ptr(), _lib.SLAK_BF16, N, C, H, W, K, wsb.data_ptr(), nb, st)
             assert rc == 0, rc
+        have_one = L.slak_dwconv2d_tri_backward_supported(_lib.SLAK_BF16, N, C, H, W, K) == 1
         for name, fn in (("two launches", two), ("one launch", one), ("two launches", two), ("one launch", one)):
+            if fn is one and not have_one:
+                continue
             for _ in range(3):
                 fn()
             for _ in range(20):
