@@ -13,6 +13,11 @@ otherwise, so ``-m gpu`` tests run the UNMODIFIED reference modules on top of ``
 
 What the modules need and this image lacks is supplied at the import boundary only, exactly as tests/golden/make_golden.py does
 for the fixtures: ``timm.models.layers.{trunc_normal_, DropPath}`` and ``timm.models.registry.register_model``.
+
+Round 5: the reference's step loop itself -- ``engine.py`` (``train_one_epoch``) and the ``utils.py`` it imports --
+are loaded the same way (``load_engine``).  Their import boundary: ``torch._six.inf`` (removed from torch 2.x; == ``math.inf``),
+``tensorboardX.SummaryWriter`` (never instantiated: log_writer=None), ``timm.data.Mixup`` / ``timm.utils.{accuracy, ModelEma,
+get_state_dict}`` (type annotations and the evaluate() helper; timm1/utils/metrics.py:25-32 restated for ``accuracy``).
 """
 import importlib.machinery
 import importlib.util
@@ -28,6 +33,8 @@ SOURCES = {
     "depthwise_conv2d_implicit_gemm": os.path.join(REF, "cutlass", "examples", "19_large_depthwise_conv2d_torch_extension",
                                                    "depthwise_conv2d_implicit_gemm.py"),
     "reference_models_SLaK": os.path.join(REF, "models", "SLaK.py"),
+    "reference_engine": os.path.join(REF, "engine.py"),          # train_one_epoch (engine.py:17-140): the step loop north_star keeps identical
+    "reference_utils": os.path.join(REF, "utils.py"),            # MetricLogger / cosine_scheduler / NativeScaler, which engine.py and main.py use
 }
 
 
@@ -108,6 +115,58 @@ def load_slak_model(dwconv_module):
     sys.modules.update(shim)
     try:
         return _exec("reference_models_SLaK", "reference_models_SLaK")
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+
+
+def _engine_shim():
+    """What engine.py:12-15 and utils.py:15-23 import and this image lacks (names only; see the module docstring)."""
+    import math
+    six = types.ModuleType("torch._six"); six.inf = math.inf
+    tbx = types.ModuleType("tensorboardX")
+
+    class SummaryWriter:                             # utils.TensorboardLogger only; log_writer is None in every test
+        def __init__(self, *a, **k):
+            raise RuntimeError("tensorboardX is not in this image")
+    tbx.SummaryWriter = SummaryWriter
+    timm = types.ModuleType("timm"); td = types.ModuleType("timm.data"); tu = types.ModuleType("timm.utils")
+
+    class Mixup:                                     # annotation only (engine.py:20); mixup_fn is None in every test
+        pass
+
+    class ModelEma:                                  # annotation only (engine.py:20): main.py:17 takes the class from model_sema.py
+        pass
+
+    def accuracy(output, target, topk=(1,)):         # timm1/utils/metrics.py:25-32
+        maxk = min(max(topk), output.size()[1])
+        batch_size = target.size(0)
+        _, pred = output.topk(maxk, 1, True, True)
+        pred = pred.t()
+        correct = pred.eq(target.reshape(1, -1).expand_as(pred))
+        return [correct[:min(k, maxk)].reshape(-1).float().sum(0) * 100. / batch_size for k in topk]
+
+    def get_state_dict(model, unwrap_fn=None):       # timm1/utils/model.py: the EMA's module state dict (utils.save_model only)
+        return (unwrap_fn(model) if unwrap_fn else model).state_dict()
+    td.Mixup = Mixup
+    tu.accuracy, tu.ModelEma, tu.get_state_dict = accuracy, ModelEma, get_state_dict
+    return {"torch._six": six, "tensorboardX": tbx, "timm": timm, "timm.data": td, "timm.utils": tu}
+
+
+def load_engine():
+    """(engine, utils): the reference's engine.py and utils.py, unmodified.  ``import utils`` (engine.py:15) resolves to the reference's
+    utils.py loaded here; nothing stays in sys.modules afterwards."""
+    shim = _engine_shim()
+    saved = {k: sys.modules.get(k) for k in list(shim) + ["utils"]}
+    sys.modules.update(shim)
+    try:
+        utils = _exec("reference_utils", "reference_utils")
+        sys.modules["utils"] = utils
+        engine = _exec("reference_engine", "reference_engine")
+        return engine, utils
     finally:
         for k, v in saved.items():
             if v is None:

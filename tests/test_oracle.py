@@ -208,3 +208,28 @@ def test_erk_init_matches_reference(tag):
     assert list(mk.masks.keys()) == names
     for n in names:
         np.testing.assert_array_equal(mk.masks[n].numpy(), g[f"{tag}/m/{n}"], err_msg=n)
+
+
+def test_reference_step_loop_loads_from_source_and_from_bytecode():
+    """oracle/ref_modules.load_engine: engine.py + utils.py of the reference, unmodified, importable in this image with only their
+    import boundary supplied -- from the checkout here, and from the bytecode under oracle/_ref/ (the path the GPU box takes)."""
+    import inspect
+    import os
+    import sys
+    from oracle import ref_modules
+    if not os.path.isdir(ref_modules.REF) and not ref_modules.available("reference_engine"):
+        pytest.skip("neither /root/reference nor oracle/_ref/ is present")
+    ref_modules.build()
+    want = ["model", "criterion", "data_loader", "optimizer", "device", "epoch", "loss_scaler", "max_norm", "model_ema", "mixup_fn", "log_writer",
+            "wandb_logger", "start_steps", "lr_schedule_values", "wd_schedule_values", "num_training_steps_per_epoch", "update_freq", "use_amp", "mask"]
+    saved = ref_modules.FORCE_BYTECODE
+    try:
+        for force in (False, True):
+            ref_modules.FORCE_BYTECODE = force
+            engine, utils = ref_modules.load_engine()
+            assert list(inspect.signature(engine.train_one_epoch).parameters) == want       # engine.py:17-22
+            assert engine.utils is utils and sys.modules.get("utils") is not utils          # engine.py:15 got the reference's utils.py; nothing stays behind
+            sched = utils.cosine_scheduler(4e-3, 1e-6, 2, 5, warmup_epochs=0)
+            assert len(sched) == 10 and sched[0] == 4e-3
+    finally:
+        ref_modules.FORCE_BYTECODE = saved
