@@ -11,8 +11,8 @@ bytecode under oracle/_ref/ on the GPU box; only its import boundary -- timm, te
 exactly as main.py:443-450 calls it (positional order and keyword names included).  The checker: tests/golden/engine_uf{1,2}.npz, the same call made in the
 build container on the reference's own model / optimizer factory / Masking / ModelEma in fp64 (tests/golden/make_golden.py --only engine).
 Asserted: ``mask.step()`` fired on every optimizer step (engine.py:82-83), the prune-and-grow rounds happened, the masks are BIT-EXACT, per-iteration losses,
-the returned statistics, the final weights and the EMA agree to fp32-vs-fp64 accuracy, and the losses are IDENTICAL to a hand-written loop of the same step
-(bench.py's) on the same product."""
+the returned statistics, the final weights and the EMA agree to fp32-vs-fp64 accuracy, and losses / masks / weights equal those of a hand-written loop of the
+same step (bench.py's) on the same product."""
 import ast
 import contextlib
 import io
@@ -168,11 +168,16 @@ def test_reference_train_one_epoch_drives_the_product(uf, gpu):
                 mask2.step()
                 opt2.zero_grad()
                 ema2.update(model2, mask2)
-    assert crit2.values == criterion.values
+    # (not bit for bit: in this fp32 composition the stem / downsample convolutions and the pointwise GEMMs are torch's MIOpen / hipBLASLt kernels, whose
+    # split reductions are not run-to-run reproducible -- two runs of the SAME loop differ in the last digits too)
+    np.testing.assert_allclose(crit2.values, criterion.values, rtol=2e-6, atol=0)
     for n in names:
         assert torch.equal(mask.masks[n], mask2.masks[n]), n
     for (k, v), (_, v2) in zip(model.state_dict().items(), model2.state_dict().items()):
-        assert torch.equal(v, v2), k
+        if v.dtype.is_floating_point:
+            assert _rel(v.double().cpu().numpy(), v2.double().cpu().numpy()) <= 1e-5, k
+        else:
+            assert torch.equal(v, v2), k
 
 
 def test_reference_engine_on_the_fused_bf16_product(gpu):
