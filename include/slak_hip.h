@@ -56,7 +56,11 @@ typedef enum { SLAK_ALGO_AUTO = 0, SLAK_ALGO_DIRECT = 1, SLAK_ALGO_MFMA = 2 } sl
 
 const char* slak_status_string(int status);
 const char* slak_last_hip_error(void);      /* text of the last HIP error seen by this library */
-int slak_version(void);                     /* ABI version, currently 1 */
+/* ABI version: bumped whenever an entry point's argument list or meaning changes (round 5: 5).  A host module compiled against this header
+ * (slak_amd/pybind/*.cpp) records the value it saw and refuses to load on a library that reports another one: a stale module would call raw-pointer
+ * entry points with a changed argument list -- silent corruption, not an error. */
+#define SLAK_ABI_VERSION 5
+int slak_version(void);                     /* == SLAK_ABI_VERSION of the header the library was built from */
 int slak_device_info(int* cu_count, int* lds_bytes_per_cu, char* arch_name, size_t arch_name_len);
 int slak_set_conv_algo(int algo);           /* process-wide override of the AUTO choice */
 /* fp32 tensors on the bf16 matrix cores: x = bf16(x) + bf16(x - bf16(x)) (and the same for the filter / dy), three MFMAs per product,

@@ -96,7 +96,7 @@ const char* slak_last_hip_error(void) {
     return copy.c_str();
 }
 
-int slak_version(void) { return 1; }
+int slak_version(void) { return SLAK_ABI_VERSION; }
 
 int slak_device_info(int* cu_count, int* lds_bytes_per_cu, char* arch_name, size_t arch_name_len) {
     int dev = 0;

@@ -2,7 +2,7 @@
 // slak_amd/block_ops._BlockFn (three branch convs + BatchNorm sums -> branch BatchNorms + add -> permute + LayerNorm -> pwconv1 -> GELU ->
 // pwconv2 -> gamma * + permute + residual, and its backward) as TWO host calls per block and step instead of ~70 ctypes calls, ~25 torch.empty
 // and 4-6 GEMM dispatches made from Python.  Same launches on the same operands in the same order as the Python node: results are bit-identical
-// (tests/test_block_runner_gpu.py).  Host-only C++ on the C ABI of include/slak_hip.h; tensors are allocated through the torch allocator, kernels
+// (tests/test_model_reference_gpu.py::test_block_runner_issues_the_same_launches_as_the_python_node).  Host-only C++ on the C ABI of include/slak_hip.h; tensors are allocated through the torch allocator, kernels
 // go to torch's CURRENT stream, the GEMMs the library does not cover are at::linear / at::mm (hipBLASLt).
 //
 // block_forward returns an EMPTY list when a precondition of the one-launch path does not hold for the shape (no three-branch forward with
@@ -292,6 +292,11 @@ std::vector<Tensor> block_backward(const Tensor& x16, const Tensor& wv, const Te
 }  // namespace
 
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
+    // compiled against one argument list per entry point: a library built from another header must not be called through it
+    if (slak_version() != SLAK_ABI_VERSION)
+        throw pybind11::import_error("_slak_block_runner_C was compiled against SLAK_ABI_VERSION " + std::to_string(SLAK_ABI_VERSION) + ", libslak_hip.so reports " +
+                                     std::to_string(slak_version()) + ": rebuild with `python -m slak_amd.build --pybind`");
+    m.attr("abi_version") = SLAK_ABI_VERSION;
     m.def("block_forward", &block_forward, "one SLaK block, training forward (see slak_amd/block_ops._BlockFn)");
     m.def("block_backward", &block_backward, "its backward");
 }
