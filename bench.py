@@ -123,6 +123,9 @@ def parse():
                                                             "tools/step_breakdown.py cuts a rocprofv3 kernel trace exactly there")
     ap.add_argument("--dry-nccl-env", action="store_true", help="print the environment the collective library would see (NCCL_* / RCCL_* / HSA_* / rendezvous variables, as "
                                                                  "config.comm_env records them) as one JSON line and exit: no GPU work")
+    ap.add_argument("--force-dist", action="store_true", help="world size 1: still init_process_group(--backend), wrap the model in DistributedDataParallel and run the fused "
+                    "SyncBatchNorm exchange (all-reduces) -- the N>1 code path executes on RCCL on ONE GPU (communicator creation, DDP reducer hooks, the asynchronous "
+                    "backward all-reduce); the line is NOT a scaling point (config.forced_distributed)")
     ap.add_argument("--per-step-sync", action="store_true", help="torch.cuda.synchronize() after every step, as engine.py:90 does (default: the K steps are only bracketed)")
     return ap.parse_args()
 
@@ -455,7 +458,11 @@ def main():
     dev_index = local_rank if a.device is None else a.device
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
-    distributed = world > 1
+    distributed = world > 1 or a.force_dist
+    if a.force_dist and world == 1:
+        os.environ.setdefault("MASTER_PORT", "29531")
+        os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
+        os.environ["SLAK_FORCE_BN_EXCHANGE"] = "1"                  # block_ops._bn3_group: the SyncBatchNorm exchange at world size 1 too
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -627,7 +634,8 @@ def main():
                    "dwconv_dtype": ("fp32" + (" on the bf16 matrix cores (two-term split, three MFMAs per product)"
                                               if (a.fp32_matrix_cores or os.environ.get("SLAK_FP32_AUTOCAST_SPLIT", "0") == "1") else " (exact VALU kernels)")) if a.fp32_dwconv else "bf16 in/out, fp32 accumulate", "optimizer": "torch AdamW(fused)" if a.torch_adamw else "slak_amd MaskedAdamW (update + mask + bf16 copies, one launch)",
                    "model_ema": bool(a.model_ema), "one_autograd_node_per_block": bool(M.Block.fused_block),
-                   "block_runner": bool(M.Block.fused_block and block_ops._runner() is not None and not distributed),   # the blocks' call sequences issued from C++ (single process; SyncBN runs the Python sequence)
+                   "block_runner": bool(M.Block.fused_block and block_ops._runner() is not None),   # the blocks' call sequences issued from C++ (round 5: under DDP / SyncBatchNorm too)
+                   "forced_distributed": bool(a.force_dist and world == 1),
                    "sync_bn": True, "block_tail": "hip (ln_nchw_to_nhwc + scale_residual)" if M.Block.fused_tail else "pytorch ops",
                    "branch_bn": "hip (bn3: one stats pass + one apply pass)" if M.ReparamLargeKernelConv.fused_bn else "pytorch (Sync)BatchNorm x3 + adds",
                    "pointwise_gemm": "hipBLASLt via torch" + (", TunableOp solutions from slak_amd/tuning/tunableop_gfx950.csv" if TUNED_GEMMS else ""),
@@ -666,6 +674,10 @@ def main():
                            "traffic": measured_traffic(dom), "kernel": "dwconv %s %s stage %d (N=%d)" % (dom["kernel"], dom["op"], dom["stage"], a.batch),
                            "avg_launch_ms": dom["ms"], "alg_bytes_per_launch": dom["alg_bytes"],
                            "valu_tflops_nominal": dom["gflop_nominal"] / dom["ms"]}
+        if out["roofline"]["traffic"]:                             # the dominant launch on the bytes it MOVES (PMC), beside `frac` on the per-op bytes of the ops it replaces
+            out["roofline"]["frac_of_measured_traffic"] = out["roofline"]["traffic"] / dom["ms"] / 1e6 / HBM_PEAK_GBS
+            out["roofline"]["note"] = ("frac prices the launch at SURVEY 8(d)'s per-op bytes of the ops it replaces; frac_of_measured_traffic is its measured HBM "
+                                       "traffic (PMC, profiles/pmc_traffic.json) over the same time -- the bandwidth the kernel really draws")
         assert abs(hot_bytes - survey_8d_bytes(stages, a.batch, 4 if a.fp32_dwconv else 2)) <= 1e-6 * hot_bytes, "the launches timed do not add up to SURVEY 8(d)'s per-op bytes"
         # the PATH-level figures inside `roofline` as well (the north star's target is on the path): every dw-conv launch of a step, as the
         # step launches it (statistics-gathering forward variants included), algorithmic bytes / summed launch time

@@ -601,7 +601,7 @@ def _bn3_group(bn1):
     import torch.distributed as dist
     if isinstance(bn1, torch.nn.SyncBatchNorm) and dist.is_available() and dist.is_initialized():
         pg = bn1.process_group if bn1.process_group is not None else dist.group.WORLD
-        if dist.get_world_size(pg) > 1:
+        if dist.get_world_size(pg) > 1 or _force_bn_exchange:         # (bench.py --force-dist: the exchange path on one rank, so that it executes on RCCL)
             return pg
     return None
 
@@ -1044,30 +1044,48 @@ def mlp_splitk(t, w1, b1, w2, b2):
 # the chain that the SyncBatchNorm statistics exchange waits for (residual kernel -> dz W2 -> GELU' -> dy1 W1 -> LayerNorm backward -> BatchNorm
 # sums) is issued first, the all-reduce goes out asynchronously, the two pointwise weight-gradient launches (which nothing in the block waits for)
 # run behind it, then the apply pass waits -- the collective's latency hides behind ~80 us of launches instead of stalling the stream.
-_runner_mod = False
+_runner_mod = False           # False: not looked for yet; None: not there / stale / failed to import
+_runner_trace = None          # tests: a callable(str) that the C++ runner calls at the points whose ORDER a test asserts (tests/test_distributed_gpu.py)
+_force_bn_exchange = os.environ.get("SLAK_FORCE_BN_EXCHANGE", "0") == "1"   # bench.py --force-dist: run the SyncBatchNorm exchange (the all-reduces) at world size 1 too
+
+
+def _runner_switches():
+    """The development switches that select paths only the Python sequence knows: with any of them off their default the runner steps aside, so an
+    A/B run measures what its switch says.  Read on every call: a test may flip a switch after the first block has run."""
+    return (use_skinny_linear and use_linear_wgrad and _SPLITK_ROWS == 6272 and fused_tri_backward and fused_tri_wgrad and bn_stats_in_conv
+            and accumulate_dgrad and os.environ.get("SLAK_BLOCK_RUNNER", "1") != "0")
 
 
 def _runner():
     """slak_amd/pybind/block_runner.cpp, when `__graft_entry__.build()` / `python -m slak_amd.build --pybind` has built it (never built here: an
     import must not start a compiler): the block's call sequence issued from C++ -- two host calls per block and step.  SLAK_BLOCK_RUNNER=0 keeps
-    the Python sequence (same launches, same results)."""
+    the Python sequence (same launches, same results).  A module OLDER than libslak_hip.so / include/slak_hip.h / its own source is not loaded
+    (it would call raw-pointer entry points with whatever argument lists it was compiled against) -- and one that does load checks
+    slak_version() against the SLAK_ABI_VERSION it was compiled with."""
     global _runner_mod
     if _runner_mod is False:
         _runner_mod = None
-        if os.environ.get("SLAK_BLOCK_RUNNER", "1") != "0" and use_skinny_linear and use_linear_wgrad and _SPLITK_ROWS == 6272 and fused_tri_backward:
-            try:                                                      # (the development switches above select paths only the Python sequence knows)
-                import importlib
-                import sys
-                from . import build
-                path = build.runner_path()
-                if os.path.exists(path):
+        try:
+            import importlib
+            import sys
+            import warnings
+            from . import build
+            path = build.runner_path()
+            if os.path.exists(path):
+                deps = [build.LIB, os.path.join(build.HERE, "..", "include", "slak_hip.h"), os.path.join(build.HERE, "pybind", "block_runner.cpp")]
+                if build._stale(path, [d for d in deps if os.path.exists(d)]):
+                    warnings.warn("slak_amd: %s is older than libslak_hip.so / slak_hip.h / block_runner.cpp and is NOT loaded (the Python call sequence "
+                                  "runs instead); rebuild with `python -m slak_amd.build --pybind`" % os.path.basename(path))
+                else:
                     d = os.path.dirname(path)
                     if d not in sys.path:
                         sys.path.insert(0, d)
                     _runner_mod = importlib.import_module(build.RUNNER_NAME)
-            except Exception:                                         # (no compiled module for this interpreter / torch: the Python sequence runs)
-                _runner_mod = None
-    return _runner_mod
+        except Exception as e:                                        # (no compiled module for this interpreter / torch, or an ABI mismatch: the Python sequence runs)
+            import warnings
+            warnings.warn("slak_amd: block runner not loaded (%s: %s)" % (type(e).__name__, e))
+            _runner_mod = None
+    return _runner_mod if (_runner_mod is not None and _runner_switches()) else None
 
 
 class _BlockFn(torch.autograd.Function):
@@ -1076,19 +1094,21 @@ class _BlockFn(torch.autograd.Function):
         bns, eps, emit = cfg["bns"], cfg["eps"], cfg["emit_lowp"]
         ctx.runner = False
         R = _runner()
-        if (R is not None and bns[0].momentum is not None and _bn3_group(bns[0]) is None and x.is_contiguous()
+        if (R is not None and bns[0].momentum is not None and x.is_contiguous()
                 and all(bn.track_running_stats and bn.num_batches_tracked is not None for bn in bns)):
             w1b, w2b = lowp_param(w1), lowp_param(w2)
+            group = _bn3_group(bns[0])                                # SyncBatchNorm: the runner calls back for the two statistics exchanges
+            exchange = None if group is None else (lambda buf, async_op: _sync_bn_all_reduce(buf, group, async_op=async_op))
             res = R.block_forward(x, x_lowp, wv, wh, ws, [g1, g2, g3], [b1, b2, b3], [bn.running_mean for bn in bns], [bn.running_var for bn in bns],
                                   float(bns[0].eps), float(bns[0].momentum), True, lnw, lnb, float(eps), w1b, lowp_param(bb1), w2b, lowp_param(bb2),
-                                  gamma, sample_scale, bool(emit))
+                                  gamma, sample_scale, bool(emit), exchange)
             if res:                                                   # (empty: the shape has no one-launch path -- the Python sequence knows the fallbacks)
-                out, out16, x16, yv, yh, ys, bnstats, s, t, mean, rstd, y1m, a, z = res
+                out, out16, x16, yv, yh, ys, bnstats, s, t, mean, rstd, y1m, a, z, count_dev = res
                 pool = getattr(bns[0], "_slak_ctr_pool", None)
                 if not (pool is not None and pool.covers(bns) and pool.bump_once()):
                     torch._foreach_add_([bn.num_batches_tracked for bn in bns], 1)
                 ctx.save_for_backward(x16, wv, wh, ws, yv, yh, ys, g1, g2, g3, bnstats, s, lnw, mean, rstd, t, w1b, y1m, a, w2b, z, gamma, sample_scale)
-                ctx.misc = (True, None, float(x.shape[0] * x.shape[2] * x.shape[3]), None, x.dtype, x_lowp is not None)
+                ctx.misc = (True, group, float(x.shape[0] * x.shape[2] * x.shape[3]), count_dev, x.dtype, x_lowp is not None)
                 ctx.runner = True
                 ctx.set_materialize_grads(False)
                 return (out, out16) if emit else out
@@ -1114,9 +1134,10 @@ class _BlockFn(torch.autograd.Function):
         (x16, wv, wh, ws, yv, yh, ys, g1, g2, g3, bnstats, s, lnw, mean, rstd, t, w1b, y1m, a, w2b, z, gamma, sample_scale) = ctx.saved_tensors
         tri_dgrad, group, count, count_dev, xdtype, had_lowp = ctx.misc
         if ctx.runner:
-            (dx, dxl, dwv, dwh, dws, dgam, dbet, dlnw, dlnb, dw1, db1, dw2, dzc, dgamma) = _runner().block_backward(
+            exchange = None if group is None else (lambda buf, async_op: _sync_bn_all_reduce(buf, group, async_op=async_op))
+            (dx, dxl, dwv, dwh, dws, dgam, dbet, dlnw, dlnb, dw1, db1, dw2, dzc, dgamma) = _runner_mod.block_backward(
                 x16, wv, wh, ws, yv, yh, ys, [g1, g2, g3], bnstats, s, lnw, mean, rstd, t, w1b, y1m, a, w2b, z, gamma, sample_scale, dout, dout16,
-                xdtype == torch.bfloat16, had_lowp)
+                xdtype == torch.bfloat16, had_lowp, count_dev, exchange, _runner_trace)
             return (dx, dxl, dwv, dwh, dws, dgam[0], dbet[0], dgam[1], dbet[1], dgam[2], dbet[2], dlnw, dlnb, dw1, db1, dw2, dzc, dgamma, None, None)
         saved = (t, w1b, y1m, a, w2b)
         dshortcut, dz, dgamma, dzc = _scale_residual_bwd(z, gamma, sample_scale, xdtype, dout, dout16)

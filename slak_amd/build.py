@@ -103,6 +103,15 @@ def build_pybind(force: bool = False, verbose: bool = False, name: str = None, s
 
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
-    if "--pybind" in sys.argv:
-        print(build_pybind(force="--force" in sys.argv, verbose=True))
-        print(build_runner(force="--force" in sys.argv, verbose=True))
+    # the host modules on top of the library: rebuilt when asked for, and ALSO whenever one exists and is now older than the library / header / its
+    # source -- `python -m slak_amd.build` must not leave a module behind that calls the new library through old argument lists
+    for path, fn in ((pybind_path(), build_pybind), (runner_path(), build_runner)):
+        if "--pybind" in sys.argv or os.path.exists(path):
+            try:
+                print(fn(force="--force" in sys.argv, verbose=True))
+            except Exception as e:
+                if os.path.exists(path):
+                    os.remove(path)
+                print("removed %s: rebuilding it failed (%s: %s)" % (path, type(e).__name__, e))
+                if "--pybind" in sys.argv:
+                    raise

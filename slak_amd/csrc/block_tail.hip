@@ -846,8 +846,7 @@ static int tail_grid(const TailDims& d, size_t lds) {                  // persis
     return d.ntiles < resident ? d.ntiles : resident;
 }
 static int set_lds(const void* k, size_t lds) {
-    if (lds > 48 * 1024) return hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess ? 0 : 1;
-    return 0;
+    return slak_set_max_lds(k, lds) ? 0 : 1;
 }
 
 // Stem (models/SLaK.py:276-279: Conv2d(in_chans, C, kernel_size=4, stride=4)): the non-overlapping 4x4 patches of the fp32 NCHW image as the

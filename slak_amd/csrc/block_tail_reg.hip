@@ -865,7 +865,7 @@ template <typename K> static int rt_persistent_grid(K k, size_t lds, int ntiles)
     return need < grid ? need : grid;
 }
 template <typename K> static int rt_set_lds(K k, size_t lds) {
-    return (lds > 48 * 1024 && hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) ? 1 : 0;
+    return slak_set_max_lds((const void*)k, lds) ? 0 : 1;
 }
 
 template <int CL, int G, bool XF32 = false, bool PATCH = false>

@@ -208,11 +208,11 @@ static int launch_typed(const DirectParams& p, bool long_h, hipStream_t st) {
     dim3 grid((unsigned)(p.C * p.groups_per_channel * p.nBands));
     if (long_h) {
         auto k = dwconv_direct_kernel<Tin, Tout, true>;
-        if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)slak_set_max_lds((const void*)k, lds);
         hipLaunchKernelGGL(k, grid, dim3(DIRECT_THREADS), lds, st, (const Tin*)p.x, p.wp, (Tout*)p.y, p);
     } else {
         auto k = dwconv_direct_kernel<Tin, Tout, false>;
-        if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)slak_set_max_lds((const void*)k, lds);
         hipLaunchKernelGGL(k, grid, dim3(DIRECT_THREADS), lds, st, (const Tin*)p.x, p.wp, (Tout*)p.y, p);
     }
     SLAK_LAUNCH_CHECK();

@@ -374,7 +374,7 @@ static int launch_mfma_fwd_t(const MfmaFwdParams& p, bool vert, hipStream_t st) 
     if constexpr (!F32) {
         if (p.nch > 1 || p.guard != 2) {                             // more than five rows (or fewer: 3 x 3): the chunked horizontal kernel
             auto k = dwconv_mfma_fwd_kernel<T, MT, KS, RPM, V, false, false, true>;
-            if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            (void)slak_set_max_lds((const void*)k, lds);
             hipLaunchKernelGGL(k, grid, dim3(MF_THREADS), lds, st, p);
             SLAK_LAUNCH_CHECK();
             return SLAK_OK;
@@ -382,11 +382,11 @@ static int launch_mfma_fwd_t(const MfmaFwdParams& p, bool vert, hipStream_t st) 
     }
     if (vert) {
         auto k = dwconv_mfma_fwd_kernel<T, MT, KS, RPM, V, true, F32>;
-        if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)slak_set_max_lds((const void*)k, lds);
         hipLaunchKernelGGL(k, grid, dim3(MF_THREADS), lds, st, p);
     } else {
         auto k = dwconv_mfma_fwd_kernel<T, MT, KS, RPM, V, false, F32>;
-        if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)slak_set_max_lds((const void*)k, lds);
         hipLaunchKernelGGL(k, grid, dim3(MF_THREADS), lds, st, p);
     }
     SLAK_LAUNCH_CHECK();

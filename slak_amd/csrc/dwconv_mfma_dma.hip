@@ -512,7 +512,7 @@ static int launch_dma_tv(MfmaDmaParams& p, const ConvDims& d, hipStream_t st) {
     fill_dma_params(p, d, VERT, MT, KS, 512);
     const size_t lds = dma_lds_bytes(p, VERT);                   // does not depend on the slice count
     static int resident = 0;                                      // per instantiation; LDS size varies little within a class
-    if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)slak_set_max_lds((const void*)k, lds);
     if (resident == 0) resident = resident_workgroups(k, lds);
     fill_dma_params(p, d, VERT, MT, KS, resident);
     hipLaunchKernelGGL(k, dim3((unsigned)(p.C * p.slices)), dim3(MF_THREADS), lds, st, p);

@@ -567,7 +567,7 @@ static int launch_quad_t(SmallTriParams& p, hipStream_t st) {
     auto k = dw ? dwconv_mfma_small_quad_kernel<T, DGRAD, true> : dwconv_mfma_small_quad_kernel<T, DGRAD, false>;
     const size_t lds = (size_t)MF_WAVES * SqLds<DGRAD>::WAVE_BYTES;
     fill_quad_params(p, p.N, p.C, p.H, p.W, p.K, quad_target_wgs());
-    if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)slak_set_max_lds((const void*)k, lds);
     hipLaunchKernelGGL(k, dim3((unsigned)(((p.C + 3) / 4) * p.slices)), dim3(MF_THREADS), lds, st, p);
     SLAK_LAUNCH_CHECK();
     return SLAK_OK;
@@ -602,7 +602,7 @@ static int launch_tri_tn(SmallTriParams& p, hipStream_t st) {
     auto k = dwconv_mfma_small_tri_kernel<T, DGRAD, NARROW>;
     fill_tri_params(p, p.N, p.C, p.H, p.W, p.K, (DGRAD ? 2 : 3) * mfma_cu_count());   // resident workgroups per CU (LDS)
     const size_t lds = (size_t)MF_WAVES * WAVE_BYTES;
-    if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)slak_set_max_lds((const void*)k, lds);
     hipLaunchKernelGGL(k, dim3((unsigned)(((p.C + 3) / 4) * p.slices)), dim3(MF_THREADS), lds, st, p);
     SLAK_LAUNCH_CHECK();
     return SLAK_OK;

@@ -713,7 +713,7 @@ static int launch_qw_t(SmallTriWgradParams& p, size_t ws_bytes, hipStream_t st) 
     if ((size_t)(p.N + 7) * p.C * p.H * p.W * 2 >= 0xffffffffull) return SLAK_ERR_UNSUPPORTED;
     if ((size_t)p.slices * p.C * (2 * p.K * MF_TAPS + 25) * sizeof(float) > ws_bytes) return SLAK_ERR_WORKSPACE;
     const size_t lds = (size_t)MF_WAVES * QW_WAVE_BYTES;
-    if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)slak_set_max_lds((const void*)k, lds);
     hipLaunchKernelGGL(k, dim3((unsigned)(((p.C + 3) / 4) * p.slices)), dim3(MF_THREADS), lds, st, p);
     SLAK_LAUNCH_CHECK();
     return SLAK_OK;
@@ -725,7 +725,7 @@ static int launch_stw_t(SmallTriWgradParams& p, size_t ws_bytes, hipStream_t st)
     fill_stw_params(p, p.N, p.C, p.H, p.W, p.K, 2 * mfma_cu_count());
     if ((size_t)p.slices * p.C * (2 * p.K * MF_TAPS + 25) * sizeof(float) > ws_bytes) return SLAK_ERR_WORKSPACE;
     const size_t lds = (size_t)MF_WAVES * (DG ? TW_WAVE_BYTES_DG : TW_WAVE_BYTES);
-    if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)slak_set_max_lds((const void*)k, lds);
     hipLaunchKernelGGL(k, dim3((unsigned)(((p.C + 3) / 4) * p.slices)), dim3(MF_THREADS), lds, st, p);
     SLAK_LAUNCH_CHECK();
     return SLAK_OK;

@@ -251,7 +251,7 @@ static int launch_sw_t(SmallWgradParams& p, const ConvDims& d, size_t ws_bytes, 
     static int resident = 0;
     fill_sw_params(p, d, VERT, 2048);
     const size_t lds0 = sw_lds_bytes(p);
-    if (lds0 > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds0);
+    (void)slak_set_max_lds((const void*)k, lds0);
     if (resident == 0) {
         int per_cu = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k, MF_THREADS, lds0) != hipSuccess || per_cu < 1) per_cu = 1;

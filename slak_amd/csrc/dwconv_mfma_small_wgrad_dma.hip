@@ -229,7 +229,7 @@ static int launch_swd_ns(SmallWgradDmaParams& p, const ConvDims& d, size_t ws_by
     if ((size_t)p.slices * d.C * d.kh * d.kw * sizeof(float) > ws_bytes) return SLAK_ERR_WORKSPACE;
     const int cblocks = (d.C + 3) / 4;
     const size_t lds = (size_t)MF_WAVES * swd_wave_bytes(NS);
-    if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)slak_set_max_lds((const void*)k, lds);
     hipLaunchKernelGGL(k, dim3((unsigned)(cblocks * p.slices)), dim3(MF_THREADS), lds, st, p);
     SLAK_LAUNCH_CHECK();
     return SLAK_OK;

@@ -608,7 +608,7 @@ static int launch_team_s(TeamParams& p, int N, int C, int H, int W, int K, hipSt
     static thread_local size_t cached_key = 0;                    // (device + 1, LDS size): the attribute is per device
     const size_t key = ((size_t)(slak_current_device() + 1) << 32) | lds;
     if (cached_key != key) {
-        if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)slak_set_max_lds((const void*)k, lds);
         cached_key = key;
     }
     if (SOLO) hipLaunchKernelGGL(k, dim3((unsigned)(p.C * p.slices)), dim3(TT_THREADS), lds, st, p);

@@ -397,11 +397,11 @@ static int launch_wgrad_t(const MfmaWgradParams& p, bool vert, hipStream_t st) {
     dim3 grid((unsigned)(p.C * p.slices));
     if (vert) {
         auto k = dwconv_mfma_wgrad_kernel<T, MT, RPN, V, true, F32>;
-        if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)slak_set_max_lds((const void*)k, lds);
         hipLaunchKernelGGL(k, grid, dim3(MF_THREADS), lds, st, p);
     } else {
         auto k = dwconv_mfma_wgrad_kernel<T, MT, RPN, V, false, F32>;
-        if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)slak_set_max_lds((const void*)k, lds);
         hipLaunchKernelGGL(k, grid, dim3(MF_THREADS), lds, st, p);
     }
     SLAK_LAUNCH_CHECK();

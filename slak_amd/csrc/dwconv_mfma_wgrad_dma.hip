@@ -343,7 +343,7 @@ static int launch_wdma_tp(WgradDmaParams& p, const ConvDims& d, size_t ws_bytes,
     fill_wdma_params(p, d, VERT, MT, 512);
     const size_t lds = wdma_lds_bytes(p, VERT);
     static int resident = 0;
-    if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)slak_set_max_lds((const void*)k, lds);
     if (resident == 0) {
         int per_cu = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k, MF_THREADS, lds) != hipSuccess || per_cu < 1) per_cu = 1;

@@ -252,7 +252,7 @@ static int launch_vwave_t(WgradWaveParams& p, const ConvDims& d, size_t ws_bytes
     static const int wgs_per_cu = [] { const char* e = getenv("SLAK_VWAVE_WGS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 2; }();
     fill_vwave_params(p, d, wgs_per_cu * mfma_cu_count());
     const size_t lds = vwave_lds_bytes(p);
-    if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)slak_set_max_lds((const void*)k, lds);
     if ((size_t)p.slices * d.C * (d.kh * d.kw + (PAIR ? MF_TAPS * MF_TAPS : 0)) * sizeof(float) > ws_bytes) return SLAK_ERR_WORKSPACE;
     hipLaunchKernelGGL(k, dim3((unsigned)(p.C * p.slices)), dim3(MF_THREADS), lds, st, p);
     SLAK_LAUNCH_CHECK();

@@ -348,7 +348,7 @@ static int launch_wide_tv(WideParams& p, const ConvDims& d, hipStream_t st) {
     static thread_local size_t cached_lds = 0; static thread_local int cached_per_cu = 0;     // per instantiation; queried once per (device, LDS size)
     const size_t lds_key = ((size_t)(slak_current_device() + 1) << 32) | lds;
     if (cached_lds != lds_key) {
-        if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)slak_set_max_lds((const void*)k, lds);
         int per_cu = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k, MF_THREADS, lds) != hipSuccess || per_cu < 1) per_cu = 1;
         cached_per_cu = per_cu > 8 ? 8 : per_cu; cached_lds = lds_key;

@@ -279,7 +279,7 @@ static int launch_wide_wgrad_tv(WideWgradParams& p, const ConvDims& d, size_t ws
     static thread_local size_t cached_key = 0; static thread_local int cached_per_cu = 0;     // per instantiation; queried once per (LDS size, block size)
     const size_t key = ((size_t)(slak_current_device() + 1) << 40) | (lds * 16 + (size_t)p.ntiles);      // (the attribute is per device)
     if (cached_key != key) {
-        if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)slak_set_max_lds((const void*)k, lds);
         int per_cu = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k, p.ntiles * 64, lds) != hipSuccess || per_cu < 1) per_cu = 1;
         cached_per_cu = per_cu > 8 ? 8 : per_cu; cached_key = key;

@@ -228,7 +228,7 @@ static int wlaunch2(const WgradParams& p, hipStream_t st) {
     dim3 grid((unsigned)(p.C * p.nslices * p.nBatches));
     dim3 block((unsigned)(64 * p.jobsPerBatch));
     auto k = dwconv_wgrad_kernel<Tdy, Tx, LONG_H, T>;
-    if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)slak_set_max_lds((const void*)k, lds);
     hipLaunchKernelGGL(k, grid, block, lds, st, (const Tdy*)p.dy, (const Tx*)p.x, p.partial, p);
     SLAK_LAUNCH_CHECK();
     return SLAK_OK;

@@ -627,7 +627,7 @@ int slak_linear_nt(const void* x, const void* wt, const void* bias, void* y, voi
     const int tiles = (M + 31) / 32;
     int wgs = mfma_cu_count(); if (wgs * LS_WAVES > tiles) wgs = (tiles + LS_WAVES - 1) / LS_WAVES;
     const unsigned xb = (unsigned)((size_t)M * K * 2);
-    auto set_lds = [](const void* k, size_t lds) { return lds <= 48 * 1024 || hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess; };
+    auto set_lds = [](const void* k, size_t lds) { return slak_set_max_lds(k, lds); };
     if (K == 96 && N % 64 == 0) {
         const size_t lds = (size_t)N * LS_XP + 1024 + (size_t)LK_WAVES * (LS_XBUF + LK_OBUF) + (G ? GL_BYTES : 0);
         const uint16_t* lut = G ? gelu_table_device() : nullptr;
@@ -666,7 +666,7 @@ int slak_linear_mlp_fwd(const void* x, const void* w1, const void* b1, const voi
     const uint16_t* lut = gelu_table_device();
     if (!lut) return SLAK_ERR_LAUNCH;
     const size_t lds = (size_t)C4 * LS_XP + 1024 + (size_t)LM_WAVES * (LS_XBUF + 2 * LK_OBUF) + GL_BYTES;
-    if (hipFuncSetAttribute((const void*)linear_mlp_fwd_k96_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return SLAK_ERR_LAUNCH;
+    if (!slak_set_max_lds((const void*)linear_mlp_fwd_k96_kernel, lds)) return SLAK_ERR_LAUNCH;
     hipLaunchKernelGGL(linear_mlp_fwd_k96_kernel, dim3(wk), dim3(LM_THREADS), lds, (hipStream_t)stream, (const uint16_t*)x, (const uint16_t*)w1,
                        (const uint16_t*)b1, (const uint16_t*)w2, (const uint16_t*)b2, (uint16_t*)y1, (uint16_t*)a, (uint16_t*)z, M,
                        (unsigned)((size_t)M * C * 2), lut);
@@ -696,7 +696,7 @@ int slak_linear_nt_gelu_bwd(const void* x, const void* wt, const void* y1, void*
     const float* table = gelu_grad_table_device();
     if (!table) return SLAK_ERR_LAUNCH;
     const size_t lds = (size_t)N * LS_XP + (size_t)LG_WAVES * (LS_XBUF + LK_OBUF) + GD_BYTES;
-    if (hipFuncSetAttribute((const void*)linear_nt_k96_gbwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return SLAK_ERR_LAUNCH;
+    if (!slak_set_max_lds((const void*)linear_nt_k96_gbwd_kernel, lds)) return SLAK_ERR_LAUNCH;
     hipLaunchKernelGGL(linear_nt_k96_gbwd_kernel, dim3(wk), dim3(LG_THREADS), lds, st, (const uint16_t*)x, (const uint16_t*)wt, (const uint16_t*)y1,
                        (uint16_t*)dy1, (float*)workspace, M, (unsigned)((size_t)M * K * 2), (unsigned)((size_t)M * N * 2), table);
     SLAK_LAUNCH_CHECK();

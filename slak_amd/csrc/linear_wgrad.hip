@@ -259,7 +259,7 @@ int launch_linear_wgrad(const void* x1, const void* x2, float* d, int M, int N1,
 #define SLAK_LW_LAUNCH(A, B)                                                                                                           \
     do {                                                                                                                               \
         auto k = linear_wgrad_kernel<A, B>;                                                                                            \
-        if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds) != hipSuccess) return SLAK_ERR_LAUNCH; \
+        if (!slak_set_max_lds((const void*)k, pl.lds)) return SLAK_ERR_LAUNCH; \
         hipLaunchKernelGGL(k, grid, dim3(256), pl.lds, st, p);                                                                         \
     } while (0)
     if (pl.w1 == 2) SLAK_LW_LAUNCH(2, 2);

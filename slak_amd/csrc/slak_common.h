@@ -12,6 +12,20 @@ namespace slak {
 // key the cache on (device, value), so a thread that moves to a second GPU sets the attribute there too.
 static inline int slak_current_device() { int dev = 0; return hipGetDevice(&dev) == hipSuccess ? dev : 0; }
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) ONCE per (kernel, device, size) and thread instead of on every launch (the call takes the runtime's
+// lock and ~2 us of host time).  The attribute is per device; a larger size for the same kernel simply sets it again.
+static inline bool slak_set_max_lds(const void* kernel, size_t lds) {
+    if (lds <= 48 * 1024) return true;
+    struct Slot { const void* k; int dev; size_t lds; };
+    static thread_local Slot cache[64];                           // direct-mapped on the kernel's address: a collision only costs the call again
+    const int dev = slak_current_device();
+    Slot& s = cache[((uintptr_t)kernel >> 4) & 63];
+    if (s.k == kernel && s.dev == dev && s.lds == lds) return true;
+    if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) { (void)hipGetLastError(); return false; }
+    s.k = kernel; s.dev = dev; s.lds = lds;
+    return true;
+}
+
 
 // ---- element types -------------------------------------------------------------------------
 struct bf16_t { uint16_t v; };          // storage-only bfloat16

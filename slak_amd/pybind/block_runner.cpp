@@ -5,6 +5,13 @@
 // (tests/test_model_reference_gpu.py::test_block_runner_issues_the_same_launches_as_the_python_node).  Host-only C++ on the C ABI of include/slak_hip.h; tensors are allocated through the torch allocator, kernels
 // go to torch's CURRENT stream, the GEMMs the library does not cover are at::linear / at::mm (hipBLASLt).
 //
+// SyncBatchNorm (round 5): with an `exchange` callable (block_ops._sync_bn_all_reduce bound to the process group) the branch BatchNorms run as
+// sums -> exchange -> apply: forward one blocking all-reduce of 6C+1 doubles, backward one all-reduce of 4C floats issued ASYNCHRONOUSLY in front of
+// the two pointwise weight gradients and waited for behind them -- so a DDP run issues its blocks from here too, not from the Python sequence.
+//
+// The caches below are shared by the forward (caller thread) and the backward (autograd's device threads, possibly one per GPU in a single process):
+// one mutex guards their lookups / inserts; entries are never erased, so references stay valid after the lock is dropped.
+//
 // block_forward returns an EMPTY list when a precondition of the one-launch path does not hold for the shape (no three-branch forward with
 // statistics / data gradient / weight gradient launch): the caller (block_ops._BlockFn) then runs the Python sequence, which knows every fallback.
 #include <torch/extension.h>
@@ -14,6 +21,8 @@
 
 #include <algorithm>
 #include <map>
+#include <mutex>
+#include <string>
 #include <vector>
 
 #include "../../include/slak_hip.h"
@@ -21,6 +30,8 @@
 namespace {
 
 using at::Tensor;
+
+std::mutex g_cache_mu;
 
 void* stream_of(const Tensor& t) { return (void*)c10::hip::getCurrentHIPStream(t.get_device()).stream(); }
 
@@ -33,6 +44,7 @@ struct Scratch { void* p; size_t n; };
 Scratch scratch(const Tensor& like, size_t bytes) {
     static std::map<std::pair<int, void*>, Tensor> cache;
     const auto key = std::make_pair((int)like.get_device(), stream_of(like));
+    std::lock_guard<std::mutex> lk(g_cache_mu);
     auto it = cache.find(key);
     if (it == cache.end() || (size_t)it->second.numel() < bytes) {
         Tensor t = at::empty({(int64_t)std::max<size_t>(bytes, (size_t)1 << 22)}, like.options().dtype(at::kByte));
@@ -49,6 +61,7 @@ Scratch scratch(const Tensor& like, size_t bytes) {
 struct Side { hipStream_t st = nullptr; hipEvent_t fork = nullptr, join = nullptr; bool ok = false; };
 Side& side_of(int dev) {
     static std::map<int, Side> m;
+    std::lock_guard<std::mutex> lk(g_cache_mu);
     auto it = m.find(dev);
     if (it != m.end()) return it->second;
     Side s;
@@ -65,6 +78,7 @@ struct Plan { bool ok; int rows; size_t ws; bool nt1, nt2, ntd1, ntd2, wg1, wg2,
 const Plan& plan_of(const Shape& s) {
     static std::map<std::vector<int>, Plan> cache;
     const std::vector<int> key = {s.N, s.C, s.H, s.W, s.K, s.C4};
+    std::lock_guard<std::mutex> lk(g_cache_mu);
     auto it = cache.find(key);
     if (it != cache.end()) return it->second;
     Plan p{};
@@ -112,12 +126,13 @@ Shape shape_of(const Tensor& x, const Tensor& wv, const Tensor& w1b) {
 const float* fp(const Tensor& t) { return (const float*)t.data_ptr(); }
 float* fpm(const Tensor& t) { return (float*)t.data_ptr(); }
 
-// -> [out, out16 | undefined, x16, yv, yh, ys, bnstats, s, t, mean, rstd, y1m, a, z], or an empty list (see the header)
+// -> [out, out16 | undefined, x16, yv, yh, ys, bnstats, s, t, mean, rstd, y1m, a, z, count_dev | undefined], or an empty list (see the header)
 std::vector<Tensor> block_forward(const Tensor& x, const c10::optional<Tensor>& x_lowp, const Tensor& wv, const Tensor& wh, const Tensor& wsm,
                                   const std::vector<Tensor>& bn_gamma, const std::vector<Tensor>& bn_beta, const std::vector<Tensor>& bn_mean,
                                   const std::vector<Tensor>& bn_var, double bn_eps, double bn_momentum, bool update_running,
                                   const Tensor& lnw, const Tensor& lnb, double ln_eps, const Tensor& w1b, const Tensor& bb1b, const Tensor& w2b,
-                                  const Tensor& bb2b, const Tensor& gamma, const c10::optional<Tensor>& sample_scale, bool emit_lowp) {
+                                  const Tensor& bb2b, const Tensor& gamma, const c10::optional<Tensor>& sample_scale, bool emit_lowp,
+                                  const pybind11::object& exchange /* None: single process */) {
     TORCH_CHECK(x.is_cuda() && x.is_contiguous() && x.dim() == 4, "x must be a contiguous (N,C,H,W) HIP tensor");
     TORCH_CHECK(bn_gamma.size() == 3 && bn_beta.size() == 3 && bn_mean.size() == 3 && bn_var.size() == 3, "three branch BatchNorms");
     const Shape s = shape_of(x, wv, w1b);
@@ -143,9 +158,22 @@ std::vector<Tensor> block_forward(const Tensor& x, const c10::optional<Tensor>& 
     const float* pre[3] = {fp(stats), fp(stats) + 2, fp(stats) + 4};
     const int pre_rows[3] = {pl.rows, pl.rows, pl.rows};
     Tensor coef = at::empty({s.C * 4}, stats.options()), bnstats = at::empty({s.C * 6}, stats.options());
-    Tensor sum = at::empty_like(yv);
+    Tensor sum = at::empty_like(yv), count_dev;
+    if (exchange.is_none()) {
     check_rc(slak_bn3_forward_local(yv.data_ptr(), yh.data_ptr(), ys.data_ptr(), gam, bet, rm, rv, (float)bn_eps, (float)bn_momentum, update_running ? 1 : 0,
                                     fpm(coef), fpm(bnstats), sum.data_ptr(), s.N, s.C, s.P, ws.p, ws.n, st, pre, pre_rows, 6), "slak_bn3_forward_local");
+    } else {                                                       // SyncBatchNorm: the conv launches' rows feed the exchange buffer, one all-reduce, then the apply pass
+        Tensor sums = at::empty({(int64_t)s.C * 6 + 1}, x.options().dtype(at::kDouble));
+        check_rc(slak_bn3_forward_sums(yv.data_ptr(), yh.data_ptr(), ys.data_ptr(), (double*)sums.data_ptr(), s.N, s.C, s.P, ws.p, ws.n, st, pre, pre_rows, 6),
+                 "slak_bn3_forward_sums");
+        const double count = (double)s.N * (double)s.P;
+        count_dev = sums.narrow(0, (int64_t)s.C * 6, 1);           // the global element count stays on the device (no host sync)
+        count_dev.fill_(count);
+        exchange(sums, false);                                     // blocking on the stream: the apply pass needs the result at once
+        check_rc(slak_bn3_forward_apply(yv.data_ptr(), yh.data_ptr(), ys.data_ptr(), (const double*)sums.data_ptr(), count, (const double*)count_dev.data_ptr(),
+                                        gam, bet, rm, rv, (float)bn_eps, (float)bn_momentum, 1, update_running ? 1 : 0, fpm(coef), fpm(bnstats), sum.data_ptr(),
+                                        s.N, s.C, s.P, st), "slak_bn3_forward_apply");
+    }
     // permute + LayerNorm
     Tensor t = at::empty({s.N, s.H, s.W, s.C}, x16.options());
     Tensor mean = at::empty({s.N, s.P}, stats.options()), rstd = at::empty({s.N, s.P}, stats.options());
@@ -181,7 +209,7 @@ std::vector<Tensor> block_forward(const Tensor& x, const c10::optional<Tensor>& 
     check_rc(slak_scale_residual_forward(x.data_ptr(), x.scalar_type() == at::kFloat ? SLAK_F32 : SLAK_BF16, z.data_ptr(), fp(gamma),
                                          has_scale ? fp(*sample_scale) : nullptr, fpm(out), emit_lowp ? out16.data_ptr() : nullptr, s.N, s.C, s.P, st),
              "slak_scale_residual_forward");
-    return {out, out16, x16, yv, yh, ys, bnstats, sum, t, mean, rstd, y1m, a, z};
+    return {out, out16, x16, yv, yh, ys, bnstats, sum, t, mean, rstd, y1m, a, z, count_dev};
 }
 
 Tensor wgrad(const Tensor& dy, const Tensor& x, int M, int N1, int N2, bool covered, const Scratch& ws, void* st) {
@@ -204,7 +232,8 @@ std::vector<Tensor> block_backward(const Tensor& x16, const Tensor& wv, const Te
                                    const Tensor& ys, const std::vector<Tensor>& bn_gamma, const Tensor& bnstats, const Tensor& sum, const Tensor& lnw,
                                    const Tensor& mean, const Tensor& rstd, const Tensor& t, const Tensor& w1b, const Tensor& y1m, const Tensor& a,
                                    const Tensor& w2b, const Tensor& z, const Tensor& gamma, const c10::optional<Tensor>& sample_scale,
-                                   const c10::optional<Tensor>& dout_opt, const c10::optional<Tensor>& dout16_opt, bool shortcut_bf16, bool had_lowp) {
+                                   const c10::optional<Tensor>& dout_opt, const c10::optional<Tensor>& dout16_opt, bool shortcut_bf16, bool had_lowp,
+                                   const c10::optional<Tensor>& count_dev, const pybind11::object& exchange, const pybind11::object& trace) {
     const Shape s = shape_of(x16, wv, w1b);
     const Plan& pl = plan_of(s);
     TORCH_CHECK(pl.ok, "block_backward: the shape has no one-launch path (block_forward would have declined it)");
@@ -257,9 +286,23 @@ std::vector<Tensor> block_backward(const Tensor& x16, const Tensor& wv, const Te
     Tensor ds = at::empty_like(sum), dlnw = at::empty_like(lnw), dlnb = at::empty_like(lnw);
     check_rc(slak_ln_nchw_to_nhwc_backward(dt_.data_ptr(), sum.data_ptr(), fp(lnw), fp(mean), fp(rstd), ds.data_ptr(), fpm(dlnw), fpm(dlnb), s.N, s.C, s.P,
                                            region(2).p, region(2).n, st), "slak_ln_nchw_to_nhwc_backward");
+    // SyncBatchNorm: the backward sums and their all-reduce go out FIRST (asynchronously); the weight gradients below do not depend on them
+    const float* gam[3] = {fp(bn_gamma[0]), fp(bn_gamma[1]), fp(bn_gamma[2])};
+    Tensor bcoef = at::empty({s.C * 9}, f32), dgam = at::empty({3, s.C}, f32), dbet = at::empty({3, s.C}, f32);
+    Tensor d1 = at::empty_like(yv), d2 = at::empty_like(yv), d3 = at::empty_like(yv);
+    Tensor lsums, gsums;
+    pybind11::object work = pybind11::none();
+    if (!exchange.is_none()) {
+        lsums = at::empty({(int64_t)s.C * 4}, f32);
+        check_rc(slak_bn3_backward_sums(ds.data_ptr(), yv.data_ptr(), yh.data_ptr(), ys.data_ptr(), fp(bnstats), fpm(lsums), s.N, s.C, s.P, ws.p, ws.n, st),
+                 "slak_bn3_backward_sums");
+        gsums = lsums.clone();
+        work = exchange(gsums, true);
+    }
     // the two pointwise weight gradients (single process: in front of the BatchNorm pass, as the Python node launches them)
     // (with both on the library's kernel: on the side stream, joined at the end of this function -- their operands are complete on the main
     // stream at the fork, their outputs, operands and workspace regions are not touched by the main stream before the join)
+    if (!trace.is_none()) trace("pointwise_wgrads");
     Side& sd = side_of(x16.get_device());
     const bool forked = sd.ok && pl.wg1 && pl.wg2 && hipEventRecord(sd.fork, (hipStream_t)st) == hipSuccess && hipStreamWaitEvent(sd.st, sd.fork, 0) == hipSuccess;
     void* wst = forked ? (void*)sd.st : st;
@@ -268,11 +311,16 @@ std::vector<Tensor> block_backward(const Tensor& x16, const Tensor& wv, const Te
     struct Join { Side* sd; void* st; bool on; ~Join() { if (on && hipEventRecord(sd->join, sd->st) == hipSuccess) (void)hipStreamWaitEvent((hipStream_t)st, sd->join, 0); } } join{&sd, st, forked};
     check_rc(deferred.end(), "slak_defer_reductions_end");         // one launch: dgamma, db2 | db1 | dlnw, dlnb | dW1 | dW2
     // branch BatchNorms
-    const float* gam[3] = {fp(bn_gamma[0]), fp(bn_gamma[1]), fp(bn_gamma[2])};
-    Tensor bcoef = at::empty({s.C * 9}, f32), dgam = at::empty({3, s.C}, f32), dbet = at::empty({3, s.C}, f32);
-    Tensor d1 = at::empty_like(yv), d2 = at::empty_like(yv), d3 = at::empty_like(yv);
+    if (exchange.is_none()) {
     check_rc(slak_bn3_backward_local(ds.data_ptr(), yv.data_ptr(), yh.data_ptr(), ys.data_ptr(), fp(bnstats), gam, fpm(bcoef), fpm(dgam), fpm(dbet),
                                      d1.data_ptr(), d2.data_ptr(), d3.data_ptr(), s.N, s.C, s.P, ws.p, ws.n, st), "slak_bn3_backward_local");
+    } else {
+        if (!work.is_none()) work.attr("wait")();                  // stream-side wait (RCCL) / host wait (gloo): the weight gradients are already queued
+        const bool has_cd = count_dev.has_value() && count_dev->defined();
+        check_rc(slak_bn3_backward_apply(ds.data_ptr(), yv.data_ptr(), yh.data_ptr(), ys.data_ptr(), fp(gsums), fp(lsums), (double)s.N * (double)s.P,
+                                         has_cd ? (const double*)count_dev->data_ptr() : nullptr, fp(bnstats), gam, fpm(bcoef), fpm(dgam), fpm(dbet),
+                                         d1.data_ptr(), d2.data_ptr(), d3.data_ptr(), s.N, s.C, s.P, st), "slak_bn3_backward_apply");
+    }
     // three branch convs: the summed data gradient, the three weight gradients
     Tensor dx16 = at::empty_like(x16);
     Tensor dwv = at::empty_like(wv), dwh = at::empty_like(wh), dws = at::empty_like(wsm);

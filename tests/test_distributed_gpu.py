@@ -51,36 +51,49 @@ def _worker(rank, world, port, out):
     res["w"] = {k: v.detach().float().cpu() for k, v in blk.state_dict().items()}
     # the same block step with the block as ONE autograd node (block_ops.fused_block): its backward issues the SyncBatchNorm all-reduce of the
     # backward sums ASYNCHRONOUSLY, launches the two pointwise weight gradients behind it and only then waits -- the ordering is recorded here
-    events = []
     orig_ar, orig_wg = block_ops._sync_bn_all_reduce, block_ops._mlp_bwd_weights
-    def ar(buf, group, async_op=False):
-        events.append("all_reduce(async=%d, %d)" % (int(async_op), buf.numel()))
-        w = orig_ar(buf, group, async_op=async_op)
-        if w is None:
-            return None
-        class _W:                                                     # (the Work object itself takes no attributes)
-            def wait(self_, *a, **k):
-                events.append("wait")
-                return w.wait(*a, **k)
-        return _W()
-    def wg(*a, **k):
-        events.append("pointwise_wgrads")
-        return orig_wg(*a, **k)
-    block_ops._sync_bn_all_reduce, block_ops._mlp_bwd_weights = ar, wg
-    torch.manual_seed(1)
-    M.ReparamLargeKernelConv.fused_tri = True; M.Block.fused_block = True
-    blk1 = M.Block(16, drop_path=0.0, layer_scale_init_value=0.5, kernel_size=(13, 5), Decom=True, bn=True, lowp_dwconv=True).to(dev)
-    ddp1 = nn.parallel.DistributedDataParallel(blk1, device_ids=[0])
-    opt1 = torch.optim.SGD(ddp1.parameters(), lr=0.1)
-    xfull1 = torch.randn(8, 16, 14, 14, device=dev)
-    with torch.autocast("cuda", dtype=torch.bfloat16):
-        loss1 = ddp1(xfull1[rank * 4:(rank + 1) * 4]).float().pow(2).mean()
-    events.append("backward")
-    loss1.backward()
-    opt1.step()
-    block_ops._sync_bn_all_reduce, block_ops._mlp_bwd_weights = orig_ar, orig_wg
-    res["w_one_node"] = {k: v.detach().float().cpu() for k, v in blk1.state_dict().items()}
-    res["events_one_node"] = events
+    have_runner = block_ops._runner() is not None
+    for variant in ("python", "runner"):                              # round 5: the C++ block runner issues the SyncBatchNorm path too (callbacks for the exchange)
+        if variant == "runner" and not have_runner:
+            continue
+        events = []
+        def ar(buf, group, async_op=False):
+            events.append("all_reduce(async=%d, %d)" % (int(async_op), buf.numel()))
+            w = orig_ar(buf, group, async_op=async_op)
+            if w is None:
+                return None
+            class _W:                                                 # (the Work object itself takes no attributes)
+                def wait(self_, *a, **k):
+                    events.append("wait")
+                    return w.wait(*a, **k)
+            return _W()
+        def wg(*a, **k):
+            events.append("pointwise_wgrads")
+            return orig_wg(*a, **k)
+        block_ops._sync_bn_all_reduce, block_ops._mlp_bwd_weights = ar, wg
+        saved_mod = block_ops._runner_mod
+        if variant == "python":
+            block_ops._runner_mod = None
+        else:
+            block_ops._runner_trace = events.append
+        try:
+            torch.manual_seed(1)
+            M.ReparamLargeKernelConv.fused_tri = True; M.Block.fused_block = True
+            blk1 = M.Block(16, drop_path=0.0, layer_scale_init_value=0.5, kernel_size=(13, 5), Decom=True, bn=True, lowp_dwconv=True).to(dev)
+            ddp1 = nn.parallel.DistributedDataParallel(blk1, device_ids=[0])
+            opt1 = torch.optim.SGD(ddp1.parameters(), lr=0.1)
+            xfull1 = torch.randn(8, 16, 14, 14, device=dev)
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                loss1 = ddp1(xfull1[rank * 4:(rank + 1) * 4]).float().pow(2).mean()
+            events.append("backward")
+            loss1.backward()
+            opt1.step()
+        finally:
+            block_ops._sync_bn_all_reduce, block_ops._mlp_bwd_weights = orig_ar, orig_wg
+            block_ops._runner_mod, block_ops._runner_trace = saved_mod, None
+        suffix = "" if variant == "python" else "_runner"
+        res["w_one_node" + suffix] = {k: v.detach().float().cpu() for k, v in blk1.state_dict().items()}
+        res["events_one_node" + suffix] = events
     # the bench's N > 1 configuration in miniature: whole (narrow) SLaK under DDP with every fused op, the bf16 hand-off between
     # blocks, cached bf16 weights and Masking prune-and-grow: ranks must stay bit-identical (weights and masks)
     import types, contextlib, io
@@ -180,10 +193,14 @@ def test_two_ranks_match_single_process(gpu, tmp_path):
         assert (got["w"][k] - ref).abs().max() <= 2e-2 * max(1e-3, ref.abs().max().item()) + 1e-5, k
         assert (got["w_one_node"][k] - ref).abs().max() <= 2e-2 * max(1e-3, ref.abs().max().item()) + 1e-5, k      # the one-node block, same step
     # the one-node block's backward: all-reduce of the 4C backward sums issued asynchronously, THEN the pointwise weight gradients, THEN the wait
-    ev = got["events_one_node"]
-    bw = ev[ev.index("backward") + 1:]
-    assert bw[:3] == ["all_reduce(async=1, 64)", "pointwise_wgrads", "wait"], ev
-    assert ev[0].startswith("all_reduce(async=0, ")                          # forward: the statistics exchange the apply pass needs at once
+    assert "events_one_node_runner" in got, "the C++ block runner was not loaded in the workers (built by __graft_entry__.build())"
+    for key in ("events_one_node", "events_one_node_runner"):               # the Python node, and the same block issued by the C++ runner (round 5)
+        ev = got[key]
+        bw = ev[ev.index("backward") + 1:]
+        assert bw[:3] == ["all_reduce(async=1, 64)", "pointwise_wgrads", "wait"], (key, ev)
+        assert ev[0].startswith("all_reduce(async=0, ")                      # forward: the statistics exchange the apply pass needs at once
+    for k, v in got["w_one_node"].items():                                   # same launches on the same operands: bit-identical weights after the step
+        assert torch.equal(v, got["w_one_node_runner"][k]), k
 
 
 def test_bench_n_gt_1_path_runs_with_two_ranks_on_one_gpu():
@@ -208,3 +225,27 @@ def test_bench_n_gt_1_path_runs_with_two_ranks_on_one_gpu():
     assert d["config"]["mask_sync"]["ranks_agree"] is True and d["config"]["mask_sync"]["resyncs"] == 0
     assert "configs[2]" in d["config"]["workload"] and d["value"] > 0
     assert abs(d["value"] - 16 * d["steps"] / (d["ms_per_step"] * d["steps"] / 1e3)) <= 1e-6 * d["value"]      # whole-job images/s from the max-over-ranks time
+
+
+def test_bench_force_dist_executes_the_rccl_path_on_one_gpu():
+    """`bench.py --force-dist` -- world size 1, init_process_group("nccl") (= RCCL), DistributedDataParallel around the model, the fused
+    SyncBatchNorm exchange forced on (18 blocking forward all-reduces + 18 asynchronous backward ones per step), Masking with args.distributed = True.  RCCL's
+    communicator creation, DDP's reducer hooks and the async backward all-reduce EXECUTE; the C++ block runner issues the blocks (config.block_runner)."""
+    import json
+    import socket
+    import subprocess
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--force-dist", "--steps", "3", "--warmup", "1", "--prime", "2", "--batch", "16",
+           "--sparsity", "0.4", "--update-frequency", "2", "--no-roofline", "--no-mask-bench", "--no-cpu-baseline", "--debug-mask-sync"]
+    env = dict(os.environ, SLAK_TUNED_GEMMS="0", OMP_NUM_THREADS="4", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    c = d["config"]
+    assert c["backend"] == "nccl" and c["rccl_version"] and c["world_size"] == 1 and c["forced_distributed"] is True
+    assert c["block_runner"] is True and c["sync_bn"] is True
+    assert c["mask_sync"]["ranks_agree"] is True and d["value"] > 0 and d["n_gpus"] == 1
+    import math
+    assert math.isfinite(c["final_loss"])
