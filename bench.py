@@ -702,7 +702,12 @@ def main():
     if rank == 0 and n_gpus == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(min(os.cpu_count() or 1, 32), stages, label)   # >32 threads only oversubscribes a 96-channel depthwise conv
     if rank == 0:
-        print(json.dumps(out))
+        try:                                                        # text that C libraries left in the C stdio buffer (RCCL's NCCL_DEBUG=VERSION banner) goes out FIRST,
+            import ctypes                                           # so that the JSON line is the last line of stdout whatever the buffering
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        print(json.dumps(out), flush=True)
     if distributed:
         dist.barrier()
         dist.destroy_process_group()
