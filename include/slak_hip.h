@@ -57,7 +57,7 @@ typedef enum { SLAK_ALGO_AUTO = 0, SLAK_ALGO_DIRECT = 1, SLAK_ALGO_MFMA = 2 } sl
 const char* slak_status_string(int status);
 const char* slak_last_hip_error(void);      /* text of the last HIP error seen by this library */
 /* ABI version: bumped whenever an entry point's argument list or meaning changes (round 5: 5).  A host module compiled against this header
- * (slak_amd/pybind/*.cpp) records the value it saw and refuses to load on a library that reports another one: a stale module would call raw-pointer
+ * (slak_amd/pybind, *.cpp) records the value it saw and refuses to load on a library that reports another one: a stale module would call raw-pointer
  * entry points with a changed argument list -- silent corruption, not an error. */
 #define SLAK_ABI_VERSION 5
 int slak_version(void);                     /* == SLAK_ABI_VERSION of the header the library was built from */
@@ -292,6 +292,22 @@ int slak_linear_nt_gelu_bwd_supported(int M, int N, int K);
 size_t slak_linear_nt_gelu_bwd_workspace_bytes(int M, int N, int K);
 int slak_linear_nt_gelu_bwd(const void* dz_bf16, const void* wt_bf16, const void* y1_bf16, void* dy1_bf16, float* dbias, int M, int N, int K,
                             void* workspace, size_t workspace_bytes, void* stream);
+
+/* Round 5 -- the pointwise Linear layers of stages 2-4 with their elementwise neighbours in the GEMM's epilogue (models/SLaK.py:156-165:
+ * pwconv1 -> nn.GELU() -> pwconv2, and their data gradients): out[M][N] = a[M][K] . b[N][K]^T, both operands K-contiguous (the nn.Linear weight as it is
+ * stored; the data gradients take its transpose), bf16 in and out, fp32 accumulate.  epilogue:
+ *   SLAK_EPI_BIAS   out = bf16(acc + bias)                                    bias [N] bf16 or NULL
+ *   SLAK_EPI_GELU   out = bf16(acc + bias), out2 = GELU(out)                  (exact erf form on the ROUNDED pre-activation, as F.gelu of a bf16 tensor; both
+ *                                                                              tensors are kept because nn.GELU's backward reads the pre-activation)
+ *   SLAK_EPI_DGELU  out = bf16(bf16(acc) * gelu'(y1)), dbias[N] = column sums of out   (y1 [M][N] bf16: the same dy1 bits as the GEMM followed by
+ *                                                                              slak_gelu_backward_bias; dbias fp32, fixed summation order; needs the workspace)
+ * Replaces on these stages: at::linear + at::gelu (two passes over [M][4C]) resp. at::mm + slak_gelu_backward_bias (the [M][4C] intermediate `dact`
+ * written and read back).  Covered: N % 128 == 0, K % 32 == 0, M >= 1, tensors below 4 GiB; anything else SLAK_ERR_UNSUPPORTED (library GEMM + pass). */
+enum { SLAK_EPI_BIAS = 0, SLAK_EPI_GELU = 1, SLAK_EPI_DGELU = 2 };
+int slak_linear_gemm_supported(int M, int N, int K, int epilogue);
+size_t slak_linear_gemm_workspace_bytes(int M, int N, int K, int epilogue);
+int slak_linear_gemm(const void* a_bf16, const void* b_bf16, const void* bias_bf16, void* out_bf16, void* out2_bf16, const void* y1_bf16, float* dbias,
+                     int M, int N, int K, int epilogue, void* workspace, size_t workspace_bytes, void* stream);
 
 /* Weight gradient of the pointwise Linear layers (models/SLaK.py:117-118 pwconv1 / pwconv2; autograd's dW = dY^T X):
  * d[N1][N2] (fp32) = x1^T x2 over the M rows of x1 [M][N1] and x2 [M][N2] (bf16, row-major), fp32 accumulate, summed in a fixed

@@ -1,0 +1,81 @@
+"""dev: slak_linear_gemm (csrc/linear_gemm.hip) against the library GEMM + elementwise pass it replaces, at the SLaK-T bs-128 shapes of stages 2-4;
+also checks the results (fp64 product of the bf16 operands)."""
+import ctypes, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch, torch.nn.functional as F
+from slak_amd import _lib
+dev = torch.device("cuda:0")
+L = _lib.lib()
+st = torch.cuda.current_stream().cuda_stream
+def ev(fn, reps=20):
+    for _ in range(5): fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize(); e0.record()
+    for _ in range(reps): fn()
+    e1.record(); e1.synchronize()
+    return e0.elapsed_time(e1) / reps * 1e3
+def gemm(a, b, bias, epi, y1=None):
+    M, K = a.shape; N = b.shape[0]
+    out = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+    out2 = torch.empty_like(out) if epi == 1 else None
+    db = torch.empty(N, device=dev, dtype=torch.float32) if epi == 2 else None
+    nb = L.slak_linear_gemm_workspace_bytes(M, N, K, epi)
+    ws = torch.empty(max(nb, 16), device=dev, dtype=torch.uint8)
+    def run():
+        _lib.check(L.slak_linear_gemm(a.data_ptr(), b.data_ptr(), bias.data_ptr() if bias is not None else None, out.data_ptr(),
+                                      out2.data_ptr() if out2 is not None else None, y1.data_ptr() if y1 is not None else None,
+                                      db.data_ptr() if db is not None else None, M, N, K, epi, ws.data_ptr(), nb, st), "slak_linear_gemm")
+    return run, out, out2, db
+shapes = [(192, 28), (384, 14), (768, 7)]
+if len(sys.argv) > 1:
+    shapes = [s for s in shapes if str(s[0]) in sys.argv[1:]]
+for (C, HW) in shapes:
+    M = 128 * HW * HW
+    torch.manual_seed(C)
+    t = torch.randn(M, C, device=dev).bfloat16(); w1 = (torch.randn(4 * C, C, device=dev) * 0.05).bfloat16(); b1 = torch.randn(4 * C, device=dev).bfloat16()
+    w2 = (torch.randn(C, 4 * C, device=dev) * 0.05).bfloat16(); b2 = torch.randn(C, device=dev).bfloat16()
+    dz = torch.randn(M, C, device=dev).bfloat16()
+    w2t = w2.t().contiguous(); w1t = w1.t().contiguous()
+    if not L.slak_linear_gemm_supported(M, 4 * C, C, 1):
+        print("C=%d: not covered" % C); continue
+    # ---- EPI_GELU: pwconv1 + GELU
+    run, y1, a, _ = gemm(t, w1, b1, 1); run(); torch.cuda.synchronize()
+    idx = torch.randint(0, M, (2048,), device=dev)
+    ref = (t[idx].double() @ w1.double().t() + b1.double())
+    err = (y1[idx].double() - ref).abs(); bound = 2.0 ** -8 * ref.abs() + 1e-5 * ref.abs().max()
+    ok1 = bool((err <= bound).all())
+    want = F.gelu(y1.float()).to(torch.bfloat16)
+    d = (a.float() - want.float()).abs()
+    ok2 = bool((d <= 2.0 ** -7 * want.float().abs() + 1e-6).all()); same = (d == 0).float().mean().item()
+    us_f = ev(run); us_lib = ev(lambda: F.linear(t, w1, b1)); us_g = ev(lambda: F.gelu(y1))
+    print("C=%d M=%d pwconv1+GELU: own %.1f us | library %.1f + gelu %.1f = %.1f us | y1 ok %s, gelu ok %s (identical %.4f)" % (C, M, us_f, us_lib, us_g, us_lib + us_g, ok1, ok2, same))
+    # ---- EPI_DGELU: dz W2, GELU', bias gradient
+    run, dy1, _, db1 = gemm(dz, w2t, None, 2, y1=y1); run(); torch.cuda.synchronize()
+    dact = torch.mm(dz, w2)
+    nb = L.slak_gelu_bwd_workspace_bytes(M, 4 * C); ws = torch.empty(nb, device=dev, dtype=torch.uint8)
+    dy1_ref = torch.empty_like(dact); db_ref = torch.empty(4 * C, device=dev)
+    def gb():
+        _lib.check(L.slak_gelu_backward_bias(dact.data_ptr(), y1.data_ptr(), dy1_ref.data_ptr(), db_ref.data_ptr(), M, 4 * C, ws.data_ptr(), nb, st), "gelu_bwd")
+    gb(); torch.cuda.synchronize()
+    # dact differs from the library's in accumulation order (one bf16 ulp here and there): compare against the fp64 product on a sample
+    ref = (dz[idx].double() @ w2.double())
+    gp = torch.autograd.functional.jacobian  # unused
+    yy = y1[idx].double(); gprime = 0.5 * (1 + torch.erf(yy / 2 ** 0.5)) + yy * torch.exp(-0.5 * yy * yy) / (2 * torch.pi) ** 0.5
+    want = ref * gprime
+    err = (dy1[idx].double() - want).abs(); bound = 2.0 ** -7 * want.abs() + 2.0 ** -8 * ref.abs() + 1e-6
+    ok3 = bool((err <= bound).all())
+    ok4 = bool(torch.allclose(db1, dy1.float().sum(0), rtol=2e-3, atol=1e-2 * dy1.float().abs().sum(0).max().item() / M ** 0.5))
+    same = (dy1 == dy1_ref).float().mean().item()
+    us_f = ev(run); us_lib = ev(lambda: torch.mm(dz, w2)); us_g = ev(gb)
+    print("C=%d M=%d dz.W2+GELU': own %.1f us | library %.1f + gelu' %.1f = %.1f us | dy1 ok %s (identical to the two launches %.4f), dbias ok %s" % (C, M, us_f, us_lib, us_g, us_lib + us_g, ok3, same, ok4))
+    # ---- EPI_BIAS: pwconv2 and dy1 . W1
+    continue
+    run, z, _, _ = gemm(a, w2, b2, 0); run(); torch.cuda.synchronize()
+    ref = (a[idx].double() @ w2.double().t() + b2.double())
+    err = (z[idx].double() - ref).abs(); ok5 = bool((err <= 2.0 ** -8 * ref.abs() + 1e-5 * ref.abs().max()).all())
+    us_f = ev(run); us_lib = ev(lambda: F.linear(a, w2, b2))
+    run2, dt, _, _ = gemm(dy1, w1t, None, 0); run2(); torch.cuda.synchronize()
+    ref = (dy1[idx].double() @ w1.double())
+    err = (dt[idx].double() - ref).abs(); ok6 = bool((err <= 2.0 ** -8 * ref.abs() + 1e-5 * ref.abs().max()).all())
+    us_f2 = ev(run2); us_lib2 = ev(lambda: torch.mm(dy1, w1))
+    print("C=%d M=%d pwconv2: own %.1f us | library %.1f us (ok %s);  dy1.W1: own %.1f us | library %.1f us (ok %s)" % (C, M, us_f, us_lib, ok5, us_f2, us_lib2, ok6))
