@@ -882,6 +882,45 @@ def linear_nt(x, wt, bias=None, gelu=False):
     return (y, g) if gelu else y
 
 
+use_linear_gemm = os.environ.get("SLAK_LINEAR_GEMM", "1") != "0"          # csrc/linear_gemm.hip: pwconv1 + GELU resp. dz W2 + GELU' + bias gradient as ONE launch on stages 2-3 (round 5); 0: library GEMM + elementwise pass
+
+
+def linear_gemm_gelu(t, w1b, b1b):
+    """(y1, a) = (t @ w1b.T + b1b, GELU(y1)) in one launch (slak_linear_gemm, SLAK_EPI_GELU), or None when the shape is not covered."""
+    if not (use_linear_gemm and t.is_cuda and t.dtype == torch.bfloat16 and t.is_contiguous() and w1b.dtype == torch.bfloat16 and w1b.is_contiguous()):
+        return None
+    K, N = w1b.shape[1], w1b.shape[0]
+    M = t.numel() // K
+    L = _lib.lib()
+    if b1b is None or b1b.dtype != torch.bfloat16 or not L.slak_linear_gemm_supported(M, N, K, 1):
+        return None
+    y1 = torch.empty(t.shape[:-1] + (N,), dtype=torch.bfloat16, device=t.device)
+    a = torch.empty_like(y1)
+    with _on(t.device):
+        _lib.check(L.slak_linear_gemm(t.data_ptr(), w1b.data_ptr(), b1b.data_ptr(), y1.data_ptr(), a.data_ptr(), None, None, M, N, K, 1, None, 0,
+                                      _stream(t.device)), "slak_linear_gemm")
+    return y1, a
+
+
+def linear_gemm_dgelu(dz2, w2t, y12):
+    """(dy1, db1) = (round(dz2 @ w2t.T) * gelu'(y12), column sums of dy1) in one launch (SLAK_EPI_DGELU), or None when the shape is not covered."""
+    if not (use_linear_gemm and dz2.is_cuda and dz2.dtype == torch.bfloat16 and dz2.is_contiguous() and w2t.dtype == torch.bfloat16 and w2t.is_contiguous()
+            and y12.dtype == torch.bfloat16 and y12.is_contiguous()):
+        return None
+    M, K = dz2.shape
+    N = w2t.shape[0]
+    L = _lib.lib()
+    if tuple(y12.shape) != (M, N) or not L.slak_linear_gemm_supported(M, N, K, 2):
+        return None
+    dy1 = torch.empty((M, N), dtype=torch.bfloat16, device=dz2.device)
+    db1 = torch.empty(N, dtype=torch.float32, device=dz2.device)
+    ws, nb = _workspace(int(L.slak_linear_gemm_workspace_bytes(M, N, K, 2)), dz2.device)
+    with _on(dz2.device):
+        _lib.check(L.slak_linear_gemm(dz2.data_ptr(), w2t.data_ptr(), None, dy1.data_ptr(), None, y12.data_ptr(), db1.data_ptr(), M, N, K, 2,
+                                      ws.data_ptr() if ws is not None else None, nb, _stream(dz2.device)), "slak_linear_gemm")
+    return dy1, db1
+
+
 def _mlp_fwd(t, w1, b1, w2, b2):
     F = torch.nn.functional
     w1b, w2b = lowp_param(w1), lowp_param(w2)
@@ -900,6 +939,8 @@ def _mlp_fwd(t, w1, b1, w2, b2):
                                              z.data_ptr(), M, C, C4, _stream(t.device)), "slak_linear_mlp_fwd")
         return z, (t, w1b, y1, a, w2b)
     r = linear_nt(t, w1b, lowp_param(b1), gelu=True)            # pwconv1 + GELU in one streaming pass on the large maps
+    if r is None and b1 is not None:
+        r = linear_gemm_gelu(t, w1b, lowp_param(b1))            # stages 2-3: the GEMM with bias, rounding and GELU in its epilogue (y1 AND a in one launch)
     if r is not None:
         y1, a = r
     else:
@@ -947,6 +988,12 @@ def _mlp_bwd_data(saved, dz):
         with _on(dz2.device):
             _lib.check(L.slak_linear_nt_gelu_bwd(dz2.data_ptr(), w2t.data_ptr(), y12.data_ptr(), dy1.data_ptr(), db1.data_ptr(), M, N4, dz2.shape[1],
                                                  ws.data_ptr(), nb, _stream(dz2.device)), "slak_linear_nt_gelu_bwd")
+        dt = linear_nt(dy1, w1b.t().contiguous()) if linear_nt_covers(dy1, w1b.shape[1]) else None
+        dt = (dt if dt is not None else torch.mm(dy1, w1b)).view_as(t)
+        return dt, dy1, db1
+    r = linear_gemm_dgelu(dz2, w2b.t().contiguous(), y12) if (dz2.is_contiguous() and y12.is_contiguous()) else None
+    if r is not None:                                            # stages 2-3: dz @ W2 with GELU' and pwconv1's bias gradient in the GEMM's epilogue
+        dy1, db1 = r
         dt = linear_nt(dy1, w1b.t().contiguous()) if linear_nt_covers(dy1, w1b.shape[1]) else None
         dt = (dt if dt is not None else torch.mm(dy1, w1b)).view_as(t)
         return dt, dy1, db1
@@ -1052,8 +1099,8 @@ _force_bn_exchange = os.environ.get("SLAK_FORCE_BN_EXCHANGE", "0") == "1"   # be
 def _runner_switches():
     """The development switches that select paths only the Python sequence knows: with any of them off their default the runner steps aside, so an
     A/B run measures what its switch says.  Read on every call: a test may flip a switch after the first block has run."""
-    return (use_skinny_linear and use_linear_wgrad and _SPLITK_ROWS == 6272 and fused_tri_backward and fused_tri_wgrad and bn_stats_in_conv
-            and accumulate_dgrad and os.environ.get("SLAK_BLOCK_RUNNER", "1") != "0")
+    return (use_skinny_linear and use_linear_wgrad and use_linear_gemm and _SPLITK_ROWS == 6272 and fused_tri_backward and fused_tri_wgrad
+            and bn_stats_in_conv and accumulate_dgrad and os.environ.get("SLAK_BLOCK_RUNNER", "1") != "0")
 
 
 def _runner():

@@ -74,7 +74,7 @@ Side& side_of(int dev) {
 struct Shape { int N, C, H, W, K, P, M, C4; };
 
 // what the library answers for a block shape, asked once
-struct Plan { bool ok; int rows; size_t ws; bool nt1, nt2, ntd1, ntd2, wg1, wg2, bwd1, gbwd, mlp1; size_t off[5], len[5]; };   // off/len: the backward's deferred-reduction regions behind the common scratch
+struct Plan { bool ok; int rows; size_t ws; bool nt1, nt2, ntd1, ntd2, wg1, wg2, bwd1, gbwd, mlp1, gg1, gg2; size_t off[5], len[5]; };   // off/len: the backward's deferred-reduction regions behind the common scratch
 const Plan& plan_of(const Shape& s) {
     static std::map<std::vector<int>, Plan> cache;
     const std::vector<int> key = {s.N, s.C, s.H, s.W, s.K, s.C4};
@@ -96,6 +96,8 @@ const Plan& plan_of(const Shape& s) {
     p.bwd1 = slak_dwconv2d_tri_backward_supported(dt, s.N, s.C, s.H, s.W, s.K) == 1;
     p.gbwd = slak_linear_nt_gelu_bwd_supported(s.M, s.C4, s.C) == 1;
     p.mlp1 = slak_linear_mlp_fwd_supported(s.M, s.C, s.C4) == 1;
+    p.gg1 = slak_linear_gemm_supported(s.M, s.C4, s.C, SLAK_EPI_GELU) == 1;    // stages 2-3: pwconv1 + GELU as one GEMM launch (round 5)
+    p.gg2 = slak_linear_gemm_supported(s.M, s.C4, s.C, SLAK_EPI_DGELU) == 1;   //             dz W2 + GELU' + pwconv1's bias gradient
     size_t ws = std::max(wtri, slak_bn3_workspace_bytes(s.N, s.C));
     ws = std::max(ws, slak_block_tail_workspace_bytes(s.N, s.C, s.P));
     ws = std::max(ws, slak_gelu_bwd_workspace_bytes(s.M, s.C4));
@@ -108,6 +110,7 @@ const Plan& plan_of(const Shape& s) {
     const size_t tail = slak_block_tail_workspace_bytes(s.N, s.C, s.P);
     p.len[0] = tail; p.len[2] = tail;
     p.len[1] = std::max(slak_gelu_bwd_workspace_bytes(s.M, s.C4), p.gbwd ? slak_linear_nt_gelu_bwd_workspace_bytes(s.M, s.C4, s.C) : (size_t)0);
+    if (p.gg2) p.len[1] = std::max(p.len[1], slak_linear_gemm_workspace_bytes(s.M, s.C4, s.C, SLAK_EPI_DGELU));
     p.len[3] = p.wg1 ? slak_linear_wgrad_workspace_bytes(s.M, s.C4, s.C) : 0;
     p.len[4] = p.wg2 ? slak_linear_wgrad_workspace_bytes(s.M, s.C, s.C4) : 0;
     size_t o = up(ws);
@@ -189,6 +192,10 @@ std::vector<Tensor> block_forward(const Tensor& x, const c10::optional<Tensor>& 
     if (pl.nt1) {
         y1m = at::empty({s.N, s.H, s.W, s.C4}, x16.options()); a = at::empty_like(y1m);
         check_rc(slak_linear_nt(t.data_ptr(), w1b.data_ptr(), bb1b.data_ptr(), y1m.data_ptr(), a.data_ptr(), s.M, s.C4, s.C, st), "slak_linear_nt");
+    } else if (pl.gg1) {                                           // stages 2-3: bias, rounding and GELU in the GEMM's epilogue
+        y1m = at::empty({s.N, s.H, s.W, s.C4}, x16.options()); a = at::empty_like(y1m);
+        check_rc(slak_linear_gemm(t.data_ptr(), w1b.data_ptr(), bb1b.data_ptr(), y1m.data_ptr(), a.data_ptr(), nullptr, nullptr, s.M, s.C4, s.C, SLAK_EPI_GELU,
+                                  nullptr, 0, st), "slak_linear_gemm");
     } else {
         y1m = at::linear(t, w1b, bb1b);
         a = at::gelu(y1m);
@@ -267,6 +274,11 @@ std::vector<Tensor> block_backward(const Tensor& x16, const Tensor& wv, const Te
         dy1 = at::empty({s.M, s.C4}, x16.options());
         check_rc(slak_linear_nt_gelu_bwd(dz2.data_ptr(), w2t.data_ptr(), y1m.data_ptr(), dy1.data_ptr(), fpm(db1), s.M, s.C4, s.C, region(1).p, region(1).n, st),
                  "slak_linear_nt_gelu_bwd");
+    } else if (pl.gg2) {                                           // stages 2-3: dz W2 with GELU' and pwconv1's bias gradient in the GEMM's epilogue
+        Tensor w2t = w2b.t().contiguous();
+        dy1 = at::empty({s.M, s.C4}, x16.options());
+        check_rc(slak_linear_gemm(dz2.data_ptr(), w2t.data_ptr(), nullptr, dy1.data_ptr(), nullptr, y1m.data_ptr(), fpm(db1), s.M, s.C4, s.C, SLAK_EPI_DGELU,
+                                  region(1).p, region(1).n, st), "slak_linear_gemm");
     } else {
     if (pl.ntd1) {
         Tensor w2t = w2b.t().contiguous();
