@@ -309,6 +309,11 @@ size_t slak_linear_gemm_workspace_bytes(int M, int N, int K, int epilogue);
 int slak_linear_gemm(const void* a_bf16, const void* b_bf16, const void* bias_bf16, void* out_bf16, void* out2_bf16, const void* y1_bf16, float* dbias,
                      int M, int N, int K, int epilogue, void* workspace, size_t workspace_bytes, void* stream);
 
+/* Transposed bf16 copies dst[i] [cols][rows] of src[i] [rows][cols] (rows, cols multiples of 8) for n matrices in ONE launch (host arrays of device
+ * pointers): the pointwise weights as the data-gradient GEMMs read them (dz . W2, dy1 . W1: models/SLaK.py:158-160 backwards).  Replaces one strided copy
+ * kernel per weight, block and step (25 launches per SLaK-T step) by one launch per optimizer step (slak_amd/block_ops.lowp_param_t caches by version). */
+int slak_transpose_bf16_batch(const void* const* src, void* const* dst, const int* rows, const int* cols, int n, void* stream);
+
 /* Weight gradient of the pointwise Linear layers (models/SLaK.py:117-118 pwconv1 / pwconv2; autograd's dW = dY^T X):
  * d[N1][N2] (fp32) = x1^T x2 over the M rows of x1 [M][N1] and x2 [M][N2] (bf16, row-major), fp32 accumulate, summed in a fixed
  * order (deterministic).  Covered: N1 and N2 multiples of 192, or one of them 96 and the other a multiple of 384 (the ConvNeXt widths

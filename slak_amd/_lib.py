@@ -126,6 +126,7 @@ SIGNATURES = {
     "slak_linear_gemm_supported": (_i, [_i, _i, _i, _i]),
     "slak_linear_gemm_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "slak_linear_gemm": (_i, [_vp] * 7 + [_i, _i, _i, _i, _vp, _sz, _vp]),
+    "slak_transpose_bf16_batch": (_i, [_vp, _vp, _vp, _vp, _i, _vp]),
     "slak_linear_wgrad_supported": (_i, [_i, _i, _i]),
     "slak_linear_wgrad_workspace_bytes": (_sz, [_i, _i, _i]),
     "slak_linear_wgrad": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _sz, _vp]),

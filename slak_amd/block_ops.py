@@ -827,6 +827,44 @@ def _refresh_lowp():
             torch._foreach_copy_(dsts, srcs)
 
 
+# Transposed bf16 copies of the pointwise weights (what dz . W2 and dy1 . W1 read), cached by the parameter's version like the copies above and refreshed --
+# ALL stale ones in ONE launch (slak_transpose_bf16_batch) -- at the first use after an optimizer step.  Without the cache (the default outside bench.py) a
+# call makes its own transposed copy, as autograd's path does.
+_lowp_t_cache = {}
+
+
+def lowp_param_t(p):
+    if not cache_lowp_weights or p.dim() != 2 or p.shape[0] % 8 or p.shape[1] % 8 or not p.is_cuda:
+        return p.to(torch.bfloat16).t().contiguous()
+    src = lowp_param(p)
+    e = _lowp_t_cache.get(id(p))
+    if e is not None and e[0]() is p and e[2].device == p.device and e[1] == p._version:
+        return e[2]
+    if e is None or e[0]() is not p or e[2].device != p.device:
+        _lowp_t_cache[id(p)] = e = [_weakref.ref(p), None, torch.empty((p.shape[1], p.shape[0]), dtype=torch.bfloat16, device=p.device)]
+    # refresh every stale transpose of this device in one launch (their bf16 sources are current: lowp_param() above refreshed them all)
+    jobs, dead = [], []
+    for key, ee in _lowp_t_cache.items():
+        q = ee[0]()
+        if q is None:
+            dead.append(key)
+        elif ee[1] != q._version and ee[2].device == p.device:
+            jobs.append((lowp_param(q), ee))
+    for key in dead:
+        del _lowp_t_cache[key]
+    import ctypes
+    n = len(jobs)
+    srcs = (ctypes.c_void_p * n)(*[sq.data_ptr() for sq, _ in jobs])
+    dsts = (ctypes.c_void_p * n)(*[ee[2].data_ptr() for _, ee in jobs])
+    rows = (ctypes.c_int * n)(*[sq.shape[0] for sq, _ in jobs])
+    cols = (ctypes.c_int * n)(*[sq.shape[1] for sq, _ in jobs])
+    with _on(p.device):
+        _lib.check(_lib.lib().slak_transpose_bf16_batch(srcs, dsts, rows, cols, n, _stream(p.device)), "slak_transpose_bf16_batch")
+    for sq, ee in jobs:
+        ee[1] = ee[0]()._version
+    return e[2]
+
+
 _SPLITK_ROWS = int(_os.environ.get("SLAK_SPLITK_ROWS", "6272"))     # rows per split of the weight-gradient GEMMs (0: one plain GEMM)
 
 
@@ -969,9 +1007,12 @@ def _mlp_wgrad(dy, x):
 _gelu_ws_cache = {}
 
 
-def _mlp_bwd_data(saved, dz):
-    """The data path of the MLP's backward: dz -> dact -> (GELU') dy1 (+ pwconv1's bias gradient) -> dt.  -> (dt, dy1 [M][4C], db1)"""
+def _mlp_bwd_data(saved, dz, wts=None):
+    """The data path of the MLP's backward: dz -> dact -> (GELU') dy1 (+ pwconv1's bias gradient) -> dt.  -> (dt, dy1 [M][4C], db1)
+    wts: (w1b^T, w2b^T) when the caller holds the cached transposed copies (lowp_param_t), else they are made here."""
     t, w1b, y1, a, w2b = saved
+    w1t_of = (lambda: wts[0]) if wts is not None else (lambda: w1b.t().contiguous())
+    w2t_of = (lambda: wts[1]) if wts is not None else (lambda: w2b.t().contiguous())
     dz2 = dz.reshape(-1, dz.shape[-1])
     y12 = y1.reshape(-1, y1.shape[-1])
     M = dz2.shape[0]
@@ -983,22 +1024,22 @@ def _mlp_bwd_data(saved, dz):
         # stage 1: dz @ W2, GELU' and pwconv1's bias gradient in ONE pass (dact never reaches HBM)
         dy1 = torch.empty((M, N4), dtype=torch.bfloat16, device=dz2.device)
         db1 = torch.empty(N4, dtype=torch.float32, device=dz2.device)
-        w2t = w2b.t().contiguous()
+        w2t = w2t_of()
         ws, nb = _workspace(int(L.slak_linear_nt_gelu_bwd_workspace_bytes(M, N4, dz2.shape[1])), dz2.device)
         with _on(dz2.device):
             _lib.check(L.slak_linear_nt_gelu_bwd(dz2.data_ptr(), w2t.data_ptr(), y12.data_ptr(), dy1.data_ptr(), db1.data_ptr(), M, N4, dz2.shape[1],
                                                  ws.data_ptr(), nb, _stream(dz2.device)), "slak_linear_nt_gelu_bwd")
-        dt = linear_nt(dy1, w1b.t().contiguous()) if linear_nt_covers(dy1, w1b.shape[1]) else None
+        dt = linear_nt(dy1, w1t_of()) if linear_nt_covers(dy1, w1b.shape[1]) else None
         dt = (dt if dt is not None else torch.mm(dy1, w1b)).view_as(t)
         return dt, dy1, db1
-    r = linear_gemm_dgelu(dz2, w2b.t().contiguous(), y12) if (dz2.is_contiguous() and y12.is_contiguous()) else None
+    r = linear_gemm_dgelu(dz2, w2t_of(), y12) if (dz2.is_contiguous() and y12.is_contiguous()) else None
     if r is not None:                                            # stages 2-3: dz @ W2 with GELU' and pwconv1's bias gradient in the GEMM's epilogue
         dy1, db1 = r
-        dt = linear_nt(dy1, w1b.t().contiguous()) if linear_nt_covers(dy1, w1b.shape[1]) else None
+        dt = linear_nt(dy1, w1t_of()) if linear_nt_covers(dy1, w1b.shape[1]) else None
         dt = (dt if dt is not None else torch.mm(dy1, w1b)).view_as(t)
         return dt, dy1, db1
     if linear_nt_covers(dz2, w2b.shape[1]):
-        dact = linear_nt(dz2, w2b.t().contiguous())              # dz @ W2: NT against the (small) transposed weight
+        dact = linear_nt(dz2, w2t_of())              # dz @ W2: NT against the (small) transposed weight
     if dact is None:
         dact = torch.mm(dz2, w2b)
     dy1 = torch.empty_like(dact)
@@ -1011,7 +1052,7 @@ def _mlp_bwd_data(saved, dz):
     with _on(dact.device):
         _lib.check(L.slak_gelu_backward_bias(dact.data_ptr(), y12.data_ptr(), dy1.data_ptr(), db1.data_ptr(), M, dact.shape[1],
                                              ws.data_ptr() if ws is not None else None, nb, _stream(dact.device)), "slak_gelu_backward_bias")
-    dt = linear_nt(dy1, w1b.t().contiguous()) if linear_nt_covers(dy1, w1b.shape[1]) else None
+    dt = linear_nt(dy1, w1t_of()) if linear_nt_covers(dy1, w1b.shape[1]) else None
     dt = (dt if dt is not None else torch.mm(dy1, w1b)).view_as(t)
     return dt, dy1, db1
 
@@ -1154,7 +1195,8 @@ class _BlockFn(torch.autograd.Function):
                 pool = getattr(bns[0], "_slak_ctr_pool", None)
                 if not (pool is not None and pool.covers(bns) and pool.bump_once()):
                     torch._foreach_add_([bn.num_batches_tracked for bn in bns], 1)
-                ctx.save_for_backward(x16, wv, wh, ws, yv, yh, ys, g1, g2, g3, bnstats, s, lnw, mean, rstd, t, w1b, y1m, a, w2b, z, gamma, sample_scale)
+                wts = (lowp_param_t(w1), lowp_param_t(w2)) if cache_lowp_weights else (None, None)
+                ctx.save_for_backward(x16, wv, wh, ws, yv, yh, ys, g1, g2, g3, bnstats, s, lnw, mean, rstd, t, w1b, y1m, a, w2b, z, gamma, sample_scale, *wts)
                 ctx.misc = (True, group, float(x.shape[0] * x.shape[2] * x.shape[3]), count_dev, x.dtype, x_lowp is not None)
                 ctx.runner = True
                 ctx.set_materialize_grads(False)
@@ -1171,24 +1213,25 @@ class _BlockFn(torch.autograd.Function):
             z = z.to(torch.bfloat16)
         z = z.contiguous()
         out, out16 = _scale_residual_fwd(x, z, gamma, sample_scale, emit)
-        ctx.save_for_backward(x16, wv, wh, ws, yv, yh, ys, g1, g2, g3, bnstats, s, lnw, mean, rstd, *saved, z, gamma, sample_scale)
+        wts = (lowp_param_t(w1), lowp_param_t(w2)) if cache_lowp_weights else (None, None)
+        ctx.save_for_backward(x16, wv, wh, ws, yv, yh, ys, g1, g2, g3, bnstats, s, lnw, mean, rstd, *saved, z, gamma, sample_scale, *wts)
         ctx.misc = (tri_dgrad, group, count, count_dev, x.dtype, x_lowp is not None)
         ctx.set_materialize_grads(False)
         return (out, out16) if emit else out
 
     @staticmethod
     def backward(ctx, dout, dout16=None):
-        (x16, wv, wh, ws, yv, yh, ys, g1, g2, g3, bnstats, s, lnw, mean, rstd, t, w1b, y1m, a, w2b, z, gamma, sample_scale) = ctx.saved_tensors
+        (x16, wv, wh, ws, yv, yh, ys, g1, g2, g3, bnstats, s, lnw, mean, rstd, t, w1b, y1m, a, w2b, z, gamma, sample_scale, w1t, w2t) = ctx.saved_tensors
         tri_dgrad, group, count, count_dev, xdtype, had_lowp = ctx.misc
         if ctx.runner:
             exchange = None if group is None else (lambda buf, async_op: _sync_bn_all_reduce(buf, group, async_op=async_op))
             (dx, dxl, dwv, dwh, dws, dgam, dbet, dlnw, dlnb, dw1, db1, dw2, dzc, dgamma) = _runner_mod.block_backward(
                 x16, wv, wh, ws, yv, yh, ys, [g1, g2, g3], bnstats, s, lnw, mean, rstd, t, w1b, y1m, a, w2b, z, gamma, sample_scale, dout, dout16,
-                xdtype == torch.bfloat16, had_lowp, count_dev, exchange, _runner_trace)
+                xdtype == torch.bfloat16, had_lowp, count_dev, exchange, _runner_trace, w1t, w2t)
             return (dx, dxl, dwv, dwh, dws, dgam[0], dbet[0], dgam[1], dbet[1], dgam[2], dbet[2], dlnw, dlnb, dw1, db1, dw2, dzc, dgamma, None, None)
         saved = (t, w1b, y1m, a, w2b)
         dshortcut, dz, dgamma, dzc = _scale_residual_bwd(z, gamma, sample_scale, xdtype, dout, dout16)
-        dt, dy1, db1 = _mlp_bwd_data(saved, dz)
+        dt, dy1, db1 = _mlp_bwd_data(saved, dz, (w1t, w2t) if w1t is not None else None)
         ds, dlnw, dlnb = _ln_bwd_impl(dt, s, lnw, mean, rstd)
         wg = {}
 

@@ -240,7 +240,8 @@ std::vector<Tensor> block_backward(const Tensor& x16, const Tensor& wv, const Te
                                    const Tensor& mean, const Tensor& rstd, const Tensor& t, const Tensor& w1b, const Tensor& y1m, const Tensor& a,
                                    const Tensor& w2b, const Tensor& z, const Tensor& gamma, const c10::optional<Tensor>& sample_scale,
                                    const c10::optional<Tensor>& dout_opt, const c10::optional<Tensor>& dout16_opt, bool shortcut_bf16, bool had_lowp,
-                                   const c10::optional<Tensor>& count_dev, const pybind11::object& exchange, const pybind11::object& trace) {
+                                   const c10::optional<Tensor>& count_dev, const pybind11::object& exchange, const pybind11::object& trace,
+                                   const c10::optional<Tensor>& w1t_opt, const c10::optional<Tensor>& w2t_opt /* cached transposed bf16 weights, or None */) {
     const Shape s = shape_of(x16, wv, w1b);
     const Plan& pl = plan_of(s);
     TORCH_CHECK(pl.ok, "block_backward: the shape has no one-launch path (block_forward would have declined it)");
@@ -268,20 +269,22 @@ std::vector<Tensor> block_backward(const Tensor& x16, const Tensor& wv, const Te
     if (shortcut_bf16) dshortcut = dshortcut.to(at::kBFloat16);
     // the MLP's data path: dz -> dact -> (GELU') dy1 (+ pwconv1's bias gradient) -> dt
     Tensor dz2 = dz.view({s.M, s.C});
+    const auto w2t_of = [&] { return (w2t_opt.has_value() && w2t_opt->defined()) ? *w2t_opt : w2b.t().contiguous(); };
+    const auto w1t_of = [&] { return (w1t_opt.has_value() && w1t_opt->defined()) ? *w1t_opt : w1b.t().contiguous(); };
     Tensor dact, dy1, db1 = at::empty({s.C4}, f32);
     if (pl.gbwd) {                                                 // stage 1: dz W2, GELU' and pwconv1's bias gradient in one pass
-        Tensor w2t = w2b.t().contiguous();
+        Tensor w2t = w2t_of();
         dy1 = at::empty({s.M, s.C4}, x16.options());
         check_rc(slak_linear_nt_gelu_bwd(dz2.data_ptr(), w2t.data_ptr(), y1m.data_ptr(), dy1.data_ptr(), fpm(db1), s.M, s.C4, s.C, region(1).p, region(1).n, st),
                  "slak_linear_nt_gelu_bwd");
     } else if (pl.gg2) {                                           // stages 2-3: dz W2 with GELU' and pwconv1's bias gradient in the GEMM's epilogue
-        Tensor w2t = w2b.t().contiguous();
+        Tensor w2t = w2t_of();
         dy1 = at::empty({s.M, s.C4}, x16.options());
         check_rc(slak_linear_gemm(dz2.data_ptr(), w2t.data_ptr(), nullptr, dy1.data_ptr(), nullptr, y1m.data_ptr(), fpm(db1), s.M, s.C4, s.C, SLAK_EPI_DGELU,
                                   region(1).p, region(1).n, st), "slak_linear_gemm");
     } else {
     if (pl.ntd1) {
-        Tensor w2t = w2b.t().contiguous();
+        Tensor w2t = w2t_of();
         dact = at::empty({s.M, s.C4}, x16.options());
         check_rc(slak_linear_nt(dz2.data_ptr(), w2t.data_ptr(), nullptr, dact.data_ptr(), nullptr, s.M, s.C4, s.C, st), "slak_linear_nt");
     } else dact = at::mm(dz2, w2b);
@@ -290,7 +293,7 @@ std::vector<Tensor> block_backward(const Tensor& x16, const Tensor& wv, const Te
     }
     Tensor dt_;
     if (pl.ntd2) {
-        Tensor w1t = w1b.t().contiguous();
+        Tensor w1t = w1t_of();
         dt_ = at::empty({s.M, s.C}, x16.options());
         check_rc(slak_linear_nt(dy1.data_ptr(), w1t.data_ptr(), nullptr, dt_.data_ptr(), nullptr, s.M, s.C, s.C4, st), "slak_linear_nt");
     } else dt_ = at::mm(dy1, w1b);

@@ -165,3 +165,41 @@ def test_mlp_through_the_fused_gemms_matches_the_library_path(gpu):
     for got, want, name in zip(res[True], res[False], ("z", "dt", "dw1", "db1", "dw2", "db2")):
         tol = 2e-2 * want.abs().max().item()
         assert (got - want).abs().max().item() <= tol, (name, (got - want).abs().max().item(), tol)
+
+
+@pytest.mark.parametrize("shapes", [[(1536, 384)], [(384, 1536), (768, 192), (8, 8), (72, 200), (3072, 768), (96, 384)]])
+def test_batched_transpose_is_t_contiguous(shapes, gpu):
+    import ctypes
+    from slak_amd import _lib
+    torch.manual_seed(1)
+    srcs = [torch.randn(r, c, device=gpu).bfloat16() for r, c in shapes]
+    dsts = [torch.full((c, r), float("nan"), device=gpu, dtype=torch.bfloat16) for r, c in shapes]
+    n = len(shapes)
+    _lib.check(_lib.lib().slak_transpose_bf16_batch((ctypes.c_void_p * n)(*[t.data_ptr() for t in srcs]), (ctypes.c_void_p * n)(*[t.data_ptr() for t in dsts]),
+                                                    (ctypes.c_int * n)(*[r for r, _ in shapes]), (ctypes.c_int * n)(*[c for _, c in shapes]), n,
+                                                    torch.cuda.current_stream().cuda_stream), "slak_transpose_bf16_batch")
+    torch.cuda.synchronize()
+    for s, d in zip(srcs, dsts):
+        assert torch.equal(d, s.t().contiguous())
+
+
+def test_cached_transposed_weights_follow_the_parameter(gpu):
+    """block_ops.lowp_param_t: the transposed bf16 copy the data-gradient GEMMs read is made once per parameter VERSION (one launch for all stale ones) and
+    follows in-place updates of the master weight."""
+    from slak_amd import block_ops
+    saved = block_ops.cache_lowp_weights
+    block_ops.cache_lowp_weights = True
+    try:
+        ws = [torch.nn.Parameter(torch.randn(r, c, device=gpu)) for r, c in ((1536, 384), (384, 1536), (768, 192))]
+        ts = [block_ops.lowp_param_t(w) for w in ws]
+        for w, t in zip(ws, ts):
+            assert torch.equal(t, w.detach().bfloat16().t().contiguous())
+        assert block_ops.lowp_param_t(ws[0]) is ts[0]                                      # same version: the cached tensor itself
+        with torch.no_grad():
+            for w in ws:
+                w.mul_(1.5)                                                                # (bumps the version counter, as optimizer.step() does)
+        t2 = [block_ops.lowp_param_t(w) for w in ws]
+        for w, t, told in zip(ws, t2, ts):
+            assert t is told and torch.equal(t, w.detach().bfloat16().t().contiguous())    # refreshed in place
+    finally:
+        block_ops.cache_lowp_weights = saved
