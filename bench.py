@@ -126,6 +126,8 @@ def parse():
     ap.add_argument("--force-dist", action="store_true", help="world size 1: still init_process_group(--backend), wrap the model in DistributedDataParallel and run the fused "
                     "SyncBatchNorm exchange (all-reduces) -- the N>1 code path executes on RCCL on ONE GPU (communicator creation, DDP reducer hooks, the asynchronous "
                     "backward all-reduce); the line is NOT a scaling point (config.forced_distributed)")
+    ap.add_argument("--ddp-reference-flags", action="store_true", help="N>1: DistributedDataParallel exactly as main.py:374-376 constructs it (broadcast_buffers and "
+                    "gradient_as_bucket_view at their defaults); default: broadcast_buffers=False, gradient_as_bucket_view=True (same results, less host time and one copy less)")
     ap.add_argument("--per-step-sync", action="store_true", help="torch.cuda.synchronize() after every step, as engine.py:90 does (default: the K steps are only bracketed)")
     return ap.parse_args()
 
@@ -500,7 +502,13 @@ def main():
     model = M.create_model("SLaK_" + a.model, kernel_size=ks, Decom=True, bn=True, drop_path_rate=drop_path,
                            lowp_dwconv=not a.fp32_dwconv).to(device)
     if distributed:
-        model = nn.parallel.DistributedDataParallel(model, device_ids=[dev_index], find_unused_parameters=False)   # main.py:374-376
+        # main.py:374-376 builds DistributedDataParallel(model, device_ids=[args.gpu], find_unused_parameters=False).  The two other constructor flags are
+        # results-neutral here and set for speed (--ddp-reference-flags restores the constructor's defaults): broadcast_buffers=False -- the only buffers are
+        # the (Sync)BatchNorm running statistics and counters, rank-identical by construction (the statistics are all-reduced), so the per-forward broadcast from
+        # rank 0 (a collective + ~1.7 ms of host time per step) re-sends what every rank already holds; gradient_as_bucket_view=True -- gradients are views of
+        # the all-reduce buckets instead of being copied into them (123 MB per step).
+        ddp_kw = {} if a.ddp_reference_flags else dict(broadcast_buffers=False, gradient_as_bucket_view=True)
+        model = nn.parallel.DistributedDataParallel(model, device_ids=[dev_index], find_unused_parameters=False, **ddp_kw)
     decay, no_decay = [], []
     for n, p in model.named_parameters():
         (no_decay if (p.dim() == 1 or n.endswith(".bias")) else decay).append(p)                                     # optim_factory.py no-decay rule
@@ -636,6 +644,7 @@ def main():
                    "model_ema": bool(a.model_ema), "one_autograd_node_per_block": bool(M.Block.fused_block),
                    "block_runner": bool(M.Block.fused_block and block_ops._runner() is not None),   # the blocks' call sequences issued from C++ (round 5: under DDP / SyncBatchNorm too)
                    "forced_distributed": bool(a.force_dist and world == 1),
+                   "ddp": (None if not distributed else ("main.py:374-376 defaults" if a.ddp_reference_flags else "broadcast_buffers=False, gradient_as_bucket_view=True")),
                    "sync_bn": True, "block_tail": "hip (ln_nchw_to_nhwc + scale_residual)" if M.Block.fused_tail else "pytorch ops",
                    "branch_bn": "hip (bn3: one stats pass + one apply pass)" if M.ReparamLargeKernelConv.fused_bn else "pytorch (Sync)BatchNorm x3 + adds",
                    "pointwise_gemm": "hipBLASLt via torch" + (", TunableOp solutions from slak_amd/tuning/tunableop_gfx950.csv" if TUNED_GEMMS else ""),
