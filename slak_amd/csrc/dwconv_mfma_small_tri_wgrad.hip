@@ -48,6 +48,11 @@ struct SmallTriWgradParams {
     int dbg;                             // dev switches of the quad kernel (SLAK_QW_DBG): 1 no compute, 2 no DMA, 4 no diagonal sums, 8 no octets
     const float* w[3]; void* dx;         // DG only: the three filters, the data gradient
 };
+#ifdef SLAK_QW_DEV                     // dev builds only (SLAK_BUILD_DEFS=-DSLAK_QW_DEV): the shipped kernel compiles the experiments out
+#define QW_DBG(bit) (p.dbg & (bit))
+#else
+#define QW_DBG(bit) 0
+#endif
 
 template <typename T> __device__ __forceinline__ f32x4_t tw_mfma16(s16x8 a, s16x8 b, f32x4_t c);
 template <> __device__ __forceinline__ f32x4_t tw_mfma16<bf16_t>(s16x8 a, s16x8 b, f32x4_t c) {
@@ -492,7 +497,7 @@ __global__ __launch_bounds__(MF_THREADS) void dwconv_mfma_small_quad_wgrad_kerne
     const int n_begin = slice * p.images_per_slice;               // (a multiple of 8)
     int n_end = n_begin + p.images_per_slice; if (n_end > p.N) n_end = p.N;
     const bool live = c < p.C && n_begin < n_end;                // (every wave reaches the finish: it has workgroup barriers)
-    const int noct = (live && !(p.dbg & 8)) ? (n_end - n_begin + 7) >> 3 : 0;
+    const int noct = (live && !QW_DBG(8)) ? (n_end - n_begin + 7) >> 3 : 0;
     char* const L = (char*)lds + wave * QW_WAVE_BYTES;
     const int HW = p.H * p.W;
     const int nt_long = p.K * MF_TAPS, ntot = 2 * nt_long + 25;  // [K x 5][5 x K][5 x 5] back to back
@@ -516,7 +521,7 @@ __global__ __launch_bounds__(MF_THREADS) void dwconv_mfma_small_quad_wgrad_kerne
     auto load_oct = [&](int q, u32x4 (&R)[4]) {
         const int n0 = n_begin + 8 * q;
         // (an octet behind the slice loads nothing: the instruction count per step stays fixed)
-        const unsigned a = (d_ok && n0 + d_pl < n_end && !(p.dbg & 2)) ? (((unsigned)n0 * gplane_b + d_row_b) & ~3u) : QW_OOB;
+        const unsigned a = (d_ok && n0 + d_pl < n_end && !QW_DBG(2)) ? (((unsigned)n0 * gplane_b + d_row_b) & ~3u) : QW_OOB;
 #pragma unroll
         for (int t = 0; t < 4; ++t) R[t] = __builtin_amdgcn_raw_buffer_load_b128(rs[t], a, 0, 0);      // dwords behind the tensor: 0
     };
@@ -557,7 +562,7 @@ __global__ __launch_bounds__(MF_THREADS) void dwconv_mfma_small_quad_wgrad_kerne
     auto octet = [&](int q, u32x4 (&R)[4]) {
         stage(R);                                                 // (the LDS queue is in order: the reads of octet q-1 are behind us)
         load_oct(q + 2, R);                                       // unconditional: the compiler's vmcnt bookkeeping needs one count on every path
-        if (q >= noct || (p.dbg & 1)) return;
+        if (q >= noct || QW_DBG(1)) return;
         // vertical branch: the dy_v tiles and the x tiles transposed (tensor 0 and tensor 3 of the slot)
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -622,7 +627,7 @@ __global__ __launch_bounds__(MF_THREADS) void dwconv_mfma_small_quad_wgrad_kerne
                 if (emit) out[vert ? (tau * kw + r) : (r * kw + tau)] = t;
             }
         };
-        if (!(p.dbg & 4)) {
+        if (!QW_DBG(4)) {
         diag(av, true, p.H, p.K, MF_TAPS, res);
         diag(ah, false, p.W, p.K, p.K, res + nt_long);
         diag(as, false, p.W, MF_TAPS, MF_TAPS, res + 2 * nt_long);
@@ -739,7 +744,11 @@ int launch_dwconv_mfma_small_tri_wgrad(const void* const* dy, const void* x, flo
     fill_stw_params(p, N, C, H, W, K, 512);
     for (int b = 0; b < 3; ++b) { p.dy[b] = dy[b]; p.dw[b] = dw[b]; }
     p.x = x; p.partial = (float*)ws; p.dx = nullptr; p.w[0] = p.w[1] = p.w[2] = nullptr;
+#ifdef SLAK_QW_DEV
     { static const int dbg = [] { const char* e = getenv("SLAK_QW_DBG"); return e ? atoi(e) : 0; }(); p.dbg = dbg; }
+#else
+    p.dbg = 0;
+#endif
     p.counters = wgrad_arrival_counters((C + 3) / 4);
     if (!p.counters) return SLAK_ERR_UNSUPPORTED;                 // (the caller runs the three per-branch launches)
     if (H <= 7 && W <= 7 && quad_wgrad_enabled())                 // planes of at most 7 x 7: eight per MFMA

@@ -41,8 +41,13 @@ struct TriRowsParams {
     int maxspan;           // channels a range touches at most (partial records per workgroup)
     int qs[TW_MAXWG + 1];  // the ranges, balanced by COST on the host: a range that crosses a channel boundary pays for summing up in mid-stream with fewer planes
     unsigned tensor_bytes;
-    int dbg;               // SLAK_TRIROWS_DBG (timing experiments): 1 = no k-loops, 2 = no DMA, 4 = no epilogue, 8 = no wait / barrier, 32 = clock probe (with 4), 64 = every plane from the first MiB
+    int dbg;               // SLAK_TRIROWS_DBG (timing experiments): 1 = no k-loops, 2 = no DMA, 4 = no epilogue, 8 = no wait / barrier, 32 = clock probe (with 4), 64 = every plane from the first MiB  -- only read in dev builds (SLAK_BUILD_DEFS=-DSLAK_TRIROWS_DEV); the shipped kernel compiles the experiments out
 };
+#ifdef SLAK_TRIROWS_DEV
+#define TW_DBG(bit) (p.dbg & (bit))
+#else
+#define TW_DBG(bit) 0
+#endif
 
 // buffer_load_dwordx4 ... lds without saving M0 around it (lds_dma16 of mfma_common.h does)
 __device__ __forceinline__ void tw_dma16(unsigned voff, v4i_t rsrc, unsigned lds_dst) {
@@ -80,7 +85,7 @@ __global__ __launch_bounds__(MF_THREADS, 1) void dwconv_mfma_tri_wgrad_rows_kern
     const int iters = q1 > q0 ? q1 - q0 : 0;
     const int c_first = q0 / p.N;
 
-    const unsigned long long clk0 = (p.dbg & 32) ? __builtin_amdgcn_s_memtime() : 0ull, rt0 = (p.dbg & 32) ? __builtin_amdgcn_s_memrealtime() : 0ull;
+    const unsigned long long clk0 = TW_DBG(32) ? __builtin_amdgcn_s_memtime() : 0ull, rt0 = TW_DBG(32) ? __builtin_amdgcn_s_memrealtime() : 0ull;
     for (unsigned o = tid * 16; o < ring_b + TW_NB * slot_b + (unsigned)(MF_WAVES * 32 * 64 + MF_WAVES * ntot) * 4 + 32; o += MF_THREADS * 16) *(u32x4*)(LB + o) = u32x4{0u, 0u, 0u, 0u};
     __syncthreads();
 
@@ -113,9 +118,9 @@ __global__ __launch_bounds__(MF_THREADS, 1) void dwconv_mfma_tri_wgrad_rows_kern
     // checked in the ISA).
     unsigned voff[TW_J]; bool iss_on = false;
     auto aim = [&](int g, unsigned gb) {
-        iss_on = g < iters && !(p.dbg & 2);
+        iss_on = g < iters && !TW_DBG(2);
 #pragma unroll
-        for (int j = 0; j < TW_J; ++j) voff[j] = src_off[j] == TW_OOB ? TW_OOB : ((p.dbg & 64) ? (gb & 0xfffffu) : gb) + src_off[j];      // (64: timing experiment, every plane from the first MiB: cache hits)
+        for (int j = 0; j < TW_J; ++j) voff[j] = src_off[j] == TW_OOB ? TW_OOB : (TW_DBG(64) ? (gb & 0xfffffu) : gb) + src_off[j];      // (64: timing experiment, every plane from the first MiB: cache hits)
     };
     auto issue_piece = [&](int g, int k) __attribute__((always_inline)) {      // k = t * TW_J + j, compile-time at every call site
         const int t = k / TW_J, j = k % TW_J;
@@ -163,13 +168,13 @@ __global__ __launch_bounds__(MF_THREADS, 1) void dwconv_mfma_tri_wgrad_rows_kern
     while (it < iters) {
     int seg_end = it + (p.N - n_cur); if (seg_end > iters) seg_end = iters;      // planes [it, seg_end) belong to channel c_first + kseg
     for (; it < seg_end; ++it) {
-        if (!(p.dbg & 8)) {
+        if (!TW_DBG(8)) {
         wait_vmcnt_dyn((it + 1 < iters ? 1 : 0) * my_instr);      // my pieces of plane `it` have landed (loads retire in order); plane it + 1's may be in flight
         wg_barrier();                                             // everyone's have; everyone is done with plane it - 1, whose slot plane it + 2 takes
         }
         const unsigned sb = (unsigned)(it % TW_NB) * slot_b;
         aim(it + 2, gb_iss);
-        if (p.dbg & 1) {
+        if (TW_DBG(1)) {
 #pragma unroll
             for (int k = 0; k < 4 * TW_J; ++k) issue_piece(it + 2, k);
             advance_issue();
@@ -250,7 +255,7 @@ __global__ __launch_bounds__(MF_THREADS, 1) void dwconv_mfma_tri_wgrad_rows_kern
     // ---- end of a channel segment: diagonal sums of the fifteen accumulators through the wave's skewed tile (G[o][i] -> row o, column i - o + 31), the
     //      workgroup's partial record `kseg`, accumulators cleared.  In mid-stream (planes of the next channel in flight) the stores below and the
     //      DMA pieces share the wave's vmcnt: everything is drained once here (one boundary per workgroup at most when per <= N).
-    if (!(p.dbg & 4)) {
+    if (!TW_DBG(4)) {
         {   // (every tap writes all of the wave's 32 x 32 entries of the skewed tile: nothing to clear between taps or extents)
             int o_max = p.H - mt * 32; if (o_max > 32) o_max = 32;
             const int lim = nt * 32 + l31 < p.H ? o_max - 4 * lhi : 0;
@@ -287,10 +292,10 @@ __global__ __launch_bounds__(MF_THREADS, 1) void dwconv_mfma_tri_wgrad_rows_kern
     }   // while (it < iters)
     wait_vmcnt<0>();
     __syncthreads();
-    if ((p.dbg & 32) && tid == 0 && bwg < 8) {                    // (dev, tools/clk_tri_rows.py: shader cycles and 100 MHz ticks this workgroup ran -> the effective clock)
+    if (TW_DBG(32) && tid == 0 && bwg < 8) {                    // (dev, tools/clk_tri_rows.py: shader cycles and 100 MHz ticks this workgroup ran -> the effective clock)
         p.dw[2][bwg * 2] = (float)(__builtin_amdgcn_s_memtime() - clk0); p.dw[2][bwg * 2 + 1] = (float)(__builtin_amdgcn_s_memrealtime() - rt0);
     }
-    if (p.dbg & 4) return;
+    if (TW_DBG(4)) return;
     // ---- arrive at every channel this workgroup holds a record of; the last arriver of a channel adds the records of workgroups b_lo .. b_hi in
     //      workgroup order (bitwise reproducible) and scatters into the three dw tensors (hand-off form: see wgrad_finish in slak_common.h) --------
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -393,7 +398,11 @@ static bool fill_tri_rows_params(TriRowsParams& p, int N, int C, int H, int W, i
     }
     if (p.maxspan > 8) return false;
     p.tensor_bytes = (unsigned)((size_t)N * C * H * W * 2);
+#ifdef SLAK_TRIROWS_DEV
     { static const int dbg = [] { const char* e = getenv("SLAK_TRIROWS_DBG"); return e ? atoi(e) : 0; }(); p.dbg = dbg; }
+#else
+    p.dbg = 0;
+#endif
     return (size_t)N * C * H * W * 2 < 0x7fffffffull;
 }
 

@@ -187,8 +187,12 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dwconv_mfma_wgrad_kernel(const 
         }
     };
 
+#ifdef SLAK_DMA_DEBUG                  // dev builds only: phase cycle counts of workgroup 0 into slak_debug_set_phase_buffer()'s buffer
     const bool prof = p.dbg != nullptr && blockIdx.x == 0 && threadIdx.x == 0;
-    unsigned long long t0 = __builtin_readcyclecounter(), t1 = 0, t2 = 0, t3 = 0, t4 = 0;
+#else
+    constexpr bool prof = false;
+#endif
+    unsigned long long t0 = prof ? __builtin_readcyclecounter() : 0ull, t1 = 0, t2 = 0, t3 = 0, t4 = 0;
     if (iters > 0) prefetch(0);
     {
         u32x4* z = (u32x4*)lds;
@@ -202,7 +206,7 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dwconv_mfma_wgrad_kernel(const 
     __syncthreads();
     if constexpr (VERT) { transpose_images(); __syncthreads(); }
 
-    t1 = __builtin_readcyclecounter();
+    if (prof) t1 = __builtin_readcyclecounter();
     f32x16 acc[NG];
 #pragma unroll
     for (int g = 0; g < NG; ++g)
@@ -262,7 +266,7 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dwconv_mfma_wgrad_kernel(const 
     // ---- diagonal sums.  Each wave dumps one accumulator tile at a time into a private 32x33 fp32 LDS scratch (aliased over
     //      the stacks, which are dead now) and lane (rho_sel, dd) adds up the diagonal i - o = dd - (NPAD-1) with plain
     //      loads in a fixed order: no atomics, bitwise reproducible.  Each (rho, tau) is produced by exactly one lane. ----
-    t2 = __builtin_readcyclecounter();
+    if (prof) t2 = __builtin_readcyclecounter();
     __syncthreads();                                          // every wave is done reading the stacks
     float* mine = dwl + wave * ntap;
     float* tile = (float*)lds + wave * (32 * 33);
@@ -294,7 +298,7 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dwconv_mfma_wgrad_kernel(const 
         __builtin_amdgcn_wave_barrier();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
-    t3 = __builtin_readcyclecounter();
+    if (prof) t3 = __builtin_readcyclecounter();
     __syncthreads();
     const int nvalid = VERT ? ntap : p.rows * p.kw, rec = p.rec ? p.rec : ntap;
     for (int t = tid; t < nvalid; t += MF_THREADS) {
@@ -303,7 +307,7 @@ __global__ __launch_bounds__(MF_THREADS, 2) void dwconv_mfma_wgrad_kernel(const 
         for (int w = 1; w < MF_WAVES; ++w) s += dwl[w * ntap + t];
         wgrad_store_partial(&p.partial[((size_t)slice * p.C + c) * rec + t], s);
     }
-    t4 = __builtin_readcyclecounter();
+    if (prof) t4 = __builtin_readcyclecounter();
     if (prof) { p.dbg[0] = t1 - t0; p.dbg[1] = t2 - t1; p.dbg[2] = t3 - t2; p.dbg[3] = t4 - t3; p.dbg[4] = iters; }
     if (p.counters) wgrad_finish(p.partial, p.dw, p.counters + c, (int*)lds, p.slices, p.C, c, 1, nvalid, tid, MF_THREADS, nullptr, 0, rec);
 }
