@@ -64,8 +64,10 @@ def _check_lowp(got, ref, dtype, what):
 
 
 def _check_dw(got, ref, n_terms, what):
+    """fp32 accumulation of n_terms products: 1e-5 of the largest gradient for short sums, growing with sqrt(n_terms), and never looser than the rtol 1e-4 the
+    reference's own test allows a weight gradient (test_correctness.py:67-90) -- the stage-1 sums (401,408 terms) are held to that."""
     err = np.abs(got.double().cpu().numpy() - ref).max()
-    assert err <= 1e-5 * max(1.0, np.abs(ref).max()) * max(1.0, n_terms ** 0.5 / 30), "%s: %.3e" % (what, err)
+    assert err <= min(1e-4, 1e-5 * max(1.0, n_terms ** 0.5 / 30)) * max(1.0, np.abs(ref).max()), "%s: %.3e" % (what, err)
 
 
 def _pair_wgrad(dyv, dys, x, K):
@@ -430,6 +432,13 @@ def test_tri_launches_at_bench_shapes(N, C, H, W, K, gpu):
     if dws is not None:
         for dw, dy, (kh, kw) in zip(dws, dys, ((K, 5), (5, K), (5, 5))):
             _check_dw(dw[ch], oracle.dwconv2d_bwd_filter(_r(dy[:, ch], dtype), xr, kh, kw), N * H * W, "dw %dx%d" % (kh, kw))
+        # size-independent property on ALL channels of the one-launch weight gradient (the work split of the rows / wave kernels depends on C * N and the CU
+        # count: every channel's record has to come out whichever workgroups shared it): with dy = x on the three branches the centre tap of each of the three
+        # gradients is sum x^2 of the channel
+        dwi = _tri_wgrad([x, x, x], x, K)
+        e = (x.double() ** 2).sum(dim=(0, 2, 3))
+        for dw, (ci, cj), name in zip(dwi, ((K // 2, 2), (2, K // 2), (2, 2)), ("Kx5", "5xK", "5x5")):
+            assert (dw[:, 0, ci, cj].double() - e).abs().max().item() <= 1e-4 * e.max().item(), name
 
 
 def test_tri_backward_in_one_launch_on_random_shapes(gpu):
