@@ -411,10 +411,17 @@ static size_t tri_rows_lds_bytes(const TriRowsParams& p) {
     return 64 + (size_t)TW_NB * 4 * p.RS * p.CPR * 16 + (size_t)MF_WAVES * 32 * 64 * 4 + (size_t)(MF_WAVES + 1) * ntot * 4 + 32 + 64;
 }
 
+static int tri_rows_wgs() {
+    static const int wgs = [] { const char* e = getenv("SLAK_TRIROWS_WGS"); return e ? atoi(e) : 0; }();      // (dev: a grid other than one workgroup per CU)
+    return wgs > 0 ? wgs : mfma_cu_count();
+}
+
 bool dwconv_mfma_tri_wgrad_rows_supported(int N, int C, int H, int W, int K, int dtype) {
     if (!tri_rows_enabled() || (dtype != SLAK_BF16 && dtype != SLAK_F16)) return false;
     TriRowsParams p;
-    return fill_tri_rows_params(p, N, C, H, W, K, 256) && tri_rows_lds_bytes(p) <= 160 * 1024 - 256;
+    // the SAME workgroup count as the launch (the device's CU count; 256 without a device): a caller that plans on this answer -- the C++ block runner asks once per
+    // shape -- must get what the launch will decide (a fixed 256 here and the real count there could disagree on a part with another CU count)
+    return fill_tri_rows_params(p, N, C, H, W, K, tri_rows_wgs()) && tri_rows_lds_bytes(p) <= 160 * 1024 - 256;
 }
 
 // records: grid * maxspan <= C + 2 * grid + 2 whatever the CU count turns out to be (grid <= min(C * N, CUs)); sized for up to 1024 CUs
@@ -444,8 +451,7 @@ int launch_dwconv_mfma_tri_wgrad_rows(const void* const* dy, const void* x, floa
     if (!dwconv_mfma_tri_wgrad_rows_supported(N, C, H, W, K, dtype)) return SLAK_ERR_UNSUPPORTED;
     if (ws == nullptr) return SLAK_ERR_WORKSPACE;
     TriRowsParams p;
-    static const int wgs = [] { const char* e = getenv("SLAK_TRIROWS_WGS"); return e ? atoi(e) : 0; }();      // (dev: a grid other than one workgroup per CU)
-    if (!fill_tri_rows_params(p, N, C, H, W, K, wgs > 0 ? wgs : mfma_cu_count())) return SLAK_ERR_UNSUPPORTED;   // one wave per SIMD: one four-wave workgroup per CU
+    if (!fill_tri_rows_params(p, N, C, H, W, K, tri_rows_wgs())) return SLAK_ERR_UNSUPPORTED;   // one wave per SIMD: one four-wave workgroup per CU
                                                                                        // (the CU count decides `per`, and with it how many channels a range can span)
     for (int b = 0; b < 3; ++b) { p.dy[b] = dy[b]; p.dw[b] = dw[b]; }
     p.x = x; p.partial = (float*)ws;

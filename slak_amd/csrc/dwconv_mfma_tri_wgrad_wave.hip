@@ -246,10 +246,15 @@ static bool fill_tri_wave_params(TriWaveParams& p, int N, int C, int H, int W, i
 }
 static size_t tri_wave_lds_bytes(int K) { return (size_t)MF_WAVES * (64 + 4 * TV_RS * TV_CPR * 16) + (size_t)MF_WAVES * (2 * K * MF_TAPS + MF_TAPS * MF_TAPS) * 4 + 32; }
 
+static int tri_wave_cus() {
+    static const int cus_env = [] { const char* e = getenv("SLAK_TRIWAVE_CUS"); return e ? atoi(e) : 0; }();      // (dev: pretend another CU count)
+    return cus_env > 0 ? cus_env : mfma_cu_count();
+}
+
 bool dwconv_mfma_tri_wgrad_wave_supported(int N, int C, int H, int W, int K, int dtype) {
     if (!tri_wave_enabled() || (dtype != SLAK_BF16 && dtype != SLAK_F16)) return false;
     TriWaveParams p;
-    return fill_tri_wave_params(p, N, C, H, W, K, 256);
+    return fill_tri_wave_params(p, N, C, H, W, K, tri_wave_cus());     // the launch's own CU count (256 without a device): plan and launch agree
 }
 
 size_t dwconv_mfma_tri_wgrad_wave_workspace(int N, int C, int K) {  // one record per wave, sized for up to 1024 CUs
@@ -279,8 +284,7 @@ int launch_dwconv_mfma_tri_wgrad_wave(const void* const* dy, const void* x, floa
     if (!dwconv_mfma_tri_wgrad_wave_supported(N, C, H, W, K, dtype)) return SLAK_ERR_UNSUPPORTED;
     if (ws == nullptr) return SLAK_ERR_WORKSPACE;
     TriWaveParams p;
-    static const int cus_env = [] { const char* e = getenv("SLAK_TRIWAVE_CUS"); return e ? atoi(e) : 0; }();      // (dev: pretend another CU count)
-    if (!fill_tri_wave_params(p, N, C, H, W, K, cus_env > 0 ? cus_env : mfma_cu_count())) return SLAK_ERR_UNSUPPORTED;
+    if (!fill_tri_wave_params(p, N, C, H, W, K, tri_wave_cus())) return SLAK_ERR_UNSUPPORTED;
     for (int b = 0; b < 3; ++b) { p.dy[b] = dy[b]; p.dw[b] = dw[b]; }
     p.x = x; p.partial = (float*)ws;
     p.counters = wgrad_arrival_counters(C);
