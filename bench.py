@@ -127,7 +127,7 @@ def parse():
                     "SyncBatchNorm exchange (all-reduces) -- the N>1 code path executes on RCCL on ONE GPU (communicator creation, DDP reducer hooks, the asynchronous "
                     "backward all-reduce); the line is NOT a scaling point (config.forced_distributed)")
     ap.add_argument("--ddp-reference-flags", action="store_true", help="N>1: DistributedDataParallel exactly as main.py:374-376 constructs it (broadcast_buffers and "
-                    "gradient_as_bucket_view at their defaults); default: broadcast_buffers=False, gradient_as_bucket_view=True (same results, less host time and one copy less)")
+                    "gradient_as_bucket_view at their defaults); default: broadcast_buffers=False, gradient_as_bucket_view=True, the stock all-reduce comm hook (same results, less host time, one copy and 312 tiny launches less)")
     ap.add_argument("--per-step-sync", action="store_true", help="torch.cuda.synchronize() after every step, as engine.py:90 does (default: the K steps are only bracketed)")
     return ap.parse_args()
 
@@ -509,6 +509,12 @@ def main():
         # the all-reduce buckets instead of being copied into them (123 MB per step).
         ddp_kw = {} if a.ddp_reference_flags else dict(broadcast_buffers=False, gradient_as_bucket_view=True)
         model = nn.parallel.DistributedDataParallel(model, device_ids=[dev_index], find_unused_parameters=False, **ddp_kw)
+        if not a.ddp_reference_flags:
+            # DDP divides every gradient by the world size as it becomes ready: one tiny launch per parameter (312 per SLaK-T step, 1.4 ms of GPU time in
+            # profiles/r05_step_breakdown_forcedist.txt).  With the stock all-reduce hook the SAME division happens once per bucket on the bucket buffer
+            # (default_hooks.allreduce_hook: buffer.div_(world) then all_reduce -- element for element the arithmetic of the default path).
+            from torch.distributed.algorithms.ddp_comm_hooks import default_hooks
+            model.register_comm_hook(None, default_hooks.allreduce_hook)
     decay, no_decay = [], []
     for n, p in model.named_parameters():
         (no_decay if (p.dim() == 1 or n.endswith(".bias")) else decay).append(p)                                     # optim_factory.py no-decay rule
@@ -644,7 +650,7 @@ def main():
                    "model_ema": bool(a.model_ema), "one_autograd_node_per_block": bool(M.Block.fused_block),
                    "block_runner": bool(M.Block.fused_block and block_ops._runner() is not None),   # the blocks' call sequences issued from C++ (round 5: under DDP / SyncBatchNorm too)
                    "forced_distributed": bool(a.force_dist and world == 1),
-                   "ddp": (None if not distributed else ("main.py:374-376 defaults" if a.ddp_reference_flags else "broadcast_buffers=False, gradient_as_bucket_view=True")),
+                   "ddp": (None if not distributed else ("main.py:374-376 defaults" if a.ddp_reference_flags else "broadcast_buffers=False, gradient_as_bucket_view=True, allreduce_hook (division per bucket, not per parameter)")),
                    "sync_bn": True, "block_tail": "hip (ln_nchw_to_nhwc + scale_residual)" if M.Block.fused_tail else "pytorch ops",
                    "branch_bn": "hip (bn3: one stats pass + one apply pass)" if M.ReparamLargeKernelConv.fused_bn else "pytorch (Sync)BatchNorm x3 + adds",
                    "pointwise_gemm": "hipBLASLt via torch" + (", TunableOp solutions from slak_amd/tuning/tunableop_gfx950.csv" if TUNED_GEMMS else ""),
