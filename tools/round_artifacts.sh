@@ -1,6 +1,6 @@
 #!/bin/bash
-# All measured artifacts of a round in one GPU session -> gpurun_out/r04/ (copy what is to be judged into profiles/)
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r04; mkdir -p $O
+# All measured artifacts of a round in one GPU session -> gpurun_out/r05/ (copy what is to be judged into profiles/)
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r05; mkdir -p $O
 cd $R
 timeout 900 python bench.py                                                         2> $O/bench_cfg1.err | tail -1 > $O/bench_cfg1.json
 timeout 600 python bench.py --sparsity 0.4 --no-cpu-baseline --no-mask-bench         2>/dev/null | tail -1 > $O/bench_cfg2_sparsity04.json
@@ -17,7 +17,9 @@ timeout 900 bash tools/pmc_run.sh > /dev/null 2>&1
 cp gpurun_out/sum/pmc_traffic.txt $O/pmc_traffic.txt; cp gpurun_out/sum/pmc_traffic.json $O/pmc_traffic.json
 timeout 600 bash tools/pmc_hot.sh > /dev/null 2>&1
 cp gpurun_out/sum/pmc_hot.txt $O/pmc_hot.txt
-timeout 300 bash tools/power_clock_probe.sh > $O/power_clock_probe.txt 2>&1
-( bash tools/prof_tri_rows.sh "128 96 56 51" 0 2 6; bash tools/prof_tri_rows.sh "128 192 28 49" 0 ) > $O/tri_wgrad_ablation.txt 2>&1
+timeout 600 python bench.py --force-dist --sparsity 0.4 --steps 20 --warmup 5 --no-roofline --no-mask-bench --no-cpu-baseline 2>/dev/null | grep '^{' | tail -1 > $O/bench_nccl_ws1.json
+SLAK_LINEAR_GEMM=0 timeout 600 python bench.py --steps 20 --warmup 5 --no-roofline --no-mask-bench --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_cfg1_linear_gemm_off.json
+timeout 400 python tools/power_trace.py 2>&1 | grep -v amdgpu.ids > $O/power_trace.txt
+timeout 300 python tools/time_gemm2.py 2>&1 | grep -v amdgpu.ids > $O/linear_gemm_times.txt
 for f in $O/bench_cfg*.json; do echo "$(basename $f): $(cut -c1-200 $f)"; done
-tail -3 $O/kernel_times.txt; head -14 $O/step_breakdown.txt; cat $O/power_clock_probe.txt
+tail -3 $O/kernel_times.txt; head -14 $O/step_breakdown.txt; cat $O/power_trace.txt $O/linear_gemm_times.txt
