@@ -3,7 +3,8 @@
 //     EPI_BIAS   out[M][N]  = bf16(A[M][K] . B[N][K]^T + bias)                                   (pwconv2, dy1 . W1)
 //     EPI_GELU   out        = bf16(A . B^T + bias),  out2 = GELU(out)                              (pwconv1 + nn.GELU: both are kept for the backward)
 //     EPI_DGELU  out        = bf16(bf16(A . B^T) * gelu'(y1)),  dbias[N] = column sums of out      (dz . W2, GELU', pwconv1's bias gradient)
-// A, B, out, out2, y1 bf16 row-major, fp32 accumulation; K in {192, 384, 768, ...} (a multiple of 32), N a multiple of 128, any M >= 1.
+// A, B, out, out2, y1 bf16 row-major, fp32 accumulation; K in {192, 256, 384} (the B fragments of a wave's 32 columns stay in its registers: K / 4 of them),
+// N a multiple of 256, any M >= 1.  (EPI_BIAS -- the plain GEMMs with K = 4C -- stays with the library: 0.85 PFLOP/s there, and B does not fit registers.)
 //
 // Why an own GEMM: at K = 192 ... 768 the library's kernels spend a tile's time in its prologue and epilogue (3 ... 12 k-iterations per 256 x 256 tile: 0.66
 // PFLOP/s measured), and the GELU / GELU' passes that follow move the [M][4C] intermediate through HBM twice more.  These GEMMs are WRITE-bound: 29.6 GFLOP
@@ -305,7 +306,7 @@ __global__ __launch_bounds__(512, 1) void linear_gemm_kernel(const Lg2Params p) 
 struct Lg2Plan { int tiles_m, panels, slabs, tps; size_t lds; };
 
 static bool lg2_plan(int M, int N, int K, int epi, Lg2Plan& pl) {
-    if (M < 1 || N < LG2_TN || N % LG2_TN || (K != 192 && K != 384) || (epi != EPI_GELU && epi != EPI_DGELU)) return false;
+    if (M < 1 || N < LG2_TN || N % LG2_TN || (K != 192 && K != 256 && K != 384) || (epi != EPI_GELU && epi != EPI_DGELU)) return false;
     if ((long long)M * N * 2 >= (1LL << 32) || (long long)M * K * 2 >= (1LL << 32)) return false;
     const size_t tbl = epi == EPI_GELU ? (size_t)G2_BYTES : (size_t)GD_BYTES;
     pl.lds = tbl + (size_t)LG2_NS * LG2_STAGE + (size_t)LG2_WAVES * 32 * LG2_SP;
@@ -388,8 +389,8 @@ int slak_linear_gemm(const void* a, const void* b, const void* bias, void* out, 
         if (!slak_set_max_lds((const void*)k, pl.lds)) return SLAK_ERR_LAUNCH;          \
         hipLaunchKernelGGL(k, grid, dim3(512), pl.lds, st, p);                          \
     } while (0)
-    if (epilogue == EPI_GELU) { if (K == 192) SLAK_LG2_LAUNCH(EPI_GELU, 12); else SLAK_LG2_LAUNCH(EPI_GELU, 24); }
-    else { if (K == 192) SLAK_LG2_LAUNCH(EPI_DGELU, 12); else SLAK_LG2_LAUNCH(EPI_DGELU, 24); }
+    if (epilogue == EPI_GELU) { if (K == 192) SLAK_LG2_LAUNCH(EPI_GELU, 12); else if (K == 256) SLAK_LG2_LAUNCH(EPI_GELU, 16); else SLAK_LG2_LAUNCH(EPI_GELU, 24); }
+    else { if (K == 192) SLAK_LG2_LAUNCH(EPI_DGELU, 12); else if (K == 256) SLAK_LG2_LAUNCH(EPI_DGELU, 16); else SLAK_LG2_LAUNCH(EPI_DGELU, 24); }
 #undef SLAK_LG2_LAUNCH
     SLAK_LAUNCH_CHECK();
     if (epilogue == EPI_DGELU) return tail_reduce_columns((const float*)workspace, dbias, pl.slabs, N, st);

@@ -34,7 +34,7 @@ def _call(a, b, bias, epi, y1=None):
     return out, out2, db
 
 
-SHAPES = [(25088, 1536, 384), (12544, 768, 192), (6272, 1536, 384), (129, 256, 192), (1, 256, 384), (127, 512, 192), (1000, 768, 384), (64 * 49, 1024, 384)]
+SHAPES = [(25088, 1536, 384), (12544, 768, 192), (6272, 1536, 384), (129, 256, 192), (1, 256, 384), (127, 512, 192), (1000, 768, 384), (64 * 49, 1024, 384), (50176, 1024, 256), (333, 512, 256)]
 
 
 @pytest.mark.parametrize("M,N,K", SHAPES)
