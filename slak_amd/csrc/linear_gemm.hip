@@ -199,14 +199,22 @@ __global__ __launch_bounds__(512, 1) void linear_gemm_kernel(const Lg2Params p) 
             wg_barrier();                                                                 // everyone's have; everyone is done with chunk g-1's stage
             if (c + 2 < NK) issue(row0, c + 2, (g + 2) % LG2_NS);
             const unsigned char* const L = ring + (g % LG2_NS) * LG2_STAGE;
-            if (!LG2_DBG(2))
-#pragma unroll
-            for (int ks = 0; ks < LG2_KC / 16; ++ks) {
+            if (!LG2_DBG(2)) {
+                // software pipeline, pinned (hipcc otherwise sinks every ds_read to right in front of its MFMA: read, wait, multiply): the fragment of row tile i
+                // for k-step ks + 1 is fetched right behind the MFMA that has just consumed row tile i of k-step ks, into the same registers
                 s16x8 fa[RM];
 #pragma unroll
-                for (int i = 0; i < RM; ++i) fa[i] = *SLAK_LDS(const s16x8, L + i * 32 * 128 + frow + (((unsigned)(2 * ks + lhi) ^ fswz) << 4));
+                for (int i = 0; i < RM; ++i) fa[i] = *SLAK_LDS(const s16x8, L + i * 32 * 128 + frow + (((unsigned)lhi ^ fswz) << 4));
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int i = 0; i < RM; ++i) acc[i] = mfma32<bf16_t>(bfrag[c * (LG2_KC / 16) + ks], fa[i], acc[i]);   // D^T: acc[4q+e] = D[row l31][col 8q + 4 lhi + e]
+                for (int ks = 0; ks < LG2_KC / 16; ++ks) {
+#pragma unroll
+                    for (int i = 0; i < RM; ++i) {
+                        acc[i] = mfma32<bf16_t>(bfrag[c * (LG2_KC / 16) + ks], fa[i], acc[i]);   // D^T: acc[4q+e] = D[row l31][col 8q + 4 lhi + e]
+                        if (ks + 1 < LG2_KC / 16) fa[i] = *SLAK_LDS(const s16x8, L + i * 32 * 128 + frow + (((unsigned)(2 * (ks + 1) + lhi) ^ fswz) << 4));
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
             }
         }
         // the next tile's first two chunks go out BEFORE this tile's stores (the ring is free but for the last chunk's stage, which other
