@@ -302,8 +302,9 @@ int slak_linear_nt_gelu_bwd(const void* dz_bf16, const void* wt_bf16, const void
  *   SLAK_EPI_DGELU  out = bf16(bf16(acc) * gelu'(y1)), dbias[N] = column sums of out   (y1 [M][N] bf16: the same dy1 bits as the GEMM followed by
  *                                                                              slak_gelu_backward_bias; dbias fp32, fixed summation order; needs the workspace)
  * Replaces on these stages: at::linear + at::gelu (two passes over [M][4C]) resp. at::mm + slak_gelu_backward_bias (the [M][4C] intermediate `dact`
- * written and read back).  Covered: epilogue GELU / DGELU with K in {192, 256, 384} (stages 2-3 of SLaK-T / -S, stage 2 of SLaK-B), N % 256 == 0, M >= 1, tensors
- * below 4 GiB; anything else -- SLAK_EPI_BIAS included: reserved -- SLAK_ERR_UNSUPPORTED (library GEMM + elementwise pass). */
+ * written and read back).  Covered: epilogue GELU / DGELU with K in {192, 256, 384} and N % 256 == 0, or K in {512, 768} and N % 128 == 0 (stages 2-4 of
+ * SLaK-T / -S, stages 2-3 of SLaK-B), M >= 1, tensors below 4 GiB; anything else -- SLAK_EPI_BIAS included: reserved -- SLAK_ERR_UNSUPPORTED (library GEMM +
+ * elementwise pass). */
 enum { SLAK_EPI_BIAS = 0, SLAK_EPI_GELU = 1, SLAK_EPI_DGELU = 2 };
 int slak_linear_gemm_supported(int M, int N, int K, int epilogue);
 size_t slak_linear_gemm_workspace_bytes(int M, int N, int K, int epilogue);

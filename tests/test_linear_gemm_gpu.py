@@ -1,4 +1,4 @@
-"""slak_linear_gemm (csrc/linear_gemm.hip, round 5): the pointwise Linear layers of stages 2-3 (models/SLaK.py:156-165: pwconv1 -> nn.GELU() -> pwconv2 and
+"""slak_linear_gemm (csrc/linear_gemm.hip, round 5): the pointwise Linear layers of stages 2-4 (models/SLaK.py:156-165: pwconv1 -> nn.GELU() -> pwconv2 and
 their data gradients) as ONE launch per GEMM with the elementwise neighbour in its epilogue, through the C ABI.
 
 Checkers: the same product in fp64 on the bf16 operands (torch CPU), rounded once; nn.GELU() (exact erf) of the ROUNDED pre-activation as F.gelu of a bf16
@@ -34,7 +34,8 @@ def _call(a, b, bias, epi, y1=None):
     return out, out2, db
 
 
-SHAPES = [(25088, 1536, 384), (12544, 768, 192), (6272, 1536, 384), (129, 256, 192), (1, 256, 384), (127, 512, 192), (1000, 768, 384), (64 * 49, 1024, 384), (50176, 1024, 256), (333, 512, 256)]
+SHAPES = [(25088, 1536, 384), (12544, 768, 192), (6272, 1536, 384), (129, 256, 192), (1, 256, 384), (127, 512, 192), (1000, 768, 384), (64 * 49, 1024, 384), (50176, 1024, 256), (333, 512, 256),
+          (6272, 3072, 768), (200, 128, 768), (12544, 2048, 512), (129, 256, 512)]   # K = 512 / 768: two teams of four waves share K
 
 
 @pytest.mark.parametrize("M,N,K", SHAPES)
@@ -128,14 +129,14 @@ def test_gemm_with_gelu_backward_epilogue_on_random_operands_vs_fp64(M, N, K, gp
 def test_what_the_kernel_does_not_cover_is_declined(gpu):
     from slak_amd import _lib
     L = _lib.lib()
-    assert L.slak_linear_gemm_supported(6272, 3072, 768, GELU) == 0                        # stage 4 (K = 768: the B fragments do not fit a wave's registers): library
+    assert L.slak_linear_gemm_supported(3136, 4096, 1024, GELU) == 0                       # K = 1024 (SLaK-B stage 4: a K-half's B fragments would need 128 registers): library
     assert L.slak_linear_gemm_supported(25088, 384, 1536, 0) == 0                          # plain GEMMs with a long K stay with the library
     assert L.slak_linear_gemm_supported(1000, 384, 192, GELU) == 0                         # N not a multiple of 256
     assert L.slak_linear_gemm_supported(401408, 384, 96, GELU) == 0                        # stage 1 has its own streaming kernels (linear_skinny.hip)
-    t = torch.zeros(16, 768, device=gpu, dtype=torch.bfloat16)
-    w = torch.zeros(3072, 768, device=gpu, dtype=torch.bfloat16)
-    o = torch.zeros(16, 3072, device=gpu, dtype=torch.bfloat16)
-    rc = L.slak_linear_gemm(t.data_ptr(), w.data_ptr(), None, o.data_ptr(), o.data_ptr(), None, None, 16, 3072, 768, GELU, None, 0, torch.cuda.current_stream().cuda_stream)
+    t = torch.zeros(16, 1024, device=gpu, dtype=torch.bfloat16)
+    w = torch.zeros(4096, 1024, device=gpu, dtype=torch.bfloat16)
+    o = torch.zeros(16, 4096, device=gpu, dtype=torch.bfloat16)
+    rc = L.slak_linear_gemm(t.data_ptr(), w.data_ptr(), None, o.data_ptr(), o.data_ptr(), None, None, 16, 4096, 1024, GELU, None, 0, torch.cuda.current_stream().cuda_stream)
     assert rc == 2                                                                          # SLAK_ERR_UNSUPPORTED
 
 

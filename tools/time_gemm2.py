@@ -26,11 +26,12 @@ def gemm(a, b, bias, epi, y1=None):
                                       out2.data_ptr() if out2 is not None else None, y1.data_ptr() if y1 is not None else None,
                                       db.data_ptr() if db is not None else None, M, N, K, epi, ws.data_ptr(), nb, st), "slak_linear_gemm")
     return run, out, out2, db
-shapes = [(192, 28), (384, 14), (768, 7)]
+BATCH = int(os.environ.get("BATCH", "128"))
+shapes = [(192, 28), (384, 14), (768, 7)] if BATCH == 128 else [(256, 28), (512, 14)]      # SLaK-T at 128 images; BATCH=64: SLaK-B's covered stages
 if len(sys.argv) > 1:
     shapes = [s for s in shapes if str(s[0]) in sys.argv[1:]]
 for (C, HW) in shapes:
-    M = 128 * HW * HW
+    M = BATCH * HW * HW
     torch.manual_seed(C)
     t = torch.randn(M, C, device=dev).bfloat16(); w1 = (torch.randn(4 * C, C, device=dev) * 0.05).bfloat16(); b1 = torch.randn(4 * C, device=dev).bfloat16()
     w2 = (torch.randn(C, 4 * C, device=dev) * 0.05).bfloat16(); b2 = torch.randn(C, device=dev).bfloat16()
