@@ -71,6 +71,7 @@ __device__ __forceinline__ void g2_lut2x8(const uint16_t* __restrict__ T, const 
 struct Lg2Params {
     const uint16_t* a; const uint16_t* b; const uint16_t* bias; uint16_t* out; uint16_t* out2; const uint16_t* y1; float* part; const void* table;
     int M, N, K, tiles_m, panels, slabs, tps;          // tps = row tiles per slab
+    int xcd_map;                                       // 1: the panels of a slab share an XCD (slabs in whole groups of eight); 0: plain (slab, panel) order
 #ifdef SLAK_LG2_DEV
     int dbg;                                           // dev builds only (SLAK_BUILD_DEFS=-DSLAK_LG2_DEV): 1 no DMA, 2 no fragment reads / MFMAs, 4 no epilogue
 #endif
@@ -118,7 +119,8 @@ __global__ __launch_bounds__(512, 1) void linear_gemm_kernel(const Lg2Params p) 
     // workgroup -> (slab, panel): the panels of a slab run on one XCD (they stream the same rows of A through its L2); the grid holds
     // ceil8(slabs) x panels workgroups, the ones behind the last slab have nothing to do
     const int xcd = blockIdx.x & 7, rr0 = blockIdx.x >> 3;
-    const int slab = xcd + 8 * (rr0 / p.panels), panel = rr0 % p.panels;
+    const int slab = p.xcd_map ? xcd + 8 * (rr0 / p.panels) : (int)blockIdx.x / p.panels;
+    const int panel = p.xcd_map ? rr0 % p.panels : (int)blockIdx.x % p.panels;
     if (slab >= p.slabs) return;
     for (int i = tid; i < TBL / 16; i += 512) ((u32x4*)smem)[i] = ((const u32x4*)p.table)[i];
     const int t_begin = slab * p.tps, t_end = min(t_begin + p.tps, p.tiles_m);
@@ -353,7 +355,7 @@ __global__ __launch_bounds__(512, 1) void linear_gemm_kernel(const Lg2Params p) 
 }
 
 // ---- host side ---------------------------------------------------------------------------------------------------------------
-struct Lg2Plan { int tiles_m, panels, slabs, tps, split; size_t lds; };
+struct Lg2Plan { int tiles_m, panels, slabs, tps, split, xcd_map, grid; size_t lds; };
 
 static bool lg2_plan(int M, int N, int K, int epi, Lg2Plan& pl) {
     if (M < 1 || (epi != EPI_GELU && epi != EPI_DGELU)) return false;
@@ -369,10 +371,19 @@ static bool lg2_plan(int M, int N, int K, int epi, Lg2Plan& pl) {
     pl.panels = N / tn;
     const int slots = mfma_cu_count();                          // one workgroup (eight waves) per CU
     int S = slots / pl.panels; if (S < 1) S = 1;
-    if (S >= 8) S -= S % 8;                                     // whole XCD groups
     if (S > pl.tiles_m) S = pl.tiles_m;
     pl.tps = (pl.tiles_m + S - 1) / S;
-    pl.slabs = (pl.tiles_m + pl.tps - 1) / pl.tps;              // no empty slabs
+    // whole XCD groups of slabs (their panels then stream the same rows of A through one L2) -- unless rounding the slab count down to a multiple of eight
+    // would lengthen every workgroup's walk (stage 4 of SLaK-T: 49 row tiles for 24 panels = 10 slabs of 5 tiles; 8 slabs would mean 7 tiles each on 2/3 of
+    // the CUs: 78 -> 56 us measured)
+    const int S8 = S - S % 8;
+    if (S8 >= 8 && (pl.tiles_m + S8 - 1) / S8 == pl.tps) {
+        pl.slabs = (pl.tiles_m + pl.tps - 1) / pl.tps;          // no empty slabs
+        pl.xcd_map = 1; pl.grid = (pl.slabs + 7) / 8 * 8 * pl.panels;
+    } else {
+        pl.slabs = (pl.tiles_m + pl.tps - 1) / pl.tps;
+        pl.xcd_map = 0; pl.grid = pl.slabs * pl.panels;
+    }
     return true;
 }
 
@@ -434,10 +445,10 @@ int slak_linear_gemm(const void* a, const void* b, const void* bias, void* out, 
 #ifdef SLAK_LG2_DEV
     { const char* e = getenv("SLAK_LG2_DBG"); p.dbg = e ? atoi(e) : 0; }
 #endif
-    p.M = M; p.N = N; p.K = K; p.tiles_m = pl.tiles_m; p.panels = pl.panels; p.slabs = pl.slabs; p.tps = pl.tps;
+    p.M = M; p.N = N; p.K = K; p.tiles_m = pl.tiles_m; p.panels = pl.panels; p.slabs = pl.slabs; p.tps = pl.tps; p.xcd_map = pl.xcd_map;
     if (epilogue == EPI_GELU) { p.table = g2_table_device(); if (!p.table) return SLAK_ERR_LAUNCH; }
     if (epilogue == EPI_DGELU) { p.table = gelu_grad_table_device(); if (!p.table) return SLAK_ERR_LAUNCH; }
-    const dim3 grid((unsigned)((pl.slabs + 7) / 8 * 8 * pl.panels));
+    const dim3 grid((unsigned)pl.grid);
 #define SLAK_LG2_LAUNCH(E, KS, SP)                                                      \
     do {                                                                                \
         auto k = linear_gemm_kernel<E, KS, SP>;                                         \
