@@ -812,7 +812,7 @@ static TailDims make_dims(int N, int C, int P, int elem_bytes, size_t lds_budget
     // (ii) enough tiles to keep ~4 workgroups per CU busy, (iii) then the widest tile that fits the LDS budget
     TailDims d; d.N = N; d.C = C; d.P = P;
     static const int cand[] = {128, 64, 56, 48, 40, 32, 28, 24, 20, 16, 12, 8};
-    static const char* ov = getenv("SLAK_TAIL_TP");
+    static const char* ov = slak_dev_getenv("SLAK_TAIL_TP");
     int best = 16; double best_score = -1e30;
     for (int TP : cand) {
         if (TP > 16 && (size_t)C * (TP + 2) * elem_bytes > lds_budget) continue;
@@ -1151,7 +1151,7 @@ int slak_gelu_backward_bias(const void* dact, const void* y1, void* dy1, float* 
     if (cols % 8) return SLAK_ERR_UNSUPPORTED;
     if (!workspace || workspace_bytes < slak_gelu_bwd_workspace_bytes(rows, cols)) return SLAK_ERR_WORKSPACE;
     // enough workgroups to fill the chip, each a contiguous block of rows (>= 8 rows to amortise the partial row)
-    static const int nwg_target = [] { const char* e = getenv("SLAK_GELU_NWG"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 1024; }();
+    static const int nwg_target = [] { const char* e = slak_dev_getenv("SLAK_GELU_NWG"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 1024; }();
     int nwg = nwg_target;
     int rpw = (rows + nwg - 1) / nwg; if (rpw < 8) rpw = 8;
     nwg = (rows + rpw - 1) / rpw;

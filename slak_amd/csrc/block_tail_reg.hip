@@ -920,7 +920,7 @@ static int launch_sr_bwd_reg(const float* dout, const uint16_t* dout16, float* d
 }
 
 static int rt_chan_max_p() {                 // largest plane (pixels) the channel-group kernels take (dev: SLAK_RT_CHAN_MAXP)
-    static const int v = [] { const char* e = getenv("SLAK_RT_CHAN_MAXP"); const int x = e ? atoi(e) : 0; return x > 0 ? x : 256; }();
+    static const int v = [] { const char* e = slak_dev_getenv("SLAK_RT_CHAN_MAXP"); const int x = e ? atoi(e) : 0; return x > 0 ? x : 256; }();
     return v;
 }
 static bool rt_chan_waves() {                // SLAK_RT_CHAN=0: small planes keep the pixel-tile residual kernel (A/B testing)

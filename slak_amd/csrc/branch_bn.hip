@@ -132,7 +132,7 @@ __global__ __launch_bounds__(BN_THREADS) void bn3_chansums(const uint16_t* __res
     }
 }
 static void bn_slices(int N, int C, int* S, int* per) {            // ~16384 wavefronts (a full machine of eight per SIMD, twice over), whole images per slice
-    static const int waves = [] { const char* e = getenv("SLAK_BN_WAVES"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 16384; }();
+    static const int waves = [] { const char* e = slak_dev_getenv("SLAK_BN_WAVES"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 16384; }();
     int s = waves / C; if (s < 1) s = 1; if (s > N) s = N;
     *per = (N + s - 1) / s; *S = (N + *per - 1) / *per;
 }

@@ -245,7 +245,7 @@ int slak_dwconv2d_tri_supported_op(int dtype, int N, int C, int H, int W, int K,
     if (op == 0 && dwconv_mfma_stream_tri_supported(N, C, H, W, K, dtype)) return 1;                        // planes of 2 x 2 tiles, forward: one MFMA stream per wave
     if (!dwconv_mfma_team_tri_supported(N, C, H, W, K, dtype, op == 1)) return 0;
     const bool one_tile = H <= 32 && W <= 32;
-    static const bool all = [] { const char* e = getenv("SLAK_TEAM_ALL"); return e && e[0] == '1'; }();     // A/B: team kernels wherever they exist
+    static const bool all = [] { const char* e = slak_dev_getenv("SLAK_TEAM_ALL"); return e && e[0] == '1'; }();     // A/B: team kernels wherever they exist
     return (one_tile || op == 1 || all) ? 1 : 0;
 }
 /* both ops (the merged inference block, callers that want all or nothing) */

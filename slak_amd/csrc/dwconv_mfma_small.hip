@@ -266,7 +266,7 @@ static bool fill_small_params(SmallParams& p, const ConvDims& d, bool vert, int 
     int slices = resident_wgs / cblocks; if (slices < 1) slices = 1;
     if (slices > d.N) slices = d.N;
     int per = (d.N + slices - 1) / slices;
-    static const int min_iters = [] { const char* e = getenv("SLAK_SMALL_MIN_ITERS"); const int v = e ? atoi(e) : 3; return v < 1 ? 1 : v; }();
+    static const int min_iters = [] { const char* e = slak_dev_getenv("SLAK_SMALL_MIN_ITERS"); const int v = e ? atoi(e) : 3; return v < 1 ? 1 : v; }();
     if (per < min_iters * NI) per = min_iters * NI;                          // at least 3 iterations per workgroup: amortise its prologue
     if (per > d.N) per = d.N;
     if (NI > per) { NI = (per + p.PPT - 1) / p.PPT * p.PPT; }

@@ -545,7 +545,7 @@ static bool quad_enabled() {                   // SLAK_SMALL_QUAD=0 keeps the on
     return v;
 }
 static int quad_target_wgs() {                 // workgroups the launch aims at (dev: SLAK_SQ_WGS per CU)
-    static const int wgs_per_cu = [] { const char* e = getenv("SLAK_SQ_WGS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 4; }();
+    static const int wgs_per_cu = [] { const char* e = slak_dev_getenv("SLAK_SQ_WGS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 4; }();
     return wgs_per_cu * mfma_cu_count();
 }
 static bool fill_quad_params(SmallTriParams& p, int N, int C, int H, int W, int K, int target_wgs) {

@@ -710,7 +710,7 @@ size_t dwconv_mfma_small_tri_wgrad_workspace(int N, int C, int K) {
 template <typename T>
 static int launch_qw_t(SmallTriWgradParams& p, size_t ws_bytes, hipStream_t st) {
     auto k = dwconv_mfma_small_quad_wgrad_kernel<T>;
-    static const int wgs_per_cu = [] { const char* e = getenv("SLAK_QW_WGS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 3; }();
+    static const int wgs_per_cu = [] { const char* e = slak_dev_getenv("SLAK_QW_WGS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 3; }();
     fill_stw_params(p, p.N, p.C, p.H, p.W, p.K, wgs_per_cu * mfma_cu_count());
     int per = (p.images_per_slice + 7) & ~7;                        // whole octets
     if (per > ((p.N + 7) & ~7)) per = (p.N + 7) & ~7;
@@ -745,7 +745,7 @@ int launch_dwconv_mfma_small_tri_wgrad(const void* const* dy, const void* x, flo
     for (int b = 0; b < 3; ++b) { p.dy[b] = dy[b]; p.dw[b] = dw[b]; }
     p.x = x; p.partial = (float*)ws; p.dx = nullptr; p.w[0] = p.w[1] = p.w[2] = nullptr;
 #ifdef SLAK_QW_DEV
-    { static const int dbg = [] { const char* e = getenv("SLAK_QW_DBG"); return e ? atoi(e) : 0; }(); p.dbg = dbg; }
+    { static const int dbg = [] { const char* e = slak_dev_getenv("SLAK_QW_DBG"); return e ? atoi(e) : 0; }(); p.dbg = dbg; }
 #else
     p.dbg = 0;
 #endif

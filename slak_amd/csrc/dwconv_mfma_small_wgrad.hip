@@ -219,7 +219,7 @@ static bool fill_sw_params(SmallWgradParams& p, const ConvDims& d, bool vert, in
     int slices = resident_wgs / cblocks; if (slices < 1) slices = 1;
     if (slices > d.N) slices = d.N;
     int per = (d.N + slices - 1) / slices;
-    static const int min_iters = [] { const char* e = getenv("SLAK_SMALL_MIN_ITERS"); const int v = e ? atoi(e) : 3; return v < 1 ? 1 : v; }();
+    static const int min_iters = [] { const char* e = slak_dev_getenv("SLAK_SMALL_MIN_ITERS"); const int v = e ? atoi(e) : 3; return v < 1 ? 1 : v; }();
     if (per < min_iters * NI) per = min_iters * NI;                          // amortise the prologue / epilogue of a workgroup
     if (per > d.N) per = d.N;
     if (NI > per) NI = per;

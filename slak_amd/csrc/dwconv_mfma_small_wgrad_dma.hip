@@ -237,7 +237,7 @@ static int launch_swd_ns(SmallWgradDmaParams& p, const ConvDims& d, size_t ws_by
 
 template <typename T, bool VERT>
 static int launch_swd_t(SmallWgradDmaParams& p, const ConvDims& d, size_t ws_bytes, hipStream_t st) {
-    static const int ns = [] { const char* e = getenv("SLAK_SWD_NS"); return e && atoi(e) == 3 ? 3 : 4; }();
+    static const int ns = [] { const char* e = slak_dev_getenv("SLAK_SWD_NS"); return e && atoi(e) == 3 ? 3 : 4; }();
     return ns == 3 ? launch_swd_ns<T, VERT, 3>(p, d, ws_bytes, st) : launch_swd_ns<T, VERT, 4>(p, d, ws_bytes, st);
 }
 

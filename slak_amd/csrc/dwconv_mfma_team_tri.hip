@@ -561,7 +561,7 @@ static size_t team_lds_bytes(const TeamParams& p, int cls) {
 
 // ring depth: as deep as two workgroups per CU allow (80 KB each), at most 6 (forward) / 3 (dgrad: three tensors per slot)
 static bool team_pick_ring(TeamParams& p, int cls) {
-    static const int forced = [] { const char* e = getenv("SLAK_TEAM_NB"); return e ? atoi(e) : 0; }();
+    static const int forced = [] { const char* e = slak_dev_getenv("SLAK_TEAM_NB"); return e ? atoi(e) : 0; }();
     const int hi = p.dgrad ? 3 : 6;
     for (int nb = (forced >= 2 && forced <= 8) ? forced : hi; nb >= 2; --nb) {
         p.NB = nb;
@@ -593,7 +593,7 @@ int dwconv_mfma_team_tri_stats_rows(int N, int C, int H, int W, int K, int dtype
 
 // which (op, class) runs one team per workgroup: bit 0 forward one-tile planes, 1 forward 2 x 2 tiles, 2 dgrad one-tile, 3 dgrad 2 x 2
 static int team_solo_mask() {
-    static const int m = [] { const char* e = getenv("SLAK_TEAM_SOLO"); return e ? atoi(e) : TT_SOLO_DEFAULT; }();
+    static const int m = [] { const char* e = slak_dev_getenv("SLAK_TEAM_SOLO"); return e ? atoi(e) : TT_SOLO_DEFAULT; }();
     return m;
 }
 

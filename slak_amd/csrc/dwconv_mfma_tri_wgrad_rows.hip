@@ -399,7 +399,7 @@ static bool fill_tri_rows_params(TriRowsParams& p, int N, int C, int H, int W, i
     if (p.maxspan > 8) return false;
     p.tensor_bytes = (unsigned)((size_t)N * C * H * W * 2);
 #ifdef SLAK_TRIROWS_DEV
-    { static const int dbg = [] { const char* e = getenv("SLAK_TRIROWS_DBG"); return e ? atoi(e) : 0; }(); p.dbg = dbg; }
+    { static const int dbg = [] { const char* e = slak_dev_getenv("SLAK_TRIROWS_DBG"); return e ? atoi(e) : 0; }(); p.dbg = dbg; }
 #else
     p.dbg = 0;
 #endif
@@ -412,7 +412,7 @@ static size_t tri_rows_lds_bytes(const TriRowsParams& p) {
 }
 
 static int tri_rows_wgs() {
-    static const int wgs = [] { const char* e = getenv("SLAK_TRIROWS_WGS"); return e ? atoi(e) : 0; }();      // (dev: a grid other than one workgroup per CU)
+    static const int wgs = [] { const char* e = slak_dev_getenv("SLAK_TRIROWS_WGS"); return e ? atoi(e) : 0; }();      // (dev: a grid other than one workgroup per CU)
     return wgs > 0 ? wgs : mfma_cu_count();
 }
 

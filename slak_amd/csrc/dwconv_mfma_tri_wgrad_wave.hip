@@ -247,7 +247,7 @@ static bool fill_tri_wave_params(TriWaveParams& p, int N, int C, int H, int W, i
 static size_t tri_wave_lds_bytes(int K) { return (size_t)MF_WAVES * (64 + 4 * TV_RS * TV_CPR * 16) + (size_t)MF_WAVES * (2 * K * MF_TAPS + MF_TAPS * MF_TAPS) * 4 + 32; }
 
 static int tri_wave_cus() {
-    static const int cus_env = [] { const char* e = getenv("SLAK_TRIWAVE_CUS"); return e ? atoi(e) : 0; }();      // (dev: pretend another CU count)
+    static const int cus_env = [] { const char* e = slak_dev_getenv("SLAK_TRIWAVE_CUS"); return e ? atoi(e) : 0; }();      // (dev: pretend another CU count)
     return cus_env > 0 ? cus_env : mfma_cu_count();
 }
 

@@ -34,6 +34,11 @@ struct WgradRowsParams {
     unsigned tensor_bytes;
     int dbg;               // SLAK_VROWS_DBG (timing experiments): 1 = no k-loop, 2 = no DMA, 4 = no epilogue
 };
+#ifdef SLAK_DEV_KNOBS                  // dev builds only: the shipped kernel compiles the timing experiments out
+#define VR_DBG(bit) (p.dbg & (bit))
+#else
+#define VR_DBG(bit) 0
+#endif
 
 // PAIR: dw (K x 5) and dw2 (5 x 5) of one block in one launch: G_r[o, i] of the small branch is the same correlation with its own dY, so x
 // is fetched and shifted once for both -- five more MFMAs per k-step behind the same operand reads, a third plane copy per slot
@@ -97,7 +102,7 @@ __global__ __launch_bounds__(MF_THREADS, PAIR ? 2 : 3) void dwconv_mfma_wgrad_vr
         for (int k = 0; k < VR_MAX_IPW; ++k) {
             if (ins_t[k] >= 0) {                                      // wave-uniform
                 const int off = (int)gbase + ins_src[k];
-                if (ins_ok[k] && !(p.dbg & 2)) {
+                if (ins_ok[k] && !VR_DBG(2)) {
                     if (ins_t[k] == 0) lds_dma16((unsigned)off, rs_dy, __builtin_amdgcn_readfirstlane(slot + ins_dst[k]));
                     else if (ins_t[k] == 1) lds_dma16((unsigned)off, rs_x, __builtin_amdgcn_readfirstlane(slot + ins_dst[k]));
                     else lds_dma16((unsigned)off, rs_d2, __builtin_amdgcn_readfirstlane(slot + ins_dst[k]));
@@ -134,13 +139,13 @@ __global__ __launch_bounds__(MF_THREADS, PAIR ? 2 : 3) void dwconv_mfma_wgrad_vr
 
     for (int it = 0; it < iters; ++it) {
         int later = iters - 1 - it; if (later > p.nb - 2) later = p.nb - 2;       // planes issued after `it` that may still be in flight
-        if (!(p.dbg & 8)) {
+        if (!VR_DBG(8)) {
         wait_vmcnt_dyn(later * my_instr);                         // my DMAs of plane `it` have landed (loads retire in order)
         wg_barrier();                                             // everyone's have; everyone is done with the slot refilled next
         }
         issue_plane(it + p.nb - 1);                               // streams in while this and the following planes are consumed
         const unsigned slot = ring_b + (unsigned)(it % p.nb) * slot_b;
-        if (p.dbg & 1) continue;
+        if (VR_DBG(1)) continue;
         const unsigned ab = slot + a_off, xb = slot + x_off, a2b = ab + 2 * copy_b;
         // k-loop, pinned software pipeline: the five 16-byte reads of the next k-step are issued one behind each of this k-step's MFMAs
         auto sh = [](unsigned hi, unsigned lo) -> unsigned { return __builtin_amdgcn_alignbit(hi, lo, 16); };
@@ -190,7 +195,7 @@ __global__ __launch_bounds__(MF_THREADS, PAIR ? 2 : 3) void dwconv_mfma_wgrad_vr
     wait_vmcnt<0>();
     __syncthreads();                                              // the ring is dead: its space becomes the diagonal-sum scratch
 
-    if (p.dbg & 4) return;
+    if (VR_DBG(4)) return;
     // ---- diagonal sums through a skewed per-wave tile (see dwconv_mfma_wgrad_dma.hip) -----------------------------------------
     float* mine = dwl + wave * ntap;
     float* tile = scratch + wave * (32 * 64);
@@ -246,9 +251,9 @@ static bool fill_vrows_params(WgradRowsParams& p, const ConvDims& d, int residen
     const int per = (d.N + slices - 1) / slices;
     p.planes_per_wg = per; p.slices = (d.N + per - 1) / per;
     p.tensor_bytes = (unsigned)((size_t)d.N * d.C * d.H * d.W * 2);
-    static const int nb_env = [] { const char* e = getenv("SLAK_VROWS_NB"); const int v = e ? atoi(e) : VR_NB_DEFAULT; return v < 2 ? 2 : (v > 4 ? 4 : v); }();
+    static const int nb_env = [] { const char* e = slak_dev_getenv("SLAK_VROWS_NB"); const int v = e ? atoi(e) : VR_NB_DEFAULT; return v < 2 ? 2 : (v > 4 ? 4 : v); }();
     p.nb = nb_env;
-    { static const int dbg = [] { const char* e = getenv("SLAK_VROWS_DBG"); return e ? atoi(e) : 0; }(); p.dbg = dbg; }
+    { static const int dbg = [] { const char* e = slak_dev_getenv("SLAK_VROWS_DBG"); return e ? atoi(e) : 0; }(); p.dbg = dbg; }
     return (size_t)d.N * d.C * d.H * d.W * 2 < 0x7fffffffull;         // (signed source offsets in the DMA plan)
 }
 
@@ -280,7 +285,7 @@ static int launch_vrows_t(WgradRowsParams& p, const ConvDims& d, size_t ws_bytes
         int per_cu = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k, MF_THREADS, lds) != hipSuccess || per_cu < 1) per_cu = 1;
         if (per_cu > 8) per_cu = 8;
-        { const char* e = getenv("SLAK_VROWS_WGS"); if (e && atoi(e) > 0 && atoi(e) < per_cu) per_cu = atoi(e); }      // (dev: fewer workgroups per CU)
+        { const char* e = slak_dev_getenv("SLAK_VROWS_WGS"); if (e && atoi(e) > 0 && atoi(e) < per_cu) per_cu = atoi(e); }      // (dev: fewer workgroups per CU)
         if ((size_t)per_cu * (lds + 512) > 160 * 1024) --per_cu;       // (the query ignores the LDS allocation granule)
         if (per_cu < 1) per_cu = 1;
         resident = per_cu * mfma_cu_count();

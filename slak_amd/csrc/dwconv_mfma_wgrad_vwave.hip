@@ -249,7 +249,7 @@ size_t dwconv_mfma_wgrad_vwave_workspace(const ConvDims& d) {
 template <typename T, bool PAIR, bool HORIZ = false>
 static int launch_vwave_t(WgradWaveParams& p, const ConvDims& d, size_t ws_bytes, hipStream_t st) {
     auto k = HORIZ ? dwconv_mfma_wgrad_vwave_kernel<T, false, true> : dwconv_mfma_wgrad_vwave_kernel<T, PAIR, false>;
-    static const int wgs_per_cu = [] { const char* e = getenv("SLAK_VWAVE_WGS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 2; }();
+    static const int wgs_per_cu = [] { const char* e = slak_dev_getenv("SLAK_VWAVE_WGS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 2; }();
     fill_vwave_params(p, d, wgs_per_cu * mfma_cu_count());
     const size_t lds = vwave_lds_bytes(p);
     (void)slak_set_max_lds((const void*)k, lds);

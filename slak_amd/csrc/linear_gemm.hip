@@ -443,7 +443,7 @@ int slak_linear_gemm(const void* a, const void* b, const void* bias, void* out, 
     p.a = (const uint16_t*)a; p.b = (const uint16_t*)b; p.bias = (const uint16_t*)bias; p.out = (uint16_t*)out; p.out2 = (uint16_t*)out2;
     p.y1 = (const uint16_t*)y1; p.part = (float*)workspace; p.table = nullptr;
 #ifdef SLAK_LG2_DEV
-    { const char* e = getenv("SLAK_LG2_DBG"); p.dbg = e ? atoi(e) : 0; }
+    { const char* e = slak_dev_getenv("SLAK_LG2_DBG"); p.dbg = e ? atoi(e) : 0; }
 #endif
     p.M = M; p.N = N; p.K = K; p.tiles_m = pl.tiles_m; p.panels = pl.panels; p.slabs = pl.slabs; p.tps = pl.tps; p.xcd_map = pl.xcd_map;
     if (epilogue == EPI_GELU) { p.table = g2_table_device(); if (!p.table) return SLAK_ERR_LAUNCH; }

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stddef.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/slak_hip.h"
 
@@ -26,6 +27,18 @@ static inline bool slak_set_max_lds(const void* kernel, size_t lds) {
     return true;
 }
 
+
+// Tuning and experiment knobs (workgroup counts, ring depths, the timing-experiment modes of a kernel) are read from the environment only by DEV builds
+// (SLAK_BUILD_DEFS=-DSLAK_DEV_KNOBS, on top of the per-kernel -DSLAK_*_DEV defines): the shipped library has the measured defaults compiled in.  What stays a
+// plain getenv in the shipped library are the A/B switches that choose between two SHIPPED code paths (SLAK_MFMA_DMA, SLAK_TRI_ROWS, SLAK_LINEAR_GEMM, ...: DESIGN 4).
+static inline const char* slak_dev_getenv(const char* name) {
+#ifdef SLAK_DEV_KNOBS
+    return getenv(name);
+#else
+    (void)name;
+    return nullptr;
+#endif
+}
 
 // ---- element types -------------------------------------------------------------------------
 struct bf16_t { uint16_t v; };          // storage-only bfloat16

@@ -26,7 +26,7 @@ constexpr unsigned TT_OOB = 0x80000000u;   // a buffer offset beyond every tenso
 #ifdef SLAK_TEAM_DEV
 #define TT_DBG(p, bit) ((p).dbg & (bit))
 #define TT_TIMELINE(p, vb) ((p).tl ? (p).tl + (size_t)(vb) * 64 : nullptr)
-static inline int team_dev_flags() { static const int dbg = [] { const char* e = getenv("SLAK_TEAM_DBG"); return e ? atoi(e) : 0; }(); return dbg; }
+static inline int team_dev_flags() { static const int dbg = [] { const char* e = slak_dev_getenv("SLAK_TEAM_DBG"); return e ? atoi(e) : 0; }(); return dbg; }
 #else
 #define TT_DBG(p, bit) 0
 #define TT_TIMELINE(p, vb) ((unsigned long long*)nullptr)

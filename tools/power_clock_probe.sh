@@ -1,6 +1,6 @@
 #!/bin/bash
-# needs a DEV build of the library (the shipped kernel compiles the experiments out): built here with SLAK_BUILD_DEFS=-DSLAK_TRIROWS_DEV
-export SLAK_BUILD_DEFS=-DSLAK_TRIROWS_DEV; ( cd $GRAFT_REPO_ROOT && touch slak_amd/csrc/dwconv_mfma_tri_wgrad_rows.hip && python -m slak_amd.build > /dev/null 2>&1 )
+# needs a DEV build of the library (the shipped kernel compiles the experiments out): built here with SLAK_BUILD_DEFS="-DSLAK_TRIROWS_DEV -DSLAK_DEV_KNOBS"
+export SLAK_BUILD_DEFS="-DSLAK_TRIROWS_DEV -DSLAK_DEV_KNOBS"; ( cd $GRAFT_REPO_ROOT && touch slak_amd/csrc/dwconv_mfma_tri_wgrad_rows.hip && python -m slak_amd.build > /dev/null 2>&1 )
 # The shader clock inside the one-launch weight gradient (128 x 96 x 56 x 56, bf16) as a function of how many CUs work and whether they stream from
 # HBM: s_memtime cycles / s_memrealtime (100 MHz) of workgroup 0.  36 = the kernel without its epilogue; 38 = without DMA as well; 100 = DMA from
 # one cached MiB.  -> profiles/rNN_power_clock_probe.txt

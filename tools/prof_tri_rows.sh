@@ -1,6 +1,6 @@
 #!/bin/bash
-# needs a DEV build of the library (the shipped kernel compiles the experiments out): built here with SLAK_BUILD_DEFS=-DSLAK_TRIROWS_DEV
-export SLAK_BUILD_DEFS=-DSLAK_TRIROWS_DEV; ( cd $GRAFT_REPO_ROOT && touch slak_amd/csrc/dwconv_mfma_tri_wgrad_rows.hip && python -m slak_amd.build > /dev/null 2>&1 )
+# needs a DEV build of the library (the shipped kernel compiles the experiments out): built here with SLAK_BUILD_DEFS="-DSLAK_TRIROWS_DEV -DSLAK_DEV_KNOBS"
+export SLAK_BUILD_DEFS="-DSLAK_TRIROWS_DEV -DSLAK_DEV_KNOBS"; ( cd $GRAFT_REPO_ROOT && touch slak_amd/csrc/dwconv_mfma_tri_wgrad_rows.hip && python -m slak_amd.build > /dev/null 2>&1 )
 # dev: true kernel durations (rocprofv3 --kernel-trace) of the one-launch weight gradient under SLAK_TRIROWS_DBG settings
 #   usage: tools/prof_tri_rows.sh "N C H K" dbg...
 cd /tmp && export TMPDIR=/tmp
