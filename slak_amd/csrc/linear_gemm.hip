@@ -283,19 +283,21 @@ __global__ __launch_bounds__(512, 1) void linear_gemm_kernel(const Lg2Params p) 
                     for (int q = 0; q < 4; q += 2) {
                         const u32x2 ya = *SLAK_LDS(const u32x2, stg + l31 * LG2_SP + (8 * q + 4 * lhi) * 2);
                         const u32x2 yb = *SLAK_LDS(const u32x2, stg + l31 * LG2_SP + (8 * (q + 1) + 4 * lhi) * 2);
-                        const uint4 yv = uint4{ya[0], ya[1], yb[0], yb[1]};
+                        // rows behind M: their dact is 0 (A's rows behind M land as zeros), but the y1 row they were handed is another row's and may hold anything --
+                        // with y = 0 the product is 0 * 0.5 = 0 exactly, so the column sums need no per-element select and accumulate in place
+                        const uint4 yv = rok ? uint4{ya[0], ya[1], yb[0], yb[1]} : uint4{0u, 0u, 0u, 0u};
                         const uint4 gv = uint4{pack2<bf16_t>(acc[i][4 * q], acc[i][4 * q + 1]), pack2<bf16_t>(acc[i][4 * q + 2], acc[i][4 * q + 3]),
                                                pack2<bf16_t>(acc[i][4 * q + 4], acc[i][4 * q + 5]), pack2<bf16_t>(acc[i][4 * q + 6], acc[i][4 * q + 7])};
                         uint4 ov;
                         float cs[8];
     #pragma unroll
-                        for (int e = 0; e < 8; ++e) cs[e] = 0.f;
+                        for (int e = 0; e < 8; ++e) cs[e] = colsum[4 * q + e];
                         float tv[8];
                         if (__builtin_amdgcn_ballot_w64(!gelu_grad_gather8(T, yv, tv)) == 0) gelu_bwd8_apply(gv, tv, ov, cs);
                         else gelu_bwd8(T, gv, yv, ov, cs);
                         py[2 * q] = ov.x; py[2 * q + 1] = ov.y; py[2 * q + 2] = ov.z; py[2 * q + 3] = ov.w;
     #pragma unroll
-                        for (int e = 0; e < 8; ++e) colsum[4 * q + e] += rok ? cs[e] : 0.f;
+                        for (int e = 0; e < 8; ++e) colsum[4 * q + e] = cs[e];
                     }
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier();
                 } else {
