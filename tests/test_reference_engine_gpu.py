@@ -222,3 +222,35 @@ def test_reference_engine_on_the_fused_bf16_product(gpu):
         init = _unpack(g["m_init/" + n], m.shape)
         assert int(m.sum().item()) == int(init.sum()), n
         assert not np.array_equal(m.cpu().numpy(), init), n                       # ... and moved some of it
+
+
+def test_reference_engine_amp_branch_on_the_product(gpu):
+    """engine.py:50-53, 66-76: the use_amp=True branch -- fp16 autocast (torch.cuda.amp.autocast's default dtype), utils.NativeScalerWithGradNormCount (GradScaler:
+    scale, unscale_, grad norm, scaler.step(optimizer)) -- on the product's model and MaskedAdamW.  The reference's op receives fp32 there
+    (depthwise_conv2d_implicit_gemm.py:16 cast_inputs=torch.float32) and so does the mirror (lowp_dwconv=False: the exact fp32 kernels); this branch NEVER calls
+    mask.step() (the reference's AMP path trains dense), which the test pins: masks unchanged, mask.steps == 0, the optimizer stepped through the scaler."""
+    engine, utils = _engine()
+    g = load_golden("engine_uf1")
+    model = _model(g, gpu)
+    sink = io.StringIO()
+    with contextlib.redirect_stdout(sink):
+        args, model_ema, optimizer, lr_values, wd_values, criterion, loader, mask, steps_per_epoch = _construct(g, gpu, utils, 1, model)
+        loss_scaler = utils.NativeScalerWithGradNormCount()                      # main.py:385
+        w0 = {k: v.detach().clone() for k, v in model.state_dict().items()}
+        m0 = {n: m.clone() for n, m in mask.masks.items()}
+        train_stats = engine.train_one_epoch(
+            model, criterion, loader, optimizer,
+            gpu, 0, loss_scaler, args.clip_grad, model_ema, None,
+            log_writer=None, wandb_logger=None, start_steps=0,
+            lr_schedule_values=lr_values, wd_schedule_values=wd_values,
+            num_training_steps_per_epoch=steps_per_epoch, update_freq=1,
+            use_amp=True, mask=mask
+        )
+    losses = np.array(criterion.values)
+    assert np.isfinite(losses).all() and np.isfinite(train_stats["grad_norm"])
+    np.testing.assert_allclose(losses[0], g["losses"][0], rtol=5e-3)              # same weights, fp16 GEMMs: the first loss is the fp64 run's to fp16 accuracy
+    np.testing.assert_allclose(losses, g["losses"], rtol=0.15)                    # (dense from here on: the recorded run prunes and regrows)
+    assert mask.steps == 0 and all(torch.equal(mask.masks[n], m0[n]) for n in m0)  # engine.py:68-76 has no mask.step()
+    moved = [k for k, v in model.state_dict().items() if v.dtype.is_floating_point and "running" not in k and not torch.equal(v, w0[k])]
+    assert len(moved) > 50, len(moved)                                            # scaler.step(optimizer) ran MaskedAdamW
+    assert loss_scaler.state_dict()["scale"] > 0
