@@ -204,3 +204,30 @@ def test_cached_transposed_weights_follow_the_parameter(gpu):
             assert t is told and torch.equal(t, w.detach().bfloat16().t().contiguous())    # refreshed in place
     finally:
         block_ops.cache_lowp_weights = saved
+
+
+@pytest.mark.parametrize("M,N,K", [(25088, 1536, 384), (6272, 3072, 768), (12544, 768, 192)])
+def test_counted_waits_hold_while_another_stream_hammers_hbm(M, N, K, gpu):
+    """The kernel waits for its LDS-DMA chunks with COUNTED vmcnt across tiles (operations retire in issue order) and reuses ring stages and staging tiles on that
+    basis.  40 launches per epilogue of the same inputs while a second stream copies buffers of changing size (memory latencies move around): every output bit must equal
+    the first launch's (tools/stress_linear_gemm.py is the long version: 1800 launches)."""
+    from slak_amd import _lib
+    L = _lib.lib()
+    torch.manual_seed(K)
+    t = torch.randn(M, K, device=gpu).bfloat16()
+    w = (torch.randn(N, K, device=gpu) * 0.05).bfloat16()
+    b = torch.randn(N, device=gpu).bfloat16()
+    y1 = torch.randn(M, N, device=gpu).bfloat16()
+    side = torch.cuda.Stream()
+    junk = [torch.empty(n, device=gpu, dtype=torch.uint8) for n in (1 << 20, 29 << 20, 211 << 20)]
+    junk2 = [torch.empty_like(j) for j in junk]
+    for epi in (GELU, DGELU):
+        first = _call(t, w, b if epi == GELU else None, epi, y1=y1 if epi == DGELU else None)
+        for it in range(40):
+            with torch.cuda.stream(side):
+                junk2[it % 3].copy_(junk[it % 3])
+            got = _call(t, w, b if epi == GELU else None, epi, y1=y1 if epi == DGELU else None)
+            for a_, b_ in zip(first, got):
+                if a_ is not None:
+                    assert torch.equal(a_.view(torch.int16 if a_.dtype == torch.bfloat16 else torch.int32), b_.view(torch.int16 if b_.dtype == torch.bfloat16 else torch.int32)), (epi, it)
+    torch.cuda.synchronize()
