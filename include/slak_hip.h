@@ -59,7 +59,7 @@ const char* slak_last_hip_error(void);      /* text of the last HIP error seen b
 /* ABI version: bumped whenever an entry point's argument list or meaning changes (round 5: 5).  A host module compiled against this header
  * (slak_amd/pybind, *.cpp) records the value it saw and refuses to load on a library that reports another one: a stale module would call raw-pointer
  * entry points with a changed argument list -- silent corruption, not an error. */
-#define SLAK_ABI_VERSION 5
+#define SLAK_ABI_VERSION 6
 int slak_version(void);                     /* == SLAK_ABI_VERSION of the header the library was built from */
 int slak_device_info(int* cu_count, int* lds_bytes_per_cu, char* arch_name, size_t arch_name_len);
 int slak_set_conv_algo(int algo);           /* process-wide override of the AUTO choice */
@@ -256,6 +256,12 @@ int slak_ln_patch_backward(const void* g_bf16, const float* x, const float* weig
  * a[n][ho * (W/4) + wo][(c * 4 + kh) * 4 + kw] = x[n, c, 4 ho + kh, 4 wo + kw]; the conv is Y[n] = weight.view(C, in_chans*16) . a[n]^T (NCHW).
  * H and W multiples of 4. */
 int slak_stem_patchify(const float* x, void* a_bf16, int N, int Cin, int H, int W, void* stream);
+
+/* Bias gradient of the stem / downsample convolutions: out[c] = sum over n and p of the bf16 NCHW gradient x[n][c][p], fp32, fixed summation
+ * order.  Replaces `grad_output.sum((0, 2, 3))` of torch's Conv2d backward (reference: models/SLaK.py:188-199, the stem and downsample
+ * nn.Conv2d layers).  workspace: slak_channel_sums_workspace_bytes(C) bytes. */
+size_t slak_channel_sums_workspace_bytes(int C);
+int slak_channel_sums_bf16(const void* x_bf16, float* out, int N, int C, int P, void* workspace, size_t workspace_bytes, void* stream);
 
 /* The pointwise convolutions on the large maps (stage 1-2: M = N*H*W rows of C <= 192 or 4C <= 768 channels against a weight of a few
  * hundred KB) are HBM streams, not GEMMs: Y[M,N] = X[M,K] . Wt[N,K]^T (+ bias[N]) with both operands K-contiguous ("NT": pwconv1 /

@@ -111,6 +111,8 @@ SIGNATURES = {
     "slak_dwconv2d_pair_backward_filter": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     "slak_dwconv2d_tri_backward_filter": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     "slak_stem_patchify": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    "slak_channel_sums_workspace_bytes": (_sz, [_i]),
+    "slak_channel_sums_bf16": (_i, [_vp, _vp, _i, _i, _i, _vp, _sz, _vp]),
     "slak_ln_patch_supported": (_i, [_i, _i, _i, _i]),
     "slak_ln_patch_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, ctypes.c_float, _vp]),
     "slak_ln_patch_backward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _sz, _vp]),

@@ -686,6 +686,19 @@ def ln_patch_covers(x):
     return bool(_lib.lib().slak_ln_patch_supported(N, C, H, W))
 
 
+def channel_sums(dy3):
+    """sum over n and p of a contiguous bf16 [N, C, P] gradient -> fp32 [C] (the bias gradient of the stem / downsample convolutions),
+    slak_channel_sums_bf16: fixed summation order."""
+    N, C, P = dy3.shape
+    L = _lib.lib()
+    out = torch.empty(C, dtype=torch.float32, device=dy3.device)
+    nb = int(L.slak_channel_sums_workspace_bytes(C))
+    part = torch.empty(nb, dtype=torch.uint8, device=dy3.device)       # own buffer: the partial sums are read by a second launch
+    with _on(dy3.device):
+        _lib.check(L.slak_channel_sums_bf16(dy3.data_ptr(), out.data_ptr(), N, C, P, part.data_ptr(), nb, _stream(dy3.device)), "slak_channel_sums_bf16")
+    return out
+
+
 class _DownsampleLnConv(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, ln_w, ln_b, conv_w, conv_b, eps):
@@ -726,7 +739,7 @@ class _DownsampleLnConv(torch.autograd.Function):
         if dwp is None:
             dwp = torch.mm(dy3.permute(1, 0, 2).reshape(Co, N * P4), a.view(N * P4, 4 * C)).float()
         dconv_w = dwp.view(Co, 2, 2, C).permute(0, 3, 1, 2).contiguous()
-        dconv_b = dy3.sum((0, 2), dtype=torch.float32) if ctx.has_bias else None
+        dconv_b = channel_sums(dy3) if ctx.has_bias else None
         dx = torch.empty_like(x)
         dlw = torch.empty_like(ln_w); dlb = torch.empty_like(ln_w)
         L = _lib.lib()
@@ -771,7 +784,7 @@ class _StemConv(torch.autograd.Function):
             dy = dy.to(torch.bfloat16)
         dy3 = dy.view(N, Co, P16)
         dw = torch.bmm(dy3, a).sum(0, dtype=torch.float32).view(Co, Ci, 4, 4)          # per-image products (K = P16 each), fp32 sum over the batch
-        db = dy3.sum((0, 2), dtype=torch.float32) if has_bias else None
+        db = channel_sums(dy3) if has_bias else None
         return None, dw, db
 
 

@@ -512,6 +512,25 @@ def test_stem_conv_matches_conv2d(N, Ci, Co, H, W, gpu):
     _close(cb.grad, cbr.grad, 1e-3, "dconv_b")
 
 
+@pytest.mark.parametrize("N,C,P", [(128, 96, 3136), (64, 192, 784), (33, 384, 196), (5, 768, 49), (1, 7, 3), (40, 130, 50), (3, 16, 1028)])
+def test_channel_sums_bf16_is_the_conv_bias_gradient(N, C, P, gpu):
+    """slak_channel_sums_bf16 = grad_output.sum((0, 2, 3)) of the stem / downsample Conv2d (models/SLaK.py:188-199), fp32 accumulation: against
+    the fp64 sum of the same bf16 values within fp32 summation error, and the same bits on every call (fixed order, no atomics)."""
+    from slak_amd import block_ops
+    torch.manual_seed(N + C + P)
+    dy = (torch.randn(N, C, P, device=gpu) + 0.25).bfloat16()
+    got = block_ops.channel_sums(dy)
+    ref = dy.double().sum((0, 2))
+    mag = dy.double().abs().sum((0, 2))
+    assert got.dtype == torch.float32 and got.shape == (C,)
+    assert ((got.double() - ref).abs() <= 2e-6 * mag + 1e-30).all(), ((got.double() - ref).abs() / mag).max().item()
+    for _ in range(3):
+        assert torch.equal(block_ops.channel_sums(dy), got)
+    L = __import__("slak_amd._lib", fromlist=["lib"]).lib()
+    assert L.slak_channel_sums_bf16(dy.data_ptr(), got.data_ptr(), N, C, P, None, 0, 0) == 3          # SLAK_ERR_WORKSPACE: nothing launched
+    assert L.slak_channel_sums_bf16(None, got.data_ptr(), N, C, P, None, 0, 0) == 1                   # SLAK_ERR_INVALID_ARG
+
+
 def test_deferred_reductions_run_in_one_launch_with_the_same_bits(gpu):
     """slak_defer_reductions_begin / _end: the column sums that end slak_gelu_backward_bias, slak_ln_nchw_to_nhwc_backward, slak_scale_residual_backward
     and slak_linear_wgrad are recorded (each call with its OWN workspace) and performed by ONE launch at _end -- bit for bit what the stand-alone
