@@ -260,6 +260,16 @@ int slak_stem_patchify(const float* x, void* a_bf16, int N, int Cin, int H, int 
 /* Bias gradient of the stem / downsample convolutions: out[c] = sum over n and p of the bf16 NCHW gradient x[n][c][p], fp32, fixed summation
  * order.  Replaces `grad_output.sum((0, 2, 3))` of torch's Conv2d backward (reference: models/SLaK.py:188-199, the stem and downsample
  * nn.Conv2d layers).  workspace: slak_channel_sums_workspace_bytes(C) bytes. */
+/* Weight and bias gradient of the stem convolution (models/SLaK.py:189-193: nn.Conv2d(in_chans, dims[0], kernel_size=4, stride=4)) from the bf16
+ * NCHW output gradient dy (N, Co, P) and the forward's patch matrix a (N, P, K) of slak_stem_patchify (K = Cin*16): dw (Co, K) fp32 =
+ * sum_{n,p} dy[n][co][p] * a[n][p][k] -- reshaped (Co, Cin, 4, 4) it is Conv2d's weight gradient -- and db (Co) = sum_{n,p} dy (NULL: not wanted).
+ * One pass over dy and a, fp32 accumulation, fixed summation order.  Supported: Co % 32 == 0, Co <= 128, P % 64 == 0, K % 8 == 0, 32 <= K <= 56
+ * (Cin = 3: K = 48); otherwise SLAK_ERR_UNSUPPORTED and the caller keeps its GEMM. */
+int slak_stem_wgrad_supported(int N, int Co, int P, int K);
+size_t slak_stem_wgrad_workspace_bytes(int N, int Co, int P, int K);
+int slak_stem_wgrad(const void* dy_bf16, const void* a_bf16, float* dw, float* db, int N, int Co, int P, int K,
+                    void* workspace, size_t workspace_bytes, void* stream);
+
 size_t slak_channel_sums_workspace_bytes(int C);
 int slak_channel_sums_bf16(const void* x_bf16, float* out, int N, int C, int P, void* workspace, size_t workspace_bytes, void* stream);
 

@@ -783,6 +783,15 @@ class _StemConv(torch.autograd.Function):
         if dy.dtype != torch.bfloat16:
             dy = dy.to(torch.bfloat16)
         dy3 = dy.view(N, Co, P16)
+        L = _lib.lib()
+        if L.slak_stem_wgrad_supported(N, Co, P16, K):                                   # dw and db in one pass over dy and a, fp32 accumulation
+            dw = torch.empty((Co, K), dtype=torch.float32, device=dy.device)
+            db = torch.empty(Co, dtype=torch.float32, device=dy.device) if has_bias else None
+            ws, nb = _workspace(int(L.slak_stem_wgrad_workspace_bytes(N, Co, P16, K)), dy.device)
+            with _on(dy.device):
+                _lib.check(L.slak_stem_wgrad(dy3.data_ptr(), a.data_ptr(), dw.data_ptr(), db.data_ptr() if has_bias else None, N, Co, P16, K,
+                                             ws.data_ptr(), nb, _stream(dy.device)), "slak_stem_wgrad")
+            return None, dw.view(Co, Ci, 4, 4), db
         dw = torch.bmm(dy3, a).sum(0, dtype=torch.float32).view(Co, Ci, 4, 4)          # per-image products (K = P16 each), fp32 sum over the batch
         db = channel_sums(dy3) if has_bias else None
         return None, dw, db

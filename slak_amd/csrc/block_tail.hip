@@ -805,6 +805,7 @@ static int reduce_partials(const float* part, float* tmp, float* out0, float* ou
 }
 
 int tail_reduce_columns(const float* part, float* out, int ntiles, int width, hipStream_t st) { return reduce_partials(part, nullptr, out, out, width, ntiles, width, st); }
+int tail_reduce_split(const float* part, float* out0, float* out1, int split, int ntiles, int width, hipStream_t st) { return reduce_partials(part, nullptr, out0, out1, split, ntiles, width, st); }
 
 // tile width: the largest of {128,64,32,16} pixels whose tile (elem_bytes per element) fits lds_budget, not (much) wider than an image
 static TailDims make_dims(int N, int C, int P, int elem_bytes, size_t lds_budget = 50 * 1024) {

@@ -101,5 +101,7 @@ __device__ __forceinline__ void gelu_bwd8_apply(const uint4& gv, const float (&t
 const float* gelu_grad_table_device();
 // column sums of part[ntiles][width] -> out[width] in one launch, fixed order (block_tail.hip: block_tail_reduce1)
 int tail_reduce_columns(const float* part, float* out, int ntiles, int width, hipStream_t st);
+// the same with the columns [0, split) going to out0 and [split, width) to out1
+int tail_reduce_split(const float* part, float* out0, float* out1, int split, int ntiles, int width, hipStream_t st);
 
 }  // namespace slak

@@ -512,6 +512,45 @@ def test_stem_conv_matches_conv2d(N, Ci, Co, H, W, gpu):
     _close(cb.grad, cbr.grad, 1e-3, "dconv_b")
 
 
+@pytest.mark.parametrize("N,Co,P,K", [(128, 96, 3136, 48), (3, 96, 3136, 48), (5, 128, 576, 48), (2, 32, 64, 32), (7, 64, 192, 56), (1, 96, 64, 48)])
+def test_stem_wgrad_is_the_conv_weight_and_bias_gradient(N, Co, P, K, gpu):
+    """slak_stem_wgrad: dw[co][k] = sum_{n,p} dy[n][co][p] a[n][p][k], db[co] = sum_{n,p} dy (Conv2d(k=4, s=4) of models/SLaK.py:189-193 on the patch
+    matrix), against fp64 on the same bf16 operands within fp32 accumulation error; the same bits on every call; db optional."""
+    from slak_amd import _lib
+    L = _lib.lib()
+    torch.manual_seed(N + Co + P)
+    dy = (torch.randn(N, Co, P, device=gpu) * 0.5 + 0.1).bfloat16()
+    a = torch.randn(N, P, K, device=gpu).bfloat16()
+    assert L.slak_stem_wgrad_supported(N, Co, P, K) == 1
+    nb = int(L.slak_stem_wgrad_workspace_bytes(N, Co, P, K))
+    ws = torch.empty(nb, dtype=torch.uint8, device=gpu)
+    st = torch.cuda.current_stream(gpu).cuda_stream
+    dw = torch.full((Co, K), float("nan"), device=gpu); db = torch.full((Co,), float("nan"), device=gpu)
+    assert L.slak_stem_wgrad(dy.data_ptr(), a.data_ptr(), dw.data_ptr(), db.data_ptr(), N, Co, P, K, ws.data_ptr(), nb, st) == 0
+    rw = torch.einsum("ncp,npk->ck", dy.double(), a.double()); rb = dy.double().sum((0, 2))
+    mw = torch.einsum("ncp,npk->ck", dy.double().abs(), a.double().abs()); mb = dy.double().abs().sum((0, 2))
+    assert ((dw.double() - rw).abs() <= 4e-6 * mw + 1e-30).all(), ((dw.double() - rw).abs() / mw).max().item()
+    assert ((db.double() - rb).abs() <= 4e-6 * mb + 1e-30).all(), ((db.double() - rb).abs() / mb).max().item()
+    dw2 = torch.empty_like(dw); db2 = torch.empty_like(db)
+    for _ in range(3):
+        assert L.slak_stem_wgrad(dy.data_ptr(), a.data_ptr(), dw2.data_ptr(), db2.data_ptr(), N, Co, P, K, ws.data_ptr(), nb, st) == 0
+        assert torch.equal(dw2, dw) and torch.equal(db2, db)
+    dw3 = torch.empty_like(dw)
+    assert L.slak_stem_wgrad(dy.data_ptr(), a.data_ptr(), dw3.data_ptr(), None, N, Co, P, K, ws.data_ptr(), nb, st) == 0
+    assert torch.equal(dw3, dw)
+    # other operands right after (what the previous launch left in LDS and in the workspace must not matter)
+    dy_b = torch.randn(N, Co, P, device=gpu).bfloat16(); a_b = (torch.randn(N, P, K, device=gpu) * 3).bfloat16()
+    ws.fill_(0xFF)
+    assert L.slak_stem_wgrad(dy_b.data_ptr(), a_b.data_ptr(), dw3.data_ptr(), db2.data_ptr(), N, Co, P, K, ws.data_ptr(), nb, st) == 0
+    rw = torch.einsum("ncp,npk->ck", dy_b.double(), a_b.double()); mw = torch.einsum("ncp,npk->ck", dy_b.double().abs(), a_b.double().abs())
+    assert ((dw3.double() - rw).abs() <= 4e-6 * mw + 1e-30).all()
+    assert ((db2.double() - dy_b.double().sum((0, 2))).abs() <= 4e-6 * dy_b.double().abs().sum((0, 2)) + 1e-30).all()
+    assert L.slak_stem_wgrad(dy.data_ptr(), a.data_ptr(), dw3.data_ptr(), None, N, Co, P, K, None, 0, st) == 3       # SLAK_ERR_WORKSPACE
+    for bad in [(N, Co + 1, P, K), (N, 160, P, K), (N, Co, P + 8, K), (N, Co, P, 24), (N, Co, P, 64)]:
+        assert L.slak_stem_wgrad_supported(*bad) == 0
+        assert L.slak_stem_wgrad(dy.data_ptr(), a.data_ptr(), dw3.data_ptr(), None, *bad, ws.data_ptr(), nb, st) == 2  # SLAK_ERR_UNSUPPORTED
+
+
 @pytest.mark.parametrize("N,C,P", [(128, 96, 3136), (64, 192, 784), (33, 384, 196), (5, 768, 49), (1, 7, 3), (40, 130, 50), (3, 16, 1028)])
 def test_channel_sums_bf16_is_the_conv_bias_gradient(N, C, P, gpu):
     """slak_channel_sums_bf16 = grad_output.sum((0, 2, 3)) of the stem / downsample Conv2d (models/SLaK.py:188-199), fp32 accumulation: against
