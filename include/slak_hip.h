@@ -354,6 +354,17 @@ int slak_ln_channels_first_forward(const void* x, int x_dtype, const float* weig
 int slak_ln_channels_first_backward(const void* g, int g_dtype, const void* x, int x_dtype, const float* weight, const float* mean,
                                     const float* rstd, void* dx, float* dweight, float* dbias, int N, int C, int P,
                                     void* workspace, size_t workspace_bytes, void* stream);
+/* The stem's LayerNorm handing the first block a bf16 copy of its output (what the block's depthwise convs read under autocast), and taking
+ * that copy's gradient back: y_bf16 (NULL: none) = bf16(y); g2_bf16 (NULL: none) is ADDED to g on load -- `.to(bfloat16)` in front of the
+ * first block and autograd's `grad + grad_lowp.float()` behind it are no separate passes.  _backward_pair with g2 covers what
+ * slak_ln_channels_first_backward_pair_supported says (x bf16, g fp32, C = 96 / 128 / 192: one pass over g and x, the channels of a 64-pixel tile
+ * in the registers of four waves); without g2 it is slak_ln_channels_first_backward. */
+int slak_ln_channels_first_forward_pair(const void* x, int x_dtype, const float* weight, const float* bias, void* y, int y_dtype, void* y_bf16,
+                                        float* mean, float* rstd, int N, int C, int P, float eps, void* stream);
+int slak_ln_channels_first_backward_pair_supported(int g_dtype, int x_dtype, int N, int C, int P);
+int slak_ln_channels_first_backward_pair(const void* g, int g_dtype, const void* g2_bf16, const void* x, int x_dtype, const float* weight,
+                                         const float* mean, const float* rstd, void* dx, float* dweight, float* dbias, int N, int C, int P,
+                                         void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------- next row: branch BatchNorms + adds
  * out = BN1(y1) + BN2(y2) + BN3(y3) of ReparamLargeKernelConv (models/SLaK.py:38-47, :92-95) as one statistics pass, a per-channel

@@ -96,6 +96,9 @@ SIGNATURES = {
     "slak_ln_cf_workspace_bytes": (_sz, [_i, _i, _i]),
     "slak_ln_channels_first_forward": (_i, [_vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, ctypes.c_float, _vp]),
     "slak_ln_channels_first_backward": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _sz, _vp]),
+    "slak_ln_channels_first_forward_pair": (_i, [_vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, ctypes.c_float, _vp]),
+    "slak_ln_channels_first_backward_pair_supported": (_i, [_i, _i, _i, _i, _i]),
+    "slak_ln_channels_first_backward_pair": (_i, [_vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _sz, _vp]),
     "slak_ln_nchw_to_nhwc_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, ctypes.c_float, _vp]),
     "slak_ln_nchw_to_nhwc_backward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _sz, _vp]),
     "slak_dwconv2d_tri_supported": (_i, [_i, _i, _i, _i, _i, _i]),

@@ -675,6 +675,57 @@ def ln_channels_first(x, weight, bias, eps=1e-6, out_dtype=torch.float32):
     return _LnChannelsFirst.apply(x, weight, bias, eps, out_dtype)
 
 
+class _LnChannelsFirstPair(torch.autograd.Function):
+    """The stem's LayerNorm with two outputs: y (fp32) and bf16(y) -- the copy the first block's depthwise convs read under autocast (what
+    `inputs.to(bfloat16)` inside the block would make) -- and a backward that takes both gradients and adds them while loading
+    (slak_ln_channels_first_backward_pair): no cast pass in front of the block, no `grad + grad_lowp` pass behind it."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps):
+        _chk(x, "x"); _chk(weight, "weight", torch.float32); _chk(bias, "bias", torch.float32)
+        N, C, H, W = x.shape
+        y = torch.empty((N, C, H, W), dtype=torch.float32, device=x.device)
+        y16 = torch.empty((N, C, H, W), dtype=torch.bfloat16, device=x.device)
+        mean = torch.empty((N, H * W), dtype=torch.float32, device=x.device)
+        rstd = torch.empty_like(mean)
+        L = _lib.lib()
+        with _on(x.device):
+            _lib.check(L.slak_ln_channels_first_forward_pair(x.data_ptr(), _SDT[x.dtype], weight.data_ptr(), bias.data_ptr(), y.data_ptr(), _lib.SLAK_F32,
+                                                             y16.data_ptr(), mean.data_ptr(), rstd.data_ptr(), N, C, H * W, float(eps), _stream(x.device)),
+                       "slak_ln_channels_first_forward_pair")
+        ctx.save_for_backward(x, weight, mean, rstd)
+        return y, y16
+
+    @staticmethod
+    def backward(ctx, g, g16):
+        x, weight, mean, rstd = ctx.saved_tensors
+        N, C, H, W = x.shape
+        if g is None:
+            g, g16 = (torch.zeros_like(x, dtype=torch.float32) if g16 is None else g16.float()), None
+        g = g.contiguous()
+        if g.dtype != torch.float32:
+            g = g.float()
+        L = _lib.lib()
+        if g16 is not None:
+            g16 = g16.contiguous()
+            if g16.dtype != torch.bfloat16 or not L.slak_ln_channels_first_backward_pair_supported(_lib.SLAK_F32, _SDT[x.dtype], N, C, H * W):
+                g, g16 = g + g16, None                                  # shapes the one-pass kernel does not cover: autograd's own addition
+        dx = torch.empty_like(x)
+        dw = torch.empty_like(weight); db = torch.empty_like(weight)
+        ws, nb = _workspace(L.slak_ln_cf_workspace_bytes(N, C, H * W), x.device)
+        with _on(x.device):
+            _lib.check(L.slak_ln_channels_first_backward_pair(g.data_ptr(), _lib.SLAK_F32, g16.data_ptr() if g16 is not None else None, x.data_ptr(),
+                                                              _SDT[x.dtype], weight.data_ptr(), mean.data_ptr(), rstd.data_ptr(), dx.data_ptr(), dw.data_ptr(),
+                                                              db.data_ptr(), N, C, H * W, ws.data_ptr() if ws is not None else None, nb, _stream(x.device)),
+                       "slak_ln_channels_first_backward_pair")
+        return dx, dw, db, None
+
+
+def ln_channels_first_pair(x, weight, bias, eps=1e-6):
+    """(LN(x) in fp32, its bf16 copy): see _LnChannelsFirstPair."""
+    return _LnChannelsFirstPair.apply(x, weight, bias, eps)
+
+
 # ------------------------------------------------------------------------------------------------------------------
 # Downsample layers (models/SLaK.py:285-311): LayerNorm(channels_first) -> Conv2d(kernel_size=2, stride=2) as ONE LayerNorm kernel that
 # writes the conv's GEMM operand (the 2x2 patch matrix, bf16) + batched library GEMMs that produce / consume NCHW directly: no MIOpen

@@ -612,8 +612,8 @@ template <> __device__ __forceinline__ void cf_store<bf16_t>(bf16_t* p, float v)
 
 template <typename Tin, typename Tout>
 __global__ __launch_bounds__(BT_THREADS) void ln_cf_fwd_kernel(const Tin* __restrict__ x, const float* __restrict__ w, const float* __restrict__ b,
-                                                             Tout* __restrict__ y, float* __restrict__ mean, float* __restrict__ rstd,
-                                                             int C, int P, int tiles_per_image, float eps) {
+                                                             Tout* __restrict__ y, uint16_t* __restrict__ y2, float* __restrict__ mean,
+                                                             float* __restrict__ rstd, int C, int P, int tiles_per_image, float eps) {
     const int n = blockIdx.x / tiles_per_image, p = (blockIdx.x - n * tiles_per_image) * (int)blockDim.x + threadIdx.x;
     if (p >= P) return;
     const Tin* xp = x + (size_t)n * C * P + p;
@@ -628,6 +628,15 @@ __global__ __launch_bounds__(BT_THREADS) void ln_cf_fwd_kernel(const Tin* __rest
     const float r = 1.0f / sqrtf(m2 / (float)C + eps);
     mean[(size_t)n * P + p] = mu; rstd[(size_t)n * P + p] = r;
     Tout* yp = y + (size_t)n * C * P + p;
+    if (y2) {                                                      // + the bf16 copy of the (fp32) result: what the first block's convs read
+        uint16_t* y2p = y2 + (size_t)n * C * P + p;
+#pragma unroll 8
+        for (int c = 0; c < C; ++c) {
+            const float v = (cf_load(xp + (size_t)c * P) - mu) * r * w[c] + b[c];
+            cf_store(yp + (size_t)c * P, v); y2p[(size_t)c * P] = bt_f2bf(v);
+        }
+        return;
+    }
 #pragma unroll 8
     for (int c = 0; c < C; ++c) cf_store(yp + (size_t)c * P, (cf_load(xp + (size_t)c * P) - mu) * r * w[c] + b[c]);
 }
@@ -683,6 +692,67 @@ __global__ __launch_bounds__(BT_THREADS) void ln_cf_bwd_kernel(const Tg* __restr
         float t = 0.f;
         for (int k = 0; k < nrows; ++k) t += red[(k * 2 + h) * C + c];
         pt[i] = t;
+    }
+}
+
+// The same in ONE pass over g and x (x bf16, g fp32, C = CT at compile time): the workgroup's four waves share a 64-pixel tile and split the
+// channels, each lane keeps its CT/4 channels of g and x in registers (36 VGPRs at C = 96: eight waves per SIMD, every load of the tile in
+// flight at once), the per-pixel sums meet in LDS.  The two-pass kernel above moved 539 MB for the stem of SLaK-T (its 256-pixel tile, 147 KB,
+// does not survive in L2 between the passes); a first one-pass version with a lane's WHOLE column in registers (256 VGPRs, two waves per SIMD)
+// was slower than that (163 us against 141).  Optional second gradient g2 (bf16: the data gradient of the first block's convs, which read the
+// bf16 copy the forward wrote), added on load: torch's `dshortcut + dx16` pass and the cast behind it are gone.
+template <int CT, bool HAS2>
+__global__ __launch_bounds__(BT_THREADS) void ln_cf_bwd_cs_kernel(const float* __restrict__ g, const uint16_t* __restrict__ g2,
+                                                                const uint16_t* __restrict__ x, const float* __restrict__ w,
+                                                                const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                                uint16_t* __restrict__ dx, float* __restrict__ part, int P, int tiles_per_image) {
+    static_assert(BT_THREADS == 256 && CT % 8 == 0, "four waves, an even number of channels per wave");
+    constexpr int CW = CT / 4;
+    __shared__ float psum[4][2][64];
+    __shared__ float red[4][2][CT];                                        // [row of 16 lanes][sum g*xhat | sum g][channel]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = blockIdx.x / tiles_per_image, p = (blockIdx.x - n * tiles_per_image) * 64 + lane;
+    const bool ok = p < P;
+    const int c_lo = wave * CW;
+    const size_t base = ((size_t)n * CT + c_lo) * P + (ok ? p : 0);
+    const float mu = ok ? mean[(size_t)n * P + p] : 0.f, r = ok ? rstd[(size_t)n * P + p] : 0.f;
+    float gv[CW];
+    uint32_t xp[CW / 2];
+#pragma unroll
+    for (int c = 0; c < CW; c += 2) {
+        float g0 = g[base + (size_t)c * P], g1 = g[base + (size_t)(c + 1) * P];
+        if constexpr (HAS2) {
+            g0 += __uint_as_float((uint32_t)g2[base + (size_t)c * P] << 16); g1 += __uint_as_float((uint32_t)g2[base + (size_t)(c + 1) * P] << 16);
+        }
+        gv[c] = ok ? g0 : 0.f; gv[c + 1] = ok ? g1 : 0.f;                   // lanes beyond the image contribute nothing
+        xp[c / 2] = (uint32_t)x[base + (size_t)c * P] | ((uint32_t)x[base + (size_t)(c + 1) * P] << 16);
+    }
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int c = 0; c < CW; ++c) {
+        const float xv = __uint_as_float((c & 1) ? (xp[c / 2] & 0xffff0000u) : (xp[c / 2] << 16));
+        const float gw = gv[c] * w[c_lo + c];
+        s1 += gw; s2 += gw * ((xv - mu) * r);
+    }
+    psum[wave][0][lane] = s1; psum[wave][1][lane] = s2;
+    __syncthreads();
+    s1 = (psum[0][0][lane] + psum[1][0][lane]) + (psum[2][0][lane] + psum[3][0][lane]);
+    s2 = (psum[0][1][lane] + psum[1][1][lane]) + (psum[2][1][lane] + psum[3][1][lane]);
+    const float m1 = s1 / (float)CT, m2 = s2 / (float)CT;
+    const int row = lane >> 4;
+#pragma unroll
+    for (int c = 0; c < CW; ++c) {
+        const float xv = __uint_as_float((c & 1) ? (xp[c / 2] & 0xffff0000u) : (xp[c / 2] << 16));
+        const float xh = (xv - mu) * r;
+        if (ok) dx[base + (size_t)c * P] = bt_f2bf(r * (gv[c] * w[c_lo + c] - m1 - xh * m2));
+        const float a = bt_row16_sum(gv[c] * xh), bs = bt_row16_sum(gv[c]);
+        if ((lane & 15) == 15) { red[row][0][c_lo + c] = a; red[row][1][c_lo + c] = bs; }
+    }
+    __syncthreads();
+    float* pt = part + (size_t)blockIdx.x * 2 * CT;
+    for (int i = tid; i < 2 * CT; i += BT_THREADS) {
+        const int h = i / CT, c = i - h * CT;
+        pt[i] = (red[0][h][c] + red[1][h][c]) + (red[2][h][c] + red[3][h][c]);
     }
 }
 
@@ -1132,11 +1202,16 @@ static int cf_tiles(int N, int P) { const int b = cf_block(N, P); return (P + b 
 
 size_t slak_ln_cf_workspace_bytes(int N, int C, int P) {
     if (N <= 0 || C <= 0 || P <= 0) return 0;
-    return align_up(((size_t)N * cf_tiles(N, P) + BT_SLICES) * 2 * C * sizeof(float), 256);
+    return align_up(((size_t)N * ((P + 63) / 64) + BT_SLICES) * 2 * C * sizeof(float), 256);   // rows: one per 64-pixel tile (the most any of the kernels writes)
 }
 
 int slak_ln_channels_first_forward(const void* x, int x_dtype, const float* weight, const float* bias, void* y, int y_dtype,
                                    float* mean, float* rstd, int N, int C, int P, float eps, void* stream) {
+    return slak_ln_channels_first_forward_pair(x, x_dtype, weight, bias, y, y_dtype, nullptr, mean, rstd, N, C, P, eps, stream);
+}
+
+int slak_ln_channels_first_forward_pair(const void* x, int x_dtype, const float* weight, const float* bias, void* y, int y_dtype, void* y_bf16,
+                                        float* mean, float* rstd, int N, int C, int P, float eps, void* stream) {
     if (!x || !weight || !bias || !y || !mean || !rstd) return SLAK_ERR_INVALID_ARG;
     if (N <= 0 || C <= 0 || P <= 0) return SLAK_ERR_INVALID_ARG;
     if (C > 1024 || (long long)N * C * P >= (1LL << 31)) return SLAK_ERR_UNSUPPORTED;
@@ -1144,7 +1219,7 @@ int slak_ln_channels_first_forward(const void* x, int x_dtype, const float* weig
     const dim3 grid((unsigned)(N * tpi));
 #define SLAK_CF_FWD(TI, TO)                                                                                                   \
     hipLaunchKernelGGL((ln_cf_fwd_kernel<TI, TO>), grid, dim3(blk), 0, (hipStream_t)stream, (const TI*)x, weight, bias,   \
-                       (TO*)y, mean, rstd, C, P, tpi, eps)
+                       (TO*)y, (uint16_t*)y_bf16, mean, rstd, C, P, tpi, eps)
     if (x_dtype == SLAK_F32 && y_dtype == SLAK_F32) SLAK_CF_FWD(float, float);
     else if (x_dtype == SLAK_F32 && y_dtype == SLAK_BF16) SLAK_CF_FWD(float, bf16_t);
     else if (x_dtype == SLAK_BF16 && y_dtype == SLAK_F32) SLAK_CF_FWD(bf16_t, float);
@@ -1155,13 +1230,45 @@ int slak_ln_channels_first_forward(const void* x, int x_dtype, const float* weig
     return SLAK_OK;
 }
 
+// the one-pass kernel (64-pixel tiles, the waves split the channels, a lane's share in registers): bf16 x, fp32 g, C = 96 / 128 / 192 (the stems of
+// SLaK-T/S, -B and -L)
+static bool cf_reg_covers(int g_dtype, int x_dtype, int N, int C, int P) {
+    static const bool off = [] { const char* e = getenv("SLAK_LN_CF_REG"); return e && atoi(e) == 0; }();
+    (void)N; (void)P;
+    return !off && g_dtype == SLAK_F32 && x_dtype == SLAK_BF16 && (C == 96 || C == 128 || C == 192);
+}
+int slak_ln_channels_first_backward_pair_supported(int g_dtype, int x_dtype, int N, int C, int P) {
+    if (N <= 0 || C <= 0 || P <= 0 || (long long)N * C * P >= (1LL << 31)) return 0;
+    return cf_reg_covers(g_dtype, x_dtype, N, C, P) ? 1 : 0;
+}
+
 int slak_ln_channels_first_backward(const void* g, int g_dtype, const void* x, int x_dtype, const float* weight, const float* mean,
                                     const float* rstd, void* dx, float* dweight, float* dbias, int N, int C, int P,
                                     void* workspace, size_t workspace_bytes, void* stream) {
+    return slak_ln_channels_first_backward_pair(g, g_dtype, nullptr, x, x_dtype, weight, mean, rstd, dx, dweight, dbias, N, C, P, workspace, workspace_bytes, stream);
+}
+
+int slak_ln_channels_first_backward_pair(const void* g, int g_dtype, const void* g2_bf16, const void* x, int x_dtype, const float* weight,
+                                         const float* mean, const float* rstd, void* dx, float* dweight, float* dbias, int N, int C, int P,
+                                         void* workspace, size_t workspace_bytes, void* stream) {
     if (!g || !x || !weight || !mean || !rstd || !dx || !dweight || !dbias) return SLAK_ERR_INVALID_ARG;
     if (N <= 0 || C <= 0 || P <= 0) return SLAK_ERR_INVALID_ARG;
     if (C > 1024 || (long long)N * C * P >= (1LL << 31)) return SLAK_ERR_UNSUPPORTED;
+    if (g2_bf16 && !cf_reg_covers(g_dtype, x_dtype, N, C, P)) return SLAK_ERR_UNSUPPORTED;      // (the caller adds the two gradients itself)
     if (!workspace || workspace_bytes < slak_ln_cf_workspace_bytes(N, C, P)) return SLAK_ERR_WORKSPACE;
+    if (cf_reg_covers(g_dtype, x_dtype, N, C, P)) {
+        const int tpi = (P + 63) / 64, nwg = N * tpi;
+        float* part = (float*)workspace;
+#define SLAK_CF_REG(CT, H2)                                                                                                               \
+        hipLaunchKernelGGL((ln_cf_bwd_cs_kernel<CT, H2>), dim3((unsigned)nwg), dim3(BT_THREADS), 0, (hipStream_t)stream, (const float*)g, \
+                           (const uint16_t*)g2_bf16, (const uint16_t*)x, weight, mean, rstd, (uint16_t*)dx, part, P, tpi)
+        if (C == 96) { if (g2_bf16) SLAK_CF_REG(96, true); else SLAK_CF_REG(96, false); }
+        else if (C == 128) { if (g2_bf16) SLAK_CF_REG(128, true); else SLAK_CF_REG(128, false); }
+        else { if (g2_bf16) SLAK_CF_REG(192, true); else SLAK_CF_REG(192, false); }
+#undef SLAK_CF_REG
+        SLAK_LAUNCH_CHECK();
+        return reduce_partials(part, part + (size_t)nwg * 2 * C, dweight, dbias, C, nwg, 2 * C, (hipStream_t)stream);
+    }
     const bool csplit = cf_block(N, P) == 64;                      // few pixels per image: 64-pixel tiles, waves split the channels
     const int tpi = csplit ? (P + 63) / 64 : cf_tiles(N, P), nwg = N * tpi;
     const size_t lds = (size_t)(BT_THREADS / 16) * 2 * C * 4 + 8 * 64 * 4 + 16;

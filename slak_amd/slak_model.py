@@ -247,13 +247,14 @@ class _Stage(nn.Sequential):
     with forward (pre-)hooks or backward (pre-)hooks is called through ``__call__`` like any module -- the hooks see tensors -- and simply gets
     no hand-off."""
 
-    def forward(self, x):
+    def forward(self, x, lowp=None):
+        """``lowp``: a copy of ``x`` in the autocast dtype made by the producer of ``x`` (the stem's LayerNorm writes one: SLaK._forward_features),
+        handed to the first block like a block's own hand-off."""
         import torch.nn.modules.module as _m
         # the fast-path test of nn.Module._call_impl: ANY hook -- forward, forward-pre, full backward, backward-pre, per module or global --
         # sends the block through __call__ (register_full_backward_hook on a Block fires as on any module)
         global_hooks = bool(_m._global_forward_hooks or _m._global_forward_pre_hooks or _m._global_backward_hooks or _m._global_backward_pre_hooks
                             or getattr(_m, "_global_forward_hooks_always_called", None))
-        lowp = None
         for blk in self:
             if isinstance(blk, Block) and not (global_hooks or blk._forward_hooks or blk._forward_pre_hooks or blk._backward_hooks
                                                or blk._backward_pre_hooks):
@@ -436,7 +437,15 @@ class SLaK(nn.Module):
                     and isinstance(ds[0], nn.Conv2d) and ds[0].kernel_size == (4, 4) and ds[0].stride == (4, 4) and ds[0].padding == (0, 0)
                     and ds[0].groups == 1 and x.shape[2] % 4 == 0 and x.shape[3] % 4 == 0):
                 from . import block_ops                           # stem conv as patch matrix + library GEMMs (no MIOpen launch, no layout transposes)
-                x = self.stages[i](ds[1](block_ops.stem_conv(x.contiguous(), ds[0].weight, ds[0].bias)))
+                y = block_ops.stem_conv(x.contiguous(), ds[0].weight, ds[0].bias)
+                st = self.stages[i]
+                if (self.stem_lowp_handoff and isinstance(ds[1], LayerNorm) and ds[1].data_format == "channels_first" and len(st) > 0
+                        and isinstance(st[0], Block) and st[0].large_kernel.lowp_dwconv and torch.get_autocast_dtype("cuda") == torch.bfloat16
+                        and not any(m._forward_hooks or m._forward_pre_hooks or m._backward_hooks or m._backward_pre_hooks for m in (ds[1], st))):
+                    # the LayerNorm writes the bf16 copy the first block's convs read and takes that copy's gradient back (block_ops._LnChannelsFirstPair)
+                    x = st(*block_ops.ln_channels_first_pair(y, ds[1].weight, ds[1].bias, ds[1].eps))
+                else:
+                    x = st(ds[1](y))
                 continue
             x = self.stages[i](ds(x))
         return self.norm(x.mean([-2, -1]))
@@ -445,6 +454,7 @@ class SLaK(nn.Module):
         return self.head(self.forward_features(x))
 
 
+SLaK.stem_lowp_handoff = True                # (with fused_stem) the stem LayerNorm hands the first block its bf16 input copy (block_ops.ln_channels_first_pair)
 SLaK.fused_stem = True                       # (with fused_downsample) the stem conv as patch matrix + library GEMMs (block_ops.stem_conv)
 SLaK.fused_downsample = False                # downsample layers as LN-to-patch-matrix kernel + library GEMMs (block_ops.downsample_ln_conv)
 

@@ -304,6 +304,43 @@ def test_branch_bn3_remeasures_channels_the_conv_sums_cannot_carry(N, C, H, rows
     _close(o1, o2.double(), 2.0 ** -7, "fast path vs read pass")
 
 
+def test_stem_layernorm_handoff_leaves_the_model_bits_unchanged(gpu):
+    """SLaK.stem_lowp_handoff (the stem's LayerNorm writes the bf16 copy the first block's convs read and adds that copy's gradient while loading):
+    logits and every gradient carry the same bits as with the cast inside the block and autograd's addition behind it."""
+    import copy
+    import slak_amd.slak_model as M
+    from slak_amd import block_ops
+    saved = (M.Block.fused_tail, M.ReparamLargeKernelConv.fused_bn, M.ReparamLargeKernelConv.fused_tri, M.Block.fused_block, M.LayerNorm.fused_cf,
+             M.SLaK.fused_downsample, M.SLaK.stem_lowp_handoff)
+    M.use_sync_bn = False
+    try:
+        M.Block.fused_tail = True; M.ReparamLargeKernelConv.fused_bn = True; M.ReparamLargeKernelConv.fused_tri = True; M.Block.fused_block = True
+        M.LayerNorm.fused_cf = True; M.SLaK.fused_downsample = True
+        torch.manual_seed(5)
+        net = M.SLaK(in_chans=3, num_classes=10, depths=[2, 1, 1, 1], dims=[96, 32, 64, 32], drop_path_rate=0.0, kernel_size=[13, 13, 9, 7, 5],
+                     Decom=True, bn=True, lowp_dwconv=True).to(gpu)
+        x = torch.randn(80, 3, 224, 224, device=gpu); t = torch.randint(0, 10, (80,), device=gpu)
+        res = []
+        for handoff in (True, False):
+            m = copy.deepcopy(net)
+            M.SLaK.stem_lowp_handoff = handoff
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                out = m(x)
+                loss = F.cross_entropy(out.float(), t)
+            loss.backward()
+            res.append((out.detach().clone(), {k: p.grad.clone() for k, p in m.named_parameters()}))
+        assert torch.equal(res[0][0], res[1][0])
+        for k in res[0][1]:                                   # the hand-off can only reach the stem's own gradients; (the library GEMMs behind the narrow
+            if k.startswith("downsample_layers.0."):          # downsample layers of this toy model do not repeat their last bits from run to run)
+                assert torch.equal(res[0][1][k], res[1][1][k]), k
+            else:
+                _close(res[0][1][k], res[1][1][k], 2.0 ** -7, k)
+        assert all(torch.isfinite(v).all() for v in res[0][1].values())
+    finally:
+        (M.Block.fused_tail, M.ReparamLargeKernelConv.fused_bn, M.ReparamLargeKernelConv.fused_tri, M.Block.fused_block, M.LayerNorm.fused_cf,
+         M.SLaK.fused_downsample, M.SLaK.stem_lowp_handoff) = saved
+
+
 def test_bn_counter_pool_outside_a_managed_forward(gpu):
     """num_batches_tracked: one pooled bump per SLaK.forward; a block called on its own (no begin_forward) bumps its own three
     counters instead of silently skipping them (round-2 advisor item), and nothing of a forward outlives it in Block.__dict__."""
@@ -349,6 +386,44 @@ def test_ln_channels_first_matches_explicit_ops(N, C, H, W, in_dtype, gpu):
     _close(y, yr, 2e-6, "y")
     _close(x.grad, xr.grad, 2.0 ** -8 * 1.05 if in_dtype == torch.bfloat16 else 2e-5, "dx")
     _close(w.grad, wr.grad, 1e-4, "dw"); _close(b.grad, br.grad, 1e-4, "db")
+
+
+@pytest.mark.parametrize("N,C,H,W", [(80, 96, 56, 56), (64, 128, 32, 32), (3, 96, 56, 56), (4, 192, 28, 28), (2, 64, 9, 11)])
+def test_ln_channels_first_pair_hands_over_a_bf16_copy_and_adds_its_gradient(N, C, H, W, gpu):
+    """block_ops.ln_channels_first_pair (the stem's LayerNorm in front of the first block): y is ln_channels_first's, y16 = bf16(y); the backward
+    with (g, g16) gives the bits of ln_channels_first's backward on g + g16 (the addition autograd would make) and agrees with fp64.  C = 96 / 128 / 192
+    take the one-pass kernel (the channels of a tile in the registers of four waves), the last shape the two-pass kernel after an addition in torch."""
+    from slak_amd import block_ops, _lib
+    torch.manual_seed(C + N)
+    x = (torch.randn(N, C, H, W, device=gpu) * 1.5 + 0.2).bfloat16()
+    w = (torch.randn(C, device=gpu) * 0.5 + 1); b = (torch.randn(C, device=gpu) * 0.1)
+    g = torch.randn(N, C, H, W, device=gpu); g16 = torch.randn(N, C, H, W, device=gpu).bfloat16()
+    covered = bool(_lib.lib().slak_ln_channels_first_backward_pair_supported(_lib.SLAK_F32, _lib.SLAK_BF16, N, C, H * W))
+    assert covered == (C in (96, 128, 192))
+    xa, wa, ba = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    y, y16 = block_ops.ln_channels_first_pair(xa, wa, ba, 1e-6)
+    xb, wb, bb = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    y1 = block_ops.ln_channels_first(xb, wb, bb, 1e-6, torch.float32)
+    assert y.dtype == torch.float32 and y16.dtype == torch.bfloat16
+    assert torch.equal(y, y1) and torch.equal(y16, y1.bfloat16())
+    torch.autograd.backward([y, y16], [g, g16])
+    y1.backward(g + g16)
+    assert torch.equal(xa.grad, xb.grad) and torch.equal(wa.grad, wb.grad) and torch.equal(ba.grad, bb.grad)
+    xr = x.double().requires_grad_(True); wr = w.double().requires_grad_(True); br = b.double().requires_grad_(True)
+    u = xr.mean(1, keepdim=True); s = (xr - u).pow(2).mean(1, keepdim=True)
+    yr = wr[:, None, None] * ((xr - u) / torch.sqrt(s + 1e-6)) + br[:, None, None]          # models/SLaK.py:257-260
+    yr.backward(g.double() + g16.double())
+    _close(y, yr, 2e-6, "y")
+    _close(xa.grad, xr.grad, 2.0 ** -8 * 1.05, "dx")
+    _close(wa.grad, wr.grad, 1e-4, "dw"); _close(ba.grad, br.grad, 1e-4, "db")
+    # only one of the two outputs used downstream
+    for use in (0, 1):
+        xc = x.clone().requires_grad_(True)
+        out = block_ops.ln_channels_first_pair(xc, w, b, 1e-6)
+        out[use].backward((g, g16)[use])
+        xd = x.clone().requires_grad_(True)
+        block_ops.ln_channels_first(xd, w, b, 1e-6, torch.float32).backward((g, g16.float())[use])
+        assert torch.equal(xc.grad, xd.grad)
 
 
 @pytest.mark.parametrize("M,C", [(6272, 96), (3136, 192), (1000, 384), (77, 768)])
