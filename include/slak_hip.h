@@ -260,6 +260,15 @@ int slak_stem_patchify(const float* x, void* a_bf16, int N, int Cin, int H, int 
 /* Bias gradient of the stem / downsample convolutions: out[c] = sum over n and p of the bf16 NCHW gradient x[n][c][p], fp32, fixed summation
  * order.  Replaces `grad_output.sum((0, 2, 3))` of torch's Conv2d backward (reference: models/SLaK.py:188-199, the stem and downsample
  * nn.Conv2d layers).  workspace: slak_channel_sums_workspace_bytes(C) bytes. */
+/* Forward of the stem convolution (models/SLaK.py:189-193: nn.Conv2d(3, dims[0], kernel_size=4, stride=4)) under bf16 autocast, from the fp32
+ * NCHW image x (N, 3, H, W): y (N, Co, H/4, W/4) bf16 = bf16(bf16(bias) + sum_k bf16(weight[co][k]) * bf16(patch[k])) with fp32 accumulation --
+ * the arithmetic of the autocast conv -- and the bf16 patch matrix a (N, P, 48) of slak_stem_patchify written in the same pass (the operand of
+ * slak_stem_wgrad).  weight: fp32 (Co, 3, 4, 4) contiguous; bias: fp32 (Co) or NULL.  Supported: Cin = 3, Co % 32 == 0, Co <= 128, H % 4 == 0,
+ * W % 4 == 0, (H/4)*(W/4) % 64 == 0; otherwise SLAK_ERR_UNSUPPORTED and the caller keeps slak_stem_patchify + its GEMM. */
+int slak_stem_conv_forward_supported(int N, int Cin, int H, int W, int Co);
+int slak_stem_conv_forward(const float* x, const float* weight, const float* bias, void* a_bf16, void* y_bf16, int N, int Cin, int H, int W, int Co,
+                           void* stream);
+
 /* Weight and bias gradient of the stem convolution (models/SLaK.py:189-193: nn.Conv2d(in_chans, dims[0], kernel_size=4, stride=4)) from the bf16
  * NCHW output gradient dy (N, Co, P) and the forward's patch matrix a (N, P, K) of slak_stem_patchify (K = Cin*16): dw (Co, K) fp32 =
  * sum_{n,p} dy[n][co][p] * a[n][p][k] -- reshaped (Co, Cin, 4, 4) it is Conv2d's weight gradient -- and db (Co) = sum_{n,p} dy (NULL: not wanted).

@@ -114,6 +114,8 @@ SIGNATURES = {
     "slak_dwconv2d_pair_backward_filter": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     "slak_dwconv2d_tri_backward_filter": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     "slak_stem_patchify": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    "slak_stem_conv_forward_supported": (_i, [_i, _i, _i, _i, _i]),
+    "slak_stem_conv_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "slak_stem_wgrad_supported": (_i, [_i, _i, _i, _i]),
     "slak_stem_wgrad_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "slak_stem_wgrad": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _sz, _vp]),

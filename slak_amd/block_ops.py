@@ -814,6 +814,15 @@ class _StemConv(torch.autograd.Function):
         P16 = (H // 4) * (W // 4)
         a = torch.empty((N, P16, Ci * 16), dtype=torch.bfloat16, device=x.device)
         L = _lib.lib()
+        if (L.slak_stem_conv_forward_supported(N, Ci, H, W, Co) and conv_w.dtype == torch.float32 and conv_w.is_contiguous()
+                and (conv_b is None or (conv_b.dtype == torch.float32 and conv_b.is_contiguous()))):
+            y = torch.empty((N, Co, H // 4, W // 4), dtype=torch.bfloat16, device=x.device)    # patches, product and bias in one pass from the image
+            with _on(x.device):
+                _lib.check(L.slak_stem_conv_forward(x.data_ptr(), conv_w.data_ptr(), conv_b.data_ptr() if conv_b is not None else None, a.data_ptr(),
+                                                    y.data_ptr(), N, Ci, H, W, Co, _stream(x.device)), "slak_stem_conv_forward")
+            ctx.save_for_backward(a)
+            ctx.shape = (Co, Ci, conv_b is not None)
+            return y
         with _on(x.device):
             _lib.check(L.slak_stem_patchify(x.data_ptr(), a.data_ptr(), N, Ci, H, W, _stream(x.device)), "slak_stem_patchify")
         wp = conv_w.detach().reshape(Co, Ci * 16).to(torch.bfloat16)

@@ -567,7 +567,7 @@ def test_downsample_ln_conv_matches_reference_modules(N, C, Co, H, W, gpu):
     _close(lb.grad, lbr.grad, 2.0 ** -7, "dln_b")
 
 
-@pytest.mark.parametrize("N,Ci,Co,H,W", [(3, 3, 96, 224, 224), (2, 3, 128, 64, 96), (2, 4, 32, 8, 12)])
+@pytest.mark.parametrize("N,Ci,Co,H,W", [(3, 3, 96, 224, 224), (2, 3, 128, 64, 96), (2, 4, 32, 8, 12), (5, 3, 64, 32, 32), (2, 3, 32, 384, 384), (3, 3, 96, 40, 40)])
 def test_stem_conv_matches_conv2d(N, Ci, Co, H, W, gpu):
     """block_ops.stem_conv = Conv2d(k=4, s=4) of models/SLaK.py:276-279 under bf16 autocast (input and weight rounded to bf16, fp32 accumulate)."""
     from slak_amd import block_ops
@@ -585,6 +585,25 @@ def test_stem_conv_matches_conv2d(N, Ci, Co, H, W, gpu):
     _close(y, yr, 2.0 ** -8 * 1.05, "y")
     _close(cw.grad, cwr.grad, 2.0 ** -7, "dconv_w")
     _close(cb.grad, cbr.grad, 1e-3, "dconv_b")
+    # the one-pass forward (slak_stem_conv_forward) writes the patch matrix slak_stem_patchify writes, bit for bit, and covers what it says
+    from slak_amd import _lib
+    L = _lib.lib()
+    P16, K = (H // 4) * (W // 4), Ci * 16
+    covered = bool(L.slak_stem_conv_forward_supported(N, Ci, H, W, Co))
+    assert covered == (Ci == 3 and Co % 32 == 0 and Co <= 128 and P16 % 64 == 0)
+    st = torch.cuda.current_stream(gpu).cuda_stream
+    a1 = torch.empty(N, P16, K, device=gpu, dtype=torch.bfloat16)
+    assert L.slak_stem_patchify(x.data_ptr(), a1.data_ptr(), N, Ci, H, W, st) == 0
+    if covered:
+        a2 = torch.full_like(a1, float("nan")); y2 = torch.full_like(y, float("nan"))
+        cwd = cw.detach()
+        assert L.slak_stem_conv_forward(x.data_ptr(), cwd.data_ptr(), cb.detach().data_ptr(), a2.data_ptr(), y2.data_ptr(), N, Ci, H, W, Co, st) == 0
+        assert torch.equal(a1, a2) and torch.equal(y2, y)
+        y3 = torch.empty_like(y)
+        assert L.slak_stem_conv_forward(x.data_ptr(), cwd.data_ptr(), None, a2.data_ptr(), y3.data_ptr(), N, Ci, H, W, Co, st) == 0
+        _close(y3, F.conv2d(x.bfloat16().double(), cwd.bfloat16().double(), None, stride=4), 2.0 ** -8 * 1.05, "y without bias")
+    else:
+        assert L.slak_stem_conv_forward(x.data_ptr(), cw.detach().data_ptr(), None, a1.data_ptr(), y.data_ptr(), N, Ci, H, W, Co, st) == 2   # SLAK_ERR_UNSUPPORTED
 
 
 @pytest.mark.parametrize("N,Co,P,K", [(128, 96, 3136, 48), (3, 96, 3136, 48), (5, 128, 576, 48), (2, 32, 64, 32), (7, 64, 192, 56), (1, 96, 64, 48)])

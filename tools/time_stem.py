@@ -32,3 +32,16 @@ for (C, P) in [(96, 3136), (192, 784), (384, 196), (768, 49)]:
     t_new = timed(lambda: block_ops.channel_sums(dy))
     t_old = timed(lambda: dy.sum((0, 2), dtype=torch.float32))
     print("channel sums C=%d P=%d: own %.1f us (%.0f GB/s)   torch %.1f us" % (C, P, t_new, dy.numel() * 2 / t_new / 1e3, t_old), flush=True)
+for Co in (96, 128):
+    x = torch.randn(N, 3, 224, 224, device=dev); w = torch.randn(Co, 3, 4, 4, device=dev) * 0.1; b = torch.randn(Co, device=dev) * 0.1
+    a = torch.empty(N, 3136, 48, device=dev, dtype=torch.bfloat16); y = torch.empty(N, Co, 56, 56, device=dev, dtype=torch.bfloat16)
+    st = torch.cuda.current_stream(dev).cuda_stream
+    t_new = timed(lambda: L.slak_stem_conv_forward(x.data_ptr(), w.data_ptr(), b.data_ptr(), a.data_ptr(), y.data_ptr(), N, 3, 224, 224, Co, st))
+
+    def old():
+        L.slak_stem_patchify(x.data_ptr(), a.data_ptr(), N, 3, 224, 224, st)
+        wp = w.reshape(Co, 48).to(torch.bfloat16)
+        return torch.baddbmm(b.to(torch.bfloat16).view(1, Co, 1).expand(N, Co, 3136), wp.unsqueeze(0).expand(N, Co, 48), a.transpose(1, 2))
+    t_old = timed(old)
+    byts = x.numel() * 4 + a.numel() * 2 + y.numel() * 2
+    print("stem conv forward Co=%d: own %.1f us (%.0f GB/s)   patchify + library GEMM %.1f us" % (Co, t_new, byts / t_new / 1e3, t_old), flush=True)
