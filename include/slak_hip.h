@@ -257,6 +257,10 @@ int slak_ln_patch_backward(const void* g_bf16, const float* x, const float* weig
  * H and W multiples of 4. */
 int slak_stem_patchify(const float* x, void* a_bf16, int N, int Cin, int H, int W, void* stream);
 
+/* y (N, C, P) bf16 = bf16(bias[c]) broadcast: the accumulator the batched GEMM of a downsample convolution (models/SLaK.py:195-199) adds its
+ * products to -- the bias of nn.Conv2d inside the GEMM (fp32 accumulate, one rounding) without torch's strided broadcast copy. */
+int slak_fill_channel_bias_bf16(const float* bias, void* y_bf16, int N, int C, int P, void* stream);
+
 /* Bias gradient of the stem / downsample convolutions: out[c] = sum over n and p of the bf16 NCHW gradient x[n][c][p], fp32, fixed summation
  * order.  Replaces `grad_output.sum((0, 2, 3))` of torch's Conv2d backward (reference: models/SLaK.py:188-199, the stem and downsample
  * nn.Conv2d layers).  workspace: slak_channel_sums_workspace_bytes(C) bytes. */

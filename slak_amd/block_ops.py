@@ -765,8 +765,12 @@ class _DownsampleLnConv(torch.autograd.Function):
             _lib.check(L.slak_ln_patch_forward(x.data_ptr(), ln_w.data_ptr(), ln_b.data_ptr(), a.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
                                                N, C, H, W, float(eps), _stream(x.device)), "slak_ln_patch_forward")
         wp = conv_w.detach().permute(0, 2, 3, 1).reshape(Co, 4 * C).to(torch.bfloat16)       # Wp[co][(kh*2+kw)*C + c]
-        if conv_b is not None:                                                                  # bias inside the GEMM (fp32 accumulate, one rounding)
-            y = torch.baddbmm(conv_b.detach().to(torch.bfloat16).view(1, Co, 1).expand(N, Co, P4), wp.unsqueeze(0).expand(N, Co, 4 * C), a.transpose(1, 2))
+        if conv_b is not None:                                                                  # bias inside the GEMM (fp32 accumulate, one rounding):
+            y = torch.empty((N, Co, P4), dtype=torch.bfloat16, device=x.device)                 # the accumulator starts at bf16(bias) (one 16-byte-store fill,
+            with _on(x.device):                                                                 # not baddbmm's strided copy of the broadcast bias)
+                _lib.check(L.slak_fill_channel_bias_bf16(conv_b.detach().float().contiguous().data_ptr(), y.data_ptr(), N, Co, P4, _stream(x.device)),
+                           "slak_fill_channel_bias_bf16")
+            y.baddbmm_(wp.unsqueeze(0).expand(N, Co, 4 * C), a.transpose(1, 2))
         else:
             y = torch.matmul(wp, a.transpose(1, 2))                                            # [N, Co, P4]: NCHW
         ctx.save_for_backward(x, ln_w, mean, rstd, a, wp)
