@@ -645,6 +645,19 @@ def test_stem_wgrad_is_the_conv_weight_and_bias_gradient(N, Co, P, K, gpu):
         assert L.slak_stem_wgrad(dy.data_ptr(), a.data_ptr(), dw3.data_ptr(), None, *bad, ws.data_ptr(), nb, st) == 2  # SLAK_ERR_UNSUPPORTED
 
 
+@pytest.mark.parametrize("N,C,P", [(128, 192, 784), (5, 384, 196), (3, 768, 49), (1, 3, 5), (2, 7, 9)])
+def test_fill_channel_bias_is_the_broadcast_bf16_bias(N, C, P, gpu):
+    """slak_fill_channel_bias_bf16: y[n][c][p] = bf16(bias[c]) -- the tensor `bias.to(bfloat16).view(1, C, 1).expand(N, C, P)` baddbmm would copy."""
+    from slak_amd import _lib
+    L = _lib.lib()
+    torch.manual_seed(C)
+    bias = torch.randn(C, device=gpu)
+    y = torch.full((N * C * P + 8,), float("nan"), device=gpu, dtype=torch.bfloat16)      # 8 guard elements behind the tensor
+    assert L.slak_fill_channel_bias_bf16(bias.data_ptr(), y.data_ptr(), N, C, P, torch.cuda.current_stream(gpu).cuda_stream) == 0
+    assert torch.equal(y[:N * C * P].view(N, C, P), bias.bfloat16().view(1, C, 1).expand(N, C, P))
+    assert torch.isnan(y[N * C * P:]).all()
+
+
 @pytest.mark.parametrize("N,C,P", [(128, 96, 3136), (64, 192, 784), (33, 384, 196), (5, 768, 49), (1, 7, 3), (40, 130, 50), (3, 16, 1028)])
 def test_channel_sums_bf16_is_the_conv_bias_gradient(N, C, P, gpu):
     """slak_channel_sums_bf16 = grad_output.sum((0, 2, 3)) of the stem / downsample Conv2d (models/SLaK.py:188-199), fp32 accumulation: against
