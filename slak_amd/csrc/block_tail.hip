@@ -1079,7 +1079,7 @@ int slak_stem_patchify(const float* x, void* a_bf16, int N, int Cin, int H, int 
 
 // y[n][c][p] = bf16(bias[c]): the accumulator the downsample convolutions' batched GEMM starts from (beta = 1).  torch materialises the
 // broadcast bias with a strided copy kernel at ~1.3 TB/s (30 us for the 38 MB of the first downsample layer); this writes 16 bytes per lane.
-__global__ __launch_bounds__(256) void fill_channel_bias_kernel(const float* __restrict__ bias, uint16_t* __restrict__ y, int C, int P, long long chunks, long long total) {
+static __global__ __launch_bounds__(256) void fill_channel_bias_kernel(const float* __restrict__ bias, uint16_t* __restrict__ y, int C, int P, long long chunks, long long total) {
     for (long long ch = (long long)blockIdx.x * 256 + threadIdx.x; ch < chunks; ch += (long long)gridDim.x * 256) {
         const long long e0 = ch * 8;
         uint16_t v[8];
@@ -1116,7 +1116,7 @@ int slak_fill_channel_bias_bf16(const float* bias, void* y_bf16, int N, int C, i
 // the slices are added by block_tail_reduce1 in a fixed order -> the same bits on every run.  (torch's sum((0, 2)) on this layout reads at
 // ~1 TB/s: 0.19 ms per SLaK-T step for four tensors of 144 MB together.)
 constexpr int CS_SLICES = 32;
-__global__ __launch_bounds__(256) void channel_sums_kernel(const uint16_t* __restrict__ x, float* __restrict__ part, int N, int C, int P, int S) {
+static __global__ __launch_bounds__(256) void channel_sums_kernel(const uint16_t* __restrict__ x, float* __restrict__ part, int N, int C, int P, int S) {
     __shared__ float red[4];
     const int c = blockIdx.x, s = blockIdx.y, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;

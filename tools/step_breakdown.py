@@ -22,7 +22,7 @@ def cat(n):
     if "marker_kernel" in n: return "marker"
     if "slak::adamw" in n or "slak::ema" in n: return "optimizer (slak adamw/ema)"
     if "slak::dwconv" in n or "toeplitz" in n: return "slak dwconv (the hot path)"
-    if "slak::ln_" in n or "slak::scale_res" in n or "block_tail" in n or "slak::stem" in n: return "slak block tail (LN/permute, scale+residual, patchify)"
+    if "slak::ln_" in n or "slak::scale_res" in n or "block_tail" in n or "slak::stem" in n or "channel_sums_kernel" in n or "fill_channel_bias_kernel" in n: return "slak block tail (LN/permute, scale+residual, patchify)"
     if "slak::linear_" in n or "slak::gelu_" in n: return "slak pointwise (linear_nt, linear_wgrad, gelu_bwd)"
     if "slak::bn3" in n: return "slak branch BatchNorm (bn3)"
     if "slak::mask" in n: return "slak mask step"
