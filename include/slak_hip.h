@@ -257,6 +257,10 @@ int slak_ln_patch_backward(const void* g_bf16, const float* x, const float* weig
  * H and W multiples of 4. */
 int slak_stem_patchify(const float* x, void* a_bf16, int N, int Cin, int H, int W, void* stream);
 
+/* dst (N, P, C) = src (N, C, P) transposed per image, bf16: the NCHW output gradient of a downsample convolution (models/SLaK.py:195-199) as the
+ * row operand [N*P][C] of its weight-gradient GEMM (slak_linear_wgrad) -- torch's `grad.transpose(1, 2).reshape(...)` copy.  C % 8 == 0. */
+int slak_nchw_to_pixel_major_bf16(const void* src, void* dst, int N, int C, int P, void* stream);
+
 /* y (N, C, P) bf16 = bf16(bias[c]) broadcast: the accumulator the batched GEMM of a downsample convolution (models/SLaK.py:195-199) adds its
  * products to -- the bias of nn.Conv2d inside the GEMM (fp32 accumulate, one rounding) without torch's strided broadcast copy. */
 int slak_fill_channel_bias_bf16(const float* bias, void* y_bf16, int N, int C, int P, void* stream);

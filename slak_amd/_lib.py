@@ -120,6 +120,7 @@ SIGNATURES = {
     "slak_stem_wgrad_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "slak_stem_wgrad": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _sz, _vp]),
     "slak_fill_channel_bias_bf16": (_i, [_vp, _vp, _i, _i, _i, _vp]),
+    "slak_nchw_to_pixel_major_bf16": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "slak_channel_sums_workspace_bytes": (_sz, [_i]),
     "slak_channel_sums_bf16": (_i, [_vp, _vp, _i, _i, _i, _vp, _sz, _vp]),
     "slak_ln_patch_supported": (_i, [_i, _i, _i, _i]),

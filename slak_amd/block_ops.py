@@ -790,7 +790,13 @@ class _DownsampleLnConv(torch.autograd.Function):
         da = torch.matmul(dy3.transpose(1, 2), wp)                                             # [N, P4, 4C]: dL/da in the patch layout
         # weight gradient: the reduction runs over n and the pixels -> dY in pixel-major order (one copy), then the row-reduction GEMM kernel
         # (the library's heuristic picks 64x64 macro tiles for K = N*P': 0.24 / 0.11 / 0.05 ms for the three layers against ~0.04 each)
-        dwp = linear_wgrad(dy3.transpose(1, 2).reshape(N * P4, Co), a.view(N * P4, 4 * C))
+        if Co % 8 == 0:
+            dy_t = torch.empty((N * P4, Co), dtype=torch.bfloat16, device=dy.device)
+            with _on(dy.device):
+                _lib.check(_lib.lib().slak_nchw_to_pixel_major_bf16(dy3.data_ptr(), dy_t.data_ptr(), N, Co, P4, _stream(dy.device)), "slak_nchw_to_pixel_major_bf16")
+        else:
+            dy_t = dy3.transpose(1, 2).reshape(N * P4, Co)
+        dwp = linear_wgrad(dy_t, a.view(N * P4, 4 * C))
         if dwp is None:
             dwp = torch.mm(dy3.permute(1, 0, 2).reshape(Co, N * P4), a.view(N * P4, 4 * C)).float()
         dconv_w = dwp.view(Co, 2, 2, C).permute(0, 3, 1, 2).contiguous()

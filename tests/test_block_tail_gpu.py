@@ -645,6 +645,20 @@ def test_stem_wgrad_is_the_conv_weight_and_bias_gradient(N, Co, P, K, gpu):
         assert L.slak_stem_wgrad(dy.data_ptr(), a.data_ptr(), dw3.data_ptr(), None, *bad, ws.data_ptr(), nb, st) == 2  # SLAK_ERR_UNSUPPORTED
 
 
+@pytest.mark.parametrize("N,C,P", [(128, 192, 784), (5, 384, 196), (3, 768, 49), (2, 8, 5), (3, 72, 130), (1, 200, 64)])
+def test_nchw_to_pixel_major_is_the_per_image_transpose(N, C, P, gpu):
+    """slak_nchw_to_pixel_major_bf16: dst[n][p][c] = src[n][c][p] (16-, 8- and 2-byte load paths, partial tiles), nothing written outside."""
+    from slak_amd import _lib
+    L = _lib.lib()
+    torch.manual_seed(C + P)
+    src = torch.randn(N, C, P, device=gpu).bfloat16()
+    dst = torch.full((N * P * C + 8,), float("nan"), device=gpu, dtype=torch.bfloat16)
+    assert L.slak_nchw_to_pixel_major_bf16(src.data_ptr(), dst.data_ptr(), N, C, P, torch.cuda.current_stream(gpu).cuda_stream) == 0
+    assert torch.equal(dst[:N * P * C].view(N, P, C), src.transpose(1, 2))
+    assert torch.isnan(dst[N * P * C:]).all()
+    assert L.slak_nchw_to_pixel_major_bf16(src.data_ptr(), dst.data_ptr(), N, C + 1, P, 0) == 2        # SLAK_ERR_UNSUPPORTED: C % 8
+
+
 @pytest.mark.parametrize("N,C,P", [(128, 192, 784), (5, 384, 196), (3, 768, 49), (1, 3, 5), (2, 7, 9)])
 def test_fill_channel_bias_is_the_broadcast_bf16_bias(N, C, P, gpu):
     """slak_fill_channel_bias_bf16: y[n][c][p] = bf16(bias[c]) -- the tensor `bias.to(bfloat16).view(1, C, 1).expand(N, C, P)` baddbmm would copy."""
