@@ -737,6 +737,9 @@ def ln_patch_covers(x):
     return bool(_lib.lib().slak_ln_patch_supported(N, C, H, W))
 
 
+downsample_2d_gemm = os.environ.get("SLAK_DS_2D", "1") != "0"      # A/B switch: the downsample convs' data gradient as one 2-D GEMM
+
+
 def channel_sums(dy3):
     """sum over n and p of a contiguous bf16 [N, C, P] gradient -> fp32 [C] (the bias gradient of the stem / downsample convolutions),
     slak_channel_sums_bf16: fixed summation order."""
@@ -787,7 +790,6 @@ class _DownsampleLnConv(torch.autograd.Function):
         if dy.dtype != torch.bfloat16:
             dy = dy.to(torch.bfloat16)
         dy3 = dy.view(N, Co, P4)
-        da = torch.matmul(dy3.transpose(1, 2), wp)                                             # [N, P4, 4C]: dL/da in the patch layout
         # weight gradient: the reduction runs over n and the pixels -> dY in pixel-major order (one copy), then the row-reduction GEMM kernel
         # (the library's heuristic picks 64x64 macro tiles for K = N*P': 0.24 / 0.11 / 0.05 ms for the three layers against ~0.04 each)
         if Co % 8 == 0:
@@ -796,6 +798,9 @@ class _DownsampleLnConv(torch.autograd.Function):
                 _lib.check(_lib.lib().slak_nchw_to_pixel_major_bf16(dy3.data_ptr(), dy_t.data_ptr(), N, Co, P4, _stream(dy.device)), "slak_nchw_to_pixel_major_bf16")
         else:
             dy_t = dy3.transpose(1, 2).reshape(N * P4, Co)
+        # dL/da in the patch layout [N, P4, 4C]: ONE [N*P4, Co] x [Co, 4C] product on the pixel-major copy (the batched form -- 128 products with
+        # M = P4 each -- ran at 0.23-0.35 PFLOP/s)
+        da = torch.mm(dy_t, wp).view(N, P4, 4 * C) if downsample_2d_gemm else torch.matmul(dy3.transpose(1, 2), wp)
         dwp = linear_wgrad(dy_t, a.view(N * P4, 4 * C))
         if dwp is None:
             dwp = torch.mm(dy3.permute(1, 0, 2).reshape(Co, N * P4), a.view(N * P4, 4 * C)).float()
