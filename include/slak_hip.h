@@ -59,7 +59,7 @@ const char* slak_last_hip_error(void);      /* text of the last HIP error seen b
 /* ABI version: bumped whenever an entry point's argument list or meaning changes (round 5: 5).  A host module compiled against this header
  * (slak_amd/pybind, *.cpp) records the value it saw and refuses to load on a library that reports another one: a stale module would call raw-pointer
  * entry points with a changed argument list -- silent corruption, not an error. */
-#define SLAK_ABI_VERSION 6
+#define SLAK_ABI_VERSION 7
 int slak_version(void);                     /* == SLAK_ABI_VERSION of the header the library was built from */
 int slak_device_info(int* cu_count, int* lds_bytes_per_cu, char* arch_name, size_t arch_name_len);
 int slak_set_conv_algo(int algo);           /* process-wide override of the AUTO choice */
@@ -325,6 +325,13 @@ int slak_linear_nt_gelu_bwd_supported(int M, int N, int K);
 size_t slak_linear_nt_gelu_bwd_workspace_bytes(int M, int N, int K);
 int slak_linear_nt_gelu_bwd(const void* dz_bf16, const void* wt_bf16, const void* y1_bf16, void* dy1_bf16, float* dbias, int M, int N, int K,
                             void* workspace, size_t workspace_bytes, void* stream);
+/* The same launch with the next product of the block's backward in it: dt[M,K] = dy1 . W1 (pwconv1's data gradient), taken from the dy1 tiles while
+ * they are on chip -- the separate slak_linear_nt launch and its re-read of dy1 (308 MB per stage-1 block of SLaK-T) are gone.  w1p = W1^T [K][N]
+ * bf16 (pwconv1's nn.Linear weight transposed) in fragment-major order: viewed (3, 32, 6, 4, 2, 8) and permuted (2, 3, 0, 4, 1, 5), contiguous.
+ * dy1 and dbias: the bits of slak_linear_nt_gelu_bwd; dt: bf16 of the same fp32 sums added in another order.  Shapes and workspace as above. */
+int slak_linear_nt_gelu_bwd_dt_supported(int M, int N, int K);
+int slak_linear_nt_gelu_bwd_dt(const void* dz_bf16, const void* wt_bf16, const void* y1_bf16, const void* w1p_bf16, void* dy1_bf16, void* dt_bf16,
+                               float* dbias, int M, int N, int K, void* workspace, size_t workspace_bytes, void* stream);
 
 /* Round 5 -- the pointwise Linear layers of stages 2-4 with their elementwise neighbours in the GEMM's epilogue (models/SLaK.py:156-165:
  * pwconv1 -> nn.GELU() -> pwconv2, and their data gradients): out[M][N] = a[M][K] . b[N][K]^T, both operands K-contiguous (the nn.Linear weight as it is

@@ -135,6 +135,8 @@ SIGNATURES = {
     "slak_linear_nt_gelu_bwd_supported": (_i, [_i, _i, _i]),
     "slak_linear_nt_gelu_bwd_workspace_bytes": (_sz, [_i, _i, _i]),
     "slak_linear_nt_gelu_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _sz, _vp]),
+    "slak_linear_nt_gelu_bwd_dt_supported": (_i, [_i, _i, _i]),
+    "slak_linear_nt_gelu_bwd_dt": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _sz, _vp]),
     "slak_linear_gemm_supported": (_i, [_i, _i, _i, _i]),
     "slak_linear_gemm_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "slak_linear_gemm": (_i, [_vp] * 7 + [_i, _i, _i, _i, _vp, _sz, _vp]),

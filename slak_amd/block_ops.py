@@ -959,7 +959,21 @@ def lowp_param_t(p):
         _lib.check(_lib.lib().slak_transpose_bf16_batch(srcs, dsts, rows, cols, n, _stream(p.device)), "slak_transpose_bf16_batch")
     for sq, ee in jobs:
         ee[1] = ee[0]()._version
+        ee[2]._slak_stamp = ee[1]                                    # (w1_fragments keys its packed copy on it)
     return e[2]
+
+
+def w1_fragments(w1t):
+    """W1^T [96][384] bf16 -> the fragment-major copy slak_linear_nt_gelu_bwd_dt reads ([pair][k-step][row tile][lane half][row][8 k]: 1 KB per
+    load, every byte used); kept on the cached transpose it was made from until lowp_param_t refreshes that one."""
+    stamp = getattr(w1t, "_slak_stamp", None)
+    c = getattr(w1t, "_slak_frag", None)
+    if stamp is not None and c is not None and c[0] == stamp:
+        return c[1]
+    w1p = w1t.view(3, 32, 6, 4, 2, 8).permute(2, 3, 0, 4, 1, 5).contiguous()
+    if stamp is not None:
+        w1t._slak_frag = (stamp, w1p)
+    return w1p
 
 
 _SPLITK_ROWS = int(_os.environ.get("SLAK_SPLITK_ROWS", "6272"))     # rows per split of the weight-gradient GEMMs (0: one plain GEMM)
@@ -1123,6 +1137,14 @@ def _mlp_bwd_data(saved, dz, wts=None):
         db1 = torch.empty(N4, dtype=torch.float32, device=dz2.device)
         w2t = w2t_of()
         ws, nb = _workspace(int(L.slak_linear_nt_gelu_bwd_workspace_bytes(M, N4, dz2.shape[1])), dz2.device)
+        if L.slak_linear_nt_gelu_bwd_dt_supported(M, N4, dz2.shape[1]):
+            # ... and dt = dy1 @ W1 from the dy1 tiles while they are on chip (no second launch, dy1 is not read back)
+            w1p = w1_fragments(w1t_of())
+            dt = torch.empty((M, dz2.shape[1]), dtype=torch.bfloat16, device=dz2.device)
+            with _on(dz2.device):
+                _lib.check(L.slak_linear_nt_gelu_bwd_dt(dz2.data_ptr(), w2t.data_ptr(), y12.data_ptr(), w1p.data_ptr(), dy1.data_ptr(), dt.data_ptr(), db1.data_ptr(),
+                                                        M, N4, dz2.shape[1], ws.data_ptr(), nb, _stream(dz2.device)), "slak_linear_nt_gelu_bwd_dt")
+            return dt.view_as(t), dy1, db1
         with _on(dz2.device):
             _lib.check(L.slak_linear_nt_gelu_bwd(dz2.data_ptr(), w2t.data_ptr(), y12.data_ptr(), dy1.data_ptr(), db1.data_ptr(), M, N4, dz2.shape[1],
                                                  ws.data_ptr(), nb, _stream(dz2.device)), "slak_linear_nt_gelu_bwd")
@@ -1322,9 +1344,12 @@ class _BlockFn(torch.autograd.Function):
         tri_dgrad, group, count, count_dev, xdtype, had_lowp = ctx.misc
         if ctx.runner:
             exchange = None if group is None else (lambda buf, async_op: _sync_bn_all_reduce(buf, group, async_op=async_op))
+            w1p = None                                                # stage 1: W1^T in fragment order for the launch that also produces dt
+            if tuple(w1b.shape) == (384, 96) and w1b.dtype == torch.bfloat16 and _lib.lib().slak_linear_nt_gelu_bwd_dt_supported(t.numel() // 96, 384, 96):
+                w1p = w1_fragments(w1t if w1t is not None else w1b.t().contiguous())
             (dx, dxl, dwv, dwh, dws, dgam, dbet, dlnw, dlnb, dw1, db1, dw2, dzc, dgamma) = _runner_mod.block_backward(
                 x16, wv, wh, ws, yv, yh, ys, [g1, g2, g3], bnstats, s, lnw, mean, rstd, t, w1b, y1m, a, w2b, z, gamma, sample_scale, dout, dout16,
-                xdtype == torch.bfloat16, had_lowp, count_dev, exchange, _runner_trace, w1t, w2t)
+                xdtype == torch.bfloat16, had_lowp, count_dev, exchange, _runner_trace, w1t, w2t, w1p)
             return (dx, dxl, dwv, dwh, dws, dgam[0], dbet[0], dgam[1], dbet[1], dgam[2], dbet[2], dlnw, dlnb, dw1, db1, dw2, dzc, dgamma, None, None)
         saved = (t, w1b, y1m, a, w2b)
         dshortcut, dz, dgamma, dzc = _scale_residual_bwd(z, gamma, sample_scale, xdtype, dout, dout16)

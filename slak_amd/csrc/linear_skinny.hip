@@ -513,6 +513,171 @@ __global__ __launch_bounds__(LG_THREADS, 1) void linear_nt_k96_gbwd_kernel(const
         }
 }
 
+// The kernel above with the NEXT product of the block's backward in it (round 5): dt = dy1 . W1 (pwconv1's data gradient, K = 384 -> 96 columns).
+// A pair's dy1 chunks go back into the wave's out tile, where a row's 64 columns lie k-contiguous -- the MFMA B operand of dt^T = W1^T . dy1^T;
+// W1^T's twelve fragments of the pair (3 row tiles x 4 k-steps, fragment-major in global memory: 1 KB per load, L2 resident) are fetched at the
+// top of the pair, a GEMM and a table pass ahead of their use.  The stand-alone slak_linear_nt launch with its 308 MB re-read of dy1 is gone.
+// What had to give is registers -- the VALU side of this kernel (y1, table values, column sums) lives in the 256 architectural VGPRs, and a first
+// version that only added the fragments and the accumulators spilled 30-100 of them to scratch (every scratch access drains vmcnt: 338 us
+// against 290 for the two launches).  Here: y1 is prefetched THREE pairs ahead (a rolling window of three register sets, 48 registers, instead of
+// a whole row block in two sets, 192), and the GELU' pass runs in two halves of two chunks (16 table values in flight instead of 32).
+__global__ __launch_bounds__(LG_THREADS, 1) void linear_nt_k96_gbwd_dt_kernel(const uint16_t* __restrict__ X, const uint16_t* __restrict__ Wt,
+                                                                            const uint16_t* __restrict__ Y1, const uint16_t* __restrict__ W1p,
+                                                                            uint16_t* __restrict__ DY, uint16_t* __restrict__ DTO,
+                                                                            float* __restrict__ part, int M, unsigned x_bytes, unsigned y_bytes,
+                                                                            const float* __restrict__ table) {
+    constexpr int K = 96, KS = 6, N = 64 * LG_NP;
+    extern __shared__ __attribute__((aligned(16))) uint16_t lds[];
+    char* const L = (char*)lds;
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, lhi = lane >> 5;
+    const int wave = wave_id_uniform();
+    char* const Lw = L;                                               // [N][LS_XP]
+    const unsigned xbuf = (unsigned)N * LS_XP + (unsigned)wave * LS_XBUF;
+    char* const ot = L + (unsigned)N * LS_XP + LG_WAVES * LS_XBUF + wave * LK_OBUF;
+    const float* const T = (const float*)(L + (unsigned)N * LS_XP + LG_WAVES * (LS_XBUF + LK_OBUF));
+    const unsigned lds_base = (unsigned)(uintptr_t)SLAK_LDS(uint16_t, lds);
+    v4i_t rsrc;
+    {
+        const uint64_t a = (uint64_t)X;
+        rsrc[0] = __builtin_amdgcn_readfirstlane((int)(a & 0xffffffffu)); rsrc[1] = __builtin_amdgcn_readfirstlane((int)((a >> 32) & 0xffffu));
+        rsrc[2] = __builtin_amdgcn_readfirstlane((int)x_bytes); rsrc[3] = 0x00020000;
+    }
+    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(Y1), 0, (int)y_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(DY, 0, (int)y_bytes, 0x00020000);
+    XDma plan; xdma_plan(plan, lane, K * 2);
+    const int ntiles_m = M >> 5, stride = gridDim.x * LG_WAVES;       // (M % 32 == 0)
+    const int fr = lane >> 3, fc = lane & 7;                          // flush layout: row fr + 8 it, 16-byte chunk fc of the 64-column pair
+    const unsigned flane = (unsigned)fr * (unsigned)(N * 2) + (unsigned)fc * 16u;
+    int tm = blockIdx.x * LG_WAVES + wave;
+    u32x4 yw[3][4];                                                   // y1 of the pairs pr, pr + 1, pr + 2 (slot pr % 3)
+    if (tm < ntiles_m) xdma_issue(plan, (unsigned)tm * 32u * K * 2u, 32, rsrc, lds_base + xbuf);
+    {
+        const unsigned g00 = tm < ntiles_m ? (unsigned)tm * 32u * (unsigned)(N * 2) + flane : 0x80000000u;
+#pragma unroll
+        for (int sl = 0; sl < 3; ++sl)
+#pragma unroll
+            for (int it = 0; it < 4; ++it) yw[sl][it] = __builtin_amdgcn_raw_buffer_load_b128(ry, g00 + (unsigned)(it * 8 * N * 2), sl * 128, 0);
+    }
+    stage_weight(Lw, Wt, N, K, LS_XP, tid, LG_THREADS);
+    for (int i = tid; i < GD_BYTES / 16; i += LG_THREADS) ((u32x4*)T)[i] = ((const u32x4*)table)[i];
+    __syncthreads();                                                  // the only workgroup barrier
+    // at the top of a row block its X DMA must have landed: it was issued a block ago, in front of > 100 loads and stores of which the last
+    // pair's fragment loads have been waited for -- any bound below 63 is met by then
+    int pending = 0;
+    const unsigned wlane = (unsigned)l31 * LS_XP + (unsigned)lhi * 16u;
+    float acc[LG_NP][8];
+#pragma unroll
+    for (int pr = 0; pr < LG_NP; ++pr)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc[pr][k] = 0.f;
+    auto lsync = [] { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); };
+    for (; tm < ntiles_m; tm += stride) {
+        wait_vmcnt_dyn(pending);
+        __builtin_amdgcn_wave_barrier();
+        s16x8 xf[KS];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) xf[ks] = __builtin_bit_cast(s16x8, *(const u32x4*)(L + xbuf + wlane + ks * 32));
+        lsync();                                                      // every lane has its fragments: the buffer is free
+        pending = 60;
+        const int tn = tm + stride;
+        if (tn < ntiles_m) xdma_issue(plan, (unsigned)tn * 32u * K * 2u, 32, rsrc, lds_base + xbuf);
+        const unsigned g0 = (unsigned)tm * 32u * (unsigned)(N * 2) + flane;
+        const unsigned g0n = tn < ntiles_m ? (unsigned)tn * 32u * (unsigned)(N * 2) + flane : 0x80000000u;
+        f32x16 zacc[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) zacc[j][i] = 0.f;
+#pragma unroll
+        for (int pr = 0; pr < LG_NP; ++pr) {
+            constexpr int dummy = 0; (void)dummy;
+            const int sl = pr % 3;
+            u32x4 w1f[3][4];                                          // W1^T[32 j + l31][64 pr + 16 u + 8 lhi .. +8], packed [pr][u][j][lane] by the caller
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) w1f[j][u] = ((const u32x4*)W1p)[(((pr * 4 + u) * 3 + j) << 6) + lane];
+            unsigned py[2][8];
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const int nt = 2 * pr + half;
+                f32x16 a;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) a[i] = 0.f;
+                const char* wt = Lw + (size_t)nt * 32 * LS_XP + wlane;
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) a = mfma32<bf16_t>(__builtin_bit_cast(s16x8, *(const u32x4*)(wt + ks * 32)), xf[ks], a);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { py[half][2 * q] = pack2<bf16_t>(a[4 * q + 0], a[4 * q + 1]); py[half][2 * q + 1] = pack2<bf16_t>(a[4 * q + 2], a[4 * q + 3]); }
+            }
+            put_tile(ot, py[0], l31, lhi, 0); put_tile(ot, py[1], l31, lhi, 1);
+            lsync();
+            // GELU' in two halves of two 8-element chunks; dy1 goes to HBM and back into the tile (each lane the chunks it read)
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2) {
+                uint4 gq[2], vq[2];
+                float tq[2][8];
+                bool ok = true;
+                float a2[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) a2[k] = acc[pr][k];
+#pragma unroll
+                for (int i2 = 0; i2 < 2; ++i2) {
+                    const int it = 2 * h2 + i2;
+                    const u32x4 g4 = *(const u32x4*)(ot + (it * 8 + fr) * LK_OP + fc * 16);
+                    gq[i2] = uint4{g4[0], g4[1], g4[2], g4[3]};
+                }
+#pragma unroll
+                for (int i2 = 0; i2 < 2; ++i2) {
+                    const int it = 2 * h2 + i2;
+                    ok = gelu_grad_gather8(T, uint4{yw[sl][it][0], yw[sl][it][1], yw[sl][it][2], yw[sl][it][3]}, tq[i2]) && ok;
+                }
+                if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) {
+#pragma unroll
+                    for (int i2 = 0; i2 < 2; ++i2) gelu_bwd8_apply(gq[i2], tq[i2], vq[i2], a2);
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) acc[pr][k] = a2[k];
+                } else {                                              // (wave-uniform, rare) an element outside the table: the general evaluation
+#pragma unroll
+                    for (int i2 = 0; i2 < 2; ++i2) {
+                        const int it = 2 * h2 + i2;
+                        gelu_bwd8(T, gq[i2], uint4{yw[sl][it][0], yw[sl][it][1], yw[sl][it][2], yw[sl][it][3]}, vq[i2], acc[pr]);
+                    }
+                }
+#pragma unroll
+                for (int i2 = 0; i2 < 2; ++i2) {
+                    const int it = 2 * h2 + i2;
+                    const u32x4 v = u32x4{vq[i2].x, vq[i2].y, vq[i2].z, vq[i2].w};
+                    __builtin_amdgcn_raw_buffer_store_b128(v, rd, g0 + (unsigned)(it * 8 * N * 2), pr * 128, 0);
+                    *(u32x4*)(ot + (it * 8 + fr) * LK_OP + fc * 16) = v;
+                    // the slot's next tenant: pair pr + 3 of this row block, or pair pr - 3 of the next one
+                    yw[sl][it] = __builtin_amdgcn_raw_buffer_load_b128(ry, (pr < 3 ? g0 : g0n) + (unsigned)(it * 8 * N * 2), (pr < 3 ? pr + 3 : pr - 3) * 128, 0);
+                }
+            }
+            lsync();
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const s16x8 bf = __builtin_bit_cast(s16x8, *(const u32x4*)(ot + l31 * LK_OP + 32 * u + 16 * lhi));
+#pragma unroll
+                for (int j = 0; j < 3; ++j) zacc[j] = mfma32<bf16_t>(__builtin_bit_cast(s16x8, w1f[j][u]), bf, zacc[j]);
+            }
+            lsync();
+        }
+        const int row = tm * 32 + l31;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) store_tile<false>(zacc[j], nullptr, DTO, nullptr, (size_t)row * K, j * 32, lhi, true);
+    }
+    // column sums: over the eight row lanes, then one partial row per wave
+#pragma unroll
+    for (int pr = 0; pr < LG_NP; ++pr)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            float v = acc[pr][k];
+            v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);
+            if (lane < 8) part[((size_t)blockIdx.x * LG_WAVES + wave) * N + pr * 64 + lane * 8 + k] = v;
+        }
+}
+
 template <int NKC>                 // K = 96 NKC
 __global__ __launch_bounds__(LS_THREADS, 1) void linear_nt_n96_kernel(const uint16_t* __restrict__ X, const uint16_t* __restrict__ Wt,
                                                                     const uint16_t* __restrict__ bias, uint16_t* __restrict__ Y,
@@ -699,6 +864,33 @@ int slak_linear_nt_gelu_bwd(const void* x, const void* wt, const void* y1, void*
     if (!slak_set_max_lds((const void*)linear_nt_k96_gbwd_kernel, lds)) return SLAK_ERR_LAUNCH;
     hipLaunchKernelGGL(linear_nt_k96_gbwd_kernel, dim3(wk), dim3(LG_THREADS), lds, st, (const uint16_t*)x, (const uint16_t*)wt, (const uint16_t*)y1,
                        (uint16_t*)dy1, (float*)workspace, M, (unsigned)((size_t)M * K * 2), (unsigned)((size_t)M * N * 2), table);
+    SLAK_LAUNCH_CHECK();
+    return tail_reduce_columns((const float*)workspace, dbias, wk * LG_WAVES, N, st);
+}
+
+/* slak_linear_nt_gelu_bwd with the next product of the block's backward in the same launch: dt [M][K] = dy1 . W1 (pwconv1's data gradient), see
+ * linear_nt_k96_gbwd_dt_kernel.  w1p = W1^T [K][N] bf16 in FRAGMENT-MAJOR order: viewed (3, 32, 6, 4, 2, 8) = [row tile j][row l31][pair pr][k-step u]
+ * [lane half lhi][8 k] and permuted to [pr][u][j][lhi][l31][8] (slak_pack_w1t_fragments makes it).  dy1 and dbias: the bits of
+ * slak_linear_nt_gelu_bwd; dt: bf16 of the same fp32 sums added in another order than slak_linear_nt's. */
+int slak_linear_nt_gelu_bwd_dt_supported(int M, int N, int K) {
+    static const bool on = [] { const char* e = getenv("SLAK_LINEAR_GELU_BWD_DT"); return !(e && e[0] == '0'); }();
+    return (on && slak_linear_nt_gelu_bwd_supported(M, N, K)) ? 1 : 0;
+}
+int slak_linear_nt_gelu_bwd_dt(const void* x, const void* wt, const void* y1, const void* w1p, void* dy1, void* dt, float* dbias, int M, int N, int K,
+                               void* workspace, size_t workspace_bytes, void* stream) {
+    if (!x || !wt || !y1 || !w1p || !dy1 || !dt || !dbias) return SLAK_ERR_INVALID_ARG;
+    if (!slak_linear_nt_gelu_bwd_dt_supported(M, N, K)) return SLAK_ERR_UNSUPPORTED;
+    if (!workspace || workspace_bytes < slak_linear_nt_gelu_bwd_workspace_bytes(M, N, K)) return SLAK_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    const int tiles = M / 32;
+    int wk = mfma_cu_count(); if (wk > 1024) wk = 1024; if (wk * LG_WAVES > tiles) wk = (tiles + LG_WAVES - 1) / LG_WAVES;
+    const float* table = gelu_grad_table_device();
+    if (!table) return SLAK_ERR_LAUNCH;
+    const size_t lds = (size_t)N * LS_XP + (size_t)LG_WAVES * (LS_XBUF + LK_OBUF) + GD_BYTES;
+    if (!slak_set_max_lds((const void*)linear_nt_k96_gbwd_dt_kernel, lds)) return SLAK_ERR_LAUNCH;
+    hipLaunchKernelGGL(linear_nt_k96_gbwd_dt_kernel, dim3(wk), dim3(LG_THREADS), lds, st, (const uint16_t*)x, (const uint16_t*)wt, (const uint16_t*)y1,
+                       (const uint16_t*)w1p, (uint16_t*)dy1, (uint16_t*)dt, (float*)workspace, M, (unsigned)((size_t)M * K * 2),
+                       (unsigned)((size_t)M * N * 2), table);
     SLAK_LAUNCH_CHECK();
     return tail_reduce_columns((const float*)workspace, dbias, wk * LG_WAVES, N, st);
 }

@@ -241,7 +241,8 @@ std::vector<Tensor> block_backward(const Tensor& x16, const Tensor& wv, const Te
                                    const Tensor& w2b, const Tensor& z, const Tensor& gamma, const c10::optional<Tensor>& sample_scale,
                                    const c10::optional<Tensor>& dout_opt, const c10::optional<Tensor>& dout16_opt, bool shortcut_bf16, bool had_lowp,
                                    const c10::optional<Tensor>& count_dev, const pybind11::object& exchange, const pybind11::object& trace,
-                                   const c10::optional<Tensor>& w1t_opt, const c10::optional<Tensor>& w2t_opt /* cached transposed bf16 weights, or None */) {
+                                   const c10::optional<Tensor>& w1t_opt, const c10::optional<Tensor>& w2t_opt /* cached transposed bf16 weights, or None */,
+                                   const c10::optional<Tensor>& w1p_opt /* W1^T in fragment-major order (slak_linear_nt_gelu_bwd_dt), or None */) {
     const Shape s = shape_of(x16, wv, w1b);
     const Plan& pl = plan_of(s);
     TORCH_CHECK(pl.ok, "block_backward: the shape has no one-launch path (block_forward would have declined it)");
@@ -271,8 +272,14 @@ std::vector<Tensor> block_backward(const Tensor& x16, const Tensor& wv, const Te
     Tensor dz2 = dz.view({s.M, s.C});
     const auto w2t_of = [&] { return (w2t_opt.has_value() && w2t_opt->defined()) ? *w2t_opt : w2b.t().contiguous(); };
     const auto w1t_of = [&] { return (w1t_opt.has_value() && w1t_opt->defined()) ? *w1t_opt : w1b.t().contiguous(); };
-    Tensor dact, dy1, db1 = at::empty({s.C4}, f32);
-    if (pl.gbwd) {                                                 // stage 1: dz W2, GELU' and pwconv1's bias gradient in one pass
+    Tensor dact, dy1, dt_, db1 = at::empty({s.C4}, f32);
+    if (pl.gbwd && w1p_opt.has_value() && w1p_opt->defined() && slak_linear_nt_gelu_bwd_dt_supported(s.M, s.C4, s.C) == 1) {
+        Tensor w2t = w2t_of();                                     // stage 1: the same with dt = dy1 W1 taken from the dy1 tiles while they are on chip
+        dy1 = at::empty({s.M, s.C4}, x16.options());
+        dt_ = at::empty({s.M, s.C}, x16.options());
+        check_rc(slak_linear_nt_gelu_bwd_dt(dz2.data_ptr(), w2t.data_ptr(), y1m.data_ptr(), w1p_opt->data_ptr(), dy1.data_ptr(), dt_.data_ptr(), fpm(db1), s.M, s.C4,
+                                            s.C, region(1).p, region(1).n, st), "slak_linear_nt_gelu_bwd_dt");
+    } else if (pl.gbwd) {                                          // stage 1: dz W2, GELU' and pwconv1's bias gradient in one pass
         Tensor w2t = w2t_of();
         dy1 = at::empty({s.M, s.C4}, x16.options());
         check_rc(slak_linear_nt_gelu_bwd(dz2.data_ptr(), w2t.data_ptr(), y1m.data_ptr(), dy1.data_ptr(), fpm(db1), s.M, s.C4, s.C, region(1).p, region(1).n, st),
@@ -291,8 +298,8 @@ std::vector<Tensor> block_backward(const Tensor& x16, const Tensor& wv, const Te
     dy1 = at::empty_like(dact);
     check_rc(slak_gelu_backward_bias(dact.data_ptr(), y1m.data_ptr(), dy1.data_ptr(), fpm(db1), s.M, s.C4, region(1).p, region(1).n, st), "slak_gelu_backward_bias");
     }
-    Tensor dt_;
-    if (pl.ntd2) {
+    if (dt_.defined()) {
+    } else if (pl.ntd2) {
         Tensor w1t = w1t_of();
         dt_ = at::empty({s.M, s.C}, x16.options());
         check_rc(slak_linear_nt(dy1.data_ptr(), w1t.data_ptr(), nullptr, dt_.data_ptr(), nullptr, s.M, s.C, s.C4, st), "slak_linear_nt");

@@ -137,6 +137,45 @@ def test_linear_nt_gelu_bwd_is_the_gemm_followed_by_the_gelu_backward(M, gpu):
     assert (db.double()[colfin] - dbr.double()[colfin]).abs().max().item() <= 2e-5 * max(1.0, want.abs().max().item()) * max(1.0, M ** 0.5 / 30)
 
 
+@pytest.mark.parametrize("M", [32, 96, 6272, 40032, 401408])
+def test_linear_nt_gelu_bwd_dt_adds_the_next_product(M, gpu):
+    """slak_linear_nt_gelu_bwd_dt: dy1 and the bias gradient carry the bits of slak_linear_nt_gelu_bwd (special pre-activations included); dt = dy1 . W1
+    agrees with the stand-alone slak_linear_nt on the stored dy1 up to the order of the fp32 additions (a bf16 rounding flips now and then) and with fp64."""
+    from slak_amd import _lib
+    L = _lib.lib()
+    N, K = 384, 96
+    assert L.slak_linear_nt_gelu_bwd_dt_supported(M, N, K) == 1
+    torch.manual_seed(M + 1)
+    dz = (torch.randn(M, K, device=gpu) * 0.5).bfloat16()
+    wt = (torch.randn(N, K, device=gpu) * 0.1).bfloat16()
+    w1t = (torch.randn(K, N, device=gpu) * 0.1).bfloat16()
+    w1p = w1t.view(3, 32, 6, 4, 2, 8).permute(2, 3, 0, 4, 1, 5).contiguous()      # fragment-major: [pair][k-step][row tile][lane half][row][8 k]
+    y1 = torch.randn(M, N, device=gpu)
+    flat = y1.view(-1)
+    sp = torch.tensor([0.0, -0.0, 1e-7, -1e-7, 3e-6, 15.9, -15.9, 16.0, -16.0, 40.0, -1e30], device=gpu)
+    flat[torch.randperm(flat.numel(), device=gpu)[:sp.numel() * 3]] = sp.repeat(3)
+    y1 = y1.bfloat16()
+    st = torch.cuda.current_stream(gpu).cuda_stream
+    nb = int(L.slak_linear_nt_gelu_bwd_workspace_bytes(M, N, K))
+    ws = torch.empty(nb, dtype=torch.uint8, device=gpu)
+    ref = torch.empty(M, N, device=gpu, dtype=torch.bfloat16); dbr = torch.empty(N, device=gpu)
+    _lib.check(L.slak_linear_nt_gelu_bwd(dz.data_ptr(), wt.data_ptr(), y1.data_ptr(), ref.data_ptr(), dbr.data_ptr(), M, N, K, ws.data_ptr(), nb, st), "two")
+    dtr = torch.empty(M, K, device=gpu, dtype=torch.bfloat16)
+    _lib.check(L.slak_linear_nt(ref.data_ptr(), w1t.data_ptr(), None, dtr.data_ptr(), None, M, K, N, st), "linear_nt")
+    for rep in range(2):                                       # twice: the second call runs over what the first left in LDS and the workspace
+        dy1 = torch.full((M, N), float("nan"), device=gpu, dtype=torch.bfloat16); db = torch.full((N,), float("nan"), device=gpu)
+        dt = torch.full((M, K), float("nan"), device=gpu, dtype=torch.bfloat16)
+        _lib.check(L.slak_linear_nt_gelu_bwd_dt(dz.data_ptr(), wt.data_ptr(), y1.data_ptr(), w1p.data_ptr(), dy1.data_ptr(), dt.data_ptr(), db.data_ptr(),
+                                                M, N, K, ws.data_ptr(), nb, st), "fused")
+        torch.cuda.synchronize()
+        assert torch.equal(dy1.view(torch.int16), ref.view(torch.int16)) and torch.equal(db, dbr)
+        want = ref.double() @ w1t.double().t()
+        scale = want.abs().max().item()
+        assert (dt.double() - want).abs().max().item() <= 2.0 ** -8 * 1.05 * scale
+        assert (dt.double() - dtr.double()).abs().max().item() <= 2.0 ** -7 * scale
+        assert (dt.view(torch.int16) != dtr.view(torch.int16)).float().mean().item() < 0.02
+
+
 def test_linear_nt_gelu_bwd_declines_what_it_does_not_cover(gpu):
     from slak_amd import _lib
     L = _lib.lib()
