@@ -590,7 +590,6 @@ __global__ __launch_bounds__(LG_THREADS, 1) void linear_nt_k96_gbwd_dt_kernel(co
             for (int i = 0; i < 16; ++i) zacc[j][i] = 0.f;
 #pragma unroll
         for (int pr = 0; pr < LG_NP; ++pr) {
-            constexpr int dummy = 0; (void)dummy;
             const int sl = pr % 3;
             u32x4 w1f[3][4];                                          // W1^T[32 j + l31][64 pr + 16 u + 8 lhi .. +8], packed [pr][u][j][lane] by the caller
 #pragma unroll
