@@ -515,6 +515,8 @@ def main():
             # (default_hooks.allreduce_hook: buffer.div_(world) then all_reduce -- element for element the arithmetic of the default path).
             from torch.distributed.algorithms.ddp_comm_hooks import default_hooks
             model.register_comm_hook(None, default_hooks.allreduce_hook)
+            # round 6: the blocks' weight-gradient launches write INTO the bucket views (block_ops.adopt_grad_slots): no per-parameter copy launch either
+            block_ops.enable_grad_slots_for(model)                   # SLAK_GRAD_SLOTS=0: the A/B switch
     decay, no_decay = [], []
     for n, p in model.named_parameters():
         (no_decay if (p.dim() == 1 or n.endswith(".bias")) else decay).append(p)                                     # optim_factory.py no-decay rule
@@ -650,10 +652,11 @@ def main():
                    "model_ema": bool(a.model_ema), "one_autograd_node_per_block": bool(M.Block.fused_block),
                    "block_runner": bool(M.Block.fused_block and block_ops._runner() is not None),   # the blocks' call sequences issued from C++ (round 5: under DDP / SyncBatchNorm too)
                    "forced_distributed": bool(a.force_dist and world == 1),
-                   "ddp": (None if not distributed else ("main.py:374-376 defaults" if a.ddp_reference_flags else "broadcast_buffers=False, gradient_as_bucket_view=True, allreduce_hook (division per bucket, not per parameter)")),
+                   "ddp": (None if not distributed else ("main.py:374-376 defaults" if a.ddp_reference_flags else "broadcast_buffers=False, gradient_as_bucket_view=True, allreduce_hook (division per bucket, not per parameter)"
+                                                          + (", block gradients written into the bucket views (no per-parameter copy)" if block_ops.grad_slots_enabled else ""))),
                    "sync_bn": True, "block_tail": "hip (ln_nchw_to_nhwc + scale_residual)" if M.Block.fused_tail else "pytorch ops",
                    "branch_bn": "hip (bn3: one stats pass + one apply pass)" if M.ReparamLargeKernelConv.fused_bn else "pytorch (Sync)BatchNorm x3 + adds",
-                   "pointwise_gemm": "hipBLASLt via torch" + (", TunableOp solutions from slak_amd/tuning/tunableop_gfx950.csv" if TUNED_GEMMS else ""),
+                   "pointwise_gemm": "slak_linear_gemm / slak_linear_nt / slak_linear_wgrad (own kernels: pwconv1 + GELU, dz W2 + GELU', the stage-1 products, every weight gradient); hipBLASLt via torch for pwconv2 / dy1 W1 of stages 2-4 and the downsample products" + (", TunableOp solutions from slak_amd/tuning/tunableop_gfx950.csv" if TUNED_GEMMS else ""),
                    "tunableop": tun,
                    "cudnn_benchmark": bool(a.cudnn_benchmark),
                    "prime_steps": a.prime,

@@ -59,7 +59,7 @@ const char* slak_last_hip_error(void);      /* text of the last HIP error seen b
 /* ABI version: bumped whenever an entry point's argument list or meaning changes (round 5: 5).  A host module compiled against this header
  * (slak_amd/pybind, *.cpp) records the value it saw and refuses to load on a library that reports another one: a stale module would call raw-pointer
  * entry points with a changed argument list -- silent corruption, not an error. */
-#define SLAK_ABI_VERSION 7
+#define SLAK_ABI_VERSION 8
 int slak_version(void);                     /* == SLAK_ABI_VERSION of the header the library was built from */
 int slak_device_info(int* cu_count, int* lds_bytes_per_cu, char* arch_name, size_t arch_name_len);
 int slak_set_conv_algo(int algo);           /* process-wide override of the AUTO choice */
@@ -429,6 +429,18 @@ int slak_bn3_forward_local(const void* y1, const void* y2, const void* y3, const
 int slak_bn3_backward_local(const void* dout, const void* y1, const void* y2, const void* y3, const float* stats, const float* const* gamma,
                             float* bcoef, float* dgamma, float* dbeta, void* dy1, void* dy2, void* dy3, int N, int C, int P,
                             void* workspace, size_t workspace_bytes, void* stream);
+/* Round 6: the same two calls with ONE destination per parameter gradient (dgamma3 / dbeta3: host arrays of three device pointers, [C]
+ * floats each) instead of two [3][C] arrays.  Under DistributedDataParallel(gradient_as_bucket_view=True) a parameter's .grad is a view
+ * of an all-reduce bucket (main.py:374-376 builds the wrapper): with these the six BatchNorm parameter gradients of a block
+ * (models/SLaK.py:38-47) are written where the reducer wants them and its per-parameter copy launch disappears.  The [3][C]
+ * forms above are wrappers over these (same kernels, same bits). */
+int slak_bn3_backward_apply_to(const void* dout, const void* y1, const void* y2, const void* y3, const float* global_sums,
+                               const float* local_sums, double count, const double* count_dev, const float* stats, const float* const* gamma_host3,
+                               float* bcoef /*[C][9]*/, float* const* dgamma3, float* const* dbeta3,
+                               void* dy1, void* dy2, void* dy3, int N, int C, int P, void* stream);
+int slak_bn3_backward_local_to(const void* dout, const void* y1, const void* y2, const void* y3, const float* stats, const float* const* gamma,
+                               float* bcoef, float* const* dgamma3, float* const* dbeta3, void* dy1, void* dy2, void* dy3, int N, int C, int P,
+                               void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------- next row: mask-aware optimizer step and EMA
  * One launch over ALL tensors each.  Descriptor arrays live in HOST memory at plan creation (device pointers inside); plans own their

@@ -1295,6 +1295,68 @@ def _runner():
     return _runner_mod if (_runner_mod is not None and _runner_switches()) else None
 
 
+# ------------------------------------------------------------------------------------------------------------------
+# Parameter gradients written where DistributedDataParallel wants them (round 6; main.py:374-376 wraps the model, engine.py:80-88 steps it).
+# DDP(gradient_as_bucket_view=True) makes every .grad a view of an all-reduce bucket -- but a step that drops the gradients
+# (zero_grad(set_to_none=True), engine.py:86 / torch's default) gets fresh tensors from autograd, and the reducer copies each into its bucket view as
+# the parameter becomes ready: one launch per parameter, 312 per SLaK-T step, 1.4 ms of GPU time and the reducer's host time around them
+# (profiles/r05_step_breakdown_forcedist.txt).  The bucket views outlive the step, so: `adopt_grad_slots` remembers a parameter's .grad tensor
+# once a backward has left a bucket view there (MaskedAdamW.step calls it), and the next backward of the block hands those tensors to the
+# C++ runner as the DESTINATIONS of its weight-gradient / reduction launches; the runner returns new tensor objects on the same storage, autograd
+# installs them as .grad without a copy, the reducer finds .grad aliasing its view and launches nothing.  Self-healing: a destination that is no
+# longer the reducer's view (DDP rebuilds its buckets once after the first iteration) is just a gradient tensor again -- the reducer copies it,
+# re-points .grad, and the next adoption picks the new view up.  A parameter whose .grad is still set at backward time (gradient accumulation
+# under no_sync(), engine.py:61-66 with update_freq > 1) is never given a destination: autograd adds in place there.
+grad_slots_enabled = False    # bench.py / Masking.add_module turn it on for a DDP wrapper with gradient_as_bucket_view=True
+_grad_slots = {}              # id(parameter) -> (weakref(parameter), destination tensor)
+grad_slot_hits = 0            # destinations handed to the runner so far (tests / bench.py's config line)
+
+
+def adopt_grad_slots(params):
+    """Remember every parameter's current .grad tensor as the destination of its next gradient (see above).  Cheap when nothing changed
+    (one data_ptr comparison per parameter); entries of dead parameters are dropped."""
+    import weakref
+    for p in params:
+        g = p.grad
+        e = _grad_slots.get(id(p))
+        if e is not None and e[0]() is not p:
+            e = None
+            del _grad_slots[id(p)]
+        if g is None or g.dtype != torch.float32 or not g.is_contiguous() or g.shape != p.shape:
+            continue
+        if e is None or e[1].data_ptr() != g.data_ptr():
+            _grad_slots[id(p)] = (weakref.ref(p), g)
+
+
+def drop_grad_slots():
+    _grad_slots.clear()
+
+
+def enable_grad_slots_for(module):
+    """Turn the destinations on when `module` is a DistributedDataParallel wrapper whose gradients are bucket views (a no-op -- and False --
+    for anything else: with main.py:374-376's constructor defaults the reducer copies out of .grad whatever it points to)."""
+    global grad_slots_enabled
+    ddp = getattr(torch.nn.parallel, "DistributedDataParallel", None)
+    if ddp is not None and isinstance(module, ddp) and bool(getattr(module, "gradient_as_bucket_view", False)) \
+            and os.environ.get("SLAK_GRAD_SLOTS", "1") != "0":
+        grad_slots_enabled = True
+        return True
+    return False
+
+
+def _grad_destinations(params):
+    """The runner's `grad_dst` list for a block's sixteen parameters: the adopted destination where there is one and .grad is unset."""
+    global grad_slot_hits
+    if not grad_slots_enabled or not _grad_slots:
+        return []
+    out = []
+    for p in params:
+        e = _grad_slots.get(id(p))
+        out.append(e[1] if (e is not None and p.grad is None and e[0]() is p) else None)
+    grad_slot_hits += sum(o is not None for o in out)
+    return out
+
+
 class _BlockFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, x_lowp, wv, wh, ws, g1, b1, g2, b2, g3, b3, lnw, lnb, w1, bb1, w2, bb2, gamma, sample_scale, cfg):
@@ -1318,6 +1380,7 @@ class _BlockFn(torch.autograd.Function):
                 ctx.save_for_backward(x16, wv, wh, ws, yv, yh, ys, g1, g2, g3, bnstats, s, lnw, mean, rstd, t, w1b, y1m, a, w2b, z, gamma, sample_scale, *wts)
                 ctx.misc = (True, group, float(x.shape[0] * x.shape[2] * x.shape[3]), count_dev, x.dtype, x_lowp is not None)
                 ctx.runner = True
+                ctx.params = (wv, wh, ws, g1, b1, g2, b2, g3, b3, lnw, lnb, w1, bb1, w2, bb2, gamma)
                 ctx.set_materialize_grads(False)
                 return (out, out16) if emit else out
         x16 = x_lowp if x_lowp is not None else x.to(torch.bfloat16)
@@ -1347,10 +1410,10 @@ class _BlockFn(torch.autograd.Function):
             w1p = None                                                # stage 1: W1^T in fragment order for the launch that also produces dt
             if tuple(w1b.shape) == (384, 96) and w1b.dtype == torch.bfloat16 and _lib.lib().slak_linear_nt_gelu_bwd_dt_supported(t.numel() // 96, 384, 96):
                 w1p = w1_fragments(w1t if w1t is not None else w1b.t().contiguous())
-            (dx, dxl, dwv, dwh, dws, dgam, dbet, dlnw, dlnb, dw1, db1, dw2, dzc, dgamma) = _runner_mod.block_backward(
+            res = _runner_mod.block_backward(
                 x16, wv, wh, ws, yv, yh, ys, [g1, g2, g3], bnstats, s, lnw, mean, rstd, t, w1b, y1m, a, w2b, z, gamma, sample_scale, dout, dout16,
-                xdtype == torch.bfloat16, had_lowp, count_dev, exchange, _runner_trace, w1t, w2t, w1p)
-            return (dx, dxl, dwv, dwh, dws, dgam[0], dbet[0], dgam[1], dbet[1], dgam[2], dbet[2], dlnw, dlnb, dw1, db1, dw2, dzc, dgamma, None, None)
+                xdtype == torch.bfloat16, had_lowp, count_dev, exchange, _runner_trace, w1t, w2t, w1p, _grad_destinations(ctx.params))
+            return (*res, None, None)                                 # dx, dx_lowp, then the sixteen parameter gradients in forward()'s order
         saved = (t, w1b, y1m, a, w2b)
         dshortcut, dz, dgamma, dzc = _scale_residual_bwd(z, gamma, sample_scale, xdtype, dout, dout16)
         dt, dy1, db1 = _mlp_bwd_data(saved, dz, (w1t, w2t) if w1t is not None else None)

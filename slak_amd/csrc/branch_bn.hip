@@ -161,6 +161,8 @@ struct Bn3Params {
     const float* gamma[3]; const float* beta[3];
     float* running_mean[3]; float* running_var[3];
 };
+struct Bn3Grads { float* dgamma[3]; float* dbeta[3]; };         // the six parameter gradients of a block's branch BatchNorms, one pointer each
+
 __device__ __forceinline__ void bn3_finalize_channel(const double (&sd)[6], double count, int c, const Bn3Params& bp, float* __restrict__ coef,
                                                      float* __restrict__ stats, float eps, float momentum, int update_running) {
     float shift = 0.f;
@@ -236,7 +238,7 @@ __global__ __launch_bounds__(BN_THREADS) void bn3_apply_fwd(const uint16_t* __re
 // then all-reduces, exactly like SyncBatchNorm: the caller passes local sums for the gradients and global sums for the coefficients).
 // bcoef[c][b][0..2] = A, B, C0 with dy_b = A*dout + B*y_b + C0.
 __global__ void bn3_finalize_bwd(const float* __restrict__ gsums, const float* __restrict__ lsums, const float* __restrict__ stats,
-                                 Bn3Params bp, float* __restrict__ bcoef, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                 Bn3Params bp, float* __restrict__ bcoef, Bn3Grads out,
                                  int C, float count, const double* __restrict__ count_dev) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
@@ -251,8 +253,8 @@ __global__ void bn3_finalize_bwd(const float* __restrict__ gsums, const float* _
         bcoef[(c * 3 + b) * 3 + 0] = A;
         bcoef[(c * 3 + b) * 3 + 1] = B;
         bcoef[(c * 3 + b) * 3 + 2] = -A * gd / count - B * mean;
-        dgamma[b * C + c] = inv * lsums[c * 4 + 1 + b];
-        dbeta[b * C + c] = lsums[c * 4];
+        out.dgamma[b][c] = inv * lsums[c * 4 + 1 + b];
+        out.dbeta[b][c] = lsums[c * 4];
     }
 }
 
@@ -320,7 +322,7 @@ __global__ __launch_bounds__(64) void bn3_local_stats(const Bn3Pre pre, const ui
     }
 }
 __global__ __launch_bounds__(64) void bn3_colreduce_finalize_bwd(const float* __restrict__ rows, int S, const float* __restrict__ stats, Bn3Params bp,
-                                                               float* __restrict__ bcoef, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                               float* __restrict__ bcoef, Bn3Grads out,
                                                                int C, float count) {
     const int c = blockIdx.x, lane = threadIdx.x;
     float s[4] = {0.f, 0.f, 0.f, 0.f};
@@ -342,8 +344,8 @@ __global__ __launch_bounds__(64) void bn3_colreduce_finalize_bwd(const float* __
         bcoef[(c * 3 + b) * 3 + 0] = A;
         bcoef[(c * 3 + b) * 3 + 1] = B;
         bcoef[(c * 3 + b) * 3 + 2] = -A * gd / count - B * mean;
-        dgamma[b * C + c] = dgam;
-        dbeta[b * C + c] = gd;
+        out.dgamma[b][c] = dgam;
+        out.dbeta[b][c] = gd;
     }
 }
 
@@ -499,11 +501,13 @@ int slak_bn3_backward_sums(const void* dout, const void* y1, const void* y2, con
     return SLAK_OK;
 }
 
-/* Single-process backward: three launches. */
-int slak_bn3_backward_local(const void* dout, const void* y1, const void* y2, const void* y3, const float* stats, const float* const* gamma,
-                            float* bcoef, float* dgamma, float* dbeta, void* dy1, void* dy2, void* dy3, int N, int C, int P,
-                            void* workspace, size_t workspace_bytes, void* stream) {
-    if (!dout || !y1 || !y2 || !y3 || !stats || !gamma || !bcoef || !dgamma || !dbeta || !dy1 || !dy2 || !dy3) return SLAK_ERR_INVALID_ARG;
+/* Single-process backward: three launches.  dgamma3 / dbeta3: HOST arrays of three device pointers ([C] floats each). */
+int slak_bn3_backward_local_to(const void* dout, const void* y1, const void* y2, const void* y3, const float* stats, const float* const* gamma,
+                               float* bcoef, float* const* dgamma3, float* const* dbeta3, void* dy1, void* dy2, void* dy3, int N, int C, int P,
+                               void* workspace, size_t workspace_bytes, void* stream) {
+    if (!dout || !y1 || !y2 || !y3 || !stats || !gamma || !bcoef || !dgamma3 || !dbeta3 || !dy1 || !dy2 || !dy3) return SLAK_ERR_INVALID_ARG;
+    Bn3Grads go;
+    for (int b = 0; b < 3; ++b) { go.dgamma[b] = dgamma3[b]; go.dbeta[b] = dbeta3[b]; if (!go.dgamma[b] || !go.dbeta[b]) return SLAK_ERR_INVALID_ARG; }
     int rc = bn_args_ok(N, C, P); if (rc) return rc;
     if (!workspace || workspace_bytes < slak_bn3_workspace_bytes(N, C)) return SLAK_ERR_WORKSPACE;
     Bn3Params bp;
@@ -512,7 +516,7 @@ int slak_bn3_backward_local(const void* dout, const void* y1, const void* y2, co
     int S, per; bn_slices(N, C, &S, &per);
     hipLaunchKernelGGL(bn3_chansums<true>, dim3((unsigned)((C * S + BN_THREADS / 64 - 1) / (BN_THREADS / 64))), dim3(BN_THREADS), 0, (hipStream_t)stream,
                        (const uint16_t*)dout, (const uint16_t*)y1, (const uint16_t*)y2, (const uint16_t*)y3, stats, rows, N, C, P, S, per);
-    hipLaunchKernelGGL(bn3_colreduce_finalize_bwd, dim3(C), dim3(64), 0, (hipStream_t)stream, (const float*)rows, S, stats, bp, bcoef, dgamma, dbeta, C,
+    hipLaunchKernelGGL(bn3_colreduce_finalize_bwd, dim3(C), dim3(64), 0, (hipStream_t)stream, (const float*)rows, S, stats, bp, bcoef, go, C,
                        (float)((double)N * P));
     const int R = N * C;
     hipLaunchKernelGGL(bn3_apply_bwd, dim3(bn_grid(R, P)), dim3(BN_THREADS), 0, (hipStream_t)stream,
@@ -522,23 +526,44 @@ int slak_bn3_backward_local(const void* dout, const void* y1, const void* y2, co
     return SLAK_OK;
 }
 
-/* dgamma, dbeta: [3][C] (local gradients); bcoef scratch [C][9]; dy1..3 outputs */
-int slak_bn3_backward_apply(const void* dout, const void* y1, const void* y2, const void* y3, const float* global_sums,
-                            const float* local_sums, double count, const double* count_dev, const float* stats, const float* const* gamma,
-                            float* bcoef, float* dgamma, float* dbeta, void* dy1, void* dy2, void* dy3, int N, int C, int P, void* stream) {
-    if (!dout || !y1 || !y2 || !y3 || !global_sums || !local_sums || !stats || !gamma || !bcoef || !dgamma || !dbeta || !dy1 || !dy2 || !dy3)
+int slak_bn3_backward_local(const void* dout, const void* y1, const void* y2, const void* y3, const float* stats, const float* const* gamma,
+                            float* bcoef, float* dgamma, float* dbeta, void* dy1, void* dy2, void* dy3, int N, int C, int P,
+                            void* workspace, size_t workspace_bytes, void* stream) {
+    if (!dgamma || !dbeta || C <= 0) return SLAK_ERR_INVALID_ARG;
+    float* const g3[3] = {dgamma, dgamma + C, dgamma + 2 * (size_t)C};
+    float* const b3[3] = {dbeta, dbeta + C, dbeta + 2 * (size_t)C};
+    return slak_bn3_backward_local_to(dout, y1, y2, y3, stats, gamma, bcoef, g3, b3, dy1, dy2, dy3, N, C, P, workspace, workspace_bytes, stream);
+}
+
+/* dgamma3, dbeta3: HOST arrays of three device pointers, [C] floats each (local gradients); bcoef scratch [C][9]; dy1..3 outputs */
+int slak_bn3_backward_apply_to(const void* dout, const void* y1, const void* y2, const void* y3, const float* global_sums,
+                               const float* local_sums, double count, const double* count_dev, const float* stats, const float* const* gamma,
+                               float* bcoef, float* const* dgamma3, float* const* dbeta3, void* dy1, void* dy2, void* dy3, int N, int C, int P, void* stream) {
+    if (!dout || !y1 || !y2 || !y3 || !global_sums || !local_sums || !stats || !gamma || !bcoef || !dgamma3 || !dbeta3 || !dy1 || !dy2 || !dy3)
         return SLAK_ERR_INVALID_ARG;
+    Bn3Grads go;
+    for (int b = 0; b < 3; ++b) { go.dgamma[b] = dgamma3[b]; go.dbeta[b] = dbeta3[b]; if (!go.dgamma[b] || !go.dbeta[b]) return SLAK_ERR_INVALID_ARG; }
     int rc = bn_args_ok(N, C, P); if (rc) return rc;
     Bn3Params bp;
     for (int b = 0; b < 3; ++b) { bp.gamma[b] = gamma[b]; bp.beta[b] = nullptr; bp.running_mean[b] = nullptr; bp.running_var[b] = nullptr; }
     hipLaunchKernelGGL(bn3_finalize_bwd, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, global_sums, local_sums, stats, bp,
-                       bcoef, dgamma, dbeta, C, (float)count, count_dev);
+                       bcoef, go, C, (float)count, count_dev);
     const int R = N * C;
     hipLaunchKernelGGL(bn3_apply_bwd, dim3(bn_grid(R, P)), dim3(BN_THREADS), 0, (hipStream_t)stream,
                        (const uint16_t*)dout, (const uint16_t*)y1, (const uint16_t*)y2, (const uint16_t*)y3, (const float*)bcoef,
                        (uint16_t*)dy1, (uint16_t*)dy2, (uint16_t*)dy3, R, C, P, bn_lpr(P));
     SLAK_LAUNCH_CHECK();
     return SLAK_OK;
+}
+
+/* dgamma, dbeta: [3][C] */
+int slak_bn3_backward_apply(const void* dout, const void* y1, const void* y2, const void* y3, const float* global_sums,
+                            const float* local_sums, double count, const double* count_dev, const float* stats, const float* const* gamma,
+                            float* bcoef, float* dgamma, float* dbeta, void* dy1, void* dy2, void* dy3, int N, int C, int P, void* stream) {
+    if (!dgamma || !dbeta || C <= 0) return SLAK_ERR_INVALID_ARG;
+    float* const g3[3] = {dgamma, dgamma + C, dgamma + 2 * (size_t)C};
+    float* const b3[3] = {dbeta, dbeta + C, dbeta + 2 * (size_t)C};
+    return slak_bn3_backward_apply_to(dout, y1, y2, y3, global_sums, local_sums, count, count_dev, stats, gamma, bcoef, g3, b3, dy1, dy2, dy3, N, C, P, stream);
 }
 
 }  // extern "C"

@@ -219,9 +219,30 @@ std::vector<Tensor> block_forward(const Tensor& x, const c10::optional<Tensor>& 
     return {out, out16, x16, yv, yh, ys, bnstats, sum, t, mean, rstd, y1m, a, z, count_dev};
 }
 
-Tensor wgrad(const Tensor& dy, const Tensor& x, int M, int N1, int N2, bool covered, const Scratch& ws, void* st) {
+// A parameter gradient's destination: the caller's tensor when it gave one that the kernels can write (float32, contiguous, on the device,
+// the parameter's element count, 16-byte aligned: the reduction launches store float4) -- else a fresh one.  A caller's tensor is returned as a
+// NEW tensor object on the same storage (detach()): autograd's AccumulateGrad then takes it over as .grad without a copy (it deep-copies a
+// gradient somebody else still holds), and DistributedDataParallel(gradient_as_bucket_view=True) finds .grad aliasing its bucket view and
+// skips its per-parameter copy launch (reducer.cpp mark_variable_ready_dense).
+struct GradDst {
+    const std::vector<c10::optional<Tensor>>* v;
+    int dev;
+    bool usable(int k, int64_t numel) const {
+        if (!v || (size_t)k >= v->size() || !(*v)[k].has_value() || !(*v)[k]->defined()) return false;
+        const Tensor& t = *(*v)[k];
+        return t.is_cuda() && t.get_device() == dev && t.scalar_type() == at::kFloat && t.is_contiguous() && t.numel() == numel &&
+               ((uintptr_t)t.data_ptr() & 15) == 0;
+    }
+    Tensor take(int k, at::IntArrayRef shape, const at::TensorOptions& f32) const {
+        int64_t n = 1; for (auto d : shape) n *= d;
+        return usable(k, n) ? (*v)[k]->detach().view(shape) : at::empty(shape, f32);
+    }
+};
+
+Tensor wgrad(const Tensor& dy, const Tensor& x, int M, int N1, int N2, bool covered, const Scratch& ws, void* st, const GradDst& gd, int slot) {
+    const auto f32 = dy.options().dtype(at::kFloat);
     if (covered) {
-        Tensor d = at::empty({N1, N2}, dy.options().dtype(at::kFloat));
+        Tensor d = gd.take(slot, {N1, N2}, f32);
         check_rc(slak_linear_wgrad(dy.data_ptr(), x.data_ptr(), fpm(d), M, N1, N2, ws.p, ws.n, st), "slak_linear_wgrad");
         return d;
     }
@@ -230,11 +251,20 @@ Tensor wgrad(const Tensor& dy, const Tensor& x, int M, int N1, int N2, bool cove
     // workgroups: measured 0.86 ms per call on stage 1)
     int S = std::max(1, M / 6272);
     while (S > 1 && M % S) --S;
-    if (S > 1) return at::bmm(dy.view({S, M / S, N1}).transpose(1, 2), x.view({S, M / S, N2})).sum(at::IntArrayRef{0}, false, at::kFloat);
+    if (S > 1) {
+        Tensor parts = at::bmm(dy.view({S, M / S, N1}).transpose(1, 2), x.view({S, M / S, N2}));
+        if (gd.usable(slot, (int64_t)N1 * N2)) {                     // the fp32 sum of the splits straight into the caller's tensor (same additions)
+            Tensor d = gd.take(slot, {N1, N2}, f32);
+            at::sum_out(d, parts, at::IntArrayRef{0}, false, at::kFloat);
+            return d;
+        }
+        return parts.sum(at::IntArrayRef{0}, false, at::kFloat);
+    }
     return at::mm(dy.t(), x).to(at::kFloat);
 }
 
-// -> [dx, dx_lowp | undefined, dwv, dwh, dws, dgamma_bn [3][C], dbeta_bn [3][C], dlnw, dlnb, dw1, db1, dw2, db2, dgamma]
+// -> [dx, dx_lowp | undefined, dwv, dwh, dws, dg1, db1, dg2, db2, dg3, db3 (branch BatchNorms), dlnw, dlnb, dw1, db1, dw2, db2, dgamma]: the sixteen parameter
+// gradients in the order of _BlockFn.forward's parameters; `grad_dst` (empty, or sixteen entries in that order, None allowed): see GradDst
 std::vector<Tensor> block_backward(const Tensor& x16, const Tensor& wv, const Tensor& wh, const Tensor& wsm, const Tensor& yv, const Tensor& yh,
                                    const Tensor& ys, const std::vector<Tensor>& bn_gamma, const Tensor& bnstats, const Tensor& sum, const Tensor& lnw,
                                    const Tensor& mean, const Tensor& rstd, const Tensor& t, const Tensor& w1b, const Tensor& y1m, const Tensor& a,
@@ -242,8 +272,12 @@ std::vector<Tensor> block_backward(const Tensor& x16, const Tensor& wv, const Te
                                    const c10::optional<Tensor>& dout_opt, const c10::optional<Tensor>& dout16_opt, bool shortcut_bf16, bool had_lowp,
                                    const c10::optional<Tensor>& count_dev, const pybind11::object& exchange, const pybind11::object& trace,
                                    const c10::optional<Tensor>& w1t_opt, const c10::optional<Tensor>& w2t_opt /* cached transposed bf16 weights, or None */,
-                                   const c10::optional<Tensor>& w1p_opt /* W1^T in fragment-major order (slak_linear_nt_gelu_bwd_dt), or None */) {
+                                   const c10::optional<Tensor>& w1p_opt /* W1^T in fragment-major order (slak_linear_nt_gelu_bwd_dt), or None */,
+                                   const std::vector<c10::optional<Tensor>>& grad_dst) {
     const Shape s = shape_of(x16, wv, w1b);
+    TORCH_CHECK(grad_dst.empty() || grad_dst.size() == 16, "grad_dst: empty, or one entry (tensor or None) per parameter of the block");
+    const GradDst gd{grad_dst.empty() ? nullptr : &grad_dst, (int)x16.get_device()};
+    enum { G_WV, G_WH, G_WS, G_G1, G_B1, G_G2, G_B2, G_G3, G_B3, G_LNW, G_LNB, G_W1, G_BB1, G_W2, G_BB2, G_GAMMA };
     const Plan& pl = plan_of(s);
     TORCH_CHECK(pl.ok, "block_backward: the shape has no one-launch path (block_forward would have declined it)");
     c10::hip::HIPGuard guard(x16.get_device());
@@ -261,7 +295,7 @@ std::vector<Tensor> block_backward(const Tensor& x16, const Tensor& wv, const Te
     Tensor dout16 = (dout16_opt.has_value() && dout16_opt->defined()) ? dout16_opt->contiguous() : Tensor();
     if (dout16.defined() && dout16.scalar_type() != at::kBFloat16) dout16 = dout16.to(at::kBFloat16);
     Tensor dsum = dout16.defined() ? at::empty_like(dout) : Tensor();
-    Tensor dz = at::empty_like(z), dgamma = at::empty_like(gamma), dzc = at::empty_like(gamma);
+    Tensor dz = at::empty_like(z), dgamma = gd.take(G_GAMMA, {s.C}, f32), dzc = gd.take(G_BB2, {s.C}, f32);
     const bool has_scale = sample_scale.has_value() && sample_scale->defined();
     check_rc(slak_scale_residual_backward(fp(dout), dout16.defined() ? dout16.data_ptr() : nullptr, dsum.defined() ? fpm(dsum) : nullptr, z.data_ptr(),
                                           fp(gamma), has_scale ? fp(*sample_scale) : nullptr, dz.data_ptr(), fpm(dgamma), fpm(dzc), s.N, s.C, s.P,
@@ -272,7 +306,7 @@ std::vector<Tensor> block_backward(const Tensor& x16, const Tensor& wv, const Te
     Tensor dz2 = dz.view({s.M, s.C});
     const auto w2t_of = [&] { return (w2t_opt.has_value() && w2t_opt->defined()) ? *w2t_opt : w2b.t().contiguous(); };
     const auto w1t_of = [&] { return (w1t_opt.has_value() && w1t_opt->defined()) ? *w1t_opt : w1b.t().contiguous(); };
-    Tensor dact, dy1, dt_, db1 = at::empty({s.C4}, f32);
+    Tensor dact, dy1, dt_, db1 = gd.take(G_BB1, {s.C4}, f32);
     if (pl.gbwd && w1p_opt.has_value() && w1p_opt->defined() && slak_linear_nt_gelu_bwd_dt_supported(s.M, s.C4, s.C) == 1) {
         Tensor w2t = w2t_of();                                     // stage 1: the same with dt = dy1 W1 taken from the dy1 tiles while they are on chip
         dy1 = at::empty({s.M, s.C4}, x16.options());
@@ -305,12 +339,23 @@ std::vector<Tensor> block_backward(const Tensor& x16, const Tensor& wv, const Te
         check_rc(slak_linear_nt(dy1.data_ptr(), w1t.data_ptr(), nullptr, dt_.data_ptr(), nullptr, s.M, s.C, s.C4, st), "slak_linear_nt");
     } else dt_ = at::mm(dy1, w1b);
     // permute + LayerNorm
-    Tensor ds = at::empty_like(sum), dlnw = at::empty_like(lnw), dlnb = at::empty_like(lnw);
+    Tensor ds = at::empty_like(sum), dlnw = gd.take(G_LNW, {s.C}, f32), dlnb = gd.take(G_LNB, {s.C}, f32);
     check_rc(slak_ln_nchw_to_nhwc_backward(dt_.data_ptr(), sum.data_ptr(), fp(lnw), fp(mean), fp(rstd), ds.data_ptr(), fpm(dlnw), fpm(dlnb), s.N, s.C, s.P,
                                            region(2).p, region(2).n, st), "slak_ln_nchw_to_nhwc_backward");
     // SyncBatchNorm: the backward sums and their all-reduce go out FIRST (asynchronously); the weight gradients below do not depend on them
     const float* gam[3] = {fp(bn_gamma[0]), fp(bn_gamma[1]), fp(bn_gamma[2])};
-    Tensor bcoef = at::empty({s.C * 9}, f32), dgam = at::empty({3, s.C}, f32), dbet = at::empty({3, s.C}, f32);
+    Tensor bcoef = at::empty({s.C * 9}, f32);
+    Tensor dgb[6];                                                 // dg1, db1, dg2, db2, dg3, db3: the caller's tensors, or rows of one [6][C] allocation
+    {
+        Tensor rows;
+        for (int k = 0; k < 6; ++k) {
+            if (gd.usable(G_G1 + k, s.C)) { dgb[k] = gd.take(G_G1 + k, {s.C}, f32); continue; }
+            if (!rows.defined()) rows = at::empty({6, s.C}, f32);
+            dgb[k] = rows.select(0, k);
+        }
+    }
+    float* const dgam3[3] = {fpm(dgb[0]), fpm(dgb[2]), fpm(dgb[4])};
+    float* const dbet3[3] = {fpm(dgb[1]), fpm(dgb[3]), fpm(dgb[5])};
     Tensor d1 = at::empty_like(yv), d2 = at::empty_like(yv), d3 = at::empty_like(yv);
     Tensor lsums, gsums;
     pybind11::object work = pybind11::none();
@@ -328,24 +373,24 @@ std::vector<Tensor> block_backward(const Tensor& x16, const Tensor& wv, const Te
     Side& sd = side_of(x16.get_device());
     const bool forked = sd.ok && pl.wg1 && pl.wg2 && hipEventRecord(sd.fork, (hipStream_t)st) == hipSuccess && hipStreamWaitEvent(sd.st, sd.fork, 0) == hipSuccess;
     void* wst = forked ? (void*)sd.st : st;
-    Tensor dw1 = wgrad(dy1, t.view({s.M, s.C}), s.M, s.C4, s.C, pl.wg1, region(3), wst);
-    Tensor dw2 = wgrad(dz2, a.view({s.M, s.C4}), s.M, s.C, s.C4, pl.wg2, region(4), wst);
+    Tensor dw1 = wgrad(dy1, t.view({s.M, s.C}), s.M, s.C4, s.C, pl.wg1, region(3), wst, gd, G_W1);
+    Tensor dw2 = wgrad(dz2, a.view({s.M, s.C4}), s.M, s.C, s.C4, pl.wg2, region(4), wst, gd, G_W2);
     struct Join { Side* sd; void* st; bool on; ~Join() { if (on && hipEventRecord(sd->join, sd->st) == hipSuccess) (void)hipStreamWaitEvent((hipStream_t)st, sd->join, 0); } } join{&sd, st, forked};
     check_rc(deferred.end(), "slak_defer_reductions_end");         // one launch: dgamma, db2 | db1 | dlnw, dlnb | dW1 | dW2
     // branch BatchNorms
     if (exchange.is_none()) {
-    check_rc(slak_bn3_backward_local(ds.data_ptr(), yv.data_ptr(), yh.data_ptr(), ys.data_ptr(), fp(bnstats), gam, fpm(bcoef), fpm(dgam), fpm(dbet),
-                                     d1.data_ptr(), d2.data_ptr(), d3.data_ptr(), s.N, s.C, s.P, ws.p, ws.n, st), "slak_bn3_backward_local");
+    check_rc(slak_bn3_backward_local_to(ds.data_ptr(), yv.data_ptr(), yh.data_ptr(), ys.data_ptr(), fp(bnstats), gam, fpm(bcoef), dgam3, dbet3,
+                                        d1.data_ptr(), d2.data_ptr(), d3.data_ptr(), s.N, s.C, s.P, ws.p, ws.n, st), "slak_bn3_backward_local_to");
     } else {
         if (!work.is_none()) work.attr("wait")();                  // stream-side wait (RCCL) / host wait (gloo): the weight gradients are already queued
         const bool has_cd = count_dev.has_value() && count_dev->defined();
-        check_rc(slak_bn3_backward_apply(ds.data_ptr(), yv.data_ptr(), yh.data_ptr(), ys.data_ptr(), fp(gsums), fp(lsums), (double)s.N * (double)s.P,
-                                         has_cd ? (const double*)count_dev->data_ptr() : nullptr, fp(bnstats), gam, fpm(bcoef), fpm(dgam), fpm(dbet),
-                                         d1.data_ptr(), d2.data_ptr(), d3.data_ptr(), s.N, s.C, s.P, st), "slak_bn3_backward_apply");
+        check_rc(slak_bn3_backward_apply_to(ds.data_ptr(), yv.data_ptr(), yh.data_ptr(), ys.data_ptr(), fp(gsums), fp(lsums), (double)s.N * (double)s.P,
+                                            has_cd ? (const double*)count_dev->data_ptr() : nullptr, fp(bnstats), gam, fpm(bcoef), dgam3, dbet3,
+                                            d1.data_ptr(), d2.data_ptr(), d3.data_ptr(), s.N, s.C, s.P, st), "slak_bn3_backward_apply_to");
     }
     // three branch convs: the summed data gradient, the three weight gradients
     Tensor dx16 = at::empty_like(x16);
-    Tensor dwv = at::empty_like(wv), dwh = at::empty_like(wh), dws = at::empty_like(wsm);
+    Tensor dwv = gd.take(G_WV, wv.sizes(), f32), dwh = gd.take(G_WH, wh.sizes(), f32), dws = gd.take(G_WS, wsm.sizes(), f32);
     if (pl.bwd1) {                                                 // 14 x 14 class: data gradient and the three weight gradients in one launch
         check_rc(slak_dwconv2d_tri_backward(d1.data_ptr(), d2.data_ptr(), d3.data_ptr(), x16.data_ptr(), fp(wv), fp(wh), fp(wsm), dx16.data_ptr(),
                                             fpm(dwv), fpm(dwh), fpm(dws), dt, s.N, s.C, s.H, s.W, s.K, ws.p, ws.n, st), "slak_dwconv2d_tri_backward");
@@ -356,7 +401,7 @@ std::vector<Tensor> block_backward(const Tensor& x16, const Tensor& wv, const Te
                                                s.N, s.C, s.H, s.W, s.K, ws.p, ws.n, st), "slak_dwconv2d_tri_backward_filter");
     }
     Tensor dx = had_lowp ? dshortcut : (dshortcut + dx16);
-    return {dx, had_lowp ? dx16 : Tensor(), dwv, dwh, dws, dgam, dbet, dlnw, dlnb, dw1, db1, dw2, dzc, dgamma};
+    return {dx, had_lowp ? dx16 : Tensor(), dwv, dwh, dws, dgb[0], dgb[1], dgb[2], dgb[3], dgb[4], dgb[5], dlnw, dlnb, dw1, db1, dw2, dzc, dgamma};
 }
 
 }  // namespace

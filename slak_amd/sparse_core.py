@@ -148,6 +148,8 @@ class Masking(object):
     def add_module(self, module):
         self.modules.append(module)
         self.module = module
+        from . import block_ops
+        block_ops.enable_grad_slots_for(module)                      # main.py:425 passes the DDP wrapper: bucket-view gradients are written in place
         for name, tensor in module.named_parameters():
             if tensor.dim() in (2, 4):
                 if self.args.only_L and 'large_kernel.LoRA' not in name:

@@ -35,7 +35,7 @@ def test_library_exports_every_declared_symbol(built_lib):
     from slak_amd import _lib
     assert sorted(_lib.SIGNATURES) == syms, "ctypes binding and header disagree"
     lib = _lib.lib()
-    assert lib.slak_version() == 7                          # SLAK_ABI_VERSION of include/slak_hip.h
+    assert lib.slak_version() == 8                          # SLAK_ABI_VERSION of include/slak_hip.h
     assert lib.slak_status_string(0) == b"ok" and lib.slak_status_string(3) == b"workspace missing or too small"
     # pure host-side argument validation (no GPU needed): status codes instead of exit()
     assert lib.slak_dwconv2d_forward(None, 0, None, 0, None, 0, 1, 1, 1, 1, 3, 3, None, 0, None) == 1

@@ -191,3 +191,96 @@ def test_rank_divergence_is_detected_and_healed_by_default():
     r0, r1 = _run(_rank_divergence_heals)
     for r in (r0, r1):
         assert r["first"] == 0 and r["resyncs"] == 1 and r["healed"] and r["raised"]
+
+
+def _bucket_view_grads(rank, world):
+    """The mechanism of block_ops.adopt_grad_slots / _grad_destinations on torch's own reducer (round 6): an autograd node that writes a parameter
+    gradient INTO the tensor a previous backward left in .grad (a DDP bucket view) and returns a new tensor object on that storage.  Pins what the
+    C++ block runner relies on: AccumulateGrad installs the returned tensor without a copy, DistributedDataParallel(gradient_as_bucket_view=True)
+    finds it aliasing its bucket view and leaves it alone, the averaged gradients and the weights equal the ordinary path's bit for bit, a
+    parameter whose .grad is still set (gradient accumulation) gets no destination, and a bucket rebuild heals by itself."""
+    from torch.distributed.algorithms.ddp_comm_hooks import default_hooks
+    from slak_amd import block_ops
+
+    class Scale(torch.autograd.Function):                             # y = x * w (w: [F]); stands in for a block: dw goes where the runner would put it
+        wrote_in_place = 0
+
+        @staticmethod
+        def forward(ctx, x, w):
+            ctx.save_for_backward(x, w)
+            ctx.param = w
+            return x * w
+
+        @staticmethod
+        def backward(ctx, dy):
+            x, w = ctx.saved_tensors
+            dst = block_ops._grad_destinations((ctx.param,))
+            dw = (dy * x).sum(0)
+            if dst and dst[0] is not None:
+                dst[0].copy_(dw)                                        # "the kernel writes into the destination"
+                Scale.wrote_in_place += 1
+                dw = dst[0].detach()                                    # a NEW tensor object on the same storage (GradDst::take)
+            return dy * w, dw
+
+    class Net(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.w1 = torch.nn.Parameter(torch.linspace(0.5, 1.5, 12))
+            self.lin = torch.nn.Linear(12, 12)
+            self.w2 = torch.nn.Parameter(torch.linspace(1.0, 2.0, 12))
+
+        def forward(self, x):
+            return Scale.apply(self.lin(Scale.apply(x, self.w1)), self.w2)
+
+    def train(slots, accumulate=False):
+        torch.manual_seed(0)
+        net = Net()
+        ddp = torch.nn.parallel.DistributedDataParallel(net, gradient_as_bucket_view=True, broadcast_buffers=False)
+        ddp.register_comm_hook(None, default_hooks.allreduce_hook)
+        block_ops.drop_grad_slots()
+        block_ops.grad_slots_enabled = slots
+        Scale.wrote_in_place = 0
+        opt = torch.optim.SGD(ddp.parameters(), lr=0.05)
+        g = torch.Generator().manual_seed(7 + rank)
+        aliased = []
+        for it in range(6):
+            x = torch.randn(5, 12, generator=g)
+            if accumulate and it % 2 == 0:
+                with ddp.no_sync():
+                    ddp(x).square().mean().backward()                  # leaves .grad set: the next backward must ACCUMULATE, not overwrite
+                x = torch.randn(5, 12, generator=g)
+            before = Scale.wrote_in_place
+            ddp(x).square().mean().backward()
+            if slots:
+                e = [block_ops._grad_slots.get(id(p)) for p in (net.w1, net.w2)]
+                aliased.append((Scale.wrote_in_place - before,
+                                all(q is not None and p.grad.data_ptr() == q[1].data_ptr() for p, q in zip((net.w1, net.w2), e))))
+                block_ops.adopt_grad_slots(list(ddp.parameters()))      # what MaskedAdamW.step does
+            opt.step()
+            opt.zero_grad(set_to_none=True)
+        block_ops.grad_slots_enabled = False
+        block_ops.drop_grad_slots()
+        return [p.detach().clone().numpy() for p in net.parameters()], aliased
+
+    ref, _ = train(False)
+    got, aliased = train(True)
+    ref_acc, _ = train(False, accumulate=True)
+    got_acc, aliased_acc = train(True, accumulate=True)
+    return dict(ref=ref, got=got, aliased=aliased, ref_acc=ref_acc, got_acc=got_acc, aliased_acc=aliased_acc)
+
+
+def test_gradients_written_into_ddp_bucket_views_match_the_copy_path():
+    r0, r1 = _run(_bucket_view_grads)
+    for r in (r0, r1):
+        for a, b in zip(r["ref"], r["got"]):
+            np.testing.assert_array_equal(a, b)                      # bit-identical weights after six steps
+        for a, b in zip(r["ref_acc"], r["got_acc"]):
+            np.testing.assert_array_equal(a, b)
+        # iteration 0: nothing adopted yet; iteration 1: the views of the first bucket layout (DDP rebuilds its buckets once, so the reducer may
+        # copy once more); from iteration 2 on both gradients are written in place and .grad IS the destination after the backward
+        assert r["aliased"][0][0] == 0
+        assert all(n == 2 and same for n, same in r["aliased"][2:]), r["aliased"]
+        # gradient accumulation: the synchronising backward of an accumulating pair finds .grad set -> no destination handed out there
+        assert all(n == 0 for n, _ in r["aliased_acc"][0::2]), r["aliased_acc"]
+    for a, b in zip(r0["got"], r1["got"]):
+        np.testing.assert_array_equal(a, b)                          # the ranks agree

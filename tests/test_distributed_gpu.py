@@ -249,3 +249,100 @@ def test_bench_force_dist_executes_the_rccl_path_on_one_gpu():
     assert c["mask_sync"]["ranks_agree"] is True and d["value"] > 0 and d["n_gpus"] == 1
     import math
     assert math.isfinite(c["final_loss"])
+
+
+def _slot_worker(rank, world, port, out):
+    """Round 6: the blocks' parameter gradients written INTO DistributedDataParallel's bucket views (block_ops.adopt_grad_slots + the runner's
+    grad_dst) against the reducer's per-parameter copy, on the N > 1 bench configuration in miniature, two ranks."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda:0")
+    import types, contextlib, io
+    from torch.distributed.algorithms.ddp_comm_hooks import default_hooks
+    from slak_amd import block_ops as B
+    import slak_amd.slak_model as M
+    from slak_amd.sparse_core import CosineDecay, Masking
+    from slak_amd.optim_factory import MaskedAdamW
+    M.use_sync_bn = True
+    M.Block.fused_tail = True; M.ReparamLargeKernelConv.fused_bn = True; M.ReparamLargeKernelConv.fused_tri = True; M.Block.fused_block = True
+    M.LayerNorm.fused_cf = True
+    B.cache_lowp_weights = True
+    res = {"runner": B._runner() is not None}
+
+    def train(slots, accumulate):
+        B.drop_grad_slots(); B.grad_slots_enabled = False; B.grad_slot_hits = 0
+        torch.manual_seed(7)
+        net = M.SLaK(in_chans=3, num_classes=10, depths=[2, 2, 2, 1], dims=[16, 32, 64, 128], drop_path_rate=0.0,
+                     kernel_size=[13, 13, 9, 7, 5], Decom=True, bn=True, lowp_dwconv=True).to(dev)
+        ddp = nn.parallel.DistributedDataParallel(net, device_ids=[0], broadcast_buffers=False, gradient_as_bucket_view=True)
+        ddp.register_comm_hook(None, default_hooks.allreduce_hook)
+        opt = MaskedAdamW(ddp.parameters(), lr=1e-3)
+        margs = types.SimpleNamespace(device=str(dev), fix=False, update_frequency=3, only_L=False, sparse_init="uniform", sparsity=0.4, distributed=True)
+        with contextlib.redirect_stdout(io.StringIO()):
+            mask = Masking(opt, None, CosineDecay(0.3, 100), prune_rate=0.3, prune_mode="magnitude", growth_mode="gradient",
+                           redistribution_mode="none", args=margs)
+            mask.add_module(ddp)                                      # turns the destinations on for a bucket-view DDP wrapper ...
+        assert B.grad_slots_enabled
+        B.grad_slots_enabled = slots                                  # ... the A/B of this test
+        g = torch.Generator(device=dev).manual_seed(100 + rank)
+        in_place = []
+        for it in range(6):
+            xs = torch.randn(4, 3, 64, 64, device=dev, generator=g); ys = torch.randint(0, 10, (4,), device=dev, generator=g)
+            if accumulate and it % 2 == 1:                            # engine.py:61-66 with update_freq 2: the first half-step leaves .grad set
+                with ddp.no_sync(), torch.autocast("cuda", dtype=torch.bfloat16):
+                    nn.functional.cross_entropy(ddp(xs), ys).backward()
+            h0 = B.grad_slot_hits
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                loss = nn.functional.cross_entropy(ddp(xs), ys)
+            loss.backward()
+            blk = net.stages[1][0]
+            ps = [blk.large_kernel.LoRA1.conv.weight, blk.large_kernel.LoRA2.bn.bias, blk.pwconv1.weight, blk.pwconv2.bias, blk.gamma, blk.norm.weight]
+            same = all((id(p) in B._grad_slots) and p.grad.data_ptr() == B._grad_slots[id(p)][1].data_ptr() for p in ps)
+            in_place.append((B.grad_slot_hits - h0, same))
+            with contextlib.redirect_stdout(io.StringIO()):
+                mask.step()
+            opt.zero_grad(set_to_none=True)
+        state = torch.cat([p.detach().float().flatten() for p in net.parameters()] + [m.flatten() for m in mask.masks.values()])
+        B.grad_slots_enabled = False; B.drop_grad_slots()
+        return state, in_place, float(loss.item())
+
+    for acc in (False, True):
+        ref, _, l0 = train(False, acc)
+        got, in_place, l1 = train(True, acc)
+        key = "acc" if acc else "plain"
+        res[key + "_identical"] = bool(torch.equal(ref, got))
+        res[key + "_in_place"] = in_place
+        res[key + "_loss"] = (l0, l1)
+        other = [torch.empty_like(got) for _ in range(world)]
+        dist.all_gather(other, got)
+        res[key + "_ranks_identical"] = bool(torch.equal(other[0], other[1]))
+    M.LayerNorm.fused_cf = False; B.cache_lowp_weights = False
+    M.ReparamLargeKernelConv.fused_tri = False; M.Block.fused_block = False; M.Block.fused_tail = False; M.ReparamLargeKernelConv.fused_bn = False
+    if rank == 0:
+        torch.save(res, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_block_gradients_written_into_ddp_bucket_views(gpu, tmp_path):
+    """The C++ runner's weight-gradient / reduction launches write into the bucket views of DistributedDataParallel(gradient_as_bucket_view=True):
+    weights and masks after six DDP + Masking steps are BIT-IDENTICAL to the reducer's copy path, on both ranks, with and without gradient
+    accumulation (where the destinations must step aside), and from the third iteration on every block parameter's .grad IS its destination."""
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    out = str(tmp_path / "slots.pt")
+    mp.spawn(_slot_worker, args=(2, port, out), nprocs=2, join=True)
+    got = torch.load(out)
+    assert got["runner"], "the C++ block runner was not loaded in the workers"
+    for key in ("plain", "acc"):
+        assert got[key + "_identical"], (key, got[key + "_loss"])
+        assert got[key + "_ranks_identical"], key
+    n_block_params = 16 * 7                                           # depths [2, 2, 2, 1]
+    ip = got["plain_in_place"]
+    assert ip[0][0] == 0                                              # nothing adopted before the first optimizer step
+    assert all(n == n_block_params and same for n, same in ip[2:]), ip
+    ia = got["acc_in_place"]                                          # odd iterations: the synchronising backward follows a no_sync() one -> .grad set -> no destinations
+    assert all(n == 0 for n, _ in ia[1::2]), ia
+    assert all(n == n_block_params and same for n, same in ia[2::2]), ia
