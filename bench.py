@@ -464,7 +464,7 @@ def main():
     if a.force_dist and world == 1:
         os.environ.setdefault("MASTER_PORT", "29531")
         os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
-        os.environ["SLAK_FORCE_BN_EXCHANGE"] = "1"                  # block_ops._bn3_group: the SyncBatchNorm exchange at world size 1 too
+        os.environ.setdefault("SLAK_FORCE_BN_EXCHANGE", "1")        # block_ops._bn3_group: the SyncBatchNorm exchange at world size 1 too (0: DDP's part alone, for the cost split)
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -507,16 +507,10 @@ def main():
         # the (Sync)BatchNorm running statistics and counters, rank-identical by construction (the statistics are all-reduced), so the per-forward broadcast from
         # rank 0 (a collective + ~1.7 ms of host time per step) re-sends what every rank already holds; gradient_as_bucket_view=True -- gradients are views of
         # the all-reduce buckets instead of being copied into them (123 MB per step).
-        ddp_kw = {} if a.ddp_reference_flags else dict(broadcast_buffers=False, gradient_as_bucket_view=True)
-        model = nn.parallel.DistributedDataParallel(model, device_ids=[dev_index], find_unused_parameters=False, **ddp_kw)
-        if not a.ddp_reference_flags:
-            # DDP divides every gradient by the world size as it becomes ready: one tiny launch per parameter (312 per SLaK-T step, 1.4 ms of GPU time in
-            # profiles/r05_step_breakdown_forcedist.txt).  With the stock all-reduce hook the SAME division happens once per bucket on the bucket buffer
-            # (default_hooks.allreduce_hook: buffer.div_(world) then all_reduce -- element for element the arithmetic of the default path).
-            from torch.distributed.algorithms.ddp_comm_hooks import default_hooks
-            model.register_comm_hook(None, default_hooks.allreduce_hook)
-            # round 6: the blocks' weight-gradient launches write INTO the bucket views (block_ops.adopt_grad_slots): no per-parameter copy launch either
-            block_ops.enable_grad_slots_for(model)                   # SLAK_GRAD_SLOTS=0: the A/B switch
+        from slak_amd import ddp as slak_ddp
+        # reference flags: the constructor call as it is.  Default: + broadcast_buffers=False, gradient_as_bucket_view=True, one collective per bucket with the
+        # division inside (ncclAvg; the stock per-bucket hook on gloo), block gradients written into the bucket views (slak_amd/ddp.py)
+        model = slak_ddp.wrap(model, [dev_index], reference_flags=a.ddp_reference_flags)
     decay, no_decay = [], []
     for n, p in model.named_parameters():
         (no_decay if (p.dim() == 1 or n.endswith(".bias")) else decay).append(p)                                     # optim_factory.py no-decay rule
@@ -594,11 +588,13 @@ def main():
     # The K timed steps above enqueue faster than the GPU executes: after a few steps the runtime's launch queue is full and every further launch
     # WAITS for the GPU, so `host_s` tends to the GPU's step time whatever the host costs.  The host's own cost per step: three steps enqueued
     # on a drained queue (nothing to wait for), synchronised afterwards.
-    h0 = time.perf_counter()
+    host_free_s = float("inf")                                    # (three rounds, the quietest one: a drained-queue round of 3 steps is easily disturbed)
     for _ in range(3):
-        step()
-    host_free_s = (time.perf_counter() - h0) / 3
-    torch.cuda.synchronize()
+        h0 = time.perf_counter()
+        for _ in range(3):
+            step()
+        host_free_s = min(host_free_s, (time.perf_counter() - h0) / 3)
+        torch.cuda.synchronize()
     if a.host_profile:                                            # after the timed region: where the enqueue time goes
         import cProfile, pstats
         pr = cProfile.Profile()
@@ -652,8 +648,9 @@ def main():
                    "model_ema": bool(a.model_ema), "one_autograd_node_per_block": bool(M.Block.fused_block),
                    "block_runner": bool(M.Block.fused_block and block_ops._runner() is not None),   # the blocks' call sequences issued from C++ (round 5: under DDP / SyncBatchNorm too)
                    "forced_distributed": bool(a.force_dist and world == 1),
-                   "ddp": (None if not distributed else ("main.py:374-376 defaults" if a.ddp_reference_flags else "broadcast_buffers=False, gradient_as_bucket_view=True, allreduce_hook (division per bucket, not per parameter)"
-                                                          + (", block gradients written into the bucket views (no per-parameter copy)" if block_ops.grad_slots_enabled else ""))),
+                   "ddp": (None if not distributed else ("main.py:374-376 defaults" if a.ddp_reference_flags else "broadcast_buffers=False, gradient_as_bucket_view=True, " + getattr(model, "_slak_comm_hook", "?")
+                                                          + (", block gradients written into the bucket views (no per-parameter copy: %d destinations used)" % block_ops.grad_slot_hits if block_ops.grad_slots_enabled else ""))),
+                   "sync_bn_backward_exchange": (None if not distributed else ("own stream, overlapped with the pointwise weight gradients" if block_ops._bn_bwd_async else "on the compute stream")),
                    "sync_bn": True, "block_tail": "hip (ln_nchw_to_nhwc + scale_residual)" if M.Block.fused_tail else "pytorch ops",
                    "branch_bn": "hip (bn3: one stats pass + one apply pass)" if M.ReparamLargeKernelConv.fused_bn else "pytorch (Sync)BatchNorm x3 + adds",
                    "pointwise_gemm": "slak_linear_gemm / slak_linear_nt / slak_linear_wgrad (own kernels: pwconv1 + GELU, dz W2 + GELU', the stage-1 products, every weight gradient); hipBLASLt via torch for pwconv2 / dy1 W1 of stages 2-4 and the downsample products" + (", TunableOp solutions from slak_amd/tuning/tunableop_gfx950.csv" if TUNED_GEMMS else ""),

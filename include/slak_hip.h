@@ -329,6 +329,7 @@ int slak_linear_nt_gelu_bwd(const void* dz_bf16, const void* wt_bf16, const void
  * they are on chip -- the separate slak_linear_nt launch and its re-read of dy1 (308 MB per stage-1 block of SLaK-T) are gone.  w1p = W1^T [K][N]
  * bf16 (pwconv1's nn.Linear weight transposed) in fragment-major order: viewed (3, 32, 6, 4, 2, 8) and permuted (2, 3, 0, 4, 1, 5), contiguous.
  * dy1 and dbias: the bits of slak_linear_nt_gelu_bwd; dt: bf16 of the same fp32 sums added in another order.  Shapes and workspace as above. */
+int slak_pack_w1t_fragments(const void* w1t_bf16 /*[K][N] row-major*/, void* w1p_bf16 /*[K * N] out*/, int N, int K, void* stream);   /* the packer of w1p (N = 384, K = 96) */
 int slak_linear_nt_gelu_bwd_dt_supported(int M, int N, int K);
 int slak_linear_nt_gelu_bwd_dt(const void* dz_bf16, const void* wt_bf16, const void* y1_bf16, const void* w1p_bf16, void* dy1_bf16, void* dt_bf16,
                                float* dbias, int M, int N, int K, void* workspace, size_t workspace_bytes, void* stream);
@@ -434,6 +435,15 @@ int slak_bn3_backward_local(const void* dout, const void* y1, const void* y2, co
  * of an all-reduce bucket (main.py:374-376 builds the wrapper): with these the six BatchNorm parameter gradients of a block
  * (models/SLaK.py:38-47) are written where the reducer wants them and its per-parameter copy launch disappears.  The [3][C]
  * forms above are wrappers over these (same kernels, same bits). */
+/* Round 6, the SyncBatchNorm exchange with two launches fewer per block and step: _forward_sums_counted also writes this rank's element count
+ * N * P into local_sums[6C] (the exchange buffer is [6C + 1] doubles: the count travels with the sums, models/SLaK.py:24-28's SyncBatchNorm
+ * needs the global count); _backward_sums_dup writes the sums twice (local_sums stays for the local parameter gradients, sums_copy is what the
+ * all-reduce overwrites in place). */
+int slak_bn3_forward_sums_counted(const void* y1, const void* y2, const void* y3, double* local_sums /*[6C + 1]*/, int N, int C, int P,
+                                  void* workspace, size_t workspace_bytes, void* stream,
+                                  const float* const* pre_sums, const int* pre_rows, int pre_stride);
+int slak_bn3_backward_sums_dup(const void* dout, const void* y1, const void* y2, const void* y3, const float* stats, float* local_sums /*[C][4]*/,
+                               float* sums_copy /*[C][4]*/, int N, int C, int P, void* workspace, size_t workspace_bytes, void* stream);
 int slak_bn3_backward_apply_to(const void* dout, const void* y1, const void* y2, const void* y3, const float* global_sums,
                                const float* local_sums, double count, const double* count_dev, const float* stats, const float* const* gamma_host3,
                                float* bcoef /*[C][9]*/, float* const* dgamma3, float* const* dbeta3,

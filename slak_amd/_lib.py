@@ -90,6 +90,9 @@ SIGNATURES = {
     "slak_dwconv2d_tri_stats_rows": (_i, [_i, _i, _i, _i, _i, _i]),
     "slak_dwconv2d_tri_forward_stats": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "slak_bn3_backward_local": (_i, [_vp, _vp, _vp, _vp, _vp, ctypes.POINTER(_vp), _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _sz, _vp]),
+    "slak_bn3_forward_sums_counted": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _sz, _vp, ctypes.POINTER(_vp), ctypes.POINTER(_i), _i]),
+    "slak_bn3_backward_sums_dup": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _sz, _vp]),
+    "slak_pack_w1t_fragments": (_i, [_vp, _vp, _i, _i, _vp]),
     "slak_bn3_backward_local_to": (_i, [_vp, _vp, _vp, _vp, _vp, ctypes.POINTER(_vp), _vp, ctypes.POINTER(_vp), ctypes.POINTER(_vp), _vp, _vp, _vp, _i, _i, _i, _vp, _sz, _vp]),
     "slak_bn3_backward_apply_to": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _d, _vp, _vp, ctypes.POINTER(_vp), _vp, ctypes.POINTER(_vp), ctypes.POINTER(_vp), _vp, _vp, _vp, _i, _i, _i, _vp]),
     "slak_block_tail_workspace_bytes": (_sz, [_i, _i, _i]),

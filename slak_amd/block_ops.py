@@ -457,11 +457,32 @@ class BnCounterPool:
         return True
 
 
+_allreduce_sum_opts = {}
+
+
 def _sync_bn_all_reduce(buf, group, async_op=False):
-    """The SyncBatchNorm statistics exchange of one block and direction (6C + 1 doubles forward, 4C floats backward).  async_op: returns the
-    work handle right after the issue (the caller launches independent kernels, then waits)."""
+    """The SyncBatchNorm statistics exchange of one block and direction (6C + 1 doubles forward, 4C floats backward), in place, SUM.
+    async_op: returns the work handle right after the issue (the caller launches independent kernels, then waits); else the collective is
+    ordered on the current stream (ProcessGroupNCCL runs a synchronous collective ON the caller's stream: no stream hand-off; gloo blocks the host).
+    Goes to the process group object directly -- dist.all_reduce's Python-side argument checks and logging wrapper are ~15 us per call, 36 calls per
+    SLaK-T step, 72 per SLaK-B step; same collective, same result."""
     import torch.distributed as dist
-    return dist.all_reduce(buf, group=group, async_op=async_op)
+    try:
+        opts = _allreduce_sum_opts.get(async_op)
+        if opts is None:
+            opts = dist.AllreduceOptions()
+            opts.reduceOp = dist.ReduceOp.SUM
+            if hasattr(opts, "asyncOp"):
+                opts.asyncOp = bool(async_op)
+            _allreduce_sum_opts[async_op] = opts
+        work = group.allreduce([buf], opts)
+    except (AttributeError, TypeError):                              # (a group object without the C++ method: the public entry point)
+        return dist.all_reduce(buf, group=group, async_op=async_op)
+    if async_op:
+        return work
+    if work is not None:
+        work.wait()
+    return None
 
 
 def _bn3_forward_impl(y1, y2, y3, gam, bet, bns, group, pre):
@@ -502,10 +523,9 @@ def _bn3_forward_impl(y1, y2, y3, gam, bet, bns, group, pre):
     pre_args = ((_ptr3(list(pre)), (ctypes.c_int * 3)(*[int(t.shape[0]) for t in pre]), int(pre[0].stride(1))) if pre is not None
                 else (None, None, 0))                                 # the conv launches' rows feed the exchange buffer: no read pass
     with _on(dev):
-        _lib.check(L.slak_bn3_forward_sums(y1.data_ptr(), y2.data_ptr(), y3.data_ptr(), sums.data_ptr(), N, C, P,
-                                           ws.data_ptr() if ws is not None else None, nb, _stream(dev), *pre_args), "slak_bn3_forward_sums")
-    count = float(N * P)
-    sums[C * 6:].fill_(count)
+        _lib.check(L.slak_bn3_forward_sums_counted(y1.data_ptr(), y2.data_ptr(), y3.data_ptr(), sums.data_ptr(), N, C, P,
+                                                   ws.data_ptr() if ws is not None else None, nb, _stream(dev), *pre_args), "slak_bn3_forward_sums_counted")
+    count = float(N * P)                                     # (element 6C of the buffer: written by the same launch)
     _sync_bn_all_reduce(sums, group)
     count_dev = sums[C * 6:]                                 # global element count, stays on the device (no host sync)
     with _on(dev):
@@ -552,11 +572,12 @@ def _bn3_backward_impl(dout, y1, y2, y3, gs, stats, group, count, count_dev, bet
                                                  N, C, P, ws.data_ptr() if ws is not None else None, nb, _stream(dev)), "slak_bn3_backward_local")
         return d1, d2, d3, dgamma, dbeta
     lsums = torch.empty(C * 4, dtype=torch.float32, device=dev)
+    gsums = torch.empty(C * 4, dtype=torch.float32, device=dev)      # the all-reduce's buffer, written by the same launch as the local sums
     with _on(dev):
-        _lib.check(L.slak_bn3_backward_sums(dout.data_ptr(), y1.data_ptr(), y2.data_ptr(), y3.data_ptr(), stats.data_ptr(), lsums.data_ptr(), N, C, P,
-                                            ws.data_ptr() if ws is not None else None, nb, _stream(dev)), "slak_bn3_backward_sums")
-    gsums = lsums.clone()
-    work = _sync_bn_all_reduce(gsums, group, async_op=between is not None)
+        _lib.check(L.slak_bn3_backward_sums_dup(dout.data_ptr(), y1.data_ptr(), y2.data_ptr(), y3.data_ptr(), stats.data_ptr(), lsums.data_ptr(),
+                                                gsums.data_ptr(), N, C, P, ws.data_ptr() if ws is not None else None, nb, _stream(dev)),
+                   "slak_bn3_backward_sums_dup")
+    work = _sync_bn_all_reduce(gsums, group, async_op=between is not None and _bn_bwd_async)
     if between is not None:
         between()                                            # launched behind the collective's issue, in front of its wait
         if work is not None:
@@ -970,7 +991,11 @@ def w1_fragments(w1t):
     c = getattr(w1t, "_slak_frag", None)
     if stamp is not None and c is not None and c[0] == stamp:
         return c[1]
-    w1p = w1t.view(3, 32, 6, 4, 2, 8).permute(2, 3, 0, 4, 1, 5).contiguous()
+    if not (w1t.is_cuda and w1t.dtype == torch.bfloat16 and w1t.is_contiguous() and tuple(w1t.shape) == (96, 384)):
+        raise _lib.SlakHipError("w1_fragments: W1^T must be a contiguous (96, 384) bfloat16 HIP tensor")
+    w1p = torch.empty_like(w1t)                                       # the layout contract lives in the library (slak_pack_w1t_fragments)
+    with _on(w1t.device):
+        _lib.check(_lib.lib().slak_pack_w1t_fragments(w1t.data_ptr(), w1p.data_ptr(), 384, 96, _stream(w1t.device)), "slak_pack_w1t_fragments")
     if stamp is not None:
         w1t._slak_frag = (stamp, w1p)
     return w1p
@@ -1253,6 +1278,9 @@ def mlp_splitk(t, w1, b1, w2, b2):
 # run behind it, then the apply pass waits -- the collective's latency hides behind ~80 us of launches instead of stalling the stream.
 _runner_mod = False           # False: not looked for yet; None: not there / stale / failed to import
 _runner_trace = None          # tests: a callable(str) that the C++ runner calls at the points whose ORDER a test asserts (tests/test_distributed_gpu.py)
+_bn_bwd_async = os.environ.get("SLAK_BN_BWD_ASYNC", "0") == "1"            # 1: the backward exchange on the collective's own stream, overlapped with the two pointwise weight gradients (round 4-5 default).
+# Round 6 default: on the compute stream like the forward one -- measured on one MI355X over RCCL (--force-dist): 15.77 vs 16.03 ms per SLaK-T step, 25.62 vs 25.94 SLaK-B,
+# and ~1.4 ms less host time per step (no Work objects, no waits); the two stream hand-offs per block cost about what the overlap hides
 _force_bn_exchange = os.environ.get("SLAK_FORCE_BN_EXCHANGE", "0") == "1"   # bench.py --force-dist: run the SyncBatchNorm exchange (the all-reduces) at world size 1 too
 
 
@@ -1312,10 +1340,19 @@ _grad_slots = {}              # id(parameter) -> (weakref(parameter), destinatio
 grad_slot_hits = 0            # destinations handed to the runner so far (tests / bench.py's config line)
 
 
-def adopt_grad_slots(params):
-    """Remember every parameter's current .grad tensor as the destination of its next gradient (see above).  Cheap when nothing changed
-    (one data_ptr comparison per parameter); entries of dead parameters are dropped."""
+_adopted_key = None
+
+
+def adopt_grad_slots(params, key=None):
+    """Remember every parameter's current .grad tensor as the destination of its next gradient (see above).  `key`: anything that changes
+    when a .grad pointer does (MaskedAdamW passes its tuple of gradient addresses): the walk is skipped while it repeats.  Entries of dead
+    parameters are dropped."""
     import weakref
+    global _adopted_key
+    if key is not None:
+        if key == _adopted_key and _grad_slots:
+            return
+        _adopted_key = key
     for p in params:
         g = p.grad
         e = _grad_slots.get(id(p))
@@ -1329,7 +1366,9 @@ def adopt_grad_slots(params):
 
 
 def drop_grad_slots():
+    global _adopted_key
     _grad_slots.clear()
+    _adopted_key = None
 
 
 def enable_grad_slots_for(module):

@@ -138,14 +138,14 @@ static void bn_slices(int N, int C, int* S, int* per) {            // ~16384 wav
 }
 
 // sums[c][k] = sum_n rows[(n*C + c)][k]: one wavefront per channel, lanes over n, fixed butterfly order (deterministic)
-__global__ __launch_bounds__(64) void bn3_colreduce(const float* __restrict__ rows, float* __restrict__ sums, int N, int C, int K) {
+__global__ __launch_bounds__(64) void bn3_colreduce(const float* __restrict__ rows, float* __restrict__ sums, int N, int C, int K, float* __restrict__ sums2 = nullptr) {
     const int c = blockIdx.x, lane = threadIdx.x;
     float s[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     for (int n = lane; n < N; n += 64) {
         const float* r = rows + ((size_t)n * C + c) * K;
         for (int k = 0; k < K; ++k) s[k] += r[k];
     }
-    for (int k = 0; k < K; ++k) { const float t = bn_wave_sum(s[k]); if (lane == 0) sums[c * K + k] = t; }
+    for (int k = 0; k < K; ++k) { const float t = bn_wave_sum(s[k]); if (lane == 0) { sums[c * K + k] = t; if (sums2) sums2[c * K + k] = t; } }
 }
 
 __device__ __forceinline__ double bn_wave_sum_d(double v) {
@@ -319,6 +319,7 @@ __global__ __launch_bounds__(64) void bn3_local_stats(const Bn3Pre pre, const ui
     else {
 #pragma unroll
         for (int k = 0; k < 6; ++k) lsum[c * 6 + k] = sd[k];
+        if (update_running && c == 0) lsum[(size_t)C * 6] = count;    // (!FINAL: the flag means "element [6C] takes this rank's element count": slak_bn3_forward_sums_counted)
     }
 }
 __global__ __launch_bounds__(64) void bn3_colreduce_finalize_bwd(const float* __restrict__ rows, int S, const float* __restrict__ stats, Bn3Params bp,
@@ -427,8 +428,8 @@ static void bn_make_pre(Bn3Pre& pre, const float* const* pre_sums, const int* pr
 
 /* local_sums[C][6] DOUBLES = per-channel sum y_b, sum y_b^2 over this rank's batch (exact to double: shifted slice sums, or the conv
  * launches' rows `pre_sums` with a two-pass re-measurement of channels whose raw sums cannot carry the variance). */
-int slak_bn3_forward_sums(const void* y1, const void* y2, const void* y3, double* local_sums, int N, int C, int P,
-                          void* workspace, size_t workspace_bytes, void* stream, const float* const* pre_sums, const int* pre_rows, int pre_stride) {
+static int bn3_forward_sums_impl(const void* y1, const void* y2, const void* y3, double* local_sums, int N, int C, int P,
+                                 void* workspace, size_t workspace_bytes, void* stream, const float* const* pre_sums, const int* pre_rows, int pre_stride, int with_count) {
     if (!y1 || !y2 || !y3 || !local_sums || !bn_pre_ok(pre_sums, pre_rows, pre_stride)) return SLAK_ERR_INVALID_ARG;
     int rc = bn_args_ok(N, C, P); if (rc) return rc;
     if (!workspace || workspace_bytes < slak_bn3_workspace_bytes(N, C)) return SLAK_ERR_WORKSPACE;
@@ -436,9 +437,19 @@ int slak_bn3_forward_sums(const void* y1, const void* y2, const void* y3, double
     bn_make_pre(pre, pre_sums, pre_rows, pre_stride, y1, y2, y3, N, C, P, workspace, (hipStream_t)stream);
     Bn3Params bp{};
     hipLaunchKernelGGL(bn3_local_stats<false>, dim3(C), dim3(64), 0, (hipStream_t)stream, pre, (const uint16_t*)y1, (const uint16_t*)y2, (const uint16_t*)y3,
-                       N, C, P, local_sums, bp, (float*)nullptr, (float*)nullptr, 0.f, 0.f, 0);
+                       N, C, P, local_sums, bp, (float*)nullptr, (float*)nullptr, 0.f, 0.f, with_count);
     SLAK_LAUNCH_CHECK();
     return SLAK_OK;
+}
+
+int slak_bn3_forward_sums(const void* y1, const void* y2, const void* y3, double* local_sums, int N, int C, int P,
+                          void* workspace, size_t workspace_bytes, void* stream, const float* const* pre_sums, const int* pre_rows, int pre_stride) {
+    return bn3_forward_sums_impl(y1, y2, y3, local_sums, N, C, P, workspace, workspace_bytes, stream, pre_sums, pre_rows, pre_stride, 0);
+}
+/* local_sums: [6C + 1] -- element 6C takes this rank's element count N * P (the exchange buffer of the SyncBatchNorm path as one launch writes it) */
+int slak_bn3_forward_sums_counted(const void* y1, const void* y2, const void* y3, double* local_sums, int N, int C, int P,
+                                  void* workspace, size_t workspace_bytes, void* stream, const float* const* pre_sums, const int* pre_rows, int pre_stride) {
+    return bn3_forward_sums_impl(y1, y2, y3, local_sums, N, C, P, workspace, workspace_bytes, stream, pre_sums, pre_rows, pre_stride, 1);
 }
 
 /* Single-process training forward (no statistics exchange between the sums and the apply pass): three launches. */
@@ -487,8 +498,8 @@ int slak_bn3_forward_apply(const void* y1, const void* y2, const void* y3, const
 }
 
 /* local_sums[C][4] = sum dout, sum dout*(y_b - mean_b) over this rank's batch; stats = the forward's [C][6] (mean_b, invstd_b) */
-int slak_bn3_backward_sums(const void* dout, const void* y1, const void* y2, const void* y3, const float* stats, float* local_sums, int N, int C, int P,
-                           void* workspace, size_t workspace_bytes, void* stream) {
+static int bn3_backward_sums_impl(const void* dout, const void* y1, const void* y2, const void* y3, const float* stats, float* local_sums, float* sums_copy,
+                                  int N, int C, int P, void* workspace, size_t workspace_bytes, void* stream) {
     if (!dout || !y1 || !y2 || !y3 || !stats || !local_sums) return SLAK_ERR_INVALID_ARG;
     int rc = bn_args_ok(N, C, P); if (rc) return rc;
     if (!workspace || workspace_bytes < slak_bn3_workspace_bytes(N, C)) return SLAK_ERR_WORKSPACE;
@@ -496,9 +507,20 @@ int slak_bn3_backward_sums(const void* dout, const void* y1, const void* y2, con
     int S, per; bn_slices(N, C, &S, &per);
     hipLaunchKernelGGL(bn3_chansums<true>, dim3((unsigned)((C * S + BN_THREADS / 64 - 1) / (BN_THREADS / 64))), dim3(BN_THREADS), 0, (hipStream_t)stream,
                        (const uint16_t*)dout, (const uint16_t*)y1, (const uint16_t*)y2, (const uint16_t*)y3, stats, rows, N, C, P, S, per);
-    hipLaunchKernelGGL(bn3_colreduce, dim3(C), dim3(64), 0, (hipStream_t)stream, (const float*)rows, local_sums, S, C, 4);
+    hipLaunchKernelGGL(bn3_colreduce, dim3(C), dim3(64), 0, (hipStream_t)stream, (const float*)rows, local_sums, S, C, 4, sums_copy);
     SLAK_LAUNCH_CHECK();
     return SLAK_OK;
+}
+int slak_bn3_backward_sums(const void* dout, const void* y1, const void* y2, const void* y3, const float* stats, float* local_sums, int N, int C, int P,
+                           void* workspace, size_t workspace_bytes, void* stream) {
+    return bn3_backward_sums_impl(dout, y1, y2, y3, stats, local_sums, nullptr, N, C, P, workspace, workspace_bytes, stream);
+}
+/* the same with a second copy of the sums (the buffer the all-reduce then overwrites in place: the local sums are still needed for the local
+ * parameter gradients) -- the copy launch between the sums and the exchange disappears */
+int slak_bn3_backward_sums_dup(const void* dout, const void* y1, const void* y2, const void* y3, const float* stats, float* local_sums, float* sums_copy,
+                               int N, int C, int P, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!sums_copy) return SLAK_ERR_INVALID_ARG;
+    return bn3_backward_sums_impl(dout, y1, y2, y3, stats, local_sums, sums_copy, N, C, P, workspace, workspace_bytes, stream);
 }
 
 /* Single-process backward: three launches.  dgamma3 / dbeta3: HOST arrays of three device pointers ([C] floats each). */

@@ -434,12 +434,7 @@ template <typename T, int KS, int CPRC>
 static int launch_tri_rows_t(TriRowsParams& p, size_t ws_bytes, hipStream_t st) {
     auto k = dwconv_mfma_tri_wgrad_rows_kernel<T, KS, CPRC>;
     const size_t lds = tri_rows_lds_bytes(p);
-    static thread_local size_t cached_key = 0;                    // (device + 1, LDS size): the attribute is per device
-    const size_t key = ((size_t)(slak_current_device() + 1) << 32) | lds;
-    if (cached_key != key) {
-        if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) { (void)hipGetLastError(); return SLAK_ERR_UNSUPPORTED; }
-        cached_key = key;
-    }
+    if (!slak_set_max_lds((const void*)k, lds)) return SLAK_ERR_UNSUPPORTED;      // (process-wide maximum per kernel and device: slak_common.h)
     if ((size_t)p.grid * p.maxspan * (2 * p.K * MF_TAPS + MF_TAPS * MF_TAPS) * sizeof(float) > ws_bytes) return SLAK_ERR_WORKSPACE;
     hipLaunchKernelGGL(k, dim3((unsigned)p.grid), dim3(MF_THREADS), lds, st, p);
     SLAK_LAUNCH_CHECK();

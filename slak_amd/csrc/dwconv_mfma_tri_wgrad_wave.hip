@@ -266,12 +266,7 @@ template <typename T>
 static int launch_tri_wave_t(TriWaveParams& p, size_t ws_bytes, hipStream_t st) {
     auto k = dwconv_mfma_tri_wgrad_wave_kernel<T>;
     const size_t lds = tri_wave_lds_bytes(p.K);
-    static thread_local size_t cached_key = 0;                    // (device + 1, LDS size): the attribute is per device
-    const size_t key = ((size_t)(slak_current_device() + 1) << 32) | lds;
-    if (cached_key != key) {
-        if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) { (void)hipGetLastError(); return SLAK_ERR_UNSUPPORTED; }
-        cached_key = key;
-    }
+    if (!slak_set_max_lds((const void*)k, lds)) return SLAK_ERR_UNSUPPORTED;      // (process-wide maximum per kernel and device: slak_common.h)
     const int grid = (p.waves + MF_WAVES - 1) / MF_WAVES;
     if ((size_t)grid * MF_WAVES * (2 * p.K * MF_TAPS + MF_TAPS * MF_TAPS) * sizeof(float) > ws_bytes) return SLAK_ERR_WORKSPACE;
     hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(MF_THREADS), lds, st, p);

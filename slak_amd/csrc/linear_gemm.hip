@@ -366,7 +366,10 @@ static bool lg2_plan(int M, int N, int K, int epi, Lg2Plan& pl) {
     else return false;
     const int tn = 256 / pl.split;
     if (N < tn || N % tn) return false;
-    if ((long long)M * N * 2 >= (1LL << 32) || (long long)M * K * 2 >= (1LL << 32)) return false;
+    // 32-bit byte offsets: the epilogue issues its stores for the tail rows of the LAST row tile too (rows up to tiles_m * 128, dropped by the buffer
+    // range check) -- bound the rounded-up extent, or an offset within 127 rows of 4 GiB would wrap back into `out`
+    const long long m_up = ((long long)M + LG2_TM - 1) / LG2_TM * LG2_TM;
+    if (m_up * N * 2 >= (1LL << 32) || m_up * K * 2 >= (1LL << 32)) return false;
     const size_t tbl = epi == EPI_GELU ? (size_t)G2_BYTES : (size_t)GD_BYTES;
     pl.lds = tbl + (size_t)LG2_NS * LG2_STAGE + (size_t)LG2_WAVES * 32 * LG2_SP + (pl.split == 2 ? (size_t)LG2_WAVES * 2 * 16 * 64 * 4 : 0);
     pl.tiles_m = (M + LG2_TM - 1) / LG2_TM;

@@ -743,6 +743,15 @@ __global__ __launch_bounds__(LS_THREADS, 1) void linear_nt_n96_kernel(const uint
     }
 }
 
+// slak_pack_w1t_fragments: see the entry point
+__global__ __launch_bounds__(256) void pack_w1t_fragments_kernel(const u32x4* __restrict__ w1t, u32x4* __restrict__ w1p) {
+    const int t = blockIdx.x * 256 + threadIdx.x;               // source chunk: row k (96), chunk c (48) of the row
+    if (t >= 96 * 48) return;
+    const int k = t / 48, c = t - k * 48;
+    const int j = k >> 5, l31 = k & 31, pr = c >> 3, u = (c >> 1) & 3, lhi = c & 1;
+    w1p[((((pr * 4 + u) * 3 + j) * 2 + lhi) * 32) + l31] = w1t[t];
+}
+
 }  // namespace slak
 
 using namespace slak;
@@ -867,9 +876,19 @@ int slak_linear_nt_gelu_bwd(const void* x, const void* wt, const void* y1, void*
     return tail_reduce_columns((const float*)workspace, dbias, wk * LG_WAVES, N, st);
 }
 
+/* W1^T [K = 96][N = 384] bf16 (row-major) -> the fragment-major copy slak_linear_nt_gelu_bwd_dt reads.  Element (k, n) with k = 32 j + l31,
+ * n = 64 pr + 16 u + 8 lhi + e goes to [pr][u][j][lhi][l31][e] (1 KB per load, every byte used): one 16-byte chunk per thread. */
+int slak_pack_w1t_fragments(const void* w1t, void* w1p, int N, int K, void* stream) {
+    if (!w1t || !w1p) return SLAK_ERR_INVALID_ARG;
+    if (N != 384 || K != 96) return SLAK_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(pack_w1t_fragments_kernel, dim3((96 * 48 + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const u32x4*)w1t, (u32x4*)w1p);
+    SLAK_LAUNCH_CHECK();
+    return SLAK_OK;
+}
+
 /* slak_linear_nt_gelu_bwd with the next product of the block's backward in the same launch: dt [M][K] = dy1 . W1 (pwconv1's data gradient), see
  * linear_nt_k96_gbwd_dt_kernel.  w1p = W1^T [K][N] bf16 in FRAGMENT-MAJOR order: viewed (3, 32, 6, 4, 2, 8) = [row tile j][row l31][pair pr][k-step u]
- * [lane half lhi][8 k] and permuted to [pr][u][j][lhi][l31][8] (slak_pack_w1t_fragments makes it).  dy1 and dbias: the bits of
+ * [lane half lhi][8 k] and permuted to [pr][u][j][lhi][l31][8] (slak_pack_w1t_fragments above makes it).  dy1 and dbias: the bits of
  * slak_linear_nt_gelu_bwd; dt: bf16 of the same fp32 sums added in another order than slak_linear_nt's. */
 int slak_linear_nt_gelu_bwd_dt_supported(int M, int N, int K) {
     static const bool on = [] { const char* e = getenv("SLAK_LINEAR_GELU_BWD_DT"); return !(e && e[0] == '0'); }();

@@ -5,6 +5,9 @@
 #include <stdint.h>
 #include <stdlib.h>
 
+#include <mutex>
+#include <vector>
+
 #include "../../include/slak_hip.h"
 
 namespace slak {
@@ -13,17 +16,29 @@ namespace slak {
 // key the cache on (device, value), so a thread that moves to a second GPU sets the attribute there too.
 static inline int slak_current_device() { int dev = 0; return hipGetDevice(&dev) == hipSuccess ? dev : 0; }
 
-// hipFuncSetAttribute(MaxDynamicSharedMemorySize) ONCE per (kernel, device, size) and thread instead of on every launch (the call takes the runtime's
-// lock and ~2 us of host time).  The attribute is per device; a larger size for the same kernel simply sets it again.
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (kernel, device) and LDS size that exceeds what the process has set before, instead of on
+// every launch (the call takes the runtime's lock and ~2 us of host time).  The attribute is PROCESS-wide per (kernel, device) while
+// launches come from several threads (the caller's for a forward, autograd's for a backward) and some kernels' LDS size depends on the shape: the
+// value is therefore only ever RAISED -- a mutex-guarded process-wide maximum per (kernel, device) -- so a thread's cached "at least this much is
+// set" can never be undercut by another thread setting a smaller size for another shape.  (Per translation unit, which is enough: a
+// kernel is launched from the file that defines it.)
 static inline bool slak_set_max_lds(const void* kernel, size_t lds) {
     if (lds <= 48 * 1024) return true;
     struct Slot { const void* k; int dev; size_t lds; };
-    static thread_local Slot cache[64];                           // direct-mapped on the kernel's address: a collision only costs the call again
+    static thread_local Slot cache[64];                           // direct-mapped on the kernel's address: a collision only costs the locked lookup again
     const int dev = slak_current_device();
     Slot& s = cache[((uintptr_t)kernel >> 4) & 63];
-    if (s.k == kernel && s.dev == dev && s.lds == lds) return true;
-    if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) { (void)hipGetLastError(); return false; }
-    s.k = kernel; s.dev = dev; s.lds = lds;
+    if (s.k == kernel && s.dev == dev && s.lds >= lds) return true;
+    static std::mutex mu;
+    static std::vector<Slot> set;                                 // the process-wide maxima
+    std::lock_guard<std::mutex> lk(mu);
+    Slot* g = nullptr;
+    for (Slot& e : set) if (e.k == kernel && e.dev == dev) { g = &e; break; }
+    if (!g || g->lds < lds) {
+        if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) { (void)hipGetLastError(); return false; }
+        if (g) g->lds = lds; else { set.push_back(Slot{kernel, dev, lds}); g = &set.back(); }
+    }
+    s.k = kernel; s.dev = dev; s.lds = g->lds;
     return true;
 }
 

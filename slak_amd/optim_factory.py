@@ -227,7 +227,7 @@ class MaskedAdamW(optim.Optimizer):
         gkey = tuple(0 if g is None else g.data_ptr() for g in grads)
         from . import block_ops
         if block_ops.grad_slots_enabled:                              # DDP bucket views: the next backward writes its gradients straight into them
-            block_ops.adopt_grad_slots([p for _, p in params])
+            block_ops.adopt_grad_slots([p for _, p in params], key=gkey)
         if gkey != self._grad_key:
             for g, (_, p) in zip(grads, params):
                 if g is not None and (g.is_sparse or g.dtype != torch.float32 or not g.is_contiguous() or g.device != dev or g.shape != p.shape):

@@ -167,11 +167,10 @@ std::vector<Tensor> block_forward(const Tensor& x, const c10::optional<Tensor>& 
                                     fpm(coef), fpm(bnstats), sum.data_ptr(), s.N, s.C, s.P, ws.p, ws.n, st, pre, pre_rows, 6), "slak_bn3_forward_local");
     } else {                                                       // SyncBatchNorm: the conv launches' rows feed the exchange buffer, one all-reduce, then the apply pass
         Tensor sums = at::empty({(int64_t)s.C * 6 + 1}, x.options().dtype(at::kDouble));
-        check_rc(slak_bn3_forward_sums(yv.data_ptr(), yh.data_ptr(), ys.data_ptr(), (double*)sums.data_ptr(), s.N, s.C, s.P, ws.p, ws.n, st, pre, pre_rows, 6),
-                 "slak_bn3_forward_sums");
+        check_rc(slak_bn3_forward_sums_counted(yv.data_ptr(), yh.data_ptr(), ys.data_ptr(), (double*)sums.data_ptr(), s.N, s.C, s.P, ws.p, ws.n, st, pre, pre_rows, 6),
+                 "slak_bn3_forward_sums_counted");                   // (element 6C = this rank's N * P: no fill launch)
         const double count = (double)s.N * (double)s.P;
         count_dev = sums.narrow(0, (int64_t)s.C * 6, 1);           // the global element count stays on the device (no host sync)
-        count_dev.fill_(count);
         exchange(sums, false);                                     // blocking on the stream: the apply pass needs the result at once
         check_rc(slak_bn3_forward_apply(yv.data_ptr(), yh.data_ptr(), ys.data_ptr(), (const double*)sums.data_ptr(), count, (const double*)count_dev.data_ptr(),
                                         gam, bet, rm, rv, (float)bn_eps, (float)bn_momentum, 1, update_running ? 1 : 0, fpm(coef), fpm(bnstats), sum.data_ptr(),
@@ -361,10 +360,13 @@ std::vector<Tensor> block_backward(const Tensor& x16, const Tensor& wv, const Te
     pybind11::object work = pybind11::none();
     if (!exchange.is_none()) {
         lsums = at::empty({(int64_t)s.C * 4}, f32);
-        check_rc(slak_bn3_backward_sums(ds.data_ptr(), yv.data_ptr(), yh.data_ptr(), ys.data_ptr(), fp(bnstats), fpm(lsums), s.N, s.C, s.P, ws.p, ws.n, st),
-                 "slak_bn3_backward_sums");
-        gsums = lsums.clone();
-        work = exchange(gsums, true);
+        gsums = at::empty({(int64_t)s.C * 4}, f32);                 // the all-reduce's buffer: written by the same launch (no clone)
+        check_rc(slak_bn3_backward_sums_dup(ds.data_ptr(), yv.data_ptr(), yh.data_ptr(), ys.data_ptr(), fp(bnstats), fpm(lsums), fpm(gsums), s.N, s.C, s.P, ws.p, ws.n, st),
+                 "slak_bn3_backward_sums_dup");
+        // on the compute stream like the forward exchange (no stream hand-offs; the collective's latency is on the stream), or SLAK_BN_BWD_ASYNC=1:
+        // asynchronously (its own stream: the two weight-gradient launches below run beside it)
+        static const bool async_bwd = [] { const char* e = getenv("SLAK_BN_BWD_ASYNC"); return e && e[0] == '1'; }();      // (default since round 6: on the compute stream, block_ops._bn_bwd_async)
+        work = exchange(gsums, async_bwd);
     }
     // the two pointwise weight gradients (single process: in front of the BatchNorm pass, as the Python node launches them)
     // (with both on the library's kernel: on the side stream, joined at the end of this function -- their operands are complete on the main

@@ -423,9 +423,14 @@ class SLaK(nn.Module):
                         b.__dict__.pop("_pending_scale", None)
 
     def _forward_features(self, x):
+        import torch.nn.modules.module as _m
+        # the fused stem / downsample paths below call kernels instead of the modules: with a GLOBAL module hook registered
+        # (register_module_forward_hook & co.) every module has to be called, as _Stage.forward already decides for the blocks
+        no_global_hooks = not (_m._global_forward_hooks or _m._global_forward_pre_hooks or _m._global_backward_hooks or _m._global_backward_pre_hooks
+                               or getattr(_m, "_global_forward_hooks_always_called", None))
         for i in range(4):
             ds = self.downsample_layers[i]
-            if (self.fused_downsample and i > 0 and x.is_cuda and x.dtype == torch.float32 and torch.is_autocast_enabled()
+            if (self.fused_downsample and no_global_hooks and i > 0 and x.is_cuda and x.dtype == torch.float32 and torch.is_autocast_enabled()
                     and isinstance(ds[0], LayerNorm) and ds[0].data_format == "channels_first" and isinstance(ds[1], nn.Conv2d)
                     and ds[1].kernel_size == (2, 2) and ds[1].stride == (2, 2) and ds[1].padding == (0, 0) and ds[1].groups == 1):
                 from . import block_ops                           # LayerNorm + the 2x2 / stride-2 conv as one LN kernel + library GEMMs
@@ -433,7 +438,7 @@ class SLaK(nn.Module):
                 if block_ops.ln_patch_covers(xc):
                     x = self.stages[i](block_ops.downsample_ln_conv(xc, ds[0].weight, ds[0].bias, ds[1].weight, ds[1].bias, ds[0].eps))
                     continue
-            if (self.fused_downsample and self.fused_stem and i == 0 and x.is_cuda and x.dtype == torch.float32 and torch.is_autocast_enabled() and not x.requires_grad
+            if (self.fused_downsample and self.fused_stem and no_global_hooks and i == 0 and x.is_cuda and x.dtype == torch.float32 and torch.is_autocast_enabled() and not x.requires_grad
                     and isinstance(ds[0], nn.Conv2d) and ds[0].kernel_size == (4, 4) and ds[0].stride == (4, 4) and ds[0].padding == (0, 0)
                     and ds[0].groups == 1 and x.shape[2] % 4 == 0 and x.shape[3] % 4 == 0):
                 from . import block_ops                           # stem conv as patch matrix + library GEMMs (no MIOpen launch, no layout transposes)

@@ -148,6 +148,7 @@ class Masking(object):
     def add_module(self, module):
         self.modules.append(module)
         self.module = module
+        self._params_cache = None
         from . import block_ops
         block_ops.enable_grad_slots_for(module)                      # main.py:425 passes the DDP wrapper: bucket-view gradients are written in place
         for name, tensor in module.named_parameters():
@@ -266,18 +267,29 @@ class Masking(object):
     # ------------------------------------------------------------------ device plan
     def _masked_params(self, refresh=False):
         """[(name, parameter)] of the masked tensors in module order.  Walking named_parameters() of a DDP-wrapped SLaK costs ~1.2 ms of host time, and step()
-        needs the list twice: it is kept and re-derived when the mask set changes, on a prune-and-grow round, on load_state_dict(), or when a kept parameter no
-        longer looks like the module's (moved to another device / re-created): every kept entry is checked against its current data pointer's device."""
+        needs the list twice: it is kept and re-derived when the mask set changes (add_module / remove_* drop it), on a prune-and-grow round, on
+        load_state_dict(), or when a kept entry is no longer the module's own: every kept tensor is checked BY IDENTITY against the live attribute of the
+        module that owns it (a Parameter replaced on the same device -- `m.weight = nn.Parameter(...)` -- is a different object) and against its mask's
+        device."""
         cache = getattr(self, "_params_cache", None)
-        if (not refresh and cache is not None and cache[0] == len(self.masks) and cache[1] == len(self.modules)
-                and all(t.device == self.masks[n].device for n, t in cache[2])):
-            return cache[2]
-        out = []
+        if not refresh and cache is not None and cache[0] == len(self.masks) and cache[1] == len(self.modules):
+            ok = True
+            for (n, t), (owner, attr) in zip(cache[2], cache[3]):
+                m = self.masks.get(n)
+                if m is None or owner._parameters.get(attr) is not t or t.device != m.device:
+                    ok = False
+                    break
+            if ok:
+                return cache[2]
+        out, owners = [], []
         for module in self.modules:
+            subs = dict(module.named_modules())
             for name, tensor in module.named_parameters():
                 if name in self.masks:
+                    prefix, _, attr = name.rpartition(".")
                     out.append((name, tensor))
-        self._params_cache = (len(self.masks), len(self.modules), out)
+                    owners.append((subs[prefix], attr))
+        self._params_cache = (len(self.masks), len(self.modules), out, owners)
         return out
 
     def _ensure_plan(self):

@@ -16,6 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def _worker(rank, world, port, out):
     sys.path.insert(0, ROOT)
+    os.environ["SLAK_BN_BWD_ASYNC"] = "1"                            # the overlapped backward exchange (round 4-5 default; opt-in since round 6): its ORDER is what this worker records
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.cuda.set_device(0)
@@ -253,7 +254,8 @@ def test_bench_force_dist_executes_the_rccl_path_on_one_gpu():
 
 def _slot_worker(rank, world, port, out):
     """Round 6: the blocks' parameter gradients written INTO DistributedDataParallel's bucket views (block_ops.adopt_grad_slots + the runner's
-    grad_dst) against the reducer's per-parameter copy, on the N > 1 bench configuration in miniature, two ranks."""
+    grad_dst) against the reducer's per-parameter copy, two ranks: (A) one Block under DDP + SGD -- every launch is this repository's, so runs
+    reproduce bit for bit; (B) the N > 1 bench configuration in miniature (narrow SLaK, MaskedAdamW, Masking, gradient accumulation)."""
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -268,16 +270,59 @@ def _slot_worker(rank, world, port, out):
     M.use_sync_bn = True
     M.Block.fused_tail = True; M.ReparamLargeKernelConv.fused_bn = True; M.ReparamLargeKernelConv.fused_tri = True; M.Block.fused_block = True
     M.LayerNorm.fused_cf = True
+    saved_ds = M.SLaK.fused_downsample
+    M.SLaK.fused_downsample = True                                    # (no MIOpen launch in the step: its weight gradients are not run-to-run reproducible)
     B.cache_lowp_weights = True
     res = {"runner": B._runner() is not None}
 
+    def wrap(mod):
+        ddp = nn.parallel.DistributedDataParallel(mod, device_ids=[0], broadcast_buffers=False, gradient_as_bucket_view=True)
+        ddp.register_comm_hook(None, default_hooks.allreduce_hook)
+        return ddp
+
+    def in_place_now(ps):
+        return all((id(p) in B._grad_slots) and p.grad.data_ptr() == B._grad_slots[id(p)][1].data_ptr() for p in ps)
+
+    # (A) one block
+    def train_block(slots):
+        B.drop_grad_slots(); B.grad_slots_enabled = False; B.grad_slot_hits = 0
+        torch.manual_seed(1)
+        blk = M.Block(16, drop_path=0.0, layer_scale_init_value=0.5, kernel_size=(13, 5), Decom=True, bn=True, lowp_dwconv=True).to(dev)
+        ddp = wrap(blk)
+        assert B.enable_grad_slots_for(ddp) and B.grad_slots_enabled
+        B.grad_slots_enabled = slots
+        opt = torch.optim.SGD(ddp.parameters(), lr=0.1)
+        g = torch.Generator(device=dev).manual_seed(50 + rank)
+        hits = []
+        for it in range(5):
+            x = torch.randn(4, 16, 14, 14, device=dev, generator=g)
+            h0 = B.grad_slot_hits
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                loss = ddp(x).float().pow(2).mean()
+            loss.backward()
+            hits.append((B.grad_slot_hits - h0, slots and in_place_now(list(blk.parameters()))))
+            B.adopt_grad_slots(list(ddp.parameters()))               # (what MaskedAdamW.step does)
+            opt.step()
+            opt.zero_grad(set_to_none=True)
+        state = torch.cat([v.detach().float().flatten() for v in blk.state_dict().values()])
+        B.grad_slots_enabled = False; B.drop_grad_slots()
+        return state, hits
+
+    ref, _ = train_block(False)
+    ref2, _ = train_block(False)
+    got, hits = train_block(True)
+    res["block_ref_reproducible"] = bool(torch.equal(ref, ref2))
+    res["block_identical"] = bool(torch.equal(ref, got))
+    res["block_maxdiff"] = float((ref - got).abs().max())
+    res["block_hits"] = hits
+
+    # (B) the bench's N > 1 configuration in miniature
     def train(slots, accumulate):
         B.drop_grad_slots(); B.grad_slots_enabled = False; B.grad_slot_hits = 0
         torch.manual_seed(7)
         net = M.SLaK(in_chans=3, num_classes=10, depths=[2, 2, 2, 1], dims=[16, 32, 64, 128], drop_path_rate=0.0,
                      kernel_size=[13, 13, 9, 7, 5], Decom=True, bn=True, lowp_dwconv=True).to(dev)
-        ddp = nn.parallel.DistributedDataParallel(net, device_ids=[0], broadcast_buffers=False, gradient_as_bucket_view=True)
-        ddp.register_comm_hook(None, default_hooks.allreduce_hook)
+        ddp = wrap(net)
         opt = MaskedAdamW(ddp.parameters(), lr=1e-3)
         margs = types.SimpleNamespace(device=str(dev), fix=False, update_frequency=3, only_L=False, sparse_init="uniform", sparsity=0.4, distributed=True)
         with contextlib.redirect_stdout(io.StringIO()):
@@ -299,8 +344,7 @@ def _slot_worker(rank, world, port, out):
             loss.backward()
             blk = net.stages[1][0]
             ps = [blk.large_kernel.LoRA1.conv.weight, blk.large_kernel.LoRA2.bn.bias, blk.pwconv1.weight, blk.pwconv2.bias, blk.gamma, blk.norm.weight]
-            same = all((id(p) in B._grad_slots) and p.grad.data_ptr() == B._grad_slots[id(p)][1].data_ptr() for p in ps)
-            in_place.append((B.grad_slot_hits - h0, same))
+            in_place.append((B.grad_slot_hits - h0, slots and in_place_now(ps)))
             with contextlib.redirect_stdout(io.StringIO()):
                 mask.step()
             opt.zero_grad(set_to_none=True)
@@ -310,15 +354,18 @@ def _slot_worker(rank, world, port, out):
 
     for acc in (False, True):
         ref, _, l0 = train(False, acc)
+        ref2, _, _ = train(False, acc)
         got, in_place, l1 = train(True, acc)
         key = "acc" if acc else "plain"
+        res[key + "_ref_reproducible"] = bool(torch.equal(ref, ref2))
         res[key + "_identical"] = bool(torch.equal(ref, got))
+        res[key + "_maxdiff"] = (float((ref - got).abs().max()), float((ref - ref2).abs().max()), float(ref.abs().max()))
         res[key + "_in_place"] = in_place
         res[key + "_loss"] = (l0, l1)
         other = [torch.empty_like(got) for _ in range(world)]
         dist.all_gather(other, got)
         res[key + "_ranks_identical"] = bool(torch.equal(other[0], other[1]))
-    M.LayerNorm.fused_cf = False; B.cache_lowp_weights = False
+    M.LayerNorm.fused_cf = False; B.cache_lowp_weights = False; M.SLaK.fused_downsample = saved_ds
     M.ReparamLargeKernelConv.fused_tri = False; M.Block.fused_block = False; M.Block.fused_tail = False; M.ReparamLargeKernelConv.fused_bn = False
     if rank == 0:
         torch.save(res, out)
@@ -328,19 +375,28 @@ def _slot_worker(rank, world, port, out):
 
 def test_block_gradients_written_into_ddp_bucket_views(gpu, tmp_path):
     """The C++ runner's weight-gradient / reduction launches write into the bucket views of DistributedDataParallel(gradient_as_bucket_view=True):
-    weights and masks after six DDP + Masking steps are BIT-IDENTICAL to the reducer's copy path, on both ranks, with and without gradient
-    accumulation (where the destinations must step aside), and from the third iteration on every block parameter's .grad IS its destination."""
+    a DDP block's weights after five steps are BIT-IDENTICAL to the reducer's copy path; the narrow SLaK with MaskedAdamW + Masking ends
+    bit-identical too wherever the copy path reproduces itself run to run (else within that run-to-run difference), on both ranks, with and without
+    gradient accumulation (where the destinations must step aside); from the third iteration on every block parameter's .grad IS its destination."""
     import socket
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     out = str(tmp_path / "slots.pt")
     mp.spawn(_slot_worker, args=(2, port, out), nprocs=2, join=True)
     got = torch.load(out)
     assert got["runner"], "the C++ block runner was not loaded in the workers"
+    assert got["block_ref_reproducible"], "the copy path of a single block does not reproduce itself"
+    assert got["block_identical"], got["block_maxdiff"]
+    bh = got["block_hits"]
+    assert bh[0][0] == 0 and all(n == 16 and same for n, same in bh[2:]), bh
     for key in ("plain", "acc"):
-        assert got[key + "_identical"], (key, got[key + "_loss"])
+        d_got, d_ref, scale = got[key + "_maxdiff"]
+        if got[key + "_ref_reproducible"]:
+            assert got[key + "_identical"], (key, got[key + "_maxdiff"], got[key + "_loss"])
+        else:                                                         # (a library kernel of the narrow model that does not reproduce: bound by its own spread)
+            assert d_got <= 4 * d_ref + 1e-6 * scale, (key, got[key + "_maxdiff"])
         assert got[key + "_ranks_identical"], key
-    n_block_params = 16 * 7                                           # depths [2, 2, 2, 1]
-    ip = got["plain_in_place"]
+    n_block_params = 16 * 4                                           # the four blocks on the 16 x 16 and 8 x 8 maps run through the C++ runner (the 4 x 4 / 2 x 2 maps of
+    ip = got["plain_in_place"]                                        # this narrow model have no one-launch conv path: Python sequence, the reducer's copy)
     assert ip[0][0] == 0                                              # nothing adopted before the first optimizer step
     assert all(n == n_block_params and same for n, same in ip[2:]), ip
     ia = got["acc_in_place"]                                          # odd iterations: the synchronising backward follows a no_sync() one -> .grad set -> no destinations
