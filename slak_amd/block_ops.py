@@ -485,6 +485,19 @@ def _sync_bn_all_reduce(buf, group, async_op=False):
     return None
 
 
+_sync_bn_all_reduce_impl = _sync_bn_all_reduce                        # (a test that records the exchange's order replaces the module attribute)
+
+
+def _runner_exchange(group):
+    """What the C++ runner gets for the statistics exchange: None (single process), the ProcessGroup itself (the runner issues the all-reduce from
+    C++), or -- when a test has patched _sync_bn_all_reduce, or SLAK_PG_DIRECT=0 -- a callable through this module."""
+    if group is None:
+        return None
+    if _sync_bn_all_reduce is _sync_bn_all_reduce_impl and _pg_direct and hasattr(group, "allreduce"):
+        return group
+    return lambda buf, async_op: _sync_bn_all_reduce(buf, group, async_op=async_op)
+
+
 def _bn3_forward_impl(y1, y2, y3, gam, bet, bns, group, pre):
     """Training-mode statistics of the three branch BatchNorms (cross-rank when ``group`` is given: one all-reduce of 6C+1 doubles), running-stat
     update, fused scale / shift / add.  -> (out, stats [6C] for the backward, count, count_dev)"""
@@ -1281,6 +1294,7 @@ _runner_trace = None          # tests: a callable(str) that the C++ runner calls
 _bn_bwd_async = os.environ.get("SLAK_BN_BWD_ASYNC", "0") == "1"            # 1: the backward exchange on the collective's own stream, overlapped with the two pointwise weight gradients (round 4-5 default).
 # Round 6 default: on the compute stream like the forward one -- measured on one MI355X over RCCL (--force-dist): 15.77 vs 16.03 ms per SLaK-T step, 25.62 vs 25.94 SLaK-B,
 # and ~1.4 ms less host time per step (no Work objects, no waits); the two stream hand-offs per block cost about what the overlap hides
+_pg_direct = os.environ.get("SLAK_PG_DIRECT", "1") != "0"                  # the runner calls ProcessGroup::allreduce itself (0: through _sync_bn_all_reduce)
 _force_bn_exchange = os.environ.get("SLAK_FORCE_BN_EXCHANGE", "0") == "1"   # bench.py --force-dist: run the SyncBatchNorm exchange (the all-reduces) at world size 1 too
 
 
@@ -1406,7 +1420,7 @@ class _BlockFn(torch.autograd.Function):
                 and all(bn.track_running_stats and bn.num_batches_tracked is not None for bn in bns)):
             w1b, w2b = lowp_param(w1), lowp_param(w2)
             group = _bn3_group(bns[0])                                # SyncBatchNorm: the runner calls back for the two statistics exchanges
-            exchange = None if group is None else (lambda buf, async_op: _sync_bn_all_reduce(buf, group, async_op=async_op))
+            exchange = _runner_exchange(group)
             res = R.block_forward(x, x_lowp, wv, wh, ws, [g1, g2, g3], [b1, b2, b3], [bn.running_mean for bn in bns], [bn.running_var for bn in bns],
                                   float(bns[0].eps), float(bns[0].momentum), True, lnw, lnb, float(eps), w1b, lowp_param(bb1), w2b, lowp_param(bb2),
                                   gamma, sample_scale, bool(emit), exchange)
@@ -1445,7 +1459,7 @@ class _BlockFn(torch.autograd.Function):
         (x16, wv, wh, ws, yv, yh, ys, g1, g2, g3, bnstats, s, lnw, mean, rstd, t, w1b, y1m, a, w2b, z, gamma, sample_scale, w1t, w2t) = ctx.saved_tensors
         tri_dgrad, group, count, count_dev, xdtype, had_lowp = ctx.misc
         if ctx.runner:
-            exchange = None if group is None else (lambda buf, async_op: _sync_bn_all_reduce(buf, group, async_op=async_op))
+            exchange = _runner_exchange(group)
             w1p = None                                                # stage 1: W1^T in fragment order for the launch that also produces dt
             if tuple(w1b.shape) == (384, 96) and w1b.dtype == torch.bfloat16 and _lib.lib().slak_linear_nt_gelu_bwd_dt_supported(t.numel() // 96, 384, 96):
                 w1p = w1_fragments(w1t if w1t is not None else w1b.t().contiguous())

@@ -56,8 +56,21 @@ __device__ __forceinline__ void tw_dma16(unsigned voff, v4i_t rsrc, unsigned lds
 
 // KS: 16-deep k-steps of both contractions (ceil(max(H, W) / 16): 3 or 4); CPRC: chunks per LDS row as a compile-time constant (every
 // fragment offset of a plane is then an instruction immediate)
-template <typename T, int KS, int CPRC>
+// SD (round 6, "small branch on the diagonal"): the 5 x 5 correlation only has the five diagonals |i - o| <= 2, so of its 2 x 2 tiles only
+// the two DIAGONAL ones are multiplied -- 40 MFMAs per plane instead of 80, 200 instead of 240 for the three branches (the launch runs at the
+// board's power cap: energy per plane is the lever).  Three things make that exact and keep the four waves' instruction streams
+// identical (no wave-dependent branch in the pinned stream):
+//   * the second tile of X's rows starts at row H - 32 instead of 32 (rows H-32 .. H-1: no padding rows; needs H <= 62): the diagonal tile
+//     pair {rows [0,32)} x {rows [0,32)}, {rows [H-32,H)} x {rows [H-32,H)} then holds EVERY pair with |i - o| <= 2 (a pair that straddles row
+//     32 has both members >= 30 >= H - 32); the block both tiles hold (o, i in [H-32, 32)) is dropped from the second one in the diagonal sums,
+//     and so are the columns i < 32 of the vertical branch's tiles over the second X tile;
+//   * both waves that hold X tile nt (mt = 0, 1) work on the SAME small tile (nt, nt): at loop step j a wave multiplies taps {0,1,2} (j even) or
+//     {3,4} (j odd) -- and wave mt = 1 walks the k-steps ROTATED by one (1, 2, 3, 0: a constant in its operand addresses), so that k-step k gets
+//     taps T(k) from wave 0 and T(k - 1) = the other taps from wave 1.  Needs an even KS (KS = 4: the 56 x 56 class);
+//   * the four waves' partial sums are added in the epilogue as before.  50 MFMAs per wave and plane instead of 60.
+template <typename T, int KS, int CPRC, bool SD>
 __global__ __launch_bounds__(MF_THREADS, 1) void dwconv_mfma_tri_wgrad_rows_kernel(const TriRowsParams p) {
+    static_assert(!SD || (KS % 2 == 0), "the tap split of the small branch alternates with the k-step's parity");
     constexpr int NG = MF_TAPS;
     constexpr unsigned PB = (unsigned)CPRC * 16;                  // row pitch (bytes)
     constexpr unsigned RSC = KS == 3 ? 56 : 68;                   // rows per copy: >= 16 KS + 4, and a copy's DMA instructions (whole KiB) end inside it
@@ -147,8 +160,12 @@ __global__ __launch_bounds__(MF_THREADS, 1) void dwconv_mfma_tri_wgrad_rows_kern
 
     // ---- fragment addresses (relative to a slot) ---------------------------------------------------------------------------
     // vertical / small: lane -> image row (o = mt * 32 + l31 resp. i = nt * 32 + l31), 8 consecutive k = columns 16 ks + 8 lhi .. +7
-    const unsigned av_off = ring_b + (unsigned)(mt * 32 + l31) * PB + lhi * 16;                     // dYv (copy 0)
-    const unsigned xv_off = ring_b + copy_b + (unsigned)(nt * 32 + l31) * PB + lhi * 16;           // X   (copy 1)
+    const int sI = SD ? (nt ? p.H - 32 : 0) : nt * 32;                // first image row of this wave's X tile
+    const unsigned rotb = SD ? (unsigned)mt * 32u : 0u;               // SD: wave (1, nt) starts one k-step further along ...
+    const unsigned wrapb = SD ? (unsigned)mt * (unsigned)(KS * 32) : 0u;   // ... and its last loop step wraps around to k-step 0
+    const unsigned av_off = ring_b + (unsigned)(mt * 32 + l31) * PB + lhi * 16 + rotb;              // dYv (copy 0)
+    const unsigned xv_off = ring_b + copy_b + (unsigned)(sI + l31) * PB + lhi * 16 + rotb;         // X   (copy 1)
+    const unsigned as_off = ring_b + 2 * copy_b + (unsigned)((SD ? sI : mt * 32) + l31) * PB + lhi * 16 + rotb;   // dYs (copy 2): SD -> the DIAGONAL tile (nt, nt)
     // horizontal: lane -> image column (o = mt * 32 + l31 resp. i = nt * 32 + l31), 8 consecutive k = rows 16 ks + 8 lhi .. +7: a 16-lane
     // group of a transposing read covers 4 rows x 16 columns (lane i16 supplies row i16 / 4, columns 4 (i16 % 4) .. +3, receives column i16)
     const int i16 = lane & 15, gq = lane >> 4;
@@ -180,7 +197,8 @@ __global__ __launch_bounds__(MF_THREADS, 1) void dwconv_mfma_tri_wgrad_rows_kern
             advance_issue();
             continue;
         }
-        const unsigned av = sb + av_off, as = av + 2 * copy_b, xv = sb + xv_off, ah = sb + ah_off, xh = sb + xh_off;
+        const unsigned av = sb + av_off, as = sb + as_off, xv = sb + xv_off, ah = sb + ah_off, xh = sb + xh_off;
+        const unsigned avw = av - wrapb, asw = as - wrapb, xvw = xv - wrapb;      // (SD) the bases of the LAST loop step's operands
         s16x8 a[2], a2[2], b[2][NG];
         // operands of the first vertical k-step (nothing to hide them behind: the plane has only just been released)
         {
@@ -189,7 +207,64 @@ __global__ __launch_bounds__(MF_THREADS, 1) void dwconv_mfma_tri_wgrad_rows_kern
             tw_taps(b[0], P3, C[0], C[1], C[2], C[3], N0);
         }
         __builtin_amdgcn_sched_barrier(0);
-        // ---- vertical + small: KS k-steps of ten MFMAs; behind them the operands of the next step (the last one: of the first horizontal step)
+        // ---- vertical + small: KS k-steps of ten MFMAs (SD: eight / seven); behind them the operands of the next step (the last one: of the first horizontal step)
+        if constexpr (SD) {
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int cu = ks & 1, nx = cu ^ 1;
+            const bool last = ks + 1 == KS, wrap = ks + 2 == KS;                      // wrap: the NEXT step is the loop's last one
+            const unsigned on = (unsigned)(ks + 1) * 32u;
+            const unsigned avn = (wrap ? avw : av) + on, asn = (wrap ? asw : as) + on, xvn = (wrap ? xvw : xv) + on;
+            u32x4 Cn; unsigned Pn = 0, Nn = 0; u32x2 w0, w1, w2, h0, h1;
+            if ((ks & 1) == 0) {                                                      // taps 0, 1, 2 of the small branch
+                tw_mfma<T, TW_ACC_V + 16 * 0>(a[cu], b[cu][0]);
+                if (!last) a[nx] = __builtin_bit_cast(s16x8, rdq(avn)); else h0 = rdt(ah);
+                __builtin_amdgcn_sched_barrier(0);
+                tw_mfma<T, TW_ACC_S + 16 * 0>(a2[cu], b[cu][0]);
+                if (!last) a2[nx] = __builtin_bit_cast(s16x8, rdq(asn)); else h1 = rdt(ah + 4 * PB);
+                __builtin_amdgcn_sched_barrier(0);
+                tw_mfma<T, TW_ACC_V + 16 * 1>(a[cu], b[cu][1]);
+                if (!last) Cn = rdq(xvn); else w0 = rdt(xh);
+                __builtin_amdgcn_sched_barrier(0);
+                tw_mfma<T, TW_ACC_S + 16 * 1>(a2[cu], b[cu][1]);
+                if (!last) Pn = rdd(xvn - 4); else w1 = rdt(xh + 4 * PB);
+                __builtin_amdgcn_sched_barrier(0);
+                tw_mfma<T, TW_ACC_V + 16 * 2>(a[cu], b[cu][2]);
+                if (!last) Nn = rdd(xvn + 16); else w2 = rdt(xh + 8 * PB);
+                __builtin_amdgcn_sched_barrier(0);
+                tw_mfma<T, TW_ACC_S + 16 * 2>(a2[cu], b[cu][2]);
+                issue_piece(it + 2, 2 * ks);
+                __builtin_amdgcn_sched_barrier(0);
+                tw_mfma<T, TW_ACC_V + 16 * 3>(a[cu], b[cu][3]);
+                issue_piece(it + 2, 2 * ks + 1);
+                __builtin_amdgcn_sched_barrier(0);
+                tw_mfma<T, TW_ACC_V + 16 * 4>(a[cu], b[cu][4]);
+            } else {                                                                  // taps 3, 4
+                tw_mfma<T, TW_ACC_V + 16 * 0>(a[cu], b[cu][0]);
+                if (!last) a[nx] = __builtin_bit_cast(s16x8, rdq(avn)); else h0 = rdt(ah);
+                __builtin_amdgcn_sched_barrier(0);
+                tw_mfma<T, TW_ACC_V + 16 * 1>(a[cu], b[cu][1]);
+                if (!last) a2[nx] = __builtin_bit_cast(s16x8, rdq(asn)); else h1 = rdt(ah + 4 * PB);
+                __builtin_amdgcn_sched_barrier(0);
+                tw_mfma<T, TW_ACC_V + 16 * 2>(a[cu], b[cu][2]);
+                if (!last) Cn = rdq(xvn); else w0 = rdt(xh);
+                __builtin_amdgcn_sched_barrier(0);
+                tw_mfma<T, TW_ACC_V + 16 * 3>(a[cu], b[cu][3]);
+                if (!last) { Pn = rdd(xvn - 4); Nn = rdd(xvn + 16); } else { w1 = rdt(xh + 4 * PB); w2 = rdt(xh + 8 * PB); }
+                __builtin_amdgcn_sched_barrier(0);
+                tw_mfma<T, TW_ACC_S + 16 * 3>(a2[cu], b[cu][3]);
+                issue_piece(it + 2, 2 * ks);
+                __builtin_amdgcn_sched_barrier(0);
+                tw_mfma<T, TW_ACC_V + 16 * 4>(a[cu], b[cu][4]);
+                issue_piece(it + 2, 2 * ks + 1);
+                __builtin_amdgcn_sched_barrier(0);
+                tw_mfma<T, TW_ACC_S + 16 * 4>(a2[cu], b[cu][4]);
+            }
+            if (!last) tw_taps(b[nx], Pn, Cn[0], Cn[1], Cn[2], Cn[3], Nn);
+            else { a[nx] = __builtin_bit_cast(s16x8, u32x4{h0[0], h0[1], h1[0], h1[1]}); tw_taps(b[nx], w0[0], w0[1], w1[0], w1[1], w2[0], w2[1]); }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        } else {
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             const int cu = ks & 1, nx = cu ^ 1;
@@ -225,6 +300,7 @@ __global__ __launch_bounds__(MF_THREADS, 1) void dwconv_mfma_tri_wgrad_rows_kern
             tw_mfma<T, TW_ACC_S + 16 * 4>(a2[cu], b[cu][4]);
             __builtin_amdgcn_sched_barrier(0);
         }
+        }
         // ---- horizontal: KS k-steps of five MFMAs (a / b buffers continue to alternate: step ks uses buffer (KS + ks) & 1) ------------------------
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
@@ -258,9 +334,17 @@ __global__ __launch_bounds__(MF_THREADS, 1) void dwconv_mfma_tri_wgrad_rows_kern
     if (!TW_DBG(4)) {
         {   // (every tap writes all of the wave's 32 x 32 entries of the skewed tile: nothing to clear between taps or extents)
             int o_max = p.H - mt * 32; if (o_max > 32) o_max = 32;
+            if constexpr (SD) {
+                const int ov = 64 - p.H;                                    // rows [H - 32, 32): in both X tiles -> counted with the first
+                const bool dup = nt == 1 && l31 < ov;
+                tw_diag5<TW_ACC_V>(tile, wr, dup ? 0 : o_max - 4 * lhi, lane, sI - mt * 32 - 31 + p.padL, p.K, mine, MF_TAPS, 1);               // dw_v[tau][r = g]
+                // the small branch's tile is (nt, nt) for both waves of an X tile (every row of it is an image row); of the second tile the block o, i < 32 is the first tile's
+                tw_diag5<TW_ACC_S>(tile, wr, 64, lane, -31 + MF_TAPS / 2, MF_TAPS, mine + 2 * ntl, MF_TAPS, 1, dup ? ov - 4 * lhi : -64);
+            } else {
             const int lim = nt * 32 + l31 < p.H ? o_max - 4 * lhi : 0;
             tw_diag5<TW_ACC_V>(tile, wr, lim, lane, dtau + p.padL, p.K, mine, MF_TAPS, 1);                          // dw_v[tau][r = g]
             tw_diag5<TW_ACC_S>(tile, wr, lim, lane, dtau + MF_TAPS / 2, MF_TAPS, mine + 2 * ntl, MF_TAPS, 1);       // dw_s[tau][r = g]
+            }
         }
         {
             int o_max = p.W - mt * 32; if (o_max > 32) o_max = 32;
@@ -430,9 +514,9 @@ size_t dwconv_mfma_tri_wgrad_rows_workspace(int N, int C, int K) {
     return align_up(((size_t)C + 2 * g + 2 + (P / g + N - 1) / N) * (2 * K * MF_TAPS + MF_TAPS * MF_TAPS) * sizeof(float), 256);
 }
 
-template <typename T, int KS, int CPRC>
+template <typename T, int KS, int CPRC, bool SD>
 static int launch_tri_rows_t(TriRowsParams& p, size_t ws_bytes, hipStream_t st) {
-    auto k = dwconv_mfma_tri_wgrad_rows_kernel<T, KS, CPRC>;
+    auto k = dwconv_mfma_tri_wgrad_rows_kernel<T, KS, CPRC, SD>;
     const size_t lds = tri_rows_lds_bytes(p);
     if (!slak_set_max_lds((const void*)k, lds)) return SLAK_ERR_UNSUPPORTED;      // (process-wide maximum per kernel and device: slak_common.h)
     if ((size_t)p.grid * p.maxspan * (2 * p.K * MF_TAPS + MF_TAPS * MF_TAPS) * sizeof(float) > ws_bytes) return SLAK_ERR_WORKSPACE;
@@ -453,8 +537,12 @@ int launch_dwconv_mfma_tri_wgrad_rows(const void* const* dy, const void* x, floa
     p.counters = wgrad_arrival_counters(C);
     if (!p.counters) return SLAK_ERR_UNSUPPORTED;
     const bool bf = dtype == SLAK_BF16;
-    if (p.CPR == 9) return bf ? launch_tri_rows_t<bf16_t, 4, 9>(p, ws_bytes, st) : launch_tri_rows_t<f16_t, 4, 9>(p, ws_bytes, st);
-    return bf ? launch_tri_rows_t<bf16_t, 3, 7>(p, ws_bytes, st) : launch_tri_rows_t<f16_t, 3, 7>(p, ws_bytes, st);
+    // small branch on the diagonal tiles (see the kernel): four k-steps and a second X tile that reaches back to row 30 or further
+    static const bool sd_on = [] { const char* e = getenv("SLAK_TRI_ROWS_SD"); return !(e && e[0] == '0'); }();      // A/B switch: 0 = all four tiles of the small branch (round 4-5)
+    if (p.CPR == 9 && sd_on && H <= 62)
+        return bf ? launch_tri_rows_t<bf16_t, 4, 9, true>(p, ws_bytes, st) : launch_tri_rows_t<f16_t, 4, 9, true>(p, ws_bytes, st);
+    if (p.CPR == 9) return bf ? launch_tri_rows_t<bf16_t, 4, 9, false>(p, ws_bytes, st) : launch_tri_rows_t<f16_t, 4, 9, false>(p, ws_bytes, st);
+    return bf ? launch_tri_rows_t<bf16_t, 3, 7, false>(p, ws_bytes, st) : launch_tri_rows_t<f16_t, 3, 7, false>(p, ws_bytes, st);
 }
 
 }  // namespace slak

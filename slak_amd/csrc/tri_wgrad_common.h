@@ -57,9 +57,10 @@ template <int BASE> __device__ __forceinline__ void tw_acc_read(float (&v)[16]) 
 // diagonal sums of the five taps of one branch through the wave's skewed tile (G[o][i] -> row o, column i - o + 31: a diagonal is a column).
 // ONE copy of the scatter / column-sum code in a run-time loop over the taps (the register NAMES are compile-time: a switch picks the read).
 // lim: per lane, how many of its rows are inside the image (0 for a lane whose column is outside): entries beyond are written as zeros, so
-// nothing of a padded row / column -- finite or not -- reaches a sum and the stores need no exec masking.
+// nothing of a padded row / column -- finite or not -- reaches a sum and the stores need no exec masking.  lo: the lane's rows below it are
+// written as zeros too (a block of the tile that another tile counts).
 template <int BASE>
-__device__ __forceinline__ void tw_diag5(float* tile, float* wr, int lim, int lane, int dtau, int KL, float* out, int s_tau, int s_g) {
+__device__ __forceinline__ void tw_diag5(float* tile, float* wr, int lim, int lane, int dtau, int KL, float* out, int s_tau, int s_g, int lo = -64) {
 #pragma unroll 1
     for (int g = 0; g < MF_TAPS; ++g) {
         float v[16];
@@ -68,7 +69,7 @@ __device__ __forceinline__ void tw_diag5(float* tile, float* wr, int lim, int la
             case 3: tw_acc_read<BASE + 48>(v); break; default: tw_acc_read<BASE + 64>(v); break;
         }
 #pragma unroll
-        for (int r = 0; r < 16; ++r) wr[((r & 3) + 8 * (r >> 2)) * 63] = (r & 3) + 8 * (r >> 2) < lim ? v[r] : 0.f;
+        for (int r = 0; r < 16; ++r) wr[((r & 3) + 8 * (r >> 2)) * 63] = ((r & 3) + 8 * (r >> 2) < lim && (r & 3) + 8 * (r >> 2) >= lo) ? v[r] : 0.f;
         __builtin_amdgcn_wave_barrier();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (lane < 63) {

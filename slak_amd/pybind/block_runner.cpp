@@ -15,6 +15,9 @@
 // block_forward returns an EMPTY list when a precondition of the one-launch path does not hold for the shape (no three-branch forward with
 // statistics / data gradient / weight gradient launch): the caller (block_ops._BlockFn) then runs the Python sequence, which knows every fallback.
 #include <torch/extension.h>
+#include <torch/csrc/distributed/c10d/ProcessGroup.hpp>
+#include <torch/csrc/distributed/c10d/Types.hpp>
+#include <torch/csrc/distributed/c10d/Work.hpp>
 #include <c10/hip/HIPGuard.h>
 #include <c10/hip/HIPStream.h>
 #include <hip/hip_runtime_api.h>
@@ -38,6 +41,40 @@ void* stream_of(const Tensor& t) { return (void*)c10::hip::getCurrentHIPStream(t
 void check_rc(int rc, const char* fn) {
     TORCH_CHECK(rc == SLAK_OK, fn, ": ", slak_status_string(rc), " (", slak_last_hip_error(), ")");
 }
+
+// The SyncBatchNorm statistics exchange: `exchange` is None (single process), a torch.distributed ProcessGroup -- the all-reduce is then issued from
+// here (ProcessGroup::allreduce: ~5 us of host time, no Python frame, the GIL is not needed) -- or a Python callable(buf, async_op) -> work | None
+// (block_ops._sync_bn_all_reduce behind a lambda: what the tests patch to record the order of the calls).
+struct Exchange {
+    pybind11::object fn;                                           // the callable form
+    c10::intrusive_ptr<c10d::ProcessGroup> pg;                     // the direct form
+    c10::intrusive_ptr<c10d::Work> work;                           // an asynchronous all-reduce in flight (direct form)
+    pybind11::object pywork = pybind11::none();                    //                                    (callable form)
+    explicit Exchange(const pybind11::object& o) {
+        if (o.is_none()) return;
+        if (pybind11::hasattr(o, "allreduce") && pybind11::hasattr(o, "rank")) {
+            try { pg = o.cast<c10::intrusive_ptr<c10d::ProcessGroup>>(); } catch (const pybind11::cast_error&) { pg = nullptr; }
+        }
+        if (!pg) fn = o;
+    }
+    bool none() const { return !pg && !fn; }
+    void run(Tensor& buf, bool async) {                            // SUM, in place
+        if (pg) {
+            c10d::AllreduceOptions opts;
+            opts.reduceOp = c10d::ReduceOp::SUM;
+            opts.asyncOp = async;
+            std::vector<Tensor> v{buf};
+            auto w = pg->allreduce(v, opts);
+            if (async) work = w; else if (w) w->wait();            // (RCCL: ordered on the current stream, no host wait; gloo: blocks the host)
+        } else {
+            pywork = fn(buf, async);
+        }
+    }
+    void wait() {
+        if (work) { work->wait(); work = nullptr; }
+        if (!pywork.is_none()) { pywork.attr("wait")(); pywork = pybind11::none(); }
+    }
+};
 
 // per-(device, stream) scratch, grown on demand; stream-ordered reuse is safe because every kernel that touches it is enqueued on that stream
 struct Scratch { void* p; size_t n; };
@@ -135,7 +172,8 @@ std::vector<Tensor> block_forward(const Tensor& x, const c10::optional<Tensor>& 
                                   const std::vector<Tensor>& bn_var, double bn_eps, double bn_momentum, bool update_running,
                                   const Tensor& lnw, const Tensor& lnb, double ln_eps, const Tensor& w1b, const Tensor& bb1b, const Tensor& w2b,
                                   const Tensor& bb2b, const Tensor& gamma, const c10::optional<Tensor>& sample_scale, bool emit_lowp,
-                                  const pybind11::object& exchange /* None: single process */) {
+                                  const pybind11::object& exchange_obj /* None: single process; else see Exchange */) {
+    Exchange exchange(exchange_obj);
     TORCH_CHECK(x.is_cuda() && x.is_contiguous() && x.dim() == 4, "x must be a contiguous (N,C,H,W) HIP tensor");
     TORCH_CHECK(bn_gamma.size() == 3 && bn_beta.size() == 3 && bn_mean.size() == 3 && bn_var.size() == 3, "three branch BatchNorms");
     const Shape s = shape_of(x, wv, w1b);
@@ -162,7 +200,7 @@ std::vector<Tensor> block_forward(const Tensor& x, const c10::optional<Tensor>& 
     const int pre_rows[3] = {pl.rows, pl.rows, pl.rows};
     Tensor coef = at::empty({s.C * 4}, stats.options()), bnstats = at::empty({s.C * 6}, stats.options());
     Tensor sum = at::empty_like(yv), count_dev;
-    if (exchange.is_none()) {
+    if (exchange.none()) {
     check_rc(slak_bn3_forward_local(yv.data_ptr(), yh.data_ptr(), ys.data_ptr(), gam, bet, rm, rv, (float)bn_eps, (float)bn_momentum, update_running ? 1 : 0,
                                     fpm(coef), fpm(bnstats), sum.data_ptr(), s.N, s.C, s.P, ws.p, ws.n, st, pre, pre_rows, 6), "slak_bn3_forward_local");
     } else {                                                       // SyncBatchNorm: the conv launches' rows feed the exchange buffer, one all-reduce, then the apply pass
@@ -171,7 +209,7 @@ std::vector<Tensor> block_forward(const Tensor& x, const c10::optional<Tensor>& 
                  "slak_bn3_forward_sums_counted");                   // (element 6C = this rank's N * P: no fill launch)
         const double count = (double)s.N * (double)s.P;
         count_dev = sums.narrow(0, (int64_t)s.C * 6, 1);           // the global element count stays on the device (no host sync)
-        exchange(sums, false);                                     // blocking on the stream: the apply pass needs the result at once
+        exchange.run(sums, false);                                 // blocking on the stream: the apply pass needs the result at once
         check_rc(slak_bn3_forward_apply(yv.data_ptr(), yh.data_ptr(), ys.data_ptr(), (const double*)sums.data_ptr(), count, (const double*)count_dev.data_ptr(),
                                         gam, bet, rm, rv, (float)bn_eps, (float)bn_momentum, 1, update_running ? 1 : 0, fpm(coef), fpm(bnstats), sum.data_ptr(),
                                         s.N, s.C, s.P, st), "slak_bn3_forward_apply");
@@ -269,10 +307,11 @@ std::vector<Tensor> block_backward(const Tensor& x16, const Tensor& wv, const Te
                                    const Tensor& mean, const Tensor& rstd, const Tensor& t, const Tensor& w1b, const Tensor& y1m, const Tensor& a,
                                    const Tensor& w2b, const Tensor& z, const Tensor& gamma, const c10::optional<Tensor>& sample_scale,
                                    const c10::optional<Tensor>& dout_opt, const c10::optional<Tensor>& dout16_opt, bool shortcut_bf16, bool had_lowp,
-                                   const c10::optional<Tensor>& count_dev, const pybind11::object& exchange, const pybind11::object& trace,
+                                   const c10::optional<Tensor>& count_dev, const pybind11::object& exchange_obj, const pybind11::object& trace,
                                    const c10::optional<Tensor>& w1t_opt, const c10::optional<Tensor>& w2t_opt /* cached transposed bf16 weights, or None */,
                                    const c10::optional<Tensor>& w1p_opt /* W1^T in fragment-major order (slak_linear_nt_gelu_bwd_dt), or None */,
                                    const std::vector<c10::optional<Tensor>>& grad_dst) {
+    Exchange exchange(exchange_obj);
     const Shape s = shape_of(x16, wv, w1b);
     TORCH_CHECK(grad_dst.empty() || grad_dst.size() == 16, "grad_dst: empty, or one entry (tensor or None) per parameter of the block");
     const GradDst gd{grad_dst.empty() ? nullptr : &grad_dst, (int)x16.get_device()};
@@ -357,8 +396,7 @@ std::vector<Tensor> block_backward(const Tensor& x16, const Tensor& wv, const Te
     float* const dbet3[3] = {fpm(dgb[1]), fpm(dgb[3]), fpm(dgb[5])};
     Tensor d1 = at::empty_like(yv), d2 = at::empty_like(yv), d3 = at::empty_like(yv);
     Tensor lsums, gsums;
-    pybind11::object work = pybind11::none();
-    if (!exchange.is_none()) {
+    if (!exchange.none()) {
         lsums = at::empty({(int64_t)s.C * 4}, f32);
         gsums = at::empty({(int64_t)s.C * 4}, f32);                 // the all-reduce's buffer: written by the same launch (no clone)
         check_rc(slak_bn3_backward_sums_dup(ds.data_ptr(), yv.data_ptr(), yh.data_ptr(), ys.data_ptr(), fp(bnstats), fpm(lsums), fpm(gsums), s.N, s.C, s.P, ws.p, ws.n, st),
@@ -366,7 +404,7 @@ std::vector<Tensor> block_backward(const Tensor& x16, const Tensor& wv, const Te
         // on the compute stream like the forward exchange (no stream hand-offs; the collective's latency is on the stream), or SLAK_BN_BWD_ASYNC=1:
         // asynchronously (its own stream: the two weight-gradient launches below run beside it)
         static const bool async_bwd = [] { const char* e = getenv("SLAK_BN_BWD_ASYNC"); return e && e[0] == '1'; }();      // (default since round 6: on the compute stream, block_ops._bn_bwd_async)
-        work = exchange(gsums, async_bwd);
+        exchange.run(gsums, async_bwd);
     }
     // the two pointwise weight gradients (single process: in front of the BatchNorm pass, as the Python node launches them)
     // (with both on the library's kernel: on the side stream, joined at the end of this function -- their operands are complete on the main
@@ -380,11 +418,11 @@ std::vector<Tensor> block_backward(const Tensor& x16, const Tensor& wv, const Te
     struct Join { Side* sd; void* st; bool on; ~Join() { if (on && hipEventRecord(sd->join, sd->st) == hipSuccess) (void)hipStreamWaitEvent((hipStream_t)st, sd->join, 0); } } join{&sd, st, forked};
     check_rc(deferred.end(), "slak_defer_reductions_end");         // one launch: dgamma, db2 | db1 | dlnw, dlnb | dW1 | dW2
     // branch BatchNorms
-    if (exchange.is_none()) {
+    if (exchange.none()) {
     check_rc(slak_bn3_backward_local_to(ds.data_ptr(), yv.data_ptr(), yh.data_ptr(), ys.data_ptr(), fp(bnstats), gam, fpm(bcoef), dgam3, dbet3,
                                         d1.data_ptr(), d2.data_ptr(), d3.data_ptr(), s.N, s.C, s.P, ws.p, ws.n, st), "slak_bn3_backward_local_to");
     } else {
-        if (!work.is_none()) work.attr("wait")();                  // stream-side wait (RCCL) / host wait (gloo): the weight gradients are already queued
+        exchange.wait();                                           // (asynchronous form) stream-side wait (RCCL) / host wait (gloo): the weight gradients are already queued
         const bool has_cd = count_dev.has_value() && count_dev->defined();
         check_rc(slak_bn3_backward_apply_to(ds.data_ptr(), yv.data_ptr(), yh.data_ptr(), ys.data_ptr(), fp(gsums), fp(lsums), (double)s.N * (double)s.P,
                                             has_cd ? (const double*)count_dev->data_ptr() : nullptr, fp(bnstats), gam, fpm(bcoef), dgam3, dbet3,
@@ -416,4 +454,12 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     m.attr("abi_version") = SLAK_ABI_VERSION;
     m.def("block_forward", &block_forward, "one SLaK block, training forward (see slak_amd/block_ops._BlockFn)");
     m.def("block_backward", &block_backward, "its backward");
+    // tests: the statistics exchange alone (any device the group's backend takes) -> true when the ProcessGroup was called from C++
+    m.def("_exchange_probe", [](const pybind11::object& exchange, Tensor buf, bool async) {
+        Exchange e(exchange);
+        if (e.none()) return false;
+        e.run(buf, async);
+        e.wait();
+        return (bool)e.pg;
+    });
 }

@@ -284,3 +284,32 @@ def test_gradients_written_into_ddp_bucket_views_match_the_copy_path():
         assert all(n == 0 for n, _ in r["aliased_acc"][0::2]), r["aliased_acc"]
     for a, b in zip(r0["got"], r1["got"]):
         np.testing.assert_array_equal(a, b)                          # the ranks agree
+
+
+def _exchange_from_cpp(rank, world):
+    """The C++ block runner issues the SyncBatchNorm statistics all-reduce itself when it is handed the ProcessGroup (block_ops._runner_exchange):
+    the pybind cast of torch's ProcessGroup and the SUM, synchronous and asynchronous, against the callable form."""
+    from slak_amd import block_ops
+    R = block_ops._runner()
+    if R is None:
+        return None
+    pg = dist.group.WORLD
+    a = torch.arange(8, dtype=torch.float64) + 10 * rank
+    direct = R._exchange_probe(block_ops._runner_exchange(pg), a, False)
+    b = torch.arange(8, dtype=torch.float32) * (rank + 1)
+    direct2 = R._exchange_probe(pg, b, True)
+    c = torch.ones(4) * (rank + 1)
+    via_py = R._exchange_probe(lambda buf, async_op: block_ops._sync_bn_all_reduce(buf, pg, async_op=async_op), c, True)
+    return dict(direct=direct, direct2=direct2, via_py=via_py, a=a.numpy(), b=b.numpy(), c=c.numpy())
+
+
+def test_runner_issues_the_statistics_all_reduce_from_cpp():
+    import pytest
+    r0, r1 = _run(_exchange_from_cpp)
+    if r0 is None:
+        pytest.skip("the C++ block runner is not built")
+    for r in (r0, r1):
+        assert r["direct"] and r["direct2"] and not r["via_py"]
+        np.testing.assert_array_equal(r["a"], 2 * np.arange(8) + 10.0)
+        np.testing.assert_array_equal(r["b"], 3.0 * np.arange(8))
+        np.testing.assert_array_equal(r["c"], 3.0 * np.ones(4))
