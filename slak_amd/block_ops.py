@@ -1294,7 +1294,8 @@ _runner_trace = None          # tests: a callable(str) that the C++ runner calls
 _bn_bwd_async = os.environ.get("SLAK_BN_BWD_ASYNC", "0") == "1"            # 1: the backward exchange on the collective's own stream, overlapped with the two pointwise weight gradients (round 4-5 default).
 # Round 6 default: on the compute stream like the forward one -- measured on one MI355X over RCCL (--force-dist): 15.77 vs 16.03 ms per SLaK-T step, 25.62 vs 25.94 SLaK-B,
 # and ~1.4 ms less host time per step (no Work objects, no waits); the two stream hand-offs per block cost about what the overlap hides
-_pg_direct = os.environ.get("SLAK_PG_DIRECT", "1") != "0"                  # the runner calls ProcessGroup::allreduce itself (0: through _sync_bn_all_reduce)
+_pg_direct = os.environ.get("SLAK_PG_DIRECT", "0") == "1"                  # 1: the runner calls ProcessGroup::allreduce itself instead of calling back into _sync_bn_all_reduce.  Opt-in: measured on one MI355X over
+# RCCL it changes neither the step (16.59 vs 16.46 ms SLaK-T, 25.97 vs 26.11 SLaK-B) nor, beyond the noise, the host time -- dist.all_reduce's Python side is no longer the cost after round 6's direct group call
 _force_bn_exchange = os.environ.get("SLAK_FORCE_BN_EXCHANGE", "0") == "1"   # bench.py --force-dist: run the SyncBatchNorm exchange (the all-reduces) at world size 1 too
 
 

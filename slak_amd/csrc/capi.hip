@@ -243,6 +243,7 @@ int slak_dwconv2d_tri_supported_op(int dtype, int N, int C, int H, int W, int K,
     if (op != 0 && op != 1) return 0;
     if (dwconv_mfma_small_tri_supported(N, C, H, W, K, dtype)) return 1;
     if (op == 0 && dwconv_mfma_stream_tri_supported(N, C, H, W, K, dtype)) return 1;                        // planes of 2 x 2 tiles, forward: one MFMA stream per wave
+    if (dwconv_mfma_wide_tri_supported(N, C, H, W, K, dtype, op == 1)) return 1;                             // round 6: maps with 64 < H, W <= 96 (96 x 96: SLaK at 384 px)
     if (!dwconv_mfma_team_tri_supported(N, C, H, W, K, dtype, op == 1)) return 0;
     const bool one_tile = H <= 32 && W <= 32;
     static const bool all = [] { const char* e = slak_dev_getenv("SLAK_TEAM_ALL"); return e && e[0] == '1'; }();     // A/B: team kernels wherever they exist
@@ -261,6 +262,8 @@ int slak_dwconv2d_tri_forward(const void* x, const float* w_v, const float* w_h,
         return SLAK_RAN("dwconv_mfma_small_tri", launch_dwconv_mfma_small_tri(false, in, out, w, dtype, N, C, H, W, K, (hipStream_t)stream));
     if (dwconv_mfma_stream_tri_supported(N, C, H, W, K, dtype))
         return SLAK_RAN("dwconv_mfma_stream_tri", launch_dwconv_mfma_stream_tri(x, out, w, dtype, N, C, H, W, K, (hipStream_t)stream));
+    if (dwconv_mfma_wide_tri_supported(N, C, H, W, K, dtype, false))
+        return SLAK_RAN("dwconv_mfma_wide_tri", launch_dwconv_mfma_wide_tri(false, in, out, w, dtype, N, C, H, W, K, (hipStream_t)stream));
     return SLAK_RAN("dwconv_mfma_team_tri", launch_dwconv_mfma_team_tri(false, in, out, w, dtype, N, C, H, W, K, (hipStream_t)stream));
 }
 
@@ -304,6 +307,8 @@ int slak_dwconv2d_tri_backward_data(const void* dy_v, const void* dy_h, const vo
     const void* in[3] = {dy_v, dy_h, dy_s}; void* out[3] = {dx, dx, dx}; const float* w[3] = {w_v, w_h, w_s};
     if (dwconv_mfma_small_tri_supported(N, C, H, W, K, dtype))
         return SLAK_RAN("dwconv_mfma_small_tri", launch_dwconv_mfma_small_tri(true, in, out, w, dtype, N, C, H, W, K, (hipStream_t)stream));
+    if (dwconv_mfma_wide_tri_supported(N, C, H, W, K, dtype, true))
+        return SLAK_RAN("dwconv_mfma_wide_tri", launch_dwconv_mfma_wide_tri(true, in, out, w, dtype, N, C, H, W, K, (hipStream_t)stream));
     return SLAK_RAN("dwconv_mfma_team_tri", launch_dwconv_mfma_team_tri(true, in, out, w, dtype, N, C, H, W, K, (hipStream_t)stream));
 }
 

@@ -160,6 +160,10 @@ bool dwconv_mfma_stream_tri_supported(int N, int C, int H, int W, int K, int dty
 int dwconv_mfma_stream_tri_stats_rows(int N, int C, int H, int W, int K, int dtype);
 int launch_dwconv_mfma_stream_tri(const void* x, void* const* out, const float* const* w, int dtype,
                                   int N, int C, int H, int W, int K, hipStream_t st, float* stats = nullptr);
+// dwconv_mfma_wide_tri.hip: the three branches of a block in one launch on maps with 64 < H, W <= 96 (forward, data gradient)
+bool dwconv_mfma_wide_tri_supported(int N, int C, int H, int W, int K, int dtype, bool dgrad);
+int launch_dwconv_mfma_wide_tri(bool dgrad, const void* const* in, void* const* out, const float* const* w, int dtype,
+                                int N, int C, int H, int W, int K, hipStream_t st);
 bool dwconv_mfma_team_tri_supported(int N, int C, int H, int W, int K, int dtype, bool dgrad);
 int dwconv_mfma_team_tri_stats_rows(int N, int C, int H, int W, int K, int dtype);
 int launch_dwconv_mfma_team_tri(bool dgrad, const void* const* in, void* const* out, const float* const* w, int dtype,

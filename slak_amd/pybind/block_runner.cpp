@@ -60,6 +60,9 @@ struct Exchange {
     bool none() const { return !pg && !fn; }
     void run(Tensor& buf, bool async) {                            // SUM, in place
         if (pg) {
+            // WITHOUT the GIL: a backend that completes work on its own threads (gloo) may have to run a Python callback there first -- DistributedDataParallel's
+            // comm-hook futures -- and a host-blocking wait() under the GIL would starve it (two ranks over gloo deadlocked exactly so: round 6)
+            pybind11::gil_scoped_release nogil;
             c10d::AllreduceOptions opts;
             opts.reduceOp = c10d::ReduceOp::SUM;
             opts.asyncOp = async;
@@ -71,7 +74,7 @@ struct Exchange {
         }
     }
     void wait() {
-        if (work) { work->wait(); work = nullptr; }
+        if (work) { pybind11::gil_scoped_release nogil; work->wait(); work = nullptr; }
         if (!pywork.is_none()) { pywork.attr("wait")(); pywork = pybind11::none(); }
     }
 };

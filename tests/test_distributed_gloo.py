@@ -295,7 +295,10 @@ def _exchange_from_cpp(rank, world):
         return None
     pg = dist.group.WORLD
     a = torch.arange(8, dtype=torch.float64) + 10 * rank
+    block_ops._pg_direct = True                                    # (opt-in: SLAK_PG_DIRECT=1)
     direct = R._exchange_probe(block_ops._runner_exchange(pg), a, False)
+    block_ops._pg_direct = False
+    assert callable(block_ops._runner_exchange(pg))
     b = torch.arange(8, dtype=torch.float32) * (rank + 1)
     direct2 = R._exchange_probe(pg, b, True)
     c = torch.ones(4) * (rank + 1)

@@ -172,12 +172,12 @@ TRI_SMALL = [(5, 7, 14, 14, 47), (4, 3, 12, 10, 9), (1, 1, 14, 14, 13), (6, 5, 7
 
 
 def test_shapes_without_a_three_branch_launch_say_so(gpu):
-    """Maps beyond 64, planes whose width is not a multiple of 8 above 32, fp32: the support query is 0 and the entry points refuse
+    """Maps beyond 96 (round 6: 64 < H, W <= 96 in multiples of 16 have the wide three-branch kernel), planes whose width is not a multiple of 8 above 32, fp32: the support query is 0 and the entry points refuse
     instead of running something else (block_ops.tri_dwconv then issues the three per-branch launches:
     tests/test_mfma_gpu.py::test_tri_dwconv_matches_the_three_branch_convs covers those shapes).  64 x 64 planes have a forward
     kernel (the stream kernel) and no data-gradient one: each op answers for itself."""
     L = _L(); lib = L.lib()
-    for (N, C, H, W, K) in [(3, 2, 96, 96, 61), (2, 2, 36, 36, 31)]:
+    for (N, C, H, W, K) in [(3, 2, 128, 128, 61), (2, 2, 36, 36, 31), (2, 2, 96, 88, 61)]:
         assert lib.slak_dwconv2d_tri_supported(L.SLAK_BF16, N, C, H, W, K) == 0
         x = torch.randn(N, C, H, W, device=gpu).bfloat16()
         ws = _filters(C, K, gpu, 1)
@@ -228,6 +228,46 @@ def test_tri_forward_and_backward_data_vs_oracle(N, C, H, W, K, dtype, gpu):
     # accumulator rounds only the sum: half an ulp of every value that is rounded, plus accumulation noise
     bound = ulp * (np.abs(ref) + sum(np.abs(p) for p in parts)) + 5e-6 * scale
     assert (np.abs(got - ref) <= bound).all(), float((np.abs(got - ref) - bound).max())
+
+
+# round 6: maps with 64 < H, W <= 96 (dwconv_mfma_wide_tri.hip): the 96 x 96 planes of SLaK at 384 px, 80-wide maps (two and a half tiles: lanes beyond
+# the map), short filters (narrow band: fewer blocks per tile), and a batch that makes workgroup ranges cross a channel boundary (fragments rebuilt in mid-stream)
+TRI_WIDE = [(3, 2, 96, 96, 61), (1, 1, 96, 96, 13), (2, 2, 80, 96, 33), (2, 3, 96, 80, 51), (2, 2, 80, 80, 61), (131, 3, 80, 80, 31)]
+
+
+@pytest.mark.parametrize("N,C,H,W,K", TRI_WIDE)
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_tri_forward_and_backward_data_on_wide_maps_vs_oracle(N, C, H, W, K, dtype, gpu):
+    L = _L()
+    assert L.lib().slak_dwconv2d_tri_supported(_dt(dtype), N, C, H, W, K) == 1
+    torch.manual_seed(N * 100 + H + K)
+    x = torch.randn(N, C, H, W, device=gpu).to(dtype)
+    dys = [torch.randn(N, C, H, W, device=gpu).to(dtype) for _ in range(3)]
+    ws = _filters(C, K, gpu, K + C)
+    wr = [_r(w, dtype) for w in ws]
+    ys, _ = _tri_fwd(x, ws, K)
+    assert L.lib().slak_debug_last_kernel().decode() == "dwconv_mfma_wide_tri"
+    xr = _r(x, dtype)
+    for y, w, name in zip(ys, wr, ("Kx5", "5xK", "5x5")):
+        _check_lowp(y, oracle.dwconv2d_fwd(xr, w), dtype, "wide tri fwd " + name)
+    dx = _tri_dgrad(dys, ws, K)
+    assert L.lib().slak_debug_last_kernel().decode() == "dwconv_mfma_wide_tri"
+    parts = [oracle.dwconv2d_bwd_data(_r(d, dtype), w) for d, w in zip(dys, wr)]
+    ref = sum(parts)
+    got = dx.detach().double().cpu().numpy()
+    scale = max(1.0, float(np.abs(ref).max()))
+    ulp = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11
+    assert np.abs(got - ref).max() <= 1e-2 * scale
+    bound = ulp * np.abs(ref) + 1e-5 * scale                        # the three partial gradients are added in the accumulator: ONE rounding
+    assert (np.abs(got - ref) <= bound).all(), float((np.abs(got - ref) - bound).max())
+    # run to run identical, and a non-finite value stays inside its own plane (the slots' guard rows and the lanes beyond the map never reach another plane's sums)
+    ys2, _ = _tri_fwd(x, ws, K)
+    assert all(torch.equal(a, b) for a, b in zip(ys, ys2)) and torch.equal(dx, _tri_dgrad(dys, ws, K))
+    if N > 1:
+        xn = x.clone(); xn[0, 0, H - 1, W - 1] = float("nan"); xn[0, 0, 0, 0] = float("inf")
+        yn, _ = _tri_fwd(xn, ws, K)
+        for a, b in zip(ys, yn):
+            assert torch.equal(a[1:], b[1:]) and (C == 1 or torch.equal(a[0, 1:], b[0, 1:]))
 
 
 @pytest.mark.parametrize("N,C,H,W,K", [(5, 7, 14, 14, 47), (6, 5, 7, 7, 13), (17, 6, 7, 7, 13), (4, 3, 12, 10, 9), (9, 4, 12, 12, 13), (1, 1, 14, 14, 13)])
@@ -362,7 +402,8 @@ BENCH_PAIR = [(128, 96, 56, 56, 51), (128, 192, 28, 28, 49),             # BASEL
               (64, 192, 48, 48, 59), (64, 384, 24, 24, 57)]              # configs[4] 61 x 61 at 384 px, stages 2, 3
 BENCH_TRI = [(128, 96, 56, 56, 51), (128, 192, 28, 28, 49), (128, 384, 14, 14, 47), (128, 768, 7, 7, 13),
              (64, 128, 56, 56, 51), (64, 512, 14, 14, 47), (64, 1024, 7, 7, 13),
-             (64, 192, 48, 48, 59), (64, 384, 24, 24, 57), (64, 768, 12, 12, 13)]
+             (64, 192, 48, 48, 59), (64, 384, 24, 24, 57), (64, 768, 12, 12, 13),
+             (64, 96, 96, 96, 61)]                                  # round 6: configs[4] stage 1 (dwconv_mfma_wide_tri: forward and data gradient in one launch each)
 
 
 @pytest.mark.parametrize("N,C,H,W,K", BENCH_PAIR)
