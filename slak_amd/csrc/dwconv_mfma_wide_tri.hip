@@ -87,10 +87,15 @@ __device__ __forceinline__ f32x16 wt_small_tile(const s16x8 (&af)[MF_TAPS][WT_ND
 #undef SLAK_WT_CASE
 }
 
+constexpr int WT_MAXDMA = 20;           // DMA instructions per plane copy at most (96 rows x 13 chunks / 64)
+constexpr int WT_MAXTR = 36;            // transpose blocks per 16-lane group of the server wave at most (24 row bands x 6 column blocks / 4)
+constexpr unsigned WT_NONE = 0xffffffffu;
+
 template <typename T, bool DGRAD>
 __global__ __launch_bounds__(MF_THREADS, 1) void dwconv_mfma_wide_tri_kernel(const WideTriParams p) {
     extern __shared__ __attribute__((aligned(16))) uint16_t lds[];
     char* const L = (char*)lds;
+    constexpr int R = DGRAD ? 2 : 3;                                  // ring slots of the row-major inputs (forward: the DMA runs two planes ahead)
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, lhi = lane >> 5;
     const int wave = wave_id_uniform();
     const int q0 = blockIdx.x * p.per;
@@ -100,9 +105,9 @@ __global__ __launch_bounds__(MF_THREADS, 1) void dwconv_mfma_wide_tri_kernel(con
     const int HW = p.H * p.W;
     const unsigned pitch = (unsigned)p.cdh * 16u, xpitch = (unsigned)p.PT * 2u;
     // ---- LDS map (byte offsets) ---------------------------------------------------------------------------------------------
-    const unsigned h_b = 0;                                           // [2] row-major slots: x (forward) / dy of the horizontal branch
-    const unsigned s_b = h_b + 2u * (unsigned)p.slot_h;               // [2] data gradient: dy of the 5 x 5 branch
-    const unsigned v_b = s_b + (DGRAD ? 2u * (unsigned)p.slot_h : 0u);   // data gradient: dy of the vertical branch, compact
+    const unsigned h_b = 0;                                           // [R] row-major slots: x (forward) / dy of the horizontal branch
+    const unsigned s_b = h_b + (unsigned)R * (unsigned)p.slot_h;      // [R] data gradient: dy of the 5 x 5 branch
+    const unsigned v_b = s_b + (DGRAD ? (unsigned)R * (unsigned)p.slot_h : 0u);   // data gradient: dy of the vertical branch, compact
     const unsigned xt_b = v_b + (DGRAD ? (unsigned)p.slot_v : 0u);    // [2] x^T (the vertical branch's operand)
     const unsigned st_b = xt_b + 2u * (unsigned)p.xt_bytes;           // [3] staging tiles
     const unsigned win_b = st_b + 3u * WT_STB;                        // [3 branches] filter windows
@@ -110,61 +115,96 @@ __global__ __launch_bounds__(MF_THREADS, 1) void dwconv_mfma_wide_tri_kernel(con
     for (unsigned o = tid * 16; o < lds_end; o += MF_THREADS * 16) *(u32x4*)(L + o) = u32x4{0u, 0u, 0u, 0u};
     wg_barrier();
 
-    // ---- the plane server's tools (wave 3) ------------------------------------------------------------------------------------
-    v4i_t rs[3];
+    // The barriers of the two roles below pair up one to one: per plane ONE (the hand-over), and at a channel boundary of the range three more
+    // (windows free -> cleared -> written), in the same order in both loops.
+    if (wave == 3) {
+        // =================== the plane server ===================
+        v4i_t rs[3];
 #pragma unroll
-    for (int t = 0; t < 3; ++t) {
-        const uint64_t a = (uint64_t)p.in[DGRAD ? t : 0];
-        rs[t][0] = __builtin_amdgcn_readfirstlane((int)(a & 0xffffffffu)); rs[t][1] = __builtin_amdgcn_readfirstlane((int)((a >> 32) & 0xffffu));
-        rs[t][2] = __builtin_amdgcn_readfirstlane((int)p.tensor_bytes); rs[t][3] = 0x00020000;
+        for (int t = 0; t < 3; ++t) {
+            const uint64_t a = (uint64_t)p.in[DGRAD ? t : 0];
+            rs[t][0] = __builtin_amdgcn_readfirstlane((int)(a & 0xffffffffu)); rs[t][1] = __builtin_amdgcn_readfirstlane((int)((a >> 32) & 0xffffu));
+            rs[t][2] = __builtin_amdgcn_readfirstlane((int)p.tensor_bytes); rs[t][3] = 0x00020000;
+        }
+        const unsigned lds_base = (unsigned)(uintptr_t)SLAK_LDS(uint16_t, lds);
+        // Destination chunk g = 64 k + lane of an image with cd chunks per row takes source chunk (g / cd) * cs + g % cd; pad chunks and rows
+        // beyond the image are skipped lanes (inactive lanes write nothing).  The per-lane source offsets do not depend on the plane: once.
+        unsigned offh[WT_MAXDMA], offv[DGRAD ? WT_MAXDMA : 1];
+#pragma unroll
+        for (int k = 0; k < WT_MAXDMA; ++k) {
+            const int g = k * 64 + lane;
+            { const int row = g / p.cdh, cc = g - row * p.cdh; offh[k] = (k < p.ninh && cc < p.cs && row < p.H) ? (unsigned)(row * p.cs + cc) * 16u : WT_NONE; }
+            if constexpr (DGRAD) { const int row = g / p.cdv, cc = g - row * p.cdv; offv[k] = (k < p.ninv && cc < p.cs && row < p.H) ? (unsigned)(row * p.cs + cc) * 16u : WT_NONE; }
+        }
+        // x^T: block (4 image rows kb, 16 image columns cb) by one ds_read_b64_tr_b16 of a 16-lane group (lane i16 supplies row 4 kb + i16 / 4, columns
+        // 16 cb + 4 (i16 % 4) .. + 3 and receives column 16 cb + i16, rows 4 kb .. + 3) and one 8-byte write (x^T row = image column + 2 guard rows).
+        // Group grp takes blocks grp, grp + 4, ..: the offsets of its blocks, once.
+        const unsigned tr_sp = DGRAD ? (unsigned)p.cdv * 16u : pitch;
+        unsigned tsrc[WT_MAXTR], tdst[WT_MAXTR];
+        {
+            const int grp = lane >> 4, i16 = lane & 15, total = (p.H >> 2) * p.trc;
+#pragma unroll
+            for (int j = 0; j < WT_MAXTR; ++j) {
+                const int b = grp + 4 * j, kb = b / p.trc, cb = b - kb * p.trc, col = cb * 16 + i16;
+                tsrc[j] = (unsigned)(kb * 4 + (i16 >> 2)) * tr_sp + (unsigned)(cb * 32 + (i16 & 3) * 8);
+                tdst[j] = (b < total && col < p.W) ? (unsigned)((2 + col) * p.PT + kb * 4) * 2u : WT_NONE;
+                if (b >= total) tsrc[j] = 0;
+            }
+        }
+        auto plane_off = [&](int q) -> unsigned { const int c = q / p.N, n = q - c * p.N; return (unsigned)(((size_t)n * p.C + c) * HW * 2); };
+        auto issue = [&](int it) {                                    // every input of plane q0 + it
+            if (it >= iters) return;
+            const unsigned src0 = plane_off(q0 + it), slot = (unsigned)(it % R) * (unsigned)p.slot_h;
+#pragma unroll
+            for (int k = 0; k < WT_MAXDMA; ++k) {
+                if (k < p.ninh) {                                       // wave-uniform
+                    const unsigned d = lds_base + h_b + slot + 2u * pitch + (unsigned)k * 1024u;
+                    if (offh[k] != WT_NONE) lds_dma16(src0 + offh[k], rs[DGRAD ? 1 : 0], __builtin_amdgcn_readfirstlane(d));
+                    if constexpr (DGRAD) if (offh[k] != WT_NONE) lds_dma16(src0 + offh[k], rs[2], __builtin_amdgcn_readfirstlane(d + (s_b - h_b)));
+                }
+                if constexpr (DGRAD) if (k < p.ninv && offv[k] != WT_NONE) lds_dma16(src0 + offv[k], rs[0], __builtin_amdgcn_readfirstlane(lds_base + v_b + (unsigned)k * 1024u));
+            }
+        };
+        auto transpose = [&](int it) {
+            if (it >= iters) return;
+            const unsigned src_b = DGRAD ? v_b : h_b + (unsigned)(it % R) * (unsigned)p.slot_h + 2u * pitch;
+            const unsigned dst_b = xt_b + (unsigned)(it & 1) * (unsigned)p.xt_bytes;
+#pragma unroll
+            for (int j0 = 0; j0 < WT_MAXTR; j0 += 6) {               // six reads in flight, then their writes
+                s16x4 v[6];
+#pragma unroll
+                for (int j = 0; j < 6; ++j) v[j] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(SLAK_LDS(s16x4, L + src_b + tsrc[j0 + j]));
+#pragma unroll
+                for (int j = 0; j < 6; ++j) if (tdst[j0 + j] != WT_NONE) *(s16x4*)(L + dst_b + tdst[j0 + j]) = v[j];
+            }
+        };
+        const int dma_per_plane = DGRAD ? 2 * p.ninh + p.ninv : p.ninh;   // (every instruction has at least one active lane: it is issued)
+        issue(0);
+        if constexpr (!DGRAD) issue(1);
+        int c_cur = -1, c = q0 / p.N, n = q0 - c * p.N;
+        for (int it = 0; it < iters; ++it) {
+            if (c != c_cur) {
+                if (c_cur >= 0) { wg_barrier(); wg_barrier(); }
+                wg_barrier();
+                c_cur = c;
+            }
+            if (it == 0) { wait_vmcnt_dyn((!DGRAD && iters > 1) ? dma_per_plane : 0); transpose(0); }
+            wg_barrier();                                             // plane `it` has landed and its x^T is complete; everyone is done with plane it - 1
+            if constexpr (DGRAD) {
+                issue(it + 1);                                        // into the slots plane it - 1 has left (the compact one was transposed before the barrier)
+                wait_vmcnt<0>();
+            } else {
+                issue(it + 2);                                        // (ring of three: plane it + 1 has been on its way since the last iteration)
+                wait_vmcnt_dyn(it + 2 < iters ? dma_per_plane : 0);  // loads retire in order: at most plane it + 2's are outstanding
+            }
+            transpose(it + 1);
+            if (++n == p.N) { n = 0; ++c; }
+        }
+        return;
     }
-    const unsigned lds_base = (unsigned)(uintptr_t)SLAK_LDS(uint16_t, lds);
-    // destination chunk g = 64 k + lane of an image with cd chunks per row takes source chunk (g / cd) * cs + g % cd; pad chunks are skipped lanes
-    auto dma_plane = [&](unsigned src0, v4i_t rsrc, unsigned dst, int cd, int nin) {
-        int row = lane / cd, cc = lane - row * cd;
-        const int inc_r = 64 / cd, inc_c = 64 % cd;
-        for (int k = 0; k < nin; ++k) {
-            if (cc < p.cs && row < p.H) lds_dma16(src0 + (unsigned)(row * p.cs + cc) * 16u, rsrc, __builtin_amdgcn_readfirstlane(dst));
-            dst += 1024u;
-            cc += inc_c; row += inc_r;
-            if (cc >= cd) { cc -= cd; ++row; }
-        }
-    };
-    auto plane_off = [&](int q) -> unsigned { const int c = q / p.N, n = q - c * p.N; return (unsigned)(((size_t)n * p.C + c) * HW * 2); };
-    auto issue = [&](int it) {                                        // every input of plane q0 + it
-        if (it >= iters) return;
-        const unsigned src0 = plane_off(q0 + it), par = (unsigned)(it & 1) * (unsigned)p.slot_h;
-        if constexpr (DGRAD) {
-            dma_plane(src0, rs[1], lds_base + h_b + par + 2u * pitch, p.cdh, p.ninh);
-            dma_plane(src0, rs[2], lds_base + s_b + par + 2u * pitch, p.cdh, p.ninh);
-            dma_plane(src0, rs[0], lds_base + v_b, p.cdv, p.ninv);
-        } else {
-            dma_plane(src0, rs[0], lds_base + h_b + par + 2u * pitch, p.cdh, p.ninh);
-        }
-    };
-    // x^T of plane `it`: block (4 image rows kb, 16 image columns cb) by one ds_read_b64_tr_b16 of a 16-lane group (lane i16 supplies row 4 kb + i16 / 4,
-    // columns 16 cb + 4 (i16 % 4) .. + 3 and receives column 16 cb + i16, rows 4 kb .. + 3) and one 8-byte write (x^T row = image column + 2 guard rows)
-    auto transpose = [&](int it) {
-        if (it >= iters) return;
-        const unsigned src_b = DGRAD ? v_b : h_b + (unsigned)(it & 1) * (unsigned)p.slot_h + 2u * pitch;
-        const unsigned sp = DGRAD ? (unsigned)p.cdv * 16u : pitch;
-        const unsigned dst_b = xt_b + (unsigned)(it & 1) * (unsigned)p.xt_bytes;
-        const int grp = lane >> 4, i16 = lane & 15;
-        const int total = (p.H >> 2) * p.trc;
-        int b = grp, kb = grp / p.trc, cb = grp - kb * p.trc;
-        for (; b < total; b += 4) {
-            const unsigned src = src_b + (unsigned)(kb * 4 + (i16 >> 2)) * sp + (unsigned)(cb * 32 + (i16 & 3) * 8);
-            const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16(SLAK_LDS(s16x4, L + src));
-            const int col = cb * 16 + i16;
-            if (col < p.W) *(s16x4*)(L + dst_b + (unsigned)((2 + col) * p.PT + kb * 4) * 2u) = v;
-            cb += 4;
-            while (cb >= p.trc) { cb -= p.trc; ++kb; }
-        }
-    };
-    if (wave == 3) issue(0);
 
-    // ---- the compute waves' constants -------------------------------------------------------------------------------------------
-    const int mt = wave;                                              // column block (waves 0..2)
+    // =================== the compute waves (0..2: column block mt of all three branches) ===================
+    const int mt = wave;
     // block ranges: tile t of a long axis with KS k-steps and a filter of KL taps meets blocks dd with 0 <= 2 t + dd - 2 < KS inside the band
     auto range = [](int t, int KS, int KL, int& lo, int& hi) {
         const int padL = KL / 2;
@@ -179,67 +219,57 @@ __global__ __launch_bounds__(MF_THREADS, 1) void dwconv_mfma_wide_tri_kernel(con
     range(mt, p.KSc, p.K, lo_h, hi_h);
     range(mt, p.KSc, MF_TAPS, lo_s, hi_s);
     s16x8 fh[MF_TAPS][WT_ND], fv[MF_TAPS][WT_ND], fs[MF_TAPS][WT_NDS];
-    char* const stg = L + st_b + (unsigned)(wave < 3 ? wave : 0) * WT_STB;
+    char* const stg = L + st_b + (unsigned)wave * WT_STB;
+    const int t192 = wave * 64 + lane;
 
-    int c_cur = -1;
-    int c = q0 / p.N, n = q0 - c * p.N;
+    int c_cur = -1, c = q0 / p.N, n = q0 - c * p.N;
     for (int it = 0; it < iters; ++it) {
         if (c != c_cur) {
             // ---- a new channel: filter windows (two copies one element apart: every 8-element window is dword aligned), then this wave's fragments
             if (c_cur >= 0) {
-                wg_barrier();                                         // (everyone is done with the old fragments' windows -- they are only read right below)
-                for (unsigned o = tid * 16; o < 3u * WT_WIN; o += MF_THREADS * 16) *(u32x4*)(L + win_b + o) = u32x4{0u, 0u, 0u, 0u};
+                wg_barrier();                                         // (nobody reads the old windows any more)
+                for (unsigned o = (unsigned)t192 * 16; o < 3u * WT_WIN; o += 192 * 16) *(u32x4*)(L + win_b + o) = u32x4{0u, 0u, 0u, 0u};
                 wg_barrier();
             }
-            if (wave < 3) {
-                const int t192 = wave * 64 + lane;
 #pragma unroll
-                for (int br = 0; br < 3; ++br) {
-                    const int kh = br == 0 ? p.K : MF_TAPS, kw = br == 1 ? p.K : MF_TAPS, ntap = kh * kw, KL = br == 2 ? MF_TAPS : p.K;
-                    uint16_t* win = (uint16_t*)(L + win_b + (unsigned)br * WT_WIN);
-                    for (int e = t192; e < ntap; e += 192) {
-                        int r = br == 0 ? e % MF_TAPS : e / kw, t = br == 0 ? e / MF_TAPS : e - (e / kw) * kw;      // short tap r, long tap t
-                        if (DGRAD) { r = MF_TAPS - 1 - r; t = KL - 1 - t; }   // the data gradient is the correlation with the filter rotated by 180 degrees
-                        const uint16_t v = cvt_to_bits(p.w[br][(size_t)c * ntap + e], (T*)nullptr);
-                        win[r * WT_LEN + WT_ZP + t] = v;
-                        win[MF_TAPS * WT_LEN + r * WT_LEN + WT_ZP + t - 1] = v;
-                    }
+            for (int br = 0; br < 3; ++br) {
+                const int kh = br == 0 ? p.K : MF_TAPS, kw = br == 1 ? p.K : MF_TAPS, ntap = kh * kw, KL = br == 2 ? MF_TAPS : p.K;
+                uint16_t* win = (uint16_t*)(L + win_b + (unsigned)br * WT_WIN);
+                for (int e = t192; e < ntap; e += 192) {
+                    int r = br == 0 ? e % MF_TAPS : e / kw, t = br == 0 ? e / MF_TAPS : e - (e / kw) * kw;      // short tap r, long tap t
+                    if (DGRAD) { r = MF_TAPS - 1 - r; t = KL - 1 - t; }       // the data gradient is the correlation with the filter rotated by 180 degrees
+                    const uint16_t v = cvt_to_bits(p.w[br][(size_t)c * ntap + e], (T*)nullptr);
+                    win[r * WT_LEN + WT_ZP + t] = v;
+                    win[MF_TAPS * WT_LEN + r * WT_LEN + WT_ZP + t - 1] = v;
                 }
             }
             wg_barrier();
-            if (wave < 3) {
-                // lane (l31 -> o within the tile, lhi -> k half) of block d holds the 8-element window that starts at 16 d + 8 lhi - l31 + padL
-                auto build = [&](auto& f, int nd, int d0, unsigned wb, int padL) {
+            // lane (l31 -> o within the tile, lhi -> k half) of block d holds the 8-element window that starts at 16 d + 8 lhi - l31 + padL
+            auto build = [&](auto& f, int nd, int d0, unsigned wb, int padL) {
 #pragma unroll
-                    for (int dd = 0; dd < nd; ++dd) {
-                        const int a = WT_ZP + 16 * (dd + d0 - 2) + lhi * 8 - l31 + padL;
-                        const int par = a & 1;
-                        const unsigned* src = (const unsigned*)(L + wb + par * MF_TAPS * WT_LEN * 2) + ((a - par) >> 1);
+                for (int dd = 0; dd < nd; ++dd) {
+                    const int a = WT_ZP + 16 * (dd + d0 - 2) + lhi * 8 - l31 + padL;
+                    const int par = a & 1;
+                    const unsigned* src = (const unsigned*)(L + wb + par * MF_TAPS * WT_LEN * 2) + ((a - par) >> 1);
 #pragma unroll
-                        for (int r = 0; r < MF_TAPS; ++r) {
-                            u32x4 d4;
+                    for (int r = 0; r < MF_TAPS; ++r) {
+                        u32x4 d4;
 #pragma unroll
-                            for (int k = 0; k < 4; ++k) d4[k] = src[r * (WT_LEN / 2) + k];
-                            f[r][dd] = __builtin_bit_cast(s16x8, d4);
-                        }
+                        for (int k = 0; k < 4; ++k) d4[k] = src[r * (WT_LEN / 2) + k];
+                        f[r][dd] = __builtin_bit_cast(s16x8, d4);
                     }
-                };
-                build(fv, WT_ND, 0, win_b, p.padL);
-                build(fh, WT_ND, 0, win_b + WT_WIN, p.padL);
-                build(fs, WT_NDS, 1, win_b + 2u * WT_WIN, MF_TAPS / 2);
-            }
+                }
+            };
+            build(fv, WT_ND, 0, win_b, p.padL);
+            build(fh, WT_ND, 0, win_b + WT_WIN, p.padL);
+            build(fs, WT_NDS, 1, win_b + 2u * WT_WIN, MF_TAPS / 2);
             c_cur = c;
         }
-        if (wave == 3 && it == 0) { wait_vmcnt<0>(); transpose(0); }
-        wg_barrier();                                                 // plane `it` has landed and its x^T is complete; everyone is done with plane it - 1
-        if (wave == 3) {
-            issue(it + 1);                                            // into the slots plane it - 1 has left
-            wait_vmcnt<0>();
-            transpose(it + 1);
-        } else {
-            const unsigned par = (unsigned)(it & 1);
-            const unsigned img_h = h_b + par * (unsigned)p.slot_h, img_s = DGRAD ? s_b + par * (unsigned)p.slot_h : img_h;
-            const unsigned img_v = xt_b + par * (unsigned)p.xt_bytes;
+        wg_barrier();                                                 // plane `it` has landed and its x^T is complete
+        {
+            const unsigned slot = (unsigned)(it % R) * (unsigned)p.slot_h;
+            const unsigned img_h = h_b + slot, img_s = DGRAD ? s_b + slot : img_h;
+            const unsigned img_v = xt_b + (unsigned)(it & 1) * (unsigned)p.xt_bytes;
             const size_t plane = ((size_t)n * p.C + c) * HW;
             for (int s = 0; s < p.MTr; ++s) {
                 // horizontal / 5 x 5: tap r, block dd = 16 bytes at row 32 s + l31 + r of the guarded image, columns 16 ks + 8 lhi ..  (ks = 2 mt - 2 + dd)
@@ -306,15 +336,16 @@ static bool fill_wide_tri_params(WideTriParams& p, int N, int C, int H, int W, i
     p.cs = W / 8;
     p.cdh = p.cs | 1;                                                 // row-per-lane b128 reads: odd chunk pitch
     p.ninh = (H * p.cdh + 63) / 64;
-    p.slot_h = (p.MTr * 32 + 4 + 4) * p.cdh * 16;                     // 2 guard rows on either side; rows up to 32 MTr + 4 are read (lanes beyond H: results dropped)
+    p.slot_h = (p.MTr * 32 + 4) * p.cdh * 16;                         // the image behind 2 guard rows; rows up to 32 MTr + 3 are read (lanes beyond H: results dropped)
     p.cdv = p.cs; while (p.cdv % 16 != 4 && p.cdv % 16 != 12) ++p.cdv;   // transposing reads: pitch = +-64 bytes mod 256
     p.ninv = (H * p.cdv + 63) / 64;
     p.slot_v = dgrad ? (int)align_up((size_t)p.ninv * 1024, 16) : 0;
     if (dgrad && p.slot_v < H * p.cdv * 16) return false;
     p.PT = p.MTr * 32 + 8;
-    p.xt_bytes = (96 + 4 + 4) * p.PT * 2;                             // x^T rows: image columns + 2 + 2 guards; rows up to 32 * 3 + 4 are read
+    p.xt_bytes = (96 + 4) * p.PT * 2;                                 // x^T rows: image columns behind 2 guard rows; rows up to 32 * 3 + 3 are read
     p.trc = (W + 15) / 16;
-    if ((size_t)p.ninh * 1024 > (size_t)p.slot_h - 2 * p.cdh * 16) return false;          // the DMA instructions of a plane stay inside its slot
+    if (p.ninh > WT_MAXDMA || p.ninv > WT_MAXDMA || ((H >> 2) * p.trc + 3) / 4 > WT_MAXTR) return false;
+    if ((H + 4) * p.cdh * 16 > p.slot_h) return false;
     const long long P = (long long)N * C;
     if (P >= 0x40000000ll) return false;
     if (wgs < 1) wgs = 1;
@@ -325,7 +356,7 @@ static bool fill_wide_tri_params(WideTriParams& p, int N, int C, int H, int W, i
 }
 
 static size_t wide_tri_lds_bytes(const WideTriParams& p, bool dgrad) {
-    return (size_t)2 * p.slot_h + (dgrad ? (size_t)2 * p.slot_h + p.slot_v : 0) + (size_t)2 * p.xt_bytes + 3 * WT_STB + 3 * WT_WIN;
+    return (size_t)(dgrad ? 4 : 3) * p.slot_h + (dgrad ? (size_t)p.slot_v : 0) + (size_t)2 * p.xt_bytes + 3 * WT_STB + 3 * WT_WIN;
 }
 
 bool dwconv_mfma_wide_tri_supported(int N, int C, int H, int W, int K, int dtype, bool dgrad) {
