@@ -45,10 +45,46 @@ struct WideTriParams {
     unsigned tensor_bytes;
 };
 
+// The store of a finished tile, cut into steps that ride behind the MFMAs of the NEXT tile (one wave per SIMD: nothing else hides them).
+// lane = row l31 of the tile, register quad q = columns 8 q + 4 lhi .. + 3: through the wave's staging tile (a wave's LDS operations execute in
+// order: the reads below see the writes above them without a wait) to two 16-byte stores per lane, 64 contiguous bytes per row.
+template <typename T>
+struct WtStore {
+    f32x16 acc; char* stg; __amdgpu_buffer_rsrc_t rsrc; unsigned soff, go0, go1; u32x4 r0, r1;
+    // rsrc: the output tensor; soff: the plane's byte offset in it (wave-uniform); go0 / go1: this lane's two 16-byte pieces in the plane (row
+    // 32 s + lane / 4 resp. 16 rows further down, columns 32 mt + 8 (lane % 4)) -- or an out-of-range offset: the buffer range check drops the
+    // store, so nothing in the MFMA stream is conditional (a branch inside the pinned pipeline makes hipcc spill the fragments)
+    __device__ __forceinline__ void arm(const f32x16& a, char* staging, __amdgpu_buffer_rsrc_t out, unsigned plane_off, int s, int mt, int lane, int H, int W, bool live) {
+        acc = a; stg = staging; rsrc = out; soff = plane_off;
+        const int row0 = lane >> 2, c4 = lane & 3, gc = mt * 32 + c4 * 8;
+        const unsigned g = (unsigned)((s * 32 + row0) * W + gc) * 2u;
+        go0 = (live && s * 32 + row0 < H && gc < W) ? g : 0x80000000u;
+        go1 = (live && s * 32 + row0 + 16 < H && gc < W) ? g + (unsigned)(16 * W) * 2u : 0x80000000u;
+    }
+    __device__ __forceinline__ void step(int k, int l31, int lhi, int lane) {
+        if (k < 4) {
+            u32x2 v;
+            v[0] = pack2<T>(acc[4 * k + 0], acc[4 * k + 1]);
+            v[1] = pack2<T>(acc[4 * k + 2], acc[4 * k + 3]);
+            *(u32x2*)(stg + (unsigned)l31 * WT_STP + (unsigned)(8 * lhi + 16 * k)) = v;
+        } else if (k == 4) {                                            // (a wave's LDS operations execute in order: no wait between the writes and these reads)
+            asm volatile("" ::: "memory");
+            const unsigned o = (unsigned)(lane >> 2) * WT_STP + (unsigned)(lane & 3) * 16u;
+            r0 = *(const u32x4*)(stg + o); r1 = *(const u32x4*)(stg + o + 16u * WT_STP);
+            asm volatile("" ::: "memory");
+        } else if (k == 7) {                                            // three MFMAs later: the reads have returned
+            __builtin_amdgcn_raw_buffer_store_b128(r0, rsrc, go0, soff, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(r1, rsrc, go1, soff, 0);
+        }
+    }
+};
+constexpr int WT_STEPS = 8;
+
 // One 32 x 32 tile of one branch: blocks dd = LO..HI (the fragment array starts at block DOFF), five short taps each, added into `acc`.
-// The pinned software pipeline of dwconv_mfma_wide.hip: the fragment of tap r for the next block is fetched right behind this block's MFMA of tap r.
-template <typename T, bool VERT, int ND, int DOFF, int LO, int HI>
-__device__ __forceinline__ f32x16 wt_tile(const s16x8 (&af)[MF_TAPS][ND], const char* L, unsigned rp, unsigned rpitch, f32x16 acc) {
+// The pinned software pipeline of dwconv_mfma_wide.hip: the fragment of tap r for the next block is fetched right behind this block's MFMA of tap r;
+// behind MFMA j also step j of the previous tile's store.
+template <typename T, bool VERT, bool FILL, int ND, int DOFF, int LO, int HI>
+__device__ __forceinline__ f32x16 wt_tile(const s16x8 (&af)[MF_TAPS][ND], const char* L, unsigned rp, unsigned rpitch, f32x16 acc, WtStore<T>& st, int l31, int lhi, int lane) {
     s16x8 b[MF_TAPS];
 #pragma unroll
     for (int r = 0; r < MF_TAPS; ++r) b[r] = __builtin_bit_cast(s16x8, *(const u32x4*)(L + rp + (unsigned)r * rpitch + LO * 32u));
@@ -59,30 +95,47 @@ __device__ __forceinline__ f32x16 wt_tile(const s16x8 (&af)[MF_TAPS][ND], const 
         for (int r = 0; r < MF_TAPS; ++r) {
             acc = VERT ? mfma32<T>(b[r], af[r][dd - DOFF], acc) : mfma32<T>(af[r][dd - DOFF], b[r], acc);
             if (dd < HI) b[r] = __builtin_bit_cast(s16x8, *(const u32x4*)(L + rp + (unsigned)r * rpitch + (dd + 1) * 32u));
+            if constexpr (FILL) if ((dd - LO) * MF_TAPS + r < WT_STEPS) st.step((dd - LO) * MF_TAPS + r, l31, lhi, lane);
             __builtin_amdgcn_sched_barrier(0);
         }
+    }
+    if constexpr (FILL) {
+#pragma unroll
+        for (int k = (HI - LO + 1) * MF_TAPS; k < WT_STEPS; ++k) st.step(k, l31, lhi, lane);  // (a tile of one block: the rest of the store)
     }
     return acc;
 }
 
 // the wave-uniform block range picks one straight-line instantiation (a run-time range inside the pinned pipeline makes hipcc shuffle the fragments)
-template <typename T, bool VERT>
-__device__ __forceinline__ f32x16 wt_long_tile(const s16x8 (&af)[MF_TAPS][WT_ND], const char* L, unsigned rp, unsigned rpitch, int lo, int hi, f32x16 acc) {
-#define SLAK_WT_CASE(LO, HI) case (LO) * 8 + (HI): return wt_tile<T, VERT, WT_ND, 0, LO, HI>(af, L, rp, rpitch, acc);
+template <typename T, bool VERT, bool FILL>
+__device__ __forceinline__ f32x16 wt_long_tile(const s16x8 (&af)[MF_TAPS][WT_ND], const char* L, unsigned rp, unsigned rpitch, int lo, int hi, f32x16 acc,
+                                               WtStore<T>& st, int l31, int lhi, int lane) {
+#define SLAK_WT_CASE(LO, HI) case (LO) * 8 + (HI): return wt_tile<T, VERT, FILL, WT_ND, 0, LO, HI>(af, L, rp, rpitch, acc, st, l31, lhi, lane);
     switch (lo * 8 + hi) {
         SLAK_WT_CASE(0, 2) SLAK_WT_CASE(0, 3) SLAK_WT_CASE(0, 4) SLAK_WT_CASE(0, 5)
         SLAK_WT_CASE(1, 2) SLAK_WT_CASE(1, 3) SLAK_WT_CASE(1, 4) SLAK_WT_CASE(1, 5)
         SLAK_WT_CASE(2, 2) SLAK_WT_CASE(2, 3) SLAK_WT_CASE(2, 4) SLAK_WT_CASE(2, 5)
-        default: return acc;                                          // an empty range
+        default:                                                      // an empty range: only the pending store
+            if constexpr (FILL) {
+#pragma unroll
+                for (int k = 0; k < WT_STEPS; ++k) st.step(k, l31, lhi, lane);
+            }
+            return acc;
     }
 #undef SLAK_WT_CASE
 }
-template <typename T>
-__device__ __forceinline__ f32x16 wt_small_tile(const s16x8 (&af)[MF_TAPS][WT_NDS], const char* L, unsigned rp, unsigned rpitch, int lo, int hi, f32x16 acc) {
-#define SLAK_WT_CASE(LO, HI) case (LO) * 8 + (HI): return wt_tile<T, false, WT_NDS, 1, LO, HI>(af, L, rp, rpitch, acc);
+template <typename T, bool FILL>
+__device__ __forceinline__ f32x16 wt_small_tile(const s16x8 (&af)[MF_TAPS][WT_NDS], const char* L, unsigned rp, unsigned rpitch, int lo, int hi, f32x16 acc,
+                                                WtStore<T>& st, int l31, int lhi, int lane) {
+#define SLAK_WT_CASE(LO, HI) case (LO) * 8 + (HI): return wt_tile<T, false, FILL, WT_NDS, 1, LO, HI>(af, L, rp, rpitch, acc, st, l31, lhi, lane);
     switch (lo * 8 + hi) {
         SLAK_WT_CASE(1, 2) SLAK_WT_CASE(1, 3) SLAK_WT_CASE(1, 4) SLAK_WT_CASE(2, 2) SLAK_WT_CASE(2, 3) SLAK_WT_CASE(2, 4)
-        default: return acc;
+        default:
+            if constexpr (FILL) {
+#pragma unroll
+                for (int k = 0; k < WT_STEPS; ++k) st.step(k, l31, lhi, lane);
+            }
+            return acc;
     }
 #undef SLAK_WT_CASE
 }
@@ -221,6 +274,17 @@ __global__ __launch_bounds__(MF_THREADS, 1) void dwconv_mfma_wide_tri_kernel(con
     s16x8 fh[MF_TAPS][WT_ND], fv[MF_TAPS][WT_ND], fs[MF_TAPS][WT_NDS];
     char* const stg = L + st_b + (unsigned)wave * WT_STB;
     const int t192 = wave * 64 + lane;
+    __amdgpu_buffer_rsrc_t ro[3];
+#pragma unroll
+    for (int t = 0; t < 3; ++t) ro[t] = __builtin_amdgcn_make_buffer_rsrc(p.out[DGRAD ? 0 : t], 0, (int)p.tensor_bytes, 0x00020000);
+    WtStore<T> pend;                                                  // the finished tile whose store is under way
+    {
+        f32x16 z0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) z0[i] = 0.f;
+        pend.arm(z0, stg, ro[0], 0u, 0, mt, lane, p.H, p.W, false);
+        pend.r0 = pend.r1 = u32x4{0u, 0u, 0u, 0u};
+    }
 
     int c_cur = -1, c = q0 / p.N, n = q0 - c * p.N;
     for (int it = 0; it < iters; ++it) {
@@ -270,7 +334,7 @@ __global__ __launch_bounds__(MF_THREADS, 1) void dwconv_mfma_wide_tri_kernel(con
             const unsigned slot = (unsigned)(it % R) * (unsigned)p.slot_h;
             const unsigned img_h = h_b + slot, img_s = DGRAD ? s_b + slot : img_h;
             const unsigned img_v = xt_b + (unsigned)(it & 1) * (unsigned)p.xt_bytes;
-            const size_t plane = ((size_t)n * p.C + c) * HW;
+            const unsigned plane_b = (unsigned)(((size_t)n * p.C + c) * HW * 2);
             for (int s = 0; s < p.MTr; ++s) {
                 // horizontal / 5 x 5: tap r, block dd = 16 bytes at row 32 s + l31 + r of the guarded image, columns 16 ks + 8 lhi ..  (ks = 2 mt - 2 + dd)
                 const unsigned rp_h = (unsigned)(s * 32 + l31) * pitch + (unsigned)lhi * 16u + (unsigned)((2 * mt - 2) * 32);
@@ -281,44 +345,26 @@ __global__ __launch_bounds__(MF_THREADS, 1) void dwconv_mfma_wide_tri_kernel(con
                 f32x16 z;
 #pragma unroll
                 for (int i = 0; i < 16; ++i) z[i] = 0.f;
-                f32x16 acc[3];
+                // every tile's store (`pend`) rides behind the MFMAs of the tile after it -- across regions and planes
                 if constexpr (DGRAD) {                                // the three partial gradients of the tile in ONE accumulator, one rounding
-                    acc[0] = wt_long_tile<T, true>(fv, L, rp_v, xpitch, lo_v, hi_v, z);
-                    acc[0] = wt_long_tile<T, false>(fh, L, img_h + rp_h, pitch, lo_h, hi_h, acc[0]);
-                    acc[0] = wt_small_tile<T>(fs, L, img_s + rp_h, pitch, lo_s, hi_s, acc[0]);
+                    f32x16 a = wt_long_tile<T, true, true>(fv, L, rp_v, xpitch, lo_v, hi_v, z, pend, l31, lhi, lane);
+                    a = wt_long_tile<T, false, false>(fh, L, img_h + rp_h, pitch, lo_h, hi_h, a, pend, l31, lhi, lane);
+                    a = wt_small_tile<T, false>(fs, L, img_s + rp_h, pitch, lo_s, hi_s, a, pend, l31, lhi, lane);
+                    pend.arm(a, stg, ro[0], plane_b, s, mt, lane, p.H, p.W, true);
                 } else {
-                    acc[0] = wt_long_tile<T, true>(fv, L, rp_v, xpitch, lo_v, hi_v, z);
-                    acc[1] = wt_long_tile<T, false>(fh, L, img_h + rp_h, pitch, lo_h, hi_h, z);
-                    acc[2] = wt_small_tile<T>(fs, L, img_s + rp_h, pitch, lo_s, hi_s, z);
-                }
-                // lane = row 32 s + l31 of the plane, register quad q = columns 32 mt + 8 q + 4 lhi .. + 3; through the staging tile to 16-byte stores
-#pragma unroll
-                for (int o = 0; o < (DGRAD ? 1 : 3); ++o) {
-                    char* op = stg + (unsigned)l31 * WT_STP + (unsigned)(4 * lhi) * 2u;
-#pragma unroll
-                    for (int qd = 0; qd < 4; ++qd) {
-                        u32x2 v;
-                        v[0] = pack2<T>(acc[o][4 * qd + 0], acc[o][4 * qd + 1]);
-                        v[1] = pack2<T>(acc[o][4 * qd + 2], acc[o][4 * qd + 3]);
-                        *(u32x2*)(op + 16 * qd) = v;
-                    }
-                    __builtin_amdgcn_wave_barrier();
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                    char* const yo = (char*)p.out[o] + plane * 2;
-#pragma unroll
-                    for (int k = 0; k < 2; ++k) {
-                        const int idx = lane + 64 * k, row = idx >> 2, c4 = idx & 3;
-                        const u32x4 v = *(const u32x4*)(stg + (unsigned)row * WT_STP + (unsigned)c4 * 16u);
-                        const int gr = s * 32 + row, gc = mt * 32 + c4 * 8;
-                        if (gr < p.H && gc < p.W) *(u32x4*)(yo + ((size_t)gr * p.W + gc) * 2) = v;
-                    }
-                    __builtin_amdgcn_wave_barrier();
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    const f32x16 av = wt_long_tile<T, true, true>(fv, L, rp_v, xpitch, lo_v, hi_v, z, pend, l31, lhi, lane);
+                    pend.arm(av, stg, ro[0], plane_b, s, mt, lane, p.H, p.W, true);
+                    const f32x16 ah = wt_long_tile<T, false, true>(fh, L, img_h + rp_h, pitch, lo_h, hi_h, z, pend, l31, lhi, lane);
+                    pend.arm(ah, stg, ro[1], plane_b, s, mt, lane, p.H, p.W, true);
+                    const f32x16 as = wt_small_tile<T, true>(fs, L, img_s + rp_h, pitch, lo_s, hi_s, z, pend, l31, lhi, lane);
+                    pend.arm(as, stg, ro[2], plane_b, s, mt, lane, p.H, p.W, true);
                 }
             }
         }
         if (++n == p.N) { n = 0; ++c; }
     }
+#pragma unroll
+    for (int k = 0; k < WT_STEPS; ++k) pend.step(k, l31, lhi, lane);  // the last tile's store
 }
 
 // ------------------------------------------------------------------------------------------------------------
