@@ -19,7 +19,6 @@
 //   * Work decomposition: the C * N planes in (channel, image) order are cut into one equal RANGE per CU (whole slices per channel leave a
 //     quarter of the CUs idle at C = 96); a range that crosses a channel boundary rebuilds its fragments there (three barriers, ~3 us).
 #include "mfma_common.h"
-#include <stdlib.h>
 
 namespace slak {
 
@@ -44,27 +43,19 @@ struct WideTriParams {
     int trc;                            // 16-column transpose blocks per 4-row band
     int per, planes;                    // planes per workgroup range, C * N
     unsigned tensor_bytes;
-    int dbg;                            // dev builds (SLAK_BUILD_DEFS=-DSLAK_WT_DEV -DSLAK_DEV_KNOBS, SLAK_WT_DBG): 1 no MFMA tiles, 2 no transposes, 4 no DMA, 8 no stores (timing experiments)
 };
-#ifdef SLAK_WT_DEV
-#define WT_DBG(bit) (p.dbg & (bit))
-#else
-#define WT_DBG(bit) 0
-#endif
 
 // The store of a finished tile, cut into steps that ride behind the MFMAs of the NEXT tile (one wave per SIMD: nothing else hides them).
 // lane = row l31 of the tile, register quad q = columns 8 q + 4 lhi .. + 3: through the wave's staging tile (a wave's LDS operations execute in
 // order: the reads below see the writes above them without a wait) to two 16-byte stores per lane, 64 contiguous bytes per row.
 template <typename T>
 struct WtStore {
-    u32x2 q[4]; char* stg; __amdgpu_buffer_rsrc_t rsrc; unsigned soff, go0, go1; u32x4 r0, r1;     // q: the tile, rounded and packed when the store is armed (half the registers of the accumulator)
+    f32x16 acc; char* stg; __amdgpu_buffer_rsrc_t rsrc; unsigned soff, go0, go1; u32x4 r0, r1;
     // rsrc: the output tensor; soff: the plane's byte offset in it (wave-uniform); go0 / go1: this lane's two 16-byte pieces in the plane (row
     // 32 s + lane / 4 resp. 16 rows further down, columns 32 mt + 8 (lane % 4)) -- or an out-of-range offset: the buffer range check drops the
     // store, so nothing in the MFMA stream is conditional (a branch inside the pinned pipeline makes hipcc spill the fragments)
     __device__ __forceinline__ void arm(const f32x16& a, char* staging, __amdgpu_buffer_rsrc_t out, unsigned plane_off, int s, int mt, int lane, int H, int W, bool live) {
-        stg = staging; rsrc = out; soff = plane_off;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) { q[k][0] = pack2<T>(a[4 * k + 0], a[4 * k + 1]); q[k][1] = pack2<T>(a[4 * k + 2], a[4 * k + 3]); }
+        acc = a; stg = staging; rsrc = out; soff = plane_off;
         const int row0 = lane >> 2, c4 = lane & 3, gc = mt * 32 + c4 * 8;
         const unsigned g = (unsigned)((s * 32 + row0) * W + gc) * 2u;
         go0 = (live && s * 32 + row0 < H && gc < W) ? g : 0x80000000u;
@@ -72,7 +63,10 @@ struct WtStore {
     }
     __device__ __forceinline__ void step(int k, int l31, int lhi, int lane) {
         if (k < 4) {
-            *(u32x2*)(stg + (unsigned)l31 * WT_STP + (unsigned)(8 * lhi + 16 * k)) = q[k];
+            u32x2 v;
+            v[0] = pack2<T>(acc[4 * k + 0], acc[4 * k + 1]);
+            v[1] = pack2<T>(acc[4 * k + 2], acc[4 * k + 3]);
+            *(u32x2*)(stg + (unsigned)l31 * WT_STP + (unsigned)(8 * lhi + 16 * k)) = v;
         } else if (k == 4) {                                            // (a wave's LDS operations execute in order: no wait between the writes and these reads)
             asm volatile("" ::: "memory");
             const unsigned o = (unsigned)(lane >> 2) * WT_STP + (unsigned)(lane & 3) * 16u;
@@ -86,79 +80,62 @@ struct WtStore {
 };
 constexpr int WT_STEPS = 8;
 
-// One 32 x 32 tile: blocks dd = LO..HI of a long branch (fragments af), five short taps each, added into `acc`.  HS: the 5 x 5 branch's tile of
-// the same rows and columns rides along -- its operand fragments b[r] ARE the horizontal branch's (same image rows, same k-step), so blocks
-// max(LO, 1) .. min(HI, 4) get a second MFMA into `accs` behind the same LDS read (two independent accumulator chains).
-// The pinned software pipeline of dwconv_mfma_wide.hip, continued ACROSS tiles: b[] arrives holding the fragments of block LO, and behind the
-// MFMAs of the last block the fragments of the NEXT tile's first block are fetched (nrp / npitch; the caller reloads b[] where a barrier lies
-// in between).  Behind MFMA j also step j of the stores that are under way (NST of them, one after the other).
-template <typename T, bool VERT, int NST, bool HS, int LO, int HI>
-__device__ __forceinline__ void wt_tile(const s16x8 (&af)[MF_TAPS][WT_ND], const s16x8 (&afs)[MF_TAPS][WT_NDS], const char* L, unsigned rp, unsigned rpitch,
-                                        s16x8 (&b)[MF_TAPS], unsigned nrp, unsigned npitch, f32x16& acc, f32x16& accs, WtStore<T> (&st)[2], int l31, int lhi, int lane) {
-    constexpr int LOS = LO < 1 ? 1 : LO, HIS = HI > 4 ? 4 : HI;
+// One 32 x 32 tile of one branch: blocks dd = LO..HI (the fragment array starts at block DOFF), five short taps each, added into `acc`.
+// The pinned software pipeline of dwconv_mfma_wide.hip: the fragment of tap r for the next block is fetched right behind this block's MFMA of tap r;
+// behind MFMA j also step j of the previous tile's store.
+template <typename T, bool VERT, bool FILL, int ND, int DOFF, int LO, int HI>
+__device__ __forceinline__ f32x16 wt_tile(const s16x8 (&af)[MF_TAPS][ND], const char* L, unsigned rp, unsigned rpitch, f32x16 acc, WtStore<T>& st, int l31, int lhi, int lane) {
+    s16x8 b[MF_TAPS];
+#pragma unroll
+    for (int r = 0; r < MF_TAPS; ++r) b[r] = __builtin_bit_cast(s16x8, *(const u32x4*)(L + rp + (unsigned)r * rpitch + LO * 32u));
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int dd = LO; dd <= HI; ++dd) {
 #pragma unroll
         for (int r = 0; r < MF_TAPS; ++r) {
-            acc = VERT ? mfma32<T>(b[r], af[r][dd], acc) : mfma32<T>(af[r][dd], b[r], acc);
-            if constexpr (HS) if (dd >= LOS && dd <= HIS) accs = mfma32<T>(afs[r][dd - 1], b[r], accs);
+            acc = VERT ? mfma32<T>(b[r], af[r][dd - DOFF], acc) : mfma32<T>(af[r][dd - DOFF], b[r], acc);
             if (dd < HI) b[r] = __builtin_bit_cast(s16x8, *(const u32x4*)(L + rp + (unsigned)r * rpitch + (dd + 1) * 32u));
-            else b[r] = __builtin_bit_cast(s16x8, *(const u32x4*)(L + nrp + (unsigned)r * npitch));
-            const int j = (dd - LO) * MF_TAPS + r;
-            if (j < NST * WT_STEPS) st[j / WT_STEPS].step(j % WT_STEPS, l31, lhi, lane);
+            if constexpr (FILL) if ((dd - LO) * MF_TAPS + r < WT_STEPS) st.step((dd - LO) * MF_TAPS + r, l31, lhi, lane);
             __builtin_amdgcn_sched_barrier(0);
         }
     }
+    if constexpr (FILL) {
 #pragma unroll
-    for (int j = (HI - LO + 1) * MF_TAPS; j < NST * WT_STEPS; ++j) st[j / WT_STEPS].step(j % WT_STEPS, l31, lhi, lane);      // (a short tile: the rest of the stores)
+        for (int k = (HI - LO + 1) * MF_TAPS; k < WT_STEPS; ++k) st.step(k, l31, lhi, lane);  // (a tile of one block: the rest of the store)
+    }
+    return acc;
 }
 
 // the wave-uniform block range picks one straight-line instantiation (a run-time range inside the pinned pipeline makes hipcc shuffle the fragments)
-template <typename T, bool VERT, int NST, bool HS>
-__device__ __forceinline__ void wt_long_tile(const s16x8 (&af)[MF_TAPS][WT_ND], const s16x8 (&afs)[MF_TAPS][WT_NDS], const char* L, unsigned rp, unsigned rpitch,
-                                             s16x8 (&b)[MF_TAPS], unsigned nrp, unsigned npitch, int lo, int hi, f32x16& acc, f32x16& accs, WtStore<T> (&st)[2],
-                                             int l31, int lhi, int lane) {
-#define SLAK_WT_CASE(LO, HI) case (LO) * 8 + (HI): wt_tile<T, VERT, NST, HS, LO, HI>(af, afs, L, rp, rpitch, b, nrp, npitch, acc, accs, st, l31, lhi, lane); break;
+template <typename T, bool VERT, bool FILL>
+__device__ __forceinline__ f32x16 wt_long_tile(const s16x8 (&af)[MF_TAPS][WT_ND], const char* L, unsigned rp, unsigned rpitch, int lo, int hi, f32x16 acc,
+                                               WtStore<T>& st, int l31, int lhi, int lane) {
+#define SLAK_WT_CASE(LO, HI) case (LO) * 8 + (HI): return wt_tile<T, VERT, FILL, WT_ND, 0, LO, HI>(af, L, rp, rpitch, acc, st, l31, lhi, lane);
     switch (lo * 8 + hi) {
         SLAK_WT_CASE(0, 2) SLAK_WT_CASE(0, 3) SLAK_WT_CASE(0, 4) SLAK_WT_CASE(0, 5)
         SLAK_WT_CASE(1, 2) SLAK_WT_CASE(1, 3) SLAK_WT_CASE(1, 4) SLAK_WT_CASE(1, 5)
         SLAK_WT_CASE(2, 2) SLAK_WT_CASE(2, 3) SLAK_WT_CASE(2, 4) SLAK_WT_CASE(2, 5)
-        default:                                                      // an empty range: the stores under way, and the next tile's first fragments
+        default:                                                      // an empty range: only the pending store
+            if constexpr (FILL) {
 #pragma unroll
-            for (int j = 0; j < NST * WT_STEPS; ++j) st[j / WT_STEPS].step(j % WT_STEPS, l31, lhi, lane);
-#pragma unroll
-            for (int r = 0; r < MF_TAPS; ++r) b[r] = __builtin_bit_cast(s16x8, *(const u32x4*)(L + nrp + (unsigned)r * npitch));
-            break;
+                for (int k = 0; k < WT_STEPS; ++k) st.step(k, l31, lhi, lane);
+            }
+            return acc;
     }
 #undef SLAK_WT_CASE
 }
-// the 5 x 5 branch on its own operand (data gradient: its dy): blocks 1 .. 4 of a four-block fragment array
-template <typename T, int LO, int HI>
-__device__ __forceinline__ void wt_small(const s16x8 (&afs)[MF_TAPS][WT_NDS], const char* L, unsigned rp, unsigned rpitch, s16x8 (&b)[MF_TAPS],
-                                         unsigned nrp, unsigned npitch, f32x16& acc) {
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int dd = LO; dd <= HI; ++dd) {
-#pragma unroll
-        for (int r = 0; r < MF_TAPS; ++r) {
-            acc = mfma32<T>(afs[r][dd - 1], b[r], acc);
-            if (dd < HI) b[r] = __builtin_bit_cast(s16x8, *(const u32x4*)(L + rp + (unsigned)r * rpitch + (dd + 1) * 32u));
-            else b[r] = __builtin_bit_cast(s16x8, *(const u32x4*)(L + nrp + (unsigned)r * npitch));
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    }
-}
-template <typename T>
-__device__ __forceinline__ void wt_small_tile(const s16x8 (&afs)[MF_TAPS][WT_NDS], const char* L, unsigned rp, unsigned rpitch, s16x8 (&b)[MF_TAPS],
-                                              unsigned nrp, unsigned npitch, int lo, int hi, f32x16& acc) {
-#define SLAK_WT_CASE(LO, HI) case (LO) * 8 + (HI): wt_small<T, LO, HI>(afs, L, rp, rpitch, b, nrp, npitch, acc); break;
+template <typename T, bool FILL>
+__device__ __forceinline__ f32x16 wt_small_tile(const s16x8 (&af)[MF_TAPS][WT_NDS], const char* L, unsigned rp, unsigned rpitch, int lo, int hi, f32x16 acc,
+                                                WtStore<T>& st, int l31, int lhi, int lane) {
+#define SLAK_WT_CASE(LO, HI) case (LO) * 8 + (HI): return wt_tile<T, false, FILL, WT_NDS, 1, LO, HI>(af, L, rp, rpitch, acc, st, l31, lhi, lane);
     switch (lo * 8 + hi) {
         SLAK_WT_CASE(1, 2) SLAK_WT_CASE(1, 3) SLAK_WT_CASE(1, 4) SLAK_WT_CASE(2, 2) SLAK_WT_CASE(2, 3) SLAK_WT_CASE(2, 4)
         default:
+            if constexpr (FILL) {
 #pragma unroll
-            for (int r = 0; r < MF_TAPS; ++r) b[r] = __builtin_bit_cast(s16x8, *(const u32x4*)(L + nrp + (unsigned)r * npitch));
-            break;
+                for (int k = 0; k < WT_STEPS; ++k) st.step(k, l31, lhi, lane);
+            }
+            return acc;
     }
 #undef SLAK_WT_CASE
 }
@@ -229,7 +206,7 @@ __global__ __launch_bounds__(MF_THREADS, 1) void dwconv_mfma_wide_tri_kernel(con
         }
         auto plane_off = [&](int q) -> unsigned { const int c = q / p.N, n = q - c * p.N; return (unsigned)(((size_t)n * p.C + c) * HW * 2); };
         auto issue = [&](int it) {                                    // every input of plane q0 + it
-            if (it >= iters || WT_DBG(4)) return;
+            if (it >= iters) return;
             const unsigned src0 = plane_off(q0 + it), slot = (unsigned)(it % R) * (unsigned)p.slot_h;
 #pragma unroll
             for (int k = 0; k < WT_MAXDMA; ++k) {
@@ -242,7 +219,7 @@ __global__ __launch_bounds__(MF_THREADS, 1) void dwconv_mfma_wide_tri_kernel(con
             }
         };
         auto transpose = [&](int it) {
-            if (it >= iters || WT_DBG(2)) return;
+            if (it >= iters) return;
             const unsigned src_b = DGRAD ? v_b : h_b + (unsigned)(it % R) * (unsigned)p.slot_h + 2u * pitch;
             const unsigned dst_b = xt_b + (unsigned)(it & 1) * (unsigned)p.xt_bytes;
 #pragma unroll
@@ -254,7 +231,7 @@ __global__ __launch_bounds__(MF_THREADS, 1) void dwconv_mfma_wide_tri_kernel(con
                 for (int j = 0; j < 6; ++j) if (tdst[j0 + j] != WT_NONE) *(s16x4*)(L + dst_b + tdst[j0 + j]) = v[j];
             }
         };
-        const int dma_per_plane = WT_DBG(4) ? 0 : (DGRAD ? 2 * p.ninh + p.ninv : p.ninh);   // (every instruction has at least one active lane: it is issued)
+        const int dma_per_plane = DGRAD ? 2 * p.ninh + p.ninv : p.ninh;   // (every instruction has at least one active lane: it is issued)
         issue(0);
         if constexpr (!DGRAD) issue(1);
         int c_cur = -1, c = q0 / p.N, n = q0 - c * p.N;
@@ -294,20 +271,19 @@ __global__ __launch_bounds__(MF_THREADS, 1) void dwconv_mfma_wide_tri_kernel(con
     int lo_h, hi_h, lo_s, hi_s;
     range(mt, p.KSc, p.K, lo_h, hi_h);
     range(mt, p.KSc, MF_TAPS, lo_s, hi_s);
-    if (WT_DBG(1)) { lo_h = lo_s = 1; hi_h = hi_s = 0; }
     s16x8 fh[MF_TAPS][WT_ND], fv[MF_TAPS][WT_ND], fs[MF_TAPS][WT_NDS];
     char* const stg = L + st_b + (unsigned)wave * WT_STB;
     const int t192 = wave * 64 + lane;
     __amdgpu_buffer_rsrc_t ro[3];
 #pragma unroll
     for (int t = 0; t < 3; ++t) ro[t] = __builtin_amdgcn_make_buffer_rsrc(p.out[DGRAD ? 0 : t], 0, (int)p.tensor_bytes, 0x00020000);
-    WtStore<T> st[2];                                                 // the finished tiles whose stores are under way (forward: two)
+    WtStore<T> pend;                                                  // the finished tile whose store is under way
     {
         f32x16 z0;
 #pragma unroll
         for (int i = 0; i < 16; ++i) z0[i] = 0.f;
-#pragma unroll
-        for (int k = 0; k < 2; ++k) { st[k].arm(z0, stg, ro[0], 0u, 0, mt, lane, p.H, p.W, false); st[k].r0 = st[k].r1 = u32x4{0u, 0u, 0u, 0u}; }
+        pend.arm(z0, stg, ro[0], 0u, 0, mt, lane, p.H, p.W, false);
+        pend.r0 = pend.r1 = u32x4{0u, 0u, 0u, 0u};
     }
 
     int c_cur = -1, c = q0 / p.N, n = q0 - c * p.N;
@@ -359,46 +335,36 @@ __global__ __launch_bounds__(MF_THREADS, 1) void dwconv_mfma_wide_tri_kernel(con
             const unsigned img_h = h_b + slot, img_s = DGRAD ? s_b + slot : img_h;
             const unsigned img_v = xt_b + (unsigned)(it & 1) * (unsigned)p.xt_bytes;
             const unsigned plane_b = (unsigned)(((size_t)n * p.C + c) * HW * 2);
-            // horizontal / 5 x 5: tap r, block dd = 16 bytes at row 32 s + l31 + r of the guarded image, columns 16 ks + 8 lhi ..  (ks = 2 mt - 2 + dd)
-            const unsigned rph0 = (unsigned)l31 * pitch + (unsigned)lhi * 16u + (unsigned)((2 * mt - 2) * 32);
-            // vertical: x^T row 32 mt + l31 + r (image column + guard), image rows 16 ks + 8 lhi ..  (ks = 2 s - 2 + dd)
-            const unsigned rpv0 = img_v + (unsigned)(mt * 32 + l31) * xpitch + (unsigned)lhi * 16u - 64u;
-            int lo_v, hi_v;
-            range(0, p.KSr, p.K, lo_v, hi_v);
-            s16x8 b[MF_TAPS];                                         // the operand fragments of the first block of the tile that comes next
-#pragma unroll
-            for (int r = 0; r < MF_TAPS; ++r) b[r] = __builtin_bit_cast(s16x8, *(const u32x4*)(L + rpv0 + (unsigned)r * xpitch + (unsigned)lo_v * 32u));
             for (int s = 0; s < p.MTr; ++s) {
-                const unsigned rp_h = (unsigned)(s * 32) * pitch + rph0, rp_v = rpv0 + (unsigned)(s * 64);
-                int lo_n = 0, hi_n = 0;                               // the vertical tile of the next row band (its first fragments are fetched behind this band's last MFMAs)
-                const bool more = s + 1 < p.MTr;
-                if (more) range(s + 1, p.KSr, p.K, lo_n, hi_n);
-                const unsigned nrp_v = more ? rp_v + 64u + (unsigned)lo_n * 32u : rp_v + (unsigned)lo_v * 32u;       // (no next band: a harmless re-read)
+                // horizontal / 5 x 5: tap r, block dd = 16 bytes at row 32 s + l31 + r of the guarded image, columns 16 ks + 8 lhi ..  (ks = 2 mt - 2 + dd)
+                const unsigned rp_h = (unsigned)(s * 32 + l31) * pitch + (unsigned)lhi * 16u + (unsigned)((2 * mt - 2) * 32);
+                // vertical: x^T row 32 mt + l31 + r (image column + guard), image rows 16 ks + 8 lhi ..  (ks = 2 s - 2 + dd)
+                const unsigned rp_v = img_v + (unsigned)(mt * 32 + l31) * xpitch + (unsigned)lhi * 16u + (unsigned)((2 * s - 2) * 32);
+                int lo_v, hi_v;
+                range(s, p.KSr, p.K, lo_v, hi_v);
                 f32x16 z;
 #pragma unroll
                 for (int i = 0; i < 16; ++i) z[i] = 0.f;
+                // every tile's store (`pend`) rides behind the MFMAs of the tile after it -- across regions and planes
                 if constexpr (DGRAD) {                                // the three partial gradients of the tile in ONE accumulator, one rounding
-                    f32x16 a = z, unused = z;
-                    wt_long_tile<T, true, 1, false>(fv, fs, L, rp_v, xpitch, b, img_h + rp_h + (unsigned)lo_h * 32u, pitch, lo_v, hi_v, a, unused, st, l31, lhi, lane);
-                    wt_long_tile<T, false, 0, false>(fh, fs, L, img_h + rp_h, pitch, b, img_s + rp_h + (unsigned)lo_s * 32u, pitch, lo_h, hi_h, a, unused, st, l31, lhi, lane);
-                    wt_small_tile<T>(fs, L, img_s + rp_h, pitch, b, nrp_v, xpitch, lo_s, hi_s, a);
-                    st[0].arm(a, stg, ro[0], plane_b, s, mt, lane, p.H, p.W, !WT_DBG(8));
+                    f32x16 a = wt_long_tile<T, true, true>(fv, L, rp_v, xpitch, lo_v, hi_v, z, pend, l31, lhi, lane);
+                    a = wt_long_tile<T, false, false>(fh, L, img_h + rp_h, pitch, lo_h, hi_h, a, pend, l31, lhi, lane);
+                    a = wt_small_tile<T, false>(fs, L, img_s + rp_h, pitch, lo_s, hi_s, a, pend, l31, lhi, lane);
+                    pend.arm(a, stg, ro[0], plane_b, s, mt, lane, p.H, p.W, true);
                 } else {
-                    // vertical tile: behind it the stores of the previous band's horizontal and 5 x 5 tiles; horizontal + 5 x 5 (one operand stream): behind it the vertical tile's
-                    f32x16 av = z, ah = z, as = z;
-                    wt_long_tile<T, true, 2, false>(fv, fs, L, rp_v, xpitch, b, img_h + rp_h + (unsigned)lo_h * 32u, pitch, lo_v, hi_v, av, as, st, l31, lhi, lane);
-                    st[0].arm(av, stg, ro[0], plane_b, s, mt, lane, p.H, p.W, !WT_DBG(8));
-                    wt_long_tile<T, false, 1, true>(fh, fs, L, img_h + rp_h, pitch, b, nrp_v, xpitch, lo_h, hi_h, ah, as, st, l31, lhi, lane);
-                    st[0].arm(ah, stg, ro[1], plane_b, s, mt, lane, p.H, p.W, !WT_DBG(8));
-                    st[1].arm(as, stg, ro[2], plane_b, s, mt, lane, p.H, p.W, !WT_DBG(8));
+                    const f32x16 av = wt_long_tile<T, true, true>(fv, L, rp_v, xpitch, lo_v, hi_v, z, pend, l31, lhi, lane);
+                    pend.arm(av, stg, ro[0], plane_b, s, mt, lane, p.H, p.W, true);
+                    const f32x16 ah = wt_long_tile<T, false, true>(fh, L, img_h + rp_h, pitch, lo_h, hi_h, z, pend, l31, lhi, lane);
+                    pend.arm(ah, stg, ro[1], plane_b, s, mt, lane, p.H, p.W, true);
+                    const f32x16 as = wt_small_tile<T, true>(fs, L, img_s + rp_h, pitch, lo_s, hi_s, z, pend, l31, lhi, lane);
+                    pend.arm(as, stg, ro[2], plane_b, s, mt, lane, p.H, p.W, true);
                 }
-                lo_v = lo_n; hi_v = hi_n;
             }
         }
         if (++n == p.N) { n = 0; ++c; }
     }
 #pragma unroll
-    for (int j = 0; j < (DGRAD ? 1 : 2) * WT_STEPS; ++j) st[j / WT_STEPS].step(j % WT_STEPS, l31, lhi, lane);      // the last tiles' stores
+    for (int k = 0; k < WT_STEPS; ++k) pend.step(k, l31, lhi, lane);  // the last tile's store
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -432,11 +398,6 @@ static bool fill_wide_tri_params(WideTriParams& p, int N, int C, int H, int W, i
     p.planes = (int)P;
     p.per = (int)((P + wgs - 1) / wgs);
     p.tensor_bytes = (unsigned)((size_t)N * C * H * W * 2);
-#ifdef SLAK_WT_DEV
-    { static const int dbg = [] { const char* e = slak_dev_getenv("SLAK_WT_DBG"); return e ? atoi(e) : 0; }(); p.dbg = dbg; }
-#else
-    p.dbg = 0;
-#endif
     return (size_t)N * C * H * W * 2 < 0x7fffffffull;
 }
 
