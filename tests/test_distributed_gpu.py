@@ -350,6 +350,8 @@ def _slot_worker(rank, world, port, out):
             opt.zero_grad(set_to_none=True)
         state = torch.cat([p.detach().float().flatten() for p in net.parameters()] + [m.flatten() for m in mask.masks.values()])
         B.grad_slots_enabled = False; B.drop_grad_slots()
+        train.names = [n for n, p in net.named_parameters() for _ in range(1)]
+        train.sizes = [p.numel() for p in net.parameters()]
         return state, in_place, float(loss.item())
 
     for acc in (False, True):
@@ -360,6 +362,13 @@ def _slot_worker(rank, world, port, out):
         res[key + "_ref_reproducible"] = bool(torch.equal(ref, ref2))
         res[key + "_identical"] = bool(torch.equal(ref, got))
         res[key + "_maxdiff"] = (float((ref - got).abs().max()), float((ref - ref2).abs().max()), float(ref.abs().max()))
+        off, bad = 0, []
+        for nm, sz in zip(train.names, train.sizes):                  # (diagnostic: which parameters differ)
+            d = float((ref[off:off + sz] - got[off:off + sz]).abs().max())
+            if d > 0:
+                bad.append((nm, d, int((ref[off:off + sz] != got[off:off + sz]).sum()), sz))
+            off += sz
+        res[key + "_differing"] = bad[:12]
         res[key + "_in_place"] = in_place
         res[key + "_loss"] = (l0, l1)
         other = [torch.empty_like(got) for _ in range(world)]
@@ -391,7 +400,7 @@ def test_block_gradients_written_into_ddp_bucket_views(gpu, tmp_path):
     for key in ("plain", "acc"):
         d_got, d_ref, scale = got[key + "_maxdiff"]
         if got[key + "_ref_reproducible"]:
-            assert got[key + "_identical"], (key, got[key + "_maxdiff"], got[key + "_loss"])
+            assert got[key + "_identical"], (key, got[key + "_maxdiff"], got[key + "_loss"], got[key + "_differing"])
         else:                                                         # (a library kernel of the narrow model that does not reproduce: bound by its own spread)
             assert d_got <= 4 * d_ref + 1e-6 * scale, (key, got[key + "_maxdiff"])
         assert got[key + "_ranks_identical"], key
