@@ -1377,7 +1377,8 @@ def adopt_grad_slots(params, key=None):
         if g is None or g.dtype != torch.float32 or not g.is_contiguous() or g.shape != p.shape:
             continue
         if e is None or e[1].data_ptr() != g.data_ptr():
-            _grad_slots[id(p)] = (weakref.ref(p), g)
+            # (the entry dies with its parameter: the destination keeps a whole all-reduce bucket alive)
+            _grad_slots[id(p)] = (weakref.ref(p, lambda _r, k=id(p): _grad_slots.pop(k, None)), g)
 
 
 def drop_grad_slots():
