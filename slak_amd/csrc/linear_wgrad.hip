@@ -3,8 +3,8 @@
 //     D[N1][N2] (fp32) = X1^T X2,   X1 [M][N1], X2 [M][N2] bf16 row-major, M = 6 k ... 400 k rows, N1, N2 in {96 ... 3072}.
 // Both operands have the REDUCTION index as their slow dimension, so neither is in MFMA fragment order; the library's TN kernels run
 // this at ~0.38 PFLOP/s (128x128 macro tiles re-read the operands through L2 12x / 3x).  Here:
-//   * a workgroup (4 waves, one per SIMD) owns a 192x192 (or 384x96 / 96x384) output tile = four 96x96 wave tiles (nine 32x32x16 MFMA
-//     accumulators each) and one SLAB of the rows; the row chunks (32 rows x both operand tiles) stream HBM/L2 -> LDS by LDS-DMA in a
+//   * a workgroup (4 waves, one per SIMD) owns a 192x192 (or 384x96 / 96x384; round 6: 256x128 / 128x256 for SLaK-B's widths) output tile = four
+//     96x96 (128x64) wave tiles (nine / eight 32x32x16 MFMA accumulators each) and one SLAB of the rows; the row chunks (32 rows x both operand tiles) stream HBM/L2 -> LDS by LDS-DMA in a
 //     4-stage ring (3 chunks in flight), rows padded to a pitch = +-64 B mod 256 by the per-lane source permutation of the DMA, so that
 //   * both MFMA operands are formed by ds_read_b64_tr_b16 (the transposing LDS read) straight from the row-major image, conflict-free;
 //   * the slabs' partial tiles (fp32) go to a workspace and a second kernel adds them in slab order: deterministic, fp32 throughout
@@ -13,12 +13,12 @@
 // 2 x (#workgroups x tile) of fp32 partials; the 192x192 tile per CU is the balance between the two.
 #include "slak_common.h"
 #include "mfma_common.h"
+#include <stdlib.h>
 
 namespace slak {
 
 constexpr int LW_KC = 32;                  // rows of the reduction per chunk (two k = 16 MFMA steps)
 constexpr int LW_NS = 4;                   // LDS stages
-constexpr int LW_WT = 96;                  // wave tile edge
 
 struct LwParams {
     const uint16_t* x1; const uint16_t* x2; float* part;      // part: [S][N1][N2] (or the result itself when S == 1)
@@ -37,10 +37,14 @@ __device__ __forceinline__ v4i_t lw_desc(const void* ptr, long long bytes) {    
     return v4i_t{(int)(unsigned)a, (int)((unsigned)(a >> 32) & 0xffffu), (int)(unsigned)(bytes > 0 ? bytes : 0), 0x00020000};
 }
 
-template <int W1, int W2>
+// NB1 x NB2: the wave tile in 32 x 32 MFMA blocks -- 3 x 3 (96 x 96: widths in multiples of 96, SLaK-T / -S / -L); round 6: 4 x 2 / 2 x 4 (128 x 64: SLaK-B's
+// widths 128 * 2^k; 4 x 4 = sixteen accumulators fill the accumulator file exactly and hipcc then shuffles them through VGPRs and scratch)
+template <int W1, int W2, int NB1 = 3, int NB2 = 3>
 __global__ __launch_bounds__(256, 1) void linear_wgrad_kernel(const LwParams p) {
     static_assert(W1 * W2 == 4, "four waves");
-    constexpr int T1 = LW_WT * W1, T2 = LW_WT * W2;
+    constexpr int NM = NB1 * NB2;                             // MFMAs per k step
+    constexpr int WT1 = 32 * NB1, WT2 = 32 * NB2;
+    constexpr int T1 = WT1 * W1, T2 = WT2 * W2;
     constexpr int PA = lw_pitch(T1), PB = lw_pitch(T2);
     constexpr int CDA = PA / 16, CDB = PB / 16;                // destination chunks per row
     constexpr int NA = LW_KC * CDA / 64, NB = LW_KC * CDB / 64;   // DMA pieces (1 KiB) per chunk and operand
@@ -91,35 +95,35 @@ __global__ __launch_bounds__(256, 1) void linear_wgrad_kernel(const LwParams p) 
     auto sgpr4 = [](v4i_t v) { return v4i_t{__builtin_amdgcn_readfirstlane(v[0]), __builtin_amdgcn_readfirstlane(v[1]), __builtin_amdgcn_readfirstlane(v[2]), __builtin_amdgcn_readfirstlane(v[3])}; };
     auto piece = [&](int k) { if (NP % 4 == 0 || pact[k]) lds_dma16(psrc[k], sgpr4(pisA[k] ? rA : rB), __builtin_amdgcn_readfirstlane(sb + pdst[k])); };
 
-    f32x16 acc[3][3];
+    f32x16 acc[NB1][NB2];
 #pragma unroll
-    for (int i = 0; i < 3; ++i)
+    for (int i = 0; i < NB1; ++i)
 #pragma unroll
-        for (int j = 0; j < 3; ++j)
+        for (int j = 0; j < NB2; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
     // fragment addressing (ds_read_b64_tr_b16): 16-lane group g4 reads a [4 rows][16 cols] block, lane (i16 >> 2) = row, (i16 & 3) = 4-column chunk
     const int g4 = lane >> 4, i16 = lane & 15;
-    const unsigned fa = (unsigned)((8 * (g4 >> 1) + (i16 >> 2)) * PA + (w1 * LW_WT + (g4 & 1) * 16 + (i16 & 3) * 4) * 2);
-    const unsigned fb = (unsigned)(BOFF + (8 * (g4 >> 1) + (i16 >> 2)) * PB + (w2 * LW_WT + (g4 & 1) * 16 + (i16 & 3) * 4) * 2);
+    const unsigned fa = (unsigned)((8 * (g4 >> 1) + (i16 >> 2)) * PA + (w1 * WT1 + (g4 & 1) * 16 + (i16 & 3) * 4) * 2);
+    const unsigned fb = (unsigned)(BOFF + (8 * (g4 >> 1) + (i16 >> 2)) * PB + (w2 * WT2 + (g4 & 1) * 16 + (i16 & 3) * 4) * 2);
     auto frag = [&](const unsigned char* L, unsigned addr, int pitch) -> s16x8 {     // 8 k of one column: two transposing reads, 4 rows apart
         const s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(SLAK_LDS(s16x4, L + addr));
         const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(SLAK_LDS(s16x4, L + addr + 4 * pitch));
         return s16x8{v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
     };
-    // fragment f = 0..11 of a chunk: (k step f / 6, operand (f % 6) / 3, 32-column block f % 3)
-    struct Frags { s16x8 a[2][3], b[2][3]; };
+    // fragment f = 0 .. 2 (NB1 + NB2) - 1 of a chunk: k step f / (NB1 + NB2), then the NB1 blocks of the first operand, then the NB2 of the second
+    struct Frags { s16x8 a[2][NB1], b[2][NB2]; };
     auto load_frag = [&](Frags& F, const unsigned char* L, int f) {
-        const int ks = f / 6, op = (f % 6) / 3, blk = f % 3;
-        if (op == 0) F.a[ks][blk] = frag(L, fa + (unsigned)(ks * 16 * PA + blk * 64), PA);
-        else F.b[ks][blk] = frag(L, fb + (unsigned)(ks * 16 * PB + blk * 64), PB);
+        const int ks = f / (NB1 + NB2), g = f % (NB1 + NB2);
+        if (g < NB1) F.a[ks][g] = frag(L, fa + (unsigned)(ks * 16 * PA + g * 64), PA);
+        else F.b[ks][g - NB1] = frag(L, fb + (unsigned)(ks * 16 * PB + (g - NB1) * 64), PB);
     };
     auto wait_chunk = [&](int ahead) {                          // my pieces of the oldest outstanding chunk have landed; `ahead` younger chunks may be in flight
         if constexpr (NP % 4 == 0) { if (ahead == 3) wait_vmcnt<3 * NPW>(); else wait_vmcnt<2 * NPW>(); }
         else wait_vmcnt_dyn(ahead * (wave < NP % 4 ? NPW : NPW - 1));
     };
-#define LW_MMA(F, ks, m) acc[(m) / 3][(m) % 3] = mfma32<bf16_t>(F.a[ks][(m) / 3], F.b[ks][(m) % 3], acc[(m) / 3][(m) % 3])
+#define LW_MMA(F, ks, m) acc[(m) / NB2][(m) % NB2] = mfma32<bf16_t>(F.a[ks][(m) / NB2], F.b[ks][(m) % NB2], acc[(m) / NB2][(m) % NB2])
 #define LW_SB() __builtin_amdgcn_sched_barrier(0)
     // One chunk (one wave per SIMD: nothing else hides latencies, so the stream is laid out by hand, <= 5 fillers per 32-cycle MFMA):
     //   first k step : 2 MFMAs | chunk c+1 confirmed landed (counted vmcnt) + barrier (every wave now holds ALL of chunk c in registers, so
@@ -131,20 +135,26 @@ __global__ __launch_bounds__(256, 1) void linear_wgrad_kernel(const LwParams p) 
         wg_barrier(); LW_SB();
         next_desc();
 #pragma unroll
-        for (int m = 2; m < 9; ++m) {
-            LW_MMA(cur, 0, m); piece(m - 2);
-            if (m == 8) { if constexpr (NPW > 7) piece(7); }
+        for (int m = 2; m < NM; ++m) {                          // NM - 2 slots for the NPW pieces of chunk c + 4 (the last slot takes what is left)
+            LW_MMA(cur, 0, m);
+            if (m - 2 < NPW) piece(m - 2);
+            if (m == NM - 1) {
+#pragma unroll
+                for (int k = NM - 2; k < NPW; ++k) piece(k);
+            }
             LW_SB();
         }
         const unsigned char* const L = smem + ((c + 1) & (LW_NS - 1)) * STAGE;
+        constexpr int NF = 2 * (NB1 + NB2), DBL = NF > NM ? NF - NM : 0;   // fragment reads of chunk c + 1: NF over NM MFMAs (the first DBL MFMAs take two)
+        static_assert(NF <= 2 * NM, "fragment reads fit behind the MFMAs");
 #pragma unroll
-        for (int m = 0; m < 9; ++m) {
+        for (int m = 0; m < NM; ++m) {
             LW_MMA(cur, 1, m);
-            if (m < 3) { load_frag(nxt, L, 2 * m); load_frag(nxt, L, 2 * m + 1); } else load_frag(nxt, L, m + 3);
+            if (m < DBL) { load_frag(nxt, L, 2 * m); load_frag(nxt, L, 2 * m + 1); } else if (m + DBL < NF) load_frag(nxt, L, m + DBL);
             LW_SB();
         }
     };
-    static_assert(NPW == 7 || NPW == 8, "piece / MFMA interleave");
+    static_assert(NPW <= NM - 1, "piece / MFMA interleave");
     if (nc > 0) {
         Frags F0, F1;
         for (int c = 0; c < LW_NS; ++c) {
@@ -155,7 +165,7 @@ __global__ __launch_bounds__(256, 1) void linear_wgrad_kernel(const LwParams p) 
         wait_chunk(3);
         wg_barrier();
 #pragma unroll
-        for (int f = 0; f < 12; ++f) load_frag(F0, smem, f);
+        for (int f = 0; f < 2 * (NB1 + NB2); ++f) load_frag(F0, smem, f);
         for (int c = 0; c < nc; c += 2) {                      // (the last chunk's prefetch reads a stage that was fetched empty: unused)
             chunk(c, F0, F1);
             if (c + 1 < nc) chunk(c + 1, F1, F0);
@@ -168,21 +178,21 @@ __global__ __launch_bounds__(256, 1) void linear_wgrad_kernel(const LwParams p) 
 
     // partial tile -> part[slab] through LDS, so that the stores are full lines (16 bytes per lane; row-per-lane dword stores are
     // store-issue bound): acc[i][j][r] = D[32 i + 8 (r / 4) + 4 (lane / 32) + r % 4][32 j + lane % 32]
-    float* const out = p.part + (size_t)slab * p.N1 * p.N2 + (size_t)(t1 * T1 + w1 * LW_WT) * p.N2 + t2 * T2 + w2 * LW_WT;
-    constexpr int EP = LW_WT * 4 + 16;                          // staging pitch (bytes): 32 rows x 96 floats per pass
+    float* const out = p.part + (size_t)slab * p.N1 * p.N2 + (size_t)(t1 * T1 + w1 * WT1) * p.N2 + t2 * T2 + w2 * WT2;
+    constexpr int EP = WT2 * 4 + 16;                            // staging pitch (bytes): 32 rows x WT2 floats per pass
     unsigned char* const E = smem + wave * (32 * EP);
     static_assert(4 * 32 * EP <= LW_NS * STAGE, "epilogue staging fits the ring");
     const int er = 4 * (lane >> 5), ec = lane & 31;
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
+    for (int i = 0; i < NB1; ++i) {
 #pragma unroll
-        for (int j = 0; j < 3; ++j)
+        for (int j = 0; j < NB2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) *(float*)(E + (er + 8 * (r >> 2) + (r & 3)) * EP + (32 * j + ec) * 4) = acc[i][j][r];
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier();
 #pragma unroll
-        for (int k = 0; k < 12; ++k) {                          // 32 rows x 24 float4
-            const int idx = k * 64 + lane, row = idx / 24, c4 = idx - row * 24;
+        for (int k = 0; k < WT2 / 8; ++k) {                     // 32 rows x WT2 / 4 float4
+            const int idx = k * 64 + lane, row = idx / (WT2 / 4), c4 = idx - row * (WT2 / 4);
             *(float4*)(out + (size_t)(32 * i + row) * p.N2 + c4 * 4) = *(const float4*)(E + row * EP + c4 * 16);
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier();
@@ -220,15 +230,24 @@ __global__ __launch_bounds__(256) void linear_wgrad_reduce_few_kernel(const floa
 }
 
 // ---- host side ---------------------------------------------------------------------------------------------------------------
-struct LwPlan { int w1, w2, tiles1, tiles2, S, cps, xcd_map; size_t lds; };
+struct LwPlan { int w1, w2, nb1, nb2, tiles1, tiles2, S, cps, xcd_map; size_t lds; };
+
+static bool lw_wide_tiles() {                 // SLAK_LINEAR_WGRAD_128=0: the 128 x 64 wave tiles off (A/B: SLaK-B's weight gradients back on the library's split-K GEMM)
+    static const bool v = [] { const char* e = getenv("SLAK_LINEAR_WGRAD_128"); return !(e && e[0] == '0'); }();
+    return v;
+}
 
 static bool lw_plan(int M, int N1, int N2, LwPlan& pl) {
     if (M < LW_KC || N1 <= 0 || N2 <= 0) return false;
+    pl.nb1 = pl.nb2 = 3;
     if (N1 % 192 == 0 && N2 % 192 == 0) { pl.w1 = 2; pl.w2 = 2; }
     else if (N2 == 96 && N1 % 384 == 0) { pl.w1 = 4; pl.w2 = 1; }
     else if (N1 == 96 && N2 % 384 == 0) { pl.w1 = 1; pl.w2 = 4; }
+    // round 6: SLaK-B's widths (128, 256, 512, 1024 and four times that): 128 x 64 wave tiles (eight accumulators), the long side on the wider operand
+    else if (lw_wide_tiles() && N1 >= N2 && N1 % 256 == 0 && N2 % 128 == 0) { pl.w1 = 2; pl.w2 = 2; pl.nb1 = 4; pl.nb2 = 2; }
+    else if (lw_wide_tiles() && N1 < N2 && N1 % 128 == 0 && N2 % 256 == 0) { pl.w1 = 2; pl.w2 = 2; pl.nb1 = 2; pl.nb2 = 4; }
     else return false;
-    pl.tiles1 = N1 / (LW_WT * pl.w1); pl.tiles2 = N2 / (LW_WT * pl.w2);
+    pl.tiles1 = N1 / (32 * pl.nb1 * pl.w1); pl.tiles2 = N2 / (32 * pl.nb2 * pl.w2);
     const int ntiles = pl.tiles1 * pl.tiles2, nchunks = (M + LW_KC - 1) / LW_KC;
     const int cus = mfma_cu_count();
     int S = cus / ntiles; if (S < 1) S = 1;
@@ -237,8 +256,9 @@ static bool lw_plan(int M, int N1, int N2, LwPlan& pl) {
     pl.cps = (nchunks + S - 1) / S;
     pl.S = (nchunks + pl.cps - 1) / pl.cps;                    // no empty slabs
     pl.xcd_map = (pl.S % 8 == 0) ? 1 : 0;
-    const int T1 = LW_WT * pl.w1, T2 = LW_WT * pl.w2;
+    const int T1 = 32 * pl.nb1 * pl.w1, T2 = 32 * pl.nb2 * pl.w2;
     pl.lds = (size_t)LW_NS * LW_KC * (lw_pitch(T1) + lw_pitch(T2));
+    if (pl.lds > 160 * 1024) return false;
     return (long long)M * (N1 > N2 ? N1 : N2) * 2 < (1LL << 32);
 }
 
@@ -256,15 +276,17 @@ int launch_linear_wgrad(const void* x1, const void* x2, float* d, int M, int N1,
     p.x1 = (const uint16_t*)x1; p.x2 = (const uint16_t*)x2; p.part = pl.S > 1 ? (float*)ws : d;
     p.M = M; p.N1 = N1; p.N2 = N2; p.tiles1 = pl.tiles1; p.tiles2 = pl.tiles2; p.S = pl.S; p.cps = pl.cps; p.xcd_map = pl.xcd_map;
     const dim3 grid((unsigned)(pl.tiles1 * pl.tiles2 * pl.S));
-#define SLAK_LW_LAUNCH(A, B)                                                                                                           \
+#define SLAK_LW_LAUNCH(A, B, NBA, NBB)                                                                                                 \
     do {                                                                                                                               \
-        auto k = linear_wgrad_kernel<A, B>;                                                                                            \
+        auto k = linear_wgrad_kernel<A, B, NBA, NBB>;                                                                                  \
         if (!slak_set_max_lds((const void*)k, pl.lds)) return SLAK_ERR_LAUNCH; \
         hipLaunchKernelGGL(k, grid, dim3(256), pl.lds, st, p);                                                                         \
     } while (0)
-    if (pl.w1 == 2) SLAK_LW_LAUNCH(2, 2);
-    else if (pl.w1 == 4) SLAK_LW_LAUNCH(4, 1);
-    else SLAK_LW_LAUNCH(1, 4);
+    if (pl.nb1 == 4) SLAK_LW_LAUNCH(2, 2, 4, 2);
+    else if (pl.nb1 == 2) SLAK_LW_LAUNCH(2, 2, 2, 4);
+    else if (pl.w1 == 2) SLAK_LW_LAUNCH(2, 2, 3, 3);
+    else if (pl.w1 == 4) SLAK_LW_LAUNCH(4, 1, 3, 3);
+    else SLAK_LW_LAUNCH(1, 4, 3, 3);
 #undef SLAK_LW_LAUNCH
     SLAK_LAUNCH_CHECK();
     if (pl.S > 1) {

@@ -71,7 +71,9 @@ def test_mlp_with_skinny_linears_matches_library_path(gpu):
 
 
 WGRAD_SHAPES = [(6272, 384, 96), (6272, 96, 384), (3136, 768, 192), (3136, 192, 768), (1568, 1536, 384), (1568, 384, 1536), (784, 3072, 768),
-                (1000, 384, 96), (777, 192, 192), (32, 192, 384), (128 * 196, 1536, 384)]
+                (1000, 384, 96), (777, 192, 192), (32, 192, 384), (128 * 196, 1536, 384),
+                # round 6: SLaK-B's widths (128 * 2^k) on the 128 x 64 wave tiles
+                (6272, 512, 128), (6272, 128, 512), (3136, 1024, 256), (1568, 512, 2048), (784, 4096, 1024), (1000, 256, 1024), (64 * 196, 2048, 512), (40, 128, 256)]
 
 
 @pytest.mark.parametrize("M,N1,N2", WGRAD_SHAPES)
@@ -94,8 +96,8 @@ def test_linear_wgrad_matches_fp32(M, N1, N2, gpu):
 def test_linear_wgrad_unsupported_shapes_fall_back(gpu):
     from slak_amd import block_ops, _lib
     L = _lib.lib()
-    assert not L.slak_linear_wgrad_supported(4096, 128, 512) and not L.slak_linear_wgrad_supported(16, 384, 96)
-    assert block_ops.linear_wgrad(torch.zeros(4096, 128, device=gpu).bfloat16(), torch.zeros(4096, 512, device=gpu).bfloat16()) is None
+    assert not L.slak_linear_wgrad_supported(4096, 160, 512) and not L.slak_linear_wgrad_supported(16, 384, 96)
+    assert block_ops.linear_wgrad(torch.zeros(4096, 160, device=gpu).bfloat16(), torch.zeros(4096, 512, device=gpu).bfloat16()) is None
 
 
 
