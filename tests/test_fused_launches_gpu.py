@@ -334,7 +334,9 @@ def test_tri_backward_in_one_launch_says_where_it_does_not_exist(gpu):
 # (channel, image) order; (129, 3), (67, 5) and (9, 37) make ranges that cross channel boundaries with 256 workgroups (the accumulators are summed
 # up and cleared in mid-stream, the first channel's sums leave with the last record), (300, 1) gives workgroups of several planes of one channel
 TRI_ROWS = [(5, 3, 56, 56, 51), (1, 1, 56, 56, 51), (7, 2, 56, 56, 51), (2, 2, 64, 64, 61), (3, 2, 48, 48, 59), (2, 3, 40, 48, 31), (2, 2, 56, 40, 13),
-            (7, 2, 64, 56, 51), (129, 3, 56, 56, 51), (67, 5, 56, 56, 51), (9, 37, 48, 48, 59), (300, 1, 56, 56, 51)]
+            (7, 2, 64, 56, 51), (129, 3, 56, 56, 51), (67, 5, 56, 56, 51), (9, 37, 48, 48, 59), (300, 1, 56, 56, 51),
+            # round 6, the 5 x 5 branch on the diagonal tiles (KS = 4, H <= 62): the second X tile starts at row H - 32 -- overlaps of 24, 30 and 2 rows, 64 columns
+            (3, 2, 40, 56, 27), (2, 2, 34, 64, 31), (2, 2, 62, 56, 51), (5, 2, 50, 56, 9)]
 
 
 @pytest.mark.parametrize("N,C,H,W,K", TRI_ROWS)
