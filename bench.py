@@ -680,9 +680,10 @@ def main():
         for k in kl:
             k["step_ms"] = k["ms"] * k["calls_per_step"]
         # the dominant launch: the stage-1 launches and the fused stage-3 backward cost within a few per cent of each other per step, so the
-        # plain maximum flips from run to run -- among those within 5 % of the largest, the one FURTHEST from the roofline is reported
+        # plain maximum flips from run to run -- among those within 10 % of the largest (round 6: 5 % let the stage-1 launches drop out of the
+        # set by a hair on some boxes and the line then quoted the stage-3 launch's 0.81), the one FURTHEST from the roofline is reported
         top = max(k["step_ms"] for k in kl)
-        near = [k for k in kl if k["step_ms"] >= 0.95 * top]
+        near = [k for k in kl if k["step_ms"] >= 0.90 * top]
         dom = min(near, key=lambda k: k["gbs"])
         hot_ms = sum(k["step_ms"] for k in kl)
         hot_bytes = sum(k["alg_bytes"] * k["calls_per_step"] for k in kl)               # 2*S*b per op and pass (9.88 GB for SLaK-T)
@@ -693,7 +694,7 @@ def main():
                            "traffic": measured_traffic(dom), "kernel": "dwconv %s %s stage %d (N=%d)" % (dom["kernel"], dom["op"], dom["stage"], a.batch),
                            "avg_launch_ms": dom["ms"], "alg_bytes_per_launch": dom["alg_bytes"],
                            "valu_tflops_nominal": dom["gflop_nominal"] / dom["ms"],
-                           # every launch within 5 % of the largest time per step (round 4's line named the stage-3 one-launch backward, 0.86)
+                           # every launch within 10 % of the largest time per step (round 4's line named the stage-3 one-launch backward, 0.86)
                            "dominant_candidates": [{"kernel": "dwconv %s %s stage %d" % (k["kernel"], k["op"], k["stage"]), "step_ms": round(k["step_ms"], 4),
                                                     "frac": round(k["gbs"] / HBM_PEAK_GBS, 4)} for k in sorted(near, key=lambda k: -k["step_ms"])]}
         if out["roofline"]["traffic"]:                             # the dominant launch on the bytes it MOVES (PMC), beside `frac` on the per-op bytes of the ops it replaces
